@@ -1,0 +1,260 @@
+"""Pins the oracle's BEHZ toolbox and BFV scheme ops.
+
+Mirrors Tests/HomomorphicEncryptionTests/RnsToolTests.swift, RnsBaseConverterTests.swift and the semantic
+(decrypt) checks of Sources/_TestUtilities/HeApiTestUtils.swift:494-720,1223-1285.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from bfv_helpers import BfvClient, crt_compose, crt_decompose, negacyclic_multiply
+
+MTILDE = 1 << 32
+
+
+def _prod(xs):
+    out = 1
+    for x in xs:
+        out *= x
+    return out
+
+
+def _poly_from_bigints(xs, moduli):
+    return np.array([[x % m for x in xs] for m in moduli], dtype=np.uint64)
+
+
+def _column(data, k):
+    return [int(v) for v in data[:, k]]
+
+
+def test_bsk_generation(oracle):
+    # Bsk for N=8192, L=4
+    ctx = oracle.PolyContext(8192, oracle.generate_primes([55] * 4, False, 8192))
+    tool = oracle.RnsTool(ctx, 557057)
+    assert tool.bsk == [1152921504606994433, 1152921504607191041, 1152921504607223809, 1152921504607338497,
+                        1152921504607518721]
+    assert tool.bsk == oracle.generate_primes([61] * 5, True, 8192)
+
+
+def test_small_montgomery_reduce_known_answers(oracle, kats):
+    # RnsToolTests.swift:118-166
+    for c in kats["small_montgomery_reduce"]["cases"]:
+        moduli = oracle.generate_primes(c["q_bits"], True)
+        ctx = oracle.PolyContext(c["degree"], moduli)
+        tool = oracle.RnsTool(ctx, 2)
+        data = np.array(c["input_in_units_of_mtilde"], dtype=np.uint64) * np.uint64(MTILDE)
+        got = tool.small_montgomery_reduce(data)
+        assert np.array_equal(got, np.array(c["expected"], dtype=np.uint64)), c
+
+
+@pytest.mark.parametrize("degree,bits", [(4, [20, 20]), (8, [30, 30, 30]), (16, [40, 40, 40, 40])])
+def test_lift_q_to_qbsk_is_exact_centered_lift(oracle, degree, bits):
+    # RnsToolTests.swift:168-208
+    moduli = oracle.generate_primes(bits, True)
+    ctx = oracle.PolyContext(degree, moduli)
+    tool = oracle.RnsTool(ctx, 2)
+    q = _prod(moduli)
+    rng = random.Random(10)
+    xs = [rng.randrange(q) for _ in range(degree)]
+    out = tool.lift_q_to_qbsk(_poly_from_bigints(xs, moduli))
+    qbsk_moduli = moduli + tool.bsk
+    big = _prod(qbsk_moduli)
+    for k, x in enumerate(xs):
+        expected = big - (q - x) if x > q // 2 else x
+        assert _column(out, k) == crt_decompose(expected, qbsk_moduli)
+
+
+@pytest.mark.parametrize("degree,bits", [(32, [20, 20]), (16, [30, 30, 30]), (8, [40, 40, 40, 40])])
+def test_convert_approximate_bsk_mtilde(oracle, degree, bits):
+    # RnsToolTests.swift:66-116
+    moduli = oracle.generate_primes(bits + [bits[-1]], True)
+    t = min(moduli)
+    moduli = [m for m in moduli if m != t]
+    ctx = oracle.PolyContext(degree, moduli)
+    tool = oracle.RnsTool(ctx, t)
+    q = _prod(moduli)
+    rng = random.Random(11)
+    xs = [rng.randrange(q) for _ in range(degree)]
+    out = tool.convert_approximate_bsk_mtilde(_poly_from_bigints(xs, moduli))
+    out_moduli = tool.bsk + [MTILDE]
+    base = _prod(out_moduli)
+    for k, x in enumerate(xs):
+        candidates = [crt_decompose(((x * (MTILDE % q)) % q + a * q) % base, out_moduli) for a in range(len(moduli))]
+        assert _column(out, k) in candidates
+
+
+@pytest.mark.parametrize("degree,bits", [(4, [20, 20]), (8, [30, 30, 30]), (16, [40, 40, 40, 40])])
+def test_approximate_floor(oracle, degree, bits):
+    # RnsToolTests.swift:210-260
+    moduli = oracle.generate_primes(bits, True)
+    ctx = oracle.PolyContext(degree, moduli)
+    tool = oracle.RnsTool(ctx, 2)
+    q, bsk = _prod(moduli), _prod(tool.bsk)
+    qbsk_moduli = moduli + tool.bsk
+    qbsk = q * bsk
+    rng = random.Random(12)
+    xs = [qbsk - 1, 1] + [rng.randrange(qbsk) for _ in range(degree - 2)]
+    out = tool.approximate_floor(_poly_from_bigints(xs, qbsk_moduli))
+    for k, x in enumerate(xs):
+        candidates = []
+        for a in range(len(moduli)):
+            candidates.append(crt_decompose((x // q + a) % bsk, tool.bsk))
+            candidates.append(crt_decompose((x // q + bsk - a) % bsk, tool.bsk))
+        assert _column(out, k) in candidates
+
+
+@pytest.mark.parametrize("degree,bits", [(4, [20, 20]), (8, [30, 30, 30])])
+def test_convert_approximate_bsk_to_q_is_exact(oracle, degree, bits):
+    # RnsToolTests.swift:262-305
+    moduli = oracle.generate_primes(bits, True)
+    ctx = oracle.PolyContext(degree, moduli)
+    tool = oracle.RnsTool(ctx, 2)
+    q, bsk_prod = _prod(moduli), _prod(tool.bsk)
+    rng = random.Random(13)
+    xs = [rng.randrange(q) for _ in range(degree)]
+    out = tool.convert_approximate_bsk_to_q(_poly_from_bigints(xs, tool.bsk))
+    for k, x in enumerate(xs):
+        expected = q - ((bsk_prod - x) % q) if x > bsk_prod // 2 else x % q
+        assert _column(out, k) == crt_decompose(expected, moduli)
+
+
+def test_convert_approximate_set_valued(oracle):
+    # RnsBaseConverterTests.swift:20-65
+    degree = 8
+    in_moduli = oracle.generate_primes([40, 40, 40], True)
+    out_moduli = oracle.generate_primes([45, 45], True)
+    in_ctx, out_ctx = oracle.PolyContext(degree, in_moduli), oracle.PolyContext(degree, out_moduli)
+    q = _prod(in_moduli)
+    rng = random.Random(14)
+    xs = [rng.randrange(q) for _ in range(degree)]
+    out = oracle.convert_approximate(in_ctx, out_ctx, _poly_from_bigints(xs, in_moduli))
+    for k, x in enumerate(xs):
+        candidates = [crt_decompose(x + a * q, out_moduli) for a in range(len(in_moduli))]
+        assert _column(out, k) in candidates
+
+
+def test_scale_and_round(oracle):
+    # RnsToolTests.swift:20-64
+    degree = 8
+    moduli = oracle.generate_primes([20, 20, 20], True)
+    t = oracle.generate_primes([15], True)[0]
+    ctx = oracle.PolyContext(degree, moduli)
+    tool = oracle.RnsTool(ctx, t)
+    q, k_count = _prod(moduli), len(moduli)
+    gamma = (1 << 62) - 40797
+    delta = q // t
+    v_bound = int(q / t * (0.5 - k_count / gamma) - (q % t) / 2.0)
+    rng = random.Random(15)
+    for _ in range(10):
+        ms = [rng.randrange(t) for _ in range(degree)]
+        cts = [(delta * m + rng.randrange(v_bound)) % q for m in ms]
+        out = tool.scale_and_round(_poly_from_bigints(cts, moduli), 1)
+        assert [int(v) for v in out] == ms
+
+
+# ------------------------------------------------------------------ BFV semantic checks
+@pytest.fixture(scope="module")
+def small_bfv(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40, 40, 41], False, degree)  # 3 ciphertext moduli + key-switching modulus
+    ctx = oracle.BfvContext(degree, t, q)
+    return ctx, BfvClient(oracle, ctx, seed=20)
+
+
+def test_encrypt_decrypt_roundtrip(oracle, small_bfv):
+    ctx, client = small_bfv
+    rng = random.Random(21)
+    message = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    ct = client.encrypt(message)
+    assert client.decrypt(ct) == message
+    assert client.decrypt_exact(ct) == message
+
+
+def test_bfv_mul_and_relinearize_decrypt_to_product(oracle, small_bfv):
+    # HeApiTestUtils.swift:494-556 (coefficient encoding: product is the negacyclic convolution mod t)
+    ctx, client = small_bfv
+    rng = random.Random(22)
+    m1 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    m2 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    ct1, ct2 = client.encrypt(m1), client.encrypt(m2)
+    product = ctx.mul(ct1[None], ct2[None])
+    assert product.shape == (1, 3, ctx.L, ctx.degree)
+    expected = negacyclic_multiply(m1, m2, ctx.t)
+    assert client.decrypt(product[0]) == expected
+    key = client.relinearization_key()
+    relin = ctx.relinearize(product, key)
+    assert relin.shape == (1, 2, ctx.L, ctx.degree)
+    assert client.decrypt(relin[0]) == expected
+    assert client.decrypt_exact(relin[0]) == expected
+
+
+def test_bfv_mod_switch_down_keeps_message(oracle, small_bfv):
+    ctx, client = small_bfv
+    rng = random.Random(23)
+    message = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    ct = client.encrypt(message)
+    lower = ctx.mod_switch_down(ct[None], poly_count=2)[0]
+    assert lower.shape == (2, ctx.L - 1, ctx.degree)
+    assert client.decrypt(lower, moduli_count=ctx.L - 1) == message
+
+
+def test_bfv_inner_product_plain(oracle, small_bfv):
+    # HeApiTestUtils.swift:560-720: sum_k ct_k * pt_k decrypts to sum of negacyclic products; nil plaintexts skipped
+    ctx, client = small_bfv
+    poly_ctx = ctx.ciphertext_context()
+    rng = random.Random(24)
+    count = 5
+    present = [1, 1, 0, 1, 1]
+    messages = [[rng.randrange(ctx.t) for _ in range(ctx.degree)] for _ in range(count)]
+    plains = [[rng.randrange(ctx.t) for _ in range(ctx.degree)] for _ in range(count)]
+    cts = np.stack([poly_ctx.forward_ntt(client.encrypt(m)) for m in messages])
+    # Plaintext.convertToEvalFormat (Plaintext.swift:149-170): centered lift of t-residues to Q, then forward NTT
+    def lift(p):
+        thresh = (ctx.t + 1) // 2
+        return poly_ctx.forward_ntt(np.array([[(v if v < thresh else q - (ctx.t - v)) for v in p]
+                                              for q in poly_ctx.moduli], dtype=np.uint64))
+    pts = np.stack([lift(p) for p in plains])
+    out = ctx.inner_product_plain(cts, pts, present)
+    expected = [0] * ctx.degree
+    for keep, m, p in zip(present, messages, plains):
+        if keep:
+            prod = negacyclic_multiply(m, p, ctx.t)
+            expected = [(a + b) % ctx.t for a, b in zip(expected, prod)]
+    assert client.decrypt(poly_ctx.inverse_ntt(out)) == expected
+    # single ct*pt (Bfv.mulAssign(ct, pt))
+    single = ctx.mul_plain(cts[0][None], pts[0][None], poly_count=2)[0]
+    assert client.decrypt(poly_ctx.inverse_ntt(single)) == negacyclic_multiply(messages[0], plains[0], ctx.t)
+
+
+def test_bfv_inner_product_ct_ct(oracle, small_bfv):
+    ctx, client = small_bfv
+    rng = random.Random(25)
+    count = 3
+    m1 = [[rng.randrange(ctx.t) for _ in range(ctx.degree)] for _ in range(count)]
+    m2 = [[rng.randrange(ctx.t) for _ in range(ctx.degree)] for _ in range(count)]
+    lhs = np.stack([client.encrypt(m) for m in m1])
+    rhs = np.stack([client.encrypt(m) for m in m2])
+    out = ctx.inner_product(lhs, rhs)
+    expected = [0] * ctx.degree
+    for a, b in zip(m1, m2):
+        expected = [(x + y) % ctx.t for x, y in zip(expected, negacyclic_multiply(a, b, ctx.t))]
+    assert client.decrypt(out) == expected
+    # one pair == mul
+    assert np.array_equal(ctx.inner_product(lhs[:1], rhs[:1]), ctx.mul(lhs[:1], rhs[:1])[0])
+
+
+def test_bfv_context_errors(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40], False, degree)
+    with pytest.raises(oracle.OracleError) as err:
+        oracle.BfvContext(degree, t, q + [q[0] + 2])  # not prime / not NTT friendly
+    assert err.value.name == "invalidEncryptionParameters"
+    with pytest.raises(oracle.OracleError) as err:
+        oracle.BfvContext(degree + 1, t, q)
+    assert err.value.name == "invalidEncryptionParameters"
+    with pytest.raises(oracle.OracleError) as err:
+        oracle.BfvContext(degree, q[0], q)  # t must be < every q_i
+    assert err.value.name == "invalidEncryptionParameters"
