@@ -1,0 +1,223 @@
+/*
+ * he_amd.h -- C ABI of the MI355X-native BFV ciphertext-arithmetic engine (libhe_amd.so).
+ *
+ * This is the drop-in boundary for the PolyRq/NTT hot path of apple/swift-homomorphic-encryption.  It is meant to
+ * be wrapped as a SwiftPM C target next to `CUtil` (reference Package.swift:100-105) and called from
+ * `Bfv<UInt64>` / `PolyContext<UInt64>`; INTEGRATION.md shows the Swift binding.  Only plain pointers and sizes
+ * cross the boundary.  All citations below are file:line relative to /root/reference/Sources/.
+ *
+ * Conventions:
+ *  - Data layout: a polynomial is the reference's Array2d row-major (moduli x N) slab of UInt64
+ *    (HomomorphicEncryption/Array2d.swift:117-119); batches are [batch][L][N]; ciphertexts [batch][polys][L][N].
+ *  - Every word handed across the boundary is canonical (< its row's modulus), as PolyRq asserts
+ *    (PolyRq/PolyRq.swift:36,85-95); every word handed back is canonical and bit-identical to the reference.
+ *  - Errors: functions return an int status, 0 = HE_OK, otherwise one code per reachable HeError case
+ *    (HomomorphicEncryption/Error.swift:19-54); the Swift wrapper throws.  Nothing aborts.
+ *  - Threading: contexts are immutable after creation and every entry point is re-entrant on a shared context
+ *    (the reference calls the path concurrently from many tasks: Bfv/Bfv.swift:270-287).  `*_device` functions
+ *    enqueue on the caller's HIP stream and return without synchronising; host-pointer functions block.
+ *  - Ownership: host pointers are borrowed for the duration of the call only (the reference's seam is
+ *    `withUnsafeMutableBufferPointer`, PolyRq/PolyRq+Ntt.swift:215-218).  Device buffers are owned by the caller
+ *    (he_device_malloc / any HIP allocation, e.g. a torch tensor's data_ptr()).
+ *  - A context lives on the HIP device that was current when it was created; calls must be made with that device
+ *    current (one process per GPU).
+ */
+#ifndef HE_AMD_H
+#define HE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: HeError cases reachable on the path (HomomorphicEncryption/Error.swift:19-54) ---- */
+enum he_status {
+    HE_OK = 0,
+    HE_ERR_INVALID_DEGREE = 1,                          /* invalidDegree            PolyRq/PolyContext.swift:46 */
+    HE_ERR_INVALID_MODULUS = 2,                         /* invalidModulus           PolyRq/PolyContext.swift:55,58 */
+    HE_ERR_COPRIME_MODULI = 3,                          /* coprimeModuli            PolyRq/PolyContext.swift:65,68 */
+    HE_ERR_EMPTY_MODULUS = 4,                           /* emptyModulus             PolyRq/PolyContext.swift:71 */
+    HE_ERR_INVALID_NTT_MODULUS = 5,                     /* invalidNttModulus        PolyRq/PolyContext.swift:175-181 */
+    HE_ERR_INVALID_POLY_CONTEXT = 6,                    /* invalidPolyContext       PolyRq/PolyRq.swift:366-368 */
+    HE_ERR_POLY_CONTEXT_MISMATCH = 7,                   /* polyContextMismatch      PolyRq/PolyRq.swift:332-336 */
+    HE_ERR_INVALID_CIPHERTEXT = 8,                      /* invalidCiphertext        Bfv/Bfv+Multiply.swift:32-34,67-72 */
+    HE_ERR_INCOMPATIBLE_CIPHERTEXTS = 9,                /* incompatibleCiphertexts  Bfv/Bfv+Multiply.swift:73-75 */
+    HE_ERR_INCOMPATIBLE_CIPHERTEXT_AND_PLAINTEXT = 10,  /*                          Bfv/Bfv.swift:122-124 */
+    HE_ERR_MISSING_RELINEARIZATION_KEY = 11,            /* missingRelinearizationKey Bfv/Bfv.swift:208-210 */
+    HE_ERR_UNEQUAL_CONTEXTS = 12,                       /* unequalContexts          HeScheme.swift:1451-1455 */
+    HE_ERR_NOT_ENOUGH_PRIMES = 13,                      /* notEnoughPrimes          Scalar.swift:147-152 */
+    HE_ERR_NOT_INVERTIBLE = 14,                         /* notInvertible            Scalar.swift:79-85 */
+    HE_ERR_INVALID_ENCRYPTION_PARAMETERS = 15,          /* invalidEncryptionParameters EncryptionParameters.swift:136-166 */
+    HE_ERR_INVALID_ARGUMENT = 16,  /* what the reference traps on with `precondition` (null pointer, shape) */
+    HE_ERR_DEVICE = 17,            /* HIP runtime failure (no GPU, out of memory, launch error) */
+    HE_ERR_UNSUPPORTED = 18        /* unsupportedHeOperation */
+};
+
+typedef struct he_poly_context he_poly_context; /* PolyContext<UInt64>   PolyRq/PolyContext.swift:19-35 */
+typedef struct he_bfv_context he_bfv_context;   /* Context<Bfv<UInt64>>  Context.swift:19 */
+typedef void* he_stream;                        /* hipStream_t; NULL = the default stream */
+
+const char* he_status_string(int status);
+/* Thread-local detail of the last failing call on this thread (HIP error text etc.); never NULL. */
+const char* he_last_error_message(void);
+/* Library version / build target, e.g. "he_amd 0.1 gfx950". */
+const char* he_version(void);
+
+/* ---- device plumbing (so a Swift host never has to link HIP) ---- */
+int he_device_count(int* out_count);
+int he_device_malloc(void** out_ptr, size_t bytes);
+int he_device_free(void* ptr);
+int he_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, he_stream stream);
+int he_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, he_stream stream);
+int he_stream_synchronize(he_stream stream);
+
+/* =====================================================================================================
+ * B1/B2: PolyContext and PolyRq operations
+ * =================================================================================================== */
+
+/* PolyContext.init(degree:moduli:) incl. its validation and error order (PolyRq/PolyContext.swift:45-141).
+ * Builds, on the current device, the per-modulus NTT tables (_NttContext.init, PolyRq/PolyRq+Ntt.swift:118-169),
+ * Barrett constants (Modulus.swift:24-45) and inverseQLast (PolyRq/PolyContext.swift:108-111). */
+int he_poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count, he_poly_context** out);
+void he_poly_context_destroy(he_poly_context* ctx);
+uint32_t he_poly_context_degree(const he_poly_context* ctx);
+uint32_t he_poly_context_moduli_count(const he_poly_context* ctx);
+int he_poly_context_moduli(const he_poly_context* ctx, uint64_t* out_moduli);
+/* PolyContext.maxLazyProductAccumulationCount() (PolyRq/PolyContext.swift:246-253) */
+uint64_t he_poly_context_max_lazy_product_accumulation_count(const he_poly_context* ctx);
+/* PolyContext.qRemainder(dividingBy:) (PolyRq/PolyContext.swift:184-191) */
+int he_poly_context_q_remainder(const he_poly_context* ctx, uint64_t modulus, uint64_t* out);
+/* ScalarType.generatePrimes (Scalar.swift:113-154), for callers that build parameters host-side. */
+int he_generate_primes(const int32_t* significant_bit_counts, uint32_t count, int preferring_small,
+                       uint32_t ntt_degree, uint64_t* out_primes);
+
+/* PolyRq<UInt64,Coeff>.forwardNtt() / PolyRq<UInt64,Eval>.inverseNtt() over a batch of polynomials
+ * (PolyRq/PolyRq+Ntt.swift:209-232,524-543).  In place.  Throws invalidNttModulus like validateNttModuli. */
+int he_ntt_forward(const he_poly_context* ctx, uint64_t* host_slab, size_t batch);
+int he_ntt_inverse(const he_poly_context* ctx, uint64_t* host_slab, size_t batch);
+int he_ntt_forward_device(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, he_stream stream);
+int he_ntt_inverse_device(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, he_stream stream);
+/* PolyContext.forwardNtt(dataPtr:modulus:) -- the reference's existing raw-pointer seam
+ * (PolyRq/PolyRq+Ntt.swift:329-347): `rows` contiguous length-N rows, all transformed mod `modulus`, which must be
+ * one of the context's moduli (else invalidPolyContext). */
+int he_ntt_forward_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* device_rows, size_t rows,
+                               he_stream stream);
+int he_ntt_inverse_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* device_rows, size_t rows,
+                               he_stream stream);
+
+/* PolyRq += / -= / prefix - / *= (Eval) / *= [T]  (PolyRq/PolyRq.swift:147-174,299-309,184-204,232-245).
+ * lhs/data are updated in place; slabs are [batch][L][N]. */
+int he_poly_add_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s);
+int he_poly_sub_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s);
+int he_poly_neg_device(const he_poly_context* ctx, uint64_t* data, size_t batch, he_stream s);
+int he_poly_mul_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s);
+/* scalar_residues: HOST array of L residues (y mod q_i) */
+int he_poly_mul_scalar_device(const he_poly_context* ctx, uint64_t* data, const uint64_t* scalar_residues,
+                              size_t batch, he_stream s);
+/* PolyRq<_,Coeff>.divideAndRoundQLast() (PolyRq/PolyRq.swift:365-393): in [batch][L][N] -> out [batch][L-1][N].
+ * invalidPolyContext when the context has no next (L == 1). */
+int he_poly_divide_and_round_q_last_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out,
+                                           size_t batch, he_stream s);
+int he_poly_divide_and_round_q_last(const he_poly_context* ctx, const uint64_t* host_in, uint64_t* host_out,
+                                    size_t batch);
+/* PolyRq.addingLazyProduct (PolyRq/PolyRq.swift:210-225): acc[k] &+= lhs[k]*rhs[k] in wrapping UInt128.
+ * acc is [L][N] UInt128 stored little-endian as (lo, hi) word pairs.  he_poly_reduce_accumulator_device is
+ * Bfv.reduceToCiphertext's per-polynomial step (Bfv/Bfv.swift:380-394). */
+int he_poly_adding_lazy_product_device(const he_poly_context* ctx, const uint64_t* lhs, const uint64_t* rhs,
+                                       uint64_t* acc_lo_hi, he_stream s);
+int he_poly_reduce_accumulator_device(const he_poly_context* ctx, const uint64_t* acc_lo_hi, uint64_t* out,
+                                      he_stream s);
+
+/* =====================================================================================================
+ * B3: Context<Bfv<UInt64>> and the HeScheme operations on the hot path
+ * =================================================================================================== */
+
+/* Context.init(encryptionParameters:) with EncryptionParameters' own checks at securityLevel .unchecked
+ * (Context.swift:94-143, EncryptionParameters.swift:136-166).  The last coefficient modulus is the key-switching
+ * modulus when more than one is given.  Builds the ciphertext / key-switching PolyContexts and one _RnsTool per
+ * level (RnsTool.swift:132-251) incl. the Bsk primes (RnsTool.swift:28-45). */
+int he_bfv_context_create(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                          uint32_t moduli_count, he_bfv_context** out);
+void he_bfv_context_destroy(he_bfv_context* ctx);
+uint32_t he_bfv_ciphertext_moduli_count(const he_bfv_context* ctx); /* L of a fresh ciphertext */
+/* Borrowed sub-contexts (valid while ctx lives); moduli_count in 1..L. NULL when out of range. */
+const he_poly_context* he_bfv_ciphertext_context(const he_bfv_context* ctx, uint32_t moduli_count);
+const he_poly_context* he_bfv_key_switching_context(const he_bfv_context* ctx, uint32_t moduli_count);
+const he_poly_context* he_bfv_qbsk_context(const he_bfv_context* ctx, uint32_t moduli_count);
+
+/* _RnsTool pieces, exposed so each can be parity-tested on its own (RnsTool.swift):
+ *   liftQToQBsk  :324-331  in [batch][L][N]    -> out [batch][2L+1][N]
+ *   floorQBskToQ :453-456  in [batch][2L+1][N] -> out [batch][L][N]          */
+int he_rns_lift_q_to_qbsk_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in, uint64_t* out,
+                                 size_t batch, he_stream s);
+int he_rns_floor_qbsk_to_q_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in, uint64_t* out,
+                                  size_t batch, he_stream s);
+
+/* Workspace: multi-kernel operations need device scratch.  Pass workspace == NULL to let the library allocate
+ * stream-ordered scratch itself (hipMallocAsync on `s`); otherwise pass at least *_workspace_bytes(). */
+size_t he_bfv_mul_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
+size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
+
+/* Bfv.mulAssign(_: inout CanonicalCiphertext, _: CanonicalCiphertext) = multiplyWithoutScaling + dropExtendedBase
+ * (Bfv/Bfv+Multiply.swift:18-85).  lhs, rhs: [batch][2][L][N] Coeff; out: [batch][3][L][N] Coeff. */
+int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
+                      uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s);
+/* Bfv.relinearize (Bfv/Bfv.swift:201-219) via _computeKeySwitchingUpdate (Bfv/Bfv+Keys.swift:123-208).
+ * ct3: [batch][3][L][N] Coeff; key: the relinearization key's L_top ciphertexts, [L_top][2][L_top+1][N] Eval over
+ * the top key-switching context (Keys.swift:66-99); out: [batch][2][L][N] Coeff.  key == NULL ->
+ * missingRelinearizationKey. */
+int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct3,
+                              const uint64_t* key, uint64_t* out, size_t batch, void* workspace,
+                              size_t workspace_bytes, he_stream s);
+/* Bfv.modSwitchDown (Bfv/Bfv.swift:163-171): [batch][polys][L][N] -> [batch][polys][L-1][N]. */
+int he_bfv_mod_switch_down_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                  const uint64_t* in, uint64_t* out, size_t batch, he_stream s);
+/* Bfv.mulAssign(_: inout EvalCiphertext, _: EvalPlaintext) (Bfv/Bfv.swift:120-129):
+ * ct [batch][polys][L][N] *= pt [batch][L][N]. */
+int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* pt, size_t batch, he_stream s);
+/* Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv/Bfv.swift:476-505), batched over `columns` independent outputs
+ * that share the ciphertext vector (the PIR dim-0 shape, PrivateInformationRetrieval/IndexPir/PirUtil.swift:427-445):
+ *   cts      [count][polys][L][N]           Eval
+ *   pts      [columns][count][L][N]         Eval plaintexts over the ciphertext context
+ *   present  HOST [columns][count] bytes, 0 = nil plaintext (skipped, Bfv.swift:494); NULL = all present
+ *   out      [columns][polys][L][N]         Eval */
+int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                      const uint64_t* cts, const uint64_t* pts, const uint8_t* present, size_t count,
+                                      size_t columns, uint64_t* out, he_stream s);
+/* Bfv.innerProduct(_: [CanonicalCiphertext], _: [CanonicalCiphertext]) (Bfv/Bfv.swift:315-361):
+ * lhs, rhs [count][2][L][N] Coeff -> out [3][L][N] Coeff. */
+int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
+                                const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,
+                                size_t workspace_bytes, he_stream s);
+size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count);
+
+/* =====================================================================================================
+ * Diagnostics and test hooks (not part of the reference's surface)
+ * =================================================================================================== */
+
+/* Builds the host-side precomputation only (no device upload): lets the setup math (roots, twiddle order, Barrett /
+ * Shoup constants) be checked where no GPU exists.  Every compute entry point on such a context returns
+ * HE_ERR_DEVICE. */
+int he_poly_context_create_host_only(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count,
+                                     he_poly_context** out);
+/* Copies the _NttContext tables of modulus row `rns_index` (PolyRq/PolyRq+Ntt.swift:109-115); any out may be NULL. */
+int he_poly_context_copy_ntt_tables(const he_poly_context* ctx, uint32_t rns_index, uint64_t* root_powers,
+                                    uint64_t* root_factors, uint64_t* inverse_root_powers,
+                                    uint64_t* inverse_root_factors, uint64_t* inverse_degree,
+                                    uint64_t* inverse_degree_root);
+/* NTT with a named kernel variant: 0 = auto, 1 = exact-quotient butterflies, 2 = generic radix-2 kernel. */
+int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, int inverse, int variant,
+                          he_stream stream);
+/* Same host-only construction for the BFV context; he_bfv_copy_bsk_moduli returns the L+1 Bsk primes
+ * (RnsTool.swift:28-33). */
+int he_bfv_context_create_host_only(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                                    uint32_t moduli_count, he_bfv_context** out);
+int he_bfv_copy_bsk_moduli(const he_bfv_context* ctx, uint64_t* out_bsk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HE_AMD_H */

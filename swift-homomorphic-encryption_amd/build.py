@@ -1,0 +1,74 @@
+"""Builds libhe_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python swift-homomorphic-encryption_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to csrc/build/, the library to lib/libhe_amd.so (git-ignored, but
+shipped to the GPU box with the repo snapshot).
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libhe_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _headers_mtime():
+    newest = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith((".hpp", ".h")):
+                newest = max(newest, os.path.getmtime(os.path.join(root, f)))
+    return newest
+
+
+def _compile(src, force, header_time):
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), header_time):
+        return obj, False
+    cmd = [_hipcc(), *FLAGS, "-c", path, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd[1:1] = ["-x", "hip"]
+    result = subprocess.run(cmd, capture_output=True, text=True)
+    if result.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{result.stdout}\n{result.stderr}")
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    header_time = _headers_mtime()
+    sources = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(sources))) as pool:
+        results = list(pool.map(lambda s: _compile(s, force, header_time), sources))
+    objects = [obj for obj, _ in results]
+    rebuilt = any(changed for _, changed in results)
+    if rebuilt or not os.path.exists(LIB_PATH):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objects]
+        result = subprocess.run(cmd, capture_output=True, text=True)
+        if result.returncode != 0:
+            raise RuntimeError(f"link failed:\n{result.stdout}\n{result.stderr}")
+    if verbose:
+        print(f"{'rebuilt' if rebuilt else 'up to date'}: {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

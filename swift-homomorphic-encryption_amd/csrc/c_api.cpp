@@ -1,0 +1,388 @@
+// c_api.cpp -- the extern "C" boundary declared in include/he_amd.h.
+#include "../../include/he_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "poly_context.hpp"
+
+using heamd::PolyContext;
+
+struct he_poly_context {
+    std::unique_ptr<PolyContext> impl;
+};
+
+namespace {
+
+inline hipStream_t as_stream(he_stream s) { return static_cast<hipStream_t>(s); }
+
+int invalid_argument(const char* what) {
+    heamd::set_last_error(std::string("invalid argument: ") + what);
+    return HE_ERR_INVALID_ARGUMENT;
+}
+
+// Stream-ordered scratch buffer that frees itself on the same stream.
+class Scratch {
+  public:
+    Scratch(hipStream_t stream) : stream_(stream) {}
+    ~Scratch() {
+        if (ptr_ != nullptr) (void)hipFreeAsync(ptr_, stream_);
+    }
+    hipError_t allocate(size_t bytes) { return hipMallocAsync(&ptr_, bytes ? bytes : 1, stream_); }
+    void* get() const { return ptr_; }
+
+  private:
+    hipStream_t stream_;
+    void* ptr_ = nullptr;
+};
+
+// Runs `body(device_ptr, stream)` on a device copy of a host slab and copies the result back (blocking).
+template <typename Body>
+int with_device_copy(uint64_t* host, size_t words, Body body) {
+    hipStream_t stream = hipStreamPerThread;
+    void* device = nullptr;
+    HEAMD_HIP_TRY(hipMalloc(&device, words * sizeof(uint64_t) + 16));
+    int status = HE_OK;
+    hipError_t e = hipMemcpyAsync(device, host, words * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        status = body(static_cast<uint64_t*>(device), stream);
+        if (status == HE_OK) e = hipMemcpyAsync(host, device, words * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(device);
+    if (status != HE_OK) return status;
+    if (e != hipSuccess) return heamd::device_failure(e, "host-pointer round trip");
+    return HE_OK;
+}
+
+int ntt_device(const he_poly_context* ctx, uint64_t* slab, size_t batch, bool inverse, hipStream_t stream) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    // validateNttModuli (PolyContext.swift:175-181) comes first in forwardNtt(poly:) / inverseNtt(poly:)
+    if (!pc.all_ntt(pc.moduli_count())) {
+        heamd::set_last_error("a modulus of this context is not an NTT modulus for degree " + std::to_string(pc.degree()));
+        return HE_ERR_INVALID_NTT_MODULUS;
+    }
+    if (batch == 0) return HE_OK;
+    if (slab == nullptr) return invalid_argument("null slab");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_ntt(inverse, slab, pc.device_context(), 0, pc.moduli_count(),
+                                    batch * pc.moduli_count(), stream));
+    return HE_OK;
+}
+
+int ntt_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* rows_ptr, size_t rows, bool inverse,
+                    hipStream_t stream) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    // PolyContext.forwardNtt(dataPtr:modulus:) walks the chain for a context whose last modulus matches and
+    // throws invalidPolyContext otherwise, or when that context has no nttContext (PolyRq+Ntt.swift:329-341).
+    const int index = pc.modulus_index(modulus);
+    if (index < 0 || !pc.host_constants()[index].has_ntt) {
+        heamd::set_last_error("modulus " + std::to_string(modulus) + " has no NTT context in this PolyContext");
+        return HE_ERR_INVALID_POLY_CONTEXT;
+    }
+    if (rows == 0) return HE_OK;
+    if (rows_ptr == nullptr) return invalid_argument("null rows");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    heamd::DeviceContext dc = pc.device_context();
+    dc.approx_ok = modulus < (uint64_t(1) << 61) ? 1 : 0;
+    HEAMD_HIP_TRY(heamd::launch_ntt(inverse, rows_ptr, dc, static_cast<uint32_t>(index), 1, rows, stream));
+    return HE_OK;
+}
+
+int elementwise(const he_poly_context* ctx, heamd::ElementwiseOp op, uint64_t* lhs, const uint64_t* rhs, size_t batch,
+                he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (batch == 0) return HE_OK;
+    if (lhs == nullptr || (rhs == nullptr && op != heamd::ElementwiseOp::Neg)) return invalid_argument("null slab");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_elementwise(op, lhs, rhs, pc.device_context(), batch * pc.moduli_count(), as_stream(s)));
+    return HE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* he_status_string(int status) {
+    switch (status) {
+        case HE_OK: return "ok";
+        case HE_ERR_INVALID_DEGREE: return "invalidDegree";
+        case HE_ERR_INVALID_MODULUS: return "invalidModulus";
+        case HE_ERR_COPRIME_MODULI: return "coprimeModuli";
+        case HE_ERR_EMPTY_MODULUS: return "emptyModulus";
+        case HE_ERR_INVALID_NTT_MODULUS: return "invalidNttModulus";
+        case HE_ERR_INVALID_POLY_CONTEXT: return "invalidPolyContext";
+        case HE_ERR_POLY_CONTEXT_MISMATCH: return "polyContextMismatch";
+        case HE_ERR_INVALID_CIPHERTEXT: return "invalidCiphertext";
+        case HE_ERR_INCOMPATIBLE_CIPHERTEXTS: return "incompatibleCiphertexts";
+        case HE_ERR_INCOMPATIBLE_CIPHERTEXT_AND_PLAINTEXT: return "incompatibleCiphertextAndPlaintext";
+        case HE_ERR_MISSING_RELINEARIZATION_KEY: return "missingRelinearizationKey";
+        case HE_ERR_UNEQUAL_CONTEXTS: return "unequalContexts";
+        case HE_ERR_NOT_ENOUGH_PRIMES: return "notEnoughPrimes";
+        case HE_ERR_NOT_INVERTIBLE: return "notInvertible";
+        case HE_ERR_INVALID_ENCRYPTION_PARAMETERS: return "invalidEncryptionParameters";
+        case HE_ERR_INVALID_ARGUMENT: return "invalidArgument";
+        case HE_ERR_DEVICE: return "deviceError";
+        case HE_ERR_UNSUPPORTED: return "unsupportedHeOperation";
+        default: return "unknown";
+    }
+}
+
+const char* he_last_error_message(void) { return heamd::last_error(); }
+const char* he_version(void) { return "he_amd 0.1 (gfx950, HIP)"; }
+
+int he_device_count(int* out_count) {
+    if (out_count == nullptr) return invalid_argument("null out_count");
+    *out_count = 0;
+    HEAMD_HIP_TRY(hipGetDeviceCount(out_count));
+    return HE_OK;
+}
+int he_device_malloc(void** out_ptr, size_t bytes) {
+    if (out_ptr == nullptr) return invalid_argument("null out_ptr");
+    *out_ptr = nullptr;
+    HEAMD_HIP_TRY(hipMalloc(out_ptr, bytes ? bytes : 1));
+    return HE_OK;
+}
+int he_device_free(void* ptr) {
+    if (ptr == nullptr) return HE_OK;
+    HEAMD_HIP_TRY(hipFree(ptr));
+    return HE_OK;
+}
+int he_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, he_stream stream) {
+    HEAMD_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return HE_OK;
+}
+int he_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, he_stream stream) {
+    HEAMD_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return HE_OK;
+}
+int he_stream_synchronize(he_stream stream) {
+    HEAMD_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PolyContext
+static int poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count, bool host_only,
+                               he_poly_context** out) {
+    if (out == nullptr) return invalid_argument("null out");
+    *out = nullptr;
+    std::unique_ptr<PolyContext> impl;
+    const int status = PolyContext::create(degree, moduli, moduli_count, impl, host_only);
+    if (status != HE_OK) {
+        if (status != HE_ERR_DEVICE) heamd::set_last_error(std::string("PolyContext.init: ") + he_status_string(status));
+        return status;
+    }
+    *out = new he_poly_context{std::move(impl)};
+    return HE_OK;
+}
+int he_poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count, he_poly_context** out) {
+    return poly_context_create(degree, moduli, moduli_count, false, out);
+}
+int he_poly_context_create_host_only(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count,
+                                     he_poly_context** out) {
+    return poly_context_create(degree, moduli, moduli_count, true, out);
+}
+void he_poly_context_destroy(he_poly_context* ctx) { delete ctx; }
+uint32_t he_poly_context_degree(const he_poly_context* ctx) { return ctx ? ctx->impl->degree() : 0; }
+uint32_t he_poly_context_moduli_count(const he_poly_context* ctx) { return ctx ? ctx->impl->moduli_count() : 0; }
+int he_poly_context_moduli(const he_poly_context* ctx, uint64_t* out_moduli) {
+    if (ctx == nullptr || out_moduli == nullptr) return invalid_argument("null pointer");
+    const auto& moduli = ctx->impl->moduli();
+    for (size_t i = 0; i < moduli.size(); ++i) out_moduli[i] = moduli[i];
+    return HE_OK;
+}
+uint64_t he_poly_context_max_lazy_product_accumulation_count(const he_poly_context* ctx) {
+    return ctx ? ctx->impl->max_lazy_product_accumulation_count(ctx->impl->moduli_count()) : 0;
+}
+int he_poly_context_q_remainder(const he_poly_context* ctx, uint64_t modulus, uint64_t* out) {
+    if (ctx == nullptr || out == nullptr || modulus == 0) return invalid_argument("null pointer or zero modulus");
+    const auto& moduli = ctx->impl->moduli();
+    *out = heamd::product_mod(moduli.data(), moduli.size(), modulus);
+    return HE_OK;
+}
+int he_poly_context_copy_ntt_tables(const he_poly_context* ctx, uint32_t rns_index, uint64_t* root_powers,
+                                    uint64_t* root_factors, uint64_t* inverse_root_powers,
+                                    uint64_t* inverse_root_factors, uint64_t* inverse_degree,
+                                    uint64_t* inverse_degree_root) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (rns_index >= pc.moduli_count() || !pc.host_constants()[rns_index].has_ntt) return HE_ERR_INVALID_NTT_MODULUS;
+    const heamd::U64x2* forward = pc.host_forward_twiddles(rns_index);
+    const heamd::U64x2* inverse = pc.host_inverse_twiddles(rns_index);
+    for (uint32_t k = 0; k < pc.degree(); ++k) {
+        if (root_powers) root_powers[k] = forward[k].x;
+        if (root_factors) root_factors[k] = forward[k].y;
+        if (inverse_root_powers) inverse_root_powers[k] = inverse[k].x;
+        if (inverse_root_factors) inverse_root_factors[k] = inverse[k].y;
+    }
+    if (inverse_degree) *inverse_degree = pc.host_constants()[rns_index].inv_degree;
+    if (inverse_degree_root) *inverse_degree_root = pc.host_constants()[rns_index].inv_degree_root;
+    return HE_OK;
+}
+int he_generate_primes(const int32_t* significant_bit_counts, uint32_t count, int preferring_small,
+                       uint32_t ntt_degree, uint64_t* out_primes) {
+    if ((count > 0 && (significant_bit_counts == nullptr || out_primes == nullptr)) ||
+        !heamd::is_power_of_two(ntt_degree))
+        return invalid_argument("generatePrimes arguments");
+    std::vector<int> bits(significant_bit_counts, significant_bit_counts + count);
+    std::vector<heamd::u64> primes;
+    if (!heamd::generate_primes(bits, preferring_small != 0, ntt_degree, primes)) return HE_ERR_NOT_ENOUGH_PRIMES;
+    for (uint32_t i = 0; i < count; ++i) out_primes[i] = primes[i];
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NTT
+int he_ntt_forward_device(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, he_stream stream) {
+    return ntt_device(ctx, device_slab, batch, false, as_stream(stream));
+}
+int he_ntt_inverse_device(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, he_stream stream) {
+    return ntt_device(ctx, device_slab, batch, true, as_stream(stream));
+}
+int he_ntt_forward_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* device_rows, size_t rows,
+                               he_stream stream) {
+    return ntt_rows_device(ctx, modulus, device_rows, rows, false, as_stream(stream));
+}
+int he_ntt_inverse_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* device_rows, size_t rows,
+                               he_stream stream) {
+    return ntt_rows_device(ctx, modulus, device_rows, rows, true, as_stream(stream));
+}
+static int ntt_host(const he_poly_context* ctx, uint64_t* host_slab, size_t batch, bool inverse) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (!pc.all_ntt(pc.moduli_count())) return HE_ERR_INVALID_NTT_MODULUS;
+    if (batch == 0) return HE_OK;
+    if (host_slab == nullptr) return invalid_argument("null slab");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    const size_t words = batch * pc.moduli_count() * pc.degree();
+    return with_device_copy(host_slab, words, [&](uint64_t* device, hipStream_t stream) {
+        return ntt_device(ctx, device, batch, inverse, stream);
+    });
+}
+int he_ntt_forward(const he_poly_context* ctx, uint64_t* host_slab, size_t batch) {
+    return ntt_host(ctx, host_slab, batch, false);
+}
+int he_ntt_inverse(const he_poly_context* ctx, uint64_t* host_slab, size_t batch) {
+    return ntt_host(ctx, host_slab, batch, true);
+}
+// Test/bench hook: run the transform with a named kernel variant (0 auto, 1 exact butterflies, 2 generic radix-2).
+int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, int inverse, int variant,
+                          he_stream stream) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (!pc.all_ntt(pc.moduli_count())) return HE_ERR_INVALID_NTT_MODULUS;
+    if (batch == 0) return HE_OK;
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_ntt(inverse != 0, device_slab, pc.device_context(), 0, pc.moduli_count(),
+                                    batch * pc.moduli_count(), as_stream(stream), variant));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ element-wise
+int he_poly_add_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s) {
+    return elementwise(ctx, heamd::ElementwiseOp::Add, lhs, rhs, batch, s);
+}
+int he_poly_sub_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s) {
+    return elementwise(ctx, heamd::ElementwiseOp::Sub, lhs, rhs, batch, s);
+}
+int he_poly_neg_device(const he_poly_context* ctx, uint64_t* data, size_t batch, he_stream s) {
+    return elementwise(ctx, heamd::ElementwiseOp::Neg, data, nullptr, batch, s);
+}
+int he_poly_mul_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s) {
+    return elementwise(ctx, heamd::ElementwiseOp::Mul, lhs, rhs, batch, s);
+}
+int he_poly_mul_scalar_device(const he_poly_context* ctx, uint64_t* data, const uint64_t* scalar_residues,
+                              size_t batch, he_stream s) {
+    if (ctx == nullptr || scalar_residues == nullptr) return invalid_argument("null pointer");
+    const PolyContext& pc = *ctx->impl;
+    if (batch == 0) return HE_OK;
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    // MultiplyConstantModulus(multiplicand:divisionModulus:) per row (PolyRq.swift:235-238)
+    std::vector<heamd::U64x2> pairs(pc.moduli_count());
+    for (uint32_t i = 0; i < pc.moduli_count(); ++i) {
+        const uint64_t p = pc.moduli()[i];
+        if (scalar_residues[i] >= p) return invalid_argument("scalar residue not reduced");
+        pairs[i] = heamd::U64x2{scalar_residues[i], heamd::shoup_factor(scalar_residues[i], p)};
+    }
+    hipStream_t stream = as_stream(s);
+    Scratch scratch(stream);
+    HEAMD_HIP_TRY(scratch.allocate(pairs.size() * sizeof(heamd::U64x2)));
+    HEAMD_HIP_TRY(hipMemcpyAsync(scratch.get(), pairs.data(), pairs.size() * sizeof(heamd::U64x2),
+                                 hipMemcpyHostToDevice, stream));
+    // the pageable host vector must outlive the async copy
+    HEAMD_HIP_TRY(hipStreamSynchronize(stream));
+    HEAMD_HIP_TRY(heamd::launch_elementwise(heamd::ElementwiseOp::MulScalar, data,
+                                            static_cast<const uint64_t*>(scratch.get()), pc.device_context(),
+                                            batch * pc.moduli_count(), stream));
+    return HE_OK;
+}
+
+int he_poly_divide_and_round_q_last_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out,
+                                           size_t batch, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (pc.moduli_count() < 2) return HE_ERR_INVALID_POLY_CONTEXT;  // no next context (PolyRq.swift:366-368)
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_divide_and_round_q_last(in, out, pc.device_context(), pc.moduli_count(), batch,
+                                                        as_stream(s)));
+    return HE_OK;
+}
+int he_poly_divide_and_round_q_last(const he_poly_context* ctx, const uint64_t* host_in, uint64_t* host_out,
+                                    size_t batch) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (pc.moduli_count() < 2) return HE_ERR_INVALID_POLY_CONTEXT;
+    if (batch == 0) return HE_OK;
+    if (host_in == nullptr || host_out == nullptr) return invalid_argument("null slab");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    const size_t n = pc.degree(), L = pc.moduli_count();
+    const size_t in_words = batch * L * n, out_words = batch * (L - 1) * n;
+    hipStream_t stream = hipStreamPerThread;
+    void* device = nullptr;
+    HEAMD_HIP_TRY(hipMalloc(&device, (in_words + out_words) * sizeof(uint64_t)));
+    uint64_t* d_in = static_cast<uint64_t*>(device);
+    uint64_t* d_out = d_in + in_words;
+    hipError_t e = hipMemcpyAsync(d_in, host_in, in_words * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = heamd::launch_divide_and_round_q_last(d_in, d_out, pc.device_context(), L, batch, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, d_out, out_words * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(device);
+    if (e != hipSuccess) return heamd::device_failure(e, "he_poly_divide_and_round_q_last");
+    return HE_OK;
+}
+
+int he_poly_adding_lazy_product_device(const he_poly_context* ctx, const uint64_t* lhs, const uint64_t* rhs,
+                                       uint64_t* acc_lo_hi, he_stream s) {
+    if (ctx == nullptr || lhs == nullptr || rhs == nullptr || acc_lo_hi == nullptr) return invalid_argument("null");
+    int status = ctx->impl->check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_adding_lazy_product(lhs, rhs, acc_lo_hi, ctx->impl->device_context(), as_stream(s)));
+    return HE_OK;
+}
+int he_poly_reduce_accumulator_device(const he_poly_context* ctx, const uint64_t* acc_lo_hi, uint64_t* out,
+                                      he_stream s) {
+    if (ctx == nullptr || acc_lo_hi == nullptr || out == nullptr) return invalid_argument("null");
+    int status = ctx->impl->check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_reduce_accumulator(acc_lo_hi, out, ctx->impl->device_context(), as_stream(s)));
+    return HE_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,38 @@
+// device_context.hpp -- the device-resident, immutable image of a PolyContext that kernels receive by value.
+#pragma once
+
+#include <stdint.h>
+
+#include "device_math.hpp"
+
+namespace heamd {
+
+// Per-modulus constants (one per RNS row).  Loaded through the scalar cache: every lane of a workgroup reads the
+// same entry.  Sources: HomomorphicEncryption/Modulus.swift:24-45 (Barrett), PolyRq/PolyRq+Ntt.swift:159-168 (N^-1).
+struct DeviceModulus {
+    uint64_t p;
+    uint64_t barrett64;        // floor(2^64 / p)
+    uint64_t barrett128_lo;    // floor(2^128 / p), low word
+    uint64_t barrett128_hi;    //                   high word
+    uint64_t product_factor;   // floor(2^(bits(p)+62) / p)
+    uint32_t product_shift;    // bits(p) - 2
+    uint32_t has_ntt;          // 1 when p is an NTT modulus for this degree
+    uint64_t inv_degree;       // N^-1 mod p                  (+ Shoup factor)
+    uint64_t inv_degree_shoup;
+    uint64_t inv_degree_root;  // N^-1 * psi^(-N/2) mod p     (+ Shoup factor)
+    uint64_t inv_degree_root_shoup;
+};
+
+struct DeviceContext {
+    const DeviceModulus* moduli;   // [L]
+    const U64x2* forward_twiddles; // [L][N]  (w, floor(w 2^64 / p)), bit-reversed order   PolyRq+Ntt.swift:125-143
+    const U64x2* inverse_twiddles; // [L][N]  stage-major re-ordered                       PolyRq+Ntt.swift:146-157
+    const U64x2* inverse_q_last;   // [L][L]  row k: (q_{k}^-1 mod q_i, Shoup) for i < k   PolyContext.swift:108-111
+    uint32_t degree;
+    uint32_t log_degree;
+    uint32_t moduli_count;         // active moduli (a prefix of the context's list)
+    uint32_t moduli_stride;        // moduli of the full context = row stride of inverse_q_last
+    uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
+};
+
+}  // namespace heamd

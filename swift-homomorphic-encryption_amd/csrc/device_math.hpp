@@ -1,0 +1,149 @@
+// device_math.hpp -- 64-bit modular arithmetic on CDNA4 vector ALUs.
+//
+// gfx950 has no 64-bit integer multiplier: every 64x64 product is built from v_mad_u64_u32 / v_mul_hi_u32
+// (32x32 -> 64).  The routines below are written so that hipcc folds the partial-product additions into
+// v_mad_u64_u32's 64-bit addend and so that the *count* of 32-bit multiplies is minimal -- the NTT is bound by the
+// integer-multiply issue rate, not by HBM (DESIGN.md section "Rooflines").
+//
+// Exactness: every public entry point of the library returns canonical residues, so kernels are free to use lazy
+// ranges internally as long as the last step lands in [0, p).  Reference semantics being reproduced:
+//   MultiplyConstantModulus.multiplyModLazy / multiplyMod   ModularArithmetic/Modulus.swift:401-415
+//   ReduceModulus.reduce(T) / reduce(T.DoubleWidth) / reduceProduct   ModularArithmetic/Modulus.swift:258-360
+//   subtractIfExceeds / addMod / subtractMod / negateMod    ModularArithmetic/Scalar.swift:146-193
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace heamd {
+
+struct alignas(16) U64x2 {
+    uint64_t x, y;
+};
+
+__device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
+__device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }
+
+// 32x32 + 64 -> 64 (selected as one v_mad_u64_u32)
+__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) {
+    return static_cast<uint64_t>(a) * b + c;
+}
+__device__ __forceinline__ uint64_t mul32(uint32_t a, uint32_t b) { return static_cast<uint64_t>(a) * b; }
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+// asm on purpose: with a plain `a * b` hipcc recognises the schoolbook pattern below, rebuilds a 64/128-bit multiply
+// and re-expands it with redundant (even multiply-by-zero) v_mad_u64_u32.
+__device__ __forceinline__ uint32_t mullo32(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// Optimisation barrier (emits nothing): hides how a value was derived, so that hipcc does not re-associate our
+// partial products with the additions that produced the operand and re-expand them as generic 64x64 multiplies.
+__device__ __forceinline__ uint64_t opaque(uint64_t v) {
+    asm("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return (static_cast<uint64_t>(hi) << 32) | lo; }
+
+// Exact high word of a 64x64 product: 4 multiplies.
+__device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const uint32_t p00_hi = mulhi32(a0, b0);
+    const uint64_t p01 = mad32(a0, b1, p00_hi);
+    const uint64_t p10 = mad32(a1, b0, lo32(p01));
+    return mad32(a1, b1, static_cast<uint64_t>(hi32(p01)) + hi32(p10));
+}
+
+// High word of a 64x64 product, allowed to be low by at most 2: 3 multiplies.
+// Keeps a1*b1 + hi32(a0*b1) + hi32(a1*b0); drops the low-column carries (< 3).
+__device__ __forceinline__ uint64_t mulhi64_approx(uint64_t a, uint64_t b) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const uint32_t p01_hi = mulhi32(a0, b1);
+    const uint32_t p10_hi = mulhi32(a1, b0);
+    return mad32(a1, b1, static_cast<uint64_t>(p01_hi) + p10_hi);
+}
+
+// Low word of a*b + c*d (mod 2^64): 6 multiplies.
+__device__ __forceinline__ uint64_t mullo64_sum2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const uint32_t c0 = lo32(c), c1 = hi32(c), d0 = lo32(d), d1 = hi32(d);
+    const uint64_t acc = mad32(c0, d0, mul32(a0, b0));
+    const uint32_t high = hi32(acc) + mullo32(a0, b1) + mullo32(a1, b0) + mullo32(c0, d1) + mullo32(c1, d0);
+    return pack64(lo32(acc), high);
+}
+
+// x >= m ? x - m : x   (x < 2m)
+__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+
+// Shoup multiplication by the constant w (wf = floor(w * 2^64 / p)), `neg_p` = 2^64 - p.
+//   lazy  : result in [0, 2p), exact quotient estimate (4 + 6 multiplies)
+//   lazy4 : result in [0, 4p), quotient estimate low by <= 2 (3 + 6 multiplies); needs 4p < 2^64
+__device__ __forceinline__ uint64_t shoup_lazy(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
+    x = opaque(x);
+    return mullo64_sum2(x, w, opaque(mulhi64(x, wf)), neg_p);
+}
+__device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
+    x = opaque(x);
+    return mullo64_sum2(x, w, opaque(mulhi64_approx(x, wf)), neg_p);
+}
+__device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
+    return csub(shoup_lazy(x, w, wf, 0 - p), p);
+}
+
+__device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + b, p); }
+__device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + p - b, p); }
+__device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t p) { return csub(p - a, p); }
+
+// Single-word Barrett: x mod p for any 64-bit x; factor = floor(2^64 / p).  (Modulus.swift:258-263)
+__device__ __forceinline__ uint64_t barrett_reduce64(uint64_t x, uint64_t p, uint64_t factor) {
+    const uint64_t q = mulhi64(x, factor);
+    return csub(x - q * p, p);
+}
+
+struct U128 {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ U128 mul_wide(uint64_t a, uint64_t b) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const uint64_t p00 = mul32(a0, b0);
+    const uint64_t p01 = mad32(a0, b1, hi32(p00));
+    const uint64_t p10 = mad32(a1, b0, lo32(p01));
+    U128 r;
+    r.lo = pack64(lo32(p00), lo32(p10));
+    r.hi = mad32(a1, b1, static_cast<uint64_t>(hi32(p01)) + hi32(p10));
+    return r;
+}
+__device__ __forceinline__ void add128(U128& acc, U128 v) {  // wrapping
+    const uint64_t lo = acc.lo + v.lo;
+    acc.hi += v.hi + (lo < acc.lo ? 1 : 0);
+    acc.lo = lo;
+}
+__device__ __forceinline__ void mac128(U128& acc, uint64_t a, uint64_t b) { add128(acc, mul_wide(a, b)); }
+
+// Barrett on a product x*y < p^2 (Modulus.swift:349-360): factor = floor(2^(bits(p)+62)/p), shift = bits(p)-2.
+__device__ __forceinline__ uint64_t barrett_mul(uint64_t x, uint64_t y, uint64_t p, uint64_t factor, int shift) {
+    const U128 prod = mul_wide(x, y);
+    // shift in [0, 60]; p >= 2 => bits(p) >= 2
+    const uint64_t shifted = shift == 0 ? prod.lo : ((prod.lo >> shift) | (prod.hi << (64 - shift)));
+    const uint64_t q = mulhi64(shifted, factor);
+    return csub(prod.lo - q * p, p);
+}
+
+// Double-word Barrett: x mod p for any 128-bit x; factor = floor(2^128 / p) as (lo, hi).  (Modulus.swift:319-325)
+// qHat = high 128 bits of x * factor; only its low word matters because z = x - qHat*p is taken mod 2^64 after
+// noting z < 2p < 2^64.
+__device__ __forceinline__ uint64_t barrett_reduce128(U128 x, uint64_t p, uint64_t f_lo, uint64_t f_hi) {
+    // x * f = x.lo*f_lo + (x.lo*f_hi + x.hi*f_lo) * 2^64 + x.hi*f_hi * 2^128 ; we need bits [128, 192)
+    const uint64_t ll_hi = mulhi64(x.lo, f_lo);
+    const U128 lh = mul_wide(x.lo, f_hi);
+    const U128 hl = mul_wide(x.hi, f_lo);
+    // middle column (bits 64..127): ll_hi + lh.lo + hl.lo -> carry into bits 128+
+    uint64_t mid = ll_hi + lh.lo;
+    uint64_t carry = mid < ll_hi ? 1 : 0;
+    const uint64_t mid2 = mid + hl.lo;
+    carry += mid2 < mid ? 1 : 0;
+    const uint64_t q_lo = lh.hi + hl.hi + carry + x.hi * f_hi;  // low word of bits [128, 192), wrapping
+    return csub(x.lo - q_lo * p, p);
+}
+
+}  // namespace heamd

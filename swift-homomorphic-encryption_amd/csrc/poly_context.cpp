@@ -1,0 +1,230 @@
+// poly_context.cpp -- builds the immutable per-(N, moduli) precomputation on the host and uploads it once.
+#include "poly_context.hpp"
+
+#include <cstring>
+
+#include "../../include/he_amd.h"
+
+namespace heamd {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_last_error(const std::string& message) { g_last_error = message; }
+const char* last_error() { return g_last_error.c_str(); }
+
+int device_failure(hipError_t error, const char* where) {
+    set_last_error(std::string("HIP error in ") + where + ": " + hipGetErrorString(error));
+    return HE_ERR_DEVICE;
+}
+
+// PolyContext.swift:49-62 validate(modulus:)
+static int validate_modulus(u64 modulus) {
+    if (!(is_prime(modulus) || is_power_of_two(modulus))) return HE_ERR_INVALID_MODULUS;
+    if (modulus < 1 || modulus > kMaxModulus) return HE_ERR_INVALID_MODULUS;
+    return HE_OK;
+}
+
+// PolyContext.swift:45-93: degree, power-of-two count, uniqueness, emptiness, then modulus validation (only the last
+// modulus when a next context exists).
+int validate_poly_context_prefix(uint32_t degree, const uint64_t* moduli, uint32_t count, bool has_next) {
+    if (!is_power_of_two(degree)) return HE_ERR_INVALID_DEGREE;
+    uint32_t powers_of_two = 0;
+    for (uint32_t i = 0; i < count; ++i) powers_of_two += is_power_of_two(moduli[i]) ? 1 : 0;
+    if (powers_of_two > 1) return HE_ERR_COPRIME_MODULI;
+    for (uint32_t i = 0; i < count; ++i)
+        for (uint32_t j = i + 1; j < count; ++j)
+            if (moduli[i] == moduli[j]) return HE_ERR_COPRIME_MODULI;
+    if (count == 0) return HE_ERR_EMPTY_MODULUS;
+    if (has_next) return validate_modulus(moduli[count - 1]);
+    for (uint32_t i = 0; i < count; ++i) {
+        const int status = validate_modulus(moduli[i]);
+        if (status != HE_OK) return status;
+    }
+    return HE_OK;
+}
+
+static DeviceModulus make_constants(u64 p) {
+    DeviceModulus m{};
+    m.p = p;
+    m.barrett64 = static_cast<u64>((static_cast<u128>(1) << 64) / p);  // Modulus.swift (MA):206-209
+    u128 f128;
+    if (is_power_of_two(p)) {
+        const int lg = floor_log2(p);
+        f128 = lg == 0 ? 0 : (static_cast<u128>(1) << (128 - lg));  // Modulus.swift (MA):227-228
+    } else {
+        f128 = ~static_cast<u128>(0) / p;  // Modulus.swift (MA):230-231
+    }
+    m.barrett128_lo = static_cast<u64>(f128);
+    m.barrett128_hi = static_cast<u64>(f128 >> 64);
+    const int bits = bit_length(p);
+    m.product_factor = static_cast<u64>((static_cast<u128>(1) << (bits + 62)) / p);  // Modulus.swift (MA):235-240
+    m.product_shift = static_cast<uint32_t>(bits >= 2 ? bits - 2 : 0);
+    return m;
+}
+
+int PolyContext::create(uint32_t degree, const uint64_t* moduli, uint32_t count, std::unique_ptr<PolyContext>& out,
+                        bool host_only) {
+    out.reset();
+    if (count > 0 && moduli == nullptr) return HE_ERR_INVALID_ARGUMENT;
+    if (count <= 1) {
+        const int status = validate_poly_context_prefix(degree, moduli, count, false);
+        if (status != HE_OK) return status;
+    } else {
+        for (uint32_t k = 1; k <= count; ++k) {
+            const int status = validate_poly_context_prefix(degree, moduli, k, k > 1);
+            if (status != HE_OK) return status;
+        }
+    }
+    std::unique_ptr<PolyContext> ctx(new PolyContext());
+    ctx->degree_ = degree;
+    ctx->log_degree_ = static_cast<uint32_t>(floor_log2(degree));
+    ctx->moduli_.assign(moduli, moduli + count);
+    const size_t n = degree;
+    ctx->host_moduli_.resize(count);
+    ctx->host_forward_.assign(static_cast<size_t>(count) * n, U64x2{0, 0});
+    ctx->host_inverse_.assign(static_cast<size_t>(count) * n, U64x2{0, 0});
+    ctx->host_inverse_q_last_.assign(static_cast<size_t>(count) * count, U64x2{0, 0});
+
+    for (uint32_t i = 0; i < count; ++i) {
+        const u64 p = moduli[i];
+        DeviceModulus m = make_constants(p);
+        // inverseQLast of the chain element whose last modulus is q_i (PolyContext.swift:108-111)
+        for (uint32_t j = 0; j < i; ++j) {
+            u64 inverse = 0;
+            if (!inverse_mod(p % moduli[j], moduli[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
+            ctx->host_inverse_q_last_[static_cast<size_t>(i) * count + j] = U64x2{inverse, shoup_factor(inverse, moduli[j])};
+        }
+        // _NttContext.init (PolyRq+Ntt.swift:118-169) when q_i is an NTT modulus (PolyContext.swift:117-121)
+        if (!is_power_of_two(p) && is_ntt_modulus(p, degree) && degree >= 1) {
+            const u64 psi = min_primitive_root_of_unity(p, 2 * static_cast<u64>(degree));
+            if (psi == 0) return HE_ERR_INVALID_NTT_MODULUS;
+            u64 inverse_psi = 0;
+            if (!inverse_mod(psi, p, inverse_psi)) return HE_ERR_NOT_INVERTIBLE;
+            U64x2* forward = ctx->host_forward_.data() + static_cast<size_t>(i) * n;
+            U64x2* inverse = ctx->host_inverse_.data() + static_cast<size_t>(i) * n;
+            std::vector<u64> inverse_powers(n, 1);
+            // rootOfUnityPowers[bitrev(k)] = psi^k  (PolyRq+Ntt.swift:125-137)
+            u64 power = 1, inverse_power = 1;
+            forward[0] = U64x2{1, shoup_factor(1 % p, p)};
+            for (uint32_t k = 1; k < degree; ++k) {
+                power = mul_mod(power, psi, p);
+                inverse_power = mul_mod(inverse_power, inverse_psi, p);
+                const uint32_t rev = reverse_bits(k, static_cast<int>(ctx->log_degree_));
+                forward[rev] = U64x2{power, shoup_factor(power, p)};
+                inverse_powers[rev] = inverse_power;
+            }
+            // stage-major re-ordering of the inverse powers (PolyRq+Ntt.swift:146-157)
+            size_t slot = 1;
+            inverse[0] = U64x2{1, shoup_factor(1 % p, p)};
+            for (int lg = static_cast<int>(ctx->log_degree_) - 1; lg >= 0; --lg) {
+                const size_t group = static_cast<size_t>(1) << lg;
+                for (size_t k = 0; k < group; ++k, ++slot) {
+                    const u64 w = inverse_powers[group + k];
+                    inverse[slot] = U64x2{w, shoup_factor(w, p)};
+                }
+            }
+            u64 inverse_degree = 0;
+            if (!inverse_mod(degree % p, p, inverse_degree)) return HE_ERR_NOT_INVERTIBLE;
+            const u64 inverse_degree_root = mul_mod(inverse_degree, inverse[n - 1].x, p);  // PolyRq+Ntt.swift:162-168
+            m.has_ntt = 1;
+            m.inv_degree = inverse_degree;
+            m.inv_degree_shoup = shoup_factor(inverse_degree, p);
+            m.inv_degree_root = inverse_degree_root;
+            m.inv_degree_root_shoup = shoup_factor(inverse_degree_root, p);
+        }
+        ctx->host_moduli_[i] = m;
+    }
+    ctx->dev_.degree = degree;
+    ctx->dev_.log_degree = ctx->log_degree_;
+    ctx->dev_.moduli_count = count;
+    ctx->dev_.moduli_stride = count;
+    if (!host_only) {
+        const int status = ctx->upload();
+        if (status != HE_OK) return status;
+    }
+    out = std::move(ctx);
+    return HE_OK;
+}
+
+int PolyContext::upload() {
+    HEAMD_HIP_TRY(hipGetDevice(&device_));
+    const size_t count = moduli_.size(), n = degree_;
+    auto round_up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t bytes_moduli = round_up(count * sizeof(DeviceModulus));
+    const size_t bytes_twiddles = round_up(count * n * sizeof(U64x2));
+    const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
+    const size_t total = bytes_moduli + 2 * bytes_twiddles + bytes_inverse_q_last;
+    HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
+    char* base = static_cast<char*>(device_block_);
+    HEAMD_HIP_TRY(hipMemcpy(base, host_moduli_.data(), count * sizeof(DeviceModulus), hipMemcpyHostToDevice));
+    char* forward = base + bytes_moduli;
+    char* inverse = forward + bytes_twiddles;
+    char* inverse_q_last = inverse + bytes_twiddles;
+    HEAMD_HIP_TRY(hipMemcpy(forward, host_forward_.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+    HEAMD_HIP_TRY(hipMemcpy(inverse, host_inverse_.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+    HEAMD_HIP_TRY(hipMemcpy(inverse_q_last, host_inverse_q_last_.data(), count * count * sizeof(U64x2),
+                            hipMemcpyHostToDevice));
+    dev_.moduli = reinterpret_cast<const DeviceModulus*>(base);
+    dev_.forward_twiddles = reinterpret_cast<const U64x2*>(forward);
+    dev_.inverse_twiddles = reinterpret_cast<const U64x2*>(inverse);
+    dev_.inverse_q_last = reinterpret_cast<const U64x2*>(inverse_q_last);
+    dev_.degree = degree_;
+    dev_.log_degree = log_degree_;
+    dev_.moduli_count = static_cast<uint32_t>(count);
+    dev_.moduli_stride = static_cast<uint32_t>(count);
+    return HE_OK;
+}
+
+PolyContext::~PolyContext() {
+    if (device_block_ != nullptr) (void)hipFree(device_block_);
+}
+
+bool PolyContext::all_ntt(uint32_t count) const {
+    for (uint32_t i = 0; i < count && i < host_moduli_.size(); ++i)
+        if (!host_moduli_[i].has_ntt) return false;
+    return true;
+}
+
+int PolyContext::modulus_index(u64 modulus) const {
+    for (size_t i = 0; i < moduli_.size(); ++i)
+        if (moduli_[i] == modulus) return static_cast<int>(i);
+    return -1;
+}
+
+u64 PolyContext::max_lazy_product_accumulation_count(uint32_t count) const {
+    u64 q_max = 0;
+    for (uint32_t i = 0; i < count; ++i) q_max = moduli_[i] > q_max ? moduli_[i] : q_max;
+    const u128 max_product = static_cast<u128>(q_max - 1) * (q_max - 1);
+    if (max_product == 0) return static_cast<u64>(INT64_MAX);
+    const u128 result = (~static_cast<u128>(0) - q_max) / max_product;
+    return result > static_cast<u128>(INT64_MAX) ? static_cast<u64>(INT64_MAX) : static_cast<u64>(result);
+}
+
+DeviceContext PolyContext::device_context(uint32_t count) const {
+    DeviceContext d = dev_;
+    d.moduli_count = count;
+    uint32_t approx = 1;
+    for (uint32_t i = 0; i < count; ++i)
+        if (moduli_[i] >= (static_cast<u64>(1) << 61)) approx = 0;
+    d.approx_ok = approx;
+    return d;
+}
+
+int PolyContext::check_device() const {
+    if (device_block_ == nullptr) {
+        set_last_error("context was created host-only (no device tables); compute entry points need a GPU context");
+        return HE_ERR_DEVICE;
+    }
+    int current = -1;
+    HEAMD_HIP_TRY(hipGetDevice(&current));
+    if (current != device_) {
+        set_last_error("context lives on HIP device " + std::to_string(device_) + " but device " +
+                       std::to_string(current) + " is current");
+        return HE_ERR_DEVICE;
+    }
+    return HE_OK;
+}
+
+}  // namespace heamd

@@ -1,0 +1,328 @@
+// poly_kernels.hip -- element-wise PolyRq kernels, RNS modulus switching and lazy inner products for gfx950.
+//
+// All of these stream every word once (HBM-bound by design): lanes move 16 B each, consecutive lanes touch
+// consecutive addresses, grids are sized to a few workgroups per CU and stride over the slab.
+// Reference semantics (Sources/HomomorphicEncryption/):
+//   PolyRq += -= prefix- *= (Eval) *= [T]      PolyRq/PolyRq.swift:147-174,184-204,232-245,299-309
+//   PolyRq.divideAndRoundQLast                  PolyRq/PolyRq.swift:365-393
+//   PolyRq.addingLazyProduct, Bfv.reduceToCiphertext, Bfv.innerProduct(ciphertexts:plaintexts:)
+//                                               PolyRq/PolyRq.swift:210-225, Bfv/Bfv.swift:365-394,476-505
+#include <hip/hip_runtime.h>
+
+#include "device_context.hpp"
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace heamd {
+
+namespace {
+
+constexpr unsigned kThreads = 256;
+
+inline unsigned grid_for(size_t work_items) {
+    const size_t blocks = (work_items + kThreads - 1) / kThreads;
+    const size_t cap = 256 * 8;  // 256 CUs x 8 workgroups
+    return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+template <ElementwiseOp OP>
+__device__ __forceinline__ uint64_t apply(uint64_t a, uint64_t b, const DeviceModulus& m, U64x2 scalar) {
+    if constexpr (OP == ElementwiseOp::Add) return add_mod(a, b, m.p);
+    if constexpr (OP == ElementwiseOp::Sub) return sub_mod(a, b, m.p);
+    if constexpr (OP == ElementwiseOp::Neg) return neg_mod(a, m.p);
+    if constexpr (OP == ElementwiseOp::Mul)
+        return barrett_mul(a, b, m.p, m.product_factor, static_cast<int>(m.product_shift));
+    if constexpr (OP == ElementwiseOp::MulScalar) return shoup_mul(a, scalar.x, scalar.y, m.p);
+    return 0;
+}
+
+// One lane = one pair of consecutive words (degree >= 2), so a pair never straddles two rows.
+template <ElementwiseOp OP>
+__global__ void __launch_bounds__(kThreads)
+    elementwise_kernel(uint64_t* __restrict__ lhs, const uint64_t* __restrict__ rhs, const DeviceContext ctx,
+                       size_t pairs) {
+    const uint32_t log_pairs_per_row = ctx.log_degree - 1;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < pairs;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const uint32_t mi = static_cast<uint32_t>((i >> log_pairs_per_row) % ctx.moduli_count);
+        const DeviceModulus m = ctx.moduli[mi];
+        U64x2 a = reinterpret_cast<U64x2*>(lhs)[i];
+        U64x2 b = {0, 0};
+        U64x2 scalar = {0, 0};
+        if constexpr (OP == ElementwiseOp::MulScalar) {
+            scalar = reinterpret_cast<const U64x2*>(rhs)[mi];
+        } else if constexpr (OP != ElementwiseOp::Neg) {
+            b = reinterpret_cast<const U64x2*>(rhs)[i];
+        }
+        a.x = apply<OP>(a.x, b.x, m, scalar);
+        a.y = apply<OP>(a.y, b.y, m, scalar);
+        reinterpret_cast<U64x2*>(lhs)[i] = a;
+    }
+}
+
+// degree 1 contexts (rows of a single word): scalar path
+template <ElementwiseOp OP>
+__global__ void __launch_bounds__(kThreads)
+    elementwise_scalar_kernel(uint64_t* __restrict__ lhs, const uint64_t* __restrict__ rhs, const DeviceContext ctx,
+                              size_t words) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < words;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const uint32_t mi = static_cast<uint32_t>((i >> ctx.log_degree) % ctx.moduli_count);
+        const DeviceModulus m = ctx.moduli[mi];
+        U64x2 scalar = {0, 0};
+        uint64_t b = 0;
+        if constexpr (OP == ElementwiseOp::MulScalar) {
+            scalar = reinterpret_cast<const U64x2*>(rhs)[mi];
+        } else if constexpr (OP != ElementwiseOp::Neg) {
+            b = rhs[i];
+        }
+        lhs[i] = apply<OP>(lhs[i], b, m, scalar);
+    }
+}
+
+template <ElementwiseOp OP>
+hipError_t launch_elementwise_op(uint64_t* lhs, const uint64_t* rhs, const DeviceContext& ctx, size_t rows,
+                                 hipStream_t stream) {
+    const size_t words = rows * ctx.degree;
+    if (words == 0) return hipSuccess;
+    if (ctx.degree >= 2) {
+        const size_t pairs = words / 2;
+        hipLaunchKernelGGL(elementwise_kernel<OP>, dim3(grid_for(pairs)), dim3(kThreads), 0, stream, lhs, rhs, ctx,
+                           pairs);
+    } else {
+        hipLaunchKernelGGL(elementwise_scalar_kernel<OP>, dim3(grid_for(words)), dim3(kThreads), 0, stream, lhs, rhs,
+                           ctx, words);
+    }
+    return hipGetLastError();
+}
+
+// ct [batch][polys][L][N] *= pt [batch][L][N]   (Bfv.mulAssign(EvalCiphertext, EvalPlaintext), Bfv.swift:120-129)
+__global__ void __launch_bounds__(kThreads)
+    mul_plain_kernel(uint64_t* __restrict__ ct, const uint64_t* __restrict__ pt, const DeviceContext ctx,
+                     uint32_t poly_count, size_t pairs_per_poly, size_t batch) {
+    const uint32_t log_pairs_per_row = ctx.log_degree - 1;
+    const size_t total = pairs_per_poly * batch;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t b = i / pairs_per_poly, k = i - b * pairs_per_poly;
+        const uint32_t mi = static_cast<uint32_t>(k >> log_pairs_per_row);
+        const DeviceModulus m = ctx.moduli[mi];
+        const U64x2 y = reinterpret_cast<const U64x2*>(pt)[i];
+        for (uint32_t c = 0; c < poly_count; ++c) {
+            U64x2* slot = reinterpret_cast<U64x2*>(ct) + (b * poly_count + c) * pairs_per_poly + k;
+            U64x2 x = *slot;
+            x.x = barrett_mul(x.x, y.x, m.p, m.product_factor, static_cast<int>(m.product_shift));
+            x.y = barrett_mul(x.y, y.y, m.p, m.product_factor, static_cast<int>(m.product_shift));
+            *slot = x;
+        }
+    }
+}
+
+// divideAndRoundQLast: one lane owns one coefficient pair (columns k, k+1) of one polynomial and walks the rows.
+//   r      = (x_last + floor(q_last/2)) mod q_last
+//   out_i  = ((x_i + (floor(q_last/2) mod q_i) - (r mod q_i)) mod q_i) * q_last^-1 mod q_i
+__global__ void __launch_bounds__(kThreads)
+    divide_and_round_q_last_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                   const DeviceContext ctx, uint32_t moduli_count, size_t polys) {
+    const uint32_t pairs_per_row = ctx.degree >> 1;
+    const size_t total = polys * pairs_per_row;
+    const uint32_t last = moduli_count - 1;
+    const uint64_t q_last = ctx.moduli[last].p;
+    const uint64_t q_last_div2 = q_last >> 1;
+    const U64x2* __restrict__ inverse_q_last = ctx.inverse_q_last + static_cast<size_t>(last) * ctx.moduli_stride;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t poly = i / pairs_per_row;
+        const uint32_t k = static_cast<uint32_t>(i - poly * pairs_per_row);
+        const U64x2* src = reinterpret_cast<const U64x2*>(in) + poly * moduli_count * pairs_per_row + k;
+        U64x2* dst = reinterpret_cast<U64x2*>(out) + poly * last * pairs_per_row + k;
+        U64x2 r = src[static_cast<size_t>(last) * pairs_per_row];
+        r.x = add_mod(r.x, q_last_div2, q_last);
+        r.y = add_mod(r.y, q_last_div2, q_last);
+        for (uint32_t row = 0; row < last; ++row) {
+            const DeviceModulus m = ctx.moduli[row];
+            const U64x2 inv = inverse_q_last[row];
+            const uint64_t half_mod_qi = barrett_reduce64(q_last_div2, m.p, m.barrett64);
+            U64x2 x = src[static_cast<size_t>(row) * pairs_per_row];
+            const uint64_t t0 = barrett_reduce64(r.x, m.p, m.barrett64);
+            const uint64_t t1 = barrett_reduce64(r.y, m.p, m.barrett64);
+            x.x = shoup_mul(sub_mod(add_mod(x.x, half_mod_qi, m.p), t0, m.p), inv.x, inv.y, m.p);
+            x.y = shoup_mul(sub_mod(add_mod(x.y, half_mod_qi, m.p), t1, m.p), inv.x, inv.y, m.p);
+            dst[static_cast<size_t>(row) * pairs_per_row] = x;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+    adding_lazy_product_kernel(const uint64_t* __restrict__ lhs, const uint64_t* __restrict__ rhs,
+                               uint64_t* __restrict__ acc, size_t words) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < words;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        U64x2 a = reinterpret_cast<U64x2*>(acc)[i];
+        U128 sum = {a.x, a.y};
+        mac128(sum, lhs[i], rhs[i]);
+        a.x = sum.lo;
+        a.y = sum.hi;
+        reinterpret_cast<U64x2*>(acc)[i] = a;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+    reduce_accumulator_kernel(const uint64_t* __restrict__ acc, uint64_t* __restrict__ out, const DeviceContext ctx,
+                              size_t words) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < words;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const DeviceModulus m = ctx.moduli[(i >> ctx.log_degree) % ctx.moduli_count];
+        const U64x2 a = reinterpret_cast<const U64x2*>(acc)[i];
+        out[i] = barrett_reduce128(U128{a.x, a.y}, m.p, m.barrett128_lo, m.barrett128_hi);
+    }
+}
+
+// Lazy inner product: each lane owns one coefficient pair of COLS output ciphertexts and streams the `count`
+// (ciphertext, plaintext) pairs, accumulating in 128 bits (Bfv.swift:476-505).  The ciphertext words are shared by
+// the COLS columns held in registers and, through L2/MALL, by the workgroups of neighbouring columns (blockIdx.x is
+// the column group, so concurrently-resident workgroups read the same ciphertext tile).
+template <int POLYS, int COLS>
+__global__ void __launch_bounds__(kThreads)
+    inner_product_plain_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
+                               const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
+                               const DeviceContext ctx, size_t count, size_t columns, uint64_t max_lazy) {
+    const uint32_t log_pairs_per_row = ctx.log_degree - 1;
+    const size_t pairs_per_poly = (static_cast<size_t>(ctx.moduli_count) << log_pairs_per_row);
+    const size_t pair = blockIdx.y * static_cast<size_t>(kThreads) + threadIdx.x;
+    if (pair >= pairs_per_poly) return;
+    const size_t col0 = static_cast<size_t>(blockIdx.x) * COLS;
+    const DeviceModulus m = ctx.moduli[pair >> log_pairs_per_row];
+    U128 acc[COLS][POLYS][2];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) acc[c][q][0] = acc[c][q][1] = U128{0, 0};
+    uint64_t since_reduce[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) since_reduce[c] = 0;
+
+    const U64x2* ct_base = reinterpret_cast<const U64x2*>(cts) + pair;
+    for (size_t j = 0; j < count; ++j) {
+        U64x2 x[POLYS];
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) x[q] = ct_base[(j * POLYS + q) * pairs_per_poly];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const size_t col = col0 + c;
+            if (col >= columns) continue;
+            if (present != nullptr && present[col * count + j] == 0) continue;
+            const U64x2 y = reinterpret_cast<const U64x2*>(pts)[(col * count + j) * pairs_per_poly + pair];
+#pragma unroll
+            for (int q = 0; q < POLYS; ++q) {
+                mac128(acc[c][q][0], x[q].x, y.x);
+                mac128(acc[c][q][1], x[q].y, y.y);
+            }
+            if (++since_reduce[c] >= max_lazy) {  // Bfv.swift:496-500 reduceInPlace cadence
+                since_reduce[c] = 0;
+#pragma unroll
+                for (int q = 0; q < POLYS; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc[c][q][h] = U128{barrett_reduce128(acc[c][q][h], m.p, m.barrett128_lo, m.barrett128_hi), 0};
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const size_t col = col0 + c;
+        if (col >= columns) continue;
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) {
+            U64x2 r;
+            r.x = barrett_reduce128(acc[c][q][0], m.p, m.barrett128_lo, m.barrett128_hi);
+            r.y = barrett_reduce128(acc[c][q][1], m.p, m.barrett128_lo, m.barrett128_hi);
+            reinterpret_cast<U64x2*>(out)[(col * POLYS + q) * pairs_per_poly + pair] = r;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_elementwise(ElementwiseOp op, uint64_t* lhs, const uint64_t* rhs, const DeviceContext& ctx,
+                              size_t rows, hipStream_t stream) {
+    switch (op) {
+        case ElementwiseOp::Add: return launch_elementwise_op<ElementwiseOp::Add>(lhs, rhs, ctx, rows, stream);
+        case ElementwiseOp::Sub: return launch_elementwise_op<ElementwiseOp::Sub>(lhs, rhs, ctx, rows, stream);
+        case ElementwiseOp::Neg: return launch_elementwise_op<ElementwiseOp::Neg>(lhs, rhs, ctx, rows, stream);
+        case ElementwiseOp::Mul: return launch_elementwise_op<ElementwiseOp::Mul>(lhs, rhs, ctx, rows, stream);
+        case ElementwiseOp::MulScalar:
+            return launch_elementwise_op<ElementwiseOp::MulScalar>(lhs, rhs, ctx, rows, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_mul_plain(uint64_t* ct, const uint64_t* pt, const DeviceContext& ctx, uint32_t poly_count,
+                            size_t batch, hipStream_t stream) {
+    if (batch == 0 || poly_count == 0) return hipSuccess;
+    if (ctx.degree < 2) return hipErrorInvalidValue;
+    const size_t pairs_per_poly = static_cast<size_t>(ctx.moduli_count) * (ctx.degree / 2);
+    hipLaunchKernelGGL(mul_plain_kernel, dim3(grid_for(pairs_per_poly * batch)), dim3(kThreads), 0, stream, ct, pt,
+                       ctx, poly_count, pairs_per_poly, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_divide_and_round_q_last(const uint64_t* in, uint64_t* out, const DeviceContext& ctx,
+                                          uint32_t moduli_count, size_t polys, hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    if (ctx.degree < 2 || moduli_count < 2) return hipErrorInvalidValue;
+    const size_t total = polys * (ctx.degree / 2);
+    hipLaunchKernelGGL(divide_and_round_q_last_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, ctx,
+                       moduli_count, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_adding_lazy_product(const uint64_t* lhs, const uint64_t* rhs, uint64_t* acc_lo_hi,
+                                      const DeviceContext& ctx, hipStream_t stream) {
+    const size_t words = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
+    hipLaunchKernelGGL(adding_lazy_product_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, lhs, rhs,
+                       acc_lo_hi, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, const DeviceContext& ctx,
+                                     hipStream_t stream) {
+    const size_t words = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
+    hipLaunchKernelGGL(reduce_accumulator_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, acc_lo_hi, out,
+                       ctx, words);
+    return hipGetLastError();
+}
+
+template <int POLYS>
+hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
+                                            uint64_t* out, const DeviceContext& ctx, size_t count, size_t columns,
+                                            uint64_t max_lazy, hipStream_t stream) {
+    constexpr int kCols = 4;
+    const size_t pairs_per_poly = static_cast<size_t>(ctx.moduli_count) * (ctx.degree / 2);
+    const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
+                    static_cast<unsigned>((pairs_per_poly + kThreads - 1) / kThreads));
+    hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
+                       present_device, out, ctx, count, columns, max_lazy);
+    return hipGetLastError();
+}
+
+hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
+                                      uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
+                                      size_t columns, uint64_t max_lazy, hipStream_t stream) {
+    if (columns == 0) return hipSuccess;
+    if (ctx.degree < 2) return hipErrorInvalidValue;
+    switch (poly_count) {
+        case 1:
+            return launch_inner_product_plain_polys<1>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
+                                                       stream);
+        case 2:
+            return launch_inner_product_plain_polys<2>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
+                                                       stream);
+        case 3:
+            return launch_inner_product_plain_polys<3>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
+                                                       stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace heamd

@@ -1,0 +1,21 @@
+"""heamd -- Python host-side mirror of the reference's PolyContext / Context<Bfv> interface over the C ABI.
+
+Thin ctypes layer over ``lib/libhe_amd.so`` (include/he_amd.h).  Device memory is borrowed from PyTorch tensors
+(``int64`` storage reinterpreted as UInt64 words); PyTorch is plumbing only -- every operation is one of the
+hand-written HIP kernels behind the C ABI.  There is NO CPU fallback: if the library is missing or no GPU is present
+the calls raise.
+
+Names follow the reference (Sources/HomomorphicEncryption): PolyContext.forwardNtt -> PolyContext.forward_ntt_, etc.
+"""
+from .binding import (  # noqa: F401
+    BfvContext,
+    HeError,
+    PolyContext,
+    device_count,
+    generate_primes,
+    library_path,
+    load_library,
+    to_device,
+    to_host,
+    version,
+)

@@ -1,0 +1,444 @@
+"""ctypes binding of include/he_amd.h (no compute happens in Python)."""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_PKG, "lib", "libhe_amd.so")
+
+U64P = ctypes.POINTER(ctypes.c_uint64)
+vp = ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+c_u32 = ctypes.c_uint32
+c_size = ctypes.c_size_t
+
+STATUS_NAMES = {
+    0: "ok", 1: "invalidDegree", 2: "invalidModulus", 3: "coprimeModuli", 4: "emptyModulus",
+    5: "invalidNttModulus", 6: "invalidPolyContext", 7: "polyContextMismatch", 8: "invalidCiphertext",
+    9: "incompatibleCiphertexts", 10: "incompatibleCiphertextAndPlaintext", 11: "missingRelinearizationKey",
+    12: "unequalContexts", 13: "notEnoughPrimes", 14: "notInvertible", 15: "invalidEncryptionParameters",
+    16: "invalidArgument", 17: "deviceError", 18: "unsupportedHeOperation",
+}
+
+
+class HeError(RuntimeError):
+    """Mirror of the reference's thrown HeError (HomomorphicEncryption/Error.swift:19-54)."""
+
+    def __init__(self, code, detail=""):
+        self.code = code
+        self.name = STATUS_NAMES.get(code, "unknown")
+        super().__init__(f"HeError.{self.name} ({code}) {detail}".strip())
+
+
+# Every symbol include/he_amd.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("he_status_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("he_last_error_message", ctypes.c_char_p, []),
+    ("he_version", ctypes.c_char_p, []),
+    ("he_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
+    ("he_device_free", ctypes.c_int, [vp]),
+    ("he_memcpy_h2d", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_memcpy_d2h", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_stream_synchronize", ctypes.c_int, [vp]),
+    ("he_poly_context_create", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
+    ("he_poly_context_destroy", None, [vp]),
+    ("he_poly_context_degree", c_u32, [vp]),
+    ("he_poly_context_moduli_count", c_u32, [vp]),
+    ("he_poly_context_moduli", ctypes.c_int, [vp, U64P]),
+    ("he_poly_context_max_lazy_product_accumulation_count", c_u64, [vp]),
+    ("he_poly_context_q_remainder", ctypes.c_int, [vp, c_u64, U64P]),
+    ("he_generate_primes", ctypes.c_int, [ctypes.POINTER(ctypes.c_int32), c_u32, ctypes.c_int, c_u32, U64P]),
+    ("he_ntt_forward", ctypes.c_int, [vp, U64P, c_size]),
+    ("he_ntt_inverse", ctypes.c_int, [vp, U64P, c_size]),
+    ("he_ntt_forward_device", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_ntt_inverse_device", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_ntt_forward_rows_device", ctypes.c_int, [vp, c_u64, vp, c_size, vp]),
+    ("he_ntt_inverse_rows_device", ctypes.c_int, [vp, c_u64, vp, c_size, vp]),
+    ("he_poly_add_device", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_sub_device", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_neg_device", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_poly_mul_device", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_mul_scalar_device", ctypes.c_int, [vp, vp, U64P, c_size, vp]),
+    ("he_poly_divide_and_round_q_last_device", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_divide_and_round_q_last", ctypes.c_int, [vp, U64P, U64P, c_size]),
+    ("he_poly_adding_lazy_product_device", ctypes.c_int, [vp, vp, vp, vp, vp]),
+    ("he_poly_reduce_accumulator_device", ctypes.c_int, [vp, vp, vp, vp]),
+    ("he_bfv_context_create", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
+    ("he_bfv_context_destroy", None, [vp]),
+    ("he_bfv_ciphertext_moduli_count", c_u32, [vp]),
+    ("he_bfv_ciphertext_context", vp, [vp, c_u32]),
+    ("he_bfv_key_switching_context", vp, [vp, c_u32]),
+    ("he_bfv_qbsk_context", vp, [vp, c_u32]),
+    ("he_rns_lift_q_to_qbsk_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_rns_floor_qbsk_to_q_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_mul_workspace_bytes", c_size, [vp, c_u32, c_size]),
+    ("he_bfv_relinearize_workspace_bytes", c_size, [vp, c_u32, c_size]),
+    ("he_bfv_inner_product_workspace_bytes", c_size, [vp, c_u32, c_size]),
+    ("he_bfv_mul_device", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_relinearize_device", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_mod_switch_down_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_mul_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_inner_product_plain_device", ctypes.c_int,
+     [vp, c_u32, c_u32, vp, vp, ctypes.POINTER(ctypes.c_uint8), c_size, c_size, vp, vp]),
+    ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    # diagnostics / test hooks
+    ("he_poly_context_create_host_only", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
+    ("he_poly_context_copy_ntt_tables", ctypes.c_int, [vp, c_u32, U64P, U64P, U64P, U64P, U64P, U64P]),
+    ("he_ntt_device_variant", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, ctypes.c_int, vp]),
+    ("he_bfv_context_create_host_only", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
+    ("he_bfv_copy_bsk_moduli", ctypes.c_int, [vp, U64P]),
+]
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libhe_amd.so.  Fails loudly when it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build the HIP extension first "
+                "(python swift-homomorphic-encryption_amd/build.py, or __graft_entry__.build()).")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, restype, argtypes in SIGNATURES:
+            fn = getattr(lib, name)  # AttributeError = header and library disagree
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        detail = load_library().he_last_error_message().decode(errors="replace")
+        raise HeError(code, detail)
+
+
+def version():
+    return load_library().he_version().decode()
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(load_library().he_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def generate_primes(bit_counts, preferring_small, ntt_degree=1):
+    bits = (ctypes.c_int32 * len(bit_counts))(*bit_counts)
+    out = np.zeros(len(bit_counts), dtype=np.uint64)
+    _check(load_library().he_generate_primes(bits, len(bit_counts), int(preferring_small), ntt_degree,
+                                            out.ctypes.data_as(U64P)))
+    return [int(v) for v in out]
+
+
+def _u64(values):
+    return np.ascontiguousarray(values, dtype=np.uint64)
+
+
+def to_device(array, device="cuda"):
+    """numpy uint64 array -> torch int64 CUDA tensor holding the same words."""
+    import torch
+
+    a = np.ascontiguousarray(array, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(tensor):
+    """torch int64 tensor -> numpy uint64 array (same words)."""
+    return tensor.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def _ptr(tensor):
+    if not tensor.is_cuda:
+        raise ValueError("expected a CUDA (HIP) tensor")
+    if not tensor.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    if tensor.element_size() != 8:
+        raise ValueError("expected 64-bit words (int64 storage)")
+    return vp(tensor.data_ptr())
+
+
+def _stream(stream):
+    import torch
+
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return vp(stream.cuda_stream)
+
+
+class PolyContext:
+    """PolyContext<UInt64> (reference PolyRq/PolyContext.swift:19-123) resident on the current GPU."""
+
+    def __init__(self, degree, moduli, host_only=False, _borrowed=None, _keepalive=None):
+        lib = load_library()
+        self._owned = _borrowed is None
+        self._keepalive = _keepalive
+        if _borrowed is not None:
+            self.h = vp(_borrowed)
+        else:
+            arr = _u64(list(moduli))
+            h = vp()
+            create = lib.he_poly_context_create_host_only if host_only else lib.he_poly_context_create
+            _check(create(degree, arr.ctypes.data_as(U64P), len(arr), ctypes.byref(h)))
+            self.h = h
+        self.degree = int(lib.he_poly_context_degree(self.h))
+        count = int(lib.he_poly_context_moduli_count(self.h))
+        out = np.zeros(count, dtype=np.uint64)
+        _check(lib.he_poly_context_moduli(self.h, out.ctypes.data_as(U64P)))
+        self.moduli = [int(v) for v in out]
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None) and _lib is not None:
+            _lib.he_poly_context_destroy(self.h)
+            self.h = None
+
+    # ---- host-side queries
+    def max_lazy_product_accumulation_count(self):
+        return int(load_library().he_poly_context_max_lazy_product_accumulation_count(self.h))
+
+    def q_remainder(self, modulus):
+        out = c_u64(0)
+        _check(load_library().he_poly_context_q_remainder(self.h, modulus, ctypes.byref(out)))
+        return int(out.value)
+
+    def ntt_tables(self, rns_index):
+        n = self.degree
+        arrs = [np.zeros(n, dtype=np.uint64) for _ in range(4)]
+        inv_n, inv_n_root = c_u64(0), c_u64(0)
+        _check(load_library().he_poly_context_copy_ntt_tables(
+            self.h, rns_index, *[a.ctypes.data_as(U64P) for a in arrs], ctypes.byref(inv_n), ctypes.byref(inv_n_root)))
+        return dict(root_powers=arrs[0], root_factors=arrs[1], inv_root_powers=arrs[2], inv_root_factors=arrs[3],
+                    inverse_degree=int(inv_n.value), inverse_degree_root=int(inv_n_root.value))
+
+    def _batch(self, tensor, rows=None):
+        per = (len(self.moduli) if rows is None else rows) * self.degree
+        if tensor.numel() % per:
+            raise ValueError(f"slab of {tensor.numel()} words is not [batch][{per // self.degree}][{self.degree}]")
+        return tensor.numel() // per
+
+    # ---- PolyRq.forwardNtt / inverseNtt (in place, device tensors)
+    def forward_ntt_(self, slab, stream=None):
+        _check(load_library().he_ntt_forward_device(self.h, _ptr(slab), self._batch(slab), _stream(stream)))
+        return slab
+
+    def inverse_ntt_(self, slab, stream=None):
+        _check(load_library().he_ntt_inverse_device(self.h, _ptr(slab), self._batch(slab), _stream(stream)))
+        return slab
+
+    def ntt_variant_(self, slab, inverse, variant, stream=None):
+        _check(load_library().he_ntt_device_variant(self.h, _ptr(slab), self._batch(slab), int(inverse), variant,
+                                                    _stream(stream)))
+        return slab
+
+    def forward_ntt_rows_(self, modulus, rows, stream=None):
+        _check(load_library().he_ntt_forward_rows_device(self.h, modulus, _ptr(rows), rows.numel() // self.degree,
+                                                         _stream(stream)))
+        return rows
+
+    def inverse_ntt_rows_(self, modulus, rows, stream=None):
+        _check(load_library().he_ntt_inverse_rows_device(self.h, modulus, _ptr(rows), rows.numel() // self.degree,
+                                                         _stream(stream)))
+        return rows
+
+    # host-pointer forms (numpy in, numpy out): the reference's borrowed-pointer seam
+    def forward_ntt_host(self, array):
+        out = _u64(array).copy()
+        _check(load_library().he_ntt_forward(self.h, out.ctypes.data_as(U64P), self._batch_np(out)))
+        return out
+
+    def inverse_ntt_host(self, array):
+        out = _u64(array).copy()
+        _check(load_library().he_ntt_inverse(self.h, out.ctypes.data_as(U64P), self._batch_np(out)))
+        return out
+
+    def _batch_np(self, array):
+        per = len(self.moduli) * self.degree
+        if array.size % per:
+            raise ValueError("slab is not [batch][L][N]")
+        return array.size // per
+
+    # ---- element-wise (in place on lhs)
+    def add_(self, lhs, rhs, stream=None):
+        _check(load_library().he_poly_add_device(self.h, _ptr(lhs), _ptr(rhs), self._batch(lhs), _stream(stream)))
+        return lhs
+
+    def sub_(self, lhs, rhs, stream=None):
+        _check(load_library().he_poly_sub_device(self.h, _ptr(lhs), _ptr(rhs), self._batch(lhs), _stream(stream)))
+        return lhs
+
+    def neg_(self, data, stream=None):
+        _check(load_library().he_poly_neg_device(self.h, _ptr(data), self._batch(data), _stream(stream)))
+        return data
+
+    def mul_(self, lhs, rhs, stream=None):
+        _check(load_library().he_poly_mul_device(self.h, _ptr(lhs), _ptr(rhs), self._batch(lhs), _stream(stream)))
+        return lhs
+
+    def mul_scalar_(self, data, scalar_residues, stream=None):
+        s = _u64(list(scalar_residues))
+        _check(load_library().he_poly_mul_scalar_device(self.h, _ptr(data), s.ctypes.data_as(U64P), self._batch(data),
+                                                        _stream(stream)))
+        return data
+
+    def divide_and_round_q_last(self, slab, stream=None):
+        import torch
+
+        batch = self._batch(slab)
+        out = torch.empty((batch, max(len(self.moduli) - 1, 0), self.degree), dtype=torch.int64, device=slab.device)
+        _check(load_library().he_poly_divide_and_round_q_last_device(self.h, _ptr(slab), vp(out.data_ptr()), batch,
+                                                                     _stream(stream)))
+        return out
+
+    def divide_and_round_q_last_host(self, array):
+        a = _u64(array)
+        batch = self._batch_np(a)
+        out = np.zeros((batch, len(self.moduli) - 1, self.degree), dtype=np.uint64)
+        _check(load_library().he_poly_divide_and_round_q_last(self.h, a.ctypes.data_as(U64P),
+                                                              out.ctypes.data_as(U64P), batch))
+        return out
+
+    def adding_lazy_product_(self, lhs, rhs, acc, stream=None):
+        _check(load_library().he_poly_adding_lazy_product_device(self.h, _ptr(lhs), _ptr(rhs), _ptr(acc),
+                                                                 _stream(stream)))
+        return acc
+
+    def reduce_accumulator(self, acc, stream=None):
+        import torch
+
+        out = torch.empty((len(self.moduli), self.degree), dtype=torch.int64, device=acc.device)
+        _check(load_library().he_poly_reduce_accumulator_device(self.h, _ptr(acc), vp(out.data_ptr()), _stream(stream)))
+        return out
+
+
+class BfvContext:
+    """Context<Bfv<UInt64>> (reference Context.swift:94-159) plus the Bfv operations on the hot path."""
+
+    def __init__(self, degree, plaintext_modulus, coefficient_moduli, host_only=False):
+        lib = load_library()
+        arr = _u64(list(coefficient_moduli))
+        h = vp()
+        create = lib.he_bfv_context_create_host_only if host_only else lib.he_bfv_context_create
+        _check(create(degree, plaintext_modulus, arr.ctypes.data_as(U64P), len(arr), ctypes.byref(h)))
+        self.h = h
+        self.degree = degree
+        self.t = plaintext_modulus
+        self.coefficient_moduli = [int(v) for v in arr]
+        self.L = int(lib.he_bfv_ciphertext_moduli_count(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.he_bfv_context_destroy(self.h)
+            self.h = None
+
+    def _L(self, moduli_count):
+        return self.L if moduli_count is None else moduli_count
+
+    def _sub(self, getter, moduli_count):
+        handle = getter(self.h, self._L(moduli_count))
+        if not handle:
+            raise HeError(16, "moduli_count out of range")
+        return PolyContext(None, None, _borrowed=handle, _keepalive=self)
+
+    def ciphertext_context(self, moduli_count=None):
+        return self._sub(load_library().he_bfv_ciphertext_context, moduli_count)
+
+    def key_switching_context(self, moduli_count=None):
+        return self._sub(load_library().he_bfv_key_switching_context, moduli_count)
+
+    def qbsk_context(self, moduli_count=None):
+        return self._sub(load_library().he_bfv_qbsk_context, moduli_count)
+
+    def bsk_moduli(self):
+        out = np.zeros(self.L + 1, dtype=np.uint64)
+        _check(load_library().he_bfv_copy_bsk_moduli(self.h, out.ctypes.data_as(U64P)))
+        return [int(v) for v in out]
+
+    def _empty(self, shape, like):
+        import torch
+
+        return torch.empty(shape, dtype=torch.int64, device=like.device)
+
+    def lift_q_to_qbsk(self, polys, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = polys.numel() // (L * self.degree)
+        out = self._empty((batch, 2 * L + 1, self.degree), polys)
+        _check(load_library().he_rns_lift_q_to_qbsk_device(self.h, L, _ptr(polys), _ptr(out), batch, _stream(stream)))
+        return out
+
+    def floor_qbsk_to_q(self, polys, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = polys.numel() // ((2 * L + 1) * self.degree)
+        out = self._empty((batch, L, self.degree), polys)
+        _check(load_library().he_rns_floor_qbsk_to_q_device(self.h, L, _ptr(polys), _ptr(out), batch, _stream(stream)))
+        return out
+
+    def mul(self, lhs, rhs, moduli_count=None, stream=None, workspace=None):
+        """Bfv.mulAssign(ct, ct): [batch][2][L][N] x [batch][2][L][N] -> [batch][3][L][N] (Coeff)."""
+        L = self._L(moduli_count)
+        batch = lhs.numel() // (2 * L * self.degree)
+        out = self._empty((batch, 3, L, self.degree), lhs)
+        ws_ptr, ws_bytes = (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
+        _check(load_library().he_bfv_mul_device(self.h, L, _ptr(lhs), _ptr(rhs), _ptr(out), batch, ws_ptr, ws_bytes,
+                                                _stream(stream)))
+        return out
+
+    def mul_workspace_bytes(self, batch, moduli_count=None):
+        return int(load_library().he_bfv_mul_workspace_bytes(self.h, self._L(moduli_count), batch))
+
+    def relinearize_workspace_bytes(self, batch, moduli_count=None):
+        return int(load_library().he_bfv_relinearize_workspace_bytes(self.h, self._L(moduli_count), batch))
+
+    def relinearize(self, ct3, key, moduli_count=None, stream=None, workspace=None):
+        """Bfv.relinearize: [batch][3][L][N] + key [L_top][2][L_top+1][N] -> [batch][2][L][N]."""
+        L = self._L(moduli_count)
+        batch = ct3.numel() // (3 * L * self.degree)
+        out = self._empty((batch, 2, L, self.degree), ct3)
+        key_ptr = vp() if key is None else _ptr(key)
+        ws_ptr, ws_bytes = (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
+        _check(load_library().he_bfv_relinearize_device(self.h, L, _ptr(ct3), key_ptr, _ptr(out), batch, ws_ptr,
+                                                        ws_bytes, _stream(stream)))
+        return out
+
+    def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = ct.numel() // (poly_count * L * self.degree)
+        out = self._empty((batch, poly_count, L - 1, self.degree), ct)
+        _check(load_library().he_bfv_mod_switch_down_device(self.h, L, poly_count, _ptr(ct), _ptr(out), batch,
+                                                            _stream(stream)))
+        return out
+
+    def mul_plain_(self, ct, pt, poly_count, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = pt.numel() // (L * self.degree)
+        _check(load_library().he_bfv_mul_plain_device(self.h, L, poly_count, _ptr(ct), _ptr(pt), batch,
+                                                      _stream(stream)))
+        return ct
+
+    def inner_product_plain(self, cts, pts, present=None, poly_count=2, columns=1, moduli_count=None, stream=None):
+        """cts [count][polys][L][N]; pts [columns][count][L][N]; present: host bytes [columns][count] or None."""
+        L = self._L(moduli_count)
+        count = cts.numel() // (poly_count * L * self.degree)
+        out = self._empty((columns, poly_count, L, self.degree), cts)
+        pres = None
+        if present is not None:
+            pres_arr = np.ascontiguousarray(present, dtype=np.uint8)
+            pres = pres_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        _check(load_library().he_bfv_inner_product_plain_device(self.h, L, poly_count, _ptr(cts), _ptr(pts), pres,
+                                                                count, columns, _ptr(out), _stream(stream)))
+        return out
+
+    def inner_product(self, lhs, rhs, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        count = lhs.numel() // (2 * L * self.degree)
+        out = self._empty((3, L, self.degree), lhs)
+        _check(load_library().he_bfv_inner_product_device(self.h, L, _ptr(lhs), _ptr(rhs), count, _ptr(out), vp(), 0,
+                                                          _stream(stream)))
+        return out

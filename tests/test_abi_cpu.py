@@ -1,0 +1,112 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/he_amd.h
+declares, the host-side setup math (validation order, primes, roots, twiddle tables, Bsk base) matches the oracle, and
+compute entry points fail loudly without a device context.  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import heamd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "he_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(he_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = heamd.load_library()
+    declared = _declared_functions()
+    assert len(declared) > 40
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/he_amd.h but not exported by libhe_amd.so"
+    bound = {name for name, _, _ in heamd.binding.SIGNATURES}
+    assert set(declared) == bound, f"binding and header disagree: {set(declared) ^ bound}"
+    assert "gfx950" in heamd.version()
+
+
+def test_generate_primes_matches_reference_kats(kats):
+    for c in kats["generate_primes"]["cases"]:
+        if max(c["bits"]) > 62:
+            continue
+        assert heamd.generate_primes(c["bits"], c["preferring_small"], c["ntt_degree"]) == c["expected"], c
+    for c in kats["generate_primes"]["error_cases"]:
+        with pytest.raises(heamd.HeError) as err:
+            heamd.generate_primes(c["bits"], c["preferring_small"], c["ntt_degree"])
+        assert err.value.name == c["error"]
+
+
+def test_poly_context_validation_order(kats):
+    # PolyContextTests.swift:22-38 -- errors are raised before any device work, so this runs without a GPU
+    for c in kats["poly_context_errors"]["cases"]:
+        with pytest.raises(heamd.HeError) as err:
+            heamd.PolyContext(c["degree"], c["moduli"])
+        assert err.value.name == c["error"], c
+        with pytest.raises(heamd.HeError) as err:
+            heamd.PolyContext(c["degree"], c["moduli"], host_only=True)
+        assert err.value.name == c["error"], c
+
+
+def test_host_only_context_queries(kats):
+    for c in kats["q_remainder"]["cases"]:
+        ctx = heamd.PolyContext(c["degree"], c["moduli"], host_only=True)
+        assert ctx.q_remainder(c["dividing_by"]) == c["expected"]
+    c = kats["max_lazy_product_accumulation_count"]["cases"][1]
+    ctx = heamd.PolyContext(c["degree"], c["moduli"], host_only=True)
+    assert ctx.max_lazy_product_accumulation_count() == c["expected"]
+    assert ctx.degree == c["degree"] and ctx.moduli == c["moduli"]
+
+
+@pytest.mark.parametrize("degree,bits", [(8, [30]), (256, [60, 62]), (4096, [55, 55]), (8192, [55, 55, 55, 55])])
+def test_ntt_tables_match_oracle(oracle, degree, bits):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli, host_only=True)
+    ref = oracle.PolyContext(degree, moduli)
+    for i in range(len(moduli)):
+        a, b = ours.ntt_tables(i), ref.ntt_tables(i)
+        for key in ("root_powers", "root_factors", "inv_root_powers", "inv_root_factors"):
+            assert np.array_equal(a[key], b[key]), (i, key)
+        assert a["inverse_degree"] == b["inverse_degree"]
+        assert a["inverse_degree_root"] == b["inverse_degree_root"]
+
+
+def test_non_ntt_modulus_has_no_tables():
+    ctx = heamd.PolyContext(4, [2, 3, 5], host_only=True)
+    with pytest.raises(heamd.HeError) as err:
+        ctx.ntt_tables(1)
+    assert err.value.name == "invalidNttModulus"
+
+
+def test_compute_without_device_context_fails_loudly():
+    import ctypes
+
+    ctx = heamd.PolyContext(8, heamd.generate_primes([30], False, 8), host_only=True)
+    buf = np.zeros(8, dtype=np.uint64)
+    lib = heamd.load_library()
+    status = lib.he_ntt_forward(ctx.h, buf.ctypes.data_as(heamd.binding.U64P), 1)
+    assert heamd.binding.STATUS_NAMES[status] == "deviceError"
+    status = lib.he_ntt_forward_device(ctx.h, ctypes.c_void_p(0x1000), 1, None)
+    assert heamd.binding.STATUS_NAMES[status] == "deviceError"
+    assert b"host-only" in lib.he_last_error_message()
+    # NTT on a context with a non-NTT modulus is rejected first (validateNttModuli), as in the reference
+    bad = heamd.PolyContext(4, [2, 3, 5], host_only=True)
+    status = lib.he_ntt_forward(bad.h, buf.ctypes.data_as(heamd.binding.U64P), 0)
+    assert heamd.binding.STATUS_NAMES[status] == "invalidNttModulus"
+
+
+def test_device_context_creation_needs_a_gpu():
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(heamd.HeError) as err:
+        heamd.PolyContext(8, heamd.generate_primes([30], False, 8))
+    assert err.value.name == "deviceError"

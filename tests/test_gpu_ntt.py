@@ -1,0 +1,181 @@
+"""GPU parity tests of the NTT kernels against the CPU oracle and the reference's KATs (through the C ABI).
+
+Mirrors Tests/HomomorphicEncryptionTests/NttTests.swift.  Bit-exact: integer work, no tolerance.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import heamd
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_slab(rng, batch, moduli, degree):
+    rows = [rng.integers(0, q, size=(batch, degree), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=1))
+
+
+def test_ntt_known_answers(kats):
+    # NttTests.swift:72-191 (N = 2..32, one and two moduli) -- exercises the generic kernel
+    for c in kats["ntt"]["cases"]:
+        coeff = np.array(c["coeff"], dtype=np.uint64)
+        evals = np.array(c["eval"], dtype=np.uint64)
+        ctx = heamd.PolyContext(coeff.shape[1], c["moduli"])
+        got = heamd.to_host(ctx.forward_ntt_(heamd.to_device(coeff)))
+        assert np.array_equal(got, evals), c
+        back = heamd.to_host(ctx.inverse_ntt_(heamd.to_device(evals)))
+        assert np.array_equal(back, coeff), c
+
+
+def test_ntt_delta_and_zero(kats):
+    for c in kats["ntt"]["delta_cases"]:
+        n = c["degree"]
+        ctx = heamd.PolyContext(n, [c["modulus"]])
+        zeros = np.zeros((1, n), dtype=np.uint64)
+        one_hot = zeros.copy()
+        one_hot[0, 0] = 1
+        ones = np.ones((1, n), dtype=np.uint64)
+        assert np.array_equal(heamd.to_host(ctx.forward_ntt_(heamd.to_device(zeros))), zeros)
+        assert np.array_equal(heamd.to_host(ctx.forward_ntt_(heamd.to_device(one_hot))), ones)
+        assert np.array_equal(heamd.to_host(ctx.inverse_ntt_(heamd.to_device(ones))), one_hot)
+
+
+@pytest.mark.parametrize(
+    "degree,bits,batch",
+    [
+        (2, [30], 3),
+        (16, [55, 52, 62, 58], 5),      # TestUtils.testCoefficientModuli shape (TestUtilities.swift:295-319)
+        (256, [60, 62], 4),             # NttTests.swift:193-206
+        (1024, [27, 28, 28], 3),
+        (2048, [61, 61, 33], 2),
+        (4096, [55, 55], 6),            # BASELINE config 1 shape (tiled kernel, 16 words per lane)
+        (8192, [55, 55, 55, 55], 5),    # BASELINE config 2 shape (tiled kernel, 32 words per lane, approx quotient)
+        (8192, [62, 61, 60, 33], 3),    # a 62-bit modulus forces the exact-quotient butterflies
+        (16384, [55, 61, 45], 2),       # tiled kernel, 512 lanes
+        (32768, [55, 40], 1),           # generic global-memory kernel
+    ],
+)
+def test_ntt_matches_oracle(oracle, degree, bits, batch):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree * 31 + len(bits))
+    slab = _rand_slab(rng, batch, moduli, degree)
+    # edge values: 0 and q-1 everywhere in the first polynomial's first/last rows
+    slab[0, 0, :] = 0
+    slab[0, -1, :] = moduli[-1] - 1
+    expected_eval = ref.forward_ntt(slab)
+    got_eval = heamd.to_host(ours.forward_ntt_(heamd.to_device(slab)))
+    assert np.array_equal(got_eval, expected_eval)
+    expected_coeff = ref.inverse_ntt(slab)
+    got_coeff = heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab)))
+    assert np.array_equal(got_coeff, expected_coeff)
+
+
+@pytest.mark.parametrize("degree,bits", [(4096, [55, 55]), (8192, [55, 55, 55, 55]), (16384, [55, 55])])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_ntt_kernel_variants_agree(oracle, degree, bits, variant):
+    """exact-quotient tiled kernel (1) and generic radix-2 kernel (2) against the oracle."""
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + variant)
+    slab = _rand_slab(rng, 2, moduli, degree)
+    assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), False, variant)), ref.forward_ntt(slab))
+    assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), True, variant)), ref.inverse_ntt(slab))
+
+
+def test_ntt_multiplication_matches_schoolbook(oracle):
+    # NttTests.swift:208-250
+    degree = 128
+    p = oracle.generate_primes([30], False, degree, word_bits=32)[0]
+    ctx = heamd.PolyContext(degree, [p])
+    rng = random.Random(2)
+    x = [rng.randrange(p) for _ in range(degree)]
+    y = [rng.randrange(p) for _ in range(degree)]
+    xe = ctx.forward_ntt_(heamd.to_device(np.array([x], dtype=np.uint64)))
+    ye = ctx.forward_ntt_(heamd.to_device(np.array([y], dtype=np.uint64)))
+    prod = heamd.to_host(ctx.inverse_ntt_(ctx.mul_(xe, ye)))[0]
+    expected = [0] * degree
+    for i in range(degree):
+        acc = 0
+        for j in range(i + 1):
+            acc += x[j] * y[i - j]
+        for j in range(i + 1, degree):
+            acc -= x[j] * y[degree + i - j]
+        expected[i] = acc % p
+    assert [int(v) for v in prod] == expected
+
+
+def test_ntt_rows_seam(oracle):
+    """PolyContext.forwardNtt(dataPtr:modulus:) (PolyRq+Ntt.swift:329-347): rows of one modulus."""
+    degree = 4096
+    moduli = oracle.generate_primes([55, 50, 45], False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    rng = np.random.default_rng(5)
+    for index, q in enumerate(moduli):
+        rows = rng.integers(0, q, size=(3, degree), dtype=np.uint64)
+        single = oracle.PolyContext(degree, [q])
+        got = heamd.to_host(ours.forward_ntt_rows_(q, heamd.to_device(rows)))
+        assert np.array_equal(got, single.forward_ntt(rows.reshape(3, 1, degree)).reshape(3, degree)), index
+        back = heamd.to_host(ours.inverse_ntt_rows_(q, heamd.to_device(got)))
+        assert np.array_equal(back, rows)
+    with pytest.raises(heamd.HeError) as err:
+        ours.forward_ntt_rows_(97, heamd.to_device(np.zeros((1, degree), dtype=np.uint64)))
+    assert err.value.name == "invalidPolyContext"
+
+
+def test_ntt_host_pointer_seam(oracle):
+    degree = 1024
+    moduli = oracle.generate_primes([40, 41], False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(6)
+    slab = _rand_slab(rng, 3, moduli, degree)
+    assert np.array_equal(ours.forward_ntt_host(slab), ref.forward_ntt(slab))
+    assert np.array_equal(ours.inverse_ntt_host(slab), ref.inverse_ntt(slab))
+
+
+def test_ntt_rejects_non_ntt_moduli():
+    ctx = heamd.PolyContext(4, [2, 3, 5])
+    with pytest.raises(heamd.HeError) as err:
+        ctx.forward_ntt_(heamd.to_device(np.zeros((1, 3, 4), dtype=np.uint64)))
+    assert err.value.name == "invalidNttModulus"
+
+
+def test_ntt_full_size_properties(oracle):
+    """BASELINE config 2 at full size (N=8192, L=4, 4096 polys = 1 GiB): size-independent properties.
+
+    * inverse(forward(x)) == x for the whole slab;
+    * linearity: forward(x + y) == forward(x) + forward(y) (mod q) on the whole slab;
+    * a random sample of 8 polynomials agrees word-for-word with the oracle.
+    """
+    import torch
+
+    degree, batch = 8192, 4096
+    moduli = oracle.generate_primes([55] * 4, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x5EED)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
+    x = torch.randint(0, 1 << 62, (batch, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    original = x.clone()
+    ours.forward_ntt_(x)
+    sample = [0, 1, 17, 1000, 2047, 2048, 4000, 4095]
+    expected = ref.forward_ntt(heamd.to_host(original[sample]))
+    assert np.array_equal(heamd.to_host(x[sample]), expected)
+    assert int((x >= bound).sum()) == 0 and int((x < 0).sum()) == 0  # canonical outputs
+    # linearity on the full slab
+    y = torch.randint(0, 1 << 62, x.shape, dtype=torch.int64, device="cuda", generator=gen) % bound
+    s = y.clone()
+    ours.add_(s, original)            # s = x + y  (coefficient domain)
+    ours.forward_ntt_(s)
+    ours.forward_ntt_(y)
+    ours.add_(y, x)                   # NTT(y) + NTT(x)
+    assert torch.equal(s, y)
+    del s, y
+    ours.inverse_ntt_(x)
+    assert torch.equal(x, original)

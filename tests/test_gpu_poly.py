@@ -1,0 +1,130 @@
+"""GPU parity tests of the element-wise PolyRq kernels, divideAndRoundQLast and the lazy accumulators.
+
+Mirrors Tests/HomomorphicEncryptionTests/PolyRqTests/PolyRqTests.swift:45-176.  Bit-exact.
+"""
+import numpy as np
+import pytest
+
+import heamd
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_slab(rng, batch, moduli, degree):
+    rows = [rng.integers(0, q, size=(batch, degree), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=1))
+
+
+def test_poly_ops_known_answers(kats):
+    k = kats["poly_ops"]
+    ctx = heamd.PolyContext(k["degree"], k["moduli"])
+    x = np.array(k["x"], dtype=np.uint64)
+    dev = heamd.to_device
+    assert np.array_equal(heamd.to_host(ctx.add_(dev(x), dev(x))), np.array(k["add_x_x"], dtype=np.uint64))
+    assert np.array_equal(heamd.to_host(ctx.sub_(dev(np.zeros_like(x)), dev(x))),
+                          np.array(k["zero_minus_x"], dtype=np.uint64))
+    assert np.array_equal(heamd.to_host(ctx.neg_(dev(x))), np.array(k["neg_x"], dtype=np.uint64))
+    y = np.array(k["mul_y"], dtype=np.uint64)
+    assert np.array_equal(heamd.to_host(ctx.mul_(dev(x), dev(y))), np.array(k["mul_x_y"], dtype=np.uint64))
+    s = k["scalar"]
+    expected = np.array([[(int(v) * s) % q for v in row] for row, q in zip(k["x"], k["moduli"])], dtype=np.uint64)
+    assert np.array_equal(heamd.to_host(ctx.mul_scalar_(dev(x), [s % q for q in k["moduli"]])), expected)
+
+
+@pytest.mark.parametrize("degree,bits,batch", [(2, [20], 1), (16, [55, 52, 62, 58], 7), (4096, [55, 55], 3),
+                                               (8192, [61, 62, 33, 55, 40], 2)])
+def test_elementwise_matches_oracle(oracle, degree, bits, batch):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + batch)
+    x, y = _rand_slab(rng, batch, moduli, degree), _rand_slab(rng, batch, moduli, degree)
+    x[0, 0, :2] = 0
+    y[0, 0, :2] = [0, moduli[0] - 1]
+    x[0, -1, -2:] = moduli[-1] - 1
+    y[0, -1, -2:] = moduli[-1] - 1
+    dev = heamd.to_device
+    assert np.array_equal(heamd.to_host(ours.add_(dev(x), dev(y))), ref.add(x, y))
+    assert np.array_equal(heamd.to_host(ours.sub_(dev(x), dev(y))), ref.sub(x, y))
+    assert np.array_equal(heamd.to_host(ours.neg_(dev(x))), ref.neg(x))
+    assert np.array_equal(heamd.to_host(ours.mul_(dev(x), dev(y))), ref.mul(x, y))
+    scalars = [int(rng.integers(0, q)) for q in moduli]
+    assert np.array_equal(heamd.to_host(ours.mul_scalar_(dev(x), scalars)), ref.mul_scalar(x, scalars))
+
+
+def test_divide_and_round_q_last_known_answers(kats):
+    for c in kats["divide_and_round_q_last"]["cases"]:
+        ctx = heamd.PolyContext(c["degree"], c["moduli"])
+        x = np.array(c["x"], dtype=np.uint64)
+        got = heamd.to_host(ctx.divide_and_round_q_last(heamd.to_device(x)))
+        assert np.array_equal(got[0], np.array(c["expected"], dtype=np.uint64)), c
+        assert np.array_equal(ctx.divide_and_round_q_last_host(x)[0], np.array(c["expected"], dtype=np.uint64))
+
+
+@pytest.mark.parametrize("degree,bits,batch", [(8, [40, 45, 50], 3), (4096, [55, 55], 4), (8192, [33, 61, 62, 55], 3),
+                                               (16384, [55] * 6, 2)])
+def test_divide_and_round_q_last_matches_oracle(oracle, degree, bits, batch):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree)
+    x = _rand_slab(rng, batch, moduli, degree)
+    x[0, -1, :4] = [0, moduli[-1] - 1, moduli[-1] // 2, moduli[-1] // 2 + 1]
+    got = heamd.to_host(ours.divide_and_round_q_last(heamd.to_device(x)))
+    assert np.array_equal(got, ref.divide_and_round_q_last(x))
+
+
+def test_divide_and_round_needs_a_next_context(oracle):
+    ctx = heamd.PolyContext(8, oracle.generate_primes([30], False, 8))
+    with pytest.raises(heamd.HeError) as err:
+        ctx.divide_and_round_q_last(heamd.to_device(np.zeros((1, 1, 8), dtype=np.uint64)))
+    assert err.value.name == "invalidPolyContext"
+
+
+def test_mod_switch_full_size_property(oracle):
+    """BASELINE config 4 shape (N=16384, 6 -> 5 moduli) on 512 polynomials: a sample matches the oracle and the
+    result is canonical; scaling the input by q_last leaves x / q_last exactly (round(q_last*y / q_last) == y)."""
+    import torch
+
+    degree, batch = 16384, 512
+    moduli = oracle.generate_primes([55] * 6, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
+    x = torch.randint(0, 1 << 62, (batch, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    out = ours.divide_and_round_q_last(x)
+    assert int((out >= bound[:, :-1]).sum()) == 0 and int((out < 0).sum()) == 0
+    sample = [0, 5, 255, 511]
+    assert np.array_equal(heamd.to_host(out[sample]), ref.divide_and_round_q_last(heamd.to_host(x[sample])))
+    # x := q_last * y (in RNS: last residue 0, others y_i * q_last mod q_i)  ==>  divideAndRound(x) == y
+    y = x[:, :-1, :].contiguous()
+    scaled = torch.zeros_like(x)
+    scaled[:, :-1, :] = y
+    sub = heamd.PolyContext(degree, moduli[:-1])
+    tmp = scaled[:, :-1, :].contiguous()
+    sub.mul_scalar_(tmp, [moduli[-1] % q for q in moduli[:-1]])
+    scaled[:, :-1, :] = tmp
+    assert torch.equal(ours.divide_and_round_q_last(scaled), y)
+
+
+def test_lazy_product_accumulation(oracle):
+    degree = 4096
+    moduli = oracle.generate_primes([59, 60], False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(7)
+    import torch
+
+    acc_dev = torch.zeros((2, degree, 2), dtype=torch.int64, device="cuda")
+    acc_ref = np.zeros((2, degree, 2), dtype=np.uint64)
+    for _ in range(5):
+        x, y = _rand_slab(rng, 1, moduli, degree)[0], _rand_slab(rng, 1, moduli, degree)[0]
+        ours.adding_lazy_product_(heamd.to_device(x), heamd.to_device(y), acc_dev)
+        ref.adding_lazy_product(x, y, acc_ref)
+    assert np.array_equal(heamd.to_host(acc_dev), acc_ref)
+    assert np.array_equal(heamd.to_host(ours.reduce_accumulator(acc_dev)), ref.reduce_accumulator(acc_ref))
+    # a full-range 128-bit accumulator (wrapping arithmetic + double-word Barrett on arbitrary input)
+    wild = rng.integers(0, 1 << 63, size=(2, degree, 2), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    assert np.array_equal(heamd.to_host(ours.reduce_accumulator(heamd.to_device(wild))), ref.reduce_accumulator(wild))
