@@ -146,6 +146,126 @@ void run_probe(const char* name, int instrs_per_op) {
     }
 }
 
+// ---- butterfly probes: register-resident 5-stage passes (80 butterflies per lane per iteration), no memory ----
+#include "../swift-homomorphic-encryption_amd/csrc/device_math.hpp"
+using namespace heamd;
+
+// conditional-subtract candidates
+__device__ __forceinline__ uint64_t csub_select(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+__device__ __forceinline__ uint64_t csub_mask(uint64_t x, uint64_t m) {
+    const uint64_t d = x - m;
+    const uint64_t mask = static_cast<uint64_t>(static_cast<int64_t>(d) >> 63);
+    return d + (m & mask);
+}
+__device__ __forceinline__ uint64_t csub_min32(uint64_t x, uint64_t m) {
+    // valid when x, m < 2^63: (x - m) wraps above 2^63 iff x < m; pick the smaller by comparing high words first
+    const uint64_t d = x - m;
+    return static_cast<int64_t>(d) < 0 ? x : d;
+}
+
+enum BflyVariant { FWD_APPROX_SELECT, FWD_APPROX_MASK, FWD_APPROX_MIN, FWD_APPROX_NOCSUB, FWD_EXACT_SELECT, INV_APPROX_SELECT, INV_APPROX_MASK, INV_APPROX_NOCSUB, CSUB_ONLY_SELECT, CSUB_ONLY_MASK, CSUB_ONLY_MIN, MUL_ONLY_APPROX, MUL_ONLY_EXACT };
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) bfly_kernel(uint64_t* out, uint64_t p, uint64_t seed, int iters, long long* cycles) {
+    uint64_t v[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = (seed * (r + 1) + threadIdx.x * 977u) % p;
+    U64x2 tw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        tw[k].x = (seed * 31 + k * 1234567 + threadIdx.x) % p;
+        tw[k].y = static_cast<uint64_t>((static_cast<unsigned __int128>(tw[k].x) << 64) / p);
+    }
+    const uint64_t neg_p = opaque(0 - p);
+    const uint64_t hb = 4 * p, two_p = 2 * p;
+    const long long t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int stride = 16 >> j;
+#pragma unroll
+            for (int base = 0; base < 32; base += 2 * stride) {
+                const U64x2 w = tw[(base / (2 * stride) + j) & 3];
+#pragma unroll
+                for (int o = 0; o < stride; ++o) {
+                    uint64_t x = v[base + o], y = v[base + o + stride];
+                    if constexpr (VARIANT == FWD_APPROX_SELECT || VARIANT == FWD_APPROX_MASK || VARIANT == FWD_APPROX_MIN || VARIANT == FWD_APPROX_NOCSUB) {
+                        if constexpr (VARIANT == FWD_APPROX_SELECT) x = csub_select(x, hb);
+                        if constexpr (VARIANT == FWD_APPROX_MASK) x = csub_mask(x, hb);
+                        if constexpr (VARIANT == FWD_APPROX_MIN) x = csub_min32(x, hb);
+                        const uint64_t t = shoup_lazy4(y, w.x, w.y, neg_p);
+                        v[base + o] = x + t;
+                        v[base + o + stride] = x + hb - t;
+                    } else if constexpr (VARIANT == FWD_EXACT_SELECT) {
+                        x = csub_select(x, two_p);
+                        const uint64_t t = shoup_lazy(y, w.x, w.y, neg_p);
+                        v[base + o] = x + t;
+                        v[base + o + stride] = x + two_p - t;
+                    } else if constexpr (VARIANT == INV_APPROX_SELECT || VARIANT == INV_APPROX_MASK || VARIANT == INV_APPROX_NOCSUB) {
+                        uint64_t sum = x + y;
+                        const uint64_t diff = x + hb - y;
+                        if constexpr (VARIANT == INV_APPROX_SELECT) sum = csub_select(sum, hb);
+                        if constexpr (VARIANT == INV_APPROX_MASK) sum = csub_mask(sum, hb);
+                        v[base + o] = sum;
+                        v[base + o + stride] = shoup_lazy4(diff, w.x, w.y, neg_p);
+                    } else if constexpr (VARIANT == CSUB_ONLY_SELECT) {
+                        v[base + o] = csub_select(x + y, hb);
+                        v[base + o + stride] = csub_select(y + w.x, hb);
+                    } else if constexpr (VARIANT == CSUB_ONLY_MASK) {
+                        v[base + o] = csub_mask(x + y, hb);
+                        v[base + o + stride] = csub_mask(y + w.x, hb);
+                    } else if constexpr (VARIANT == CSUB_ONLY_MIN) {
+                        v[base + o] = csub_min32(x + y, hb);
+                        v[base + o + stride] = csub_min32(y + w.x, hb);
+                    } else if constexpr (VARIANT == MUL_ONLY_APPROX) {
+                        v[base + o] = shoup_lazy4(y, w.x, w.y, neg_p);
+                        v[base + o + stride] = x;
+                    } else if constexpr (VARIANT == MUL_ONLY_EXACT) {
+                        v[base + o] = shoup_lazy(y, w.x, w.y, neg_p);
+                        v[base + o + stride] = x;
+                    }
+                }
+            }
+        }
+    }
+    const long long t1 = wall_clock64();
+    uint64_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sum ^= v[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+template <int VARIANT>
+void run_bfly(const char* name, int ops_per_iter) {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const uint64_t p = 36028797018652673ull;
+    for (int wg_per_cu : {1, 2, 4}) {
+        const int blocks = prop.multiProcessorCount * wg_per_cu, iters = 400;
+        uint64_t* out;
+        long long* cycles;
+        CHECK(hipMalloc(&out, size_t(blocks) * 256 * 8));
+        CHECK(hipMalloc(&cycles, size_t(blocks) * 8));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        bfly_kernel<VARIANT><<<blocks, 256>>>(out, p, 12345, 10, cycles);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        bfly_kernel<VARIANT><<<blocks, 256>>>(out, p, 6789, iters, cycles);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double ops = double(blocks) * 256 * iters * ops_per_iter;  // lane-level butterflies (or csub pairs)
+        printf("%-20s waves/SIMD=%d  %.3f ms  %.3f T lane-ops/s  -> ns per wave-op per SIMD %.2f\n", name, wg_per_cu, ms,
+               ops / (ms * 1e-3) / 1e12, (ms * 1e6) / (double(iters) * ops_per_iter * wg_per_cu));
+        CHECK(hipFree(out));
+        CHECK(hipFree(cycles));
+    }
+}
+
 // ---- streaming copy: 8 B/lane vs 16 B/lane, to see what HBM rate the NTT's access widths can reach ----
 template <typename T>
 __global__ void __launch_bounds__(256) copy_kernel(const T* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -207,6 +327,19 @@ int main() {
     run_probe<MAD_U32_U24>("v_mad_u32_u24", 1);
     run_probe<MUL_HI_U32_U24>("v_mul_hi_u32_u24", 1);
     run_probe<FMA_F64>("v_fma_f64", 1);
+    run_bfly<FWD_APPROX_SELECT>("fwd_approx_select", 80);
+    run_bfly<FWD_APPROX_MASK>("fwd_approx_mask", 80);
+    run_bfly<FWD_APPROX_MIN>("fwd_approx_min", 80);
+    run_bfly<FWD_APPROX_NOCSUB>("fwd_approx_nocsub", 80);
+    run_bfly<FWD_EXACT_SELECT>("fwd_exact_select", 80);
+    run_bfly<INV_APPROX_SELECT>("inv_approx_select", 80);
+    run_bfly<INV_APPROX_MASK>("inv_approx_mask", 80);
+    run_bfly<INV_APPROX_NOCSUB>("inv_approx_nocsub", 80);
+    run_bfly<CSUB_ONLY_SELECT>("csub_only_select", 160);
+    run_bfly<CSUB_ONLY_MASK>("csub_only_mask", 160);
+    run_bfly<CSUB_ONLY_MIN>("csub_only_min", 160);
+    run_bfly<MUL_ONLY_APPROX>("mul_only_approx", 80);
+    run_bfly<MUL_ONLY_EXACT>("mul_only_exact", 80);
     run_copy();
     return 0;
 }

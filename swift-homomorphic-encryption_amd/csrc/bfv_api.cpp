@@ -1,61 +1,310 @@
-// bfv_api.cpp -- B3 entry points (Context<Bfv<UInt64>> and the HeScheme operations on the hot path).
-// PLACEHOLDER for the first GPU bring-up of the B1/B2 kernels: every entry point reports unsupportedHeOperation.
-#include "../../include/he_amd.h"
+// bfv_api.cpp -- B3 entry points: Context<Bfv<UInt64>> and the HeScheme operations on the hot path
+// (reference Sources/HomomorphicEncryption/Bfv/*.swift).  Each operation is a short pipeline of HIP kernels on the
+// caller's stream; nothing here touches the data on the host.
+#include <memory>
+#include <vector>
 
-#include "poly_context.hpp"
+#include "api_internal.hpp"
+#include "bfv_context.hpp"
+#include "kernels.hpp"
+#include "rns_kernels.hpp"
 
-struct he_bfv_context {};
+using heamd::as_stream;
+using heamd::BfvContext;
+using heamd::DeviceContext;
+using heamd::invalid_argument;
+using heamd::PolyContext;
+using heamd::RnsToolLevel;
+using heamd::Scratch;
 
-static int unsupported(const char* what) {
-    heamd::set_last_error(std::string(what) + ": not built yet");
-    return HE_ERR_UNSUPPORTED;
+struct he_bfv_context {
+    std::unique_ptr<BfvContext> impl;
+    // non-owning he_poly_context views handed out by he_bfv_*_context(), index = ciphertext moduli count
+    std::vector<std::unique_ptr<he_poly_context>> ciphertext, key_switching, qbsk;
+};
+
+namespace {
+
+int bfv_create(uint32_t degree, uint64_t t, const uint64_t* q, uint32_t count, bool host_only, he_bfv_context** out) {
+    if (out == nullptr) return invalid_argument("null out");
+    *out = nullptr;
+    std::unique_ptr<BfvContext> impl;
+    const int status = BfvContext::create(degree, t, q, count, impl, host_only);
+    if (status != HE_OK) {
+        if (status != HE_ERR_DEVICE) heamd::set_last_error(std::string("Context.init: ") + he_status_string(status));
+        return status;
+    }
+    auto* handle = new he_bfv_context{};
+    const uint32_t L = impl->top_level();
+    handle->ciphertext.resize(L + 1);
+    handle->key_switching.resize(L + 1);
+    handle->qbsk.resize(L + 1);
+    for (uint32_t k = 1; k <= L; ++k) {
+        handle->ciphertext[k].reset(new he_poly_context{const_cast<PolyContext*>(impl->ciphertext(k)), false});
+        if (impl->key_switching(k) != nullptr)
+            handle->key_switching[k].reset(new he_poly_context{const_cast<PolyContext*>(impl->key_switching(k)), false});
+        handle->qbsk[k].reset(new he_poly_context{impl->tool(k)->qbsk.get(), false});
+    }
+    handle->impl = std::move(impl);
+    *out = handle;
+    return HE_OK;
 }
+
+// Common argument checks; returns the level's tool on success.
+int check_level(const he_bfv_context* ctx, uint32_t moduli_count, const RnsToolLevel** tool) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    if (!ctx->impl->valid(moduli_count)) return invalid_argument("moduli_count out of range");
+    if (ctx->impl->host_only()) {
+        heamd::set_last_error("context was created host-only (no device tables)");
+        return HE_ERR_DEVICE;
+    }
+    const int status = ctx->impl->ciphertext(moduli_count)->check_device();
+    if (status != HE_OK) return status;
+    *tool = ctx->impl->tool(moduli_count);
+    if ((*tool)->device.L > heamd::rns_max_supported_moduli()) {
+        heamd::set_last_error("more than 8 ciphertext moduli are not supported by the BEHZ kernels yet");
+        return HE_ERR_UNSUPPORTED;
+    }
+    return HE_OK;
+}
+
+size_t qbsk_poly_words(const BfvContext& ctx, uint32_t L) { return size_t(2 * L + 1) * ctx.degree(); }
+
+// Resolves caller workspace vs stream-ordered scratch.
+int resolve_workspace(void* workspace, size_t workspace_bytes, size_t needed, Scratch& scratch, uint64_t** out) {
+    if (workspace != nullptr) {
+        if (workspace_bytes < needed) return invalid_argument("workspace too small");
+        *out = static_cast<uint64_t*>(workspace);
+        return HE_OK;
+    }
+    HEAMD_HIP_TRY(scratch.allocate(needed));
+    *out = static_cast<uint64_t*>(scratch.get());
+    return HE_OK;
+}
+
+// Eval form over [Q, Bsk] -> Coeff over Q: (x t) -> inverse NTT -> floorQBskToQ  (Bfv+Multiply.swift:31-48)
+int drop_extended_base(const RnsToolLevel& tool, uint64_t* eval_qbsk, uint64_t* out, size_t polys, hipStream_t stream) {
+    DeviceContext scaled = tool.qbsk->device_context();
+    scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
+    const uint32_t rows = tool.qbsk->moduli_count();
+    HEAMD_HIP_TRY(heamd::launch_ntt(true, eval_qbsk, scaled, 0, rows, polys * rows, stream));
+    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(eval_qbsk, out, tool.device, polys, stream));
+    return HE_OK;
+}
+
+}  // namespace
 
 extern "C" {
-int he_bfv_context_create(uint32_t, uint64_t, const uint64_t*, uint32_t, he_bfv_context** out) {
-    if (out) *out = nullptr;
-    return unsupported("he_bfv_context_create");
+
+int he_bfv_context_create(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                          uint32_t moduli_count, he_bfv_context** out) {
+    return bfv_create(degree, plaintext_modulus, coefficient_moduli, moduli_count, false, out);
 }
-int he_bfv_context_create_host_only(uint32_t, uint64_t, const uint64_t*, uint32_t, he_bfv_context** out) {
-    if (out) *out = nullptr;
-    return unsupported("he_bfv_context_create_host_only");
+int he_bfv_context_create_host_only(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                                    uint32_t moduli_count, he_bfv_context** out) {
+    return bfv_create(degree, plaintext_modulus, coefficient_moduli, moduli_count, true, out);
 }
 void he_bfv_context_destroy(he_bfv_context* ctx) { delete ctx; }
-uint32_t he_bfv_ciphertext_moduli_count(const he_bfv_context*) { return 0; }
-const he_poly_context* he_bfv_ciphertext_context(const he_bfv_context*, uint32_t) { return nullptr; }
-const he_poly_context* he_bfv_key_switching_context(const he_bfv_context*, uint32_t) { return nullptr; }
-const he_poly_context* he_bfv_qbsk_context(const he_bfv_context*, uint32_t) { return nullptr; }
-int he_bfv_copy_bsk_moduli(const he_bfv_context*, uint64_t*) { return unsupported("he_bfv_copy_bsk_moduli"); }
-int he_rns_lift_q_to_qbsk_device(const he_bfv_context*, uint32_t, const uint64_t*, uint64_t*, size_t, he_stream) {
-    return unsupported("he_rns_lift_q_to_qbsk_device");
+uint32_t he_bfv_ciphertext_moduli_count(const he_bfv_context* ctx) { return ctx ? ctx->impl->top_level() : 0; }
+const he_poly_context* he_bfv_ciphertext_context(const he_bfv_context* ctx, uint32_t k) {
+    return (ctx && ctx->impl->valid(k)) ? ctx->ciphertext[k].get() : nullptr;
 }
-int he_rns_floor_qbsk_to_q_device(const he_bfv_context*, uint32_t, const uint64_t*, uint64_t*, size_t, he_stream) {
-    return unsupported("he_rns_floor_qbsk_to_q_device");
+const he_poly_context* he_bfv_key_switching_context(const he_bfv_context* ctx, uint32_t k) {
+    return (ctx && ctx->impl->valid(k)) ? ctx->key_switching[k].get() : nullptr;
 }
-size_t he_bfv_mul_workspace_bytes(const he_bfv_context*, uint32_t, size_t) { return 0; }
-size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context*, uint32_t, size_t) { return 0; }
-size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context*, uint32_t, size_t) { return 0; }
-int he_bfv_mul_device(const he_bfv_context*, uint32_t, const uint64_t*, const uint64_t*, uint64_t*, size_t, void*,
-                      size_t, he_stream) {
-    return unsupported("he_bfv_mul_device");
+const he_poly_context* he_bfv_qbsk_context(const he_bfv_context* ctx, uint32_t k) {
+    return (ctx && ctx->impl->valid(k)) ? ctx->qbsk[k].get() : nullptr;
 }
-int he_bfv_relinearize_device(const he_bfv_context*, uint32_t, const uint64_t*, const uint64_t*, uint64_t*, size_t,
-                              void*, size_t, he_stream) {
-    return unsupported("he_bfv_relinearize_device");
+int he_bfv_copy_bsk_moduli(const he_bfv_context* ctx, uint64_t* out_bsk) {
+    if (ctx == nullptr || out_bsk == nullptr) return invalid_argument("null pointer");
+    const auto& list = ctx->impl->bsk_mtilde();
+    for (size_t i = 0; i + 1 < list.size(); ++i) out_bsk[i] = list[i];
+    return HE_OK;
 }
-int he_bfv_mod_switch_down_device(const he_bfv_context*, uint32_t, uint32_t, const uint64_t*, uint64_t*, size_t,
-                                  he_stream) {
-    return unsupported("he_bfv_mod_switch_down_device");
+
+int he_rns_lift_q_to_qbsk_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in, uint64_t* out,
+                                 size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk(in, out, tool->device, batch, as_stream(s)));
+    return HE_OK;
 }
-int he_bfv_mul_plain_device(const he_bfv_context*, uint32_t, uint32_t, uint64_t*, const uint64_t*, size_t, he_stream) {
-    return unsupported("he_bfv_mul_plain_device");
+int he_rns_floor_qbsk_to_q_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in, uint64_t* out,
+                                  size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(in, out, tool->device, batch, as_stream(s)));
+    return HE_OK;
 }
-int he_bfv_inner_product_plain_device(const he_bfv_context*, uint32_t, uint32_t, const uint64_t*, const uint64_t*,
-                                      const uint8_t*, size_t, size_t, uint64_t*, he_stream) {
-    return unsupported("he_bfv_inner_product_plain_device");
+
+// ------------------------------------------------------------------------------------------ ct x ct
+size_t he_bfv_mul_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
+    if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
+    return batch * 7 * qbsk_poly_words(*ctx->impl, moduli_count) * sizeof(uint64_t);  // 4 lifted + 3 tensor polys
 }
-int he_bfv_inner_product_device(const he_bfv_context*, uint32_t, const uint64_t*, const uint64_t*, size_t, uint64_t*,
-                                void*, size_t, he_stream) {
-    return unsupported("he_bfv_inner_product_device");
+
+int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
+                      uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = moduli_count;
+    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    Scratch scratch(stream);
+    uint64_t* ws = nullptr;
+    status = resolve_workspace(workspace, workspace_bytes, he_bfv_mul_workspace_bytes(ctx, L, batch), scratch, &ws);
+    if (status != HE_OK) return status;
+    uint64_t* lifted = ws;                   // [batch][4][2L+1][N]  (a0, a1, b0, b1)
+    uint64_t* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
+    // computeBehzPolys (Bfv+Multiply.swift:51-57): lift each of the four polynomials, then forward NTT.  Two strided
+    // launches (lhs polys -> slots 0,1; rhs polys -> slots 2,3) so that item b owns lifted[b][0..3].
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 0,
+                                                       stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext,
+                                                       2 * ext, stream));
+    const DeviceContext qbsk = tool->qbsk->device_context();
+    HEAMD_HIP_TRY(heamd::launch_ntt(false, lifted, qbsk, 0, static_cast<uint32_t>(rows), batch * 4 * rows, stream));
+    HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, qbsk, batch, stream));  // Bfv+Multiply.swift:80-82
+    return drop_extended_base(*tool, tensor, out, batch * 3, stream);
 }
+
+// ------------------------------------------------------------------------------------------ relinearize
+size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
+    if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
+    const size_t L = moduli_count, n = ctx->impl->degree();
+    return batch * (L * (L + 1) + 2 * (L + 1)) * n * sizeof(uint64_t);
 }
+
+int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct3,
+                              const uint64_t* key, uint64_t* out, size_t batch, void* workspace,
+                              size_t workspace_bytes, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (key == nullptr || !ctx->impl->has_key_switching()) {
+        heamd::set_last_error("no relinearization key");
+        return HE_ERR_MISSING_RELINEARIZATION_KEY;  // Bfv.swift:208-210
+    }
+    if (batch == 0) return HE_OK;
+    if (ct3 == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = moduli_count;
+    const size_t n = ctx->impl->degree();
+    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
+    const DeviceContext ks = ks_ctx->device_context();
+    Scratch scratch(stream);
+    uint64_t* ws = nullptr;
+    status = resolve_workspace(workspace, workspace_bytes, he_bfv_relinearize_workspace_bytes(ctx, L, batch), scratch,
+                               &ws);
+    if (status != HE_OK) return status;
+    uint64_t* spread = ws;                              // [batch][L][L+1][N]
+    uint64_t* prod = ws + batch * L * (L + 1) * n;      // [batch][2][L+1][N]
+    const size_t ct_stride = 3 * size_t(L) * n;
+    // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on poly 2 of every ciphertext
+    HEAMD_HIP_TRY(heamd::launch_key_switch_spread(ct3 + 2 * size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(false, spread, ks, 0, L + 1, batch * L * (L + 1), stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, stream));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ mod switch, ct x pt
+int he_bfv_mod_switch_down_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                  const uint64_t* in, uint64_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (moduli_count < 2) return HE_ERR_INVALID_POLY_CONTEXT;  // PolyRq.swift:366-368
+    if (batch == 0 || poly_count == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_divide_and_round_q_last(in, out, pc->device_context(), moduli_count,
+                                                        batch * poly_count, as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* pt, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0 || poly_count == 0) return HE_OK;
+    if (ct == nullptr || pt == nullptr) return invalid_argument("null operand");
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_mul_plain(ct, pt, pc->device_context(), poly_count, batch, as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                      const uint64_t* cts, const uint64_t* pts, const uint8_t* present, size_t count,
+                                      size_t columns, uint64_t* out, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (count == 0) return invalid_argument("empty ciphertext vector");  // precondition, Bfv.swift:481-483
+    if (columns == 0) return HE_OK;
+    if (cts == nullptr || pts == nullptr || out == nullptr) return invalid_argument("null operand");
+    if (poly_count < 1 || poly_count > 3) return invalid_argument("poly_count must be 1..3");
+    hipStream_t stream = as_stream(s);
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    Scratch scratch(stream);
+    const uint8_t* present_device = nullptr;
+    if (present != nullptr) {
+        HEAMD_HIP_TRY(scratch.allocate(count * columns));
+        HEAMD_HIP_TRY(hipMemcpyAsync(scratch.get(), present, count * columns, hipMemcpyHostToDevice, stream));
+        HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
+        present_device = static_cast<const uint8_t*>(scratch.get());
+    }
+    HEAMD_HIP_TRY(heamd::launch_inner_product_plain(cts, pts, present_device, out, pc->device_context(), poly_count,
+                                                    count, columns,
+                                                    pc->max_lazy_product_accumulation_count(moduli_count), stream));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ inner product ct . ct
+size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count) {
+    if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
+    return (count * 4 + 3) * qbsk_poly_words(*ctx->impl, moduli_count) * sizeof(uint64_t);
+}
+
+int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
+                                const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,
+                                size_t workspace_bytes, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (count == 0) return invalid_argument("empty ciphertext vector");
+    if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = moduli_count;
+    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    Scratch scratch(stream);
+    uint64_t* ws = nullptr;
+    status = resolve_workspace(workspace, workspace_bytes, he_bfv_inner_product_workspace_bytes(ctx, L, count), scratch,
+                               &ws);
+    if (status != HE_OK) return status;
+    uint64_t* lifted = ws;                    // [count][4][2L+1][N]
+    uint64_t* sum = ws + count * 4 * ext;     // [3][2L+1][N]
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 0,
+                                                       stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext,
+                                                       2 * ext, stream));
+    const DeviceContext qbsk = tool->qbsk->device_context();
+    HEAMD_HIP_TRY(heamd::launch_ntt(false, lifted, qbsk, 0, static_cast<uint32_t>(rows), count * 4 * rows, stream));
+    // maxProductCount = maxLazyProductAccumulationCount() / 2 because poly1 takes two products per pair (Bfv.swift:339)
+    const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
+    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate(lifted, sum, qbsk, count, max_lazy ? max_lazy : 1, stream));
+    return drop_extended_base(*tool, sum, out, 3, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+// bfv_context.cpp -- builds Context<Bfv<UInt64>>: parameter checks, the ciphertext / key-switching PolyContexts and
+// one _RnsTool per level, all host-side, then uploads the constant tables the BEHZ kernels read.
+#include "bfv_context.hpp"
+
+#include <cstring>
+
+#include "../../include/he_amd.h"
+
+namespace heamd {
+
+namespace {
+
+U64x2 shoup_pair(u64 multiplicand, u64 p) { return U64x2{multiplicand, shoup_factor(multiplicand, p)}; }
+
+DeviceModulus barrett_constants(u64 p) {
+    DeviceModulus m{};
+    m.p = p;
+    m.barrett64 = static_cast<u64>((static_cast<u128>(1) << 64) / p);
+    u128 f128;
+    if (is_power_of_two(p)) {
+        const int lg = floor_log2(p);
+        f128 = lg == 0 ? 0 : (static_cast<u128>(1) << (128 - lg));
+    } else {
+        f128 = ~static_cast<u128>(0) / p;
+    }
+    m.barrett128_lo = static_cast<u64>(f128);
+    m.barrett128_hi = static_cast<u64>(f128 >> 64);
+    const int bits = bit_length(p);
+    m.product_factor = static_cast<u64>((static_cast<u128>(1) << (bits + 62)) / p);
+    m.product_shift = static_cast<uint32_t>(bits >= 2 ? bits - 2 : 0);
+    return m;
+}
+
+// (prod of `moduli` except index `skip`) mod m      -- RnsBaseConverter.swift:41-54, CrtComposer.swift:35-40
+u64 punctured_product(const u64* moduli, size_t count, size_t skip, u64 m) {
+    u64 prod = 1 % m;
+    for (size_t k = 0; k < count; ++k)
+        if (moduli[k] != moduli[skip]) prod = mul_mod(prod, moduli[k] % m, m);
+    return prod;
+}
+
+// Bump allocator over a host staging buffer mirrored 1:1 on the device.
+class Arena {
+  public:
+    template <typename T>
+    size_t reserve(size_t count) {
+        offset_ = (offset_ + 15) & ~static_cast<size_t>(15);
+        const size_t at = offset_;
+        offset_ += count * sizeof(T);
+        bytes_.resize(offset_);
+        return at;
+    }
+    template <typename T>
+    T* at(size_t offset) {
+        return reinterpret_cast<T*>(bytes_.data() + offset);
+    }
+    size_t size() const { return bytes_.size(); }
+    const char* data() const { return bytes_.data(); }
+
+  private:
+    std::vector<char> bytes_;
+    size_t offset_ = 0;
+};
+
+}  // namespace
+
+BfvContext::~BfvContext() {
+    for (auto& level : tools_)
+        if (level.device_block != nullptr) (void)hipFree(level.device_block);
+}
+
+int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std::unique_ptr<BfvContext>& out,
+                       bool host_only) {
+    out.reset();
+    if (count > 0 && q == nullptr) return HE_ERR_INVALID_ARGUMENT;
+    // EncryptionParameters.init at securityLevel .unchecked (EncryptionParameters.swift:136-166)
+    if (!is_power_of_two(degree)) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
+    if (count == 0 || count > 32) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
+    for (uint32_t i = 0; i < count; ++i)
+        if (!(q[i] > t) || !is_ntt_modulus(q[i], degree)) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
+    for (uint32_t i = 0; i <= count; ++i) {
+        const u64 m = i < count ? q[i] : t;
+        if (!is_prime(m) || m < 1 || m > kMaxModulus || m == kGamma || m == kMTilde)
+            return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
+    }
+    // Context.init (Context.swift:94-143)
+    {   // secretKeyContext: validates the full chain (uniqueness etc.)
+        std::unique_ptr<PolyContext> secret_key_context;
+        const int status = PolyContext::create(degree, q, count, secret_key_context, true);
+        if (status != HE_OK) return status;
+    }
+    std::unique_ptr<BfvContext> ctx(new BfvContext());
+    ctx->degree_ = degree;
+    ctx->t_ = t;
+    ctx->host_only_ = host_only;
+    ctx->coefficient_moduli_.assign(q, q + count);
+    ctx->has_ks_ = count > 1;
+    const uint32_t L = count > 1 ? count - 1 : count;  // Context.swift:102-107
+    ctx->L_ = L;
+    ctx->ciphertext_.resize(L + 1);
+    ctx->key_switching_.resize(L + 1);
+    ctx->tools_.resize(L + 1);
+    for (uint32_t k = 1; k <= L; ++k) {
+        const int status = PolyContext::create(degree, q, k, ctx->ciphertext_[k], host_only);
+        if (status != HE_OK) return status;
+    }
+    if (ctx->has_ks_) {
+        std::vector<u64> moduli(L + 1);
+        for (uint32_t k = 1; k <= L; ++k) {  // Context.swift:114-127
+            std::memcpy(moduli.data(), q, k * sizeof(u64));
+            moduli[k] = q[count - 1];
+            const int status = PolyContext::create(degree, moduli.data(), k + 1, ctx->key_switching_[k], host_only);
+            if (status != HE_OK) return status;
+            if (!(static_cast<u64>(k + 1) < ctx->key_switching_[k]->max_lazy_product_accumulation_count(k + 1)))
+                return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;  // Context.swift:122-124
+        }
+    }
+    {   // plaintextContext (Context.swift:128-130)
+        std::unique_ptr<PolyContext> plaintext_context;
+        const int status = PolyContext::create(degree, &t, 1, plaintext_context, true);
+        if (status != HE_OK) return status;
+    }
+    {   // RnsToolContext.init (RnsTool.swift:28-45): L+1 ascending NTT-friendly 61-bit primes, then mTilde
+        std::vector<int> bits(L + 1, 61);
+        if (!generate_primes(bits, true, degree, ctx->bsk_mtilde_)) return HE_ERR_NOT_ENOUGH_PRIMES;
+        ctx->bsk_mtilde_.push_back(kMTilde);
+        std::unique_ptr<PolyContext> check;
+        const int status = PolyContext::create(degree, ctx->bsk_mtilde_.data(),
+                                               static_cast<uint32_t>(ctx->bsk_mtilde_.size()), check, true);
+        if (status != HE_OK) return status;
+        // tGammaContext = [t, gamma] (RnsTool.swift:62-64) only needs to be constructible here
+        const u64 t_gamma[2] = {t, kGamma};
+        const int tg = PolyContext::create(degree, t_gamma, 2, check, true);
+        if (tg != HE_OK) return tg;
+    }
+    for (uint32_t k = L; k >= 1; --k) {  // Context.swift:136-141
+        const int status = ctx->build_tool(k);
+        if (status != HE_OK) return status;
+    }
+    out = std::move(ctx);
+    return HE_OK;
+}
+
+// _RnsTool.init(from:to:rnsToolContext:) (RnsTool.swift:132-251) for the level with k ciphertext moduli.
+int BfvContext::build_tool(uint32_t k) {
+    RnsToolLevel& level = tools_[k];
+    const u64* q = coefficient_moduli_.data();
+    const size_t L = k;
+    if (L + 2 > bsk_mtilde_.size()) return HE_ERR_INVALID_POLY_CONTEXT;
+    level.ext_moduli.assign(bsk_mtilde_.begin(), bsk_mtilde_.begin() + L + 2);  // getContext(moduliCount: L+2), :185-186
+    const u64* ext = level.ext_moduli.data();
+    const u64* bsk = ext;  // L+1 entries; B = bsk[0..L), m_sk = bsk[L]
+    const u64 m_sk = bsk[L];
+
+    // qBskContext (RnsTool.swift:234-239): validates the appended moduli and uniqueness
+    std::vector<u64> qbsk(q, q + L);
+    qbsk.insert(qbsk.end(), bsk, bsk + L + 1);
+    for (uint32_t prefix = static_cast<uint32_t>(L) + 1; prefix <= 2 * L + 1; ++prefix) {
+        const int status = validate_poly_context_prefix(degree_, qbsk.data(), prefix, true);
+        if (status != HE_OK) return status;
+    }
+    {
+        const int status = PolyContext::create(degree_, qbsk.data(), static_cast<uint32_t>(qbsk.size()), level.qbsk,
+                                               host_only_);
+        if (status != HE_OK) return status;
+    }
+
+    Arena arena;
+    const size_t o_q_moduli = arena.reserve<DeviceModulus>(L);
+    const size_t o_ext_moduli = arena.reserve<DeviceModulus>(L + 2);
+    const size_t o_lift_scale = arena.reserve<U64x2>(L);
+    const size_t o_inv_punct_q = arena.reserve<U64x2>(L);
+    const size_t o_q_to_ext = arena.reserve<u64>((L + 2) * L);
+    const size_t o_q_mod_bsk = arena.reserve<U64x2>(L + 1);
+    const size_t o_inv_mtilde = arena.reserve<U64x2>(L + 1);
+    const size_t o_inv_q_bsk = arena.reserve<U64x2>(L + 1);
+    const size_t o_inv_punct_b = arena.reserve<U64x2>(L);
+    const size_t o_b_to_msk = arena.reserve<u64>(L);
+    const size_t o_b_to_q = arena.reserve<u64>(L * L);
+    const size_t o_b_mod_q = arena.reserve<U64x2>(L);
+    const size_t o_neg_b_mod_q = arena.reserve<U64x2>(L);
+    const size_t o_scaled = arena.reserve<DeviceModulus>(2 * L + 1);
+
+    for (size_t i = 0; i < L; ++i) arena.at<DeviceModulus>(o_q_moduli)[i] = barrett_constants(q[i]);
+    for (size_t j = 0; j < L + 2; ++j) arena.at<DeviceModulus>(o_ext_moduli)[j] = barrett_constants(ext[j]);
+    for (size_t i = 0; i < L; ++i) {
+        u64 inverse = 0;
+        if (!inverse_mod(punctured_product(q, L, i, q[i]), q[i], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_inv_punct_q)[i] = shoup_pair(inverse, q[i]);
+        // poly * mTildeModQ then convertApproximateProducts (RnsTool.swift:313-316, RnsBaseConverter.swift:97-106):
+        // two exact multiplications mod q_i == one by the product of the constants
+        arena.at<U64x2>(o_lift_scale)[i] = shoup_pair(mul_mod(kMTilde % q[i], inverse, q[i]), q[i]);
+        for (size_t j = 0; j < L + 2; ++j)
+            arena.at<u64>(o_q_to_ext)[j * L + i] = punctured_product(q, L, i, ext[j]);
+    }
+    for (size_t j = 0; j <= L; ++j) {
+        const u64 q_mod = product_mod(q, L, bsk[j]);
+        arena.at<U64x2>(o_q_mod_bsk)[j] = shoup_pair(q_mod, bsk[j]);
+        u64 inverse = 0;
+        if (!inverse_mod(kMTilde % bsk[j], bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_inv_mtilde)[j] = shoup_pair(inverse, bsk[j]);
+        if (!inverse_mod(q_mod, bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_inv_q_bsk)[j] = shoup_pair(inverse, bsk[j]);
+    }
+    for (size_t i = 0; i < L; ++i) {
+        u64 inverse = 0;
+        if (!inverse_mod(punctured_product(bsk, L, i, bsk[i]), bsk[i], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_inv_punct_b)[i] = shoup_pair(inverse, bsk[i]);
+        arena.at<u64>(o_b_to_msk)[i] = punctured_product(bsk, L, i, m_sk);
+        for (size_t row = 0; row < L; ++row)
+            arena.at<u64>(o_b_to_q)[row * L + i] = punctured_product(bsk, L, i, q[row]);
+        const u64 b_mod_qi = product_mod(bsk, L, q[i]);
+        arena.at<U64x2>(o_b_mod_q)[i] = shoup_pair(b_mod_qi, q[i]);
+        arena.at<U64x2>(o_neg_b_mod_q)[i] = shoup_pair(neg_mod(b_mod_qi, q[i]), q[i]);
+    }
+    U64x2 neg_inv_q_mod_mtilde{}, inv_b_mod_msk{};
+    {
+        u64 inverse = 0;
+        if (!inverse_mod(product_mod(q, L, kMTilde), kMTilde, inverse)) return HE_ERR_NOT_INVERTIBLE;
+        neg_inv_q_mod_mtilde = shoup_pair(neg_mod(inverse, kMTilde), kMTilde);
+        if (!inverse_mod(product_mod(bsk, L, m_sk), m_sk, inverse)) return HE_ERR_NOT_INVERTIBLE;
+        inv_b_mod_msk = shoup_pair(inverse, m_sk);
+    }
+    // dropExtendedBase multiplies by t before the inverse NTT (Bfv+Multiply.swift:41-44); both are exact maps mod
+    // each modulus, so t is folded into the inverse transform's final N^-1 constants instead.
+    for (size_t r = 0; r < 2 * L + 1; ++r) {
+        DeviceModulus m = level.qbsk->host_constants()[r];
+        const u64 p = m.p;
+        m.inv_degree = mul_mod(m.inv_degree, t_ % p, p);
+        m.inv_degree_shoup = shoup_factor(m.inv_degree, p);
+        m.inv_degree_root = mul_mod(m.inv_degree_root, t_ % p, p);
+        m.inv_degree_root_shoup = shoup_factor(m.inv_degree_root, p);
+        arena.at<DeviceModulus>(o_scaled)[r] = m;
+    }
+
+    RnsToolDevice& d = level.device;
+    d.L = static_cast<uint32_t>(L);
+    d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
+    d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;
+    d.inv_b_mod_msk = inv_b_mod_msk;
+    if (host_only_) return HE_OK;
+
+    HEAMD_HIP_TRY(hipMalloc(&level.device_block, arena.size()));
+    HEAMD_HIP_TRY(hipMemcpy(level.device_block, arena.data(), arena.size(), hipMemcpyHostToDevice));
+    const char* base = static_cast<const char*>(level.device_block);
+    d.q_moduli = reinterpret_cast<const DeviceModulus*>(base + o_q_moduli);
+    d.ext_moduli = reinterpret_cast<const DeviceModulus*>(base + o_ext_moduli);
+    d.lift_scale = reinterpret_cast<const U64x2*>(base + o_lift_scale);
+    d.inv_punctured_q = reinterpret_cast<const U64x2*>(base + o_inv_punct_q);
+    d.q_to_ext = reinterpret_cast<const uint64_t*>(base + o_q_to_ext);
+    d.q_mod_bsk = reinterpret_cast<const U64x2*>(base + o_q_mod_bsk);
+    d.inv_mtilde_mod_bsk = reinterpret_cast<const U64x2*>(base + o_inv_mtilde);
+    d.inv_q_mod_bsk = reinterpret_cast<const U64x2*>(base + o_inv_q_bsk);
+    d.inv_punctured_b = reinterpret_cast<const U64x2*>(base + o_inv_punct_b);
+    d.b_to_msk = reinterpret_cast<const uint64_t*>(base + o_b_to_msk);
+    d.b_to_q = reinterpret_cast<const uint64_t*>(base + o_b_to_q);
+    d.b_mod_q = reinterpret_cast<const U64x2*>(base + o_b_mod_q);
+    d.neg_b_mod_q = reinterpret_cast<const U64x2*>(base + o_neg_b_mod_q);
+    level.qbsk_moduli_scaled_by_t = reinterpret_cast<const DeviceModulus*>(base + o_scaled);
+    return HE_OK;
+}
+
+}  // namespace heamd

@@ -1,0 +1,75 @@
+// bfv_context.hpp -- host-side mirror of Context<Bfv<UInt64>> (reference Sources/HomomorphicEncryption/
+// Context.swift:94-159) with one _RnsTool per ciphertext level (RnsTool.swift:74-251), and their device images.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "device_context.hpp"
+#include "host_math.hpp"
+#include "poly_context.hpp"
+
+namespace heamd {
+
+// Device image of one _RnsTool (input base Q = q_0..q_{L-1}, extended base [Bsk_0..Bsk_L, mTilde]).
+// All pointers index one device block owned by the BfvContext.  (w, w') pairs are Shoup constants.
+struct RnsToolDevice {
+    uint32_t L;                        // input moduli
+    uint32_t log_degree;
+    const DeviceModulus* q_moduli;     // [L]     Barrett constants of q_i
+    const DeviceModulus* ext_moduli;   // [L+2]   Barrett constants of Bsk_0..Bsk_L and the (L+2)'th extended modulus
+    const U64x2* lift_scale;           // [L]     (mTilde * (Q/q_i)^-1) mod q_i           RnsTool.swift:313-316
+    const U64x2* inv_punctured_q;      // [L]     (Q/q_i)^-1 mod q_i                      CrtComposer.swift:32-50
+    const uint64_t* q_to_ext;          // [L+2][L] (Q/q_i) mod ext_j                      RnsBaseConverter.swift:41-54
+    const U64x2* q_mod_bsk;            // [L+1]   Q mod Bsk_j                             RnsTool.swift:224-227
+    const U64x2* inv_mtilde_mod_bsk;   // [L+1]   mTilde^-1 mod Bsk_j                     RnsTool.swift:228-231
+    const U64x2* inv_q_mod_bsk;        // [L+1]   Q^-1 mod Bsk_j                          RnsTool.swift:241-245
+    const U64x2* inv_punctured_b;      // [L]     (B/Bsk_i)^-1 mod Bsk_i
+    const uint64_t* b_to_msk;          // [L]     (B/Bsk_i) mod m_sk
+    const uint64_t* b_to_q;            // [L][L]  (B/Bsk_k) mod q_i  (row i, column k)
+    const U64x2* b_mod_q;              // [L]     B mod q_i                               RnsTool.swift:211-216
+    const U64x2* neg_b_mod_q;          // [L]     -B mod q_i                              RnsTool.swift:217-223
+    U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169
+    U64x2 inv_b_mod_msk;               //         B^-1 mod m_sk                           RnsTool.swift:246-250
+};
+
+struct RnsToolLevel {
+    std::vector<u64> ext_moduli;              // L+2 entries
+    std::unique_ptr<PolyContext> qbsk;        // [q_0..q_{L-1}, Bsk_0..Bsk_L]  (RnsTool.swift:235-239)
+    RnsToolDevice device{};
+    const DeviceModulus* qbsk_moduli_scaled_by_t = nullptr;  // qbsk constants with N^-1 replaced by t * N^-1
+    void* device_block = nullptr;
+};
+
+class BfvContext {
+  public:
+    static int create(uint32_t degree, u64 plaintext_modulus, const u64* coefficient_moduli, uint32_t count,
+                      std::unique_ptr<BfvContext>& out, bool host_only);
+    ~BfvContext();
+
+    uint32_t degree() const { return degree_; }
+    u64 plaintext_modulus() const { return t_; }
+    uint32_t top_level() const { return L_; }
+    bool has_key_switching() const { return has_ks_; }
+    const std::vector<u64>& bsk_mtilde() const { return bsk_mtilde_; }
+    // k = number of ciphertext moduli, 1..L
+    const PolyContext* ciphertext(uint32_t k) const { return valid(k) ? ciphertext_[k].get() : nullptr; }
+    const PolyContext* key_switching(uint32_t k) const { return valid(k) ? key_switching_[k].get() : nullptr; }
+    const RnsToolLevel* tool(uint32_t k) const { return valid(k) ? &tools_[k] : nullptr; }
+    bool valid(uint32_t k) const { return k >= 1 && k <= L_; }
+    bool host_only() const { return host_only_; }
+
+  private:
+    BfvContext() = default;
+    int build_tool(uint32_t k);
+
+    uint32_t degree_ = 0, L_ = 0;
+    u64 t_ = 0;
+    bool has_ks_ = false, host_only_ = false;
+    std::vector<u64> coefficient_moduli_;
+    std::vector<u64> bsk_mtilde_;  // Bsk_0..Bsk_L, mTilde  (RnsTool.swift:28-37)
+    std::vector<std::unique_ptr<PolyContext>> ciphertext_, key_switching_;
+    std::vector<RnsToolLevel> tools_;
+};
+
+}  // namespace heamd

@@ -7,38 +7,16 @@
 #include <string>
 #include <vector>
 
+#include "api_internal.hpp"
 #include "kernels.hpp"
 #include "poly_context.hpp"
 
+using heamd::as_stream;
+using heamd::invalid_argument;
 using heamd::PolyContext;
-
-struct he_poly_context {
-    std::unique_ptr<PolyContext> impl;
-};
+using heamd::Scratch;
 
 namespace {
-
-inline hipStream_t as_stream(he_stream s) { return static_cast<hipStream_t>(s); }
-
-int invalid_argument(const char* what) {
-    heamd::set_last_error(std::string("invalid argument: ") + what);
-    return HE_ERR_INVALID_ARGUMENT;
-}
-
-// Stream-ordered scratch buffer that frees itself on the same stream.
-class Scratch {
-  public:
-    Scratch(hipStream_t stream) : stream_(stream) {}
-    ~Scratch() {
-        if (ptr_ != nullptr) (void)hipFreeAsync(ptr_, stream_);
-    }
-    hipError_t allocate(size_t bytes) { return hipMallocAsync(&ptr_, bytes ? bytes : 1, stream_); }
-    void* get() const { return ptr_; }
-
-  private:
-    hipStream_t stream_;
-    void* ptr_ = nullptr;
-};
 
 // Runs `body(device_ptr, stream)` on a device copy of a host slab and copies the result back (blocking).
 template <typename Body>
@@ -182,7 +160,7 @@ static int poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t
         if (status != HE_ERR_DEVICE) heamd::set_last_error(std::string("PolyContext.init: ") + he_status_string(status));
         return status;
     }
-    *out = new he_poly_context{std::move(impl)};
+    *out = new he_poly_context{impl.release(), true};
     return HE_OK;
 }
 int he_poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count, he_poly_context** out) {

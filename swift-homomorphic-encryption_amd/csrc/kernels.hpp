@@ -9,7 +9,7 @@
 
 namespace heamd {
 
-enum { kNttVariantAuto = 0, kNttVariantExact = 1, kNttVariantGeneric = 2 };
+enum { kNttVariantAuto = 0, kNttVariantExact = 1, kNttVariantGeneric = 2, kNttVariantWide = 3 };
 
 // NTT of `rows` contiguous length-N rows.  Row r uses modulus index mod_base + (r % mod_period).
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,

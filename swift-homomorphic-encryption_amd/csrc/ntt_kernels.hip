@@ -185,7 +185,7 @@ struct Schedule {
 };
 
 template <int LOGN, int LOGT, bool APPROX>
-__global__ void __launch_bounds__(1 << LOGT)
+__global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(1 << LOGT)
 }
 
 template <int LOGN, int LOGT, bool APPROX>
-__global__ void __launch_bounds__(1 << LOGT)
+__global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
@@ -413,6 +413,14 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         return hipSuccess;
     }
     const bool approx = ctx.approx_ok != 0 && force_variant != kNttVariantExact && force_variant != kNttVariantGeneric;
+    if (force_variant == kNttVariantWide) {
+        switch (ctx.log_degree) {
+            case 12: return launch_tiled<12, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+            case 13: return launch_tiled<13, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+            case 14: return launch_tiled<14, 10>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+            default: break;
+        }
+    }
     if (force_variant != kNttVariantGeneric) {
         switch (ctx.log_degree) {
             case 12: return launch_tiled<12, 8>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);

@@ -1,0 +1,371 @@
+// rns_kernels.hip -- BEHZ base conversions, the ct x ct tensor product and hybrid key switching for gfx950.
+//
+// Every kernel here is per-coefficient (or per-word) independent work over [.., rows, N] slabs: one lane per
+// coefficient column, consecutive lanes on consecutive columns, each row access a coalesced 512-byte wave load.
+// Reference semantics (Sources/HomomorphicEncryption/):
+//   _RnsTool.liftQToQBsk            RnsTool.swift:313-368   (+ _RnsBaseConverter, RnsBaseConverter.swift:97-143)
+//   _RnsTool.floorQBskToQ           RnsTool.swift:378-456
+//   Bfv.multiplyWithoutScaling      Bfv/Bfv+Multiply.swift:63-85 (tensor product in Eval form over [Q, Bsk])
+//   Bfv._computeKeySwitchingUpdate  Bfv/Bfv+Keys.swift:123-208
+// All base-conversion sums are exact wrapping UInt128 sums followed by the double-word Barrett reduction, exactly as
+// the reference does, so the overflow term "a" of the fast base conversion is reproduced bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "bfv_context.hpp"
+#include "device_math.hpp"
+#include "rns_kernels.hpp"
+
+namespace heamd {
+
+namespace {
+
+constexpr unsigned kThreads = 256;
+constexpr int kMaxL = 8;  // compile-time specialisations for L = 1..kMaxL
+
+inline unsigned grid_for(size_t work_items) {
+    const size_t blocks = (work_items + kThreads - 1) / kThreads;
+    const size_t cap = 256 * 16;
+    return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+__device__ __forceinline__ uint64_t reduce128(U128 x, const DeviceModulus& m) {
+    return barrett_reduce128(x, m.p, m.barrett128_lo, m.barrett128_hi);
+}
+__device__ __forceinline__ uint64_t shoup_mul_pair(uint64_t x, U64x2 c, uint64_t p) { return shoup_mul(x, c.x, c.y, p); }
+
+// ---- liftQToQBsk: in [polys][L][N] -> out [polys][2L+1][N] -------------------------------------------------------
+// Polynomial p = item * polys_per_item + c is read at in + item * in_item_stride + c * L * N and written at
+// out + item * out_item_stride + c * (2L+1) * N (strides in words), so one launch can fill a slot range of a larger
+// per-item record.
+struct LiftLayout {
+    size_t polys_per_item, in_item_stride, out_item_stride;
+};
+
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+    lift_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool, size_t polys,
+                const LiftLayout layout) {
+    const uint32_t logn = tool.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = polys << logn;
+    constexpr uint64_t kMTildeValue = uint64_t(1) << 32;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t poly = idx >> logn, k = idx & (n - 1);
+        const size_t item = poly / layout.polys_per_item, c = poly - item * layout.polys_per_item;
+        const uint64_t* src = in + item * layout.in_item_stride + c * L * n + k;
+        uint64_t* dst = out + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
+        uint64_t y[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const uint64_t x = src[i * n];
+            dst[i * n] = x;  // rows [0, L): the input itself (RnsTool.swift:329-330)
+            y[i] = shoup_mul_pair(x, tool.lift_scale[i], tool.q_moduli[i].p);
+        }
+        // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
+        U128 acc{0, 0};
+#pragma unroll
+        for (int i = 0; i < L; ++i) mac128(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
+        uint64_t r = reduce128(acc, tool.ext_moduli[L + 1]);
+        r = shoup_mul_pair(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
+        const bool below = r < (kMTildeValue >> 1);
+#pragma unroll
+        for (int j = 0; j <= L; ++j) {
+            const DeviceModulus m = tool.ext_moduli[j];
+            U128 sum{0, 0};
+#pragma unroll
+            for (int i = 0; i < L; ++i) mac128(sum, y[i], tool.q_to_ext[j * L + i]);
+            uint64_t v = reduce128(sum, m);
+            const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
+            const U64x2 q_mod = tool.q_mod_bsk[j];
+            v += shoup_lazy(centered, q_mod.x, q_mod.y, 0 - m.p);           // RnsTool.swift:363
+            dst[(L + j) * n] = shoup_mul_pair(v, tool.inv_mtilde_mod_bsk[j], m.p);  // RnsTool.swift:364
+        }
+    }
+}
+
+// ---- floorQBskToQ: in [polys][2L+1][N] -> out [polys][L][N] ------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+    floor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool, size_t polys) {
+    const uint32_t logn = tool.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = polys << logn;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t poly = idx >> logn, k = idx & (n - 1);
+        const uint64_t* src = in + poly * (2 * L + 1) * n + k;
+        uint64_t* dst = out + poly * L * n + k;
+        // approximateFloor (RnsTool.swift:378-398)
+        uint64_t y[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) y[i] = shoup_mul_pair(src[i * n], tool.inv_punctured_q[i], tool.q_moduli[i].p);
+        uint64_t f[L + 1];
+#pragma unroll
+        for (int j = 0; j <= L; ++j) {
+            const DeviceModulus m = tool.ext_moduli[j];
+            U128 sum{0, 0};
+#pragma unroll
+            for (int i = 0; i < L; ++i) mac128(sum, y[i], tool.q_to_ext[j * L + i]);
+            const uint64_t converted = reduce128(sum, m);
+            f[j] = shoup_mul_pair(src[(L + j) * n] + m.p - converted, tool.inv_q_mod_bsk[j], m.p);
+        }
+        // convertApproximateBskToQ (RnsTool.swift:402-450)
+        const DeviceModulus msk = tool.ext_moduli[L];
+        uint64_t z[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) z[i] = shoup_mul_pair(f[i], tool.inv_punctured_b[i], tool.ext_moduli[i].p);
+        U128 alpha_sum{0, 0};
+#pragma unroll
+        for (int i = 0; i < L; ++i) mac128(alpha_sum, z[i], tool.b_to_msk[i]);
+        uint64_t alpha = reduce128(alpha_sum, msk);
+        alpha = shoup_mul_pair(alpha + msk.p - f[L], tool.inv_b_mod_msk, msk.p);
+        const bool exceeds = alpha > (msk.p >> 1);
+#pragma unroll
+        for (int row = 0; row < L; ++row) {
+            const DeviceModulus m = tool.q_moduli[row];
+            U128 sum{0, 0};
+#pragma unroll
+            for (int i = 0; i < L; ++i) mac128(sum, z[i], tool.b_to_q[row * L + i]);
+            const uint64_t converted = reduce128(sum, m);
+            const uint64_t adjust = exceeds ? shoup_mul_pair(msk.p - alpha, tool.b_mod_q[row], m.p)
+                                            : shoup_mul_pair(alpha, tool.neg_b_mod_q[row], m.p);
+            dst[row * n] = add_mod(converted, adjust, m.p);
+        }
+    }
+}
+
+// ---- tensor product: (a0, a1) x (b0, b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1), word-wise in Eval form ----------------
+// in: [items][4][rows][N] (a0, a1, b0, b1); out: [items][3][rows][N]
+__global__ void __launch_bounds__(kThreads)
+    tensor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx, size_t items) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t poly_words = size_t(ctx.moduli_count) << logn;
+    const size_t total = items * poly_words;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t item = idx / poly_words, w = idx - item * poly_words;
+        const DeviceModulus m = ctx.moduli[w >> logn];
+        const uint64_t* src = in + item * 4 * poly_words + w;
+        const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
+        const int shift = static_cast<int>(m.product_shift);
+        uint64_t* dst = out + item * 3 * poly_words + w;
+        dst[0] = barrett_mul(a0, b0, m.p, m.product_factor, shift);
+        dst[poly_words] = add_mod(barrett_mul(a0, b1, m.p, m.product_factor, shift),
+                                  barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p);
+        dst[2 * poly_words] = barrett_mul(a1, b1, m.p, m.product_factor, shift);
+    }
+}
+
+// ---- lazy tensor accumulation for Bfv.innerProduct(ct, ct) (Bfv.swift:315-361) -----------------------------------
+// in: [count][4][rows][N]; out: [3][rows][N] = reduce(sum_k tensor_k)
+__global__ void __launch_bounds__(kThreads)
+    tensor_accumulate_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
+                             size_t count, uint64_t max_lazy) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t poly_words = size_t(ctx.moduli_count) << logn;
+    for (size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x; w < poly_words; w += size_t(gridDim.x) * kThreads) {
+        const DeviceModulus m = ctx.moduli[w >> logn];
+        U128 d0{0, 0}, d1{0, 0}, d2{0, 0};
+        uint64_t since = 0;
+        for (size_t item = 0; item < count; ++item) {
+            const uint64_t* src = in + item * 4 * poly_words + w;
+            const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
+            mac128(d0, a0, b0);
+            mac128(d1, a0, b1);
+            mac128(d1, a1, b0);
+            mac128(d2, a1, b1);
+            if (++since >= max_lazy) {  // reduceInPlace cadence, Bfv.swift:349-353
+                since = 0;
+                d0 = U128{reduce128(d0, m), 0};
+                d1 = U128{reduce128(d1, m), 0};
+                d2 = U128{reduce128(d2, m), 0};
+            }
+        }
+        out[w] = reduce128(d0, m);
+        out[poly_words + w] = reduce128(d1, m);
+        out[2 * poly_words + w] = reduce128(d2, m);
+    }
+}
+
+// ---- key switching, step 1: decompose-and-spread (Bfv+Keys.swift:165-172) ----------------------------------------
+// target: row j of polynomial `poly` at  target_base + poly * target_stride + j * N   (Coeff, mod q_j)
+// out: [polys][L][L+1][N]: word (poly, j, r, k) = target[j][k] mod ks_modulus[r]  (reduced only when q_j > modulus r)
+__global__ void __launch_bounds__(kThreads)
+    key_switch_spread_kernel(const uint64_t* __restrict__ target_base, size_t target_stride,
+                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys) {
+    const uint32_t logn = ks.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = (polys * L) << logn;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t k = idx & (n - 1);
+        const size_t pj = idx >> logn;
+        const size_t poly = pj / L, j = pj - poly * L;
+        const uint64_t x = target_base[poly * target_stride + j * n + k];
+        const uint64_t qj = ks.moduli[j].p;
+        uint64_t* dst = out + (pj * (L + 1)) * n + k;
+        for (uint32_t r = 0; r <= L; ++r) {
+            const DeviceModulus m = ks.moduli[r];
+            dst[r * n] = qj > m.p ? barrett_reduce64(x, m.p, m.barrett64) : x;
+        }
+    }
+}
+
+// ---- key switching, step 2: lazy inner product with the key (Bfv+Keys.swift:180-202) ------------------------------
+// spread: [polys][L][L+1][N] (Eval); key: [L_top][2][L_top+1][N]; out: [polys][2][L+1][N]
+//   out[poly][c][r][k] = ( sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] ) mod ks_modulus[r]
+__global__ void __launch_bounds__(kThreads)
+    key_switch_mac_kernel(const uint64_t* __restrict__ spread, const uint64_t* __restrict__ key,
+                          uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, uint32_t top_rows,
+                          size_t polys) {
+    const uint32_t logn = ks.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = (polys * (L + 1)) << logn;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t k = idx & (n - 1);
+        const size_t pr = idx >> logn;
+        const size_t poly = pr / (L + 1);
+        const uint32_t r = static_cast<uint32_t>(pr - poly * (L + 1));
+        const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
+        const DeviceModulus m = ks.moduli[r];
+        U128 acc0{0, 0}, acc1{0, 0};
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint64_t x = spread[((poly * L + j) * (L + 1) + r) * n + k];
+            const uint64_t* key_j = key + (size_t(j) * 2 * top_rows + key_row) * n + k;
+            mac128(acc0, x, key_j[0]);
+            mac128(acc1, x, key_j[size_t(top_rows) * n]);
+        }
+        uint64_t* dst = out + (poly * 2 * (L + 1) + r) * n + k;
+        dst[0] = reduce128(acc0, m);
+        dst[size_t(L + 1) * n] = reduce128(acc1, m);
+    }
+}
+
+// ---- key switching, step 4: drop the special modulus and add into the ciphertext (Bfv.swift:216-217) --------------
+// prod: [polys][2][L+1][N] Coeff over (q_0..q_{L-1}, q_ks); ct: poly c of item at ct_base + item*ct_stride + c*L*N;
+// out: [polys][2][L][N] = ct + divideAndRoundQLast(prod)
+__global__ void __launch_bounds__(kThreads)
+    key_switch_finish_kernel(const uint64_t* __restrict__ prod, const uint64_t* __restrict__ ct_base, size_t ct_stride,
+                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys) {
+    const uint32_t logn = ks.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = (polys * 2) << logn;
+    const uint64_t q_last = ks.moduli[L].p, q_last_div2 = q_last >> 1;
+    const U64x2* __restrict__ inverse_q_last = ks.inverse_q_last + size_t(L) * ks.moduli_stride;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+        const size_t k = idx & (n - 1);
+        const size_t pc = idx >> logn;  // poly * 2 + c
+        const size_t poly = pc >> 1, c = pc & 1;
+        const uint64_t* src = prod + pc * (L + 1) * n + k;
+        const uint64_t* ct = ct_base + poly * ct_stride + c * L * n + k;
+        uint64_t* dst = out + pc * L * n + k;
+        const uint64_t r = add_mod(src[size_t(L) * n], q_last_div2, q_last);
+        for (uint32_t row = 0; row < L; ++row) {
+            const DeviceModulus m = ks.moduli[row];
+            const U64x2 inv = inverse_q_last[row];
+            const uint64_t half_mod_qi = barrett_reduce64(q_last_div2, m.p, m.barrett64);
+            const uint64_t t = barrett_reduce64(r, m.p, m.barrett64);
+            const uint64_t v = shoup_mul(sub_mod(add_mod(src[row * n], half_mod_qi, m.p), t, m.p), inv.x, inv.y, m.p);
+            dst[row * n] = add_mod(ct[row * n], v, m.p);
+        }
+    }
+}
+
+template <template <int> class Launcher, typename... Args>
+hipError_t dispatch_L(uint32_t L, Args&&... args) {
+    switch (L) {
+        case 1: return Launcher<1>::run(args...);
+        case 2: return Launcher<2>::run(args...);
+        case 3: return Launcher<3>::run(args...);
+        case 4: return Launcher<4>::run(args...);
+        case 5: return Launcher<5>::run(args...);
+        case 6: return Launcher<6>::run(args...);
+        case 7: return Launcher<7>::run(args...);
+        case 8: return Launcher<8>::run(args...);
+        default: return hipErrorNotSupported;
+    }
+}
+static_assert(kMaxL == 8, "dispatch_L covers 1..8");
+
+template <int L>
+struct LiftLauncher {
+    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
+                          const LiftLayout& layout, hipStream_t s) {
+        hipLaunchKernelGGL(lift_kernel<L>, dim3(grid_for(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out, tool,
+                           polys, layout);
+        return hipGetLastError();
+    }
+};
+template <int L>
+struct FloorLauncher {
+    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
+        hipLaunchKernelGGL(floor_kernel<L>, dim3(grid_for(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
+                           tool, polys);
+        return hipGetLastError();
+    }
+};
+
+}  // namespace
+
+uint32_t rns_max_supported_moduli() { return kMaxL; }
+
+hipError_t launch_lift_q_to_qbsk(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
+                                 hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    const size_t n = size_t(1) << tool.log_degree;
+    const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n};
+    return dispatch_L<LiftLauncher>(tool.L, in, out, tool, polys, layout, stream);
+}
+
+hipError_t launch_lift_q_to_qbsk_strided(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t items,
+                                         size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
+                                         size_t out_offset, hipStream_t stream) {
+    if (items == 0 || polys_per_item == 0) return hipSuccess;
+    const LiftLayout layout{polys_per_item, in_item_stride, out_item_stride};
+    return dispatch_L<LiftLauncher>(tool.L, in, out + out_offset, tool, items * polys_per_item, layout, stream);
+}
+
+hipError_t launch_floor_qbsk_to_q(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
+                                  hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    return dispatch_L<FloorLauncher>(tool.L, in, out, tool, polys, stream);
+}
+
+hipError_t launch_tensor(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t items,
+                         hipStream_t stream) {
+    if (items == 0) return hipSuccess;
+    const size_t total = items * (size_t(qbsk.moduli_count) << qbsk.log_degree);
+    hipLaunchKernelGGL(tensor_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk, items);
+    return hipGetLastError();
+}
+
+hipError_t launch_tensor_accumulate(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t count,
+                                    uint64_t max_lazy, hipStream_t stream) {
+    const size_t total = size_t(qbsk.moduli_count) << qbsk.log_degree;
+    hipLaunchKernelGGL(tensor_accumulate_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk, count,
+                       max_lazy);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_switch_spread(const uint64_t* target_base, size_t target_stride, uint64_t* out,
+                                    const DeviceContext& ks, uint32_t L, size_t polys, hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(key_switch_spread_kernel, dim3(grid_for((polys * L) << ks.log_degree)), dim3(kThreads), 0,
+                       stream, target_base, target_stride, out, ks, L, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
+                                 uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(key_switch_mac_kernel, dim3(grid_for((polys * (L + 1)) << ks.log_degree)), dim3(kThreads), 0,
+                       stream, spread, key, out, ks, L, top_rows, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_switch_finish(const uint64_t* prod, const uint64_t* ct_base, size_t ct_stride, uint64_t* out,
+                                    const DeviceContext& ks, uint32_t L, size_t polys, hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(key_switch_finish_kernel, dim3(grid_for((polys * 2) << ks.log_degree)), dim3(kThreads), 0,
+                       stream, prod, ct_base, ct_stride, out, ks, L, polys);
+    return hipGetLastError();
+}
+
+}  // namespace heamd

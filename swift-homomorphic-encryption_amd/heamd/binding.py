@@ -106,6 +106,13 @@ def load_library():
             raise ImportError(
                 f"{_LIB_PATH} is missing: build the HIP extension first "
                 "(python swift-homomorphic-encryption_amd/build.py, or __graft_entry__.build()).")
+        try:
+            # PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Import it first so that libhe_amd.so
+            # binds to the SAME HIP runtime instance as the tensors it is handed (two runtimes in one process do not
+            # see each other's devices).  Without PyTorch the library uses the system ROCm runtime.
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover
+            pass
         lib = ctypes.CDLL(_LIB_PATH)
         for name, restype, argtypes in SIGNATURES:
             fn = getattr(lib, name)  # AttributeError = header and library disagree

@@ -110,3 +110,37 @@ def test_device_context_creation_needs_a_gpu():
     with pytest.raises(heamd.HeError) as err:
         heamd.PolyContext(8, heamd.generate_primes([30], False, 8))
     assert err.value.name == "deviceError"
+
+
+def test_bfv_host_only_context_matches_oracle(oracle):
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours = heamd.BfvContext(degree, 557057, q, host_only=True)
+    ref = oracle.BfvContext(degree, 557057, q)
+    assert ours.L == ref.L == 4
+    assert ours.bsk_moduli() == ref.rns_tool().bsk
+    for k in (1, 2, 3, 4):
+        assert ours.ciphertext_context(k).moduli == ref.ciphertext_context(k).moduli
+        assert ours.key_switching_context(k).moduli == ref.key_switching_context(k).moduli
+        assert ours.qbsk_context(k).moduli == ref.qbsk_context(k).moduli
+    # the qBsk context's NTT tables (61-bit Bsk primes) match the oracle's
+    a, b = ours.qbsk_context().ntt_tables(8), ref.qbsk_context().ntt_tables(8)
+    assert np.array_equal(a["root_powers"], b["root_powers"]) and np.array_equal(a["inv_root_factors"], b["inv_root_factors"])
+
+
+def test_bfv_context_errors(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40], False, degree)
+    for bad in ((degree, t, q + [q[0] + 2]), (degree + 1, t, q), (degree, q[0], q), (degree, t, [])):
+        with pytest.raises(heamd.HeError) as err:
+            heamd.BfvContext(*bad, host_only=True)
+        assert err.value.name == "invalidEncryptionParameters", bad
+        with pytest.raises(oracle.OracleError) as ref_err:
+            oracle.BfvContext(*bad)
+        assert ref_err.value.name == "invalidEncryptionParameters"
+    # compute on a host-only context fails loudly
+    ctx = heamd.BfvContext(degree, t, q, host_only=True)
+    lib = heamd.load_library()
+    status = lib.he_bfv_mul_device(ctx.h, 1, None, None, None, 1, None, 0, None)
+    assert heamd.binding.STATUS_NAMES[status] == "deviceError"

@@ -1,0 +1,217 @@
+"""GPU parity tests of the BEHZ kernels and the Bfv<UInt64> scheme operations against the CPU oracle, plus the
+reference's semantic (decrypt) checks (Sources/_TestUtilities/HeApiTestUtils.swift:494-720,1223-1285).  Bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+import heamd
+from bfv_helpers import BfvClient, negacyclic_multiply
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform(rng, shape_prefix, moduli, degree):
+    """uint64 array [*shape_prefix][L][N] with row i uniform in [0, moduli[i])."""
+    rows = [rng.integers(0, q, size=tuple(shape_prefix) + (degree,), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=len(shape_prefix)))
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40, 40, 41], False, degree)
+    return heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q), BfvClient(oracle, oracle.BfvContext(degree, t, q), seed=30)
+
+
+@pytest.fixture(scope="module")
+def config3(oracle):
+    """BASELINE config 3 parameters: N=8192, t=557057, 4 ciphertext moduli + 1 key-switching modulus (55-bit)."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    return heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+
+
+def test_context_matches_oracle(oracle, config3):
+    ours, ref = config3
+    assert ours.L == ref.L == 4
+    assert ours.bsk_moduli() == ref.rns_tool().bsk
+    assert ours.ciphertext_context().moduli == ref.ciphertext_context().moduli
+    assert ours.key_switching_context(2).moduli == ref.key_switching_context(2).moduli
+    assert ours.qbsk_context(3).moduli == ref.qbsk_context(3).moduli
+
+
+@pytest.mark.parametrize("level", [None, 2, 1])
+def test_lift_and_floor_match_oracle(oracle, small, level):
+    ours, ref, _ = small
+    L = ours.L if level is None else level
+    tool = ref.rns_tool(L)
+    moduli = ref.ciphertext_context(L).moduli
+    rng = np.random.default_rng(40 + L)
+    x = _uniform(rng, (5,), moduli, ours.degree)
+    x[0, :, :3] = 0
+    x[0, :, 3] = [m - 1 for m in moduli]
+    lifted = heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x), L))
+    expected = np.stack([tool.lift_q_to_qbsk(p) for p in x])
+    assert np.array_equal(lifted, expected)
+    qbsk_moduli = ref.qbsk_context(L).moduli
+    y = _uniform(rng, (5,), qbsk_moduli, ours.degree)
+    floored = heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y), L))
+    assert np.array_equal(floored, np.stack([tool.floor_qbsk_to_q(p) for p in y]))
+
+
+def test_lift_matches_oracle_config3(oracle, config3):
+    ours, ref = config3
+    rng = np.random.default_rng(41)
+    x = _uniform(rng, (3,), ref.ciphertext_context().moduli, ours.degree)
+    got = heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x)))
+    assert np.array_equal(got, np.stack([ref.rns_tool().lift_q_to_qbsk(p) for p in x]))
+    y = _uniform(rng, (3,), ref.qbsk_context().moduli, ours.degree)
+    got = heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y)))
+    assert np.array_equal(got, np.stack([ref.rns_tool().floor_qbsk_to_q(p) for p in y]))
+
+
+@pytest.mark.parametrize("level", [None, 2])
+def test_mul_matches_oracle(oracle, small, level):
+    """Bfv.mulAssign(ct, ct) word for word, top level and (literal restatement) a lower level."""
+    ours, ref, _ = small
+    L = ours.L if level is None else level
+    moduli = ref.ciphertext_context(L).moduli
+    rng = np.random.default_rng(50 + L)
+    lhs, rhs = _uniform(rng, (4, 2), moduli, ours.degree), _uniform(rng, (4, 2), moduli, ours.degree)
+    got = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), L))
+    assert got.shape == (4, 3, L, ours.degree)
+    assert np.array_equal(got, ref.mul(lhs, rhs, L))
+
+
+def test_mul_relinearize_decrypts_to_product(oracle, small):
+    # HeApiTestUtils.swift:494-556 with genuine encryptions and a genuine relinearization key
+    ours, ref, client = small
+    rng = random.Random(51)
+    m1 = [rng.randrange(ours.t) for _ in range(ours.degree)]
+    m2 = [rng.randrange(ours.t) for _ in range(ours.degree)]
+    ct1, ct2 = client.encrypt(m1), client.encrypt(m2)
+    product = ours.mul(heamd.to_device(ct1[None]), heamd.to_device(ct2[None]))
+    expected = negacyclic_multiply(m1, m2, ours.t)
+    assert client.decrypt(heamd.to_host(product)[0]) == expected
+    key = client.relinearization_key()
+    relin = ours.relinearize(product, heamd.to_device(key))
+    assert np.array_equal(heamd.to_host(relin), ref.relinearize(heamd.to_host(product), key))
+    assert client.decrypt(heamd.to_host(relin)[0]) == expected
+
+
+@pytest.mark.parametrize("level", [None, 2, 1])
+def test_relinearize_matches_oracle(oracle, small, level):
+    ours, ref, _ = small
+    L = ours.L if level is None else level
+    moduli = ref.ciphertext_context(L).moduli
+    rng = np.random.default_rng(60 + L)
+    ct3 = _uniform(rng, (3, 3), moduli, ours.degree)
+    key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, ours.degree)
+    got = heamd.to_host(ours.relinearize(heamd.to_device(ct3), heamd.to_device(key), L))
+    assert np.array_equal(got, ref.relinearize(ct3, key, L))
+    with pytest.raises(heamd.HeError) as err:
+        ours.relinearize(heamd.to_device(ct3), None, L)
+    assert err.value.name == "missingRelinearizationKey"
+
+
+def test_mul_and_relinearize_config3(oracle, config3):
+    """BASELINE config 3 shape (N=8192, L=4): batch of 16, two items checked word for word against the oracle."""
+    ours, ref = config3
+    rng = np.random.default_rng(61)
+    moduli = ref.ciphertext_context().moduli
+    lhs, rhs = _uniform(rng, (16, 2), moduli, ours.degree), _uniform(rng, (16, 2), moduli, ours.degree)
+    key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, ours.degree)
+    product = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs))
+    relin = ours.relinearize(product, heamd.to_device(key))
+    sample = [0, 15]
+    expected_product = ref.mul(lhs[sample], rhs[sample])
+    assert np.array_equal(heamd.to_host(product)[sample], expected_product)
+    assert np.array_equal(heamd.to_host(relin)[sample], ref.relinearize(expected_product, key))
+    # caller-provided workspace gives the same words
+    import torch
+
+    ws = torch.empty(ours.mul_workspace_bytes(16) // 8, dtype=torch.int64, device="cuda")
+    again = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), workspace=ws)
+    assert torch.equal(again, product)
+
+
+def test_mod_switch_down_matches_oracle(oracle, small):
+    ours, ref, client = small
+    rng = np.random.default_rng(70)
+    ct = _uniform(rng, (3, 2), ref.ciphertext_context().moduli, ours.degree)
+    got = heamd.to_host(ours.mod_switch_down(heamd.to_device(ct), 2))
+    assert np.array_equal(got, ref.mod_switch_down(ct, 2))
+    message = [int(v) for v in rng.integers(0, ours.t, size=ours.degree)]
+    lower = heamd.to_host(ours.mod_switch_down(heamd.to_device(client.encrypt(message)[None]), 2))[0]
+    assert client.decrypt(lower, moduli_count=ours.L - 1) == message
+    with pytest.raises(heamd.HeError) as err:
+        ours.mod_switch_down(heamd.to_device(ct[:, :, :1].copy()), 2, moduli_count=1)
+    assert err.value.name == "invalidPolyContext"
+
+
+def test_mul_plain_and_inner_product_plain(oracle, small):
+    ours, ref, client = small
+    poly_ctx = ref.ciphertext_context()
+    rng = np.random.default_rng(80)
+    count, columns = 6, 5
+    cts = _uniform(rng, (count, 2), poly_ctx.moduli, ours.degree)
+    pts = _uniform(rng, (columns, count), poly_ctx.moduli, ours.degree)
+    present = rng.integers(0, 2, size=(columns, count), dtype=np.uint8)
+    present[0, :] = 1
+    present[1, :] = 0  # a column whose plaintexts are all nil: the reference returns the zero accumulator
+    got = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), present, 2, columns))
+    for col in range(columns):
+        assert np.array_equal(got[col], ref.inner_product_plain(cts, pts[col], present[col])), col
+    no_mask = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), None, 2, columns))
+    assert np.array_equal(no_mask[2], ref.inner_product_plain(cts, pts[2], None))
+    # Bfv.mulAssign(ct, pt)
+    ct = heamd.to_device(cts[:3])
+    ours.mul_plain_(ct, heamd.to_device(pts[0, :3]), 2)
+    assert np.array_equal(heamd.to_host(ct), ref.mul_plain(cts[:3], pts[0, :3], 2))
+
+
+def test_inner_product_ct_ct(oracle, small):
+    ours, ref, client = small
+    rng = random.Random(90)
+    count = 3
+    m1 = [[rng.randrange(ours.t) for _ in range(ours.degree)] for _ in range(count)]
+    m2 = [[rng.randrange(ours.t) for _ in range(ours.degree)] for _ in range(count)]
+    lhs = np.stack([client.encrypt(m) for m in m1])
+    rhs = np.stack([client.encrypt(m) for m in m2])
+    got = heamd.to_host(ours.inner_product(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(got, ref.inner_product(lhs, rhs))
+    expected = [0] * ours.degree
+    for a, b in zip(m1, m2):
+        expected = [(x + y) % ours.t for x, y in zip(expected, negacyclic_multiply(a, b, ours.t))]
+    assert client.decrypt(got) == expected
+
+
+def test_inner_product_plain_pir_shape(oracle, config3):
+    """BASELINE config 5's inner loop at reduced d0/d1 (N=8192, L=4): 32 ciphertexts x 8 columns."""
+    ours, ref = config3
+    rng = np.random.default_rng(100)
+    moduli = ref.ciphertext_context().moduli
+    count, columns = 32, 8
+    cts = _uniform(rng, (count, 2), moduli, ours.degree)
+    pts = _uniform(rng, (columns, count), moduli, ours.degree)
+    got = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), None, 2, columns))
+    for col in (0, 7):
+        assert np.array_equal(got[col], ref.inner_product_plain(cts, pts[col], None))
+
+
+def test_single_modulus_context(oracle):
+    """One coefficient modulus: no key-switching modulus (Context.swift:102-107); ct x ct still works."""
+    degree = 32
+    t = oracle.generate_primes([13], True, degree)[0]
+    q = oracle.generate_primes([50], False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    assert ours.L == 1
+    rng = np.random.default_rng(110)
+    lhs, rhs = _uniform(rng, (2, 2), q, degree), _uniform(rng, (2, 2), q, degree)
+    got = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(got, ref.mul(lhs, rhs))
+    with pytest.raises(heamd.HeError) as err:
+        ours.relinearize(heamd.to_device(got), heamd.to_device(np.zeros((1, 2, 2, degree), dtype=np.uint64)))
+    assert err.value.name == "missingRelinearizationKey"

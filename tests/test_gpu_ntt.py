@@ -75,9 +75,9 @@ def test_ntt_matches_oracle(oracle, degree, bits, batch):
 
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55]), (8192, [55, 55, 55, 55]), (16384, [55, 55])])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_ntt_kernel_variants_agree(oracle, degree, bits, variant):
-    """exact-quotient tiled kernel (1) and generic radix-2 kernel (2) against the oracle."""
+    """exact-quotient tiled kernel (1), generic radix-2 kernel (2), 2x-wide workgroup tiled kernel (3) vs the oracle."""
     moduli = oracle.generate_primes(bits, False, degree)
     ours = heamd.PolyContext(degree, moduli)
     ref = oracle.PolyContext(degree, moduli)
