@@ -1,0 +1,116 @@
+"""Device-resident timings of every BASELINE.json config on one GPU (HIP events on the launch stream).
+
+    python bench_tools/path_bench.py [--quick]
+
+Prints one JSON object; bench.py embeds the same numbers under "extras".  Algorithmic bytes per unit follow
+SURVEY.md section 8(d).
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "swift-homomorphic-encryption_amd"))
+
+
+def _timed(torch, fn, reps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / reps
+
+
+def _uniform(torch, moduli, prefix, degree, seed):
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(*([1] * len(prefix)), len(moduli), 1)
+    x = torch.randint(0, 1 << 62, tuple(prefix) + (len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen)
+    return x % bound
+
+
+def config3_ct_mul(torch, heamd, batch=1024, reps=5):
+    """ct x ct + relinearize, N=8192, 4 ciphertext moduli + 1 key-switching modulus (BASELINE configs[2])."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    lhs = _uniform(torch, moduli, (batch, 2), degree, 1)
+    rhs = _uniform(torch, moduli, (batch, 2), degree, 2)
+    key = _uniform(torch, q, (ctx.L, 2), degree, 3)
+    ws_mul = torch.empty(ctx.mul_workspace_bytes(batch) // 8, dtype=torch.int64, device="cuda")
+    ws_relin = torch.empty(ctx.relinearize_workspace_bytes(batch) // 8, dtype=torch.int64, device="cuda")
+    state = {}
+
+    def mul():
+        state["ct3"] = ctx.mul(lhs, rhs, workspace=ws_mul)
+
+    def relin():
+        state["ct2"] = ctx.relinearize(state["ct3"], key, workspace=ws_relin)
+
+    def both():
+        mul()
+        relin()
+
+    t_mul = _timed(torch, mul, reps)
+    t_relin = _timed(torch, relin, reps)
+    t_both = _timed(torch, both, reps)
+    compulsory = 1_572_864  # read 2 cts x 2 polys + write 2 polys
+    return {
+        "batch": batch,
+        "ct_mul_per_s": batch / t_mul,
+        "relinearize_per_s": batch / t_relin,
+        "ct_mul_relinearize_per_s": batch / t_both,
+        "compulsory_GBps": compulsory * batch / t_both / 1e9,
+        "frac_of_8TBps_at_compulsory_bytes": compulsory * batch / t_both / 8e12,
+    }
+
+
+def config4_mod_switch(torch, heamd, batch=8192, reps=5):
+    """divideAndRoundQLast, N=16384, 6 -> 5 moduli (BASELINE configs[3])."""
+    degree = 16384
+    moduli = heamd.generate_primes([55] * 6, False, degree)
+    ctx = heamd.PolyContext(degree, moduli)
+    x = _uniform(torch, moduli, (batch,), degree, 4)
+    t = _timed(torch, lambda: ctx.divide_and_round_q_last(x), reps)
+    bytes_per_poly = (6 + 5) * degree * 8
+    return {"batch": batch, "poly_per_s": batch / t, "GBps": bytes_per_poly * batch / t / 1e9,
+            "frac_of_8TBps": bytes_per_poly * batch / t / 8e12}
+
+
+def config5_inner_product(torch, heamd, count=256, columns=64, reps=3):
+    """PIR dim-0 shape on one GPU: `columns` outputs, each sum of `count` ct x pt products, N=8192, L=4."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    cts = _uniform(torch, moduli, (count, 2), degree, 5)
+    pts = _uniform(torch, moduli, (columns, count), degree, 6)
+    t = _timed(torch, lambda: ctx.inner_product_plain(cts, pts, None, 2, columns), reps)
+    macs = count * columns
+    db_bytes = macs * 4 * degree * 8
+    return {"count": count, "columns": columns, "ct_pt_mac_per_s": macs / t, "database_GBps": db_bytes / t / 1e9,
+            "frac_of_8TBps": db_bytes / t / 8e12}
+
+
+def run_all(quick=False):
+    import torch
+
+    import heamd
+
+    out = {}
+    out["config3_ct_mul"] = config3_ct_mul(torch, heamd, batch=256 if quick else 1024)
+    out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
+    out["config5_inner_product_1gpu"] = config5_inner_product(torch, heamd, count=64 if quick else 256,
+                                                              columns=16 if quick else 64)
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run_all("--quick" in sys.argv), indent=1))
