@@ -267,6 +267,11 @@ int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, siz
     return HE_OK;
 }
 
+int he_debug_set_ntt_timeline(uint64_t* device_buffer) {
+    HEAMD_HIP_TRY(heamd::set_ntt_timeline_buffer(device_buffer));
+    return HE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ element-wise
 int he_poly_add_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s) {
     return elementwise(ctx, heamd::ElementwiseOp::Add, lhs, rhs, batch, s);

@@ -15,6 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef HEAMD_CSUB_BORROW
+#define HEAMD_CSUB_BORROW 1
+#endif
+
 namespace heamd {
 
 struct alignas(16) U64x2 {
@@ -73,7 +77,16 @@ __device__ __forceinline__ uint64_t mullo64_sum2(uint64_t a, uint64_t b, uint64_
 }
 
 // x >= m ? x - m : x   (x < 2m)
-__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
+__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) {
+#if HEAMD_CSUB_BORROW
+    // one subtract-with-borrow pair; the borrow itself selects (no separate 64-bit compare)
+    unsigned long d;
+    const bool borrow = __builtin_usubl_overflow(x, m, &d);
+    return borrow ? x : static_cast<uint64_t>(d);
+#else
+    return x >= m ? x - m : x;
+#endif
+}
 
 // Shoup multiplication by the constant w (wf = floor(w * 2^64 / p)), `neg_p` = 2^64 - p.
 //   lazy  : result in [0, 2p), exact quotient estimate (4 + 6 multiplies)

@@ -9,12 +9,31 @@
 
 namespace heamd {
 
-enum { kNttVariantAuto = 0, kNttVariantExact = 1, kNttVariantGeneric = 2, kNttVariantWide = 3 };
+// kernel selection for launch_ntt (tests / benchmarks; production callers pass kNttVariantAuto):
+//   0 auto (tiled kernel, 16 words per lane, where supported)   1 same kernel, exact-quotient butterflies
+//   2 generic radix-2 kernel   3 tiled kernel with 2x wider workgroups   4..7 pipelined kernel with flags 0..3
+//   (bit0 next-row register prefetch, bit1 staggered second wave)   8 tiled (non-persistent) kernel
+//   16+ measurement-only ablations of the tiled forward kernel
+enum {
+    kNttVariantAuto = 0,
+    kNttVariantExact = 1,
+    kNttVariantGeneric = 2,
+    kNttVariantWide = 3,
+    kNttVariantPipelinedBase = 4,
+    kNttVariantTiled = 8,
+    kNttVariantWidest = 9,  // tiled kernel, 1024 lanes x 8 words (N = 8192 only)
+    kNttVariantAblateBase = 16
+};
+bool ntt_pipelined_supports(uint32_t log_degree);
+hipError_t launch_ntt_pipelined(bool inverse, bool approx, int flags, uint64_t* slab, const DeviceContext& ctx,
+                                uint32_t mod_base, uint32_t mod_period, size_t rows, hipStream_t stream);
 
 // NTT of `rows` contiguous length-N rows.  Row r uses modulus index mod_base + (r % mod_period).
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                       size_t rows, hipStream_t stream, int force_variant = kNttVariantAuto);
 const char* ntt_variant_name(uint32_t log_degree);
+// measurement hook: variant 32 of the forward N=8192 kernel stamps phase boundaries into this buffer (16 words/row)
+hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer);
 
 enum class ElementwiseOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, MulScalar = 4 };
 // lhs[k] = op(lhs[k], rhs[k]) over `rows` rows of [..][L][N]; rhs may be NULL for Neg.  For MulScalar `rhs` is a

@@ -20,177 +20,36 @@
 #include "device_context.hpp"
 #include "device_math.hpp"
 #include "kernels.hpp"
+#include "ntt_common.hpp"
 
 namespace heamd {
 
 namespace {
 
-// ---- LDS tile addressing: word index -> padded word index (all accesses are 8-byte ds_read/write_b64) ----------
-// +1 word per 8 words de-conflicts the stride-8/16 reads of the last pass; +8 words per 256 de-conflicts the
-// middle pass whose lanes are 256 words apart (bank math in DESIGN.md).
-__device__ __forceinline__ uint32_t lds_slot(uint32_t idx) { return idx + (idx >> 3) + ((idx >> 8) << 3); }
-constexpr uint32_t lds_words(uint32_t n) { return n + (n >> 3) + ((n >> 8) << 3) + 8; }
+using namespace ntt;
 
-// element index held in register r of lane tid during a pass over element bits [LO, LO + W)
-template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ uint32_t element_index(uint32_t r, uint32_t tid) {
-    if constexpr (W == LOGE) {
-        return ((tid >> LO) << (LO + LOGE)) | (r << LO) | (tid & ((1u << LO) - 1u));
-    } else {
-        static_assert(LO == 0, "a partial pass sits on the low bits");
-        constexpr int X = LOGE - W;  // extra register bits = the top X element bits
-        return ((r >> W) << (LOGN - X)) | (tid << W) | (r & ((1u << W) - 1u));
+// ABLATE (measurement only, results are wrong when non-zero): bit0 uniform twiddles, bit1 skip the LDS exchanges,
+// bit2 skip global load/store, bit3 skip the per-butterfly conditional subtract.
+// Timeline instrumentation (ABLATE bit 4): lane 0 of wave 0 stamps s_memtime at every phase boundary into
+// g_ntt_timeline[block * 16 + k]; results stay correct.
+__device__ uint64_t* g_ntt_timeline = nullptr;
+template <int ABLATE>
+__device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
+    if constexpr (ABLATE & 16) {
+        if (drain_vmem) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (drain_lds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0 && g_ntt_timeline != nullptr)
+            g_ntt_timeline[static_cast<size_t>(blockIdx.x) * 16 + k] = __builtin_readcyclecounter();
     }
 }
 
-template <bool APPROX>
-struct Lazy {
-    // values live in [0, BOUND * p)
-    static constexpr int kBound = APPROX ? 8 : 4;
-    __device__ static __forceinline__ uint64_t mul(uint64_t x, U64x2 w, uint64_t neg_p) {
-        if constexpr (APPROX) {
-            return shoup_lazy4(x, w.x, w.y, neg_p);
-        } else {
-            return shoup_lazy(x, w.x, w.y, neg_p);
-        }
-    }
-};
-
-// ---- forward pass over element bits [LO, LO+W): stages run from the top bit down --------------------------------
-template <int LOGN, int LOGE, int LO, int W, bool APPROX, bool UNIFORM_TWIDDLES>
-__device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
-                                             uint64_t p, bool first_stage_canonical) {
-    constexpr int E = 1 << LOGE;
-    const uint64_t neg_p = opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
-    const uint64_t half_bound = (APPROX ? 4 : 2) * p;  // Harvey: fold x into [0, half_bound) before the butterfly
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const int b = LO + W - 1 - j;         // element bit paired by this stage
-        const int s = LOGN - 1 - b;           // global stage number; m = 2^s groups
-        const int stride = 1 << (b - LO);     // register distance of a pair
-#pragma unroll
-        for (int base = 0; base < E; base += 2 * stride) {
-            const uint32_t idx = element_index<LOGN, LOGE, LO, W>(base, tid);
-            const U64x2 w = tw[(1u << s) + (idx >> (b + 1))];
-#pragma unroll
-            for (int o = 0; o < stride; ++o) {
-                uint64_t x = v[base + o];
-                const uint64_t y = v[base + o + stride];
-                if (!(first_stage_canonical && j == 0)) x = csub(x, half_bound);
-                const uint64_t t = Lazy<APPROX>::mul(y, w, neg_p);
-                v[base + o] = x + t;
-                v[base + o + stride] = x + half_bound - t;
-            }
-        }
-    }
-    (void)UNIFORM_TWIDDLES;
-}
-
-// ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
-// transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
-template <int LOGN, int LOGE, int LO, int W, bool APPROX>
-__device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
-                                             const DeviceModulus& mod, bool first_stage_canonical) {
-    constexpr int E = 1 << LOGE;
-    constexpr uint32_t N = 1u << LOGN;
-    const uint64_t p = mod.p;
-    const uint64_t neg_p = opaque(0 - p);
-    const uint64_t bound = (APPROX ? 4 : 2) * p;  // inputs/outputs of a stage live in [0, bound)
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const int b = LO + j;
-        const int stride = 1 << (b - LO);
-        const uint32_t m = N >> (b + 1);
-        const bool last_stage = (b == LOGN - 1);
-#pragma unroll
-        for (int base = 0; base < E; base += 2 * stride) {
-            const uint32_t idx = element_index<LOGN, LOGE, LO, W>(base, tid);
-            U64x2 w = {0, 0};
-            if (!last_stage) w = tw[(N - 2 * m + 1) + (idx >> (b + 1))];
-#pragma unroll
-            for (int o = 0; o < stride; ++o) {
-                const uint64_t x = v[base + o];
-                const uint64_t y = v[base + o + stride];
-                uint64_t sum = x + y;
-                const uint64_t diff = x + bound - y;
-                if (last_stage) {
-                    v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
-                    v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
-                } else {
-                    if (!(first_stage_canonical && j == 0)) sum = csub(sum, bound);
-                    v[base + o] = sum;
-                    v[base + o + stride] = Lazy<APPROX>::mul(diff, w, neg_p);
-                }
-            }
-        }
-    }
-}
-
-template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void lds_store(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* lds) {
-#pragma unroll
-    for (int r = 0; r < (1 << LOGE); ++r) lds[lds_slot(element_index<LOGN, LOGE, LO, W>(r, tid))] = v[r];
-}
-template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* lds) {
-#pragma unroll
-    for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[lds_slot(element_index<LOGN, LOGE, LO, W>(r, tid))];
-}
-
-// Global <-> registers.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at
-// a time.  For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
-template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* __restrict__ x) {
-    if constexpr (LO == 0 && W >= 1) {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); r += 2) {
-            const U64x2 pair = *reinterpret_cast<const U64x2*>(x + element_index<LOGN, LOGE, LO, W>(r, tid));
-            v[r] = pair.x;
-            v[r + 1] = pair.y;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) v[r] = x[element_index<LOGN, LOGE, LO, W>(r, tid)];
-    }
-}
-template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* __restrict__ x) {
-    if constexpr (LO == 0 && W >= 1) {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); r += 2) {
-            U64x2 pair;
-            pair.x = v[r];
-            pair.y = v[r + 1];
-            *reinterpret_cast<U64x2*>(x + element_index<LOGN, LOGE, LO, W>(r, tid)) = pair;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) x[element_index<LOGN, LOGE, LO, W>(r, tid)] = v[r];
-    }
-}
-
-template <bool APPROX>
-__device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
-    if constexpr (APPROX) x = csub(x, 4 * p);
-    x = csub(x, 2 * p);
-    return csub(x, p);
-}
-
-// Pass schedule: P = ceil(LOGN / LOGE) passes; the partial pass (R = LOGN - (P-1) LOGE bits) sits on the low bits,
-// i.e. it is the LAST forward pass and the FIRST inverse pass.
-template <int LOGN, int LOGE>
-struct Schedule {
-    static constexpr int P = (LOGN + LOGE - 1) / LOGE;
-    static constexpr int R = LOGN - (P - 1) * LOGE;
-};
-
-template <int LOGN, int LOGT, bool APPROX>
-__global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
+template <int LOGN, int LOGT, bool APPROX, int ABLATE = 0>
+__global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
-    static_assert(S::P >= 1 && S::P <= 4, "unsupported pass count");
+    static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     const size_t row = blockIdx.x;
@@ -209,39 +68,83 @@ __global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
-        global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
-        forward_pass<LOGN, LOGE, LO0, LOGE, APPROX, true>(v, tid, tw, p, true);
-        lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds);
-        __syncthreads();
+        stamp<ABLATE>(0, false, false);
+        if constexpr (ABLATE & 16) {
+            if (threadIdx.x == 0 && g_ntt_timeline != nullptr) {
+                uint32_t hw_id;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+                uint32_t xcc_id;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+                g_ntt_timeline[static_cast<size_t>(blockIdx.x) * 16 + 15] = (static_cast<uint64_t>(xcc_id) << 32) | hw_id;
+            }
+        }
+        if constexpr (ABLATE & 4) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
+        } else {
+            global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
+        }
+        stamp<ABLATE>(1, true, false);
+        forward_pass<LOGN, LOGE, LO0, LOGE, APPROX, true, ABLATE>(v, tid, tw, p, true);
+        stamp<ABLATE>(2, false, false);
+        if constexpr (!(ABLATE & 2)) {
+            lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds);
+            __syncthreads();
+        }
+        stamp<ABLATE>(3, false, true);
         if constexpr (S::P >= 3) {
             constexpr int LO1 = LOGN - 2 * LOGE;
-            lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO1, LOGE, APPROX, false>(v, tid, tw, p, false);
-            lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            __syncthreads();
+            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+            stamp<ABLATE>(4, false, true);
+            forward_pass<LOGN, LOGE, LO1, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            stamp<ABLATE>(5, true, false);
+            if constexpr (!(ABLATE & 2)) {
+                lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+                lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>();
+            }
+            stamp<ABLATE>(6, false, true);
         }
         if constexpr (S::P >= 4) {
             constexpr int LO2 = LOGN - 3 * LOGE;
-            lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO2, LOGE, APPROX, false>(v, tid, tw, p, false);
-            lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            __syncthreads();
+            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+            forward_pass<LOGN, LOGE, LO2, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            if constexpr (!(ABLATE & 2)) {
+                lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+                lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>();
+            }
         }
-        lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
-        forward_pass<LOGN, LOGE, 0, S::R, APPROX, false>(v, tid, tw, p, false);
+        if constexpr (S::P >= 5) {
+            constexpr int LO3 = LOGN - 4 * LOGE;
+            lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+            forward_pass<LOGN, LOGE, LO3, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+            lds_transpose_fence<LOGN, LOGE, LO3, 0>();
+        }
+        if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
+        stamp<ABLATE>(7, false, true);
+        forward_pass<LOGN, LOGE, 0, S::R, APPROX, false, ABLATE>(v, tid, tw, p, false);
 #pragma unroll
         for (int r = 0; r < E; ++r) v[r] = canonicalize<APPROX>(v[r], p);
-        global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+        stamp<ABLATE>(8, true, false);
+        if constexpr (ABLATE & 4) {
+            uint64_t sum = 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) sum ^= v[r];
+            if (sum == 0x123456789ull) x[tid] = sum;  // keeps the work alive without streaming the row out
+        } else {
+            global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+        }
+        stamp<ABLATE>(9, true, false);
     }
 }
 
 template <int LOGN, int LOGT, bool APPROX>
-__global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
+__global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
-    static_assert(S::P >= 1 && S::P <= 4, "unsupported pass count");
+    static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     const size_t row = blockIdx.x;
@@ -256,24 +159,32 @@ __global__ void __launch_bounds__(1 << LOGT, (LOGT >= 9 ? 4 : 2))
         inverse_pass<LOGN, LOGE, 0, LOGN, APPROX>(v, tid, tw, mod, true);
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
+        // every transpose but the last one (into the top pass) stays inside a wave
         global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
         inverse_pass<LOGN, LOGE, 0, S::R, APPROX>(v, tid, tw, mod, true);
         lds_store<LOGN, LOGE, 0, S::R>(v, tid, lds);
-        __syncthreads();
         if constexpr (S::P >= 3) {
+            lds_transpose_fence<LOGN, LOGE, 0, S::R>();
             constexpr int LO1 = S::R;
             lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
             inverse_pass<LOGN, LOGE, LO1, LOGE, APPROX>(v, tid, tw, mod, false);
             lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            __syncthreads();
         }
         if constexpr (S::P >= 4) {
+            lds_transpose_fence<LOGN, LOGE, S::R, S::R + LOGE>();
             constexpr int LO2 = S::R + LOGE;
             lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
             inverse_pass<LOGN, LOGE, LO2, LOGE, APPROX>(v, tid, tw, mod, false);
             lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            __syncthreads();
         }
+        if constexpr (S::P >= 5) {
+            lds_transpose_fence<LOGN, LOGE, S::R + LOGE, S::R + 2 * LOGE>();
+            constexpr int LO3 = S::R + 2 * LOGE;
+            lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+            inverse_pass<LOGN, LOGE, LO3, LOGE, APPROX>(v, tid, tw, mod, false);
+            lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+        }
+        __syncthreads();
         constexpr int LOL = LOGN - LOGE;
         lds_load<LOGN, LOGE, LOL, LOGE>(v, tid, lds);
         inverse_pass<LOGN, LOGE, LOL, LOGE, APPROX>(v, tid, tw, mod, false);
@@ -385,7 +296,24 @@ hipError_t launch_tiled(bool inverse, bool approx, uint64_t* slab, const DeviceC
     return hipGetLastError();
 }
 
+template <int ABLATE>
+hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
+                           size_t rows, hipStream_t stream) {
+    constexpr size_t lds_bytes = lds_words(1u << 13) * sizeof(uint64_t);
+    auto kernel = ntt_forward_tiled<13, 8, true, ABLATE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(256), lds_bytes, stream, slab, ctx, mod_base,
+                       mod_period);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_timeline), &device_buffer, sizeof(device_buffer));
+}
 
 const char* ntt_variant_name(uint32_t log_degree) {
     switch (log_degree) {
@@ -412,8 +340,33 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         }
         return hipSuccess;
     }
+    if (force_variant >= kNttVariantAblateBase && ctx.log_degree == 13 && !inverse) {
+        switch (force_variant - kNttVariantAblateBase) {  // measurement-only kernels: results are NOT an NTT
+            case 1: return launch_ablation<1>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 2: return launch_ablation<2>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 3: return launch_ablation<3>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 4: return launch_ablation<4>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 7: return launch_ablation<7>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 8: return launch_ablation<8>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 9: return launch_ablation<9>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 15: return launch_ablation<15>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 16: return launch_ablation<16>(slab, ctx, mod_base, mod_period, rows, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     const bool approx = ctx.approx_ok != 0 && force_variant != kNttVariantExact && force_variant != kNttVariantGeneric;
-    if (force_variant == kNttVariantWide) {
+    if (ntt_pipelined_supports(ctx.log_degree) && force_variant >= kNttVariantPipelinedBase &&
+        force_variant < kNttVariantPipelinedBase + 4) {
+        // persistent / software-prefetching kernels: kept as measured alternatives (they lose to plain occupancy,
+        // see profiles/r01_ntt_variants*.txt)
+        return launch_ntt_pipelined(inverse, approx, force_variant - kNttVariantPipelinedBase, slab, ctx, mod_base,
+                                    mod_period, rows, stream);
+    }
+    if (force_variant == kNttVariantWidest && ctx.log_degree == 13)
+        return launch_tiled<13, 10>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+    // production choice (auto): the tiled kernel with 16 words per lane -- 16 waves per CU hide the latencies that
+    // 32 words per lane (8 waves per CU) leave exposed; the VALU is then ~96 % busy
+    if (force_variant == kNttVariantWide || force_variant == kNttVariantAuto || force_variant == kNttVariantExact) {
         switch (ctx.log_degree) {
             case 12: return launch_tiled<12, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
             case 13: return launch_tiled<13, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
