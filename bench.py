@@ -55,6 +55,20 @@ def synthetic_slab(torch, moduli, batch, degree, seed):
     return x % bound
 
 
+def pmc_traffic_gbps(batch, forward_seconds):
+    """HBM traffic of one forward launch as counted by the PMC passes committed under profiles/ (bench.py cannot
+    run rocprofv3 around itself); None when the committed profile was taken at another batch size."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_ntt_traffic.json")
+    try:
+        with open(path) as f:
+            profile = json.load(f)
+    except OSError:
+        return None
+    if profile.get("batch") != batch or profile.get("degree") != DEGREE:
+        return None
+    return profile["hbm_bytes_per_launch"] / forward_seconds / 1e9
+
+
 def time_kernel(torch, fn, reps):
     """Average duration (s) of fn() over reps launches, HIP events on the current (launch) stream."""
     start = torch.cuda.Event(enable_timing=True)
@@ -196,12 +210,15 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_forward_tiled<13,8> (forward NTT, one workgroup per residue row)",
+                "kernel": "ntt_forward_tiled<13, 10, 2, 0> (forward NTT: one 1024-lane workgroup per residue row, "
+                          "8 words per lane, headroom butterflies)",
                 "achieved": achieved_gbps,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic_gbps(args.batch, forward_s),
+                "traffic_source": "profiles/r01c_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                  "gfx950 FETCH_SIZE x2 correction), bytes per launch / this run's launch time",
                 "algorithmic_bytes_per_launch": bytes_per_transform * args.batch,
                 "avg_launch_ms": forward_s * 1e3,
             },

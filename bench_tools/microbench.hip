@@ -163,7 +163,7 @@ __device__ __forceinline__ uint64_t csub_min32(uint64_t x, uint64_t m) {
     return static_cast<int64_t>(d) < 0 ? x : d;
 }
 
-enum BflyVariant { FWD_APPROX_SELECT, FWD_APPROX_MASK, FWD_APPROX_MIN, FWD_APPROX_NOCSUB, FWD_EXACT_SELECT, INV_APPROX_SELECT, INV_APPROX_MASK, INV_APPROX_NOCSUB, CSUB_ONLY_SELECT, CSUB_ONLY_MASK, CSUB_ONLY_MIN, MUL_ONLY_APPROX, MUL_ONLY_EXACT };
+enum BflyVariant { FWD_APPROX_SELECT, FWD_APPROX_MASK, FWD_APPROX_MIN, FWD_APPROX_NOCSUB, FWD_EXACT_SELECT, INV_APPROX_SELECT, INV_APPROX_MASK, INV_APPROX_NOCSUB, CSUB_ONLY_SELECT, CSUB_ONLY_MASK, CSUB_ONLY_MIN, MUL_ONLY_APPROX, MUL_ONLY_EXACT, FWD_HEADROOM, INV_HEADROOM, MUL_ONLY_HEADROOM };
 
 template <int VARIANT>
 __global__ void __launch_bounds__(256) bfly_kernel(uint64_t* out, uint64_t p, uint64_t seed, int iters, long long* cycles) {
@@ -208,6 +208,18 @@ __global__ void __launch_bounds__(256) bfly_kernel(uint64_t* out, uint64_t p, ui
                         if constexpr (VARIANT == INV_APPROX_MASK) sum = csub_mask(sum, hb);
                         v[base + o] = sum;
                         v[base + o + stride] = shoup_lazy4(diff, w.x, w.y, neg_p);
+                    } else if constexpr (VARIANT == FWD_HEADROOM) {
+                        const uint64_t t = shoup_headroom(y & 0x3fffffffffffffffull, w.x, w.y >> 1, 0 - two_p);
+                        v[base + o] = x + t;
+                        v[base + o + stride] = x + 2 * hb - t;
+                    } else if constexpr (VARIANT == INV_HEADROOM) {
+                        const uint64_t sum = x + y;
+                        const uint64_t diff = x + hb - y;
+                        v[base + o] = sum;
+                        v[base + o + stride] = shoup_headroom(diff & 0x3fffffffffffffffull, w.x, w.y >> 1, 0 - two_p);
+                    } else if constexpr (VARIANT == MUL_ONLY_HEADROOM) {
+                        v[base + o] = shoup_headroom(y & 0x3fffffffffffffffull, w.x, w.y >> 1, 0 - two_p);
+                        v[base + o + stride] = x;
                     } else if constexpr (VARIANT == CSUB_ONLY_SELECT) {
                         v[base + o] = csub_select(x + y, hb);
                         v[base + o + stride] = csub_select(y + w.x, hb);
@@ -335,6 +347,9 @@ int main() {
     run_bfly<INV_APPROX_SELECT>("inv_approx_select", 80);
     run_bfly<INV_APPROX_MASK>("inv_approx_mask", 80);
     run_bfly<INV_APPROX_NOCSUB>("inv_approx_nocsub", 80);
+    run_bfly<FWD_HEADROOM>("fwd_headroom(+and)", 80);
+    run_bfly<INV_HEADROOM>("inv_headroom(+and)", 80);
+    run_bfly<MUL_ONLY_HEADROOM>("mul_only_headroom", 80);
     run_bfly<CSUB_ONLY_SELECT>("csub_only_select", 160);
     run_bfly<CSUB_ONLY_MASK>("csub_only_mask", 160);
     run_bfly<CSUB_ONLY_MIN>("csub_only_min", 160);

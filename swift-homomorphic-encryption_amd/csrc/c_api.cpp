@@ -71,6 +71,7 @@ int ntt_rows_device(const he_poly_context* ctx, uint64_t modulus, uint64_t* rows
     if (status != HE_OK) return status;
     heamd::DeviceContext dc = pc.device_context();
     dc.approx_ok = modulus < (uint64_t(1) << 61) ? 1 : 0;
+    dc.headroom_ok = (modulus < (uint64_t(1) << 55) && modulus >= (uint64_t(1) << 40)) ? 1 : 0;
     HEAMD_HIP_TRY(heamd::launch_ntt(inverse, rows_ptr, dc, static_cast<uint32_t>(index), 1, rows, stream));
     return HE_OK;
 }

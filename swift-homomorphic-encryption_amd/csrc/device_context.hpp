@@ -33,6 +33,7 @@ struct DeviceContext {
     uint32_t moduli_count;         // active moduli (a prefix of the context's list)
     uint32_t moduli_stride;        // moduli of the full context = row stride of inverse_q_last
     uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
+    uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): NTT may trade folds for top bits
 };
 
 }  // namespace heamd

@@ -33,7 +33,21 @@ __device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) {
     return static_cast<uint64_t>(a) * b + c;
 }
 __device__ __forceinline__ uint64_t mul32(uint32_t a, uint32_t b) { return static_cast<uint64_t>(a) * b; }
-__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+#ifndef HEAMD_MULHI_VIA_MAD
+#define HEAMD_MULHI_VIA_MAD 1
+#endif
+// High half of a 32x32 product.  v_mul_hi_u32 issues at about half the rate of v_mad_u64_u32 on gfx950
+// (profiles/r01_microbench_instruction_rates.txt: 20.4 vs 36.3 T lane-ops/s), so take the high register of a full
+// multiply-add instead; asm because hipcc would narrow `(uint64_t(a) * b) >> 32` back to v_mul_hi_u32.
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if HEAMD_MULHI_VIA_MAD
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return static_cast<uint32_t>(d >> 32);
+#else
+    return __umulhi(a, b);
+#endif
+}
 // asm on purpose: with a plain `a * b` hipcc recognises the schoolbook pattern below, rebuilds a 64/128-bit multiply
 // and re-expands it with redundant (even multiply-by-zero) v_mad_u64_u32.
 __device__ __forceinline__ uint32_t mullo32(uint32_t a, uint32_t b) {
@@ -99,6 +113,36 @@ __device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t
     x = opaque(x);
     return mullo64_sum2(x, w, opaque(mulhi64_approx(x, wf)), neg_p);
 }
+// Shoup multiplication for moduli with spare top bits, as two straight-line instruction blocks (hipcc keeps
+// re-deriving a generic 64x64 multiply from the C form; see profiles/r01c_isa_notes.txt for the instruction mix):
+//   x < 2^62, wf_half = floor(w 2^63 / p) = wf >> 1 (< 2^63), neg_2p = 2^64 - 2p  ->  x w - q 2p  in [0, 8p)
+// q = floor((x wf_half) / 2^64) low by <= 2: a0 b1 + a1 b0 < 2^63 + 2^62 never carries out of 64 bits, so the cross
+// terms ride v_mad_u64_u32's 64-bit addend: 5 multiply-adds + 4 v_mul_lo_u32, no v_mul_hi_u32, no carry chains.
+__device__ __forceinline__ uint64_t shoup_headroom(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
+    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf_half), b1 = hi32(wf_half);
+    uint64_t cross, q, carry;
+    asm("v_mad_u64_u32 %0, %2, %3, %6, 0\n\t"
+        "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+        "v_lshrrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %1, %2, %4, %6, %0"
+        : "=&v"(cross), "=&v"(q), "=&s"(carry)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
+    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
+    uint64_t acc, carry2;
+    uint32_t u0, u1, u2, u3;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
+        "v_mul_lo_u32 %1, %6, %9\n\t"
+        "v_mul_lo_u32 %2, %7, %8\n\t"
+        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
+        "v_mul_lo_u32 %3, %10, %13\n\t"
+        "v_mul_lo_u32 %4, %11, %12\n\t"
+        "v_add3_u32 %1, %1, %2, %3"
+        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
+        : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
+    return pack64(lo32(acc), hi32(acc) + u0 + u3);
+}
+
 __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
     return csub(shoup_lazy(x, w, wf, 0 - p), p);
 }

@@ -22,6 +22,7 @@ enum {
     kNttVariantPipelinedBase = 4,
     kNttVariantTiled = 8,
     kNttVariantWidest = 9,  // tiled kernel, 1024 lanes x 8 words (N = 8192 only)
+    kNttVariantApprox = 10, // production kernel pinned to the [0, 8p) schedule (no headroom mode)
     kNttVariantAblateBase = 16
 };
 bool ntt_pipelined_supports(uint32_t log_degree);

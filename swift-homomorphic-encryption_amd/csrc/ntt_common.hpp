@@ -69,26 +69,54 @@ __device__ __forceinline__ void lds_transpose_fence() {
     }
 }
 
-template <bool APPROX>
+// Butterfly arithmetic modes (chosen per launch from the moduli the launch covers):
+//   kModeExact    any p <= 2^62 - 1 : exact Shoup quotient, products in [0, 2p), values in [0, 4p)
+//   kModeApprox   p < 2^61          : 3-multiply quotient estimate, products in [0, 4p), values in [0, 8p)
+//   kModeHeadroom 2^40 <= p < 2^55  : shoup_headroom (products in [0, 8p)), and the spare top bits absorb the growth
+//                                     instead of a conditional subtract per butterfly: the forward transform never
+//                                     folds (a word gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62),
+//                                     the inverse folds only once sums could pass 2^6 p (its multiplicand x + B - y
+//                                     must stay < 2^62); one float-estimated quotient brings forward outputs back
+//                                     to [0, p).
+constexpr int kModeExact = 0, kModeApprox = 1, kModeHeadroom = 2;
+
+template <int MODE>
 struct Lazy {
-    // values live in [0, BOUND * p)
-    static constexpr int kBound = APPROX ? 8 : 4;
-    __device__ static __forceinline__ uint64_t mul(uint64_t x, U64x2 w, uint64_t neg_p) {
-        if constexpr (APPROX) {
-            return shoup_lazy4(x, w.x, w.y, neg_p);
+    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;  // products < p << this
+    // cap on stage inputs of the inverse transform, as a shift of p
+    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 6;
+    // twiddle as the butterflies want it: headroom mode multiplies by floor(w 2^63 / p) = wf >> 1
+    __device__ static __forceinline__ U64x2 prepare(U64x2 w) {
+        if constexpr (MODE == kModeHeadroom) w.y >>= 1;
+        return w;
+    }
+    // `reduction` = 2^64 - p (exact / approx, in VGPRs) or 2^64 - 2p (headroom, uniform)
+    __device__ static __forceinline__ uint64_t mul(uint64_t x, U64x2 w, uint64_t reduction) {
+        if constexpr (MODE == kModeHeadroom) {
+            return shoup_headroom(x, w.x, w.y, reduction);
+        } else if constexpr (MODE == kModeApprox) {
+            return shoup_lazy4(x, w.x, w.y, reduction);
         } else {
-            return shoup_lazy(x, w.x, w.y, neg_p);
+            return shoup_lazy(x, w.x, w.y, reduction);
+        }
+    }
+    __device__ static __forceinline__ uint64_t reduction_constant(uint64_t p) {
+        if constexpr (MODE == kModeHeadroom) {
+            return 0 - 2 * p;
+        } else {
+            return opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
         }
     }
 };
 
 // ---- forward pass over element bits [LO, LO+W): stages run from the top bit down --------------------------------
-template <int LOGN, int LOGE, int LO, int W, bool APPROX, bool UNIFORM_TWIDDLES, int ABLATE = 0>
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ABLATE = 0>
 __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
                                              uint64_t p, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
-    const uint64_t neg_p = opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
-    const uint64_t half_bound = (APPROX ? 4 : 2) * p;  // Harvey: fold x into [0, half_bound) before the butterfly
+    const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
+    const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
+    static_assert(MODE != kModeHeadroom || 1 + 8 * LOGN <= 127, "headroom mode: growth must stay below 2^7 p");
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + W - 1 - j;         // element bit paired by this stage
@@ -100,13 +128,14 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
             // is one address per stage and the register part an immediate offset
             const U64x2* const tw_stage = tw + (1u << s) + (lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1));
             // ABLATE bit 0 (measurement only, wrong results): one wave-uniform twiddle instead of the gather
-            const U64x2 w = (ABLATE & 1) ? tw[(1u << s)] : tw_stage[register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)];
+            const U64x2 w = Lazy<MODE>::prepare(
+                (ABLATE & 1) ? tw[(1u << s)] : tw_stage[register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)]);
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 uint64_t x = v[base + o];
                 const uint64_t y = v[base + o + stride];
-                if (!(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
-                const uint64_t t = Lazy<APPROX>::mul(y, w, neg_p);
+                if (MODE != kModeHeadroom && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
+                const uint64_t t = Lazy<MODE>::mul(y, w, neg_p);
                 v[base + o] = x + t;
                 v[base + o + stride] = x + half_bound - t;
             }
@@ -117,26 +146,33 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
 
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
-template <int LOGN, int LOGE, int LO, int W, bool APPROX>
+template <int LOGN, int LOGE, int LO, int W, int MODE>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
                                              const DeviceModulus& mod, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
     constexpr uint32_t N = 1u << LOGN;
     const uint64_t p = mod.p;
-    const uint64_t neg_p = opaque(0 - p);
-    const uint64_t bound = (APPROX ? 4 : 2) * p;  // inputs/outputs of a stage live in [0, bound)
+    const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
+    // Words entering the stage on element bit b live in [0, p << in_shift(b)): canonical input for b = 0; after
+    // that sums double the bound and products are < p << K (K = Lazy::kProductLog), so in_shift(b) = min(b + K - 1, H);
+    // once it reaches the cap H every sum is folded back under p << H.
+    constexpr int H = Lazy<MODE>::kInverseCapLog, K = Lazy<MODE>::kProductLog;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + j;
         const int stride = 1 << (b - LO);
         const uint32_t m = N >> (b + 1);
         const bool last_stage = (b == LOGN - 1);
+        const bool canonical_in = first_stage_canonical && j == 0;
+        const int in_shift = canonical_in ? 0 : (b + K - 1 < H ? b + K - 1 : H);
+        const uint64_t bound = p << in_shift;
+        const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
 #pragma unroll
         for (int base = 0; base < E; base += 2 * stride) {
             U64x2 w = {0, 0};
             if (!last_stage)
-                w = (tw + (N - 2 * m + 1) + (lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1)))
-                    [register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)];
+                w = Lazy<MODE>::prepare((tw + (N - 2 * m + 1) + (lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1)))
+                                            [register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)]);
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 const uint64_t x = v[base + o];
@@ -147,9 +183,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                     v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
                     v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                 } else {
-                    if (!(first_stage_canonical && j == 0)) sum = csub(sum, bound);
+                    if (fold) sum = csub(sum, bound);
                     v[base + o] = sum;
-                    v[base + o + stride] = Lazy<APPROX>::mul(diff, w, neg_p);
+                    v[base + o + stride] = Lazy<MODE>::mul(diff, w, neg_p);
                 }
             }
         }
@@ -204,11 +240,41 @@ __device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uin
     }
 }
 
-template <bool APPROX>
+template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
-    if constexpr (APPROX) x = csub(x, 4 * p);
+    static_assert(MODE == kModeExact || MODE == kModeApprox, "headroom outputs go through HeadroomReducer");
+    if constexpr (MODE == kModeApprox) x = csub(x, 4 * p);
     x = csub(x, 2 * p);
     return csub(x, p);
+}
+
+// x < 64 p, 2^40 <= p < 2^55  ->  x mod p, with the quotient estimated in fp32 from the high words:
+// e = (x >> 32) * (2^32 / p) * (1 - 2^-18).  The dropped low word costs < 2^32 / p <= 2^-8, the down-bias
+// < 64 * 2^-18 and fp32 rounding (three roundings, each 2^-24 relative, all dominated by the bias) keeps
+// e <= x / p, so q = floor(e) is floor(x / p) or one less and one conditional subtract finishes.
+struct HeadroomReducer {
+    uint64_t p;
+    float scale;
+    __device__ __forceinline__ explicit HeadroomReducer(uint64_t modulus)
+        : p(modulus), scale((4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus)) {}
+    __device__ __forceinline__ uint64_t operator()(uint64_t x) const {
+        const uint32_t q = static_cast<uint32_t>(static_cast<float>(static_cast<uint32_t>(x >> 32)) * scale);
+        const uint64_t qp = mad32(q, static_cast<uint32_t>(p),
+                                  static_cast<uint64_t>(mullo32(q, static_cast<uint32_t>(p >> 32))) << 32);
+        return csub(x - qp, p);
+    }
+};
+
+template <int MODE, int N>
+__device__ __forceinline__ void canonicalize_all(uint64_t (&v)[N], uint64_t p) {
+    if constexpr (MODE == kModeHeadroom) {
+        const HeadroomReducer reduce(p);
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = reduce(v[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = canonicalize<MODE>(v[r], p);
+    }
 }
 
 // Pass schedule: P = ceil(LOGN / LOGE) passes; the partial pass (R = LOGN - (P-1) LOGE bits) sits on the low bits,

@@ -43,7 +43,7 @@ __device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
     }
 }
 
-template <int LOGN, int LOGT, bool APPROX, int ABLATE = 0>
+template <int LOGN, int LOGT, int MODE, int ABLATE = 0>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
@@ -62,9 +62,8 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 
     if constexpr (S::P == 1) {
         global_load<LOGN, LOGE, 0, LOGN>(v, tid, x);
-        forward_pass<LOGN, LOGE, 0, LOGN, APPROX, true>(v, tid, tw, p, true);
-#pragma unroll
-        for (int r = 0; r < E; ++r) v[r] = canonicalize<APPROX>(v[r], p);
+        forward_pass<LOGN, LOGE, 0, LOGN, MODE, true>(v, tid, tw, p, true);
+        canonicalize_all<MODE>(v, p);
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
@@ -85,7 +84,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
             global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
         }
         stamp<ABLATE>(1, true, false);
-        forward_pass<LOGN, LOGE, LO0, LOGE, APPROX, true, ABLATE>(v, tid, tw, p, true);
+        forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ABLATE>(v, tid, tw, p, true);
         stamp<ABLATE>(2, false, false);
         if constexpr (!(ABLATE & 2)) {
             lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds);
@@ -96,7 +95,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
             constexpr int LO1 = LOGN - 2 * LOGE;
             if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
             stamp<ABLATE>(4, false, true);
-            forward_pass<LOGN, LOGE, LO1, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             stamp<ABLATE>(5, true, false);
             if constexpr (!(ABLATE & 2)) {
                 lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
@@ -107,7 +106,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         if constexpr (S::P >= 4) {
             constexpr int LO2 = LOGN - 3 * LOGE;
             if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO2, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             if constexpr (!(ABLATE & 2)) {
                 lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
                 lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>();
@@ -116,15 +115,14 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         if constexpr (S::P >= 5) {
             constexpr int LO3 = LOGN - 4 * LOGE;
             lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO3, LOGE, APPROX, false, ABLATE>(v, tid, tw, p, false);
+            forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
             lds_transpose_fence<LOGN, LOGE, LO3, 0>();
         }
         if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
         stamp<ABLATE>(7, false, true);
-        forward_pass<LOGN, LOGE, 0, S::R, APPROX, false, ABLATE>(v, tid, tw, p, false);
-#pragma unroll
-        for (int r = 0; r < E; ++r) v[r] = canonicalize<APPROX>(v[r], p);
+        forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ABLATE>(v, tid, tw, p, false);
+        canonicalize_all<MODE>(v, p);
         stamp<ABLATE>(8, true, false);
         if constexpr (ABLATE & 4) {
             uint64_t sum = 0;
@@ -138,7 +136,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     }
 }
 
-template <int LOGN, int LOGT, bool APPROX>
+template <int LOGN, int LOGT, int MODE>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
     constexpr int LOGE = LOGN - LOGT;
@@ -156,38 +154,38 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 
     if constexpr (S::P == 1) {
         global_load<LOGN, LOGE, 0, LOGN>(v, tid, x);
-        inverse_pass<LOGN, LOGE, 0, LOGN, APPROX>(v, tid, tw, mod, true);
+        inverse_pass<LOGN, LOGE, 0, LOGN, MODE>(v, tid, tw, mod, true);
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
         global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
-        inverse_pass<LOGN, LOGE, 0, S::R, APPROX>(v, tid, tw, mod, true);
+        inverse_pass<LOGN, LOGE, 0, S::R, MODE>(v, tid, tw, mod, true);
         lds_store<LOGN, LOGE, 0, S::R>(v, tid, lds);
         if constexpr (S::P >= 3) {
             lds_transpose_fence<LOGN, LOGE, 0, S::R>();
             constexpr int LO1 = S::R;
             lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO1, LOGE, APPROX>(v, tid, tw, mod, false);
+            inverse_pass<LOGN, LOGE, LO1, LOGE, MODE>(v, tid, tw, mod, false);
             lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
         }
         if constexpr (S::P >= 4) {
             lds_transpose_fence<LOGN, LOGE, S::R, S::R + LOGE>();
             constexpr int LO2 = S::R + LOGE;
             lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO2, LOGE, APPROX>(v, tid, tw, mod, false);
+            inverse_pass<LOGN, LOGE, LO2, LOGE, MODE>(v, tid, tw, mod, false);
             lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
         }
         if constexpr (S::P >= 5) {
             lds_transpose_fence<LOGN, LOGE, S::R + LOGE, S::R + 2 * LOGE>();
             constexpr int LO3 = S::R + 2 * LOGE;
             lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO3, LOGE, APPROX>(v, tid, tw, mod, false);
+            inverse_pass<LOGN, LOGE, LO3, LOGE, MODE>(v, tid, tw, mod, false);
             lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
         }
         __syncthreads();
         constexpr int LOL = LOGN - LOGE;
         lds_load<LOGN, LOGE, LOL, LOGE>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LOL, LOGE, APPROX>(v, tid, tw, mod, false);
+        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE>(v, tid, tw, mod, false);
         global_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
     }
 }
@@ -221,8 +219,8 @@ __global__ void __launch_bounds__(256)
             const uint64_t tv = shoup_lazy(buf[a + t], w.x, w.y, neg_p);
             uint64_t xo = xv + tv, yo = xv + two_p - tv;
             if (last) {
-                xo = canonicalize<false>(xo, p);
-                yo = canonicalize<false>(yo, p);
+                xo = canonicalize<kModeExact>(xo, p);
+                yo = canonicalize<kModeExact>(yo, p);
             }
             buf[a] = xo;
             buf[a + t] = yo;
@@ -275,16 +273,20 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int LOGN, int LOGT>
-hipError_t launch_tiled(bool inverse, bool approx, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
     using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t);
     Kernel kernel;
     if (inverse) {
-        kernel = approx ? ntt_inverse_tiled<LOGN, LOGT, true> : ntt_inverse_tiled<LOGN, LOGT, false>;
+        kernel = mode == kModeHeadroom ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
+                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
+                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
     } else {
-        kernel = approx ? ntt_forward_tiled<LOGN, LOGT, true> : ntt_forward_tiled<LOGN, LOGT, false>;
+        kernel = mode == kModeHeadroom ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom>
+                 : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox>
+                                       : ntt_forward_tiled<LOGN, LOGT, kModeExact>;
     }
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -300,7 +302,7 @@ template <int ABLATE>
 hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                            size_t rows, hipStream_t stream) {
     constexpr size_t lds_bytes = lds_words(1u << 13) * sizeof(uint64_t);
-    auto kernel = ntt_forward_tiled<13, 8, true, ABLATE>;
+    auto kernel = ntt_forward_tiled<13, 8, kModeApprox, ABLATE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
@@ -317,9 +319,9 @@ hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer) {
 
 const char* ntt_variant_name(uint32_t log_degree) {
     switch (log_degree) {
-        case 12: return "tiled<4096,256thr,16/lane>";
-        case 13: return "tiled<8192,256thr,32/lane>";
-        case 14: return "tiled<16384,512thr,32/lane>";
+        case 12: return "ntt_tiled<4096, 512 lanes x 8 words>";
+        case 13: return "ntt_tiled<8192, 1024 lanes x 8 words>";
+        case 14: return "ntt_tiled<16384, 1024 lanes x 16 words>";
         default: return "generic radix-2";
     }
 }
@@ -355,6 +357,10 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         }
     }
     const bool approx = ctx.approx_ok != 0 && force_variant != kNttVariantExact && force_variant != kNttVariantGeneric;
+    // kNttVariantApprox pins the [0, 8p) schedule even when the moduli leave headroom (measurement / tests)
+    const int mode = !approx ? kModeExact
+                     : (ctx.headroom_ok != 0 && force_variant != kNttVariantApprox) ? kModeHeadroom
+                                                                                     : kModeApprox;
     if (ntt_pipelined_supports(ctx.log_degree) && force_variant >= kNttVariantPipelinedBase &&
         force_variant < kNttVariantPipelinedBase + 4) {
         // persistent / software-prefetching kernels: kept as measured alternatives (they lose to plain occupancy,
@@ -362,23 +368,31 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         return launch_ntt_pipelined(inverse, approx, force_variant - kNttVariantPipelinedBase, slab, ctx, mod_base,
                                     mod_period, rows, stream);
     }
-    if (force_variant == kNttVariantWidest && ctx.log_degree == 13)
-        return launch_tiled<13, 10>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
-    // production choice (auto): the tiled kernel with 16 words per lane -- 16 waves per CU hide the latencies that
-    // 32 words per lane (8 waves per CU) leave exposed; the VALU is then ~96 % busy
-    if (force_variant == kNttVariantWide || force_variant == kNttVariantAuto || force_variant == kNttVariantExact) {
+    // production choice (auto): 8 words per lane wherever a workgroup of <= 1024 lanes allows it.  Two rows fit the
+    // CU's LDS at a time, so the waves per CU -- what hides the global/LDS latencies -- are set by the lanes per row:
+    // 32 waves per CU with 8 words per lane against 16 with 16 words (measured: profiles/r01c_ntt_variants.txt).
+    if (force_variant == kNttVariantAuto || force_variant == kNttVariantExact || force_variant == kNttVariantApprox ||
+        force_variant == kNttVariantWidest) {
         switch (ctx.log_degree) {
-            case 12: return launch_tiled<12, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
-            case 13: return launch_tiled<13, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
-            case 14: return launch_tiled<14, 10>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+            case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            default: break;
+        }
+    }
+    if (force_variant == kNttVariantWide) {  // 16 words per lane
+        switch (ctx.log_degree) {
+            case 12: return launch_tiled<12, 8>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 13: return launch_tiled<13, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             default: break;
         }
     }
     if (force_variant != kNttVariantGeneric) {
-        switch (ctx.log_degree) {
-            case 12: return launch_tiled<12, 8>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
-            case 13: return launch_tiled<13, 8>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
-            case 14: return launch_tiled<14, 9>(inverse, approx, slab, ctx, mod_base, mod_period, rows, stream);
+        switch (ctx.log_degree) {  // kNttVariantTiled: 32 words per lane
+            case 12: return launch_tiled<12, 7>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 13: return launch_tiled<13, 8>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 14: return launch_tiled<14, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             default: break;
         }
     }

@@ -75,7 +75,7 @@ def test_ntt_matches_oracle(oracle, degree, bits, batch):
 
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55]), (8192, [55, 55, 55, 55]), (16384, [55, 55])])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_ntt_kernel_variants_agree(oracle, degree, bits, variant):
     """exact-quotient tiled kernel (1), generic radix-2 kernel (2), 2x-wide workgroup tiled kernel (3) vs the oracle."""
     moduli = oracle.generate_primes(bits, False, degree)
@@ -85,6 +85,32 @@ def test_ntt_kernel_variants_agree(oracle, degree, bits, variant):
     slab = _rand_slab(rng, 2 if variant < 4 else 300, moduli, degree)  # > 2 x CUs rows: persistent kernels loop
     assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), False, variant)), ref.forward_ntt(slab))
     assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), True, variant)), ref.inverse_ntt(slab))
+
+
+@pytest.mark.parametrize("degree", [4096, 8192, 16384])
+@pytest.mark.parametrize("bits", [[55, 55, 54], [41, 41], [48, 55]])
+def test_ntt_headroom_mode_extremes(oracle, degree, bits):
+    """Moduli in [2^40, 2^55) take the fold-free schedule (ntt_common.hpp kModeHeadroom): drive it with the inputs that
+    grow fastest (all q-1, alternating 0 / q-1, one-hot q-1) next to random rows and compare with the oracle."""
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + len(bits))
+    slab = _rand_slab(rng, 6, moduli, degree)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    slab[0] = top
+    slab[1] = 0
+    slab[1, :, ::2] = top
+    slab[2] = 0
+    slab[2, :, 1::2] = top
+    slab[3] = 0
+    slab[3, :, degree - 1] = top[:, 0]
+    slab[4, :, : degree // 2] = top
+    for inverse, expected in ((False, ref.forward_ntt(slab)), (True, ref.inverse_ntt(slab))):
+        got = heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), inverse, 0))
+        assert np.array_equal(got, expected)
+        pinned = heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), inverse, 10))
+        assert np.array_equal(pinned, expected)
 
 
 def test_ntt_multiplication_matches_schoolbook(oracle):
