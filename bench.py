@@ -127,10 +127,9 @@ def main():
     import torch
 
     import heamd
+    from heamd import sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = sharding.rank_and_world()
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -144,7 +143,10 @@ def main():
 
     moduli = heamd.generate_primes(MODULI_BITS, False, DEGREE)
     ctx = heamd.PolyContext(DEGREE, moduli)
-    slab = synthetic_slab(torch, moduli, args.batch, DEGREE, seed=0x5EED + rank)
+    # weak scaling: the job is batch * world polynomials, rank r owns the contiguous shard [begin, end)
+    total_polys = args.batch * world
+    begin, end = sharding.shard_bounds(total_polys, world, rank)
+    slab = synthetic_slab(torch, moduli, end - begin, DEGREE, seed=0x5EED + rank)
 
     def step():
         ctx.forward_ntt_(slab)
@@ -163,9 +165,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if distributed:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = sharding.max_over_ranks(elapsed, device="cuda")
 
     # ---- separately timed kernels (rank 0 reports): forward is the dominant kernel for the roofline figure
     forward_s = time_kernel(torch, lambda: ctx.forward_ntt_(slab), max(5, args.steps))
@@ -176,11 +176,11 @@ def main():
     gather_ms = None
     if distributed and not args.skip_gather:
         # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI)
-        out = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device="cuda")
-        dist.all_gather_into_tensor(out.view(-1), slab.view(-1))
+        out = sharding.gather_shards(slab, total_polys)
         torch.cuda.synchronize()
+        del out
         t1 = time.perf_counter()
-        dist.all_gather_into_tensor(out.view(-1), slab.view(-1))
+        out = sharding.gather_shards(slab, total_polys)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
         del out

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: two processes over gloo exercise the product's sharding / gather / clock-reduction helpers
+(heamd/sharding.py, used by bench.py with RCCL on GPUs).  The per-shard compute here is the CPU oracle -- this test
+is about who owns which polynomials and that the gathered job equals the unsharded transform, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for extra in (ROOT, os.path.join(ROOT, "swift-homomorphic-encryption_amd")):
+    if extra not in sys.path:
+        sys.path.insert(0, extra)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _global_slab(total, moduli, degree):
+    rng = np.random.default_rng(20240924)
+    return np.stack([rng.integers(0, q, size=(total, degree), dtype=np.uint64) for q in moduli], axis=1).copy()
+
+
+def _worker(rank, world, port, total, degree, bits, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from heamd import sharding
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        assert sharding.rank_and_world() == (rank, rank, world)
+        moduli = oracle.generate_primes(bits, False, degree)
+        ctx = oracle.PolyContext(degree, moduli)
+        full = _global_slab(total, moduli, degree)
+        begin, end = sharding.shard_bounds(total, world, rank)
+        shard = full[begin:end].copy()
+        if end > begin:
+            ctx.forward_ntt_inplace(shard, threads=1)
+        local = torch.from_numpy(shard.view(np.int64))
+        gathered = sharding.gather_shards(local, total)
+        got = gathered.numpy().view(np.uint64)
+        expected = ctx.forward_ntt(full) if total else full
+        slowest = sharding.max_over_ranks(1.0 + rank)
+        results[rank] = (bool(np.array_equal(got, expected)), tuple(got.shape), slowest, (begin, end))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7, 1])
+def test_two_rank_sharded_ntt_matches_unsharded(total):
+    import torch.multiprocessing as mp
+
+    world, degree, bits = 2, 256, [40, 41]
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_worker, args=(world, _free_port(), total, degree, bits, results), nprocs=world, join=True)
+    assert sorted(results.keys()) == [0, 1]
+    covered = []
+    for rank in range(world):
+        equal, shape, slowest, bounds = results[rank]
+        assert equal, f"rank {rank}: gathered result differs from the unsharded transform"
+        assert shape == (total, len(bits), degree)
+        assert slowest == 2.0  # MAX over ranks of (1 + rank)
+        covered.append(bounds)
+    assert covered[0][0] == 0 and covered[0][1] == covered[1][0] and covered[1][1] == total
+
+
+def test_shard_bounds_partition():
+    from heamd import sharding
+
+    for total in (0, 1, 5, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            edges = [sharding.shard_bounds(total, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sharding.shard_sizes(total, world)
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
