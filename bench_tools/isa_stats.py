@@ -53,7 +53,7 @@ def main():
         slots = sum(c * SLOTS.get(o, 1) for o, c in ops.items() if o.startswith("v_"))
         print(f"== {name}\n   {meta.get(name)}\n   instructions {sum(ops.values())}  VALU {valu}  est. VALU slots {slots}"
               f"  s_nop {ops.get('s_nop', 0)}  s_waitcnt {ops.get('s_waitcnt', 0)}")
-        print("   " + "  ".join(f"{o}:{c}" for o, c in ops.most_common(28)))
+        print("   " + "  ".join(f"{o}:{c}" for o, c in ops.most_common(70)))
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ import heamd  # noqa: E402
 NAMES = {0: "auto", 1: "auto-exact", 2: "generic", 3: "tiled-wide", 4: "pipe f0", 5: "pipe f1(pref)", 6: "pipe f2(stag)", 7: "pipe f3(both)", 8: "tiled", 9: "tiled-1024thr", 10: "auto-approx"}
 
 
-def run(degree, bits, batch, variants=(0, 1, 3), reps=10):
+def run(degree, bits, batch, variants=(0, 1, 3), reps=30):
     moduli = heamd.generate_primes(bits, False, degree)
     ctx = heamd.PolyContext(degree, moduli)
     bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
@@ -20,7 +20,7 @@ def run(degree, bits, batch, variants=(0, 1, 3), reps=10):
     bytes_per = 2 * len(moduli) * degree * 8 * batch
     for variant in variants:
         for inverse in (False, True):
-            for _ in range(3):
+            for _ in range(10):
                 ctx.ntt_variant_(x, inverse, variant)
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -36,6 +36,6 @@ def run(degree, bits, batch, variants=(0, 1, 3), reps=10):
 
 
 if __name__ == "__main__":
-    run(8192, [55] * 4, 4096, variants=(0, 10, 1, 9, 8))
+    run(8192, [55] * 4, 4096, variants=(9, 0, 9, 0, 10, 1, 3, 8))
     run(4096, [55] * 2, 8192, variants=(0, 10, 1))
     run(16384, [55] * 4, 1024, variants=(0, 10, 1))

@@ -28,6 +28,10 @@ struct DeviceContext {
     const U64x2* forward_twiddles; // [L][N]  (w, floor(w 2^64 / p)), bit-reversed order   PolyRq+Ntt.swift:125-143
     const U64x2* inverse_twiddles; // [L][N]  stage-major re-ordered                       PolyRq+Ntt.swift:146-157
     const U64x2* inverse_q_last;   // [L][L]  row k: (q_{k}^-1 mod q_i, Shoup) for i < k   PolyContext.swift:108-111
+    // the same tables with the Shoup factor halved, (w, floor(w 2^63 / p)): what the headroom butterflies multiply by.
+    // Present (non-null) only when every modulus of the context is in [2^40, 2^55).
+    const U64x2* forward_twiddles_half;
+    const U64x2* inverse_twiddles_half;
     uint32_t degree;
     uint32_t log_degree;
     uint32_t moduli_count;         // active moduli (a prefix of the context's list)

@@ -69,6 +69,14 @@ __device__ __forceinline__ void lds_transpose_fence() {
     }
 }
 
+// Twiddle tables never change while a context lives: read them through the constant address space, so that a
+// wave-uniform address becomes a scalar-cache load (s_load_dwordx4) wherever it sits relative to barriers.
+__device__ __forceinline__ U64x2 load_twiddle(const U64x2* entry) {
+    using ConstWord = const __attribute__((address_space(4))) uint64_t;
+    ConstWord* const words = (ConstWord*)(entry);
+    return U64x2{words[0], words[1]};
+}
+
 // Butterfly arithmetic modes (chosen per launch from the moduli the launch covers):
 //   kModeExact    any p <= 2^62 - 1 : exact Shoup quotient, products in [0, 2p), values in [0, 4p)
 //   kModeApprox   p < 2^61          : 3-multiply quotient estimate, products in [0, 4p), values in [0, 8p)
@@ -78,21 +86,27 @@ __device__ __forceinline__ void lds_transpose_fence() {
 //                                     the inverse folds only once sums could pass 2^6 p (its multiplicand x + B - y
 //                                     must stay < 2^62); one float-estimated quotient brings forward outputs back
 //                                     to [0, p).
-constexpr int kModeExact = 0, kModeApprox = 1, kModeHeadroom = 2;
+//   kModeHeadroomHalved             : kModeHeadroom reading the context's pre-halved Shoup factors
+constexpr int kModeExact = 0, kModeApprox = 1, kModeHeadroom = 2, kModeHeadroomHalved = 3;
+constexpr bool is_headroom(int mode) { return mode == kModeHeadroom || mode == kModeHeadroomHalved; }
 
 template <int MODE>
 struct Lazy {
+    static constexpr bool kHeadroom = is_headroom(MODE);
     static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;  // products < p << this
     // cap on stage inputs of the inverse transform, as a shift of p
     static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 6;
     // twiddle as the butterflies want it: headroom mode multiplies by floor(w 2^63 / p) = wf >> 1
     __device__ static __forceinline__ U64x2 prepare(U64x2 w) {
-        if constexpr (MODE == kModeHeadroom) w.y >>= 1;
+        if constexpr (MODE == kModeHeadroom) w.y >>= 1;  // kModeHeadroomHalved: the table already holds wf >> 1
         return w;
     }
     // `reduction` = 2^64 - p (exact / approx, in VGPRs) or 2^64 - 2p (headroom, uniform)
+    template <bool UNIFORM = false>
     __device__ static __forceinline__ uint64_t mul(uint64_t x, U64x2 w, uint64_t reduction) {
-        if constexpr (MODE == kModeHeadroom) {
+        if constexpr (kHeadroom && UNIFORM) {
+            return shoup_headroom_uniform(x, w.x, w.y, reduction);
+        } else if constexpr (kHeadroom) {
             return shoup_headroom(x, w.x, w.y, reduction);
         } else if constexpr (MODE == kModeApprox) {
             return shoup_lazy4(x, w.x, w.y, reduction);
@@ -101,7 +115,7 @@ struct Lazy {
         }
     }
     __device__ static __forceinline__ uint64_t reduction_constant(uint64_t p) {
-        if constexpr (MODE == kModeHeadroom) {
+        if constexpr (kHeadroom) {
             return 0 - 2 * p;
         } else {
             return opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
@@ -116,37 +130,45 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
     constexpr int E = 1 << LOGE;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
-    static_assert(MODE != kModeHeadroom || 1 + 8 * LOGN <= 127, "headroom mode: growth must stay below 2^7 p");
+    static_assert(!is_headroom(MODE) || 1 + 8 * LOGN <= 127, "headroom mode: growth must stay below 2^7 p");
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + W - 1 - j;         // element bit paired by this stage
         const int s = LOGN - 1 - b;           // global stage number; m = 2^s groups
         const int stride = 1 << (b - LO);     // register distance of a pair
+        // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint, so the lane part is
+        // one address per stage and the register part an immediate offset.  When the six in-wave lane bits all sit
+        // at or below b the index is the same for the whole wave: read it through the scalar cache into SGPRs.
+        const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
+        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+        const U64x2* const tw_stage = tw + (1u << s) + lane_twiddle;
 #pragma unroll
         for (int base = 0; base < E; base += 2 * stride) {
-            // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint, so the lane part
-            // is one address per stage and the register part an immediate offset
-            const U64x2* const tw_stage = tw + (1u << s) + (lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1));
             // ABLATE bit 0 (measurement only, wrong results): one wave-uniform twiddle instead of the gather
             const U64x2 w = Lazy<MODE>::prepare(
-                (ABLATE & 1) ? tw[(1u << s)] : tw_stage[register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)]);
+                load_twiddle((ABLATE & 1) ? tw + (1u << s) : tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1))));
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 uint64_t x = v[base + o];
                 const uint64_t y = v[base + o + stride];
-                if (MODE != kModeHeadroom && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
-                const uint64_t t = Lazy<MODE>::mul(y, w, neg_p);
+                if (!is_headroom(MODE) && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
+                uint64_t t;
+                if (uniform && !(ABLATE & 1)) {
+                    t = Lazy<MODE>::template mul<true>(y, w, neg_p);
+                } else {
+                    t = Lazy<MODE>::template mul<false>(y, w, neg_p);
+                }
                 v[base + o] = x + t;
                 v[base + o + stride] = x + half_bound - t;
             }
         }
     }
-    (void)UNIFORM_TWIDDLES;
 }
 
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
-template <int LOGN, int LOGE, int LO, int W, int MODE>
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES = false>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
                                              const DeviceModulus& mod, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
@@ -167,12 +189,15 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
         const int in_shift = canonical_in ? 0 : (b + K - 1 < H ? b + K - 1 : H);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
+        const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
+        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+        const U64x2* const tw_stage = tw + (N - 2 * m + 1) + lane_twiddle;
 #pragma unroll
         for (int base = 0; base < E; base += 2 * stride) {
             U64x2 w = {0, 0};
             if (!last_stage)
-                w = Lazy<MODE>::prepare((tw + (N - 2 * m + 1) + (lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1)))
-                                            [register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)]);
+                w = Lazy<MODE>::prepare(load_twiddle(tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1))));
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 const uint64_t x = v[base + o];
@@ -185,7 +210,11 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                 } else {
                     if (fold) sum = csub(sum, bound);
                     v[base + o] = sum;
-                    v[base + o + stride] = Lazy<MODE>::mul(diff, w, neg_p);
+                    if (uniform) {
+                        v[base + o + stride] = Lazy<MODE>::template mul<true>(diff, w, neg_p);
+                    } else {
+                        v[base + o + stride] = Lazy<MODE>::template mul<false>(diff, w, neg_p);
+                    }
                 }
             }
         }
@@ -200,6 +229,7 @@ __device__ __forceinline__ void lds_store(const uint64_t (&v)[1 << LOGE], uint32
 }
 template <int LOGN, int LOGE, int LO, int W>
 __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* lds) {
+    // (tried: volatile reads to keep single ds_read_b64 instead of merged ds_read2_b64 -- 1.5 % slower, r01d notes)
     const uint64_t* const base = lds + lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
 #pragma unroll
     for (int r = 0; r < (1 << LOGE); ++r) v[r] = base[lds_slot(register_part<LOGN, LOGE, LO, W>(r))];
@@ -241,6 +271,15 @@ __device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uin
 }
 
 template <int MODE>
+__device__ __forceinline__ const U64x2* twiddle_table(const DeviceContext& ctx, bool inverse) {
+    if constexpr (MODE == kModeHeadroomHalved) {
+        return inverse ? ctx.inverse_twiddles_half : ctx.forward_twiddles_half;
+    } else {
+        return inverse ? ctx.inverse_twiddles : ctx.forward_twiddles;
+    }
+}
+
+template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
     static_assert(MODE == kModeExact || MODE == kModeApprox, "headroom outputs go through HeadroomReducer");
     if constexpr (MODE == kModeApprox) x = csub(x, 4 * p);
@@ -258,7 +297,9 @@ struct HeadroomReducer {
     __device__ __forceinline__ explicit HeadroomReducer(uint64_t modulus)
         : p(modulus), scale((4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus)) {}
     __device__ __forceinline__ uint64_t operator()(uint64_t x) const {
-        const uint32_t q = static_cast<uint32_t>(static_cast<float>(static_cast<uint32_t>(x >> 32)) * scale);
+        float high;  // asm: hipcc otherwise converts through its generic 64-bit path (7 instructions)
+        asm("v_cvt_f32_u32 %0, %1" : "=v"(high) : "v"(hi32(x)));
+        const uint32_t q = static_cast<uint32_t>(high * scale);
         const uint64_t qp = mad32(q, static_cast<uint32_t>(p),
                                   static_cast<uint64_t>(mullo32(q, static_cast<uint32_t>(p >> 32))) << 32);
         return csub(x - qp, p);
@@ -267,7 +308,7 @@ struct HeadroomReducer {
 
 template <int MODE, int N>
 __device__ __forceinline__ void canonicalize_all(uint64_t (&v)[N], uint64_t p) {
-    if constexpr (MODE == kModeHeadroom) {
+    if constexpr (is_headroom(MODE)) {
         const HeadroomReducer reduce(p);
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = reduce(v[r]);

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     const size_t row = blockIdx.x;
     const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
     const DeviceModulus mod = ctx.moduli[mi];
-    const U64x2* __restrict__ tw = ctx.forward_twiddles + (static_cast<size_t>(mi) << LOGN);
+    const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, false) + (static_cast<size_t>(mi) << LOGN);
     uint64_t* __restrict__ x = slab + (row << LOGN);
     const uint64_t p = mod.p;
     uint64_t v[E];
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
                 g_ntt_timeline[static_cast<size_t>(blockIdx.x) * 16 + 15] = (static_cast<uint64_t>(xcc_id) << 32) | hw_id;
             }
         }
-        if constexpr (ABLATE & 4) {
+        if constexpr (ABLATE & (4 | 32)) {  // bit 5: skip the load only
 #pragma unroll
             for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
         } else {
@@ -114,17 +114,19 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         }
         if constexpr (S::P >= 5) {
             constexpr int LO3 = LOGN - 4 * LOGE;
-            lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
             forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
-            lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-            lds_transpose_fence<LOGN, LOGE, LO3, 0>();
+            if constexpr (!(ABLATE & 2)) {
+                lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+                lds_transpose_fence<LOGN, LOGE, LO3, 0>();
+            }
         }
         if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
         stamp<ABLATE>(7, false, true);
         forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ABLATE>(v, tid, tw, p, false);
         canonicalize_all<MODE>(v, p);
         stamp<ABLATE>(8, true, false);
-        if constexpr (ABLATE & 4) {
+        if constexpr (ABLATE & (4 | 64)) {  // bit 6: skip the store only
             uint64_t sum = 0;
 #pragma unroll
             for (int r = 0; r < E; ++r) sum ^= v[r];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     const size_t row = blockIdx.x;
     const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
     const DeviceModulus mod = ctx.moduli[mi];
-    const U64x2* __restrict__ tw = ctx.inverse_twiddles + (static_cast<size_t>(mi) << LOGN);
+    const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, true) + (static_cast<size_t>(mi) << LOGN);
     uint64_t* __restrict__ x = slab + (row << LOGN);
     uint64_t v[E];
 
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         __syncthreads();
         constexpr int LOL = LOGN - LOGE;
         lds_load<LOGN, LOGE, LOL, LOGE>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE>(v, tid, tw, mod, false);
+        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true>(v, tid, tw, mod, false);  // top bits: wave-uniform twiddles
         global_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
     }
 }
@@ -280,11 +282,13 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t);
     Kernel kernel;
     if (inverse) {
-        kernel = mode == kModeHeadroom ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
+        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
+                 : mode == kModeHeadroom ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
                  : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
                                        : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
     } else {
-        kernel = mode == kModeHeadroom ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom>
+        kernel = mode == kModeHeadroomHalved ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroomHalved>
+                 : mode == kModeHeadroom ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom>
                  : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox>
                                        : ntt_forward_tiled<LOGN, LOGT, kModeExact>;
     }
@@ -301,12 +305,14 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
 template <int ABLATE>
 hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                            size_t rows, hipStream_t stream) {
+    // the production configuration for N = 8192 (1024 lanes, headroom butterflies on the pre-halved tables)
     constexpr size_t lds_bytes = lds_words(1u << 13) * sizeof(uint64_t);
-    auto kernel = ntt_forward_tiled<13, 8, kModeApprox, ABLATE>;
+    if (ctx.forward_twiddles_half == nullptr) return hipErrorInvalidValue;
+    auto kernel = ntt_forward_tiled<13, 10, kModeHeadroomHalved, ABLATE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(256), lds_bytes, stream, slab, ctx, mod_base,
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1024), lds_bytes, stream, slab, ctx, mod_base,
                        mod_period);
     return hipGetLastError();
 }
@@ -344,6 +350,7 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
     }
     if (force_variant >= kNttVariantAblateBase && ctx.log_degree == 13 && !inverse) {
         switch (force_variant - kNttVariantAblateBase) {  // measurement-only kernels: results are NOT an NTT
+            case 0: return launch_ablation<0>(slab, ctx, mod_base, mod_period, rows, stream);
             case 1: return launch_ablation<1>(slab, ctx, mod_base, mod_period, rows, stream);
             case 2: return launch_ablation<2>(slab, ctx, mod_base, mod_period, rows, stream);
             case 3: return launch_ablation<3>(slab, ctx, mod_base, mod_period, rows, stream);
@@ -353,13 +360,18 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 9: return launch_ablation<9>(slab, ctx, mod_base, mod_period, rows, stream);
             case 15: return launch_ablation<15>(slab, ctx, mod_base, mod_period, rows, stream);
             case 16: return launch_ablation<16>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 32: return launch_ablation<32>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 64: return launch_ablation<64>(slab, ctx, mod_base, mod_period, rows, stream);
             default: return hipErrorInvalidValue;
         }
     }
     const bool approx = ctx.approx_ok != 0 && force_variant != kNttVariantExact && force_variant != kNttVariantGeneric;
     // kNttVariantApprox pins the [0, 8p) schedule even when the moduli leave headroom (measurement / tests)
     const int mode = !approx ? kModeExact
-                     : (ctx.headroom_ok != 0 && force_variant != kNttVariantApprox) ? kModeHeadroom
+                     : (ctx.headroom_ok != 0 && force_variant != kNttVariantApprox)
+                         ? (ctx.forward_twiddles_half != nullptr && force_variant != kNttVariantWidest
+                                ? kModeHeadroomHalved
+                                : kModeHeadroom)
                                                                                      : kModeApprox;
     if (ntt_pipelined_supports(ctx.log_degree) && force_variant >= kNttVariantPipelinedBase &&
         force_variant < kNttVariantPipelinedBase + 4) {

@@ -155,7 +155,10 @@ int PolyContext::upload() {
     const size_t bytes_moduli = round_up(count * sizeof(DeviceModulus));
     const size_t bytes_twiddles = round_up(count * n * sizeof(U64x2));
     const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
-    const size_t total = bytes_moduli + 2 * bytes_twiddles + bytes_inverse_q_last;
+    bool all_headroom = count > 0;
+    for (u64 q : moduli_)
+        if (q >= (static_cast<u64>(1) << 55) || q < (static_cast<u64>(1) << 40)) all_headroom = false;
+    const size_t total = bytes_moduli + (all_headroom ? 4 : 2) * bytes_twiddles + bytes_inverse_q_last;
     HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
     char* base = static_cast<char*>(device_block_);
     HEAMD_HIP_TRY(hipMemcpy(base, host_moduli_.data(), count * sizeof(DeviceModulus), hipMemcpyHostToDevice));
@@ -166,6 +169,20 @@ int PolyContext::upload() {
     HEAMD_HIP_TRY(hipMemcpy(inverse, host_inverse_.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
     HEAMD_HIP_TRY(hipMemcpy(inverse_q_last, host_inverse_q_last_.data(), count * count * sizeof(U64x2),
                             hipMemcpyHostToDevice));
+    dev_.forward_twiddles_half = nullptr;
+    dev_.inverse_twiddles_half = nullptr;
+    if (all_headroom) {
+        // (w, floor(w 2^63 / p)) = (w, wf >> 1): the factor the headroom butterflies use (ntt_common.hpp)
+        char* forward_half = inverse_q_last + bytes_inverse_q_last;
+        char* inverse_half = forward_half + bytes_twiddles;
+        std::vector<U64x2> halved(count * n);
+        for (size_t k = 0; k < count * n; ++k) halved[k] = U64x2{host_forward_[k].x, host_forward_[k].y >> 1};
+        HEAMD_HIP_TRY(hipMemcpy(forward_half, halved.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+        for (size_t k = 0; k < count * n; ++k) halved[k] = U64x2{host_inverse_[k].x, host_inverse_[k].y >> 1};
+        HEAMD_HIP_TRY(hipMemcpy(inverse_half, halved.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+        dev_.forward_twiddles_half = reinterpret_cast<const U64x2*>(forward_half);
+        dev_.inverse_twiddles_half = reinterpret_cast<const U64x2*>(inverse_half);
+    }
     dev_.moduli = reinterpret_cast<const DeviceModulus*>(base);
     dev_.forward_twiddles = reinterpret_cast<const U64x2*>(forward);
     dev_.inverse_twiddles = reinterpret_cast<const U64x2*>(inverse);
