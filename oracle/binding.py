@@ -126,6 +126,13 @@ def _declare(L):
     L.orc_bfv_inner_product_plain.argtypes = [vp, c_size, c_size, U64P, U64P, ctypes.POINTER(ctypes.c_uint8), c_size,
                                               U64P]
     L.orc_bfv_inner_product.argtypes = [vp, c_size, U64P, U64P, c_size, U64P]
+    L.orc_is_valid_galois_element.argtypes = [c_u64, c_u64]
+    L.orc_poly_apply_galois_coeff.argtypes = [vp, U64P, U64P, c_u64, c_size]
+    L.orc_poly_apply_galois_eval.argtypes = [vp, U64P, U64P, c_u64, c_size]
+    L.orc_poly_multiply_power_of_x.argtypes = [vp, U64P, ctypes.c_int64, c_size]
+    L.orc_bfv_apply_galois.argtypes = [vp, c_size, U64P, c_u64, U64P, U64P, c_size]
+    L.orc_bfv_plaintext_to_eval.argtypes = [vp, c_size, U64P, U64P, c_size]
+    L.orc_bfv_plaintext_to_coeff.argtypes = [vp, c_size, U64P, U64P, c_size]
 
 
 def _check(code):
@@ -292,6 +299,20 @@ class PolyContext:
         _check(lib().orc_poly_mul_scalar(self.h, _p(out), _p(s), self._batch(out)))
         return out
 
+    def apply_galois(self, data, element, eval_format=False):
+        """PolyRq.applyGalois (PolyRq/Galois.swift:115-168): f(x) -> f(x^element) in Coeff or Eval format."""
+        data = _u64(data)
+        out = np.zeros_like(data)
+        fn = lib().orc_poly_apply_galois_eval if eval_format else lib().orc_poly_apply_galois_coeff
+        _check(fn(self.h, _p(data), _p(out), element, self._batch(data)))
+        return out
+
+    def multiply_power_of_x(self, data, power):
+        """PolyRq<Coeff>.multiplyPowerOfX (PolyRq/PolyRq.swift:398-422)."""
+        out = _u64(data).copy()
+        _check(lib().orc_poly_multiply_power_of_x(self.h, _p(out), power, self._batch(out)))
+        return out
+
     def divide_and_round_q_last(self, data, threads=1):
         L, n = self.shape
         data = _u64(data)
@@ -445,6 +466,33 @@ class BfvContext:
         target, key = _u64(target), _u64(key)
         out = np.zeros((2, L, self.degree), dtype=np.uint64)
         _check(lib().orc_bfv_key_switching_update(self.h, L, _p(target), _p(key), _p(out)))
+        return out
+
+    def apply_galois(self, ct, element, key, moduli_count=None):
+        """Bfv.applyGalois (Bfv/Bfv.swift:174-198) on [batch][2][L][N] Coeff ciphertexts."""
+        L = self._L(moduli_count)
+        ct = _u64(ct)
+        batch = ct.size // (2 * L * self.degree)
+        out = np.zeros((batch, 2, L, self.degree), dtype=np.uint64)
+        _check(lib().orc_bfv_apply_galois(self.h, L, _p(ct), element, _p(_u64(key)), _p(out), batch))
+        return out
+
+    def plaintext_to_eval(self, plaintext, moduli_count=None):
+        """Plaintext.convertToEvalFormat (Plaintext.swift:149-170): [batch][N] mod t -> [batch][L][N]."""
+        L = self._L(moduli_count)
+        pt = _u64(plaintext)
+        batch = pt.size // self.degree
+        out = np.zeros((batch, L, self.degree), dtype=np.uint64)
+        _check(lib().orc_bfv_plaintext_to_eval(self.h, L, _p(pt), _p(out), batch))
+        return out
+
+    def plaintext_to_coeff(self, plaintext_eval, moduli_count=None):
+        """Plaintext.convertToCoeffFormat (Plaintext.swift:176-191): [batch][L][N] -> [batch][N] mod t."""
+        L = self._L(moduli_count)
+        pt = _u64(plaintext_eval)
+        batch = pt.size // (L * self.degree)
+        out = np.zeros((batch, self.degree), dtype=np.uint64)
+        _check(lib().orc_bfv_plaintext_to_coeff(self.h, L, _p(pt), _p(out), batch))
         return out
 
     def mod_switch_down(self, ct, poly_count, moduli_count=None):

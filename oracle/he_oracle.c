@@ -1657,3 +1657,144 @@ int orc_bfv_inner_product(const orc_bfv_context* ctx, size_t L, const uint64_t* 
     free(acc);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * "Next" rows of the scope table: Galois automorphisms, x^k multiplication, plaintext <-> Eval.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Galois.swift:100-105 isValidGaloisElement */
+int orc_is_valid_galois_element(uint64_t element, uint64_t degree) {
+    return degree != 0 && (degree & (degree - 1)) == 0 && (element & 1) == 1 && element < (degree << 1) && element > 1;
+}
+
+/* Galois.swift:115-143 PolyRq<Coeff>.applyGalois with GaloisCoeffIterator (:34-48):
+ * coefficient i goes to (i * element) mod N, negated when floor(i * element / N) is odd. */
+int orc_poly_apply_galois_coeff(const orc_poly_context* ctx, const uint64_t* in, uint64_t* out, uint64_t element,
+                                size_t batch) {
+    const uint64_t n = ctx->degree;
+    if (!orc_is_valid_galois_element(element, n)) return ORC_ERR_INVALID_ARGUMENT;
+    int log2n = 0;
+    while (((uint64_t)1 << log2n) < n) ++log2n;
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t r = 0; r < ctx->count; ++r) {
+            const uint64_t* src = in + (b * ctx->count + r) * n;
+            uint64_t* dst = out + (b * ctx->count + r) * n;
+            uint64_t raw_out_index = 0, out_index = 0;
+            for (uint64_t i = 0; i < n; ++i) {
+                int negate = ((raw_out_index >> log2n) & 1) != 0;
+                dst[out_index] = negate ? neg_mod(src[i], ctx->moduli[r]) : src[i];
+                raw_out_index += element;
+                out_index = raw_out_index & (n - 1);
+            }
+        }
+    return ORC_OK;
+}
+
+/* Galois.swift:153-168 PolyRq<Eval>.applyGalois with GaloisEvalIterator (:81-92):
+ * out[i] = in[bitrev_logN(((element * bitrev_{logN+1}(i + N)) >> 1) mod N)]. */
+int orc_poly_apply_galois_eval(const orc_poly_context* ctx, const uint64_t* in, uint64_t* out, uint64_t element,
+                               size_t batch) {
+    const uint64_t n = ctx->degree;
+    if (!orc_is_valid_galois_element(element, n)) return ORC_ERR_INVALID_ARGUMENT;
+    int log2n = 0;
+    while (((uint64_t)1 << log2n) < n) ++log2n;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t reversed = orc_reverse_bits((uint32_t)(i + n), log2n + 1);
+        uint64_t index_raw = ((element * reversed) >> 1) & (n - 1);
+        uint64_t in_index = orc_reverse_bits((uint32_t)index_raw, log2n);
+        for (size_t b = 0; b < batch; ++b)
+            for (size_t r = 0; r < ctx->count; ++r) out[(b * ctx->count + r) * n + i] = in[(b * ctx->count + r) * n + in_index];
+    }
+    return ORC_OK;
+}
+
+/* PolyRq.swift:398-422 multiplyPowerOfX, literally: rotate the columns (Array2d.swift:193-211), then negate a range. */
+int orc_poly_multiply_power_of_x(const orc_poly_context* ctx, uint64_t* data, int64_t power, size_t batch) {
+    const int64_t n = (int64_t)ctx->degree, twice = n << 1;
+    const int64_t abs_power = power < 0 ? -power : power;
+    const int64_t abs_step = abs_power % twice;
+    if (abs_step == 0) return ORC_OK;
+    const int64_t rotation_step = power < 0 ? -abs_step : abs_step;
+    int64_t effective = (rotation_step % n) % n; /* Swift %: sign of the dividend */
+    if (effective < 0) effective += n;           /* toRemainder */
+    int64_t neg_begin, neg_end;
+    if (power < 0 && abs_step < n) { neg_begin = n - abs_step; neg_end = n; }
+    else if (power < 0) { neg_begin = 0; neg_end = twice - abs_step; }
+    else if (abs_step < n) { neg_begin = 0; neg_end = abs_step; }
+    else { neg_begin = abs_step - n; neg_end = n; }
+    uint64_t* row = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t r = 0; r < ctx->count; ++r) {
+            uint64_t* d = data + (b * ctx->count + r) * (size_t)n;
+            if (effective != 0) { /* new row = d[n-e..n) + d[0..n-e) */
+                memcpy(row, d + (n - effective), (size_t)effective * sizeof(uint64_t));
+                memcpy(row + effective, d, (size_t)(n - effective) * sizeof(uint64_t));
+                memcpy(d, row, (size_t)n * sizeof(uint64_t));
+            }
+            for (int64_t k = neg_begin; k < neg_end; ++k) d[k] = neg_mod(d[k], ctx->moduli[r]);
+        }
+    free(row);
+    return ORC_OK;
+}
+
+/* Bfv.swift:174-198 applyGalois(ciphertext:element:using:): 2-poly Coeff ciphertexts,
+ * c0' = galois(c0) + update0, c1' = update1, update = keySwitchingUpdate(galois(c1), galoisKey[element]). */
+int orc_bfv_apply_galois(const orc_bfv_context* ctx, size_t L, const uint64_t* ct, uint64_t element,
+                         const uint64_t* key, uint64_t* out, size_t batch) {
+    if (L < 1 || L > ctx->L) return ORC_ERR_INVALID_ARGUMENT;
+    if (!key || !ctx->key_switching[L]) return ORC_ERR_MISSING_RELINEARIZATION_KEY;
+    const orc_poly_context* qctx = ctx->ciphertext[L];
+    const size_t n = (size_t)ctx->degree, poly = L * n;
+    if (!orc_is_valid_galois_element(element, ctx->degree)) return ORC_ERR_INVALID_ARGUMENT;
+    uint64_t* rotated = (uint64_t*)malloc(2 * poly * sizeof(uint64_t));
+    uint64_t* update = (uint64_t*)malloc(2 * poly * sizeof(uint64_t));
+    for (size_t b = 0; b < batch; ++b) {
+        orc_poly_apply_galois_coeff(qctx, ct + b * 2 * poly, rotated, element, 2);
+        orc_bfv_key_switching_update(ctx, L, rotated + poly, key, update);
+        uint64_t* o = out + b * 2 * poly;
+        for (size_t i = 0; i < L; ++i)
+            for (size_t k = 0; k < n; ++k) {
+                o[i * n + k] = add_mod(rotated[i * n + k], update[i * n + k], qctx->moduli[i]);
+                o[poly + i * n + k] = update[poly + i * n + k];
+            }
+    }
+    free(update);
+    free(rotated);
+    return ORC_OK;
+}
+
+/* Plaintext.swift:149-170 convertToEvalFormat: centered lift of coefficients mod t into each q_i
+ * (x < (t+1)/2 ? x : x + (q_i - t); RnsTool.swift:123-125,168), then forward NTT. */
+int orc_bfv_plaintext_to_eval(const orc_bfv_context* ctx, size_t L, const uint64_t* plaintext, uint64_t* out,
+                              size_t batch) {
+    if (L < 1 || L > ctx->L) return ORC_ERR_INVALID_ARGUMENT;
+    const orc_poly_context* qctx = ctx->ciphertext[L];
+    const size_t n = (size_t)ctx->degree;
+    const uint64_t t_threshold = (ctx->t + 1) / 2;
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t i = 0; i < L; ++i) {
+            const uint64_t t_increment = qctx->moduli[i] - ctx->t;
+            for (size_t k = 0; k < n; ++k) {
+                uint64_t x = plaintext[b * n + k];
+                out[(b * L + i) * n + k] = x < t_threshold ? x : x + t_increment;
+            }
+        }
+    return orc_forward_ntt(qctx, out, batch);
+}
+
+/* Plaintext.swift:176-191 convertToCoeffFormat: inverse NTT, undo the lift on row 0, keep row 0. */
+int orc_bfv_plaintext_to_coeff(const orc_bfv_context* ctx, size_t L, const uint64_t* plaintext_eval, uint64_t* out,
+                               size_t batch) {
+    if (L < 1 || L > ctx->L) return ORC_ERR_INVALID_ARGUMENT;
+    const orc_poly_context* qctx = ctx->ciphertext[L];
+    const size_t n = (size_t)ctx->degree;
+    const uint64_t t_threshold = (ctx->t + 1) / 2, t_increment = qctx->moduli[0] - ctx->t;
+    uint64_t* tmp = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    for (size_t b = 0; b < batch; ++b) {
+        memcpy(tmp, plaintext_eval + b * L * n, L * n * sizeof(uint64_t));
+        orc_inverse_ntt(qctx, tmp, 1);
+        for (size_t k = 0; k < n; ++k) out[b * n + k] = tmp[k] >= t_threshold ? tmp[k] - t_increment : tmp[k];
+    }
+    free(tmp);
+    return ORC_OK;
+}

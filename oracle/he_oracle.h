@@ -166,6 +166,29 @@ int orc_bfv_inner_product_plain(const orc_bfv_context* ctx, size_t moduli_count,
 int orc_bfv_inner_product(const orc_bfv_context* ctx, size_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
                           size_t count, uint64_t* out);
 
+
+/* ---- "next" rows ---- */
+/* isValidGaloisElement (PolyRq/Galois.swift:100-105) */
+int orc_is_valid_galois_element(uint64_t element, uint64_t degree);
+/* PolyRq<Coeff>.applyGalois (PolyRq/Galois.swift:115-143): f(x) -> f(x^element); in/out [batch][L][N] */
+int orc_poly_apply_galois_coeff(const orc_poly_context* ctx, const uint64_t* in, uint64_t* out, uint64_t element,
+                                size_t batch);
+/* PolyRq<Eval>.applyGalois (PolyRq/Galois.swift:153-168) */
+int orc_poly_apply_galois_eval(const orc_poly_context* ctx, const uint64_t* in, uint64_t* out, uint64_t element,
+                               size_t batch);
+/* PolyRq<Coeff>.multiplyPowerOfX (PolyRq/PolyRq.swift:398-422), in place */
+int orc_poly_multiply_power_of_x(const orc_poly_context* ctx, uint64_t* data, int64_t power, size_t batch);
+/* Bfv.applyGalois (Bfv/Bfv.swift:174-198): ct [batch][2][L][N] Coeff, key = the Galois key of `element`
+ * ([L][2][L_top+1][N] Eval, same layout as the relinearization key) -> out [batch][2][L][N] */
+int orc_bfv_apply_galois(const orc_bfv_context* ctx, size_t moduli_count, const uint64_t* ct, uint64_t element,
+                         const uint64_t* key, uint64_t* out, size_t batch);
+/* Plaintext.convertToEvalFormat (Plaintext.swift:149-170): [batch][N] mod t -> [batch][L][N] Eval */
+int orc_bfv_plaintext_to_eval(const orc_bfv_context* ctx, size_t moduli_count, const uint64_t* plaintext,
+                              uint64_t* out, size_t batch);
+/* Plaintext.convertToCoeffFormat (Plaintext.swift:176-191): [batch][L][N] Eval -> [batch][N] mod t */
+int orc_bfv_plaintext_to_coeff(const orc_bfv_context* ctx, size_t moduli_count, const uint64_t* plaintext_eval,
+                               uint64_t* out, size_t batch);
+
 #ifdef __cplusplus
 }
 #endif

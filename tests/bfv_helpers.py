@@ -100,20 +100,45 @@ class BfvClient:
             out.append(((2 * self.t * x + q) // (2 * q)) % self.t)
         return out
 
-    def relinearization_key(self):
-        """Bfv+Keys.swift:57-103: key [L][2][L+1][N] in Eval form over the top key-switching context."""
+    def _key_switch_key(self, current_eval):
+        """Bfv+Keys.swift:69-103 _generateKeySwitchKey: key [L][2][L+1][N] in Eval form over the top key-switching
+        context; ciphertext j encrypts q_ks * currentKey in residue row j only."""
         ks_ctx = self.ctx.key_switching_context()
         q_ks = self.all_moduli[-1]
-        s = self._s_eval_for(ks_ctx)
-        s2 = ks_ctx.mul(s, s)
         ciphers = []
         for row, qi in enumerate(ks_ctx.moduli[:-1]):
             key = ks_ctx.forward_ntt(self.encrypt_zero(ks_ctx))
             factor = q_ks % qi
-            key[0, row] = np.array([(int(key[0, row, k]) + factor * int(s2[row, k])) % qi for k in range(self.n)],
-                                   dtype=np.uint64)
+            key[0, row] = np.array([(int(key[0, row, k]) + factor * int(current_eval[row, k])) % qi
+                                    for k in range(self.n)], dtype=np.uint64)
             ciphers.append(key)
         return np.stack(ciphers)
+
+    def relinearization_key(self):
+        """Bfv+Keys.swift:57-67: switches from s^2 to s."""
+        ks_ctx = self.ctx.key_switching_context()
+        s = self._s_eval_for(ks_ctx)
+        return self._key_switch_key(ks_ctx.mul(s, s))
+
+    def galois_key(self, element):
+        """Bfv+Keys.swift:38-45: switches from s(x^element) to s."""
+        ks_ctx = self.ctx.key_switching_context()
+        rotated_all = self.secret_ctx.apply_galois(self.s_eval_all[None], element, eval_format=True)[0]
+        rows = [self.all_moduli.index(q) for q in ks_ctx.moduli]
+        return self._key_switch_key(rotated_all[rows])
+
+
+def galois_plain(message, element, t):
+    """f(x) -> f(x^element) on a coefficient vector mod t (PolyRq/Galois.swift:115-143 over the plaintext ring)."""
+    n = len(message)
+    out = [0] * n
+    for i, v in enumerate(message):
+        j = (i * element) % (2 * n)
+        if j >= n:
+            out[j - n] = (-v) % t
+        else:
+            out[j] = v % t
+    return out
 
 
 def crt_compose(residues, moduli):

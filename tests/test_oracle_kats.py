@@ -235,3 +235,38 @@ def test_ntt_tables_layout(oracle):
     assert [int(v) for v in t["inv_root_powers"]] == expected
     assert t["inverse_degree"] == pow(degree, p - 2, p)
     assert t["inverse_degree_root"] == (t["inverse_degree"] * expected[degree - 1]) % p
+
+
+def test_apply_galois_known_answers(oracle, kats):
+    """GaloisTests.swift:20-86: the three KAT polynomials, Coeff and Eval forms, and the commuting property."""
+    for case in kats["apply_galois"]["cases"]:
+        degree, moduli = case["degree"], case["moduli"]
+        ctx = oracle.PolyContext(degree, moduli)
+        data = np.array(case["data"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        expected = np.array(case["expected"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        assert np.array_equal(ctx.apply_galois(data, case["element"]), expected)
+        via_eval = ctx.inverse_ntt(ctx.apply_galois(ctx.forward_ntt(data), case["element"], eval_format=True))
+        assert np.array_equal(via_eval, expected)
+        for index in range(1, degree):
+            element = 2 * index + 1
+            assert np.array_equal(ctx.forward_ntt(ctx.apply_galois(data, element)),
+                                  ctx.apply_galois(ctx.forward_ntt(data), element, eval_format=True))
+        # swapping rows twice is the identity (GaloisElement.swappingRows = 2N - 1, Galois.swift)
+        swap = 2 * degree - 1
+        assert np.array_equal(ctx.apply_galois(ctx.apply_galois(data, swap), swap), data)
+
+
+def test_multiply_power_of_x_is_negacyclic_shift(oracle):
+    """PolyRq.multiplyPowerOfX (PolyRq.swift:398-422) restated literally must equal x^power mod (x^N + 1)."""
+    degree, moduli = 16, [97, 193]
+    ctx = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(11)
+    data = np.stack([rng.integers(0, q, size=(2, degree), dtype=np.uint64) for q in moduli], axis=1)
+    for power in range(-3 * degree, 3 * degree + 1):
+        expected = np.zeros_like(data)
+        for r, q in enumerate(moduli):
+            for i in range(degree):
+                j = (i + power) % (2 * degree)
+                column, negate = (j - degree, True) if j >= degree else (j, False)
+                expected[:, r, column] = (q - data[:, r, i]) % q if negate else data[:, r, i]
+        assert np.array_equal(ctx.multiply_power_of_x(data, power), expected), power

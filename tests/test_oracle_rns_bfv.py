@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from bfv_helpers import BfvClient, crt_compose, crt_decompose, negacyclic_multiply
+from bfv_helpers import BfvClient, crt_compose, crt_decompose, galois_plain, negacyclic_multiply
 
 MTILDE = 1 << 32
 
@@ -188,6 +188,49 @@ def test_bfv_mul_and_relinearize_decrypt_to_product(oracle, small_bfv):
     assert relin.shape == (1, 2, ctx.L, ctx.degree)
     assert client.decrypt(relin[0]) == expected
     assert client.decrypt_exact(relin[0]) == expected
+
+
+def test_bfv_apply_galois_decrypts_to_rotated_plaintext(oracle, small_bfv):
+    # HeAPITests / HeApiTestUtils applyGalois checks: decrypt(applyGalois(ct, g)) = m(x^g) mod t (Bfv.swift:174-198)
+    ctx, client = small_bfv
+    rng = random.Random(26)
+    message = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    ct = client.encrypt(message)
+    for element in (3, 2 * ctx.degree - 1, 9):
+        key = client.galois_key(element)
+        rotated = ctx.apply_galois(ct[None], element, key)
+        assert rotated.shape == (1, 2, ctx.L, ctx.degree)
+        assert client.decrypt(rotated[0]) == galois_plain(message, element, ctx.t)
+    # below top level (after one mod switch) with the same key
+    lower = ctx.mod_switch_down(ct[None], poly_count=2)
+    key = client.galois_key(3)
+    rotated = ctx.apply_galois(lower, 3, key, moduli_count=ctx.L - 1)
+    assert client.decrypt(rotated[0], moduli_count=ctx.L - 1) == galois_plain(message, 3, ctx.t)
+
+
+def test_plaintext_eval_roundtrip_and_multiply(oracle, small_bfv):
+    # Plaintext.convertToEvalFormat / convertToCoeffFormat (Plaintext.swift:149-191) and ct x pt
+    # (HeApiTestUtils.swift:1223-1285): decrypt(ct * eval(pt)) = negacyclic product mod t
+    ctx, client = small_bfv
+    rng = random.Random(27)
+    m1 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    m2 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    pt = np.array([m2, m1], dtype=np.uint64)
+    for level in (ctx.L, ctx.L - 1):
+        pt_eval = ctx.plaintext_to_eval(pt, moduli_count=level)
+        assert pt_eval.shape == (2, level, ctx.degree)
+        assert np.array_equal(ctx.plaintext_to_coeff(pt_eval, moduli_count=level), pt)
+        moduli = ctx.ciphertext_context(level).moduli
+        coeff = ctx.ciphertext_context(level).inverse_ntt(pt_eval)
+        threshold = (ctx.t + 1) // 2
+        for i, q in enumerate(moduli):
+            expected_row = [v if v < threshold else v + q - ctx.t for v in m2]
+            assert coeff[0, i].tolist() == expected_row
+    ct = client.encrypt(m1)
+    qctx = ctx.ciphertext_context()
+    ct_eval = qctx.forward_ntt(ct)
+    product = ctx.mul_plain(ct_eval[None], ctx.plaintext_to_eval(pt[:1]), poly_count=2)[0]
+    assert client.decrypt(qctx.inverse_ntt(product)) == negacyclic_multiply(m1, m2, ctx.t)
 
 
 def test_bfv_mod_switch_down_keeps_message(oracle, small_bfv):
