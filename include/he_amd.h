@@ -52,7 +52,8 @@ enum he_status {
     HE_ERR_INVALID_ENCRYPTION_PARAMETERS = 15,          /* invalidEncryptionParameters EncryptionParameters.swift:136-166 */
     HE_ERR_INVALID_ARGUMENT = 16,  /* what the reference traps on with `precondition` (null pointer, shape) */
     HE_ERR_DEVICE = 17,            /* HIP runtime failure (no GPU, out of memory, launch error) */
-    HE_ERR_UNSUPPORTED = 18        /* unsupportedHeOperation */
+    HE_ERR_UNSUPPORTED = 18,       /* unsupportedHeOperation */
+    HE_ERR_MISSING_GALOIS_KEY = 19 /* missingGaloisKey / missingGaloisElement  Bfv/Bfv.swift:184-189 */
 };
 
 typedef struct he_poly_context he_poly_context; /* PolyContext<UInt64>   PolyRq/PolyContext.swift:19-35 */
@@ -130,6 +131,16 @@ int he_poly_adding_lazy_product_device(const he_poly_context* ctx, const uint64_
 int he_poly_reduce_accumulator_device(const he_poly_context* ctx, const uint64_t* acc_lo_hi, uint64_t* out,
                                       he_stream s);
 
+/* ---- "next" rows of the scope table: index permutations; in and out must not alias ---- */
+/* PolyRq.applyGalois(element:) f(x) -> f(x^element) on [batch][L][N] slabs; eval_format = 0 for Coeff
+ * (PolyRq/Galois.swift:115-143), 1 for Eval (PolyRq/Galois.swift:153-168).  An invalid element (even, <= 1,
+ * >= 2N; Galois.swift:100-105) is the reference's precondition -> HE_ERR_INVALID_ARGUMENT. */
+int he_poly_apply_galois_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out, size_t batch,
+                                uint64_t element, int eval_format, he_stream s);
+/* PolyRq<Coeff>.multiplyPowerOfX(power) (PolyRq/PolyRq.swift:398-422): f(x) x^power mod (x^N + 1), any sign. */
+int he_poly_multiply_power_of_x_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out, size_t batch,
+                                       int64_t power, he_stream s);
+
 /* =====================================================================================================
  * B3: Context<Bfv<UInt64>> and the HeScheme operations on the hot path
  * =================================================================================================== */
@@ -193,6 +204,23 @@ int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count
                                 const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,
                                 size_t workspace_bytes, he_stream s);
 size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count);
+
+/* ---- "next" rows of the scope table ---- */
+/* Bfv.applyGalois(ciphertext:element:using:) (Bfv/Bfv.swift:174-198): ct [batch][2][L][N] Coeff,
+ * galois_key = EvaluationKey.galoisKey.keys[element] in the relinearization key's layout
+ * ([L_top][2][L_top+1][N] Eval; Bfv+Keys.swift:38-45,69-103) -> out [batch][2][L][N] Coeff.
+ * NULL key -> HE_ERR_MISSING_GALOIS_KEY. */
+int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct,
+                               uint64_t element, const uint64_t* galois_key, uint64_t* out, size_t batch,
+                               void* workspace, size_t workspace_bytes, he_stream s);
+size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
+/* Plaintext<Coeff>.convertToEvalFormat(moduliCount:) (Plaintext.swift:149-170): plaintext [batch][N] (values < t)
+ * -> out [batch][L][N] Eval.  This is the database preprocessing step of PIR (MulPir.swift:507-556). */
+int he_bfv_plaintext_to_eval_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext,
+                                    uint64_t* out, size_t batch, he_stream s);
+/* Plaintext<Eval>.convertToCoeffFormat() (Plaintext.swift:176-191): [batch][L][N] Eval -> [batch][N] (values < t). */
+int he_bfv_plaintext_to_coeff_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext_eval,
+                                     uint64_t* out, size_t batch, he_stream s);
 
 /* =====================================================================================================
  * Diagnostics and test hooks (not part of the reference's surface)

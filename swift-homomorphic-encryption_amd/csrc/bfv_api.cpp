@@ -214,7 +214,103 @@ int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, 
     HEAMD_HIP_TRY(heamd::launch_ntt(false, spread, ks, 0, L + 1, batch * L * (L + 1), stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, 2, stream));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ Galois automorphism
+namespace {
+bool is_valid_galois_element(uint64_t element, uint64_t degree) {  // Galois.swift:100-105
+    return degree != 0 && (degree & (degree - 1)) == 0 && (element & 1) == 1 && element < (degree << 1) && element > 1;
+}
+// g^-1 mod 2N for odd g (Newton iteration doubles the correct low bits)
+uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
+    uint64_t x = g;  // correct to 3 bits
+    for (int k = 0; k < 6; ++k) x *= 2 - g * x;
+    return static_cast<uint32_t>(x & (modulus - 1));
+}
+}  // namespace
+
+size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
+    if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
+    const size_t L = moduli_count, n = ctx->impl->degree();
+    return batch * (2 * L + L * (L + 1) + 2 * (L + 1)) * n * sizeof(uint64_t);
+}
+
+int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct, uint64_t element,
+                               const uint64_t* galois_key, uint64_t* out, size_t batch, void* workspace,
+                               size_t workspace_bytes, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (galois_key == nullptr || !ctx->impl->has_key_switching()) {
+        heamd::set_last_error("no Galois key for this element");
+        return HE_ERR_MISSING_GALOIS_KEY;  // Bfv.swift:184-189
+    }
+    if (!is_valid_galois_element(element, ctx->impl->degree())) return invalid_argument("invalid Galois element");
+    if (batch == 0) return HE_OK;
+    if (ct == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = moduli_count;
+    const size_t n = ctx->impl->degree();
+    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
+    const PolyContext* q_ctx = ctx->impl->ciphertext(L);
+    const DeviceContext ks = ks_ctx->device_context();
+    Scratch scratch(stream);
+    uint64_t* ws = nullptr;
+    status = resolve_workspace(workspace, workspace_bytes, he_bfv_apply_galois_workspace_bytes(ctx, L, batch), scratch,
+                               &ws);
+    if (status != HE_OK) return status;
+    uint64_t* rotated = ws;                                     // [batch][2][L][N]
+    uint64_t* spread = rotated + batch * 2 * L * n;             // [batch][L][L+1][N]
+    uint64_t* prod = spread + batch * L * (L + 1) * n;          // [batch][2][L+1][N]
+    const size_t ct_stride = 2 * size_t(L) * n;
+    // Bfv.swift:190-196: c0' = galois(c0) + update0, c1' = update1, update = keySwitch(galois(c1))
+    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
+                                             inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_spread(rotated + size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(false, spread, ks, 0, L + 1, batch * L * (L + 1), stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, galois_key, prod, ks, L, ctx->impl->top_level() + 1, batch,
+                                               stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, rotated, ct_stride, out, ks, L, batch, 1, stream));
+    return HE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ plaintext <-> Eval
+int he_bfv_plaintext_to_eval_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext,
+                                    uint64_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (plaintext == nullptr || out == nullptr) return invalid_argument("null plaintext");
+    hipStream_t stream = as_stream(s);
+    const PolyContext* q_ctx = ctx->impl->ciphertext(moduli_count);
+    const DeviceContext dc = q_ctx->device_context(moduli_count);
+    // Plaintext.convertToEvalFormat (Plaintext.swift:149-170): centered lift, then forwardNtt
+    HEAMD_HIP_TRY(heamd::launch_plaintext_lift(plaintext, out, dc, ctx->impl->plaintext_modulus(), batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(false, out, dc, 0, moduli_count, batch * moduli_count, stream));
+    return HE_OK;
+}
+
+int he_bfv_plaintext_to_coeff_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext_eval,
+                                     uint64_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (plaintext_eval == nullptr || out == nullptr) return invalid_argument("null plaintext");
+    hipStream_t stream = as_stream(s);
+    const PolyContext* q_ctx = ctx->impl->ciphertext(moduli_count);
+    const DeviceContext dc = q_ctx->device_context(moduli_count);
+    const size_t n = ctx->impl->degree();
+    // Plaintext.convertToCoeffFormat (Plaintext.swift:176-191) keeps residue row 0 only and rows are independent
+    // under the inverse NTT, so only row 0 is transformed
+    HEAMD_HIP_TRY(heamd::launch_first_rows(plaintext_eval, out, dc, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt(true, out, dc, 0, 1, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_plaintext_unlift(out, q_ctx->moduli()[0], ctx->impl->plaintext_modulus(), batch * n,
+                                                 stream));
     return HE_OK;
 }
 

@@ -113,6 +113,7 @@ const char* he_status_string(int status) {
         case HE_ERR_INVALID_ARGUMENT: return "invalidArgument";
         case HE_ERR_DEVICE: return "deviceError";
         case HE_ERR_UNSUPPORTED: return "unsupportedHeOperation";
+        case HE_ERR_MISSING_GALOIS_KEY: return "missingGaloisKey";
         default: return "unknown";
     }
 }
@@ -286,6 +287,46 @@ int he_poly_neg_device(const he_poly_context* ctx, uint64_t* data, size_t batch,
 int he_poly_mul_device(const he_poly_context* ctx, uint64_t* lhs, const uint64_t* rhs, size_t batch, he_stream s) {
     return elementwise(ctx, heamd::ElementwiseOp::Mul, lhs, rhs, batch, s);
 }
+int he_poly_apply_galois_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out, size_t batch,
+                                uint64_t element, int eval_format, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    const uint64_t n = pc.degree();
+    // isValidGaloisElement (Galois.swift:100-105) is a precondition of applyGalois
+    if ((element & 1) == 0 || element <= 1 || element >= 2 * n) return invalid_argument("invalid Galois element");
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr || in == out) return invalid_argument("null or aliased slabs");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    const size_t rows = batch * pc.moduli_count();
+    if (eval_format != 0) {
+        HEAMD_HIP_TRY(heamd::launch_galois_eval(in, out, pc.device_context(), static_cast<uint32_t>(element), rows,
+                                                as_stream(s)));
+    } else {
+        uint64_t inverse = element;  // Newton: g^-1 mod 2^k for odd g
+        for (int k = 0; k < 6; ++k) inverse *= 2 - element * inverse;
+        HEAMD_HIP_TRY(heamd::launch_galois_coeff(in, out, pc.device_context(),
+                                                 static_cast<uint32_t>(inverse & (2 * n - 1)), rows, as_stream(s)));
+    }
+    return HE_OK;
+}
+
+int he_poly_multiply_power_of_x_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out, size_t batch,
+                                       int64_t power, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr || in == out) return invalid_argument("null or aliased slabs");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    const int64_t twice = 2 * static_cast<int64_t>(pc.degree());
+    int64_t shift = power % twice;  // x^(2N) = 1
+    if (shift < 0) shift += twice;
+    HEAMD_HIP_TRY(heamd::launch_multiply_power_of_x(in, out, pc.device_context(), static_cast<uint32_t>(shift),
+                                                    batch * pc.moduli_count(), as_stream(s)));
+    return HE_OK;
+}
+
 int he_poly_mul_scalar_device(const he_poly_context* ctx, uint64_t* data, const uint64_t* scalar_residues,
                               size_t batch, he_stream s) {
     if (ctx == nullptr || scalar_residues == nullptr) return invalid_argument("null pointer");

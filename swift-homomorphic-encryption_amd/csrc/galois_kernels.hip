@@ -1,0 +1,166 @@
+// galois_kernels.hip -- index-permuting PolyRq kernels and the plaintext <-> ciphertext-ring lifts for gfx950.
+//
+// Reference semantics (Sources/HomomorphicEncryption/):
+//   PolyRq<Coeff>.applyGalois   f(x) -> f(x^g): coefficient i goes to (i g) mod N, negated when floor(i g / N) is odd
+//                               PolyRq/Galois.swift:115-143 (GaloisCoeffIterator :34-48)
+//   PolyRq<Eval>.applyGalois    out[i] = in[bitrev(((g bitrev_{logN+1}(i + N)) >> 1) mod N)]
+//                               PolyRq/Galois.swift:153-168 (GaloisEvalIterator :81-92)
+//   PolyRq<Coeff>.multiplyPowerOfX   f(x) x^k mod (x^N + 1)          PolyRq/PolyRq.swift:398-422
+//   Plaintext.convertToEvalFormat / convertToCoeffFormat             Plaintext.swift:149-191
+//
+// All are pure data movement (one read, one write per word, no multiplies): writes are coalesced -- each lane owns
+// consecutive OUTPUT words and gathers its inputs -- because a permutation's scattered side costs less as reads,
+// which L2 absorbs (a residue row is 64 KiB).  in and out must not alias.
+#include <hip/hip_runtime.h>
+
+#include "device_context.hpp"
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace heamd {
+
+namespace {
+
+constexpr unsigned kThreads = 256;
+
+inline unsigned grid_for(size_t work_items) {
+    const size_t blocks = (work_items + kThreads - 1) / kThreads;
+    const size_t cap = 256 * 8;
+    return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+// Output word j of a row takes input word src (sign flipped when `negate`): shared by the automorphism and by the
+// multiplication by a power of x, which differ only in how the doubled index i in [0, 2N) is derived from j.
+//   automorphism:  i = j * g^-1 mod 2N     (then i g = j or j + N mod 2N)
+//   x^s:           i = (j - s) mod 2N
+__device__ __forceinline__ uint64_t signed_gather(const uint64_t* __restrict__ row, uint32_t doubled_index, uint32_t n,
+                                                  uint64_t p) {
+    const bool negate = doubled_index >= n;
+    const uint64_t v = row[negate ? doubled_index - n : doubled_index];
+    return negate ? neg_mod(v, p) : v;
+}
+
+enum class CoeffMap { Galois, PowerOfX };
+
+template <CoeffMap MAP>
+__global__ void __launch_bounds__(kThreads)
+    coeff_permute_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
+                         uint32_t parameter, size_t words) {
+    const uint32_t logn = ctx.log_degree, n = ctx.degree, mask2n = 2 * n - 1;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t row = idx >> logn;
+        const uint32_t j = static_cast<uint32_t>(idx) & (n - 1);
+        const uint64_t p = ctx.moduli[row % ctx.moduli_count].p;
+        const uint32_t i = (MAP == CoeffMap::Galois ? j * parameter : j + 2 * n - parameter) & mask2n;
+        out[idx] = signed_gather(in + (row << logn), i, n, p);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+    galois_eval_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
+                       uint32_t element, size_t words) {
+    const uint32_t logn = ctx.log_degree, n = ctx.degree;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t row = idx >> logn;
+        const uint32_t i = static_cast<uint32_t>(idx) & (n - 1);
+        const uint32_t reversed = __brev(i + n) >> (32 - (logn + 1));
+        const uint32_t raw = ((element * reversed) >> 1) & (n - 1);
+        const uint32_t source = logn == 0 ? 0 : __brev(raw) >> (32 - logn);
+        out[idx] = in[(row << logn) + source];
+    }
+}
+
+// plaintext [batch][N] (values < t) -> out [batch][L][N]: x < (t+1)/2 ? x : x + (q_i - t)      Plaintext.swift:157-167
+__global__ void __launch_bounds__(kThreads)
+    plaintext_lift_kernel(const uint64_t* __restrict__ plaintext, uint64_t* __restrict__ out, const DeviceContext ctx,
+                          uint64_t t, size_t words) {
+    const uint32_t logn = ctx.log_degree, n = ctx.degree;
+    const uint64_t threshold = (t + 1) >> 1;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t row = idx >> logn;
+        const size_t poly = row / ctx.moduli_count;
+        const uint32_t mi = static_cast<uint32_t>(row - poly * ctx.moduli_count);
+        const uint64_t x = plaintext[(poly << logn) + (idx & (n - 1))];
+        out[idx] = x < threshold ? x : x + (ctx.moduli[mi].p - t);
+    }
+}
+
+// first residue rows, Coeff form, [batch][N] in place: x >= (t+1)/2 ? x - (q_0 - t) : x          Plaintext.swift:181-186
+__global__ void __launch_bounds__(kThreads)
+    plaintext_unlift_kernel(uint64_t* __restrict__ rows, uint64_t q0, uint64_t t, size_t words) {
+    const uint64_t threshold = (t + 1) >> 1, increment = q0 - t;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const uint64_t x = rows[idx];
+        rows[idx] = x >= threshold ? x - increment : x;
+    }
+}
+
+// copies residue row 0 of every polynomial: in [batch][L][N] -> out [batch][N]
+__global__ void __launch_bounds__(kThreads)
+    first_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t logn, uint32_t rows_per_poly,
+                     size_t words) {
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t poly = idx >> logn;
+        out[idx] = in[((poly * rows_per_poly) << logn) + (idx & ((size_t(1) << logn) - 1))];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,
+                               size_t rows, hipStream_t stream) {
+    const size_t words = rows << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(coeff_permute_kernel<CoeffMap::Galois>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out,
+                       ctx, inverse_element, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
+                                      size_t rows, hipStream_t stream) {
+    const size_t words = rows << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(coeff_permute_kernel<CoeffMap::PowerOfX>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in,
+                       out, ctx, shift, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t element, size_t rows,
+                              hipStream_t stream) {
+    const size_t words = rows << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(galois_eval_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, ctx, element,
+                       words);
+    return hipGetLastError();
+}
+
+hipError_t launch_plaintext_lift(const uint64_t* plaintext, uint64_t* out, const DeviceContext& ctx, uint64_t t,
+                                 size_t batch, hipStream_t stream) {
+    const size_t words = (batch * ctx.moduli_count) << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(plaintext_lift_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, plaintext, out, ctx, t,
+                       words);
+    return hipGetLastError();
+}
+
+hipError_t launch_plaintext_unlift(uint64_t* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(plaintext_unlift_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, rows, q0, t, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_rows(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, size_t batch,
+                             hipStream_t stream) {
+    const size_t words = batch << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(first_row_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, ctx.log_degree,
+                       ctx.moduli_count, words);
+    return hipGetLastError();
+}
+
+}  // namespace heamd

@@ -56,4 +56,24 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                       uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
                                       size_t columns, uint64_t max_lazy, hipStream_t stream);
 
+
+// ---- galois_kernels.hip (in and out must not alias) ------------------------------------------------------------
+// f(x) -> f(x^g) on Coeff rows; `inverse_element` = g^-1 mod 2N
+hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,
+                               size_t rows, hipStream_t stream);
+// f(x) -> f(x^g) on Eval (bit-reversed) rows
+hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t element,
+                              size_t rows, hipStream_t stream);
+// f(x) x^shift mod (x^N + 1), 0 <= shift < 2N
+hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
+                                      size_t rows, hipStream_t stream);
+// plaintext [batch][N] mod t -> centered lift into every row of [batch][L][N] (L = ctx.moduli_count)
+hipError_t launch_plaintext_lift(const uint64_t* plaintext, uint64_t* out, const DeviceContext& ctx, uint64_t t,
+                                 size_t batch, hipStream_t stream);
+// rows [words] over q0, Coeff form: undo the centered lift in place
+hipError_t launch_plaintext_unlift(uint64_t* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream);
+// residue row 0 of every polynomial: [batch][L][N] -> [batch][N]
+hipError_t launch_first_rows(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, size_t batch,
+                             hipStream_t stream);
+
 }  // namespace heamd

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(kThreads)
 // out: [polys][2][L][N] = ct + divideAndRoundQLast(prod)
 __global__ void __launch_bounds__(kThreads)
     key_switch_finish_kernel(const uint64_t* __restrict__ prod, const uint64_t* __restrict__ ct_base, size_t ct_stride,
-                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys) {
+                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
+                             uint32_t added_polys) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = (polys * 2) << logn;
@@ -263,7 +264,9 @@ __global__ void __launch_bounds__(kThreads)
             const uint64_t half_mod_qi = barrett_reduce64(q_last_div2, m.p, m.barrett64);
             const uint64_t t = barrett_reduce64(r, m.p, m.barrett64);
             const uint64_t v = shoup_mul(sub_mod(add_mod(src[row * n], half_mod_qi, m.p), t, m.p), inv.x, inv.y, m.p);
-            dst[row * n] = add_mod(ct[row * n], v, m.p);
+            // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
+            // replaces c1 (Bfv.swift:194-195)
+            dst[row * n] = c < added_polys ? add_mod(ct[row * n], v, m.p) : v;
         }
     }
 }
@@ -361,10 +364,11 @@ hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, ui
 }
 
 hipError_t launch_key_switch_finish(const uint64_t* prod, const uint64_t* ct_base, size_t ct_stride, uint64_t* out,
-                                    const DeviceContext& ks, uint32_t L, size_t polys, hipStream_t stream) {
+                                    const DeviceContext& ks, uint32_t L, size_t polys, uint32_t added_polys,
+                                    hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     hipLaunchKernelGGL(key_switch_finish_kernel, dim3(grid_for((polys * 2) << ks.log_degree)), dim3(kThreads), 0,
-                       stream, prod, ct_base, ct_stride, out, ks, L, polys);
+                       stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys);
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ STATUS_NAMES = {
     5: "invalidNttModulus", 6: "invalidPolyContext", 7: "polyContextMismatch", 8: "invalidCiphertext",
     9: "incompatibleCiphertexts", 10: "incompatibleCiphertextAndPlaintext", 11: "missingRelinearizationKey",
     12: "unequalContexts", 13: "notEnoughPrimes", 14: "notInvertible", 15: "invalidEncryptionParameters",
-    16: "invalidArgument", 17: "deviceError", 18: "unsupportedHeOperation",
+    16: "invalidArgument", 17: "deviceError", 18: "unsupportedHeOperation", 19: "missingGaloisKey",
 }
 
 
@@ -65,6 +65,8 @@ SIGNATURES = [
     ("he_poly_divide_and_round_q_last", ctypes.c_int, [vp, U64P, U64P, c_size]),
     ("he_poly_adding_lazy_product_device", ctypes.c_int, [vp, vp, vp, vp, vp]),
     ("he_poly_reduce_accumulator_device", ctypes.c_int, [vp, vp, vp, vp]),
+    ("he_poly_apply_galois_device", ctypes.c_int, [vp, vp, vp, c_size, c_u64, ctypes.c_int, vp]),
+    ("he_poly_multiply_power_of_x_device", ctypes.c_int, [vp, vp, vp, c_size, ctypes.c_int64, vp]),
     ("he_bfv_context_create", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_bfv_context_destroy", None, [vp]),
     ("he_bfv_ciphertext_moduli_count", c_u32, [vp]),
@@ -83,6 +85,10 @@ SIGNATURES = [
     ("he_bfv_inner_product_plain_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, ctypes.POINTER(ctypes.c_uint8), c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    ("he_bfv_apply_galois_workspace_bytes", c_size, [vp, c_u32, c_size]),
+    ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_plaintext_to_eval_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_plaintext_to_coeff_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     # diagnostics / test hooks
     ("he_poly_context_create_host_only", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_poly_context_copy_ntt_tables", ctypes.c_int, [vp, c_u32, U64P, U64P, U64P, U64P, U64P, U64P]),
@@ -313,6 +319,24 @@ class PolyContext:
                                                               out.ctypes.data_as(U64P), batch))
         return out
 
+    def apply_galois(self, slab, element, eval_format=False, stream=None):
+        """PolyRq.applyGalois(element:) on [batch][L][N]; returns a new slab (the permutation is out of place)."""
+        import torch
+
+        out = torch.empty_like(slab)
+        _check(load_library().he_poly_apply_galois_device(self.h, _ptr(slab), vp(out.data_ptr()), self._batch(slab),
+                                                          int(element), int(bool(eval_format)), _stream(stream)))
+        return out
+
+    def multiply_power_of_x(self, slab, power, stream=None):
+        """PolyRq<Coeff>.multiplyPowerOfX(power); returns a new slab."""
+        import torch
+
+        out = torch.empty_like(slab)
+        _check(load_library().he_poly_multiply_power_of_x_device(self.h, _ptr(slab), vp(out.data_ptr()),
+                                                                 self._batch(slab), int(power), _stream(stream)))
+        return out
+
     def adding_lazy_product_(self, lhs, rhs, acc, stream=None):
         _check(load_library().he_poly_adding_lazy_product_device(self.h, _ptr(lhs), _ptr(rhs), _ptr(acc),
                                                                  _stream(stream)))
@@ -413,6 +437,38 @@ class BfvContext:
         ws_ptr, ws_bytes = (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
         _check(load_library().he_bfv_relinearize_device(self.h, L, _ptr(ct3), key_ptr, _ptr(out), batch, ws_ptr,
                                                         ws_bytes, _stream(stream)))
+        return out
+
+    def apply_galois_workspace_bytes(self, batch, moduli_count=None):
+        return int(load_library().he_bfv_apply_galois_workspace_bytes(self.h, self._L(moduli_count), batch))
+
+    def apply_galois(self, ct, element, key, moduli_count=None, stream=None, workspace=None):
+        """Bfv.applyGalois: [batch][2][L][N] Coeff + the element's Galois key -> [batch][2][L][N]."""
+        L = self._L(moduli_count)
+        batch = ct.numel() // (2 * L * self.degree)
+        out = self._empty((batch, 2, L, self.degree), ct)
+        key_ptr = vp() if key is None else _ptr(key)
+        ws_ptr, ws_bytes = (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
+        _check(load_library().he_bfv_apply_galois_device(self.h, L, _ptr(ct), int(element), key_ptr, _ptr(out), batch,
+                                                         ws_ptr, ws_bytes, _stream(stream)))
+        return out
+
+    def plaintext_to_eval(self, plaintext, moduli_count=None, stream=None):
+        """Plaintext.convertToEvalFormat: [batch][N] (values < t) -> [batch][L][N] Eval."""
+        L = self._L(moduli_count)
+        batch = plaintext.numel() // self.degree
+        out = self._empty((batch, L, self.degree), plaintext)
+        _check(load_library().he_bfv_plaintext_to_eval_device(self.h, L, _ptr(plaintext), _ptr(out), batch,
+                                                              _stream(stream)))
+        return out
+
+    def plaintext_to_coeff(self, plaintext_eval, moduli_count=None, stream=None):
+        """Plaintext.convertToCoeffFormat: [batch][L][N] Eval -> [batch][N] (values < t)."""
+        L = self._L(moduli_count)
+        batch = plaintext_eval.numel() // (L * self.degree)
+        out = self._empty((batch, self.degree), plaintext_eval)
+        _check(load_library().he_bfv_plaintext_to_coeff_device(self.h, L, _ptr(plaintext_eval), _ptr(out), batch,
+                                                               _stream(stream)))
         return out
 
     def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):

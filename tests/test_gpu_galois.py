@@ -1,0 +1,160 @@
+"""GPU parity tests of the "next" rows: Galois automorphisms, x^k multiplication, the
+Galois key switch on ciphertexts and plaintext <-> Eval conversion.  Bit-exact against the CPU oracle, pinned by
+the reference's KATs (Tests/HomomorphicEncryptionTests/PolyRqTests/GaloisTests.swift:20-86) and by decryption."""
+import random
+
+import numpy as np
+import pytest
+
+import heamd
+from bfv_helpers import BfvClient, galois_plain, negacyclic_multiply
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform(rng, shape_prefix, moduli, degree):
+    rows = [rng.integers(0, q, size=tuple(shape_prefix) + (degree,), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=len(shape_prefix)))
+
+
+def test_apply_galois_known_answers(kats):
+    for case in kats["apply_galois"]["cases"]:
+        degree, moduli = case["degree"], case["moduli"]
+        ctx = heamd.PolyContext(degree, moduli)
+        data = np.array(case["data"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        expected = np.array(case["expected"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        got = heamd.to_host(ctx.apply_galois(heamd.to_device(data), case["element"]))
+        assert np.array_equal(got, expected)
+        evaluated = ctx.forward_ntt_(heamd.to_device(data))
+        rotated = ctx.apply_galois(evaluated, case["element"], eval_format=True)
+        assert np.array_equal(heamd.to_host(ctx.inverse_ntt_(rotated)), expected)
+
+
+@pytest.mark.parametrize("degree,bits,batch", [(8, [20], 3), (64, [40, 41], 4), (4096, [55, 55], 3),
+                                                (8192, [55, 55, 55, 55], 2), (16384, [55, 61, 45], 1)])
+def test_apply_galois_matches_oracle(oracle, degree, bits, batch):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + batch)
+    slab = _uniform(rng, (batch,), moduli, degree)
+    slab[0, :, 0] = 0
+    slab[0, :, 1] = [m - 1 for m in moduli]
+    elements = {3, 5, 2 * degree - 1, degree + 1, degree - 1} | {int(2 * rng.integers(1, degree) + 1) for _ in range(3)}
+    for element in sorted(e for e in elements if 1 < e < 2 * degree):
+        for eval_format in (False, True):
+            got = heamd.to_host(ours.apply_galois(heamd.to_device(slab), element, eval_format=eval_format))
+            assert np.array_equal(got, ref.apply_galois(slab, element, eval_format=eval_format)), (element, eval_format)
+    # the two forms commute with the NTT (GaloisTests.swift:66-70)
+    element = 2 * (degree // 4) + 1
+    via_coeff = ours.forward_ntt_(ours.apply_galois(heamd.to_device(slab), element))
+    via_eval = ours.apply_galois(ours.forward_ntt_(heamd.to_device(slab)), element, eval_format=True)
+    assert np.array_equal(heamd.to_host(via_coeff), heamd.to_host(via_eval))
+
+
+def test_apply_galois_rejects_bad_elements():
+    ctx = heamd.PolyContext(16, [97])
+    slab = heamd.to_device(np.zeros((1, 1, 16), dtype=np.uint64))
+    for element in (0, 1, 2, 32, 33):
+        with pytest.raises(heamd.HeError) as err:
+            ctx.apply_galois(slab, element)
+        assert err.value.name == "invalidArgument"
+
+
+@pytest.mark.parametrize("degree,bits", [(16, [20, 21]), (4096, [55, 55]), (8192, [55, 40])])
+def test_multiply_power_of_x_matches_oracle(oracle, degree, bits):
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree)
+    slab = _uniform(rng, (3,), moduli, degree)
+    powers = [0, 1, -1, degree - 1, degree, degree + 1, 2 * degree - 1, 2 * degree, -degree, -2 * degree + 1,
+              5 * degree + 3, -7 * degree - 2]
+    for power in powers:
+        got = heamd.to_host(ours.multiply_power_of_x(heamd.to_device(slab), power))
+        assert np.array_equal(got, ref.multiply_power_of_x(slab, power)), power
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40, 40, 41], False, degree)
+    ref = oracle.BfvContext(degree, t, q)
+    return heamd.BfvContext(degree, t, q), ref, BfvClient(oracle, ref, seed=50)
+
+
+def test_bfv_apply_galois_matches_oracle_and_decrypts(oracle, small):
+    ours, ref, client = small
+    rng = random.Random(51)
+    messages = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(3)]
+    cts = np.stack([client.encrypt(m) for m in messages])
+    for element in (3, 2 * ref.degree - 1, 25):
+        key = client.galois_key(element)
+        got = heamd.to_host(ours.apply_galois(heamd.to_device(cts), element, heamd.to_device(key)))
+        assert np.array_equal(got, ref.apply_galois(cts, element, key))
+        for ct, message in zip(got, messages):
+            assert client.decrypt(ct) == galois_plain(message, element, ref.t)
+    lower = ref.mod_switch_down(cts, poly_count=2)
+    key = client.galois_key(3)
+    got = heamd.to_host(ours.apply_galois(heamd.to_device(lower), 3, heamd.to_device(key), moduli_count=ref.L - 1))
+    assert np.array_equal(got, ref.apply_galois(lower, 3, key, moduli_count=ref.L - 1))
+    assert client.decrypt(got[0], moduli_count=ref.L - 1) == galois_plain(messages[0], 3, ref.t)
+
+
+def test_bfv_apply_galois_errors(small):
+    ours, ref, _ = small
+    ct = heamd.to_device(np.zeros((1, 2, ours.L, ours.degree), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:
+        ours.apply_galois(ct, 3, None)
+    assert err.value.name == "missingGaloisKey"
+    key = heamd.to_device(np.zeros((ours.L, 2, ours.L + 1, ours.degree), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:
+        ours.apply_galois(ct, 4, key)
+    assert err.value.name == "invalidArgument"
+
+
+def test_bfv_apply_galois_config3_shape(oracle):
+    """N=8192, 4+1 55-bit moduli, uniform words (exact ciphertext words are what parity means here)."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(52)
+    cts = _uniform(rng, (3, 2), q[:-1], degree)
+    key = _uniform(rng, (ours.L, 2), q, degree)
+    element = 2 * 1234 + 1
+    workspace = None
+    got = heamd.to_host(ours.apply_galois(heamd.to_device(cts), element, heamd.to_device(key), workspace=workspace))
+    assert np.array_equal(got, ref.apply_galois(cts, element, key))
+
+
+def test_plaintext_conversions_match_oracle(oracle, small):
+    ours, ref, client = small
+    rng = np.random.default_rng(53)
+    pt = rng.integers(0, ref.t, size=(5, ref.degree), dtype=np.uint64)
+    pt[0, :4] = [0, ref.t - 1, (ref.t + 1) // 2, (ref.t + 1) // 2 - 1]
+    for level in (ref.L, ref.L - 1, 1):
+        got = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(pt), moduli_count=level))
+        expected = ref.plaintext_to_eval(pt, moduli_count=level)
+        assert np.array_equal(got, expected)
+        back = heamd.to_host(ours.plaintext_to_coeff(heamd.to_device(expected), moduli_count=level))
+        assert np.array_equal(back, pt)
+    # ct x pt with the device-made Eval plaintext decrypts to the negacyclic product (HeApiTestUtils.swift:1223-1285)
+    r = random.Random(54)
+    m1 = [r.randrange(ref.t) for _ in range(ref.degree)]
+    ct = client.encrypt(m1)
+    qctx = ours.ciphertext_context()
+    ct_eval = qctx.forward_ntt_(heamd.to_device(ct[None]))
+    pt_eval = ours.plaintext_to_eval(heamd.to_device(pt[:1]))
+    product = qctx.inverse_ntt_(ours.mul_plain_(ct_eval, pt_eval, poly_count=2))
+    assert client.decrypt(heamd.to_host(product)[0]) == negacyclic_multiply(m1, [int(v) for v in pt[0]], ref.t)
+
+
+def test_plaintext_to_eval_pir_shape(oracle):
+    """Database preprocessing shape (MulPir.swift:507-556): N=8192, L=4, a slab of plaintexts."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(55)
+    pt = rng.integers(0, 557057, size=(6, degree), dtype=np.uint64)
+    got = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(pt)))
+    assert np.array_equal(got, ref.plaintext_to_eval(pt))
+    assert np.array_equal(heamd.to_host(ours.plaintext_to_coeff(heamd.to_device(got))), pt)
