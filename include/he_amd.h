@@ -223,6 +223,28 @@ int he_bfv_plaintext_to_coeff_device(const he_bfv_context* ctx, uint32_t moduli_
                                      uint64_t* out, size_t batch, he_stream s);
 
 /* =====================================================================================================
+ * B4: application hook -- the PIR server's per-chunk response, device-resident
+ * =================================================================================================== */
+
+/* PirUtilProtocol.computeResponseForOneChunk (PrivateInformationRetrieval/IndexPir/PirUtil.swift:408-486,
+ * MulPirServer.computeResponseForOneChunk IndexPir/MulPir.swift:369-410), all device pointers except `present`:
+ *   dimensions          host, [dimension_count]             IndexPirParameter.dimensions
+ *   dim0_query_eval     [d0][2][L][N] Eval                   expandedDim0Query
+ *   remaining_query     [remaining_query_count][2][L][N] Coeff   expandedRemainingQuery (NULL / 0 for one dimension)
+ *   database            [prod(dimensions)][L][N] Eval        dataChunk; plaintext k of column c at index c*d0 + k
+ *                                                            (MulPir.swift:547-555)
+ *   present             host, [prod(dimensions)] or NULL     0 = nil plaintext
+ *   relinearization_key [L][2][L+1][N] Eval                  needed when dimension_count > 1
+ *   out                 [2][1][N] Coeff over q_0             the response ciphertext after modSwitchDownToSingle
+ * L = he_bfv_ciphertext_moduli_count(ctx).  The reference's precondition (columns == 1 or == remaining query count)
+ * and a final result count != 1 return HE_ERR_INVALID_ARGUMENT. */
+int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                         uint32_t dimension_count, const uint64_t* dim0_query_eval,
+                                         const uint64_t* remaining_query, size_t remaining_query_count,
+                                         const uint64_t* database, const uint8_t* present,
+                                         const uint64_t* relinearization_key, uint64_t* out, he_stream s);
+
+/* =====================================================================================================
  * Diagnostics and test hooks (not part of the reference's surface)
  * =================================================================================================== */
 

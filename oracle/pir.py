@@ -1,0 +1,49 @@
+"""CPU oracle (TEST INFRASTRUCTURE): the PIR server's per-chunk response, composed from the pinned C oracle.
+
+Restates PirUtilProtocol.computeResponseForOneChunk
+(/root/reference Sources/PrivateInformationRetrieval/IndexPir/PirUtil.swift:408-486; the MulPirServer twin at
+IndexPir/MulPir.swift:369-410 is the same algorithm without the task fan-out):
+
+  1. per database column c: Bfv.innerProduct(ciphertexts: dim-0 query, plaintexts: column c) in Eval form, then
+     convertToCanonicalFormat (Coeff for BFV)                                          PirUtil.swift:428-446
+  2. per remaining dimension of size d: results <- [relinearize(innerProduct(query[cur..<cur+d],
+     results[j d ..< (j+1) d])) for j]                                                PirUtil.swift:448-479
+  3. modSwitchDownToSingle, Coeff format                                               PirUtil.swift:481-485
+"""
+import numpy as np
+
+
+def compute_response_for_one_chunk(bfv, dimensions, dim0_query_eval, remaining_query, database, present=None,
+                                   relinearization_key=None):
+    """bfv: oracle.BfvContext.  dim0_query_eval [d0][2][L][N] Eval; remaining_query [d1+d2+..][2][L][N] Coeff;
+    database [prod(dimensions)][L][N] Eval, plaintext k of column c at index c*d0 + k; present: [prod] 0/1 or None.
+    Returns the response ciphertext [2][1][N] (Coeff, single modulus)."""
+    dimensions = [int(d) for d in dimensions]
+    d0 = dimensions[0]
+    per_chunk = int(np.prod(dimensions))
+    columns = per_chunk // d0
+    L, n = bfv.L, bfv.degree
+    database = np.asarray(database, dtype=np.uint64).reshape(per_chunk, L, n)
+    dim0_query_eval = np.asarray(dim0_query_eval, dtype=np.uint64).reshape(d0, 2, L, n)
+    remaining_count = 0 if remaining_query is None else np.asarray(remaining_query).size // (2 * L * n)
+    assert columns == 1 or columns == remaining_count  # precondition, PirUtil.swift:422
+    qctx = bfv.ciphertext_context()
+    results = []
+    for c in range(columns):
+        mask = None if present is None else np.asarray(present, dtype=np.uint8)[c * d0:(c + 1) * d0]
+        product = bfv.inner_product_plain(dim0_query_eval, database[c * d0:(c + 1) * d0], present=mask, poly_count=2)
+        results.append(qctx.inverse_ntt(product[None])[0])
+    cursor = 0
+    for d in dimensions[1:]:
+        query = np.asarray(remaining_query, dtype=np.uint64).reshape(-1, 2, L, n)[cursor:cursor + d]
+        next_results = []
+        for start in range(0, len(results), d):
+            product = bfv.inner_product(query, np.stack(results[start:start + d]))
+            next_results.append(bfv.relinearize(product[None], relinearization_key)[0])
+        results = next_results
+        cursor += d
+    assert len(results) == 1
+    ct = results[0][None]
+    for level in range(L, 1, -1):  # Bfv.modSwitchDownToSingle: modSwitchDown until one modulus is left
+        ct = bfv.mod_switch_down(ct, poly_count=2, moduli_count=level)
+    return ct[0]

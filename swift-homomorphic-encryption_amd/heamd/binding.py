@@ -89,6 +89,8 @@ SIGNATURES = [
     ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
     ("he_bfv_plaintext_to_eval_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_coeff_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_pir_compute_response_chunk_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, ctypes.POINTER(ctypes.c_uint8), vp, vp, vp]),
     # diagnostics / test hooks
     ("he_poly_context_create_host_only", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_poly_context_copy_ntt_tables", ctypes.c_int, [vp, c_u32, U64P, U64P, U64P, U64P, U64P, U64P]),
@@ -469,6 +471,24 @@ class BfvContext:
         out = self._empty((batch, self.degree), plaintext_eval)
         _check(load_library().he_bfv_plaintext_to_coeff_device(self.h, L, _ptr(plaintext_eval), _ptr(out), batch,
                                                                _stream(stream)))
+        return out
+
+    def pir_compute_response_chunk(self, dimensions, dim0_query_eval, remaining_query, database, present=None,
+                                   relinearization_key=None, stream=None):
+        """PirUtilProtocol.computeResponseForOneChunk -> response ciphertext [2][1][N] (Coeff, one modulus)."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = self._empty((2, 1, self.degree), dim0_query_eval)
+        pres = None
+        if present is not None:
+            pres_arr = np.ascontiguousarray(present, dtype=np.uint8)
+            pres = pres_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        _check(load_library().he_pir_compute_response_chunk_device(self.h, dims, len(dimensions),
+                                                                   _ptr(dim0_query_eval), rest, rest_count,
+                                                                   _ptr(database), pres, key, _ptr(out),
+                                                                   _stream(stream)))
         return out
 
     def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):

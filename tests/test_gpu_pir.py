@@ -1,0 +1,86 @@
+"""GPU parity of the device-resident PIR response against the oracle's composition of the pinned
+primitives, plus the semantic check: the response decrypts to the queried database entry."""
+import random
+
+import numpy as np
+import pytest
+
+import heamd
+from bfv_helpers import BfvClient
+
+pytestmark = pytest.mark.gpu
+
+
+def _uniform(rng, shape_prefix, moduli, degree):
+    rows = [rng.integers(0, q, size=tuple(shape_prefix) + (degree,), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=len(shape_prefix)))
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40, 40, 41], False, degree)
+    ref = oracle.BfvContext(degree, t, q)
+    return heamd.BfvContext(degree, t, q), ref, BfvClient(oracle, ref, seed=60)
+
+
+@pytest.mark.parametrize("dims", [[4, 3], [4], [2, 2, 2], [5, 1]])
+def test_pir_response_matches_oracle_and_decrypts(oracle, small, dims):
+    ours, ref, client = small
+    rng = random.Random(61 + len(dims))
+    total = int(np.prod(dims))
+    entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(total)]
+    database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64))
+    present = np.ones(total, dtype=np.uint8)
+    if total > 5:
+        present[5] = 0
+    qctx = ref.ciphertext_context()
+    key = client.relinearization_key()
+    one, zero = [1] + [0] * (ref.degree - 1), [0] * ref.degree
+    selection = [rng.randrange(d) for d in dims]
+    dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == selection[0] else zero)) for k in range(dims[0])])
+    rest_list = [client.encrypt(one if k == selection[i] else zero) for i in range(1, len(dims)) for k in range(dims[i])]
+    rest = np.stack(rest_list) if rest_list else None
+    expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database, present, key)
+    got = heamd.to_host(ours.pir_compute_response_chunk(
+        dims, heamd.to_device(dim0), None if rest is None else heamd.to_device(rest), heamd.to_device(database),
+        present, heamd.to_device(key)))
+    assert np.array_equal(got, expected)
+    # column-major flattening: index = sum_i selection[i] * prod(dims[:i])
+    index, stride = 0, 1
+    for sel, d in zip(selection, dims):
+        index += sel * stride
+        stride *= d
+    want = entries[index] if present[index] else zero
+    assert client.decrypt(got, moduli_count=1) == want
+
+
+def test_pir_response_rejects_mismatched_dimensions(small):
+    ours, ref, _ = small
+    L, n = ours.L, ours.degree
+    dim0 = heamd.to_device(np.zeros((2, 2, L, n), dtype=np.uint64))
+    rest = heamd.to_device(np.zeros((2, 2, L, n), dtype=np.uint64))
+    database = heamd.to_device(np.zeros((6, L, n), dtype=np.uint64))
+    key = heamd.to_device(np.zeros((L, 2, L + 1, n), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:  # 3 columns but 2 remaining query ciphertexts (PirUtil.swift:422)
+        ours.pir_compute_response_chunk([2, 3], dim0, rest[:2], database, None, key)
+    assert err.value.name == "invalidArgument"
+
+
+def test_pir_response_config_shape(oracle):
+    """N=8192, L=4 (BASELINE configs[4] ring), a 16 x 8 chunk of uniform words: exact words vs the oracle."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(62)
+    dims = [16, 8]
+    moduli = q[:-1]
+    dim0 = _uniform(rng, (dims[0], 2), moduli, degree)
+    rest = _uniform(rng, (dims[1], 2), moduli, degree)
+    database = _uniform(rng, (dims[0] * dims[1],), moduli, degree)
+    key = _uniform(rng, (ours.L, 2), q, degree)
+    expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database, None, key)
+    got = heamd.to_host(ours.pir_compute_response_chunk(dims, heamd.to_device(dim0), heamd.to_device(rest),
+                                                        heamd.to_device(database), None, heamd.to_device(key)))
+    assert np.array_equal(got, expected)

@@ -301,3 +301,30 @@ def test_bfv_context_errors(oracle):
     with pytest.raises(oracle.OracleError) as err:
         oracle.BfvContext(degree, q[0], q)  # t must be < every q_i
     assert err.value.name == "invalidEncryptionParameters"
+
+
+def test_pir_response_selects_the_queried_entry(oracle, small_bfv):
+    """PirUtil.computeResponseForOneChunk (PirUtil.swift:408-486) on a 4 x 3 database: one-hot queries per dimension,
+    the response (one modulus left) decrypts to the selected plaintext polynomial."""
+    ctx, client = small_bfv
+    rng = random.Random(28)
+    dims = [4, 3]
+    entries = [[rng.randrange(ctx.t) for _ in range(ctx.degree)] for _ in range(12)]
+    database = ctx.plaintext_to_eval(np.array(entries, dtype=np.uint64))
+    present = np.ones(12, dtype=np.uint8)
+    present[5] = 0  # a nil plaintext (skipped by innerProduct, Bfv.swift:486-489)
+    qctx = ctx.ciphertext_context()
+    key = client.relinearization_key()
+    one, zero = [1] + [0] * (ctx.degree - 1), [0] * ctx.degree
+    for row, column in ((2, 1), (0, 2), (1, 1)):
+        dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == row else zero)) for k in range(dims[0])])
+        rest = np.stack([client.encrypt(one if k == column else zero) for k in range(dims[1])])
+        response = oracle.pir.compute_response_for_one_chunk(ctx, dims, dim0, rest, database, present, key)
+        assert response.shape == (2, 1, ctx.degree)
+        index = column * dims[0] + row
+        expected = entries[index] if present[index] else zero
+        assert client.decrypt(response, moduli_count=1) == expected
+    # one-dimensional database: no ct x ct step, no key needed
+    dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == 3 else zero)) for k in range(4)])
+    response = oracle.pir.compute_response_for_one_chunk(ctx, [4], dim0, None, database[:4], None, None)
+    assert client.decrypt(response, moduli_count=1) == entries[3]
