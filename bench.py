@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="polynomials in the CPU sample (0 = auto)")
     ap.add_argument("--skip-gather", action="store_true")
+    ap.add_argument("--skip-other-configs", action="store_true", help="do not time configs 3-5 (extras only)")
     return ap.parse_args()
 
 
@@ -231,6 +232,14 @@ def main():
                 "library": heamd.version(),
             },
         }
+        if world == 1 and not args.skip_other_configs:
+            # the other BASELINE.json configs on this GPU (ciphertext-mul/s, mod-switch, PIR inner loop); not `value`
+            sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
+            import path_bench
+
+            del slab
+            torch.cuda.empty_cache()
+            result["extras"]["other_configs"] = path_bench.run_all(quick=False)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(moduli, args.cpu_sample)
         else:
