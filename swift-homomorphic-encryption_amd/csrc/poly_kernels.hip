@@ -187,58 +187,70 @@ __global__ void __launch_bounds__(kThreads)
     inner_product_plain_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
                                const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
                                const DeviceContext ctx, size_t count, size_t columns, uint64_t max_lazy) {
-    const uint32_t log_pairs_per_row = ctx.log_degree - 1;
-    const size_t pairs_per_poly = (static_cast<size_t>(ctx.moduli_count) << log_pairs_per_row);
-    const size_t pair = blockIdx.y * static_cast<size_t>(kThreads) + threadIdx.x;
-    if (pair >= pairs_per_poly) return;
+    // One lane = one word of COLS output columns (8-byte streams: the width the copy probe runs fastest at, and half
+    // the accumulator registers of a 16-byte lane, so twice the waves hide the latency of the plaintext stream).
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) << ctx.log_degree;
+    const size_t word = blockIdx.y * static_cast<size_t>(kThreads) + threadIdx.x;
+    if (word >= words_per_poly) return;
     const size_t col0 = static_cast<size_t>(blockIdx.x) * COLS;
-    const DeviceModulus m = ctx.moduli[pair >> log_pairs_per_row];
-    U128 acc[COLS][POLYS][2];
+    const DeviceModulus m = ctx.moduli[word >> ctx.log_degree];
+    U128 acc[COLS][POLYS];
 #pragma unroll
     for (int c = 0; c < COLS; ++c)
 #pragma unroll
-        for (int q = 0; q < POLYS; ++q) acc[c][q][0] = acc[c][q][1] = U128{0, 0};
+        for (int q = 0; q < POLYS; ++q) acc[c][q] = U128{0, 0};
     uint64_t since_reduce[COLS];
+    bool live[COLS];
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) since_reduce[c] = 0;
+    for (int c = 0; c < COLS; ++c) {
+        since_reduce[c] = 0;
+        live[c] = col0 + c < columns;
+    }
+    // every stream is "uniform base + this lane's word": the uniform part stays in SGPRs.  A column past the end
+    // re-reads the last real column (its products are never stored).
+    const uint64_t* ct_base = cts + word;
+    const uint64_t* pt_lane = pts + word;
+    size_t pt_column[COLS];  // uniform word offsets of the columns' first plaintexts
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) pt_column[c] = (live[c] ? col0 + c : columns - 1) * count * words_per_poly;
 
-    const U64x2* ct_base = reinterpret_cast<const U64x2*>(cts) + pair;
-    for (size_t j = 0; j < count; ++j) {
-        U64x2 x[POLYS];
+    // software pipeline: the loads of item j + 1 are in flight while item j is multiplied
+    uint64_t x_next[POLYS], y_next[COLS];
+    auto fetch = [&](size_t j) {
 #pragma unroll
-        for (int q = 0; q < POLYS; ++q) x[q] = ct_base[(j * POLYS + q) * pairs_per_poly];
+        for (int q = 0; q < POLYS; ++q) x_next[q] = ct_base[(j * POLYS + q) * words_per_poly];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) y_next[c] = pt_lane[pt_column[c] + j * words_per_poly];
+    };
+    if (count > 0) fetch(0);
+    for (size_t j = 0; j < count; ++j) {
+        uint64_t x[POLYS], y[COLS];
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) x[q] = x_next[q];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) y[c] = y_next[c];
+        if (j + 1 < count) fetch(j + 1);
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {
-            const size_t col = col0 + c;
-            if (col >= columns) continue;
-            if (present != nullptr && present[col * count + j] == 0) continue;
-            const U64x2 y = reinterpret_cast<const U64x2*>(pts)[(col * count + j) * pairs_per_poly + pair];
+            if (!live[c]) continue;
+            if (present != nullptr && present[(col0 + c) * count + j] == 0) continue;  // nil plaintext, Bfv.swift:486-489
 #pragma unroll
-            for (int q = 0; q < POLYS; ++q) {
-                mac128(acc[c][q][0], x[q].x, y.x);
-                mac128(acc[c][q][1], x[q].y, y.y);
-            }
+            for (int q = 0; q < POLYS; ++q) mac128(acc[c][q], x[q], y[c]);
             if (++since_reduce[c] >= max_lazy) {  // Bfv.swift:496-500 reduceInPlace cadence
                 since_reduce[c] = 0;
 #pragma unroll
                 for (int q = 0; q < POLYS; ++q)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        acc[c][q][h] = U128{barrett_reduce128(acc[c][q][h], m.p, m.barrett128_lo, m.barrett128_hi), 0};
+                    acc[c][q] = U128{barrett_reduce128(acc[c][q], m.p, m.barrett128_lo, m.barrett128_hi), 0};
             }
         }
     }
 #pragma unroll
     for (int c = 0; c < COLS; ++c) {
-        const size_t col = col0 + c;
-        if (col >= columns) continue;
+        if (!live[c]) continue;
 #pragma unroll
-        for (int q = 0; q < POLYS; ++q) {
-            U64x2 r;
-            r.x = barrett_reduce128(acc[c][q][0], m.p, m.barrett128_lo, m.barrett128_hi);
-            r.y = barrett_reduce128(acc[c][q][1], m.p, m.barrett128_lo, m.barrett128_hi);
-            reinterpret_cast<U64x2*>(out)[(col * POLYS + q) * pairs_per_poly + pair] = r;
-        }
+        for (int q = 0; q < POLYS; ++q)
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] =
+                barrett_reduce128(acc[c][q], m.p, m.barrett128_lo, m.barrett128_hi);
     }
 }
 
@@ -298,9 +310,9 @@ hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t*
                                             uint64_t* out, const DeviceContext& ctx, size_t count, size_t columns,
                                             uint64_t max_lazy, hipStream_t stream) {
     constexpr int kCols = 4;
-    const size_t pairs_per_poly = static_cast<size_t>(ctx.moduli_count) * (ctx.degree / 2);
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
     const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
-                    static_cast<unsigned>((pairs_per_poly + kThreads - 1) / kThreads));
+                    static_cast<unsigned>((words_per_poly + kThreads - 1) / kThreads));
     hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
                        present_device, out, ctx, count, columns, max_lazy);
     return hipGetLastError();
@@ -310,7 +322,6 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                       uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
                                       size_t columns, uint64_t max_lazy, hipStream_t stream) {
     if (columns == 0) return hipSuccess;
-    if (ctx.degree < 2) return hipErrorInvalidValue;
     switch (poly_count) {
         case 1:
             return launch_inner_product_plain_polys<1>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
