@@ -59,7 +59,7 @@ def synthetic_slab(torch, moduli, batch, degree, seed):
 def pmc_traffic_gbps(batch, forward_seconds):
     """HBM traffic of one forward launch as counted by the PMC passes committed under profiles/ (bench.py cannot
     run rocprofv3 around itself); None when the committed profile was taken at another batch size."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_ntt_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01e_pmc_ntt_traffic.json")
     try:
         with open(path) as f:
             profile = json.load(f)
@@ -211,14 +211,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_forward_tiled<13, 10, 2, 0> (forward NTT: one 1024-lane workgroup per residue row, "
+                "kernel": "ntt_forward_tiled<13, 10, 3, 0> (forward NTT: one 1024-lane workgroup per residue row, "
                           "8 words per lane, headroom butterflies)",
                 "achieved": achieved_gbps,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
                 "traffic": pmc_traffic_gbps(args.batch, forward_s),
-                "traffic_source": "profiles/r01c_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": "profiles/r01e_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "gfx950 FETCH_SIZE x2 correction), bytes per launch / this run's launch time",
                 "algorithmic_bytes_per_launch": bytes_per_transform * args.batch,
                 "avg_launch_ms": forward_s * 1e3,
