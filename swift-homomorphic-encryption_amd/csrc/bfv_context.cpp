@@ -28,6 +28,8 @@ DeviceModulus barrett_constants(u64 p) {
     const int bits = bit_length(p);
     m.product_factor = static_cast<u64>((static_cast<u128>(1) << (bits + 62)) / p);
     m.product_shift = static_cast<uint32_t>(bits >= 2 ? bits - 2 : 0);
+    m.two64_mod_p = static_cast<u64>((static_cast<u128>(1) << 64) % p);
+    m.two64_mod_p_shoup = shoup_factor(m.two64_mod_p, p);
     return m;
 }
 

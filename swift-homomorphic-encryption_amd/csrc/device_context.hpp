@@ -21,6 +21,8 @@ struct DeviceModulus {
     uint64_t inv_degree_shoup;
     uint64_t inv_degree_root;  // N^-1 * psi^(-N/2) mod p     (+ Shoup factor)
     uint64_t inv_degree_root_shoup;
+    uint64_t two64_mod_p;        // 2^64 mod p (+ Shoup factor): folds the high word of a 128-bit sum
+    uint64_t two64_mod_p_shoup;
 };
 
 struct DeviceContext {

@@ -174,6 +174,39 @@ __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t w
     return csub(shoup_lazy(x, w, wf, 0 - p), p);
 }
 
+// Shoup multiplication by a wave-uniform constant, canonical result: x < 2^63, w < p <= 2^62 - 1, wf the usual
+// floor(w 2^64 / p).  Uses the halved factor so that every partial-product column fits the 64-bit addend of a
+// v_mad_u64_u32 (a0 b1 + a1 b0 + hi(a0 b0) < 2^64 for a < 2^63, b < 2^63): q = floor(x (wf >> 1) / 2^64) exactly,
+// x w - q 2p in [0, 3p).  The constants stay in SGPRs (each instruction reads at most one).
+__device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
+    const uint64_t wf_half = wf >> 1, neg_2p = 0 - 2 * p;
+    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf_half), b1 = hi32(wf_half);
+    uint64_t low, cross, q, carry;
+    asm("v_mad_u64_u32 %0, %3, %4, %6, 0\n\t"
+        "v_lshrrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %1, %3, %4, %7, %0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1\n\t"
+        "v_lshrrev_b64 %1, 32, %1\n\t"
+        "v_mad_u64_u32 %2, %3, %5, %7, %1"
+        : "=&v"(low), "=&v"(cross), "=&v"(q), "=&s"(carry)
+        : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
+    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
+    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
+    uint64_t acc, carry2;
+    uint32_t u0, u1, u2, u3;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
+        "v_mul_lo_u32 %1, %6, %9\n\t"
+        "v_mul_lo_u32 %2, %7, %8\n\t"
+        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
+        "v_mul_lo_u32 %3, %10, %13\n\t"
+        "v_mul_lo_u32 %4, %11, %12\n\t"
+        "v_add3_u32 %1, %1, %2, %3"
+        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
+        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
+    const uint64_t r = pack64(lo32(acc), hi32(acc) + u0 + u3);
+    return csub(csub(r, 2 * p), p);
+}
+
 __device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + b, p); }
 __device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + p - b, p); }
 __device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t p) { return csub(p - a, p); }
@@ -203,6 +236,80 @@ __device__ __forceinline__ void add128(U128& acc, U128 v) {  // wrapping
     acc.lo = lo;
 }
 __device__ __forceinline__ void mac128(U128& acc, uint64_t a, uint64_t b) { add128(acc, mul_wide(a, b)); }
+
+// ---- sums of 64x64 products without a carry chain per term ---------------------------------------------------
+// sum = t + c 2^32 + h 2^64 + (t_carry + c_carry 2^32) 2^64: every partial-product column rides the 64-bit addend of
+// its own v_mad_u64_u32 and the carry-outs are counted (7 instructions per product instead of ~18 for a 128-bit
+// multiply-add).  Exact for any operands while h does not wrap (65 536 products of 62-bit operands).
+struct ProductSum {
+    uint64_t t, c, h;
+    uint32_t t_carry, c_carry;
+};
+__device__ __forceinline__ ProductSum product_sum_zero() { return ProductSum{0, 0, 0, 0, 0}; }
+// b in VGPRs
+__device__ __forceinline__ void product_sum_add(ProductSum& s, uint64_t a, uint64_t b) {
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, %0\n\t"
+        "v_addc_co_u32 %3, %5, 0, %3, %5\n\t"
+        "v_mad_u64_u32 %1, %5, %6, %9, %1\n\t"
+        "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+        "v_mad_u64_u32 %1, %5, %7, %8, %1\n\t"
+        "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+        "v_mad_u64_u32 %2, %5, %7, %9, %2"
+        : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "+v"(s.c_carry), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "v"(lo32(b)), "v"(hi32(b)));
+}
+// b wave-uniform (a table constant): stays in SGPRs
+__device__ __forceinline__ void product_sum_add_uniform(ProductSum& s, uint64_t a, uint64_t b) {
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, %0\n\t"
+        "v_addc_co_u32 %3, %5, 0, %3, %5\n\t"
+        "v_mad_u64_u32 %1, %5, %6, %9, %1\n\t"
+        "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+        "v_mad_u64_u32 %1, %5, %7, %8, %1\n\t"
+        "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+        "v_mad_u64_u32 %2, %5, %7, %9, %2"
+        : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "+v"(s.c_carry), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "s"(lo32(b)), "s"(hi32(b)));
+}
+// the sum mod 2^128
+__device__ __forceinline__ U128 product_sum_value(const ProductSum& s) {
+    U128 r;
+    r.lo = s.t + (s.c << 32);
+    r.hi = s.h + s.t_carry + (s.c >> 32) + (static_cast<uint64_t>(s.c_carry) << 32) + (r.lo < s.t ? 1 : 0);
+    return r;
+}
+
+// x mod p for any 64-bit x with wave-uniform p and factor = floor(2^64 / p).  For p >= 2^32 the factor is a single
+// 32-bit word and the quotient estimate is two multiply-adds; smaller moduli take the general path.
+__device__ __forceinline__ uint64_t barrett_reduce64_uniform(uint64_t x, uint64_t p, uint64_t factor) {
+    if (hi32(factor) != 0) return barrett_reduce64(x, p, factor);  // uniform branch: p < 2^32
+    uint64_t t, qp, carry, carry2;
+    uint32_t q_high;
+    asm("v_mad_u64_u32 %0, %1, %2, %4, 0\n\t"       // x0 f
+        "v_lshrrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %4, %0\n\t"      // x1 f + hi32(x0 f): its high word is q = floor(x f / 2^64)
+        "v_lshrrev_b64 %0, 32, %0"
+        : "=&v"(t), "=&s"(carry)
+        : "v"(lo32(x)), "v"(hi32(x)), "s"(lo32(factor)));
+    const uint32_t q = lo32(t);
+    asm("v_mul_lo_u32 %1, %3, %5\n\t"               // q p1
+        "v_mad_u64_u32 %0, %2, %3, %4, 0"             // q p0
+        : "=&v"(qp), "=&v"(q_high), "=&s"(carry2)
+        : "v"(q), "s"(lo32(p)), "s"(hi32(p)));
+    const uint64_t q_times_p = pack64(lo32(qp), hi32(qp) + q_high);
+    return csub(x - q_times_p, p);
+}
+
+// Canonical residue of a ProductSum whose value is < 2^127 (at most 8 products of operands < 2^62):
+// (hi 2^64 + lo) mod p = ((hi (2^64 mod p)) mod p + lo mod p) mod p.
+template <typename Modulus>
+__device__ __forceinline__ uint64_t reduce_product_sum(const ProductSum& s, const Modulus& m) {
+    const U128 v = product_sum_value(s);
+    const uint64_t high = shoup_mul_uniform(v.hi, m.two64_mod_p, m.two64_mod_p_shoup, m.p);
+    const uint64_t low = barrett_reduce64_uniform(v.lo, m.p, m.barrett64);
+    return add_mod(high, low, m.p);
+}
 
 // Barrett on a product x*y < p^2 (Modulus.swift:349-360): factor = floor(2^(bits(p)+62)/p), shift = bits(p)-2.
 __device__ __forceinline__ uint64_t barrett_mul(uint64_t x, uint64_t y, uint64_t p, uint64_t factor, int shift) {

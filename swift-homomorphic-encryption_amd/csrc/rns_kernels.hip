@@ -28,10 +28,19 @@ inline unsigned grid_for(size_t work_items) {
     return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
+// one lane per work item, no striding (kernels that keep many table constants live)
+inline unsigned exact_grid(size_t work_items) {
+    const size_t blocks = (work_items + kThreads - 1) / kThreads;
+    return static_cast<unsigned>(blocks ? blocks : 1);
+}
+
 __device__ __forceinline__ uint64_t reduce128(U128 x, const DeviceModulus& m) {
     return barrett_reduce128(x, m.p, m.barrett128_lo, m.barrett128_hi);
 }
-__device__ __forceinline__ uint64_t shoup_mul_pair(uint64_t x, U64x2 c, uint64_t p) { return shoup_mul(x, c.x, c.y, p); }
+// x < 2^63 times a table constant (wave-uniform), canonical result
+__device__ __forceinline__ uint64_t shoup_mul_pair(uint64_t x, U64x2 c, uint64_t p) {
+    return shoup_mul_uniform(x, c.x, c.y, p);
+}
 
 // ---- liftQToQBsk: in [polys][L][N] -> out [polys][2L+1][N] -------------------------------------------------------
 // Polynomial p = item * polys_per_item + c is read at in + item * in_item_stride + c * L * N and written at
@@ -49,7 +58,9 @@ __global__ void __launch_bounds__(kThreads)
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
     constexpr uint64_t kMTildeValue = uint64_t(1) << 32;
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+    // one coefficient per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
+    // spills SGPRs into VGPR lanes
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
         const size_t item = poly / layout.polys_per_item, c = poly - item * layout.polys_per_item;
         const uint64_t* src = in + item * layout.in_item_stride + c * L * n + k;
@@ -62,22 +73,25 @@ __global__ void __launch_bounds__(kThreads)
             y[i] = shoup_mul_pair(x, tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
-        U128 acc{0, 0};
+        ProductSum acc = product_sum_zero();
 #pragma unroll
-        for (int i = 0; i < L; ++i) mac128(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
-        uint64_t r = reduce128(acc, tool.ext_moduli[L + 1]);
+        for (int i = 0; i < L; ++i) product_sum_add_uniform(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
+        // the (L+2)'th extended modulus is mTilde = 2^32 at the top level; a lower-level tool takes a prefix of
+        // [Bsk..., mTilde] and finds a Bsk prime there (the reference's own behaviour, reproduced as is)
+        const DeviceModulus last = tool.ext_moduli[L + 1];
+        uint64_t r = last.p == kMTildeValue ? lo32(product_sum_value(acc).lo) : reduce_product_sum(acc, last);
         r = shoup_mul_pair(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
         const bool below = r < (kMTildeValue >> 1);
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            U128 sum{0, 0};
+            ProductSum sum = product_sum_zero();
 #pragma unroll
-            for (int i = 0; i < L; ++i) mac128(sum, y[i], tool.q_to_ext[j * L + i]);
-            uint64_t v = reduce128(sum, m);
+            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
+            uint64_t v = reduce_product_sum(sum, m);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
             const U64x2 q_mod = tool.q_mod_bsk[j];
-            v += shoup_lazy(centered, q_mod.x, q_mod.y, 0 - m.p);           // RnsTool.swift:363
+            v += shoup_mul_pair(centered, q_mod, m.p);                      // RnsTool.swift:363 (v < 2p < 2^63)
             dst[(L + j) * n] = shoup_mul_pair(v, tool.inv_mtilde_mod_bsk[j], m.p);  // RnsTool.swift:364
         }
     }
@@ -90,7 +104,7 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
         const uint64_t* src = in + poly * (2 * L + 1) * n + k;
         uint64_t* dst = out + poly * L * n + k;
@@ -102,10 +116,10 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            U128 sum{0, 0};
+            ProductSum sum = product_sum_zero();
 #pragma unroll
-            for (int i = 0; i < L; ++i) mac128(sum, y[i], tool.q_to_ext[j * L + i]);
-            const uint64_t converted = reduce128(sum, m);
+            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
+            const uint64_t converted = reduce_product_sum(sum, m);
             f[j] = shoup_mul_pair(src[(L + j) * n] + m.p - converted, tool.inv_q_mod_bsk[j], m.p);
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
@@ -113,21 +127,23 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t z[L];
 #pragma unroll
         for (int i = 0; i < L; ++i) z[i] = shoup_mul_pair(f[i], tool.inv_punctured_b[i], tool.ext_moduli[i].p);
-        U128 alpha_sum{0, 0};
+        ProductSum alpha_sum = product_sum_zero();
 #pragma unroll
-        for (int i = 0; i < L; ++i) mac128(alpha_sum, z[i], tool.b_to_msk[i]);
-        uint64_t alpha = reduce128(alpha_sum, msk);
+        for (int i = 0; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
+        uint64_t alpha = reduce_product_sum(alpha_sum, msk);
         alpha = shoup_mul_pair(alpha + msk.p - f[L], tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
         for (int row = 0; row < L; ++row) {
             const DeviceModulus m = tool.q_moduli[row];
-            U128 sum{0, 0};
+            ProductSum sum = product_sum_zero();
 #pragma unroll
-            for (int i = 0; i < L; ++i) mac128(sum, z[i], tool.b_to_q[row * L + i]);
-            const uint64_t converted = reduce128(sum, m);
-            const uint64_t adjust = exceeds ? shoup_mul_pair(msk.p - alpha, tool.b_mod_q[row], m.p)
-                                            : shoup_mul_pair(alpha, tool.neg_b_mod_q[row], m.p);
+            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, z[i], tool.b_to_q[row * L + i]);
+            const uint64_t converted = reduce_product_sum(sum, m);
+            // RnsTool.swift:436-446: alpha > m_sk/2 ? (m_sk - alpha) (B mod q) : alpha (-B mod q); the second form is
+            // the negation of alpha (B mod q), so one product serves both
+            const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
+            const uint64_t adjust = exceeds ? magnitude : neg_mod(magnitude, m.p);
             dst[row * n] = add_mod(converted, adjust, m.p);
         }
     }
@@ -291,15 +307,17 @@ template <int L>
 struct LiftLauncher {
     static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
                           const LiftLayout& layout, hipStream_t s) {
-        hipLaunchKernelGGL(lift_kernel<L>, dim3(grid_for(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out, tool,
-                           polys, layout);
+        if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(lift_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
+                           tool, polys, layout);
         return hipGetLastError();
     }
 };
 template <int L>
 struct FloorLauncher {
     static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
-        hipLaunchKernelGGL(floor_kernel<L>, dim3(grid_for(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
+        if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(floor_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
                            tool, polys);
         return hipGetLastError();
     }
