@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over the NTT kernels (run on the GPU box):  bash bench_tools/pmc_passes.sh <out-dir> <variant ...>
+# PMC passes (run on the GPU box):  [TARGET=script.py FILTER=substr] bash bench_tools/pmc_passes.sh <out-dir> <args ...>
+# default target: the NTT kernels (bench_tools/ntt_profile_target.py <variant ...>)
 # One rocprofv3 run per counter group (SQ has 8 slots, TCC 4); no trace domains next to --pmc.
 set -u
 export TMPDIR=/tmp
@@ -18,6 +19,6 @@ GROUPS_=(
 i=0
 for g in "${GROUPS_[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $g --output-format csv -d "$OUT/pass$i" -- python bench_tools/ntt_profile_target.py $VARIANTS > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see $OUT/pass$i.log)"
+  rocprofv3 --pmc $g --output-format csv -d "$OUT/pass$i" -- python ${TARGET:-bench_tools/ntt_profile_target.py} $VARIANTS > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see $OUT/pass$i.log)"
 done
-python bench_tools/pmc_summary.py "$OUT" | tee "$OUT/summary.txt"
+python bench_tools/pmc_summary.py "$OUT" ${FILTER:-ntt_} | tee "$OUT/summary.txt"

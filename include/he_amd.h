@@ -214,6 +214,11 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
                                uint64_t element, const uint64_t* galois_key, uint64_t* out, size_t batch,
                                void* workspace, size_t workspace_bytes, he_stream s);
 size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
+/* _RnsTool.scaleAndRound(poly:scalingFactor:) (RnsTool.swift:272-302), the RNS step of Bfv.decrypt
+ * (Bfv/Bfv+Decrypt.swift): in [batch][L][N] Coeff (c0 + c1 s [+ c2 s^2]) -> out [batch][N], values < t.
+ * scaling_factor < t (the ciphertext's correction factor). */
+int he_rns_scale_and_round_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in,
+                                  uint64_t scaling_factor, uint64_t* out, size_t batch, he_stream s);
 /* Plaintext<Coeff>.convertToEvalFormat(moduliCount:) (Plaintext.swift:149-170): plaintext [batch][N] (values < t)
  * -> out [batch][L][N] Eval.  This is the database preprocessing step of PIR (MulPir.swift:507-556). */
 int he_bfv_plaintext_to_eval_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext,

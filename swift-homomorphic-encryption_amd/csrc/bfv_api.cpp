@@ -277,6 +277,23 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
     return HE_OK;
 }
 
+// ------------------------------------------------------------------------------------------ scaleAndRound
+int he_rns_scale_and_round_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* in,
+                                  uint64_t scaling_factor, uint64_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null polynomial");
+    const uint64_t t = ctx->impl->plaintext_modulus();
+    if (scaling_factor >= t) return invalid_argument("scaling factor not reduced mod t");
+    // inverseGammaModT.multiplyMod(scalingFactor) (RnsTool.swift:298)
+    const uint64_t scaled = heamd::mul_mod(tool->device.inv_gamma_mod_t, scaling_factor, t);
+    const heamd::U64x2 final_scale{scaled, heamd::shoup_factor(scaled, t)};
+    HEAMD_HIP_TRY(heamd::launch_scale_and_round(in, out, tool->device, final_scale, batch, as_stream(s)));
+    return HE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ plaintext <-> Eval
 int he_bfv_plaintext_to_eval_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintext,
                                     uint64_t* out, size_t batch, he_stream s) {

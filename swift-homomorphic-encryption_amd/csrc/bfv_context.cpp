@@ -182,6 +182,10 @@ int BfvContext::build_tool(uint32_t k) {
     const size_t o_b_mod_q = arena.reserve<U64x2>(L);
     const size_t o_neg_b_mod_q = arena.reserve<U64x2>(L);
     const size_t o_scaled = arena.reserve<DeviceModulus>(2 * L + 1);
+    const size_t o_sr_scale = arena.reserve<U64x2>(L);
+    const size_t o_q_to_tg = arena.reserve<u64>(2 * L);
+    const size_t o_tg_moduli = arena.reserve<DeviceModulus>(2);
+    const size_t o_neg_inv_q_tg = arena.reserve<U64x2>(2);
 
     for (size_t i = 0; i < L; ++i) arena.at<DeviceModulus>(o_q_moduli)[i] = barrett_constants(q[i]);
     for (size_t j = 0; j < L + 2; ++j) arena.at<DeviceModulus>(o_ext_moduli)[j] = barrett_constants(ext[j]);
@@ -235,8 +239,26 @@ int BfvContext::build_tool(uint32_t k) {
         arena.at<DeviceModulus>(o_scaled)[r] = m;
     }
 
+    // scaleAndRound tables (RnsTool.swift:145-169): [t, gamma] is the output base of rnsConvertQToTGamma
+    const u64 t_gamma[2] = {t_, kGamma};
+    u64 inv_gamma_mod_t = 0;
+    if (!inverse_mod(kGamma % t_, t_, inv_gamma_mod_t)) return HE_ERR_NOT_INVERTIBLE;
+    for (size_t j = 0; j < 2; ++j) {
+        arena.at<DeviceModulus>(o_tg_moduli)[j] = barrett_constants(t_gamma[j]);
+        u64 inverse = 0;
+        if (!inverse_mod(product_mod(q, L, t_gamma[j]), t_gamma[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_neg_inv_q_tg)[j] = shoup_pair(neg_mod(inverse, t_gamma[j]), t_gamma[j]);
+        for (size_t i = 0; i < L; ++i) arena.at<u64>(o_q_to_tg)[j * L + i] = punctured_product(q, L, i, t_gamma[j]);
+    }
+    for (size_t i = 0; i < L; ++i) {
+        const u64 gamma_t = mul_mod(kGamma % q[i], t_ % q[i], q[i]);
+        // poly *= prodGammaTModQ, then the converter's (Q/q_i)^-1: two exact products mod q_i = one
+        arena.at<U64x2>(o_sr_scale)[i] = shoup_pair(mul_mod(gamma_t, arena.at<U64x2>(o_inv_punct_q)[i].x, q[i]), q[i]);
+    }
+
     RnsToolDevice& d = level.device;
     d.L = static_cast<uint32_t>(L);
+    d.inv_gamma_mod_t = inv_gamma_mod_t;
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
     d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;
     d.inv_b_mod_msk = inv_b_mod_msk;
@@ -259,6 +281,10 @@ int BfvContext::build_tool(uint32_t k) {
     d.b_mod_q = reinterpret_cast<const U64x2*>(base + o_b_mod_q);
     d.neg_b_mod_q = reinterpret_cast<const U64x2*>(base + o_neg_b_mod_q);
     level.qbsk_moduli_scaled_by_t = reinterpret_cast<const DeviceModulus*>(base + o_scaled);
+    d.scale_round_scale = reinterpret_cast<const U64x2*>(base + o_sr_scale);
+    d.q_to_t_gamma = reinterpret_cast<const uint64_t*>(base + o_q_to_tg);
+    d.t_gamma = reinterpret_cast<const DeviceModulus*>(base + o_tg_moduli);
+    d.neg_inv_q_mod_t_gamma = reinterpret_cast<const U64x2*>(base + o_neg_inv_q_tg);
     return HE_OK;
 }
 

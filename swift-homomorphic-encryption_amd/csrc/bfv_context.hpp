@@ -29,6 +29,12 @@ struct RnsToolDevice {
     const uint64_t* b_to_q;            // [L][L]  (B/Bsk_k) mod q_i  (row i, column k)
     const U64x2* b_mod_q;              // [L]     B mod q_i                               RnsTool.swift:211-216
     const U64x2* neg_b_mod_q;          // [L]     -B mod q_i                              RnsTool.swift:217-223
+    // scaleAndRound (RnsTool.swift:272-302): base conversion Q -> [t, gamma]
+    const U64x2* scale_round_scale;    // [L]     (gamma t mod q_i) (Q/q_i)^-1 mod q_i            RnsTool.swift:149, :97-106
+    const uint64_t* q_to_t_gamma;      // [2][L]  (Q/q_i) mod t, (Q/q_i) mod gamma
+    const DeviceModulus* t_gamma;      // [2]     Barrett constants of t and gamma
+    const U64x2* neg_inv_q_mod_t_gamma;// [2]     -(Q^-1) mod t, mod gamma                          RnsTool.swift:157-160
+    uint64_t inv_gamma_mod_t;          //         gamma^-1 mod t                                    RnsTool.swift:150-153
     U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169
     U64x2 inv_b_mod_msk;               //         B^-1 mod m_sk                           RnsTool.swift:246-250
 };

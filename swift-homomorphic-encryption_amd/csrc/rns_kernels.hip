@@ -149,6 +149,40 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// ---- scaleAndRound: in [polys][L][N] (Coeff over Q) -> out [polys][N] (mod t)        RnsTool.swift:272-302 ----------
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+    scale_and_round_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool,
+                           const U64x2 final_scale, size_t polys) {
+    const uint32_t logn = tool.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = polys << logn;
+    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
+        const size_t poly = idx >> logn, k = idx & (n - 1);
+        const uint64_t* src = in + poly * L * n + k;
+        uint64_t y[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) y[i] = shoup_mul_pair(src[i * n], tool.scale_round_scale[i], tool.q_moduli[i].p);
+        uint64_t converted[2];  // (gamma t x) converted to base [t, gamma], times -(Q^-1)          :279-282
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const DeviceModulus m = tool.t_gamma[j];
+            ProductSum sum = product_sum_zero();
+#pragma unroll
+            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_t_gamma[j * L + i]);
+            converted[j] = shoup_mul_pair(reduce_product_sum(sum, m), tool.neg_inv_q_mod_t_gamma[j], m.p);
+        }
+        const DeviceModulus t = tool.t_gamma[0];
+        const uint64_t gamma = tool.t_gamma[1].p;
+        const uint64_t mod_gamma = converted[1];
+        // centred remainder mod gamma, taken mod t                                                :289-297
+        const bool above = mod_gamma > (gamma >> 1);
+        const uint64_t reduced = barrett_reduce64_uniform(above ? gamma - mod_gamma : mod_gamma, t.p, t.barrett64);
+        const uint64_t s_gamma = above ? neg_mod(reduced, t.p) : reduced;
+        out[idx] = shoup_mul_pair(sub_mod(converted[0], s_gamma, t.p), final_scale, t.p);          // :298-301
+    }
+}
+
 // ---- tensor product: (a0, a1) x (b0, b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1), word-wise in Eval form ----------------
 // in: [items][4][rows][N] (a0, a1, b0, b1); out: [items][3][rows][N]
 __global__ void __launch_bounds__(kThreads)
@@ -323,9 +357,26 @@ struct FloorLauncher {
     }
 };
 
+template <int L>
+struct ScaleAndRoundLauncher {
+    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
+                          hipStream_t s) {
+        if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(scale_and_round_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
+                           in, out, tool, final_scale, polys);
+        return hipGetLastError();
+    }
+};
+
 }  // namespace
 
 uint32_t rns_max_supported_moduli() { return kMaxL; }
+
+hipError_t launch_scale_and_round(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, U64x2 final_scale,
+                                  size_t polys, hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    return dispatch_L<ScaleAndRoundLauncher>(tool.L, in, out, tool, final_scale, polys, stream);
+}
 
 hipError_t launch_lift_q_to_qbsk(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
                                  hipStream_t stream) {

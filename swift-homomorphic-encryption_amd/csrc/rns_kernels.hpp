@@ -32,6 +32,9 @@ hipError_t launch_key_switch_spread(const uint64_t* target_base, size_t target_s
                                     const DeviceContext& ks, uint32_t L, size_t polys, hipStream_t stream);
 hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                  uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
+// scaleAndRound: in [polys][L][N] -> out [polys][N]; final_scale = Shoup pair of (gamma^-1 scalingFactor) mod t
+hipError_t launch_scale_and_round(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, U64x2 final_scale,
+                                  size_t polys, hipStream_t stream);
 // out[poly][c] = (c < added_polys ? ct[poly][c] : 0) + divideAndRoundQLast(prod[poly][c])
 hipError_t launch_key_switch_finish(const uint64_t* prod, const uint64_t* ct_base, size_t ct_stride, uint64_t* out,
                                     const DeviceContext& ks, uint32_t L, size_t polys, uint32_t added_polys,

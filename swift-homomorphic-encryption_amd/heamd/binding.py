@@ -87,6 +87,7 @@ SIGNATURES = [
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
     ("he_bfv_apply_galois_workspace_bytes", c_size, [vp, c_u32, c_size]),
     ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
+    ("he_rns_scale_and_round_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, c_size, vp]),
     ("he_bfv_plaintext_to_eval_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_coeff_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_pir_compute_response_chunk_device", ctypes.c_int,
@@ -453,6 +454,15 @@ class BfvContext:
         ws_ptr, ws_bytes = (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
         _check(load_library().he_bfv_apply_galois_device(self.h, L, _ptr(ct), int(element), key_ptr, _ptr(out), batch,
                                                          ws_ptr, ws_bytes, _stream(stream)))
+        return out
+
+    def scale_and_round(self, poly, scaling_factor=1, moduli_count=None, stream=None):
+        """_RnsTool.scaleAndRound: [batch][L][N] Coeff -> [batch][N] mod t."""
+        L = self._L(moduli_count)
+        batch = poly.numel() // (L * self.degree)
+        out = self._empty((batch, self.degree), poly)
+        _check(load_library().he_rns_scale_and_round_device(self.h, L, _ptr(poly), int(scaling_factor), _ptr(out),
+                                                            batch, _stream(stream)))
         return out
 
     def plaintext_to_eval(self, plaintext, moduli_count=None, stream=None):

@@ -158,3 +158,44 @@ def test_plaintext_to_eval_pir_shape(oracle):
     got = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(pt)))
     assert np.array_equal(got, ref.plaintext_to_eval(pt))
     assert np.array_equal(heamd.to_host(ours.plaintext_to_coeff(heamd.to_device(got))), pt)
+
+
+@pytest.mark.parametrize("level", [None, 2, 1])
+def test_scale_and_round_matches_oracle_and_decrypts(oracle, small, level):
+    """_RnsTool.scaleAndRound (RnsTool.swift:272-302) on the device: word-exact vs the oracle on uniform inputs, and
+    the decrypt path c0 + c1 s -> scaleAndRound recovers the message (Bfv+Decrypt.swift:29-40,188-204)."""
+    ours, ref, client = small
+    L = ref.L if level is None else level
+    moduli = ref.ciphertext_context(L).moduli
+    tool = ref.rns_tool(L)
+    rng = np.random.default_rng(70 + L)
+    x = _uniform(rng, (6,), moduli, ref.degree)
+    x[0, :, 0] = 0
+    x[0, :, 1] = [m - 1 for m in moduli]
+    for scaling in (1, 2, ref.t - 1):
+        got = heamd.to_host(ours.scale_and_round(heamd.to_device(x), scaling, moduli_count=L))
+        expected = np.stack([tool.scale_and_round(p, scaling) for p in x])
+        assert np.array_equal(got, expected), scaling
+    r = random.Random(71)
+    message = [r.randrange(ref.t) for _ in range(ref.degree)]
+    ct = client.encrypt(message, moduli_count=L)
+    qctx = ref.ciphertext_context(L)
+    s = client._s_eval_for(qctx)
+    ct_eval = qctx.forward_ntt(ct)
+    dot = qctx.inverse_ntt(qctx.add(ct_eval[0], qctx.mul(ct_eval[1], s)))
+    decrypted = heamd.to_host(ours.scale_and_round(heamd.to_device(dot[None]), 1, moduli_count=L))[0]
+    assert [int(v) for v in decrypted] == message
+
+
+def test_scale_and_round_config3_shape(oracle):
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(72)
+    x = _uniform(rng, (3,), q[:-1], degree)
+    tool = ref.rns_tool()
+    got = heamd.to_host(ours.scale_and_round(heamd.to_device(x), 1))
+    assert np.array_equal(got, np.stack([tool.scale_and_round(p, 1) for p in x]))
+    with pytest.raises(heamd.HeError) as err:
+        ours.scale_and_round(heamd.to_device(x), 557057)
+    assert err.value.name == "invalidArgument"
