@@ -53,7 +53,9 @@ enum he_status {
     HE_ERR_INVALID_ARGUMENT = 16,  /* what the reference traps on with `precondition` (null pointer, shape) */
     HE_ERR_DEVICE = 17,            /* HIP runtime failure (no GPU, out of memory, launch error) */
     HE_ERR_UNSUPPORTED = 18,       /* unsupportedHeOperation */
-    HE_ERR_MISSING_GALOIS_KEY = 19 /* missingGaloisKey / missingGaloisElement  Bfv/Bfv.swift:184-189 */
+    HE_ERR_MISSING_GALOIS_KEY = 19, /* missingGaloisKey / missingGaloisElement  Bfv/Bfv.swift:184-189 */
+    HE_ERR_SERIALIZED_BUFFER_SIZE_MISMATCH = 20, /* serializedBufferSizeMismatch  PolyRq/PolyRq+Serialize.swift:41-51 */
+    HE_ERR_INVALID_COEFFICIENT_PACKING = 21      /* invalidCoefficientPacking     CoefficientPacking.swift:27-31 */
 };
 
 typedef struct he_poly_context he_poly_context; /* PolyContext<UInt64>   PolyRq/PolyContext.swift:19-35 */
@@ -140,6 +142,18 @@ int he_poly_apply_galois_device(const he_poly_context* ctx, const uint64_t* in, 
 /* PolyRq<Coeff>.multiplyPowerOfX(power) (PolyRq/PolyRq.swift:398-422): f(x) x^power mod (x^N + 1), any sign. */
 int he_poly_multiply_power_of_x_device(const he_poly_context* ctx, const uint64_t* in, uint64_t* out, size_t batch,
                                        int64_t power, he_stream s);
+
+/* ---- wire format: PolyRq.serialize / PolyRq(deserialize:) on device buffers ----
+ * Each residue row is a big-endian bit stream of N coefficients, ceilLog2(q_r) - skip_lsbs bits each, zero-padded
+ * to a byte; rows follow one another (CoefficientPacking.swift:169-213, PolyRq/PolyRq+Serialize.swift:69-99).
+ * he_poly_serialization_byte_count = PolyContext.serializationByteCount(skipLSBs:) (0 on invalid arguments).
+ * device_bytes is [batch][byte count] (serialize) / [batch][bytes_per_poly] (deserialize; the leading byte count
+ * of each record is read, a shorter record is serializedBufferSizeMismatch). */
+size_t he_poly_serialization_byte_count(const he_poly_context* ctx, int skip_lsbs);
+int he_poly_serialize_device(const he_poly_context* ctx, const uint64_t* device_slab, size_t batch, int skip_lsbs,
+                             uint8_t* device_bytes, he_stream s);
+int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device_bytes, size_t bytes_per_poly,
+                               size_t batch, int skip_lsbs, uint64_t* device_slab, he_stream s);
 
 /* =====================================================================================================
  * B3: Context<Bfv<UInt64>> and the HeScheme operations on the hot path

@@ -126,6 +126,17 @@ def _declare(L):
     L.orc_bfv_inner_product_plain.argtypes = [vp, c_size, c_size, U64P, U64P, ctypes.POINTER(ctypes.c_uint8), c_size,
                                               U64P]
     L.orc_bfv_inner_product.argtypes = [vp, c_size, U64P, U64P, c_size, U64P]
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    L.orc_coefficients_to_bytes_byte_count.restype = c_size
+    L.orc_coefficients_to_bytes_byte_count.argtypes = [c_size, ctypes.c_int, ctypes.c_int]
+    L.orc_bytes_to_coefficients_coeff_count.restype = c_size
+    L.orc_bytes_to_coefficients_coeff_count.argtypes = [c_size, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.orc_coefficients_to_bytes.argtypes = [U64P, c_size, ctypes.c_int, ctypes.c_int, U8P, c_size]
+    L.orc_bytes_to_coefficients.argtypes = [U8P, c_size, ctypes.c_int, ctypes.c_int, U64P, c_size]
+    L.orc_poly_serialization_byte_count.restype = c_size
+    L.orc_poly_serialization_byte_count.argtypes = [vp, ctypes.c_int]
+    L.orc_poly_serialize.argtypes = [vp, U64P, ctypes.c_int, U8P]
+    L.orc_poly_deserialize.argtypes = [vp, U8P, c_size, ctypes.c_int, U64P]
     L.orc_is_valid_galois_element.argtypes = [c_u64, c_u64]
     L.orc_poly_apply_galois_coeff.argtypes = [vp, U64P, U64P, c_u64, c_size]
     L.orc_poly_apply_galois_eval.argtypes = [vp, U64P, U64P, c_u64, c_size]
@@ -147,6 +158,29 @@ def _u64(a):
 
 def _p(a):
     return a.ctypes.data_as(U64P)
+
+
+# ---------------------------------------------------------------- wire format
+def _u8p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def coefficients_to_bytes(coeffs, bits_per_coeff, skip_lsbs=0):
+    """CoefficientPacking.coefficientsToBytes (CoefficientPacking.swift:155-166)."""
+    coeffs = _u64(list(coeffs))
+    count = int(lib().orc_coefficients_to_bytes_byte_count(len(coeffs), bits_per_coeff, skip_lsbs))
+    out = np.zeros(count, dtype=np.uint8)
+    _check(lib().orc_coefficients_to_bytes(_p(coeffs), len(coeffs), bits_per_coeff, skip_lsbs, _u8p(out), count))
+    return out
+
+
+def bytes_to_coefficients(data, bits_per_coeff, decode, skip_lsbs=0):
+    """CoefficientPacking.bytesToCoefficients (CoefficientPacking.swift:59-72)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    count = int(lib().orc_bytes_to_coefficients_coeff_count(len(data), bits_per_coeff, int(decode), skip_lsbs))
+    out = np.zeros(count, dtype=np.uint64)
+    _check(lib().orc_bytes_to_coefficients(_u8p(data), len(data), bits_per_coeff, skip_lsbs, _p(out), count))
+    return out
 
 
 # ---------------------------------------------------------------- scalar layer
@@ -297,6 +331,33 @@ class PolyContext:
         s = _u64(list(scalar_residues))
         assert len(s) == len(self.moduli)
         _check(lib().orc_poly_mul_scalar(self.h, _p(out), _p(s), self._batch(out)))
+        return out
+
+    def serialization_byte_count(self, skip_lsbs=0):
+        return int(lib().orc_poly_serialization_byte_count(self.h, skip_lsbs))
+
+    def serialize(self, data, skip_lsbs=0):
+        """PolyRq.serialize (PolyRq+Serialize.swift:69-87) per polynomial: [batch][L][N] -> uint8 [batch][bytes]."""
+        data = _u64(data)
+        batch, per = self._batch(data), self.serialization_byte_count(skip_lsbs)
+        L, n = self.shape
+        out = np.zeros((batch, per), dtype=np.uint8)
+        flat = data.reshape(batch, L * n)
+        for b in range(batch):
+            _check(lib().orc_poly_serialize(self.h, _p(np.ascontiguousarray(flat[b])), skip_lsbs, _u8p(out[b])))
+        return out
+
+    def deserialize(self, data, skip_lsbs=0):
+        """PolyRq(deserialize:context:skipLSBs:) per polynomial: uint8 [batch][bytes] -> [batch][L][N]."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        data = data.reshape(-1, data.shape[-1])
+        L, n = self.shape
+        out = np.zeros((data.shape[0], L, n), dtype=np.uint64)
+        for b in range(data.shape[0]):
+            row = np.ascontiguousarray(data[b])
+            tmp = np.zeros(L * n, dtype=np.uint64)
+            _check(lib().orc_poly_deserialize(self.h, _u8p(row), len(row), skip_lsbs, _p(tmp)))
+            out[b] = tmp.reshape(L, n)
         return out
 
     def apply_galois(self, data, element, eval_format=False):

@@ -1798,3 +1798,139 @@ int orc_bfv_plaintext_to_coeff(const orc_bfv_context* ctx, size_t L, const uint6
     free(tmp);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Wire format: CoefficientPacking + PolyRq.serialize / load
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* CoefficientPacking.coefficientsToBytesByteCount (CoefficientPacking.swift:141-144) */
+size_t orc_coefficients_to_bytes_byte_count(size_t coeff_count, int bits_per_coeff, int skip_lsbs) {
+    size_t bits = coeff_count * (size_t)(bits_per_coeff - skip_lsbs);
+    return (bits + 7) / 8;
+}
+/* CoefficientPacking.bytesToCoefficientsCoeffCount (CoefficientPacking.swift:34-44) */
+size_t orc_bytes_to_coefficients_coeff_count(size_t byte_count, int bits_per_coeff, int decode, int skip_lsbs) {
+    size_t serialized = (size_t)(bits_per_coeff - skip_lsbs);
+    if (decode) return 8 * byte_count / serialized;
+    return (8 * byte_count + serialized - 1) / serialized;
+}
+static int packing_valid(int bits_per_coeff, int skip_lsbs) { /* :27-31 */
+    return bits_per_coeff > 0 && bits_per_coeff > skip_lsbs && skip_lsbs >= 0;
+}
+
+/* CoefficientPacking.coefficientsToBytesInplace (CoefficientPacking.swift:169-213), the byte-by-byte loop as written */
+int orc_coefficients_to_bytes(const uint64_t* coeffs, size_t coeff_count, int bits_per_coeff, int skip_lsbs,
+                              uint8_t* bytes, size_t bytes_count) {
+    if (!packing_valid(bits_per_coeff, skip_lsbs)) return ORC_ERR_INVALID_ARGUMENT;
+    if (bytes_count == 0) return ORC_OK;
+    size_t byte_index = 0;
+    const int serialized_bit_count = bits_per_coeff - skip_lsbs;
+    uint8_t byte = 0;
+    int remaining_bits = 8;
+    for (size_t k = 0; k < coeff_count; ++k) {
+        uint64_t coeff = coeffs[k] >> skip_lsbs;
+        int remaining_coeff_bits = serialized_bit_count;
+        do {
+            if (remaining_bits == 0) {
+                remaining_bits = 8;
+                bytes[byte_index] = byte;
+                byte_index += 1;
+                if (byte_index == bytes_count) return ORC_OK;
+                byte = 0;
+            }
+            int shift = remaining_bits < remaining_coeff_bits ? remaining_bits : remaining_coeff_bits;
+            uint8_t byte_value = (uint8_t)((coeff >> (remaining_coeff_bits - shift)) & 0xff);
+            byte = (uint8_t)(((unsigned)byte << shift) | byte_value);
+            remaining_coeff_bits -= shift;
+            remaining_bits -= shift;
+        } while (remaining_coeff_bits > 0);
+    }
+    if (byte_index < bytes_count) {
+        byte = (uint8_t)((unsigned)byte << remaining_bits);
+        bytes[byte_index] = byte;
+        byte_index += 1;
+    }
+    return byte_index == bytes_count ? ORC_OK : ORC_ERR_INVALID_ARGUMENT;
+}
+
+/* CoefficientPacking.bytesToCoefficientsInplace (CoefficientPacking.swift:75-138), the 64-bit buffer walk as written */
+int orc_bytes_to_coefficients(const uint8_t* bytes, size_t byte_count, int bits_per_coeff, int skip_lsbs,
+                              uint64_t* coeffs, size_t coeff_count) {
+    if (!packing_valid(bits_per_coeff, skip_lsbs)) return ORC_ERR_INVALID_ARGUMENT;
+    const int serialized_bit_count = bits_per_coeff - skip_lsbs;
+    size_t coeff_index = 0;
+    int unused_bit_count = 0;
+    uint64_t unused_bits = 0;
+    for (size_t chunk = 0; chunk < byte_count; chunk += 8) {
+        size_t end = chunk + 8 < byte_count ? chunk + 8 : byte_count;
+        uint64_t buffer = 0; /* BufferType(bigEndianBytes:), left-aligned when short (Util.swift) */
+        for (size_t b = chunk; b < end; ++b) buffer |= (uint64_t)bytes[b] << (8 * (7 - (b - chunk)));
+        int new_bits_count = 0;
+        if (unused_bit_count != 0) {
+            new_bits_count = serialized_bit_count - unused_bit_count;
+            uint64_t coeff = buffer >> (64 - new_bits_count);
+            coeff |= unused_bits << new_bits_count;
+            if (coeff_index < coeff_count) coeffs[coeff_index] = coeff << skip_lsbs;
+            coeff_index += 1;
+        }
+        size_t remaining = coeff_count > coeff_index ? coeff_count - coeff_index : 0;
+        size_t per_buffer = (size_t)((64 - new_bits_count) / serialized_bit_count);
+        size_t take = remaining < per_buffer ? remaining : per_buffer;
+        for (size_t i = 0; i < take; ++i) {
+            int msbs_to_clear = new_bits_count + (int)i * serialized_bit_count;
+            uint64_t coeff = buffer << msbs_to_clear;
+            coeff >>= 64 - serialized_bit_count;
+            coeffs[coeff_index] = coeff << skip_lsbs;
+            coeff_index += 1;
+        }
+        unused_bit_count += 64 % serialized_bit_count;
+        if (unused_bit_count >= serialized_bit_count) unused_bit_count -= serialized_bit_count;
+        unused_bits = unused_bit_count == 0 ? 0 : buffer & (((uint64_t)1 << unused_bit_count) - 1);
+    }
+    if (coeff_index < coeff_count) {
+        coeffs[coeff_index] = unused_bits << (serialized_bit_count - unused_bit_count + skip_lsbs);
+        coeff_index += 1;
+    }
+    return coeff_index == coeff_count ? ORC_OK : ORC_ERR_INVALID_ARGUMENT;
+}
+
+static int ceil_log2_u64(uint64_t x) { /* ModularArithmetic/Scalar.swift:266-269 */
+    int log2 = 63 - __builtin_clzll(x);
+    return log2 + ((x & (x - 1)) == 0 ? 0 : 1);
+}
+
+/* PolyContext.serializationByteCount (PolyRq+Serialize.swift:90-99) */
+size_t orc_poly_serialization_byte_count(const orc_poly_context* ctx, int skip_lsbs) {
+    size_t total = 0;
+    for (size_t r = 0; r < ctx->count; ++r)
+        total += orc_coefficients_to_bytes_byte_count((size_t)ctx->degree, ceil_log2_u64(ctx->moduli[r]), skip_lsbs);
+    return total;
+}
+/* PolyRq.serialize (PolyRq+Serialize.swift:69-87): rows packed one after the other, each padded to a byte */
+int orc_poly_serialize(const orc_poly_context* ctx, const uint64_t* data, int skip_lsbs, uint8_t* bytes) {
+    size_t offset = 0;
+    for (size_t r = 0; r < ctx->count; ++r) {
+        int bits = ceil_log2_u64(ctx->moduli[r]);
+        size_t count = orc_coefficients_to_bytes_byte_count((size_t)ctx->degree, bits, skip_lsbs);
+        int status = orc_coefficients_to_bytes(data + r * ctx->degree, (size_t)ctx->degree, bits, skip_lsbs,
+                                               bytes + offset, count);
+        if (status != ORC_OK) return status;
+        offset += count;
+    }
+    return ORC_OK;
+}
+/* PolyRq.load(from:skipLSBs:) (PolyRq+Serialize.swift:31-62); a short buffer is serializedBufferSizeMismatch */
+int orc_poly_deserialize(const orc_poly_context* ctx, const uint8_t* bytes, size_t byte_count, int skip_lsbs,
+                         uint64_t* data) {
+    size_t offset = 0;
+    for (size_t r = 0; r < ctx->count; ++r) {
+        int bits = ceil_log2_u64(ctx->moduli[r]);
+        size_t count = orc_coefficients_to_bytes_byte_count((size_t)ctx->degree, bits, skip_lsbs);
+        if (offset + count > byte_count) return ORC_ERR_INVALID_ARGUMENT;
+        int status = orc_bytes_to_coefficients(bytes + offset, count, bits, skip_lsbs, data + r * ctx->degree,
+                                               (size_t)ctx->degree);
+        if (status != ORC_OK) return status;
+        offset += count;
+    }
+    return ORC_OK;
+}

@@ -189,6 +189,20 @@ int orc_bfv_plaintext_to_eval(const orc_bfv_context* ctx, size_t moduli_count, c
 int orc_bfv_plaintext_to_coeff(const orc_bfv_context* ctx, size_t moduli_count, const uint64_t* plaintext_eval,
                                uint64_t* out, size_t batch);
 
+
+/* ---- wire format: CoefficientPacking.swift, PolyRq/PolyRq+Serialize.swift ---- */
+size_t orc_coefficients_to_bytes_byte_count(size_t coeff_count, int bits_per_coeff, int skip_lsbs);
+size_t orc_bytes_to_coefficients_coeff_count(size_t byte_count, int bits_per_coeff, int decode, int skip_lsbs);
+int orc_coefficients_to_bytes(const uint64_t* coeffs, size_t coeff_count, int bits_per_coeff, int skip_lsbs,
+                              uint8_t* bytes, size_t bytes_count);
+int orc_bytes_to_coefficients(const uint8_t* bytes, size_t byte_count, int bits_per_coeff, int skip_lsbs,
+                              uint64_t* coeffs, size_t coeff_count);
+size_t orc_poly_serialization_byte_count(const orc_poly_context* ctx, int skip_lsbs);
+/* data [L][N] -> bytes[orc_poly_serialization_byte_count] */
+int orc_poly_serialize(const orc_poly_context* ctx, const uint64_t* data, int skip_lsbs, uint8_t* bytes);
+int orc_poly_deserialize(const orc_poly_context* ctx, const uint8_t* bytes, size_t byte_count, int skip_lsbs,
+                         uint64_t* data);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,8 @@ const char* he_status_string(int status) {
         case HE_ERR_DEVICE: return "deviceError";
         case HE_ERR_UNSUPPORTED: return "unsupportedHeOperation";
         case HE_ERR_MISSING_GALOIS_KEY: return "missingGaloisKey";
+        case HE_ERR_SERIALIZED_BUFFER_SIZE_MISMATCH: return "serializedBufferSizeMismatch";
+        case HE_ERR_INVALID_COEFFICIENT_PACKING: return "invalidCoefficientPacking";
         default: return "unknown";
     }
 }
@@ -324,6 +326,76 @@ int he_poly_multiply_power_of_x_device(const he_poly_context* ctx, const uint64_
     if (shift < 0) shift += twice;
     HEAMD_HIP_TRY(heamd::launch_multiply_power_of_x(in, out, pc.device_context(), static_cast<uint32_t>(shift),
                                                     batch * pc.moduli_count(), as_stream(s)));
+    return HE_OK;
+}
+
+namespace {
+// bit widths and row offsets of PolyRq.serialize (PolyRq+Serialize.swift:69-99); HE_OK or the reference's errors
+int serialize_layout(const PolyContext& pc, int skip_lsbs, heamd::SerializeLayout& layout) {
+    if (pc.moduli_count() > heamd::kMaxSerializedRows) {
+        heamd::set_last_error("serialization supports at most 64 residue rows");
+        return HE_ERR_UNSUPPORTED;
+    }
+    layout.rows = pc.moduli_count();
+    layout.byte_offset[0] = 0;
+    for (uint32_t r = 0; r < layout.rows; ++r) {
+        const uint64_t q = pc.moduli()[r];
+        int bits = 64 - __builtin_clzll(q);               // significant bits
+        if ((q & (q - 1)) == 0) bits -= 1;                // ceilLog2 (ModularArithmetic/Scalar.swift:266-269)
+        // CoefficientPacking.validate (CoefficientPacking.swift:27-31)
+        if (!(bits > 0 && bits > skip_lsbs && skip_lsbs >= 0)) {
+            heamd::set_last_error("invalid coefficient packing: bitsPerCoeff " + std::to_string(bits) + ", skipLSBs " +
+                                  std::to_string(skip_lsbs));
+            return HE_ERR_INVALID_COEFFICIENT_PACKING;
+        }
+        layout.width[r] = static_cast<uint32_t>(bits - skip_lsbs);
+        layout.byte_offset[r + 1] = layout.byte_offset[r] + (uint64_t(pc.degree()) * layout.width[r] + 7) / 8;
+    }
+    return HE_OK;
+}
+}  // namespace
+
+size_t he_poly_serialization_byte_count(const he_poly_context* ctx, int skip_lsbs) {
+    if (ctx == nullptr) return 0;
+    heamd::SerializeLayout layout{};
+    if (serialize_layout(*ctx->impl, skip_lsbs, layout) != HE_OK) return 0;
+    return static_cast<size_t>(layout.byte_offset[layout.rows]);
+}
+
+int he_poly_serialize_device(const he_poly_context* ctx, const uint64_t* device_slab, size_t batch, int skip_lsbs,
+                             uint8_t* device_bytes, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    heamd::SerializeLayout layout{};
+    int status = serialize_layout(pc, skip_lsbs, layout);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (device_slab == nullptr || device_bytes == nullptr) return invalid_argument("null buffer");
+    status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_serialize(device_slab, device_bytes, layout, pc.device_context().log_degree,
+                                          static_cast<uint32_t>(skip_lsbs), batch, as_stream(s)));
+    return HE_OK;
+}
+
+int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device_bytes, size_t bytes_per_poly,
+                               size_t batch, int skip_lsbs, uint64_t* device_slab, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    heamd::SerializeLayout layout{};
+    int status = serialize_layout(pc, skip_lsbs, layout);
+    if (status != HE_OK) return status;
+    if (bytes_per_poly < layout.byte_offset[layout.rows]) {  // PolyRq+Serialize.swift:41-51
+        heamd::set_last_error("serialized buffer holds " + std::to_string(bytes_per_poly) + " bytes, expected " +
+                              std::to_string(layout.byte_offset[layout.rows]));
+        return HE_ERR_SERIALIZED_BUFFER_SIZE_MISMATCH;
+    }
+    if (batch == 0) return HE_OK;
+    if (device_slab == nullptr || device_bytes == nullptr) return invalid_argument("null buffer");
+    status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_deserialize(device_bytes, device_slab, layout, pc.device_context().log_degree,
+                                            static_cast<uint32_t>(skip_lsbs), bytes_per_poly, batch, as_stream(s)));
     return HE_OK;
 }
 

@@ -164,3 +164,95 @@ hipError_t launch_first_rows(const uint64_t* in, uint64_t* out, const DeviceCont
 }
 
 }  // namespace heamd
+
+// ---- wire format: CoefficientPacking / PolyRq.serialize / load ----------------------------------
+// Each residue row is a big-endian bit stream of N coefficients, `width[r]` = ceilLog2(q_r) - skipLSBs bits each (the
+// value shifted right by skipLSBs), padded with zero bits to a whole byte; rows follow one another
+// (CoefficientPacking.swift:169-213, PolyRq/PolyRq+Serialize.swift:69-87).
+namespace heamd {
+
+namespace {
+
+__device__ __forceinline__ uint32_t row_of_byte(const SerializeLayout& layout, uint64_t byte_in_poly) {
+    uint32_t r = 0;
+    while (r + 1 < layout.rows && byte_in_poly >= layout.byte_offset[r + 1]) ++r;
+    return r;
+}
+
+// one lane = one output byte
+__global__ void __launch_bounds__(256)
+    serialize_kernel(const uint64_t* __restrict__ slab, uint8_t* __restrict__ bytes, const SerializeLayout layout,
+                     uint32_t logn, uint32_t skip, size_t total_bytes) {
+    const uint64_t per_poly = layout.byte_offset[layout.rows];
+    const uint32_t n = 1u << logn;
+    for (size_t idx = blockIdx.x * size_t(256) + threadIdx.x; idx < total_bytes; idx += size_t(gridDim.x) * 256) {
+        const size_t poly = idx / per_poly;
+        const uint64_t in_poly = idx - poly * per_poly;
+        const uint32_t r = row_of_byte(layout, in_poly);
+        const uint32_t w = layout.width[r];
+        const uint64_t bit = (in_poly - layout.byte_offset[r]) * 8;
+        uint32_t k = static_cast<uint32_t>(bit / w), offset = static_cast<uint32_t>(bit - uint64_t(k) * w);
+        const uint64_t* row = slab + ((poly * layout.rows + r) << logn);
+        uint32_t byte = 0, needed = 8;
+        while (needed > 0 && k < n) {
+            const uint32_t available = w - offset;
+            const uint32_t take = available < needed ? available : needed;
+            const uint64_t value = row[k] >> skip;
+            byte = (byte << take) | static_cast<uint32_t>((value >> (available - take)) & ((1u << take) - 1u));
+            needed -= take;
+            offset += take;
+            if (offset == w) {
+                offset = 0;
+                ++k;
+            }
+        }
+        bytes[idx] = static_cast<uint8_t>(byte << needed);  // zero padding after the last coefficient
+    }
+}
+
+// one lane = one coefficient; bytes past the row's end read as zero (CoefficientPacking.swift:128-133)
+__global__ void __launch_bounds__(256)
+    deserialize_kernel(const uint8_t* __restrict__ bytes, uint64_t* __restrict__ slab, const SerializeLayout layout,
+                       uint32_t logn, uint32_t skip, size_t bytes_per_poly, size_t total_words) {
+    const uint32_t n = 1u << logn;
+    for (size_t idx = blockIdx.x * size_t(256) + threadIdx.x; idx < total_words; idx += size_t(gridDim.x) * 256) {
+        const size_t row_index = idx >> logn;
+        const uint32_t k = static_cast<uint32_t>(idx) & (n - 1);
+        const size_t poly = row_index / layout.rows;
+        const uint32_t r = static_cast<uint32_t>(row_index - poly * layout.rows);
+        const uint32_t w = layout.width[r];
+        const uint64_t row_bytes = layout.byte_offset[r + 1] - layout.byte_offset[r];
+        const uint8_t* row = bytes + poly * bytes_per_poly + layout.byte_offset[r];
+        const uint64_t bit = uint64_t(k) * w;
+        const uint64_t first = bit >> 3;
+        const uint32_t offset = static_cast<uint32_t>(bit & 7);
+        uint64_t window = 0;  // 8 bytes big-endian starting at `first`
+#pragma unroll
+        for (int b = 0; b < 8; ++b) window = (window << 8) | (first + b < row_bytes ? row[first + b] : 0);
+        const uint64_t ninth = first + 8 < row_bytes ? row[first + 8] : 0;
+        const uint64_t aligned = offset == 0 ? window : ((window << offset) | (ninth >> (8 - offset)));
+        slab[idx] = (aligned >> (64 - w)) << skip;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_serialize(const uint64_t* slab, uint8_t* bytes, const SerializeLayout& layout, uint32_t log_degree,
+                            uint32_t skip_lsbs, size_t batch, hipStream_t stream) {
+    const size_t total = batch * layout.byte_offset[layout.rows];
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(serialize_kernel, dim3(grid_for(total)), dim3(256), 0, stream, slab, bytes, layout, log_degree,
+                       skip_lsbs, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_deserialize(const uint8_t* bytes, uint64_t* slab, const SerializeLayout& layout, uint32_t log_degree,
+                              uint32_t skip_lsbs, size_t bytes_per_poly, size_t batch, hipStream_t stream) {
+    const size_t total = (batch * layout.rows) << log_degree;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(deserialize_kernel, dim3(grid_for(total)), dim3(256), 0, stream, bytes, slab, layout, log_degree,
+                       skip_lsbs, bytes_per_poly, total);
+    return hipGetLastError();
+}
+
+}  // namespace heamd

@@ -57,6 +57,18 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                       size_t columns, uint64_t max_lazy, hipStream_t stream);
 
 
+// wire format of a polynomial: per residue row, the serialized bit width and the byte offset of the row
+constexpr uint32_t kMaxSerializedRows = 64;
+struct SerializeLayout {
+    uint32_t rows;
+    uint32_t width[kMaxSerializedRows];            // ceilLog2(q_r) - skipLSBs
+    uint64_t byte_offset[kMaxSerializedRows + 1];  // prefix sums of ceil(N width / 8); [rows] = bytes per polynomial
+};
+hipError_t launch_serialize(const uint64_t* slab, uint8_t* bytes, const SerializeLayout& layout, uint32_t log_degree,
+                            uint32_t skip_lsbs, size_t batch, hipStream_t stream);
+hipError_t launch_deserialize(const uint8_t* bytes, uint64_t* slab, const SerializeLayout& layout, uint32_t log_degree,
+                              uint32_t skip_lsbs, size_t bytes_per_poly, size_t batch, hipStream_t stream);
+
 // ---- galois_kernels.hip (in and out must not alias) ------------------------------------------------------------
 // f(x) -> f(x^g) on Coeff rows; `inverse_element` = g^-1 mod 2N
 hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,

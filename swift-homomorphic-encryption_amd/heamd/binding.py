@@ -19,6 +19,7 @@ STATUS_NAMES = {
     9: "incompatibleCiphertexts", 10: "incompatibleCiphertextAndPlaintext", 11: "missingRelinearizationKey",
     12: "unequalContexts", 13: "notEnoughPrimes", 14: "notInvertible", 15: "invalidEncryptionParameters",
     16: "invalidArgument", 17: "deviceError", 18: "unsupportedHeOperation", 19: "missingGaloisKey",
+    20: "serializedBufferSizeMismatch", 21: "invalidCoefficientPacking",
 }
 
 
@@ -66,6 +67,9 @@ SIGNATURES = [
     ("he_poly_adding_lazy_product_device", ctypes.c_int, [vp, vp, vp, vp, vp]),
     ("he_poly_reduce_accumulator_device", ctypes.c_int, [vp, vp, vp, vp]),
     ("he_poly_apply_galois_device", ctypes.c_int, [vp, vp, vp, c_size, c_u64, ctypes.c_int, vp]),
+    ("he_poly_serialization_byte_count", c_size, [vp, ctypes.c_int]),
+    ("he_poly_serialize_device", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, vp, vp]),
+    ("he_poly_deserialize_device", ctypes.c_int, [vp, vp, c_size, c_size, ctypes.c_int, vp, vp]),
     ("he_poly_multiply_power_of_x_device", ctypes.c_int, [vp, vp, vp, c_size, ctypes.c_int64, vp]),
     ("he_bfv_context_create", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_bfv_context_destroy", None, [vp]),
@@ -320,6 +324,29 @@ class PolyContext:
         out = np.zeros((batch, len(self.moduli) - 1, self.degree), dtype=np.uint64)
         _check(load_library().he_poly_divide_and_round_q_last(self.h, a.ctypes.data_as(U64P),
                                                               out.ctypes.data_as(U64P), batch))
+        return out
+
+    def serialization_byte_count(self, skip_lsbs=0):
+        return int(load_library().he_poly_serialization_byte_count(self.h, skip_lsbs))
+
+    def serialize(self, slab, skip_lsbs=0, stream=None):
+        """PolyRq.serialize per polynomial: [batch][L][N] -> uint8 tensor [batch][byte count]."""
+        import torch
+
+        batch = self._batch(slab)
+        out = torch.empty((batch, self.serialization_byte_count(skip_lsbs)), dtype=torch.uint8, device=slab.device)
+        _check(load_library().he_poly_serialize_device(self.h, _ptr(slab), batch, skip_lsbs, vp(out.data_ptr()),
+                                                       _stream(stream)))
+        return out
+
+    def deserialize(self, data, skip_lsbs=0, stream=None):
+        """PolyRq(deserialize:context:skipLSBs:) per record: uint8 tensor [batch][bytes] -> [batch][L][N]."""
+        import torch
+
+        batch, per = data.shape[0], data.shape[1]
+        out = torch.empty((batch, len(self.moduli), self.degree), dtype=torch.int64, device=data.device)
+        _check(load_library().he_poly_deserialize_device(self.h, vp(data.data_ptr()), per, batch, skip_lsbs,
+                                                         vp(out.data_ptr()), _stream(stream)))
         return out
 
     def apply_galois(self, slab, element, eval_format=False, stream=None):

@@ -199,3 +199,65 @@ def test_scale_and_round_config3_shape(oracle):
     with pytest.raises(heamd.HeError) as err:
         ours.scale_and_round(heamd.to_device(x), 557057)
     assert err.value.name == "invalidArgument"
+
+
+def test_serialize_known_answers(kats):
+    """PolyRq+SerializeTests.swift:57-103 and the CoefficientPacking KATs (:148-212) through one-row contexts."""
+    import torch
+
+    for case in kats["poly_serialize"]["roundtrip"]:
+        moduli = case["moduli"]
+        degree = len(case["poly"]) // len(moduli)
+        ctx = heamd.PolyContext(degree, moduli)
+        poly = np.array(case["poly"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        packed = ctx.serialize(heamd.to_device(poly), case["skip"])
+        back = heamd.to_host(ctx.deserialize(packed, case["skip"]))
+        assert back.ravel().tolist() == case["expected"]
+    # coefficientsToBytes KATs with a power-of-two "modulus" row: ceilLog2(2^bits) = bits
+    for case in kats["coefficient_packing"]["coeffs_to_bytes"]:
+        count = len(case["coeffs"])
+        if count & (count - 1):
+            continue  # a PolyContext needs a power-of-two degree; the other KATs are covered by the oracle comparison
+        ctx = heamd.PolyContext(count, [1 << case["bits"]])
+        packed = ctx.serialize(heamd.to_device(np.array(case["coeffs"], dtype=np.uint64).reshape(1, 1, count)),
+                               case["skip"])
+        assert packed.cpu().numpy().ravel().tolist() == case["expected"]
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("degree,bits", [(32, [14, 16, 21, 22, 27]), (8192, [55, 55, 55, 55]), (4096, [27, 28, 28]),
+                                         (64, [62, 33, 8])])
+def test_serialize_matches_oracle(oracle, degree, bits):
+    import torch
+
+    moduli = oracle.generate_primes(bits, False, 1)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + len(bits))
+    slab = _uniform(rng, (3,), moduli, degree)
+    slab[0, :, 0] = 0
+    slab[0, :, -1] = [m - 1 for m in moduli]
+    for skip in (0, 1, 5):
+        assert ours.serialization_byte_count(skip) == ref.serialization_byte_count(skip)
+        packed = ours.serialize(heamd.to_device(slab), skip)
+        expected = ref.serialize(slab, skip)
+        assert np.array_equal(packed.cpu().numpy(), expected)
+        back = heamd.to_host(ours.deserialize(torch.from_numpy(expected).cuda(), skip))
+        assert np.array_equal(back, ref.deserialize(expected, skip))
+        if skip == 0:
+            assert np.array_equal(back, slab)
+
+
+def test_deserialize_rejects_short_records(oracle):
+    import torch
+
+    narrow = heamd.PolyContext(32, oracle.generate_primes([5, 5, 5], False, 1, word_bits=32))
+    wide = heamd.PolyContext(32, oracle.generate_primes([5, 5, 16], False, 1, word_bits=32))
+    assert wide.serialization_byte_count() == 104  # PolyRq+SerializeTests.swift:21-36
+    packed = narrow.serialize(heamd.to_device(np.zeros((1, 3, 32), dtype=np.uint64)))
+    with pytest.raises(heamd.HeError) as err:
+        wide.deserialize(packed)
+    assert err.value.name == "serializedBufferSizeMismatch"
+    with pytest.raises(heamd.HeError) as err:
+        narrow.serialize(heamd.to_device(np.zeros((1, 3, 32), dtype=np.uint64)), skip_lsbs=5)
+    assert err.value.name == "invalidCoefficientPacking"
+    assert isinstance(packed, torch.Tensor)

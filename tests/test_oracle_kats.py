@@ -270,3 +270,49 @@ def test_multiply_power_of_x_is_negacyclic_shift(oracle):
                 column, negate = (j - degree, True) if j >= degree else (j, False)
                 expected[:, r, column] = (q - data[:, r, i]) % q if negate else data[:, r, i]
         assert np.array_equal(ctx.multiply_power_of_x(data, power), expected), power
+
+
+def test_coefficient_packing_known_answers(oracle, kats):
+    """CoefficientPackingTests.swift:83-212."""
+    for case in kats["coefficient_packing"]["bytes_to_coeffs"]:
+        got = oracle.bytes_to_coefficients(case["bytes"], case["bits"], case["decode"], case["skip"])
+        assert got.tolist() == case["expected"]
+    for case in kats["coefficient_packing"]["coeffs_to_bytes"]:
+        assert oracle.coefficients_to_bytes(case["coeffs"], case["bits"], case["skip"]).tolist() == case["expected"]
+
+
+def test_coefficient_packing_roundtrips(oracle):
+    """CoefficientPackingTests.swift:23-81 (bytesRoundtrip, coeffsRoundtrip) for every width."""
+    rng = np.random.default_rng(5)
+    for log2t in range(1, 61):
+        data = rng.integers(0, 256, size=512, dtype=np.uint8)
+        coeffs = oracle.bytes_to_coefficients(data, log2t, False)
+        assert all(int(c) < (1 << log2t) + 1 for c in coeffs)
+        assert oracle.coefficients_to_bytes(coeffs, log2t)[: len(data)].tolist() == data.tolist()
+        values = rng.integers(0, (1 << log2t) + 1, size=512, dtype=np.uint64)
+        packed = oracle.coefficients_to_bytes(values, log2t + 1)
+        assert oracle.bytes_to_coefficients(packed, log2t + 1, True)[: len(values)].tolist() == values.tolist()
+
+
+def test_poly_serialize_known_answers(oracle, kats):
+    """PolyRq+SerializeTests.swift:39-103."""
+    for case in kats["poly_serialize"]["roundtrip"]:
+        moduli = case["moduli"]
+        degree = len(case["poly"]) // len(moduli)
+        ctx = oracle.PolyContext(degree, moduli)
+        poly = np.array(case["poly"], dtype=np.uint64).reshape(1, len(moduli), degree)
+        packed = ctx.serialize(poly, case["skip"])
+        assert packed.shape[1] == ctx.serialization_byte_count(case["skip"])
+        assert ctx.deserialize(packed, case["skip"]).ravel().tolist() == case["expected"]
+    moduli = oracle.generate_primes([14, 16, 21, 22, 27], False, 1)
+    ctx = oracle.PolyContext(32, moduli)
+    rng = np.random.default_rng(6)
+    poly = np.stack([rng.integers(0, q, size=(3, 32), dtype=np.uint64) for q in moduli], axis=1)
+    assert np.array_equal(ctx.deserialize(ctx.serialize(poly)), poly)
+    # a buffer serialized for one context does not fit a wider one (serializedBufferSizeMismatch, :21-36)
+    narrow = oracle.PolyContext(32, oracle.generate_primes([5, 5, 5], False, 1, word_bits=32))
+    wide = oracle.PolyContext(32, oracle.generate_primes([5, 5, 16], False, 1, word_bits=32))
+    assert wide.serialization_byte_count() == 104
+    packed = narrow.serialize(np.zeros((1, 3, 32), dtype=np.uint64))
+    with pytest.raises(oracle.OracleError):
+        wide.deserialize(packed)
