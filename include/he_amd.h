@@ -263,6 +263,17 @@ int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32
                                          const uint64_t* database, const uint8_t* present,
                                          const uint64_t* relinearization_key, uint64_t* out, he_stream s);
 
+/* PirUtil.expand(ciphertexts:outputCount:using:) (PrivateInformationRetrieval/IndexPir/PirUtil.swift:196-355):
+ * oblivious expansion of `ciphertext_count` query ciphertexts [..][2][L][N] (Coeff, top level) into `output_count`
+ * ciphertexts, in the reference's output order.  The evaluation key is given as parallel host arrays:
+ * galois_elements[k] and the device pointer galois_keys[k] of that element's key (layout as in
+ * he_bfv_apply_galois_device).  Per tree level the largest element <= the target element is applied
+ * 2^(log2(target-1) - log2(element-1)) times (PirUtil.swift:217-231); none available -> HE_ERR_MISSING_GALOIS_KEY.
+ * The count preconditions of PirUtil.swift:325-326 return HE_ERR_INVALID_ARGUMENT. */
+int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
+                         size_t output_count, const uint64_t* galois_elements, const uint64_t* const* galois_keys,
+                         size_t galois_key_count, uint64_t* out, he_stream s);
+
 /* =====================================================================================================
  * Diagnostics and test hooks (not part of the reference's surface)
  * =================================================================================================== */

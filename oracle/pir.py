@@ -47,3 +47,65 @@ def compute_response_for_one_chunk(bfv, dimensions, dim0_query_eval, remaining_q
     for level in range(L, 1, -1):  # Bfv.modSwitchDownToSingle: modSwitchDown until one modulus is left
         ct = bfv.mod_switch_down(ct, poly_count=2, moduli_count=level)
     return ct[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Query expansion (PirUtil.swift:196-355), restated with the same recursion and output order.
+
+
+def _log2(x):
+    return x.bit_length() - 1
+
+
+def _ceil_log2(x):
+    return _log2(x) + (0 if x & (x - 1) == 0 else 1)
+
+
+def expand_ciphertext_for_one_step(bfv, ct, log_step, galois_keys):
+    """PirUtil.expandCiphertextForOneStep (PirUtil.swift:204-236). ct [2][L][N] Coeff; galois_keys {element: key}."""
+    degree = bfv.degree
+    qctx = bfv.ciphertext_context()
+    shifting_power = 1 << (log_step - 1)
+    target = (1 << (_log2(degree) - log_step + 1)) + 1
+    usable = [e for e in galois_keys if e <= target]
+    if not usable:
+        raise KeyError("missingGaloisKey")
+    element = max(usable)
+    count = 1 << (_log2(target - 1) - _log2(element - 1))
+    c1, current = ct, 1
+    for _ in range(count):
+        c1 = bfv.apply_galois(c1[None], element, galois_keys[element])[0]
+        current = (current * element) % (2 * degree)
+    assert current == target
+    difference = qctx.sub(ct, c1)
+    difference = qctx.multiply_power_of_x(difference, -shifting_power)
+    return qctx.add(c1, ct), difference
+
+
+def expand_ciphertext(bfv, ct, output_count, log_step, expected_height, galois_keys):
+    """PirUtil.expandCiphertext (PirUtil.swift:249-300)."""
+    qctx = bfv.ciphertext_context()
+    if output_count == 1:
+        return [ct] if log_step > expected_height else [qctx.add(ct, ct)]
+    second = output_count >> 1
+    first = output_count - second
+    p0, p1 = expand_ciphertext_for_one_step(bfv, ct, log_step, galois_keys)
+    first_half = expand_ciphertext(bfv, p0, first, log_step + 1, expected_height, galois_keys)
+    second_half = expand_ciphertext(bfv, p1, second, log_step + 1, expected_height, galois_keys)
+    out = []
+    for a, b in zip(first_half[:second], second_half):
+        out += [a, b]
+    return out + first_half[len(first_half) - (first - second):] if first > second else out
+
+
+def expand(bfv, ciphertexts, output_count, galois_keys):
+    """PirUtil.expand (PirUtil.swift:313-355): ciphertexts [count][2][L][N] Coeff -> [output_count][2][L][N]."""
+    ciphertexts = np.asarray(ciphertexts, dtype=np.uint64)
+    degree = bfv.degree
+    assert (len(ciphertexts) - 1) * degree < output_count <= len(ciphertexts) * degree
+    remaining, out = output_count, []
+    for ct in ciphertexts:
+        to_generate = min(remaining, degree)
+        remaining -= to_generate
+        out += expand_ciphertext(bfv, ct, to_generate, 1, _ceil_log2(to_generate), galois_keys)
+    return np.stack(out)

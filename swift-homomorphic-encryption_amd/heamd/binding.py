@@ -96,6 +96,8 @@ SIGNATURES = [
     ("he_bfv_plaintext_to_coeff_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_pir_compute_response_chunk_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, ctypes.POINTER(ctypes.c_uint8), vp, vp, vp]),
+    ("he_pir_expand_device", ctypes.c_int,
+     [vp, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp]),
     # diagnostics / test hooks
     ("he_poly_context_create_host_only", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_poly_context_copy_ntt_tables", ctypes.c_int, [vp, c_u32, U64P, U64P, U64P, U64P, U64P, U64P]),
@@ -508,6 +510,18 @@ class BfvContext:
         out = self._empty((batch, self.degree), plaintext_eval)
         _check(load_library().he_bfv_plaintext_to_coeff_device(self.h, L, _ptr(plaintext_eval), _ptr(out), batch,
                                                                _stream(stream)))
+        return out
+
+    def pir_expand(self, ciphertexts, output_count, galois_keys, stream=None):
+        """PirUtil.expand: [count][2][L][N] Coeff + {element: key tensor} -> [output_count][2][L][N]."""
+        count = ciphertexts.numel() // (2 * self.L * self.degree)
+        out = self._empty((output_count, 2, self.L, self.degree), ciphertexts)
+        elements = sorted(galois_keys)
+        element_array = _u64(elements)
+        key_array = (vp * max(len(elements), 1))(*[vp(galois_keys[e].data_ptr()) for e in elements])
+        _check(load_library().he_pir_expand_device(self.h, _ptr(ciphertexts), count, output_count,
+                                                   element_array.ctypes.data_as(U64P), key_array, len(elements),
+                                                   _ptr(out), _stream(stream)))
         return out
 
     def pir_compute_response_chunk(self, dimensions, dim0_query_eval, remaining_query, database, present=None,

@@ -84,3 +84,60 @@ def test_pir_response_config_shape(oracle):
     got = heamd.to_host(ours.pir_compute_response_chunk(dims, heamd.to_device(dim0), heamd.to_device(rest),
                                                         heamd.to_device(database), None, heamd.to_device(key)))
     assert np.array_equal(got, expected)
+
+
+def _compressed_query(ctx, total, ones):
+    """PirUtil.compressInputsForOneCiphertext (PirUtil.swift:357-377)."""
+    height = (total - 1).bit_length()
+    inverse = pow(pow(2, height, ctx.t), -1, ctx.t)
+    message = [0] * ctx.degree
+    for index in ones:
+        message[index] = inverse
+    return message
+
+
+@pytest.mark.parametrize("total,ones,key_shifts", [(8, [3], None), (5, [0, 4], None), (1, [0], None), (6, [5], None),
+                                                   (8, [6], [2]), (13, [12, 1], None)])
+def test_pir_expand_matches_oracle_and_decrypts(oracle, small, total, ones, key_shifts):
+    """PirUtil.expand (PirUtil.swift:196-355): same words and order as the oracle's recursion; output i decrypts to
+    the constant [i in ones].  key_shifts=[2] keeps only the element N/4 + 1, which the first two levels reach by
+    repeated application (PirUtil.swift:221-231)."""
+    ours, ref, client = small
+    n = ref.degree
+    shifts = key_shifts if key_shifts is not None else list(range(0, max((total - 1).bit_length(), 1)))
+    keys = {(n >> k) + 1: client.galois_key((n >> k) + 1) for k in shifts}
+    query = client.encrypt(_compressed_query(ref, total, ones))
+    expected = oracle.pir.expand(ref, query[None], total, keys)
+    device_keys = {e: heamd.to_device(k) for e, k in keys.items()}
+    got = heamd.to_host(ours.pir_expand(heamd.to_device(query[None]), total, device_keys))
+    assert np.array_equal(got, expected)
+    if key_shifts is None:
+        for index in range(total):
+            assert client.decrypt(got[index]) == [1 if index in ones else 0] + [0] * (n - 1), index
+
+
+def test_pir_expand_two_query_ciphertexts(oracle, small):
+    """More outputs than one ciphertext can carry: the second ciphertext expands the remainder (PirUtil.swift:327-333)."""
+    ours, ref, client = small
+    n = ref.degree
+    total = n + 3
+    keys = {(n >> k) + 1: client.galois_key((n >> k) + 1) for k in range(0, (n - 1).bit_length())}
+    first = client.encrypt(_compressed_query(ref, n, [7]))
+    second = client.encrypt(_compressed_query(ref, 3, [2]))
+    queries = np.stack([first, second])
+    expected = oracle.pir.expand(ref, queries, total, keys)
+    got = heamd.to_host(ours.pir_expand(heamd.to_device(queries), total, {e: heamd.to_device(k) for e, k in keys.items()}))
+    assert np.array_equal(got, expected)
+    assert client.decrypt(got[7])[0] == 1 and client.decrypt(got[8])[0] == 0
+    assert client.decrypt(got[n + 2])[0] == 1 and client.decrypt(got[n])[0] == 0
+
+
+def test_pir_expand_errors(small):
+    ours, ref, client = small
+    ct = heamd.to_device(np.zeros((1, 2, ours.L, ours.degree), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:
+        ours.pir_expand(ct, 4, {})
+    assert err.value.name == "missingGaloisKey"
+    with pytest.raises(heamd.HeError) as err:
+        ours.pir_expand(ct, ours.degree + 1, {})
+    assert err.value.name == "invalidArgument"

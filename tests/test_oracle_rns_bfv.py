@@ -328,3 +328,30 @@ def test_pir_response_selects_the_queried_entry(oracle, small_bfv):
     dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == 3 else zero)) for k in range(4)])
     response = oracle.pir.compute_response_for_one_chunk(ctx, [4], dim0, None, database[:4], None, None)
     assert client.decrypt(response, moduli_count=1) == entries[3]
+
+
+def _compressed_query(ctx, total, ones):
+    """PirUtil.compressInputsForOneCiphertext (PirUtil.swift:357-377): inverse(2^ceilLog2(total)) at the chosen indices."""
+    height = (total - 1).bit_length()
+    inverse = pow(pow(2, height, ctx.t), -1, ctx.t)
+    message = [0] * ctx.degree
+    for index in ones:
+        message[index] = inverse
+    return message
+
+
+@pytest.mark.parametrize("total,ones", [(8, [3]), (5, [0, 4]), (1, [0]), (6, [5])])
+def test_pir_expand_produces_encrypted_selection_bits(oracle, small_bfv, total, ones):
+    """PirUtil.expand (PirUtil.swift:313-355): output i decrypts to the constant polynomial [i in ones]."""
+    ctx, client = small_bfv
+    n = ctx.degree
+    # MulPir's evaluation key holds the elements N/2^k + 1 (IndexPirParameter / MulPir.swift evaluationKeyConfig)
+    keys = {(n >> k) + 1: client.galois_key((n >> k) + 1) for k in range(0, (total - 1).bit_length())}
+    if not keys:
+        keys = {n + 1: client.galois_key(n + 1)}
+    query = client.encrypt(_compressed_query(ctx, total, ones))
+    expanded = oracle.pir.expand(ctx, query[None], total, keys)
+    assert expanded.shape == (total, 2, ctx.L, n)
+    for index in range(total):
+        want = [1 if index in ones else 0] + [0] * (n - 1)
+        assert client.decrypt(expanded[index]) == want, index
