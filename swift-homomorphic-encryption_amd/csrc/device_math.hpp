@@ -115,8 +115,9 @@ __device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t
 }
 // Shoup multiplication for moduli with spare top bits, as two straight-line instruction blocks (hipcc keeps
 // re-deriving a generic 64x64 multiply from the C form; see profiles/r01c_isa_notes.txt for the instruction mix):
-//   x < 2^62, wf_half = floor(w 2^63 / p) = wf >> 1 (< 2^63), neg_2p = 2^64 - 2p  ->  x w - q 2p  in [0, 8p)
-// q = floor((x wf_half) / 2^64) low by <= 2: a0 b1 + a1 b0 < 2^63 + 2^62 never carries out of 64 bits, so the cross
+//   x < 2^63, wf_half = floor(w 2^63 / p) = wf >> 1 (< 2^63), neg_2p = 2^64 - 2p  ->  x w - q 2p  in [0, 5p)
+// q = floor((x wf_half) / 2^64) low by <= 1 (and wf_half costs < 3/2 more): a0 b1 + a1 b0 < 2^63 + 2^63 - 2^33 never
+// carries out of 64 bits, so the cross
 // terms ride v_mad_u64_u32's 64-bit addend: 5 multiply-adds + 4 v_mul_lo_u32, no v_mul_hi_u32, no carry chains.
 __device__ __forceinline__ uint64_t shoup_headroom(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
     const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf_half), b1 = hi32(wf_half);

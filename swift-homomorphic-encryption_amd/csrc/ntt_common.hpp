@@ -83,8 +83,8 @@ __device__ __forceinline__ U64x2 load_twiddle(const U64x2* entry) {
 //   kModeHeadroom 2^40 <= p < 2^55  : shoup_headroom (products in [0, 8p)), and the spare top bits absorb the growth
 //                                     instead of a conditional subtract per butterfly: the forward transform never
 //                                     folds (a word gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62),
-//                                     the inverse folds only once sums could pass 2^6 p (its multiplicand x + B - y
-//                                     must stay < 2^62); one float-estimated quotient brings forward outputs back
+//                                     the inverse folds only once sums could pass 2^7 p (its multiplicand x + B - y
+//                                     must stay < 2^63); one float-estimated quotient brings forward outputs back
 //                                     to [0, p).
 //   kModeHeadroomHalved             : kModeHeadroom reading the context's pre-halved Shoup factors
 constexpr int kModeExact = 0, kModeApprox = 1, kModeHeadroom = 2, kModeHeadroomHalved = 3;
@@ -95,7 +95,7 @@ struct Lazy {
     static constexpr bool kHeadroom = is_headroom(MODE);
     static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;  // products < p << this
     // cap on stage inputs of the inverse transform, as a shift of p
-    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 6;
+    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 7;
     // twiddle as the butterflies want it: headroom mode multiplies by floor(w 2^63 / p) = wf >> 1
     __device__ static __forceinline__ U64x2 prepare(U64x2 w) {
         if constexpr (MODE == kModeHeadroom) w.y >>= 1;  // kModeHeadroomHalved: the table already holds wf >> 1
