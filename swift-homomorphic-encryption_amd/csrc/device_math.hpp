@@ -110,8 +110,61 @@ __device__ __forceinline__ uint64_t shoup_lazy(uint64_t x, uint64_t w, uint64_t 
     return mullo64_sum2(x, w, opaque(mulhi64(x, wf)), neg_p);
 }
 __device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
-    x = opaque(x);
-    return mullo64_sum2(x, w, opaque(mulhi64_approx(x, wf)), neg_p);
+    // straight-line form: the 65-bit cross column a0 b1 + a1 b0 keeps its carry-out in an SGPR pair and re-enters as
+    // bit 32 of the quotient estimate (q low by <= 2 -> result < 3p)
+    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf), b1 = hi32(wf);
+    uint64_t cross, q, carry;
+    uint32_t carried;
+    asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
+        "v_cndmask_b32 %2, 0, 1, %3\n\t"
+        "v_lshrrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %7, %0"
+        : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    q += static_cast<uint64_t>(carried) << 32;
+    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
+    const uint32_t n0 = lo32(neg_p), n1 = hi32(neg_p);
+    uint64_t acc, carry2;
+    uint32_t u0, u1, u2, u3;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
+        "v_mul_lo_u32 %1, %6, %9\n\t"
+        "v_mul_lo_u32 %2, %7, %8\n\t"
+        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
+        "v_mul_lo_u32 %3, %10, %13\n\t"
+        "v_mul_lo_u32 %4, %11, %12\n\t"
+        "v_add3_u32 %1, %1, %2, %3"
+        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
+        : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "v"(n0), "v"(n1));
+    return pack64(lo32(acc), hi32(acc) + u0 + u3);
+}
+// the same with a wave-uniform twiddle and reduction constant in SGPRs
+__device__ __forceinline__ uint64_t shoup_lazy4_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
+    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf), b1 = hi32(wf);
+    uint64_t cross, q, carry;
+    uint32_t carried;
+    asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
+        "v_cndmask_b32 %2, 0, 1, %3\n\t"
+        "v_lshrrev_b64 %0, 32, %0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %7, %0"
+        : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
+        : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
+    q += static_cast<uint64_t>(carried) << 32;
+    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
+    const uint32_t n0 = lo32(neg_p), n1 = hi32(neg_p);
+    uint64_t acc, carry2;
+    uint32_t u0, u1, u2, u3;
+    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
+        "v_mul_lo_u32 %1, %6, %9\n\t"
+        "v_mul_lo_u32 %2, %7, %8\n\t"
+        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
+        "v_mul_lo_u32 %3, %10, %13\n\t"
+        "v_mul_lo_u32 %4, %11, %12\n\t"
+        "v_add3_u32 %1, %1, %2, %3"
+        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
+        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
+    return pack64(lo32(acc), hi32(acc) + u0 + u3);
 }
 // Shoup multiplication for moduli with spare top bits, as two straight-line instruction blocks (hipcc keeps
 // re-deriving a generic 64x64 multiply from the C form; see profiles/r01c_isa_notes.txt for the instruction mix):

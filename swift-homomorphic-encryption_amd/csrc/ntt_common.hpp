@@ -108,6 +108,8 @@ struct Lazy {
             return shoup_headroom_uniform(x, w.x, w.y, reduction);
         } else if constexpr (kHeadroom) {
             return shoup_headroom(x, w.x, w.y, reduction);
+        } else if constexpr (MODE == kModeApprox && UNIFORM) {
+            return shoup_lazy4_uniform(x, w.x, w.y, reduction);
         } else if constexpr (MODE == kModeApprox) {
             return shoup_lazy4(x, w.x, w.y, reduction);
         } else {
@@ -117,6 +119,8 @@ struct Lazy {
     __device__ static __forceinline__ uint64_t reduction_constant(uint64_t p) {
         if constexpr (kHeadroom) {
             return 0 - 2 * p;
+        } else if constexpr (MODE == kModeApprox) {
+            return 0 - p;  // asm multiply: the uniform constant is read from SGPRs (or copied once when needed in VGPRs)
         } else {
             return opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
         }
