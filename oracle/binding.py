@@ -137,6 +137,13 @@ def _declare(L):
     L.orc_poly_serialization_byte_count.argtypes = [vp, ctypes.c_int]
     L.orc_poly_serialize.argtypes = [vp, U64P, ctypes.c_int, U8P]
     L.orc_poly_deserialize.argtypes = [vp, U8P, c_size, ctypes.c_int, U64P]
+    L.orc_ctr_drbg_create.argtypes = [U8P, ctypes.POINTER(vp)]
+    L.orc_ctr_drbg_destroy.argtypes = [vp]
+    L.orc_ctr_drbg_destroy.restype = None
+    L.orc_ctr_drbg_state.argtypes = [vp, U8P, U8P]
+    L.orc_ctr_drbg_state.restype = None
+    L.orc_ctr_drbg_generate.argtypes = [vp, U8P, c_size]
+    L.orc_poly_random_from_seed.argtypes = [vp, U8P, U64P]
     L.orc_is_valid_galois_element.argtypes = [c_u64, c_u64]
     L.orc_poly_apply_galois_coeff.argtypes = [vp, U64P, U64P, c_u64, c_size]
     L.orc_poly_apply_galois_eval.argtypes = [vp, U64P, U64P, c_u64, c_size]
@@ -181,6 +188,32 @@ def bytes_to_coefficients(data, bits_per_coeff, decode, skip_lsbs=0):
     out = np.zeros(count, dtype=np.uint64)
     _check(lib().orc_bytes_to_coefficients(_u8p(data), len(data), bits_per_coeff, skip_lsbs, _p(out), count))
     return out
+
+
+class CtrDrbg:
+    """NistCtrDrbg (Random/NistCtrDrbg.swift)."""
+
+    def __init__(self, entropy):
+        e = np.frombuffer(bytes(entropy), dtype=np.uint8).copy()
+        assert len(e) == 32
+        h = ctypes.c_void_p()
+        _check(lib().orc_ctr_drbg_create(_u8p(e), ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ctr_drbg_destroy(self.h)
+            self.h = None
+
+    def state(self):
+        key, nonce = np.zeros(16, dtype=np.uint8), np.zeros(16, dtype=np.uint8)
+        lib().orc_ctr_drbg_state(self.h, _u8p(key), _u8p(nonce))
+        return bytes(key), bytes(nonce)
+
+    def generate(self, count):
+        out = np.zeros(count, dtype=np.uint8)
+        _check(lib().orc_ctr_drbg_generate(self.h, _u8p(out), count))
+        return bytes(out)
 
 
 # ---------------------------------------------------------------- scalar layer
@@ -331,6 +364,17 @@ class PolyContext:
         s = _u64(list(scalar_residues))
         assert len(s) == len(self.moduli)
         _check(lib().orc_poly_mul_scalar(self.h, _p(out), _p(s), self._batch(out)))
+        return out
+
+    def random_from_seeds(self, seeds):
+        """PolyRq.random(context:using: NistAes128Ctr(seed:)) per 32-byte seed: uint8 [batch][32] -> [batch][L][N]."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint8).reshape(-1, 32)
+        L, n = self.shape
+        out = np.zeros((len(seeds), L, n), dtype=np.uint64)
+        for b, seed in enumerate(seeds):
+            tmp = np.zeros(L * n, dtype=np.uint64)
+            _check(lib().orc_poly_random_from_seed(self.h, _u8p(np.ascontiguousarray(seed)), _p(tmp)))
+            out[b] = tmp.reshape(L, n)
         return out
 
     def serialization_byte_count(self, skip_lsbs=0):

@@ -1934,3 +1934,147 @@ int orc_poly_deserialize(const orc_poly_context* ctx, const uint8_t* bytes, size
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Seeded polynomials: NistAes128Ctr = BufferedRng<NistCtrDrbg> (Random/NistCtrDrbg.swift,
+ * Random/NistAes128Ctr.swift, Random/BufferedRng.swift) and PolyRq.randomizeUniform(using:)
+ * (PolyRq/PolyRq+Randomize.swift:56-75).  AES-128 itself is FIPS-197 (the reference calls swift-crypto's
+ * AES._CTR, a pinned third-party dependency: swift-crypto 3.15.1); restated byte-wise here.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+static uint8_t aes_sbox[256];
+static int aes_sbox_ready = 0;
+static uint8_t gf_mul(uint8_t a, uint8_t b) {
+    uint8_t r = 0;
+    while (b) {
+        if (b & 1) r ^= a;
+        a = (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0));
+        b >>= 1;
+    }
+    return r;
+}
+static void aes_init_sbox(void) { /* FIPS-197 5.1.1: multiplicative inverse then the affine map */
+    if (aes_sbox_ready) return;
+    for (int x = 0; x < 256; ++x) {
+        uint8_t inv = 0;
+        if (x) for (int y = 1; y < 256; ++y) if (gf_mul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        uint8_t s = inv;
+        for (int k = 1; k <= 4; ++k) s ^= (uint8_t)((inv << k) | (inv >> (8 - k)));
+        aes_sbox[x] = (uint8_t)(s ^ 0x63);
+    }
+    aes_sbox_ready = 1;
+}
+typedef struct { uint8_t round_keys[11][16]; } aes128_key;
+static void aes128_expand(const uint8_t key[16], aes128_key* out) { /* FIPS-197 5.2 */
+    aes_init_sbox();
+    memcpy(out->round_keys[0], key, 16);
+    uint8_t rcon = 1;
+    for (int r = 1; r <= 10; ++r) {
+        const uint8_t* prev = out->round_keys[r - 1];
+        uint8_t* cur = out->round_keys[r];
+        uint8_t t[4] = {aes_sbox[prev[13]], aes_sbox[prev[14]], aes_sbox[prev[15]], aes_sbox[prev[12]]};
+        t[0] ^= rcon;
+        rcon = (uint8_t)((rcon << 1) ^ ((rcon & 0x80) ? 0x1b : 0));
+        for (int i = 0; i < 4; ++i) cur[i] = prev[i] ^ t[i];
+        for (int i = 4; i < 16; ++i) cur[i] = prev[i] ^ cur[i - 4];
+    }
+}
+static void aes128_encrypt_block(const aes128_key* k, const uint8_t in[16], uint8_t out[16]) { /* FIPS-197 5.1 */
+    uint8_t s[16];
+    for (int i = 0; i < 16; ++i) s[i] = in[i] ^ k->round_keys[0][i];
+    for (int r = 1; r <= 10; ++r) {
+        uint8_t t[16];
+        for (int c = 0; c < 4; ++c)          /* SubBytes + ShiftRows: state is column-major, s[4c + row] */
+            for (int row = 0; row < 4; ++row) t[4 * c + row] = aes_sbox[s[4 * ((c + row) & 3) + row]];
+        if (r < 10) {
+            for (int c = 0; c < 4; ++c) {    /* MixColumns */
+                const uint8_t* a = t + 4 * c;
+                s[4 * c + 0] = (uint8_t)(gf_mul(a[0], 2) ^ gf_mul(a[1], 3) ^ a[2] ^ a[3]);
+                s[4 * c + 1] = (uint8_t)(a[0] ^ gf_mul(a[1], 2) ^ gf_mul(a[2], 3) ^ a[3]);
+                s[4 * c + 2] = (uint8_t)(a[0] ^ a[1] ^ gf_mul(a[2], 2) ^ gf_mul(a[3], 3));
+                s[4 * c + 3] = (uint8_t)(gf_mul(a[0], 3) ^ a[1] ^ a[2] ^ gf_mul(a[3], 2));
+            }
+        } else {
+            memcpy(s, t, 16);
+        }
+        for (int i = 0; i < 16; ++i) s[i] ^= k->round_keys[r][i];
+    }
+    memcpy(out, s, 16);
+}
+
+/* NistCtrDrbg (Random/NistCtrDrbg.swift:23-96): key, 128-bit big-endian counter V ("nonce"), reseed counter */
+struct orc_ctr_drbg {
+    uint8_t key[16];
+    uint8_t v[16]; /* big-endian */
+    int64_t reseed_counter;
+};
+static void be128_add(uint8_t v[16], uint64_t amount) {
+    for (int i = 15; i >= 0 && amount; --i) {
+        uint64_t sum = (uint64_t)v[i] + (amount & 0xff);
+        v[i] = (uint8_t)sum;
+        amount = (amount >> 8) + (sum >> 8);
+    }
+}
+/* AES._CTR.encrypt(data, key, nonce: V + 1): keystream blocks E(V+1), E(V+2), ... xor data */
+static void drbg_ctr_encrypt(const orc_ctr_drbg* d, const uint8_t* data, size_t count, uint8_t* out) {
+    aes128_key k;
+    aes128_expand(d->key, &k);
+    uint8_t counter[16], block[16];
+    memcpy(counter, d->v, 16);
+    for (size_t off = 0; off < count; off += 16) {
+        be128_add(counter, 1);
+        aes128_encrypt_block(&k, counter, block);
+        for (size_t i = 0; i < 16 && off + i < count; ++i) out[off + i] = (uint8_t)(block[i] ^ (data ? data[off + i] : 0));
+    }
+}
+static void drbg_update(orc_ctr_drbg* d, const uint8_t provided[32]) { /* ctrDrbgUpdate, :58-66 */
+    uint8_t x[32];
+    drbg_ctr_encrypt(d, provided, 32, x);
+    memcpy(d->key, x, 16);
+    memcpy(d->v, x + 16, 16);
+}
+int orc_ctr_drbg_create(const uint8_t entropy[32], orc_ctr_drbg** out) { /* init(entropy:), :47-55 */
+    orc_ctr_drbg* d = (orc_ctr_drbg*)calloc(1, sizeof(orc_ctr_drbg));
+    d->reseed_counter = 1;
+    drbg_update(d, entropy);
+    *out = d;
+    return ORC_OK;
+}
+void orc_ctr_drbg_destroy(orc_ctr_drbg* d) { free(d); }
+void orc_ctr_drbg_state(const orc_ctr_drbg* d, uint8_t key[16], uint8_t nonce_be[16]) {
+    memcpy(key, d->key, 16);
+    memcpy(nonce_be, d->v, 16);
+}
+int orc_ctr_drbg_generate(orc_ctr_drbg* d, uint8_t* out, size_t count) { /* ctrDrbgGenerate, :68-83 */
+    if (count > ((size_t)1 << 16)) return ORC_ERR_INVALID_ARGUMENT;
+    drbg_ctr_encrypt(d, NULL, count, out);
+    be128_add(d->v, (count + 15) / 16);
+    uint8_t zeros[32] = {0};
+    drbg_update(d, zeros);
+    d->reseed_counter += 1;
+    return ORC_OK;
+}
+
+/* PolyRq.random(context:using: NistAes128Ctr(seed:)) -- the `a` polynomial of a seeded ciphertext
+ * (SerializedCiphertext.swift:53-58, Bfv+Encrypt.swift:155-156): 128 stream bits per coefficient, little-endian,
+ * reduced mod q_i; the stream is the concatenation of generate(4096) calls (BufferedRng, bufferCount 4096). */
+int orc_poly_random_from_seed(const orc_poly_context* ctx, const uint8_t seed[32], uint64_t* out) {
+    orc_ctr_drbg* d = NULL;
+    orc_ctr_drbg_create(seed, &d);
+    const size_t n = (size_t)ctx->degree;
+    uint8_t buffer[4096];
+    size_t offset = sizeof(buffer);
+    for (size_t r = 0; r < ctx->count; ++r)
+        for (size_t k = 0; k < n; ++k) {
+            if (offset == sizeof(buffer)) {
+                orc_ctr_drbg_generate(d, buffer, sizeof(buffer));
+                offset = 0;
+            }
+            u128 value = 0;
+            for (int b = 15; b >= 0; --b) value = (value << 8) | buffer[offset + b];
+            offset += 16;
+            out[r * n + k] = reduce_u128(&ctx->reduce[r], value);
+        }
+    orc_ctr_drbg_destroy(d);
+    return ORC_OK;
+}

@@ -203,6 +203,16 @@ int orc_poly_serialize(const orc_poly_context* ctx, const uint64_t* data, int sk
 int orc_poly_deserialize(const orc_poly_context* ctx, const uint8_t* bytes, size_t byte_count, int skip_lsbs,
                          uint64_t* data);
 
+
+/* ---- seeded polynomials: Random/NistCtrDrbg.swift, PolyRq/PolyRq+Randomize.swift:56-75 ---- */
+typedef struct orc_ctr_drbg orc_ctr_drbg;
+int orc_ctr_drbg_create(const uint8_t entropy[32], orc_ctr_drbg** out);
+void orc_ctr_drbg_destroy(orc_ctr_drbg* drbg);
+void orc_ctr_drbg_state(const orc_ctr_drbg* drbg, uint8_t key[16], uint8_t nonce_big_endian[16]);
+int orc_ctr_drbg_generate(orc_ctr_drbg* drbg, uint8_t* out, size_t count);
+/* PolyRq.random(context:using: NistAes128Ctr(seed: seed)) -> out [L][N] */
+int orc_poly_random_from_seed(const orc_poly_context* ctx, const uint8_t seed[32], uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

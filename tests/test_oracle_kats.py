@@ -316,3 +316,36 @@ def test_poly_serialize_known_answers(oracle, kats):
     packed = narrow.serialize(np.zeros((1, 3, 32), dtype=np.uint64))
     with pytest.raises(oracle.OracleError):
         wide.deserialize(packed)
+
+
+def test_nist_ctr_drbg_vectors(oracle, kats):
+    """NistCtrDrbgTests.swift:21-161."""
+    block = kats["nist_ctr_drbg"]
+    trace = block["state_trace"]
+    drbg = oracle.CtrDrbg(bytes.fromhex(trace["entropy"]))
+    assert [x.hex() for x in drbg.state()] == trace["after_init"]
+    drbg.generate(64)
+    assert [x.hex() for x in drbg.state()] == trace["after_first_generate"]
+    drbg.generate(64)
+    assert [x.hex() for x in drbg.state()] == trace["after_second_generate"]
+    assert len(block["vectors"]) >= 10
+    for vector in block["vectors"]:
+        drbg = oracle.CtrDrbg(bytes.fromhex(vector["entropy"]))
+        expected = bytes.fromhex(vector["returned_bits"])
+        drbg.generate(len(expected))
+        assert drbg.generate(len(expected)) == expected
+
+
+def test_seeded_polynomial_is_the_buffered_stream_reduced(oracle):
+    """PolyRq.randomizeUniform(using:) (PolyRq+Randomize.swift:56-75) over NistAes128Ctr (4096-byte refills):
+    coefficient (i, k) = LE u128 at stream offset 16 (i N + k), reduced mod q_i."""
+    degree, moduli = 512, oracle.generate_primes([55, 40, 20], False, 512)
+    ctx = oracle.PolyContext(degree, moduli)
+    seed = bytes(range(32))
+    poly = ctx.random_from_seeds(np.frombuffer(seed, dtype=np.uint8))[0]
+    drbg = oracle.CtrDrbg(seed)
+    stream = b"".join(drbg.generate(4096) for _ in range(len(moduli) * degree * 16 // 4096))
+    for i, q in enumerate(moduli):
+        for k in (0, 1, 255, 256, degree - 1):
+            offset = 16 * (i * degree + k)
+            assert int(poly[i, k]) == int.from_bytes(stream[offset:offset + 16], "little") % q
