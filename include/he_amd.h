@@ -155,6 +155,14 @@ int he_poly_serialize_device(const he_poly_context* ctx, const uint64_t* device_
 int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device_bytes, size_t bytes_per_poly,
                                size_t batch, int skip_lsbs, uint64_t* device_slab, he_stream s);
 
+/* The second polynomial of a seeded ciphertext (SerializedCiphertext.swift:53-58, Bfv/Bfv+Encrypt.swift:155-156):
+ * device_slab[b] = PolyRq<UInt64, Eval>.random(context:using: NistAes128Ctr(seed: device_seeds[b])), seeds are
+ * [batch][32] bytes (NistCtrDrbg.SeedCount).  NIST SP 800-90A CTR_DRBG/AES-128 as Random/NistCtrDrbg.swift has it,
+ * 4096-byte refills (Random/NistAes128Ctr.swift), 128 stream bits per coefficient reduced mod q_i
+ * (PolyRq/PolyRq+Randomize.swift:56-75).  A Coeff ciphertext then takes he_ntt_inverse_device of the result. */
+int he_poly_random_from_seeds_device(const he_poly_context* ctx, const uint8_t* device_seeds, size_t batch,
+                                     uint64_t* device_slab, he_stream s);
+
 /* =====================================================================================================
  * B3: Context<Bfv<UInt64>> and the HeScheme operations on the hot path
  * =================================================================================================== */

@@ -399,6 +399,18 @@ int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device
     return HE_OK;
 }
 
+int he_poly_random_from_seeds_device(const he_poly_context* ctx, const uint8_t* device_seeds, size_t batch,
+                                     uint64_t* device_slab, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (batch == 0) return HE_OK;
+    if (device_seeds == nullptr || device_slab == nullptr) return invalid_argument("null buffer");
+    int status = pc.check_device();
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_seeded_uniform(device_seeds, device_slab, pc.device_context(), batch, as_stream(s)));
+    return HE_OK;
+}
+
 int he_poly_mul_scalar_device(const he_poly_context* ctx, uint64_t* data, const uint64_t* scalar_residues,
                               size_t batch, he_stream s) {
     if (ctx == nullptr || scalar_residues == nullptr) return invalid_argument("null pointer");

@@ -57,6 +57,10 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                       size_t columns, uint64_t max_lazy, hipStream_t stream);
 
 
+// seeded_kernels.hip: out[b] = PolyRq.random(context, NistAes128Ctr(seed: seeds[b])), seeds [batch][32] bytes
+hipError_t launch_seeded_uniform(const uint8_t* seeds, uint64_t* out, const DeviceContext& ctx, size_t batch,
+                                 hipStream_t stream);
+
 // wire format of a polynomial: per residue row, the serialized bit width and the byte offset of the row
 constexpr uint32_t kMaxSerializedRows = 64;
 struct SerializeLayout {

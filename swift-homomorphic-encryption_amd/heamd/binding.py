@@ -67,6 +67,7 @@ SIGNATURES = [
     ("he_poly_adding_lazy_product_device", ctypes.c_int, [vp, vp, vp, vp, vp]),
     ("he_poly_reduce_accumulator_device", ctypes.c_int, [vp, vp, vp, vp]),
     ("he_poly_apply_galois_device", ctypes.c_int, [vp, vp, vp, c_size, c_u64, ctypes.c_int, vp]),
+    ("he_poly_random_from_seeds_device", ctypes.c_int, [vp, vp, c_size, vp, vp]),
     ("he_poly_serialization_byte_count", c_size, [vp, ctypes.c_int]),
     ("he_poly_serialize_device", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, vp, vp]),
     ("he_poly_deserialize_device", ctypes.c_int, [vp, vp, c_size, c_size, ctypes.c_int, vp, vp]),
@@ -326,6 +327,16 @@ class PolyContext:
         out = np.zeros((batch, len(self.moduli) - 1, self.degree), dtype=np.uint64)
         _check(load_library().he_poly_divide_and_round_q_last(self.h, a.ctypes.data_as(U64P),
                                                               out.ctypes.data_as(U64P), batch))
+        return out
+
+    def random_from_seeds(self, seeds, stream=None):
+        """PolyRq.random(context:using: NistAes128Ctr(seed:)) per seed: uint8 tensor [batch][32] -> [batch][L][N]."""
+        import torch
+
+        batch = seeds.numel() // 32
+        out = torch.empty((batch, len(self.moduli), self.degree), dtype=torch.int64, device=seeds.device)
+        _check(load_library().he_poly_random_from_seeds_device(self.h, vp(seeds.data_ptr()), batch,
+                                                               vp(out.data_ptr()), _stream(stream)))
         return out
 
     def serialization_byte_count(self, skip_lsbs=0):

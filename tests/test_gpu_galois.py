@@ -261,3 +261,55 @@ def test_deserialize_rejects_short_records(oracle):
         narrow.serialize(heamd.to_device(np.zeros((1, 3, 32), dtype=np.uint64)), skip_lsbs=5)
     assert err.value.name == "invalidCoefficientPacking"
     assert isinstance(packed, torch.Tensor)
+
+
+@pytest.mark.parametrize("degree,bits,batch", [(512, [55, 40, 20], 5), (16, [20, 21], 3), (8192, [55, 55, 55, 55], 3),
+                                                (4096, [27, 28, 28], 9)])
+def test_seeded_polynomials_match_oracle(oracle, degree, bits, batch):
+    """`a` of a seeded ciphertext (SerializedCiphertext.swift:53-58): AES-128 CTR_DRBG stream, 4096-byte refills,
+    128 bits per coefficient reduced mod q_i -- word-exact against the oracle (itself pinned by the NIST vectors)."""
+    import torch
+
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + batch)
+    seeds = rng.integers(0, 256, size=(batch, 32), dtype=np.uint8)
+    seeds[0] = 0
+    seeds[1] = 255
+    got = heamd.to_host(ours.random_from_seeds(torch.from_numpy(seeds).cuda()))
+    assert np.array_equal(got, ref.random_from_seeds(seeds))
+
+
+def test_seeded_ciphertext_roundtrip(oracle, small):
+    """Seeded wire format end to end on the device: serialize poly0, keep the seed; the server deserializes poly0,
+    regenerates a from the seed and inverse-transforms it -- the rebuilt ciphertext decrypts to the message."""
+    import torch
+
+    ours, ref, client = small
+    qctx_ref = ref.ciphertext_context()
+    qctx = ours.ciphertext_context()
+    r = random.Random(80)
+    message = [r.randrange(ref.t) for _ in range(ref.degree)]
+    seed = np.array([r.randrange(256) for _ in range(32)], dtype=np.uint8)
+    # encryptZero with a = random(seed) in Eval form (Bfv+Encrypt.swift:150-181)
+    a = qctx_ref.random_from_seeds(seed)[0]
+    c0 = qctx_ref.inverse_ntt(qctx_ref.mul(a, client._s_eval_for(qctx_ref)))
+    c0 = qctx_ref.neg(qctx_ref.add(c0, client._error(qctx_ref)))
+    zero_ct = np.stack([c0, qctx_ref.inverse_ntt(a)])
+    plain = client.encrypt(message)  # only used for its plaintext translation: subtract its own zero part
+    ct = zero_ct.copy()
+    q = 1
+    for m in qctx_ref.moduli:
+        q *= m
+    t = ref.t
+    for i, qi in enumerate(qctx_ref.moduli):
+        for k, m in enumerate(message):
+            adjust = ((q % t) * m + (t + 1) // 2) // t
+            ct[0, i, k] = (int(ct[0, i, k]) + ((q // t) % qi) * m + adjust) % qi
+    assert client.decrypt(ct) == message and plain.shape == ct.shape
+    wire_poly0 = qctx.serialize(heamd.to_device(ct[:1]))
+    rebuilt0 = qctx.deserialize(wire_poly0)
+    rebuilt1 = qctx.inverse_ntt_(qctx.random_from_seeds(torch.from_numpy(seed[None]).cuda()))
+    rebuilt = np.stack([heamd.to_host(rebuilt0)[0], heamd.to_host(rebuilt1)[0]])
+    assert np.array_equal(rebuilt, ct)
+    assert client.decrypt(rebuilt) == message
