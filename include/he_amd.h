@@ -163,6 +163,22 @@ int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device
 int he_poly_random_from_seeds_device(const he_poly_context* ctx, const uint8_t* device_seeds, size_t batch,
                                      uint64_t* device_slab, he_stream s);
 
+/* ---- PolyRq<UInt32> (polynomial layer): the same operations on slabs of 4-byte words ----
+ * The context is an ordinary he_poly_context whose moduli all fit UInt32 (<= 2^30 - 1, ModularArithmetic/
+ * Scalar.swift:498-511; e.g. the n_4096_logq_27_28_28 parameter sets, EncryptionParameters.swift:313-378); a larger
+ * modulus returns HE_ERR_INVALID_MODULUS.  Layout [batch][L][N] of uint32_t; semantics as the UInt64 entry points
+ * (the reference's generic code is the same for both word types).  Degrees above 32768: HE_ERR_UNSUPPORTED. */
+int he_ntt_forward_device_u32(const he_poly_context* ctx, uint32_t* device_slab, size_t batch, he_stream s);
+int he_ntt_inverse_device_u32(const he_poly_context* ctx, uint32_t* device_slab, size_t batch, he_stream s);
+int he_poly_add_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s);
+int he_poly_sub_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s);
+int he_poly_neg_device_u32(const he_poly_context* ctx, uint32_t* data, size_t batch, he_stream s);
+int he_poly_mul_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s);
+int he_poly_mul_scalar_device_u32(const he_poly_context* ctx, uint32_t* data, const uint32_t* scalar_residues,
+                                  size_t batch, he_stream s);
+int he_poly_divide_and_round_q_last_device_u32(const he_poly_context* ctx, const uint32_t* device_in,
+                                               uint32_t* device_out, size_t batch, he_stream s);
+
 /* =====================================================================================================
  * B3: Context<Bfv<UInt64>> and the HeScheme operations on the hot path
  * =================================================================================================== */

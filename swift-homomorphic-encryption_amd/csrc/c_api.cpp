@@ -399,6 +399,99 @@ int he_poly_deserialize_device(const he_poly_context* ctx, const uint8_t* device
     return HE_OK;
 }
 
+// ------------------------------------------------------------------------------------------ PolyRq<UInt32>
+namespace {
+int ntt32(const he_poly_context* ctx, uint32_t* slab, size_t batch, bool inverse, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (!pc.all_ntt(pc.moduli_count())) return HE_ERR_INVALID_NTT_MODULUS;
+    heamd::DeviceContext32 dc{};
+    int status = pc.device_context32(pc.moduli_count(), dc);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (slab == nullptr) return invalid_argument("null slab");
+    hipError_t e = heamd::launch_ntt32(inverse, slab, dc, 0, pc.moduli_count(), batch * pc.moduli_count(), as_stream(s));
+    if (e == hipErrorNotSupported) {
+        heamd::set_last_error("UInt32 transform supports degrees up to 32768");
+        return HE_ERR_UNSUPPORTED;
+    }
+    HEAMD_HIP_TRY(e);
+    return HE_OK;
+}
+int elementwise32(const he_poly_context* ctx, heamd::ElementwiseOp op, uint32_t* lhs, const uint32_t* rhs, size_t batch,
+                  he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    heamd::DeviceContext32 dc{};
+    int status = pc.device_context32(pc.moduli_count(), dc);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (lhs == nullptr || (rhs == nullptr && op != heamd::ElementwiseOp::Neg)) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_elementwise32(op, lhs, rhs, nullptr, dc, batch * pc.moduli_count(), as_stream(s)));
+    return HE_OK;
+}
+}  // namespace
+
+int he_ntt_forward_device_u32(const he_poly_context* ctx, uint32_t* device_slab, size_t batch, he_stream s) {
+    return ntt32(ctx, device_slab, batch, false, s);
+}
+int he_ntt_inverse_device_u32(const he_poly_context* ctx, uint32_t* device_slab, size_t batch, he_stream s) {
+    return ntt32(ctx, device_slab, batch, true, s);
+}
+int he_poly_add_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s) {
+    return elementwise32(ctx, heamd::ElementwiseOp::Add, lhs, rhs, batch, s);
+}
+int he_poly_sub_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s) {
+    return elementwise32(ctx, heamd::ElementwiseOp::Sub, lhs, rhs, batch, s);
+}
+int he_poly_neg_device_u32(const he_poly_context* ctx, uint32_t* data, size_t batch, he_stream s) {
+    return elementwise32(ctx, heamd::ElementwiseOp::Neg, data, nullptr, batch, s);
+}
+int he_poly_mul_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s) {
+    return elementwise32(ctx, heamd::ElementwiseOp::Mul, lhs, rhs, batch, s);
+}
+int he_poly_mul_scalar_device_u32(const he_poly_context* ctx, uint32_t* data, const uint32_t* scalar_residues,
+                                  size_t batch, he_stream s) {
+    if (ctx == nullptr || scalar_residues == nullptr) return invalid_argument("null pointer");
+    const PolyContext& pc = *ctx->impl;
+    heamd::DeviceContext32 dc{};
+    int status = pc.device_context32(pc.moduli_count(), dc);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (data == nullptr) return invalid_argument("null slab");
+    std::vector<uint64_t> pairs(2 * pc.moduli_count());
+    for (uint32_t i = 0; i < pc.moduli_count(); ++i) {
+        const uint64_t p = pc.moduli()[i];
+        if (scalar_residues[i] >= p) return invalid_argument("scalar residue not reduced");
+        pairs[2 * i] = scalar_residues[i];
+        pairs[2 * i + 1] = heamd::shoup_factor(scalar_residues[i], p);
+    }
+    hipStream_t stream = as_stream(s);
+    Scratch scratch(stream);
+    HEAMD_HIP_TRY(scratch.allocate(pairs.size() * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(hipMemcpyAsync(scratch.get(), pairs.data(), pairs.size() * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                 stream));
+    HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // the pageable host vector must outlive the async copy
+    HEAMD_HIP_TRY(heamd::launch_elementwise32(heamd::ElementwiseOp::MulScalar, data, nullptr,
+                                              static_cast<const uint64_t*>(scratch.get()), dc,
+                                              batch * pc.moduli_count(), stream));
+    return HE_OK;
+}
+int he_poly_divide_and_round_q_last_device_u32(const he_poly_context* ctx, const uint32_t* device_in,
+                                               uint32_t* device_out, size_t batch, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    const PolyContext& pc = *ctx->impl;
+    if (pc.moduli_count() < 2) return HE_ERR_INVALID_POLY_CONTEXT;  // PolyRq.swift:366-368
+    heamd::DeviceContext32 dc{};
+    int status = pc.device_context32(pc.moduli_count(), dc);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (device_in == nullptr || device_out == nullptr) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_divide_and_round_q_last32(device_in, device_out, dc, pc.moduli_count(), batch,
+                                                          as_stream(s)));
+    return HE_OK;
+}
+
 int he_poly_random_from_seeds_device(const he_poly_context* ctx, const uint8_t* device_seeds, size_t batch,
                                      uint64_t* device_slab, he_stream s) {
     if (ctx == nullptr) return invalid_argument("null context");

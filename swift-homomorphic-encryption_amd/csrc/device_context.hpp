@@ -42,4 +42,17 @@ struct DeviceContext {
     uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): NTT may trade folds for top bits
 };
 
+// Image of a context whose moduli all fit UInt32 (<= 2^30 - 1), for slabs of 4-byte words: the same per-modulus
+// constants, twiddles as (w, floor(w 2^32 / p)) pairs (the high halves of the 64-bit Shoup factors).
+struct alignas(8) U32x2 {
+    uint32_t x, y;
+};
+struct DeviceContext32 {
+    const DeviceModulus* moduli;
+    const U32x2* forward_twiddles;  // [L][N]
+    const U32x2* inverse_twiddles;  // [L][N]
+    const U64x2* inverse_q_last;    // [L][L]
+    uint32_t degree, log_degree, moduli_count, moduli_stride;
+};
+
 }  // namespace heamd

@@ -57,6 +57,15 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                       size_t columns, uint64_t max_lazy, hipStream_t stream);
 
 
+// word32_kernels.hip: PolyRq<UInt32> (4-byte words; every modulus <= 2^30 - 1)
+hipError_t launch_ntt32(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base, uint32_t mod_period,
+                        size_t rows, hipStream_t stream);
+// scalars: device array of L (scalar, 64-bit Shoup factor) pairs, only for MulScalar
+hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t* rhs, const uint64_t* scalars,
+                                const DeviceContext32& ctx, size_t rows, hipStream_t stream);
+hipError_t launch_divide_and_round_q_last32(const uint32_t* in, uint32_t* out, const DeviceContext32& ctx,
+                                            uint32_t moduli_count, size_t polys, hipStream_t stream);
+
 // seeded_kernels.hip: out[b] = PolyRq.random(context, NistAes128Ctr(seed: seeds[b])), seeds [batch][32] bytes
 hipError_t launch_seeded_uniform(const uint8_t* seeds, uint64_t* out, const DeviceContext& ctx, size_t batch,
                                  hipStream_t stream);

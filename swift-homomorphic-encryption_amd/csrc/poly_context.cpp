@@ -198,6 +198,43 @@ int PolyContext::upload() {
 
 PolyContext::~PolyContext() {
     if (device_block_ != nullptr) (void)hipFree(device_block_);
+    if (device_block32_ != nullptr) (void)hipFree(device_block32_);
+}
+
+int PolyContext::device_context32(uint32_t count, DeviceContext32& out) const {
+    for (uint32_t i = 0; i < count; ++i)
+        if (moduli_[i] > ((static_cast<u64>(1) << 30) - 1)) {
+            set_last_error("modulus " + std::to_string(moduli_[i]) + " does not fit UInt32 (max 2^30 - 1)");
+            return HE_ERR_INVALID_MODULUS;
+        }
+    const int status = check_device();
+    if (status != HE_OK) return status;
+    std::lock_guard<std::mutex> guard(word32_lock_);
+    if (device_block32_ == nullptr) {
+        const size_t total = moduli_.size() * degree_;
+        std::vector<U32x2> forward(total), inverse(total);
+        for (size_t k = 0; k < total; ++k) {
+            // floor(floor(w 2^64 / p) / 2^32) = floor(w 2^32 / p)
+            forward[k] = U32x2{static_cast<uint32_t>(host_forward_[k].x), static_cast<uint32_t>(host_forward_[k].y >> 32)};
+            inverse[k] = U32x2{static_cast<uint32_t>(host_inverse_[k].x), static_cast<uint32_t>(host_inverse_[k].y >> 32)};
+        }
+        void* block = nullptr;
+        HEAMD_HIP_TRY(hipMalloc(&block, 2 * total * sizeof(U32x2) + 16));
+        HEAMD_HIP_TRY(hipMemcpy(block, forward.data(), total * sizeof(U32x2), hipMemcpyHostToDevice));
+        HEAMD_HIP_TRY(hipMemcpy(static_cast<char*>(block) + total * sizeof(U32x2), inverse.data(), total * sizeof(U32x2),
+                                hipMemcpyHostToDevice));
+        device_block32_ = block;
+        dev32_.moduli = dev_.moduli;
+        dev32_.forward_twiddles = static_cast<const U32x2*>(block);
+        dev32_.inverse_twiddles = static_cast<const U32x2*>(block) + total;
+        dev32_.inverse_q_last = dev_.inverse_q_last;
+        dev32_.degree = degree_;
+        dev32_.log_degree = log_degree_;
+        dev32_.moduli_stride = static_cast<uint32_t>(moduli_.size());
+    }
+    out = dev32_;
+    out.moduli_count = count;
+    return HE_OK;
 }
 
 bool PolyContext::all_ntt(uint32_t count) const {

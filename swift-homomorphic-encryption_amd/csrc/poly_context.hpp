@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,9 @@ class PolyContext {
     DeviceContext device_context() const { return device_context(moduli_count()); }
     // true when the caller's current HIP device is the one this context lives on
     int check_device() const;
+    // PolyRq<UInt32>: every modulus <= 2^30 - 1 (ModularArithmetic/Scalar.swift:498-511).  The 4-byte-word device
+    // image (32-bit twiddle pairs) is built on first use.  HE_OK / HE_ERR_INVALID_MODULUS / HE_ERR_DEVICE.
+    int device_context32(uint32_t count, DeviceContext32& out) const;
 
   private:
     PolyContext() = default;
@@ -68,6 +72,9 @@ class PolyContext {
     int device_ = -1;
     DeviceContext dev_{};
     void* device_block_ = nullptr;
+    mutable std::mutex word32_lock_;
+    mutable void* device_block32_ = nullptr;
+    mutable DeviceContext32 dev32_{};
 };
 
 // Validation of one chain element (designated init) -- shared with the BFV context builder.

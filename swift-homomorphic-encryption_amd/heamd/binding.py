@@ -68,6 +68,14 @@ SIGNATURES = [
     ("he_poly_reduce_accumulator_device", ctypes.c_int, [vp, vp, vp, vp]),
     ("he_poly_apply_galois_device", ctypes.c_int, [vp, vp, vp, c_size, c_u64, ctypes.c_int, vp]),
     ("he_poly_random_from_seeds_device", ctypes.c_int, [vp, vp, c_size, vp, vp]),
+    ("he_ntt_forward_device_u32", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_ntt_inverse_device_u32", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_poly_add_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_sub_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_neg_device_u32", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_poly_mul_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_poly_mul_scalar_device_u32", ctypes.c_int, [vp, vp, ctypes.POINTER(ctypes.c_uint32), c_size, vp]),
+    ("he_poly_divide_and_round_q_last_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
     ("he_poly_serialization_byte_count", c_size, [vp, ctypes.c_int]),
     ("he_poly_serialize_device", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, vp, vp]),
     ("he_poly_deserialize_device", ctypes.c_int, [vp, vp, c_size, c_size, ctypes.c_int, vp, vp]),
@@ -327,6 +335,44 @@ class PolyContext:
         out = np.zeros((batch, len(self.moduli) - 1, self.degree), dtype=np.uint64)
         _check(load_library().he_poly_divide_and_round_q_last(self.h, a.ctypes.data_as(U64P),
                                                               out.ctypes.data_as(U64P), batch))
+        return out
+
+    # ---- PolyRq<UInt32>: int32 tensors [batch][L][N] holding UInt32 words ----
+    def _batch32(self, slab):
+        return slab.numel() // (len(self.moduli) * self.degree)
+
+    def forward_ntt_u32_(self, slab, stream=None):
+        _check(load_library().he_ntt_forward_device_u32(self.h, vp(slab.data_ptr()), self._batch32(slab), _stream(stream)))
+        return slab
+
+    def inverse_ntt_u32_(self, slab, stream=None):
+        _check(load_library().he_ntt_inverse_device_u32(self.h, vp(slab.data_ptr()), self._batch32(slab), _stream(stream)))
+        return slab
+
+    def elementwise_u32_(self, op, lhs, rhs=None, stream=None):
+        lib = load_library()
+        batch = self._batch32(lhs)
+        if op == "neg":
+            _check(lib.he_poly_neg_device_u32(self.h, vp(lhs.data_ptr()), batch, _stream(stream)))
+        else:
+            fn = {"add": lib.he_poly_add_device_u32, "sub": lib.he_poly_sub_device_u32,
+                  "mul": lib.he_poly_mul_device_u32}[op]
+            _check(fn(self.h, vp(lhs.data_ptr()), vp(rhs.data_ptr()), batch, _stream(stream)))
+        return lhs
+
+    def mul_scalar_u32_(self, data, scalar_residues, stream=None):
+        arr = (ctypes.c_uint32 * len(self.moduli))(*[int(v) for v in scalar_residues])
+        _check(load_library().he_poly_mul_scalar_device_u32(self.h, vp(data.data_ptr()), arr, self._batch32(data),
+                                                            _stream(stream)))
+        return data
+
+    def divide_and_round_q_last_u32(self, slab, stream=None):
+        import torch
+
+        batch = self._batch32(slab)
+        out = torch.empty((batch, len(self.moduli) - 1, self.degree), dtype=torch.int32, device=slab.device)
+        _check(load_library().he_poly_divide_and_round_q_last_device_u32(self.h, vp(slab.data_ptr()),
+                                                                         vp(out.data_ptr()), batch, _stream(stream)))
         return out
 
     def random_from_seeds(self, seeds, stream=None):
