@@ -99,6 +99,23 @@ def config5_inner_product(torch, heamd, count=256, columns=64, reps=3):
             "frac_of_8TBps": db_bytes / t / 8e12}
 
 
+def config5_pir_chunk(torch, heamd, d0=256, d1=64, reps=3):
+    """One PIR chunk response end to end on the device (PirUtil.computeResponseForOneChunk): d0 x d1 database of Eval
+    plaintexts, dim-0 ct x pt inner products, one ct x ct inner product + relinearize, mod-switch to one modulus."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    dim0 = _uniform(torch, moduli, (d0, 2), degree, 7)
+    rest = _uniform(torch, moduli, (d1, 2), degree, 8)
+    database = _uniform(torch, moduli, (d0 * d1,), degree, 9)
+    key = _uniform(torch, q, (ctx.L, 2), degree, 10)
+    t = _timed(torch, lambda: ctx.pir_compute_response_chunk([d0, d1], dim0, rest, database, None, key), reps)
+    db_bytes = d0 * d1 * 4 * degree * 8
+    return {"dimensions": [d0, d1], "database_GB": db_bytes / 1e9, "chunk_response_ms": t * 1e3,
+            "chunk_responses_per_s": 1 / t, "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12}
+
+
 def run_all(quick=False):
     import torch
 
@@ -109,6 +126,8 @@ def run_all(quick=False):
     out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
     out["config5_inner_product_1gpu"] = config5_inner_product(torch, heamd, count=64 if quick else 256,
                                                               columns=16 if quick else 64)
+    out["config5_pir_chunk_response_1gpu"] = config5_pir_chunk(torch, heamd, d0=64 if quick else 256,
+                                                                d1=16 if quick else 64)
     return out
 
 
