@@ -1204,7 +1204,7 @@ int orc_rns_lift_q_to_qbsk(const orc_rns_tool* tool, const uint64_t* in, uint64_
 /* RnsTool.swift:378-398 approximateFloor */
 int orc_rns_approximate_floor(const orc_rns_tool* tool, const uint64_t* in, uint64_t* out) {
     size_t n = (size_t)tool->degree, L = tool->L;
-    uint64_t* products = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    uint64_t* products = (uint64_t*)calloc(L * n, sizeof(uint64_t));
     base_converter_products(&tool->q_to_bsk, in, products, n);
     base_converter_convert_products(&tool->q_to_bsk, products, out, n);
     free(products);
@@ -1225,7 +1225,7 @@ int orc_rns_convert_approximate_bsk_to_q(const orc_rns_tool* tool, const uint64_
     size_t n = (size_t)tool->degree, L = tool->L;
     const uint64_t m_sk = tool->ext_moduli[L];
     const uint64_t* poly_mod_msk = in + L * n;
-    uint64_t* products = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    uint64_t* products = (uint64_t*)calloc(L * n, sizeof(uint64_t));
     uint64_t* alpha = (uint64_t*)malloc(n * sizeof(uint64_t));
     uint8_t* exceeds = (uint8_t*)malloc(n);
     base_converter_products(&tool->b_to_msk, in, products, n);

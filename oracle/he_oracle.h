@@ -126,7 +126,7 @@ int orc_rns_convert_approximate(const orc_poly_context* input, const orc_poly_co
 /* decrypt-side scaleAndRound (RnsTool.swift:272-302): in [L][N] over Q -> out [N] mod t */
 int orc_rns_scale_and_round(const orc_rns_tool* tool, const uint64_t* in, uint64_t scaling_factor, uint64_t* out);
 
-/* ---------- BFV context + scheme ops (Context.swift, Bfv/*.swift) ---------- */
+/* ---------- BFV context + scheme ops (Context.swift and the files under Bfv/) ---------- */
 typedef struct orc_bfv_context orc_bfv_context;
 int orc_bfv_context_create(uint64_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
                            size_t moduli_count, orc_bfv_context** out);
