@@ -14,6 +14,7 @@
 #include "device_context.hpp"
 #include "device_math.hpp"
 #include "kernels.hpp"
+#include "ntt_common.hpp"
 
 namespace heamd {
 
@@ -91,6 +92,211 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// ---- register-tiled transform for N = 4096 / 8192 / 16384: the 8-byte kernel's structure (ntt_kernels.hip) on 4-byte
+// words -- one workgroup per row, 2^LOGE words per lane, passes of LOGE radix-2 stages on registers, LDS transposes
+// in between (wave-private after the first), wave-uniform twiddles through the scalar cache.  The lane <-> element
+// maps, the pass schedule and the fences are the shared helpers of ntt_common.hpp; only the arithmetic is narrower.
+using ntt::element_index;
+using ntt::lane_part;
+using ntt::register_part;
+using ntt::Schedule;
+
+__device__ __forceinline__ U32x2 load_twiddle32(const U32x2* entry) {
+    using ConstWord = const __attribute__((address_space(4))) uint32_t;
+    ConstWord* const words = (ConstWord*)(entry);
+    return U32x2{words[0], words[1]};
+}
+
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void forward_pass32(uint32_t (&v)[1 << LOGE], uint32_t tid, const U32x2* __restrict__ tw,
+                                               uint32_t p, bool first_stage_canonical) {
+    constexpr int E = 1 << LOGE;
+    const uint32_t two_p = 2 * p;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int b = LO + W - 1 - j, s = LOGN - 1 - b, stride = 1 << (b - LO);
+        const bool uniform = (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
+        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+        const U32x2* const tw_stage = tw + (1u << s) + lane_twiddle;
+#pragma unroll
+        for (int base = 0; base < E; base += 2 * stride) {
+            const U32x2 w = load_twiddle32(tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)));
+#pragma unroll
+            for (int o = 0; o < stride; ++o) {
+                uint32_t x = v[base + o];
+                if (!(first_stage_canonical && j == 0)) x = csub32(x, two_p);
+                const uint32_t t = shoup32_lazy(v[base + o + stride], w.x, w.y, p);
+                v[base + o] = x + t;
+                v[base + o + stride] = x + two_p - t;
+            }
+        }
+    }
+}
+
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void inverse_pass32(uint32_t (&v)[1 << LOGE], uint32_t tid, const U32x2* __restrict__ tw,
+                                               const DeviceModulus& mod, bool first_stage_canonical) {
+    constexpr int E = 1 << LOGE;
+    constexpr uint32_t N = 1u << LOGN;
+    const uint32_t p = static_cast<uint32_t>(mod.p), two_p = 2 * p;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int b = LO + j, stride = 1 << (b - LO);
+        const uint32_t m = N >> (b + 1);
+        const bool last_stage = (b == LOGN - 1);
+        const bool uniform = (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
+        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+        const U32x2* const tw_stage = tw + (N - 2 * m + 1) + lane_twiddle;
+#pragma unroll
+        for (int base = 0; base < E; base += 2 * stride) {
+            U32x2 w = {0, 0};
+            if (!last_stage) w = load_twiddle32(tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1)));
+#pragma unroll
+            for (int o = 0; o < stride; ++o) {
+                const uint32_t x = v[base + o], y = v[base + o + stride];
+                // inputs in [0, 2p) (canonical on the very first stage): sum < 4p, diff in (0, 4p)
+                const uint32_t sum = x + y, diff = x + two_p - y;
+                if (last_stage) {
+                    v[base + o] = csub32(shoup32_lazy(sum, static_cast<uint32_t>(mod.inv_degree),
+                                                      static_cast<uint32_t>(mod.inv_degree_shoup >> 32), p), p);
+                    v[base + o + stride] = csub32(shoup32_lazy(diff, static_cast<uint32_t>(mod.inv_degree_root),
+                                                               static_cast<uint32_t>(mod.inv_degree_root_shoup >> 32), p), p);
+                } else {
+                    v[base + o] = (first_stage_canonical && j == 0) ? sum : csub32(sum, two_p);
+                    v[base + o + stride] = shoup32_lazy(diff, w.x, w.y, p);
+                }
+            }
+        }
+    }
+}
+
+__host__ __device__ constexpr uint32_t tile32_slot(uint32_t idx) { return idx + (idx >> 5); }
+constexpr uint32_t tile32_words(uint32_t n) { return n + (n >> 5) + 8; }
+
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void tile32_store(const uint32_t (&v)[1 << LOGE], uint32_t tid, uint32_t* lds) {
+    uint32_t* const base = lds + tile32_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+#pragma unroll
+    for (int r = 0; r < (1 << LOGE); ++r) base[tile32_slot(register_part<LOGN, LOGE, LO, W>(r))] = v[r];
+}
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void tile32_load(uint32_t (&v)[1 << LOGE], uint32_t tid, const uint32_t* lds) {
+    const uint32_t* const base = lds + tile32_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+#pragma unroll
+    for (int r = 0; r < (1 << LOGE); ++r) v[r] = base[tile32_slot(register_part<LOGN, LOGE, LO, W>(r))];
+}
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void row32_load(uint32_t (&v)[1 << LOGE], uint32_t tid, const uint32_t* __restrict__ x) {
+#pragma unroll
+    for (int r = 0; r < (1 << LOGE); ++r)
+        v[r] = x[register_part<LOGN, LOGE, LO, W>(r) + lane_part<LOGN, LOGE, LO, W>(tid)];
+}
+template <int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void row32_store(const uint32_t (&v)[1 << LOGE], uint32_t tid, uint32_t* __restrict__ x) {
+#pragma unroll
+    for (int r = 0; r < (1 << LOGE); ++r)
+        x[register_part<LOGN, LOGE, LO, W>(r) + lane_part<LOGN, LOGE, LO, W>(tid)] = v[r];
+}
+
+template <int LOGN, int LOGT, bool INVERSE>
+__global__ void __launch_bounds__(1 << LOGT)
+    ntt32_tiled_kernel(uint32_t* __restrict__ slab, const DeviceContext32 ctx, uint32_t mod_base, uint32_t mod_period) {
+    constexpr int LOGE = LOGN - LOGT;
+    constexpr int E = 1 << LOGE;
+    using S = Schedule<LOGN, LOGE>;
+    static_assert(S::P >= 2 && S::P <= 5, "unsupported pass count");
+    extern __shared__ uint32_t tile[];
+    const uint32_t tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
+    const DeviceModulus mod = ctx.moduli[mi];
+    const uint32_t p = static_cast<uint32_t>(mod.p);
+    const U32x2* __restrict__ tw = (INVERSE ? ctx.inverse_twiddles : ctx.forward_twiddles) + (static_cast<size_t>(mi) << LOGN);
+    uint32_t* __restrict__ x = slab + (row << LOGN);
+    uint32_t v[E];
+    if constexpr (!INVERSE) {
+        constexpr int LO0 = LOGN - LOGE;
+        row32_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
+        forward_pass32<LOGN, LOGE, LO0, LOGE>(v, tid, tw, p, true);
+        tile32_store<LOGN, LOGE, LO0, LOGE>(v, tid, tile);
+        __syncthreads();
+        if constexpr (S::P >= 3) {
+            constexpr int LO1 = LOGN - 2 * LOGE;
+            tile32_load<LOGN, LOGE, LO1, LOGE>(v, tid, tile);
+            forward_pass32<LOGN, LOGE, LO1, LOGE>(v, tid, tw, p, false);
+            tile32_store<LOGN, LOGE, LO1, LOGE>(v, tid, tile);
+            ntt::lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>();
+        }
+        if constexpr (S::P >= 4) {
+            constexpr int LO2 = LOGN - 3 * LOGE;
+            tile32_load<LOGN, LOGE, LO2, LOGE>(v, tid, tile);
+            forward_pass32<LOGN, LOGE, LO2, LOGE>(v, tid, tw, p, false);
+            tile32_store<LOGN, LOGE, LO2, LOGE>(v, tid, tile);
+            ntt::lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>();
+        }
+        if constexpr (S::P >= 5) {
+            constexpr int LO3 = LOGN - 4 * LOGE;
+            tile32_load<LOGN, LOGE, LO3, LOGE>(v, tid, tile);
+            forward_pass32<LOGN, LOGE, LO3, LOGE>(v, tid, tw, p, false);
+            tile32_store<LOGN, LOGE, LO3, LOGE>(v, tid, tile);
+            ntt::lds_transpose_fence<LOGN, LOGE, LO3, 0>();
+        }
+        tile32_load<LOGN, LOGE, 0, S::R>(v, tid, tile);
+        forward_pass32<LOGN, LOGE, 0, S::R>(v, tid, tw, p, false);
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = csub32(csub32(v[r], 2 * p), p);
+        row32_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+    } else {
+        row32_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+        inverse_pass32<LOGN, LOGE, 0, S::R>(v, tid, tw, mod, true);
+        tile32_store<LOGN, LOGE, 0, S::R>(v, tid, tile);
+        if constexpr (S::P >= 3) {
+            ntt::lds_transpose_fence<LOGN, LOGE, 0, S::R>();
+            constexpr int LO1 = S::R;
+            tile32_load<LOGN, LOGE, LO1, LOGE>(v, tid, tile);
+            inverse_pass32<LOGN, LOGE, LO1, LOGE>(v, tid, tw, mod, false);
+            tile32_store<LOGN, LOGE, LO1, LOGE>(v, tid, tile);
+        }
+        if constexpr (S::P >= 4) {
+            ntt::lds_transpose_fence<LOGN, LOGE, S::R, S::R + LOGE>();
+            constexpr int LO2 = S::R + LOGE;
+            tile32_load<LOGN, LOGE, LO2, LOGE>(v, tid, tile);
+            inverse_pass32<LOGN, LOGE, LO2, LOGE>(v, tid, tw, mod, false);
+            tile32_store<LOGN, LOGE, LO2, LOGE>(v, tid, tile);
+        }
+        if constexpr (S::P >= 5) {
+            ntt::lds_transpose_fence<LOGN, LOGE, S::R + LOGE, S::R + 2 * LOGE>();
+            constexpr int LO3 = S::R + 2 * LOGE;
+            tile32_load<LOGN, LOGE, LO3, LOGE>(v, tid, tile);
+            inverse_pass32<LOGN, LOGE, LO3, LOGE>(v, tid, tw, mod, false);
+            tile32_store<LOGN, LOGE, LO3, LOGE>(v, tid, tile);
+        }
+        __syncthreads();
+        constexpr int LOL = LOGN - LOGE;
+        tile32_load<LOGN, LOGE, LOL, LOGE>(v, tid, tile);
+        inverse_pass32<LOGN, LOGE, LOL, LOGE>(v, tid, tw, mod, false);
+        row32_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
+    }
+}
+
+template <int LOGN, int LOGT>
+hipError_t launch_ntt32_tiled(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base,
+                              uint32_t mod_period, size_t rows, hipStream_t stream) {
+    constexpr size_t lds_bytes = tile32_words(1u << LOGN) * sizeof(uint32_t);
+    using Kernel = void (*)(uint32_t*, const DeviceContext32, uint32_t, uint32_t);
+    Kernel kernel = inverse ? ntt32_tiled_kernel<LOGN, LOGT, true> : ntt32_tiled_kernel<LOGN, LOGT, false>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
+                       mod_base, mod_period);
+    return hipGetLastError();
+}
+
 // ---- element-wise: one lane = one word -------------------------------------------------------------------------
 template <ElementwiseOp OP>
 __global__ void __launch_bounds__(kThreads)
@@ -153,6 +359,14 @@ hipError_t launch_ntt32(bool inverse, uint32_t* slab, const DeviceContext32& ctx
         const size_t chunk = (kMaxRowsPerLaunch / mod_period) * mod_period;
         const size_t now = rows - done < chunk ? rows - done : chunk;
         const uint32_t n = ctx.degree;
+        if (ctx.log_degree >= 12 && ctx.log_degree <= 14) {  // register-tiled kernels, 8 (16) words per lane
+            hipError_t e = ctx.log_degree == 12   ? launch_ntt32_tiled<12, 9>(inverse, slab + done * n, ctx, mod_base, mod_period, now, stream)
+                           : ctx.log_degree == 13 ? launch_ntt32_tiled<13, 10>(inverse, slab + done * n, ctx, mod_base, mod_period, now, stream)
+                                                  : launch_ntt32_tiled<14, 10>(inverse, slab + done * n, ctx, mod_base, mod_period, now, stream);
+            if (e != hipSuccess) return e;
+            done += now;
+            continue;
+        }
         const unsigned threads = n / 2 < 64 ? 64 : (n / 2 > 1024 ? 1024 : n / 2);
         const size_t lds_bytes = (static_cast<size_t>(n) + (n >> 5) + 1) * sizeof(uint32_t);
         auto kernel = inverse ? ntt32_kernel<true> : ntt32_kernel<false>;

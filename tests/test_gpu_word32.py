@@ -38,7 +38,7 @@ def test_ntt_known_answers_u32(kats):
 
 @pytest.mark.parametrize("degree,bits,batch", [(2, [20], 3), (64, [30, 29], 4), (1024, [27, 28, 28], 3),
                                                 (4096, [27, 28, 28], 7),   # n_4096_logq_27_28_28 (EncryptionParameters.swift:313-378)
-                                                (8192, [30, 30, 29], 3), (32768, [30], 1)])
+                                                (8192, [30, 30, 29], 3), (16384, [30, 29], 2), (32768, [30], 1)])
 def test_ntt_u32_matches_oracle(oracle, degree, bits, batch):
     moduli = oracle.generate_primes(bits, False, degree, word_bits=32)
     ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
