@@ -313,3 +313,41 @@ def test_seeded_ciphertext_roundtrip(oracle, small):
     rebuilt = np.stack([heamd.to_host(rebuilt0)[0], heamd.to_host(rebuilt1)[0]])
     assert np.array_equal(rebuilt, ct)
     assert client.decrypt(rebuilt) == message
+
+
+def test_single_modulus_context_edge_cases(oracle):
+    """A context with one coefficient modulus has no key-switching modulus (Context.swift:102-107): the conversions
+    still work, the key-switching entry points report the missing key."""
+    degree = 64
+    t = oracle.generate_primes([12], True, degree)[0]
+    q = oracle.generate_primes([40], False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    assert ours.L == ref.L == 1
+    rng = np.random.default_rng(95)
+    pt = rng.integers(0, t, size=(2, degree), dtype=np.uint64)
+    got = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(pt)))
+    assert np.array_equal(got, ref.plaintext_to_eval(pt))
+    assert np.array_equal(heamd.to_host(ours.plaintext_to_coeff(heamd.to_device(got))), pt)
+    x = _uniform(rng, (2,), q, degree)
+    tool = ref.rns_tool()
+    assert np.array_equal(heamd.to_host(ours.scale_and_round(heamd.to_device(x), 1)),
+                          np.stack([tool.scale_and_round(p, 1) for p in x]))
+    ct = heamd.to_device(np.zeros((1, 2, 1, degree), dtype=np.uint64))
+    key = heamd.to_device(np.zeros((1, 2, 2, degree), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:
+        ours.apply_galois(ct, 3, key)
+    assert err.value.name == "missingGaloisKey"
+
+
+def test_zero_batches_are_no_ops(oracle):
+    import torch
+
+    degree = 64
+    moduli = oracle.generate_primes([40, 41], False, degree)
+    ctx = heamd.PolyContext(degree, moduli)
+    empty = torch.empty((0, 2, degree), dtype=torch.int64, device="cuda")
+    assert ctx.apply_galois(empty, 3).shape == (0, 2, degree)
+    assert ctx.multiply_power_of_x(empty, 5).shape == (0, 2, degree)
+    assert ctx.serialize(empty).shape == (0, ctx.serialization_byte_count())
+    assert ctx.random_from_seeds(torch.empty((0, 32), dtype=torch.uint8, device="cuda")).shape == (0, 2, degree)
+    assert ctx.deserialize(torch.empty((0, ctx.serialization_byte_count()), dtype=torch.uint8, device="cuda")).shape == (0, 2, degree)

@@ -141,3 +141,17 @@ def test_pir_expand_errors(small):
     with pytest.raises(heamd.HeError) as err:
         ours.pir_expand(ct, ours.degree + 1, {})
     assert err.value.name == "invalidArgument"
+
+
+def test_pir_one_dimension_single_modulus(oracle):
+    """dimension_count == 1 and L == 1: no ct x ct step, no key, no mod-switch (PirUtil.swift:448-485 degenerate)."""
+    degree = 64
+    t = oracle.generate_primes([12], True, degree)[0]
+    q = oracle.generate_primes([45], False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    rng = np.random.default_rng(96)
+    dim0 = _uniform(rng, (3, 2), q, degree)
+    database = _uniform(rng, (3,), q, degree)
+    expected = oracle.pir.compute_response_for_one_chunk(ref, [3], dim0, None, database, None, None)
+    got = heamd.to_host(ours.pir_compute_response_chunk([3], heamd.to_device(dim0), None, heamd.to_device(database)))
+    assert np.array_equal(got, expected)
