@@ -95,6 +95,7 @@ def _declare(L):
     L.orc_poly_adding_lazy_product.argtypes = [vp, U64P, U64P, U64P]
     L.orc_poly_reduce_accumulator.argtypes = [vp, U64P, U64P]
     L.orc_rns_tool_create.argtypes = [vp, c_u64, ctypes.POINTER(vp)]
+    L.orc_rns_tool_create_word.argtypes = [vp, c_u64, ctypes.c_int, ctypes.POINTER(vp)]
     L.orc_rns_tool_destroy.argtypes = [vp]
     L.orc_rns_tool_destroy.restype = None
     L.orc_rns_tool_bsk_count.restype = c_size
@@ -108,6 +109,7 @@ def _declare(L):
     L.orc_rns_convert_approximate.argtypes = [vp, vp, U64P, U64P]
     L.orc_rns_scale_and_round.argtypes = [vp, U64P, c_u64, U64P]
     L.orc_bfv_context_create.argtypes = [c_u64, c_u64, U64P, c_size, ctypes.POINTER(vp)]
+    L.orc_bfv_context_create_word.argtypes = [c_u64, c_u64, U64P, c_size, ctypes.c_int, ctypes.POINTER(vp)]
     L.orc_bfv_context_destroy.argtypes = [vp]
     L.orc_bfv_context_destroy.restype = None
     L.orc_bfv_ciphertext_moduli_count.restype = c_size
@@ -448,7 +450,7 @@ def convert_approximate(input_ctx, output_ctx, data):
 class RnsTool:
     """Mirror of _RnsTool<UInt64> (HomomorphicEncryption/RnsTool.swift)."""
 
-    def __init__(self, input_ctx, t, _borrowed=None):
+    def __init__(self, input_ctx, t, _borrowed=None, word_bits=64):
         self._owned = _borrowed is None
         self.input_ctx = input_ctx
         self.t = t
@@ -456,7 +458,7 @@ class RnsTool:
             self.h = ctypes.c_void_p(_borrowed)
         else:
             h = ctypes.c_void_p()
-            _check(lib().orc_rns_tool_create(input_ctx.h, t, ctypes.byref(h)))
+            _check(lib().orc_rns_tool_create_word(input_ctx.h, t, word_bits, ctypes.byref(h)))
             self.h = h
         count = int(lib().orc_rns_tool_bsk_count(self.h))
         out = np.zeros(count, dtype=np.uint64)
@@ -507,11 +509,15 @@ class RnsTool:
 class BfvContext:
     """Mirror of Context<Bfv<UInt64>> (HomomorphicEncryption/Context.swift) + the Bfv ops on the hot path."""
 
-    def __init__(self, degree, plaintext_modulus, coefficient_moduli):
+    def __init__(self, degree, plaintext_modulus, coefficient_moduli, word_bits=64):
+        """word_bits = 32 builds Context<Bfv<UInt32>>: moduli <= 2^30 - 1, gamma = 2^30 - 20405, mTilde = 2^16 and
+        29-bit Bsk primes (ModularArithmetic/Scalar.swift:498-511, RnsTool.swift:30-33)."""
         arr = _u64(list(coefficient_moduli))
         h = ctypes.c_void_p()
-        _check(lib().orc_bfv_context_create(degree, plaintext_modulus, _p(arr), len(arr), ctypes.byref(h)))
+        _check(lib().orc_bfv_context_create_word(degree, plaintext_modulus, _p(arr), len(arr), word_bits,
+                                                 ctypes.byref(h)))
         self.h = h
+        self.word_bits = word_bits
         self.degree = degree
         self.t = plaintext_modulus
         self.coefficient_moduli = [int(x) for x in arr]

@@ -17,6 +17,8 @@ typedef orc_u128 u128;
 #define ORC_MAX_MODULUS ((((uint64_t)1) << 62) - 1) /* MA/Modulus.swift:177-180 */
 #define ORC_MTILDE (((uint64_t)1) << 32)             /* MA/Scalar.swift:523-525 */
 #define ORC_GAMMA ((((uint64_t)1) << 62) - 40797)    /* MA/Scalar.swift:517-519 rnsCorrectionFactor */
+#define ORC_MTILDE32 (((uint64_t)1) << 16)           /* MA/Scalar.swift:508-510 (UInt32) */
+#define ORC_GAMMA32 ((((uint64_t)1) << 30) - 20405)  /* MA/Scalar.swift:502-506 (UInt32) */
 
 /* ------------------------------------------------------------------------------------------------
  * Scalar helpers
@@ -957,6 +959,8 @@ struct orc_rns_tool {
     size_t L;                 /* input moduli count */
     uint64_t* q;              /* [L] */
     uint64_t t;
+    uint64_t gamma, mtilde;   /* T.rnsCorrectionFactor, T.mTilde (MA/Scalar.swift:498-525): 2^62-40797 / 2^32 for
+                               * UInt64, 2^30-20405 / 2^16 for UInt32 */
     orc_modulus t_reduce;
     size_t ext_count;         /* L+2: the prefix of [Bsk..., mTilde] this tool sees (RnsTool.swift:185-186) */
     uint64_t* ext_moduli;     /* [L+2]; rows 0..L are "Bsk", row L+1 is "mTilde" (see SURVEY 4.3 for lower levels) */
@@ -998,7 +1002,7 @@ void orc_rns_tool_destroy(orc_rns_tool* tool) {
 /* RnsTool.swift:132-251.  `bsk_mtilde` is the full [Bsk..., mTilde] list of the shared RnsToolContext
  * (RnsTool.swift:28-45); the tool takes its first L+2 entries (:185-186). */
 static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, const uint64_t* bsk_mtilde,
-                                  size_t bsk_mtilde_count, orc_rns_tool** out) {
+                                  size_t bsk_mtilde_count, int word_bits, orc_rns_tool** out) {
     *out = NULL;
     size_t L = input->count;
     if (L + 2 > bsk_mtilde_count) return ORC_ERR_INVALID_POLY_CONTEXT;
@@ -1016,7 +1020,10 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
     memcpy(tool->ext_moduli, bsk_mtilde, (L + 2) * sizeof(uint64_t));
     const uint64_t* bsk = tool->ext_moduli; /* L+1 entries */
     const uint64_t m_sk = bsk[L];
-    const uint64_t gamma = ORC_GAMMA;
+    const uint64_t gamma = word_bits == 32 ? ORC_GAMMA32 : ORC_GAMMA;
+    const uint64_t mtilde = word_bits == 32 ? ORC_MTILDE32 : ORC_MTILDE;
+    tool->gamma = gamma;
+    tool->mtilde = mtilde;
 
 #define TOOL_FAIL(code)           \
     do {                          \
@@ -1051,12 +1058,12 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
         }
     }
     {
-        orc_modulus m_tilde = modulus_init(ORC_MTILDE);
+        orc_modulus m_tilde = modulus_init(mtilde);
         uint64_t q_mod = q_remainder_n(input->moduli, L, &m_tilde);
         uint64_t inverse;
-        status = orc_inverse_mod(q_mod, ORC_MTILDE, &inverse);
+        status = orc_inverse_mod(q_mod, mtilde, &inverse);
         if (status) TOOL_FAIL(status);
-        tool->neg_inverse_q_mod_mtilde = shoup_init(neg_mod(inverse, ORC_MTILDE), ORC_MTILDE);
+        tool->neg_inverse_q_mod_mtilde = shoup_init(neg_mod(inverse, mtilde), mtilde);
     }
     tool->b_mod_q = (orc_shoup*)malloc(L * sizeof(orc_shoup));
     tool->neg_b_mod_q = (orc_shoup*)malloc(L * sizeof(orc_shoup));
@@ -1073,7 +1080,7 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
         uint64_t q_mod = q_remainder_n(input->moduli, L, &m);
         tool->q_mod_bsk[j] = shoup_init(q_mod, bsk[j]);
         uint64_t inverse;
-        status = orc_inverse_mod(ORC_MTILDE % bsk[j], bsk[j], &inverse);
+        status = orc_inverse_mod(mtilde % bsk[j], bsk[j], &inverse);
         if (status) TOOL_FAIL(status);
         tool->inverse_mtilde_mod_bsk[j] = shoup_init(inverse, bsk[j]);
         status = orc_inverse_mod(q_mod, bsk[j], &inverse);
@@ -1081,7 +1088,7 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
         tool->inverse_q_mod_bsk[j] = shoup_init(inverse, bsk[j]);
     }
     tool->m_tilde_mod_q = (uint64_t*)malloc(L * sizeof(uint64_t));
-    for (size_t i = 0; i < L; ++i) tool->m_tilde_mod_q[i] = reduce_u64(&input->reduce[i], ORC_MTILDE);
+    for (size_t i = 0; i < L; ++i) tool->m_tilde_mod_q[i] = reduce_u64(&input->reduce[i], mtilde);
     {
         uint64_t* qbsk_moduli = (uint64_t*)malloc((2 * L + 1) * sizeof(uint64_t));
         memcpy(qbsk_moduli, input->moduli, L * sizeof(uint64_t));
@@ -1116,18 +1123,19 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
     return ORC_OK;
 }
 
-/* RnsToolContext.init (RnsTool.swift:28-45): Bsk = L+1 NTT-friendly primes of bitWidth-3 = 61 bits, ascending. */
-static int generate_bsk_mtilde(uint64_t degree, size_t L, uint64_t** out, size_t* out_count) {
+/* RnsToolContext.init (RnsTool.swift:28-45): Bsk = L+1 NTT-friendly primes of bitWidth-3 bits (61 for UInt64, 29 for
+ * UInt32), ascending. */
+static int generate_bsk_mtilde(uint64_t degree, size_t L, int word_bits, uint64_t** out, size_t* out_count) {
     int* bits = (int*)malloc((L + 1) * sizeof(int));
-    for (size_t i = 0; i <= L; ++i) bits[i] = 61;
+    for (size_t i = 0; i <= L; ++i) bits[i] = word_bits - 3;
     uint64_t* list = (uint64_t*)malloc((L + 2) * sizeof(uint64_t));
-    int status = orc_generate_primes(bits, (int)(L + 1), 1, degree, 64, list);
+    int status = orc_generate_primes(bits, (int)(L + 1), 1, degree, word_bits, list);
     free(bits);
     if (status) {
         free(list);
         return status;
     }
-    list[L + 1] = ORC_MTILDE;
+    list[L + 1] = word_bits == 32 ? ORC_MTILDE32 : ORC_MTILDE;
     /* bSkMTildeContext = PolyContext(degree, moduli: Bsk + [mTilde]) (RnsTool.swift:36-37) */
     orc_poly_context* check;
     status = orc_poly_context_create(degree, list, L + 2, &check);
@@ -1141,14 +1149,18 @@ static int generate_bsk_mtilde(uint64_t degree, size_t L, uint64_t** out, size_t
     return ORC_OK;
 }
 
-int orc_rns_tool_create(const orc_poly_context* input, uint64_t t, orc_rns_tool** out) {
+int orc_rns_tool_create_word(const orc_poly_context* input, uint64_t t, int word_bits, orc_rns_tool** out) {
+    if (word_bits != 32 && word_bits != 64) return ORC_ERR_INVALID_ARGUMENT;
     uint64_t* list;
     size_t count;
-    int status = generate_bsk_mtilde(input->degree, input->count, &list, &count);
+    int status = generate_bsk_mtilde(input->degree, input->count, word_bits, &list, &count);
     if (status) return status;
-    status = rns_tool_create_shared(input, t, list, count, out);
+    status = rns_tool_create_shared(input, t, list, count, word_bits, out);
     free(list);
     return status;
+}
+int orc_rns_tool_create(const orc_poly_context* input, uint64_t t, orc_rns_tool** out) {
+    return orc_rns_tool_create_word(input, t, 64, out);
 }
 
 size_t orc_rns_tool_bsk_count(const orc_rns_tool* tool) { return tool->L + 1; }
@@ -1173,14 +1185,14 @@ int orc_rns_convert_approximate_bsk_mtilde(const orc_rns_tool* tool, const uint6
 /* RnsTool.swift:339-368 smallMontgomeryReduce */
 int orc_rns_small_montgomery_reduce(const orc_rns_tool* tool, uint64_t* inout) {
     size_t n = (size_t)tool->degree, L = tool->L;
-    const uint64_t m_tilde_div_threshold = ORC_MTILDE >> 1;
+    const uint64_t m_tilde_div_threshold = tool->mtilde >> 1;
     uint64_t* m_tilde_row = inout + (L + 1) * n;
     for (size_t k = 0; k < n; ++k) m_tilde_row[k] = shoup_mul(&tool->neg_inverse_q_mod_mtilde, m_tilde_row[k]);
     for (size_t j = 0; j <= L; ++j) {
         uint64_t bsk = tool->ext_moduli[j];
         for (size_t k = 0; k < n; ++k) {
             uint64_t r = m_tilde_row[k];
-            r = (r < m_tilde_div_threshold) ? r : r + bsk - ORC_MTILDE;
+            r = (r < m_tilde_div_threshold) ? r : r + bsk - tool->mtilde;
             uint64_t x = inout[j * n + k];
             x += shoup_mul_lazy(&tool->q_mod_bsk[j], r);
             inout[j * n + k] = shoup_mul(&tool->inverse_mtilde_mod_bsk[j], x);
@@ -1264,7 +1276,7 @@ int orc_rns_floor_qbsk_to_q(const orc_rns_tool* tool, const uint64_t* in, uint64
 /* RnsTool.swift:272-302 scaleAndRound */
 int orc_rns_scale_and_round(const orc_rns_tool* tool, const uint64_t* in, uint64_t scaling_factor, uint64_t* out) {
     size_t n = (size_t)tool->degree, L = tool->L;
-    const uint64_t t = tool->t, gamma = ORC_GAMMA;
+    const uint64_t t = tool->t, gamma = tool->gamma;
     uint64_t* scaled = (uint64_t*)malloc(L * n * sizeof(uint64_t));
     uint64_t* t_gamma = (uint64_t*)malloc(2 * n * sizeof(uint64_t));
     for (size_t i = 0; i < L; ++i) {
@@ -1320,7 +1332,18 @@ void orc_bfv_context_destroy(orc_bfv_context* ctx) {
 }
 
 int orc_bfv_context_create(uint64_t degree, uint64_t t, const uint64_t* q, size_t count, orc_bfv_context** out) {
+    return orc_bfv_context_create_word(degree, t, q, count, 64, out);
+}
+
+/* Context<Bfv<T>>.init for T = UInt64 (word_bits 64) or UInt32 (word_bits 32): the word type fixes the largest
+ * modulus (2^62-1 / 2^30-1), gamma, mTilde and the Bsk prime size (MA/Scalar.swift:498-525, RnsTool.swift:30-33). */
+int orc_bfv_context_create_word(uint64_t degree, uint64_t t, const uint64_t* q, size_t count, int word_bits,
+                                orc_bfv_context** out) {
     *out = NULL;
+    if (word_bits != 32 && word_bits != 64) return ORC_ERR_INVALID_ARGUMENT;
+    const uint64_t max_modulus = word_bits == 32 ? ((((uint64_t)1) << 30) - 1) : ORC_MAX_MODULUS;
+    const uint64_t gamma = word_bits == 32 ? ORC_GAMMA32 : ORC_GAMMA;
+    const uint64_t mtilde = word_bits == 32 ? ORC_MTILDE32 : ORC_MTILDE;
     /* EncryptionParameters.init checks (securityLevel: .unchecked), HE/EncryptionParameters.swift:136-166 */
     if (!is_power_of_two(degree)) return ORC_ERR_INVALID_ENCRYPTION_PARAMETERS;
     if (count == 0 || count > 32) return ORC_ERR_INVALID_ENCRYPTION_PARAMETERS;
@@ -1328,7 +1351,7 @@ int orc_bfv_context_create(uint64_t degree, uint64_t t, const uint64_t* q, size_
         if (!(q[i] > t) || !is_ntt_modulus(q[i], degree)) return ORC_ERR_INVALID_ENCRYPTION_PARAMETERS;
     for (size_t i = 0; i <= count; ++i) {
         uint64_t m = i < count ? q[i] : t;
-        if (!orc_is_prime(m) || m < 1 || m > ORC_MAX_MODULUS || m == ORC_GAMMA || m == ORC_MTILDE)
+        if (!orc_is_prime(m) || m < 1 || m > max_modulus || m == gamma || m == mtilde)
             return ORC_ERR_INVALID_ENCRYPTION_PARAMETERS;
     }
     int status;
@@ -1359,7 +1382,8 @@ int orc_bfv_context_create(uint64_t degree, uint64_t t, const uint64_t* q, size_
             status = orc_poly_context_create(degree, moduli, k + 1, &ctx->key_switching[k]);
             /* HE/Context.swift:122-124 */
             if (!status &&
-                !((uint64_t)(k + 1) < orc_poly_context_max_lazy_product_accumulation_count(ctx->key_switching[k], 64)))
+                !((uint64_t)(k + 1) <
+                  orc_poly_context_max_lazy_product_accumulation_count(ctx->key_switching[k], word_bits)))
                 status = ORC_ERR_INVALID_ENCRYPTION_PARAMETERS;
         }
         free(moduli);
@@ -1372,9 +1396,10 @@ int orc_bfv_context_create(uint64_t degree, uint64_t t, const uint64_t* q, size_
     if (!status) {
         uint64_t* bsk_mtilde;
         size_t bsk_mtilde_count;
-        status = generate_bsk_mtilde(degree, L, &bsk_mtilde, &bsk_mtilde_count); /* HE/Context.swift:133-135 */
+        status = generate_bsk_mtilde(degree, L, word_bits, &bsk_mtilde, &bsk_mtilde_count); /* HE/Context.swift:133-135 */
         for (size_t k = L; k >= 1 && !status; --k) /* HE/Context.swift:136-141 */
-            status = rns_tool_create_shared(ctx->ciphertext[k], t, bsk_mtilde, bsk_mtilde_count, &ctx->tools[k]);
+            status = rns_tool_create_shared(ctx->ciphertext[k], t, bsk_mtilde, bsk_mtilde_count, word_bits,
+                                            &ctx->tools[k]);
         if (bsk_mtilde_count) free(bsk_mtilde);
     }
     if (status) {

@@ -105,6 +105,8 @@ int orc_poly_reduce_accumulator(const orc_poly_context* ctx, const uint64_t* acc
 typedef struct orc_rns_tool orc_rns_tool;
 /* Standalone tool, as `_RnsTool(from:to:)` (RnsTool.swift:254-261): Bsk generated for this input context. */
 int orc_rns_tool_create(const orc_poly_context* input, uint64_t t, orc_rns_tool** out);
+/* the same for T = UInt32 (word_bits 32: gamma 2^30-20405, mTilde 2^16, 29-bit Bsk) or UInt64 (word_bits 64) */
+int orc_rns_tool_create_word(const orc_poly_context* input, uint64_t t, int word_bits, orc_rns_tool** out);
 void orc_rns_tool_destroy(orc_rns_tool* tool);
 size_t orc_rns_tool_bsk_count(const orc_rns_tool* tool);
 void orc_rns_tool_bsk_moduli(const orc_rns_tool* tool, uint64_t* out);
@@ -130,6 +132,8 @@ int orc_rns_scale_and_round(const orc_rns_tool* tool, const uint64_t* in, uint64
 typedef struct orc_bfv_context orc_bfv_context;
 int orc_bfv_context_create(uint64_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
                            size_t moduli_count, orc_bfv_context** out);
+int orc_bfv_context_create_word(uint64_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                                size_t moduli_count, int word_bits, orc_bfv_context** out);
 void orc_bfv_context_destroy(orc_bfv_context* ctx);
 size_t orc_bfv_ciphertext_moduli_count(const orc_bfv_context* ctx); /* L at top level */
 const orc_poly_context* orc_bfv_ciphertext_context(const orc_bfv_context* ctx, size_t moduli_count);

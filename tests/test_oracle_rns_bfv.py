@@ -355,3 +355,36 @@ def test_pir_expand_produces_encrypted_selection_bits(oracle, small_bfv, total, 
     for index in range(total):
         want = [1 if index in ones else 0] + [0] * (n - 1)
         assert client.decrypt(expanded[index]) == want, index
+
+
+@pytest.fixture(scope="module")
+def small_bfv32(oracle):
+    """Context<Bfv<UInt32>>-shaped parameters: 27-28-bit moduli as in n_4096_logq_27_28_28
+    (EncryptionParameters.swift:313-378), scaled down to N = 64."""
+    degree = 64
+    t = oracle.generate_primes([10], True, degree, word_bits=32)[0]
+    q = oracle.generate_primes([27, 28, 28, 29], False, degree, word_bits=32)
+    ctx = oracle.BfvContext(degree, t, q, word_bits=32)
+    return ctx, BfvClient(oracle, ctx, seed=33)
+
+
+def test_bfv_uint32_constants_and_decrypt(oracle, small_bfv32):
+    """The UInt32 word type changes the BEHZ constants (gamma 2^30-20405, mTilde 2^16, 29-bit Bsk); the same
+    semantic checks must hold (HeAPITests run every test for Bfv<UInt32> and Bfv<UInt64>)."""
+    ctx, client = small_bfv32
+    bsk = ctx.rns_tool().bsk
+    assert len(bsk) == ctx.L + 1 and all((1 << 28) < b < (1 << 29) for b in bsk) and bsk == sorted(bsk)
+    rng = random.Random(34)
+    m1 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    m2 = [rng.randrange(ctx.t) for _ in range(ctx.degree)]
+    ct1, ct2 = client.encrypt(m1), client.encrypt(m2)
+    assert client.decrypt(ct1) == m1 and client.decrypt_exact(ct1) == m1
+    product = ctx.mul(ct1[None], ct2[None])
+    expected = negacyclic_multiply(m1, m2, ctx.t)
+    assert client.decrypt(product[0]) == expected
+    relin = ctx.relinearize(product, client.relinearization_key())
+    assert client.decrypt(relin[0]) == expected and client.decrypt_exact(relin[0]) == expected
+    lower = ctx.mod_switch_down(relin, poly_count=2)
+    assert client.decrypt(lower[0], moduli_count=ctx.L - 1) == expected
+    with pytest.raises(oracle.OracleError):  # a 31-bit modulus does not fit UInt32's Modulus (max 2^30 - 1)
+        oracle.BfvContext(ctx.degree, ctx.t, oracle.generate_primes([31, 31], False, ctx.degree), word_bits=32)
