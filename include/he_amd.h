@@ -243,6 +243,14 @@ int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count
                                 size_t workspace_bytes, he_stream s);
 size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count);
 
+/* Context<Bfv<UInt32>> (scheme layer): the word type fixes the largest modulus (2^30 - 1), gamma =
+ * 2^30 - 20405, mTilde = 2^16 and the 29-bit Bsk primes (ModularArithmetic/Scalar.swift:498-511,
+ * RnsTool.swift:30-33).  The handle works with every he_bfv_* / he_rns_* / he_pir_* entry point above and below;
+ * slabs stay 8-byte words holding the zero-extended UInt32 values, so results equal the reference's Bfv<UInt32>
+ * words exactly.  (Packed 4-byte storage exists for the polynomial layer only: he_*_device_u32.) */
+int he_bfv_context_create_u32(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                              uint32_t moduli_count, he_bfv_context** out);
+
 /* ---- "next" rows of the scope table ---- */
 /* Bfv.applyGalois(ciphertext:element:using:) (Bfv/Bfv.swift:174-198): ct [batch][2][L][N] Coeff,
  * galois_key = EvaluationKey.galoisKey.keys[element] in the relinearization key's layout

@@ -25,11 +25,12 @@ struct he_bfv_context {
 
 namespace {
 
-int bfv_create(uint32_t degree, uint64_t t, const uint64_t* q, uint32_t count, bool host_only, he_bfv_context** out) {
+int bfv_create(uint32_t degree, uint64_t t, const uint64_t* q, uint32_t count, bool host_only, he_bfv_context** out,
+               int word_bits = 64) {
     if (out == nullptr) return invalid_argument("null out");
     *out = nullptr;
     std::unique_ptr<BfvContext> impl;
-    const int status = BfvContext::create(degree, t, q, count, impl, host_only);
+    const int status = BfvContext::create(degree, t, q, count, impl, host_only, word_bits);
     if (status != HE_OK) {
         if (status != HE_ERR_DEVICE) heamd::set_last_error(std::string("Context.init: ") + he_status_string(status));
         return status;
@@ -103,6 +104,10 @@ int he_bfv_context_create(uint32_t degree, uint64_t plaintext_modulus, const uin
 int he_bfv_context_create_host_only(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
                                     uint32_t moduli_count, he_bfv_context** out) {
     return bfv_create(degree, plaintext_modulus, coefficient_moduli, moduli_count, true, out);
+}
+int he_bfv_context_create_u32(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
+                              uint32_t moduli_count, he_bfv_context** out) {
+    return bfv_create(degree, plaintext_modulus, coefficient_moduli, moduli_count, false, out, 32);
 }
 void he_bfv_context_destroy(he_bfv_context* ctx) { delete ctx; }
 uint32_t he_bfv_ciphertext_moduli_count(const he_bfv_context* ctx) { return ctx ? ctx->impl->top_level() : 0; }

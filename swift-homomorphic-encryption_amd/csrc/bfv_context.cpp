@@ -72,9 +72,13 @@ BfvContext::~BfvContext() {
 }
 
 int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std::unique_ptr<BfvContext>& out,
-                       bool host_only) {
+                       bool host_only, int word_bits) {
     out.reset();
     if (count > 0 && q == nullptr) return HE_ERR_INVALID_ARGUMENT;
+    if (word_bits != 32 && word_bits != 64) return HE_ERR_INVALID_ARGUMENT;
+    const u64 max_modulus = word_bits == 32 ? ((static_cast<u64>(1) << 30) - 1) : kMaxModulus;
+    const u64 gamma = word_bits == 32 ? ((static_cast<u64>(1) << 30) - 20405) : kGamma;   // MA/Scalar.swift:502-519
+    const u64 mtilde = word_bits == 32 ? (static_cast<u64>(1) << 16) : kMTilde;           // MA/Scalar.swift:508-525
     // EncryptionParameters.init at securityLevel .unchecked (EncryptionParameters.swift:136-166)
     if (!is_power_of_two(degree)) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
     if (count == 0 || count > 32) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
@@ -82,7 +86,7 @@ int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std
         if (!(q[i] > t) || !is_ntt_modulus(q[i], degree)) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
     for (uint32_t i = 0; i <= count; ++i) {
         const u64 m = i < count ? q[i] : t;
-        if (!is_prime(m) || m < 1 || m > kMaxModulus || m == kGamma || m == kMTilde)
+        if (!is_prime(m) || m < 1 || m > max_modulus || m == gamma || m == mtilde)
             return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;
     }
     // Context.init (Context.swift:94-143)
@@ -94,6 +98,9 @@ int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std
     std::unique_ptr<BfvContext> ctx(new BfvContext());
     ctx->degree_ = degree;
     ctx->t_ = t;
+    ctx->gamma_ = gamma;
+    ctx->mtilde_ = mtilde;
+    ctx->word_bits_ = word_bits;
     ctx->host_only_ = host_only;
     ctx->coefficient_moduli_.assign(q, q + count);
     ctx->has_ks_ = count > 1;
@@ -113,8 +120,14 @@ int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std
             moduli[k] = q[count - 1];
             const int status = PolyContext::create(degree, moduli.data(), k + 1, ctx->key_switching_[k], host_only);
             if (status != HE_OK) return status;
-            if (!(static_cast<u64>(k + 1) < ctx->key_switching_[k]->max_lazy_product_accumulation_count(k + 1)))
-                return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;  // Context.swift:122-124
+            u64 max_lazy = ctx->key_switching_[k]->max_lazy_product_accumulation_count(k + 1);
+            if (word_bits == 32) {  // T.DoubleWidth = UInt64 (PolyContext.swift:246-253)
+                u64 q_max = 0;
+                for (uint32_t i = 0; i <= k; ++i) q_max = moduli[i] > q_max ? moduli[i] : q_max;
+                const u64 square = (q_max - 1) * (q_max - 1);
+                max_lazy = square == 0 ? static_cast<u64>(INT32_MAX) : (~static_cast<u64>(0) - q_max) / square;
+            }
+            if (!(static_cast<u64>(k + 1) < max_lazy)) return HE_ERR_INVALID_ENCRYPTION_PARAMETERS;  // Context.swift:122-124
         }
     }
     {   // plaintextContext (Context.swift:128-130)
@@ -123,15 +136,15 @@ int BfvContext::create(uint32_t degree, u64 t, const u64* q, uint32_t count, std
         if (status != HE_OK) return status;
     }
     {   // RnsToolContext.init (RnsTool.swift:28-45): L+1 ascending NTT-friendly 61-bit primes, then mTilde
-        std::vector<int> bits(L + 1, 61);
+        std::vector<int> bits(L + 1, word_bits - 3);  // T.bitWidth - 3 (RnsTool.swift:30-33)
         if (!generate_primes(bits, true, degree, ctx->bsk_mtilde_)) return HE_ERR_NOT_ENOUGH_PRIMES;
-        ctx->bsk_mtilde_.push_back(kMTilde);
+        ctx->bsk_mtilde_.push_back(mtilde);
         std::unique_ptr<PolyContext> check;
         const int status = PolyContext::create(degree, ctx->bsk_mtilde_.data(),
                                                static_cast<uint32_t>(ctx->bsk_mtilde_.size()), check, true);
         if (status != HE_OK) return status;
         // tGammaContext = [t, gamma] (RnsTool.swift:62-64) only needs to be constructible here
-        const u64 t_gamma[2] = {t, kGamma};
+        const u64 t_gamma[2] = {t, gamma};
         const int tg = PolyContext::create(degree, t_gamma, 2, check, true);
         if (tg != HE_OK) return tg;
     }
@@ -195,7 +208,7 @@ int BfvContext::build_tool(uint32_t k) {
         arena.at<U64x2>(o_inv_punct_q)[i] = shoup_pair(inverse, q[i]);
         // poly * mTildeModQ then convertApproximateProducts (RnsTool.swift:313-316, RnsBaseConverter.swift:97-106):
         // two exact multiplications mod q_i == one by the product of the constants
-        arena.at<U64x2>(o_lift_scale)[i] = shoup_pair(mul_mod(kMTilde % q[i], inverse, q[i]), q[i]);
+        arena.at<U64x2>(o_lift_scale)[i] = shoup_pair(mul_mod(mtilde_ % q[i], inverse, q[i]), q[i]);
         for (size_t j = 0; j < L + 2; ++j)
             arena.at<u64>(o_q_to_ext)[j * L + i] = punctured_product(q, L, i, ext[j]);
     }
@@ -203,7 +216,7 @@ int BfvContext::build_tool(uint32_t k) {
         const u64 q_mod = product_mod(q, L, bsk[j]);
         arena.at<U64x2>(o_q_mod_bsk)[j] = shoup_pair(q_mod, bsk[j]);
         u64 inverse = 0;
-        if (!inverse_mod(kMTilde % bsk[j], bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        if (!inverse_mod(mtilde_ % bsk[j], bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
         arena.at<U64x2>(o_inv_mtilde)[j] = shoup_pair(inverse, bsk[j]);
         if (!inverse_mod(q_mod, bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
         arena.at<U64x2>(o_inv_q_bsk)[j] = shoup_pair(inverse, bsk[j]);
@@ -222,8 +235,8 @@ int BfvContext::build_tool(uint32_t k) {
     U64x2 neg_inv_q_mod_mtilde{}, inv_b_mod_msk{};
     {
         u64 inverse = 0;
-        if (!inverse_mod(product_mod(q, L, kMTilde), kMTilde, inverse)) return HE_ERR_NOT_INVERTIBLE;
-        neg_inv_q_mod_mtilde = shoup_pair(neg_mod(inverse, kMTilde), kMTilde);
+        if (!inverse_mod(product_mod(q, L, mtilde_), mtilde_, inverse)) return HE_ERR_NOT_INVERTIBLE;
+        neg_inv_q_mod_mtilde = shoup_pair(neg_mod(inverse, mtilde_), mtilde_);
         if (!inverse_mod(product_mod(bsk, L, m_sk), m_sk, inverse)) return HE_ERR_NOT_INVERTIBLE;
         inv_b_mod_msk = shoup_pair(inverse, m_sk);
     }
@@ -240,9 +253,9 @@ int BfvContext::build_tool(uint32_t k) {
     }
 
     // scaleAndRound tables (RnsTool.swift:145-169): [t, gamma] is the output base of rnsConvertQToTGamma
-    const u64 t_gamma[2] = {t_, kGamma};
+    const u64 t_gamma[2] = {t_, gamma_};
     u64 inv_gamma_mod_t = 0;
-    if (!inverse_mod(kGamma % t_, t_, inv_gamma_mod_t)) return HE_ERR_NOT_INVERTIBLE;
+    if (!inverse_mod(gamma_ % t_, t_, inv_gamma_mod_t)) return HE_ERR_NOT_INVERTIBLE;
     for (size_t j = 0; j < 2; ++j) {
         arena.at<DeviceModulus>(o_tg_moduli)[j] = barrett_constants(t_gamma[j]);
         u64 inverse = 0;
@@ -251,7 +264,7 @@ int BfvContext::build_tool(uint32_t k) {
         for (size_t i = 0; i < L; ++i) arena.at<u64>(o_q_to_tg)[j * L + i] = punctured_product(q, L, i, t_gamma[j]);
     }
     for (size_t i = 0; i < L; ++i) {
-        const u64 gamma_t = mul_mod(kGamma % q[i], t_ % q[i], q[i]);
+        const u64 gamma_t = mul_mod(gamma_ % q[i], t_ % q[i], q[i]);
         // poly *= prodGammaTModQ, then the converter's (Q/q_i)^-1: two exact products mod q_i = one
         arena.at<U64x2>(o_sr_scale)[i] = shoup_pair(mul_mod(gamma_t, arena.at<U64x2>(o_inv_punct_q)[i].x, q[i]), q[i]);
     }
@@ -259,6 +272,7 @@ int BfvContext::build_tool(uint32_t k) {
     RnsToolDevice& d = level.device;
     d.L = static_cast<uint32_t>(L);
     d.inv_gamma_mod_t = inv_gamma_mod_t;
+    d.mtilde = mtilde_;
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
     d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;
     d.inv_b_mod_msk = inv_b_mod_msk;

@@ -35,6 +35,7 @@ struct RnsToolDevice {
     const DeviceModulus* t_gamma;      // [2]     Barrett constants of t and gamma
     const U64x2* neg_inv_q_mod_t_gamma;// [2]     -(Q^-1) mod t, mod gamma                          RnsTool.swift:157-160
     uint64_t inv_gamma_mod_t;          //         gamma^-1 mod t                                    RnsTool.swift:150-153
+    uint64_t mtilde;                   //         T.mTilde: 2^32 (UInt64) or 2^16 (UInt32)          MA/Scalar.swift:508-525
     U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169
     U64x2 inv_b_mod_msk;               //         B^-1 mod m_sk                           RnsTool.swift:246-250
 };
@@ -49,8 +50,10 @@ struct RnsToolLevel {
 
 class BfvContext {
   public:
+    // word_bits = 64: Context<Bfv<UInt64>>; 32: Context<Bfv<UInt32>> (moduli <= 2^30 - 1, gamma = 2^30 - 20405,
+    // mTilde = 2^16, 29-bit Bsk primes; MA/Scalar.swift:498-511, RnsTool.swift:30-33) on the same 8-byte words
     static int create(uint32_t degree, u64 plaintext_modulus, const u64* coefficient_moduli, uint32_t count,
-                      std::unique_ptr<BfvContext>& out, bool host_only);
+                      std::unique_ptr<BfvContext>& out, bool host_only, int word_bits = 64);
     ~BfvContext();
 
     uint32_t degree() const { return degree_; }
@@ -71,6 +74,8 @@ class BfvContext {
 
     uint32_t degree_ = 0, L_ = 0;
     u64 t_ = 0;
+    u64 gamma_ = kGamma, mtilde_ = kMTilde;
+    int word_bits_ = 64;
     bool has_ks_ = false, host_only_ = false;
     std::vector<u64> coefficient_moduli_;
     std::vector<u64> bsk_mtilde_;  // Bsk_0..Bsk_L, mTilde  (RnsTool.swift:28-37)

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
-    constexpr uint64_t kMTildeValue = uint64_t(1) << 32;
+    const uint64_t kMTildeValue = tool.mtilde;  // 2^32 (UInt64 contexts) or 2^16 (UInt32 contexts)
     // one coefficient per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
     // spills SGPRs into VGPR lanes
     for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(kThreads)
         // the (L+2)'th extended modulus is mTilde = 2^32 at the top level; a lower-level tool takes a prefix of
         // [Bsk..., mTilde] and finds a Bsk prime there (the reference's own behaviour, reproduced as is)
         const DeviceModulus last = tool.ext_moduli[L + 1];
-        uint64_t r = last.p == kMTildeValue ? lo32(product_sum_value(acc).lo) : reduce_product_sum(acc, last);
+        uint64_t r = last.p == kMTildeValue ? (product_sum_value(acc).lo & (kMTildeValue - 1))
+                                            : reduce_product_sum(acc, last);
         r = shoup_mul_pair(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
         const bool below = r < (kMTildeValue >> 1);
 #pragma unroll

@@ -81,6 +81,7 @@ SIGNATURES = [
     ("he_poly_deserialize_device", ctypes.c_int, [vp, vp, c_size, c_size, ctypes.c_int, vp, vp]),
     ("he_poly_multiply_power_of_x_device", ctypes.c_int, [vp, vp, vp, c_size, ctypes.c_int64, vp]),
     ("he_bfv_context_create", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
+    ("he_bfv_context_create_u32", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_bfv_context_destroy", None, [vp]),
     ("he_bfv_ciphertext_moduli_count", c_u32, [vp]),
     ("he_bfv_ciphertext_context", vp, [vp, c_u32]),
@@ -442,11 +443,14 @@ class PolyContext:
 class BfvContext:
     """Context<Bfv<UInt64>> (reference Context.swift:94-159) plus the Bfv operations on the hot path."""
 
-    def __init__(self, degree, plaintext_modulus, coefficient_moduli, host_only=False):
+    def __init__(self, degree, plaintext_modulus, coefficient_moduli, host_only=False, word_bits=64):
+        """word_bits=32: Context<Bfv<UInt32>> constants on 8-byte words (he_bfv_context_create_u32)."""
         lib = load_library()
         arr = _u64(list(coefficient_moduli))
         h = vp()
         create = lib.he_bfv_context_create_host_only if host_only else lib.he_bfv_context_create
+        if word_bits == 32:
+            create = lib.he_bfv_context_create_u32
         _check(create(degree, plaintext_modulus, arr.ctypes.data_as(U64P), len(arr), ctypes.byref(h)))
         self.h = h
         self.degree = degree

@@ -215,3 +215,40 @@ def test_single_modulus_context(oracle):
     with pytest.raises(heamd.HeError) as err:
         ours.relinearize(heamd.to_device(got), heamd.to_device(np.zeros((1, 2, 2, degree), dtype=np.uint64)))
     assert err.value.name == "missingRelinearizationKey"
+
+
+def test_bfv_uint32_context_matches_oracle(oracle):
+    """Context<Bfv<UInt32>>: gamma = 2^30 - 20405, mTilde = 2^16, 29-bit Bsk primes; every scheme
+    operation word-exact against the oracle built with the same word type, plus the decrypt checks."""
+    degree = 64
+    t = oracle.generate_primes([10], True, degree, word_bits=32)[0]
+    q = oracle.generate_primes([27, 28, 28, 29], False, degree, word_bits=32)
+    ours = heamd.BfvContext(degree, t, q, word_bits=32)
+    ref = oracle.BfvContext(degree, t, q, word_bits=32)
+    client = BfvClient(oracle, ref, seed=97)
+    assert ours.bsk_moduli() == ref.rns_tool().bsk and all(b < (1 << 29) for b in ours.bsk_moduli())
+    rng = np.random.default_rng(98)
+    moduli = q[:-1]
+    for level in (ours.L, ours.L - 1):
+        x = _uniform(rng, (4,), moduli[:level], degree)
+        tool = ref.rns_tool(level)
+        lifted = heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x), level))
+        assert np.array_equal(lifted, np.stack([tool.lift_q_to_qbsk(p) for p in x]))
+        y = _uniform(rng, (4,), ref.qbsk_context(level).moduli, degree)
+        floored = heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y), level))
+        assert np.array_equal(floored, np.stack([tool.floor_qbsk_to_q(p) for p in y]))
+        assert np.array_equal(heamd.to_host(ours.scale_and_round(heamd.to_device(x), 1, moduli_count=level)),
+                              np.stack([tool.scale_and_round(p, 1) for p in x]))
+    r = random.Random(99)
+    m1 = [r.randrange(t) for _ in range(degree)]
+    m2 = [r.randrange(t) for _ in range(degree)]
+    ct1, ct2 = client.encrypt(m1)[None], client.encrypt(m2)[None]
+    product = heamd.to_host(ours.mul(heamd.to_device(ct1), heamd.to_device(ct2)))
+    assert np.array_equal(product, ref.mul(ct1, ct2))
+    key = client.relinearization_key()
+    relin = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key)))
+    assert np.array_equal(relin, ref.relinearize(product, key))
+    assert client.decrypt(relin[0]) == negacyclic_multiply(m1, m2, t)
+    with pytest.raises(heamd.HeError) as err:
+        heamd.BfvContext(degree, t, oracle.generate_primes([31, 31], False, degree), word_bits=32)
+    assert err.value.name == "invalidEncryptionParameters"
