@@ -183,6 +183,20 @@ int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const ui
 }
 
 // ------------------------------------------------------------------------------------------ relinearize
+namespace {
+// Bfv+Keys.swift:165-179: decompose the target over q_0..q_{L-1}, lift each piece to every key-switching modulus
+// and take it to Eval.  One fused kernel where the degree has a tiled NTT, two launches otherwise.
+hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t* spread, const DeviceContext& ks,
+                          uint32_t L, size_t polys, hipStream_t stream) {
+    hipError_t e = heamd::launch_ntt_spread(target, target_stride, L, polys, spread, ks, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
+    if (e != hipSuccess) return e;
+    return heamd::launch_ntt(false, spread, ks, 0, L + 1, polys * L * (L + 1), stream);
+}
+}  // namespace
+
 size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
     if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
     const size_t L = moduli_count, n = ctx->impl->degree();
@@ -215,8 +229,7 @@ int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, 
     uint64_t* prod = ws + batch * L * (L + 1) * n;      // [batch][2][L+1][N]
     const size_t ct_stride = 3 * size_t(L) * n;
     // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on poly 2 of every ciphertext
-    HEAMD_HIP_TRY(heamd::launch_key_switch_spread(ct3 + 2 * size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_ntt(false, spread, ks, 0, L + 1, batch * L * (L + 1), stream));
+    HEAMD_HIP_TRY(spread_to_eval(ct3 + 2 * size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, 2, stream));
@@ -273,8 +286,7 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
     // Bfv.swift:190-196: c0' = galois(c0) + update0, c1' = update1, update = keySwitch(galois(c1))
     HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
                                              inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_spread(rotated + size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_ntt(false, spread, ks, 0, L + 1, batch * L * (L + 1), stream));
+    HEAMD_HIP_TRY(spread_to_eval(rotated + size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, galois_key, prod, ks, L, ctx->impl->top_level() + 1, batch,
                                                stream));
     HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));

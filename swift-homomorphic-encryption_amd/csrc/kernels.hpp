@@ -32,6 +32,12 @@ hipError_t launch_ntt_pipelined(bool inverse, bool approx, int flags, uint64_t* 
 // NTT of `rows` contiguous length-N rows.  Row r uses modulus index mod_base + (r % mod_period).
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                       size_t rows, hipStream_t stream, int force_variant = kNttVariantAuto);
+// Key-switching decomposition fused into the forward NTT (Bfv+Keys.swift:165-179): spread [polys][L][L+1][N] row
+// (poly, j, r) = NTT_{ks modulus r}( source row j of polynomial `poly`, reduced mod r when q_j > modulus r ), read
+// from source + poly * poly_stride + j * N.  hipErrorNotSupported for degrees without a tiled kernel (the caller
+// then runs launch_key_switch_spread + launch_ntt).
+hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
+                             uint64_t* spread, const DeviceContext& ks_ctx, hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
 // measurement hook: variant 32 of the forward N=8192 kernel stamps phase boundaries into this buffer (16 words/row)
 hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer);

@@ -43,9 +43,20 @@ __device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
     }
 }
 
-template <int LOGN, int LOGT, int MODE, int ABLATE = 0>
+// SPREAD: the key-switching decomposition fused into the load (Bfv+Keys.swift:165-179): output row
+// (poly, j, r) of a [polys][L][L+1][N] slab is the transform mod ks_modulus[r] of row j of polynomial `poly`,
+// read straight from the ciphertext (and reduced mod r first when q_j > modulus r) instead of from a copy that a
+// separate kernel would have to write and this one read back.
+struct SpreadSource {
+    const uint64_t* base;  // row j of polynomial `poly` at base + poly * stride + j * N
+    size_t stride;
+    uint32_t L;
+};
+
+template <int LOGN, int LOGT, int MODE, int ABLATE = 0, bool SPREAD = false>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
-    ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
+    ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
+                      const SpreadSource spread) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
@@ -80,6 +91,14 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         if constexpr (ABLATE & (4 | 32)) {  // bit 5: skip the load only
 #pragma unroll
             for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
+        } else if constexpr (SPREAD) {
+            const size_t group = row / mod_period;  // poly * L + j
+            const size_t poly = group / spread.L, j = group - poly * spread.L;
+            global_load<LOGN, LOGE, LO0, LOGE>(v, tid, spread.base + poly * spread.stride + (j << LOGN));
+            if (ctx.moduli[j].p > p) {  // uniform: the source row is canonical mod q_j, not mod this row's modulus
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = barrett_reduce64_uniform(v[r], p, mod.barrett64);
+            }
         } else {
             global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
         }
@@ -274,29 +293,42 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+template <typename Kernel>
+hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
+    if (lds_bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds_bytes));
+}
+
+template <int LOGN, int LOGT, bool SPREAD>
+hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+                                uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream) {
+    constexpr int LOGE = LOGN - LOGT;
+    constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
+    auto kernel = mode == kModeHeadroomHalved ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroomHalved, 0, SPREAD>
+                  : mode == kModeHeadroom     ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom, 0, SPREAD>
+                  : mode == kModeApprox       ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, 0, SPREAD>
+                                              : ntt_forward_tiled<LOGN, LOGT, kModeExact, 0, SPREAD>;
+    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
+                       mod_base, mod_period, spread);
+    return hipGetLastError();
+}
+
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream) {
+    if (!inverse) {
+        return launch_forward_tiled<LOGN, LOGT, false>(mode, slab, ctx, mod_base, mod_period, rows,
+                                                       SpreadSource{nullptr, 0, 0}, stream);
+    }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t);
-    Kernel kernel;
-    if (inverse) {
-        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
-                 : mode == kModeHeadroom ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
-                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
-                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
-    } else {
-        kernel = mode == kModeHeadroomHalved ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroomHalved>
-                 : mode == kModeHeadroom ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom>
-                 : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox>
-                                       : ntt_forward_tiled<LOGN, LOGT, kModeExact>;
-    }
-    if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-        if (e != hipSuccess) return e;
-    }
+    auto kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
+                  : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
+                  : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
+                                              : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
+    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
                        mod_base, mod_period);
     return hipGetLastError();
@@ -313,11 +345,34 @@ hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1024), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period);
+                       mod_period, SpreadSource{nullptr, 0, 0});
     return hipGetLastError();
 }
 
+// the production butterfly schedule for a context (what kNttVariantAuto picks)
+int production_mode(const DeviceContext& ctx) {
+    if (ctx.approx_ok == 0) return kModeExact;
+    if (ctx.headroom_ok == 0) return kModeApprox;
+    return ctx.forward_twiddles_half != nullptr ? kModeHeadroomHalved : kModeHeadroom;
+}
+
 }  // namespace
+
+hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
+                             uint64_t* spread, const DeviceContext& ks_ctx, hipStream_t stream) {
+    const uint32_t period = source_moduli + 1;
+    const size_t rows = polys * source_moduli * period;
+    if (rows == 0) return hipSuccess;
+    if (rows > (size_t(1) << 30) || ks_ctx.moduli_count < period) return hipErrorInvalidValue;
+    const SpreadSource src{source, poly_stride, source_moduli};
+    const int mode = production_mode(ks_ctx);
+    switch (ks_ctx.log_degree) {
+        case 12: return launch_forward_tiled<12, 9, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        case 13: return launch_forward_tiled<13, 10, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        case 14: return launch_forward_tiled<14, 10, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        default: return hipErrorNotSupported;  // caller falls back to spread kernel + launch_ntt
+    }
+}
 
 hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_timeline), &device_buffer, sizeof(device_buffer));
