@@ -5,7 +5,9 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB_PATH = os.path.join(_PKG, "lib", "libhe_amd.so")
+# HEAMD_LIBRARY points at another build of the same ABI (a deployment's install path, or an A/B kernel experiment:
+# bench_tools/ab_variants.py)
+_LIB_PATH = os.environ.get("HEAMD_LIBRARY") or os.path.join(_PKG, "lib", "libhe_amd.so")
 
 U64P = ctypes.POINTER(ctypes.c_uint64)
 vp = ctypes.c_void_p
