@@ -349,6 +349,17 @@ hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mo
     return hipGetLastError();
 }
 
+uint32_t compute_unit_count() {
+    static const uint32_t count = [] {
+        int device = 0, units = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || units <= 0)
+            return 256u;
+        return static_cast<uint32_t>(units);
+    }();
+    return count;
+}
+
 // the production butterfly schedule for a context (what kNttVariantAuto picks)
 int production_mode(const DeviceContext& ctx) {
     if (ctx.approx_ok == 0) return kModeExact;
@@ -402,6 +413,10 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
+    }
+    if (force_variant == kNttVariantStream) {
+        if (inverse || !ntt_stream_supports(ctx)) return hipErrorNotSupported;
+        return launch_ntt_forward_stream(slab, ctx, mod_base, mod_period, rows, 2 * compute_unit_count(), stream);
     }
     if (force_variant >= kNttVariantAblateBase && ctx.log_degree == 13 && !inverse) {
         switch (force_variant - kNttVariantAblateBase) {  // measurement-only kernels: results are NOT an NTT
