@@ -115,137 +115,121 @@ __device__ __forceinline__ uint64_t shoup_lazy(uint64_t x, uint64_t w, uint64_t 
     x = opaque(x);
     return mullo64_sum2(x, w, opaque(mulhi64(x, wf)), neg_p);
 }
-__device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
-    // straight-line form: the 65-bit cross column a0 b1 + a1 b0 keeps its carry-out in an SGPR pair and re-enters as
-    // bit 32 of the quotient estimate (q low by <= 2 -> result < 3p)
-    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf), b1 = hi32(wf);
-    uint64_t cross, q, carry;
-    uint32_t carried;
-    asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
-        "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
-        "v_cndmask_b32 %2, 0, 1, %3\n\t"
-        "v_lshrrev_b64 %0, 32, %0\n\t"
-        "v_mad_u64_u32 %1, %3, %5, %7, %0"
-        : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
-        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
-    q += static_cast<uint64_t>(carried) << 32;
-    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
-    const uint32_t n0 = lo32(neg_p), n1 = hi32(neg_p);
-    uint64_t acc, carry2;
-    uint32_t u0, u1, u2, u3;
-    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
-        "v_mul_lo_u32 %1, %6, %9\n\t"
-        "v_mul_lo_u32 %2, %7, %8\n\t"
-        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
-        "v_mul_lo_u32 %3, %10, %13\n\t"
-        "v_mul_lo_u32 %4, %11, %12\n\t"
-        "v_add3_u32 %1, %1, %2, %3"
-        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
-        : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "v"(n0), "v"(n1));
-    return pack64(lo32(acc), hi32(acc) + u0 + u3);
-}
-// the same with a wave-uniform twiddle and reduction constant in SGPRs
-__device__ __forceinline__ uint64_t shoup_lazy4_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
-    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf), b1 = hi32(wf);
-    uint64_t cross, q, carry;
-    uint32_t carried;
-    asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
-        "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
-        "v_cndmask_b32 %2, 0, 1, %3\n\t"
-        "v_lshrrev_b64 %0, 32, %0\n\t"
-        "v_mad_u64_u32 %1, %3, %5, %7, %0"
-        : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
-        : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
-    q += static_cast<uint64_t>(carried) << 32;
-    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
-    const uint32_t n0 = lo32(neg_p), n1 = hi32(neg_p);
-    uint64_t acc, carry2;
-    uint32_t u0, u1, u2, u3;
-    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
-        "v_mul_lo_u32 %1, %6, %9\n\t"
-        "v_mul_lo_u32 %2, %7, %8\n\t"
-        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
-        "v_mul_lo_u32 %3, %10, %13\n\t"
-        "v_mul_lo_u32 %4, %11, %12\n\t"
-        "v_add3_u32 %1, %1, %2, %3"
-        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
-        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
-    return pack64(lo32(acc), hi32(acc) + u0 + u3);
-}
-// Shoup multiplication for moduli with spare top bits, as two straight-line instruction blocks (hipcc keeps
-// re-deriving a generic 64x64 multiply from the C form; see profiles/r01c_isa_notes.txt for the instruction mix):
-//   x < 2^63, wf_half = floor(w 2^63 / p) = wf >> 1 (< 2^63), neg_2p = 2^64 - 2p  ->  x w - q 2p  in [0, 5p)
-// q = floor((x wf_half) / 2^64) low by <= 1 (and wf_half costs < 3/2 more): a0 b1 + a1 b0 < 2^63 + 2^63 - 2^33 never
-// carries out of 64 bits, so the cross terms ride v_mad_u64_u32's 64-bit addend.  The low 64 bits of
-// x w + q (2^64 - 2p) are two multiply-add chains: the 2^0 column (a0 w0 + q0 n0, 64 bits, optionally on top of an
-// addend -- the forward butterfly's x + w y comes out of the multiplier for free) and the 2^32 column
-// (a0 w1 + a1 w0 + q0 n1 + q1 n0, of which only the low word matters).  9 multiply-adds, one shift, one add; no
-// v_mul_hi_u32, no carry chains, no VCC.  TW is the register class of the twiddle words: "v", or "s" for a
-// wave-uniform twiddle (first forward / last inverse pass) whose four words then stay in SGPRs -- each instruction
-// reads at most one.
-#define HEAMD_HEADROOM_QUOTIENT(TW)                                                                   \
-    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf_half), b1 = hi32(wf_half);                \
-    uint64_t cross, q, carry;                                                                         \
-    asm("v_mad_u64_u32 %0, %2, %3, %6, 0\n\t"                                                         \
-        "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"                                                        \
-        "v_lshrrev_b64 %0, 32, %0\n\t"                                                                \
-        "v_mad_u64_u32 %1, %2, %4, %6, %0"                                                            \
-        : "=&v"(cross), "=&v"(q), "=&s"(carry)                                                        \
-        : "v"(a0), "v"(a1), TW(b0), TW(b1));                                                          \
-    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);                            \
-    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);                                              \
-    uint64_t acc, high, carry2
-#define HEAMD_HEADROOM_HIGH_COLUMN                                                                    \
-    "v_mad_u64_u32 %1, %2, %3, %6, 0\n\t"                                                             \
-    "v_mad_u64_u32 %1, %2, %4, %5, %1\n\t"                                                            \
-    "v_mad_u64_u32 %1, %2, %7, %10, %1\n\t"                                                           \
-    "v_mad_u64_u32 %1, %2, %8, %9, %1"
 
-template <bool UNIFORM>
-__device__ __forceinline__ uint64_t shoup_headroom_any(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
-    if constexpr (UNIFORM) {
-        HEAMD_HEADROOM_QUOTIENT("s");
-        asm("v_mad_u64_u32 %0, %2, %3, %5, 0\n\t"
-            "v_mad_u64_u32 %0, %2, %7, %9, %0\n\t" HEAMD_HEADROOM_HIGH_COLUMN
-            : "=&v"(acc), "=&v"(high), "=&s"(carry2)
+// ---- straight-line Shoup products (asm: hipcc keeps re-deriving a generic 64x64 multiply from the C form) -----------
+// Low 64 bits of  addend + x w + q neg  (neg = 2^64 - p or 2^64 - 2p), as two multiply-add chains: the 2^0 column
+// (a0 w0 + q0 n0, 64 bits, on top of the addend -- the forward butterfly's x + w y leaves the multiplier's addend
+// port for free) and the 2^32 column (a0 w1 + a1 w0 + q0 n1 + q1 n0, of which only the low word matters).  Six
+// multiply-adds and one add; no v_mul_hi_u32, no carry chains, no VCC.  UNIFORM: the twiddle words are wave-uniform
+// and stay in SGPRs (first forward / last inverse pass); the reduction constant always does -- every instruction
+// reads at most one SGPR.
+template <bool UNIFORM, bool ADD>
+__device__ __forceinline__ uint64_t shoup_low64(uint64_t addend, uint64_t x, uint64_t w, uint64_t q, uint64_t neg) {
+    const uint32_t a0 = lo32(x), a1 = hi32(x), q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
+    const uint32_t n0 = lo32(neg), n1 = hi32(neg);
+    uint64_t acc, high, carry;
+#define HEAMD_LOW64_TAIL                           \
+    "v_mad_u64_u32 %0, %2, %7, %9, %0\n\t"          \
+    "v_mad_u64_u32 %1, %2, %3, %6, 0\n\t"           \
+    "v_mad_u64_u32 %1, %2, %4, %5, %1\n\t"          \
+    "v_mad_u64_u32 %1, %2, %7, %10, %1\n\t"         \
+    "v_mad_u64_u32 %1, %2, %8, %9, %1"
+    if constexpr (UNIFORM && ADD) {
+        asm("v_mad_u64_u32 %0, %2, %3, %5, %11\n\t" HEAMD_LOW64_TAIL
+            : "=&v"(acc), "=&v"(high), "=&s"(carry)
+            : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1), "v"(addend));
+    } else if constexpr (UNIFORM) {
+        asm("v_mad_u64_u32 %0, %2, %3, %5, 0\n\t" HEAMD_LOW64_TAIL
+            : "=&v"(acc), "=&v"(high), "=&s"(carry)
             : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
-        return pack64(lo32(acc), opaque32(hi32(acc) + lo32(high)));
+    } else if constexpr (ADD) {
+        asm("v_mad_u64_u32 %0, %2, %3, %5, %11\n\t" HEAMD_LOW64_TAIL
+            : "=&v"(acc), "=&v"(high), "=&s"(carry)
+            : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1), "v"(addend));
     } else {
-        HEAMD_HEADROOM_QUOTIENT("v");
-        asm("v_mad_u64_u32 %0, %2, %3, %5, 0\n\t"
-            "v_mad_u64_u32 %0, %2, %7, %9, %0\n\t" HEAMD_HEADROOM_HIGH_COLUMN
-            : "=&v"(acc), "=&v"(high), "=&s"(carry2)
+        asm("v_mad_u64_u32 %0, %2, %3, %5, 0\n\t" HEAMD_LOW64_TAIL
+            : "=&v"(acc), "=&v"(high), "=&s"(carry)
             : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
-        return pack64(lo32(acc), opaque32(hi32(acc) + lo32(high)));
     }
+#undef HEAMD_LOW64_TAIL
+    return pack64(lo32(acc), opaque32(hi32(acc) + lo32(high)));
+}
+
+// Quotient estimate floor(x f / 2^64) from three multiply-adds (the a0 b0 partial product is dropped):
+//   CARRY = false  needs x < 2^63 and f < 2^63 (headroom mode multiplies by f = wf >> 1): a0 b1 + a1 b0 <
+//                  2^63 + 2^63 - 2^33 never leaves 64 bits; estimate low by <= 1;
+//   CARRY = true   any x, f: the 65th bit of the cross column waits in an SGPR pair and re-enters as bit 32 of the
+//                  estimate; low by <= 2.
+template <bool UNIFORM, bool CARRY>
+__device__ __forceinline__ uint64_t shoup_quotient(uint64_t x, uint64_t f) {
+    const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(f), b1 = hi32(f);
+    uint64_t cross, q, carry;
+    if constexpr (CARRY) {
+        uint32_t carried;
+        if constexpr (UNIFORM) {
+            asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
+                "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
+                "v_cndmask_b32 %2, 0, 1, %3\n\t"
+                "v_lshrrev_b64 %0, 32, %0\n\t"
+                "v_mad_u64_u32 %1, %3, %5, %7, %0"
+                : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
+                : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
+        } else {
+            asm("v_mad_u64_u32 %0, %3, %4, %7, 0\n\t"
+                "v_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
+                "v_cndmask_b32 %2, 0, 1, %3\n\t"
+                "v_lshrrev_b64 %0, 32, %0\n\t"
+                "v_mad_u64_u32 %1, %3, %5, %7, %0"
+                : "=&v"(cross), "=&v"(q), "=&v"(carried), "=&s"(carry)
+                : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+        }
+        return pack64(lo32(q), opaque32(hi32(q) + carried));
+    } else {
+        if constexpr (UNIFORM) {
+            asm("v_mad_u64_u32 %0, %2, %3, %6, 0\n\t"
+                "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+                "v_lshrrev_b64 %0, 32, %0\n\t"
+                "v_mad_u64_u32 %1, %2, %4, %6, %0"
+                : "=&v"(cross), "=&v"(q), "=&s"(carry)
+                : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
+        } else {
+            asm("v_mad_u64_u32 %0, %2, %3, %6, 0\n\t"
+                "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+                "v_lshrrev_b64 %0, 32, %0\n\t"
+                "v_mad_u64_u32 %1, %2, %4, %6, %0"
+                : "=&v"(cross), "=&v"(q), "=&s"(carry)
+                : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+        }
+        return q;
+    }
+}
+
+// lazy4: any 64-bit x, p < 2^61; result x w - q p in [0, 4p) (q low by <= 2 -> < 3p)
+__device__ __forceinline__ uint64_t shoup_lazy4(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
+    return shoup_low64<false, false>(0, x, w, shoup_quotient<false, true>(x, wf), neg_p);
+}
+__device__ __forceinline__ uint64_t shoup_lazy4_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t neg_p) {
+    return shoup_low64<true, false>(0, x, w, shoup_quotient<true, true>(x, wf), neg_p);
+}
+// addend + (x w - q p) mod 2^64
+template <bool UNIFORM>
+__device__ __forceinline__ uint64_t shoup_lazy4_fma(uint64_t addend, uint64_t x, uint64_t w, uint64_t wf,
+                                                    uint64_t neg_p) {
+    return shoup_low64<UNIFORM, true>(addend, x, w, shoup_quotient<UNIFORM, true>(x, wf), neg_p);
+}
+// headroom: x < 2^63, wf_half = floor(w 2^63 / p) = wf >> 1, neg_2p = 2^64 - 2p; result x w - q 2p in [0, 5p)
+// (q low by <= 1, and wf_half costs < 3/2 more)
+__device__ __forceinline__ uint64_t shoup_headroom(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
+    return shoup_low64<false, false>(0, x, w, shoup_quotient<false, false>(x, wf_half), neg_2p);
+}
+__device__ __forceinline__ uint64_t shoup_headroom_uniform(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
+    return shoup_low64<true, false>(0, x, w, shoup_quotient<true, false>(x, wf_half), neg_2p);
 }
 // addend + (x w - q 2p) mod 2^64
 template <bool UNIFORM>
 __device__ __forceinline__ uint64_t shoup_headroom_fma(uint64_t addend, uint64_t x, uint64_t w, uint64_t wf_half,
                                                        uint64_t neg_2p) {
-    if constexpr (UNIFORM) {
-        HEAMD_HEADROOM_QUOTIENT("s");
-        asm("v_mad_u64_u32 %0, %2, %3, %5, %11\n\t"
-            "v_mad_u64_u32 %0, %2, %7, %9, %0\n\t" HEAMD_HEADROOM_HIGH_COLUMN
-            : "=&v"(acc), "=&v"(high), "=&s"(carry2)
-            : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1), "v"(addend));
-        return pack64(lo32(acc), opaque32(hi32(acc) + lo32(high)));
-    } else {
-        HEAMD_HEADROOM_QUOTIENT("v");
-        asm("v_mad_u64_u32 %0, %2, %3, %5, %11\n\t"
-            "v_mad_u64_u32 %0, %2, %7, %9, %0\n\t" HEAMD_HEADROOM_HIGH_COLUMN
-            : "=&v"(acc), "=&v"(high), "=&s"(carry2)
-            : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1), "v"(addend));
-        return pack64(lo32(acc), opaque32(hi32(acc) + lo32(high)));
-    }
-}
-#undef HEAMD_HEADROOM_QUOTIENT
-#undef HEAMD_HEADROOM_HIGH_COLUMN
-__device__ __forceinline__ uint64_t shoup_headroom(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
-    return shoup_headroom_any<false>(x, w, wf_half, neg_2p);
-}
-__device__ __forceinline__ uint64_t shoup_headroom_uniform(uint64_t x, uint64_t w, uint64_t wf_half, uint64_t neg_2p) {
-    return shoup_headroom_any<true>(x, w, wf_half, neg_2p);
+    return shoup_low64<UNIFORM, true>(addend, x, w, shoup_quotient<UNIFORM, false>(x, wf_half), neg_2p);
 }
 
 __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {

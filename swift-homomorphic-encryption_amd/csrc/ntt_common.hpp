@@ -157,11 +157,16 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                 uint64_t x = v[base + o];
                 const uint64_t y = v[base + o + stride];
                 if (!is_headroom(MODE) && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
-                if constexpr (is_headroom(MODE)) {
-                    // x + w y leaves the multiplier's addend port; x - w y + 8p = (2x + 8p) - (x + w y)
-                    const uint64_t sum = (uniform && !(ABLATE & 1))
-                                             ? shoup_headroom_fma<true>(x, y, w.x, w.y, neg_p)
-                                             : shoup_headroom_fma<false>(x, y, w.x, w.y, neg_p);
+                if constexpr (is_headroom(MODE) || MODE == kModeApprox) {
+                    // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
+                    uint64_t sum;
+                    if constexpr (is_headroom(MODE)) {
+                        sum = (uniform && !(ABLATE & 1)) ? shoup_headroom_fma<true>(x, y, w.x, w.y, neg_p)
+                                                         : shoup_headroom_fma<false>(x, y, w.x, w.y, neg_p);
+                    } else {
+                        sum = (uniform && !(ABLATE & 1)) ? shoup_lazy4_fma<true>(x, y, w.x, w.y, neg_p)
+                                                         : shoup_lazy4_fma<false>(x, y, w.x, w.y, neg_p);
+                    }
                     v[base + o] = sum;
                     v[base + o + stride] = ((x << 1) + half_bound) - sum;
                     continue;
