@@ -124,8 +124,9 @@ def run_all(quick=False):
     out = {}
     out["config3_ct_mul"] = config3_ct_mul(torch, heamd, batch=256 if quick else 1024)
     out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
-    out["config5_inner_product_1gpu"] = config5_inner_product(torch, heamd, count=64 if quick else 256,
-                                                              columns=16 if quick else 64)
+    # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)
+    out["config5_inner_product_1gpu"] = config5_inner_product(torch, heamd, count=64 if quick else 1024,
+                                                              columns=16 if quick else 128)
     out["config5_pir_chunk_response_1gpu"] = config5_pir_chunk(torch, heamd, d0=64 if quick else 256,
                                                                 d1=16 if quick else 64)
     return out
