@@ -59,7 +59,7 @@ def synthetic_slab(torch, moduli, batch, degree, seed):
 def pmc_traffic_gbps(batch, forward_seconds):
     """HBM traffic of one forward launch as counted by the PMC passes committed under profiles/ (bench.py cannot
     run rocprofv3 around itself); None when the committed profile was taken at another batch size."""
-    path = os.path.join(ROOT, "profiles", "r01e_pmc_ntt_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01h_pmc_ntt_traffic.json")
     try:
         with open(path) as f:
             profile = json.load(f)
@@ -174,6 +174,12 @@ def main():
     bytes_per_transform = 2 * len(moduli) * DEGREE * 8  # read + write each word once
     achieved_gbps = bytes_per_transform * args.batch / forward_s / 1e9
 
+    # the attainable figure next to the nominal peak: a device-to-device copy of the same slab
+    scratch = torch.empty_like(slab)
+    copy_s = time_kernel(torch, lambda: scratch.copy_(slab), max(5, args.steps))
+    copy_gbps = 2 * slab.numel() * 8 / copy_s / 1e9
+    del scratch
+
     gather_ms = None
     if distributed and not args.skip_gather:
         # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI)
@@ -218,10 +224,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
                 "traffic": pmc_traffic_gbps(args.batch, forward_s),
-                "traffic_source": "profiles/r01e_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": "profiles/r01h_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "gfx950 FETCH_SIZE x2 correction), bytes per launch / this run's launch time",
                 "algorithmic_bytes_per_launch": bytes_per_transform * args.batch,
                 "avg_launch_ms": forward_s * 1e3,
+                "copy_rate": copy_gbps,  # measured read + write rate of a plain copy of the same 1 GiB slab
+                "frac_of_copy_rate": achieved_gbps / copy_gbps,
             },
             "extras": {
                 "forward_poly_ntt_per_s": args.batch / forward_s,
