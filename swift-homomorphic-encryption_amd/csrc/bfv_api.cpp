@@ -322,7 +322,14 @@ int he_bfv_plaintext_to_eval_device(const he_bfv_context* ctx, uint32_t moduli_c
     hipStream_t stream = as_stream(s);
     const PolyContext* q_ctx = ctx->impl->ciphertext(moduli_count);
     const DeviceContext dc = q_ctx->device_context(moduli_count);
-    // Plaintext.convertToEvalFormat (Plaintext.swift:149-170): centered lift, then forwardNtt
+    // Plaintext.convertToEvalFormat (Plaintext.swift:149-170): centered lift, then forwardNtt -- one kernel where the
+    // degree has a tiled NTT (the lift rides the transform's load), two launches otherwise
+    hipError_t fused = heamd::launch_ntt_lift(plaintext, ctx->impl->plaintext_modulus(), batch, out, dc, stream);
+    if (fused != hipErrorNotSupported) {
+        HEAMD_HIP_TRY(fused);
+        return HE_OK;
+    }
+    (void)hipGetLastError();
     HEAMD_HIP_TRY(heamd::launch_plaintext_lift(plaintext, out, dc, ctx->impl->plaintext_modulus(), batch, stream));
     HEAMD_HIP_TRY(heamd::launch_ntt(false, out, dc, 0, moduli_count, batch * moduli_count, stream));
     return HE_OK;

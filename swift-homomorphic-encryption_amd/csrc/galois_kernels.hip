@@ -110,7 +110,67 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// ---- PirUtil.expand, one tree level (PirUtil.swift:204-236, 262-299) ---------------------------------------------
+// parents, c1: [batch][2][L][N] Coeff (c1 = applyGalois(parent)); next: [2 batch][2][L][N] with the children interleaved:
+//   next[2k]     = c1_k + parent_k                                     (p0)
+//   next[2k + 1] = (parent_k - c1_k) * x^(-2^(logStep-1))               (p1), shift = that power mod 2N
+__global__ void __launch_bounds__(kThreads)
+    expand_step_kernel(const uint64_t* __restrict__ parents, const uint64_t* __restrict__ c1,
+                       uint64_t* __restrict__ next, const DeviceContext ctx, uint32_t shift, size_t words) {
+    const uint32_t logn = ctx.log_degree, n = ctx.degree, mask2n = 2 * n - 1;
+    const size_t ct_words = (size_t(2) * ctx.moduli_count) << logn;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t ct = idx / ct_words, w = idx - ct * ct_words;
+        const size_t row = w >> logn;
+        const uint32_t j = static_cast<uint32_t>(w) & (n - 1);
+        const uint64_t p = ctx.moduli[row % ctx.moduli_count].p;
+        const size_t row_base = ct * ct_words + (row << logn);
+        next[2 * ct * ct_words + w] = add_mod(c1[row_base + j], parents[row_base + j], p);
+        const uint32_t i = (j + 2 * n - shift) & mask2n;
+        const bool negate = i >= n;
+        const uint32_t source = negate ? i - n : i;
+        const uint64_t difference = sub_mod(parents[row_base + source], c1[row_base + source], p);
+        next[(2 * ct + 1) * ct_words + w] = negate ? neg_mod(difference, p) : difference;
+    }
+}
+
+// table entry k = (source ciphertext index, destination index << 1 | doubled): dst[destination] = src[source], times
+// two when `doubled` (a leaf above its tree's height is emitted as ciphertext + ciphertext, PirUtil.swift:262-268)
+__global__ void __launch_bounds__(kThreads)
+    expand_move_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ table,
+                       const DeviceContext ctx, size_t words) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t ct_words = (size_t(2) * ctx.moduli_count) << logn;
+    for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
+         idx += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t k = idx / ct_words, w = idx - k * ct_words;
+        const uint32_t source = table[2 * k], packed = table[2 * k + 1];
+        const uint64_t x = src[source * ct_words + w];
+        const uint64_t p = ctx.moduli[(w >> logn) % ctx.moduli_count].p;
+        dst[static_cast<size_t>(packed >> 1) * ct_words + w] = (packed & 1u) ? add_mod(x, x, p) : x;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_expand_step(const uint64_t* parents, const uint64_t* c1, uint64_t* next, const DeviceContext& ctx,
+                              uint32_t shift, size_t batch, hipStream_t stream) {
+    const size_t words = (batch * 2 * ctx.moduli_count) << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_step_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, parents, c1, next, ctx,
+                       shift, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t* table, const DeviceContext& ctx,
+                              size_t count, hipStream_t stream) {
+    const size_t words = (count * 2 * ctx.moduli_count) << ctx.log_degree;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_move_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, src, dst, table, ctx,
+                       words);
+    return hipGetLastError();
+}
 
 hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,
                                size_t rows, hipStream_t stream) {

@@ -42,6 +42,10 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
 // then runs launch_key_switch_spread + launch_ntt).
 hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
                              uint64_t* spread, const DeviceContext& ks_ctx, hipStream_t stream);
+// Plaintext.convertToEvalFormat fused into the forward NTT (Plaintext.swift:149-170): out [polys][L][N] row (poly, r)
+// = NTT_{q_r}(centred lift of plaintexts[poly][N] mod q_r).  hipErrorNotSupported for degrees without a tiled kernel.
+hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulus, size_t polys, uint64_t* out,
+                           const DeviceContext& ctx, hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
 // measurement hook: variant 32 of the forward N=8192 kernel stamps phase boundaries into this buffer (16 words/row)
 hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer);
@@ -100,6 +104,12 @@ hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceCo
 hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t element,
                               size_t rows, hipStream_t stream);
 // f(x) x^shift mod (x^N + 1), 0 <= shift < 2N
+// PirUtil.expand, one level: children of `batch` parents interleaved into next (c1 + parent, (parent - c1) x^-shift')
+hipError_t launch_expand_step(const uint64_t* parents, const uint64_t* c1, uint64_t* next, const DeviceContext& ctx,
+                              uint32_t shift, size_t batch, hipStream_t stream);
+// dst[table[2k+1] >> 1] = src[table[2k]] (doubled mod q when table[2k+1] & 1), whole ciphertexts [2][L][N]
+hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t* table, const DeviceContext& ctx,
+                              size_t count, hipStream_t stream);
 hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
                                       size_t rows, hipStream_t stream);
 // plaintext [batch][N] mod t -> centered lift into every row of [batch][L][N] (L = ctx.moduli_count)

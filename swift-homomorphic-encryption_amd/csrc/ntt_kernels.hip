@@ -43,17 +43,23 @@ __device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
     }
 }
 
-// SPREAD: the key-switching decomposition fused into the load (Bfv+Keys.swift:165-179): output row
-// (poly, j, r) of a [polys][L][L+1][N] slab is the transform mod ks_modulus[r] of row j of polynomial `poly`,
-// read straight from the ciphertext (and reduced mod r first when q_j > modulus r) instead of from a copy that a
-// separate kernel would have to write and this one read back.
+// Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
+// this kernel read it back) is applied to the words as they are loaded.
+//   kSourceSpread  the key-switching decomposition (Bfv+Keys.swift:165-179): output row (poly, j, r) of a
+//                  [polys][L][L+1][N] slab is the transform mod ks_modulus[r] of row j of polynomial `poly`, read
+//                  straight from the ciphertext and reduced mod r first when q_j > modulus r;
+//   kSourceLift    Plaintext.convertToEvalFormat (Plaintext.swift:149-170): output row (poly, r) of a [polys][L][N]
+//                  slab is the transform mod q_r of the centred lift of plaintext `poly` ([N] values < t):
+//                  x < (t + 1) / 2 ? x : x + (q_r - t).
+constexpr int kSourceSlab = 0, kSourceSpread = 1, kSourceLift = 2;
 struct SpreadSource {
     const uint64_t* base;  // row j of polynomial `poly` at base + poly * stride + j * N
     size_t stride;
-    uint32_t L;
+    uint32_t L;            // source rows per polynomial (1 for a plaintext)
+    uint64_t plaintext_modulus;
 };
 
-template <int LOGN, int LOGT, int MODE, int ABLATE = 0, bool SPREAD = false>
+template <int LOGN, int LOGT, int MODE, int ABLATE = 0, int SPREAD = kSourceSlab>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
                       const SpreadSource spread) {
@@ -91,11 +97,15 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         if constexpr (ABLATE & (4 | 32)) {  // bit 5: skip the load only
 #pragma unroll
             for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
-        } else if constexpr (SPREAD) {
+        } else if constexpr (SPREAD != kSourceSlab) {
             const size_t group = row / mod_period;  // poly * L + j
             const size_t poly = group / spread.L, j = group - poly * spread.L;
             global_load<LOGN, LOGE, LO0, LOGE>(v, tid, spread.base + poly * spread.stride + (j << LOGN));
-            if (ctx.moduli[j].p > p) {  // uniform: the source row is canonical mod q_j, not mod this row's modulus
+            if constexpr (SPREAD == kSourceLift) {
+                const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = v[r] < threshold ? v[r] : v[r] + increment;
+            } else if (ctx.moduli[j].p > p) {  // uniform: the source row is canonical mod q_j, not mod this row's modulus
 #pragma unroll
                 for (int r = 0; r < E; ++r) v[r] = barrett_reduce64_uniform(v[r], p, mod.barrett64);
             }
@@ -300,7 +310,7 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
                                static_cast<int>(lds_bytes));
 }
 
-template <int LOGN, int LOGT, bool SPREAD>
+template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                 uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream) {
     constexpr int LOGE = LOGN - LOGT;
@@ -319,8 +329,8 @@ template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream) {
     if (!inverse) {
-        return launch_forward_tiled<LOGN, LOGT, false>(mode, slab, ctx, mod_base, mod_period, rows,
-                                                       SpreadSource{nullptr, 0, 0}, stream);
+        return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
+                                                             SpreadSource{nullptr, 0, 0, 0}, stream);
     }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
@@ -345,7 +355,7 @@ hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1024), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period, SpreadSource{nullptr, 0, 0});
+                       mod_period, SpreadSource{nullptr, 0, 0, 0});
     return hipGetLastError();
 }
 
@@ -375,13 +385,29 @@ hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_
     const size_t rows = polys * source_moduli * period;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30) || ks_ctx.moduli_count < period) return hipErrorInvalidValue;
-    const SpreadSource src{source, poly_stride, source_moduli};
+    const SpreadSource src{source, poly_stride, source_moduli, 0};
     const int mode = production_mode(ks_ctx);
     switch (ks_ctx.log_degree) {
-        case 12: return launch_forward_tiled<12, 9, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
-        case 13: return launch_forward_tiled<13, 10, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
-        case 14: return launch_forward_tiled<14, 10, true>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        case 12: return launch_forward_tiled<12, 9, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        case 13: return launch_forward_tiled<13, 10, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
+        case 14: return launch_forward_tiled<14, 10, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
         default: return hipErrorNotSupported;  // caller falls back to spread kernel + launch_ntt
+    }
+}
+
+hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulus, size_t polys, uint64_t* out,
+                           const DeviceContext& ctx, hipStream_t stream) {
+    const uint32_t period = ctx.moduli_count;
+    const size_t rows = polys * period;
+    if (rows == 0) return hipSuccess;
+    if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
+    const SpreadSource src{plaintexts, size_t(1) << ctx.log_degree, 1, plaintext_modulus};
+    const int mode = production_mode(ctx);
+    switch (ctx.log_degree) {
+        case 12: return launch_forward_tiled<12, 9, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
+        case 13: return launch_forward_tiled<13, 10, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
+        case 14: return launch_forward_tiled<14, 10, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
+        default: return hipErrorNotSupported;  // caller falls back to the lift kernel + launch_ntt
     }
 }
 

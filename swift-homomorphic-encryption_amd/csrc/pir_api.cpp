@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "api_internal.hpp"
+#include "kernels.hpp"
 
 using heamd::as_stream;
 using heamd::invalid_argument;
@@ -190,42 +191,86 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
             levels[order[slot].first][order[slot].second].leaf_slot = static_cast<long>(slot);
     }
 
-    // ---- execute
+    // ---- upload the data movement of every level in one table: per level its leaves (-> output slot, doubled when
+    // the leaf sits above its tree's height) and, when leaves and internal nodes mix, the gather of the parents
+    struct LevelMoves {
+        size_t leaf_offset = 0, leaf_count = 0, parent_offset = 0, parent_count = 0;
+        bool gather = false;
+    };
+    std::vector<LevelMoves> moves(levels.size());
+    std::vector<uint32_t> table;
     size_t widest = 0;
-    for (const auto& level : levels) widest = level.size() > widest ? level.size() : widest;
-    Scratch cur_mem(stream), next_mem(stream), parent_mem(stream), rotated_mem(stream), tmp_mem(stream);
+    if (output_count > 0x7fffffffull) return invalid_argument("too many outputs");
+    for (size_t depth = 0; depth < levels.size(); ++depth) {
+        const std::vector<ExpandNode>& level = levels[depth];
+        widest = level.size() > widest ? level.size() : widest;
+        const int log_step = static_cast<int>(depth) + 1;
+        LevelMoves& m = moves[depth];
+        m.leaf_offset = table.size();
+        for (size_t i = 0; i < level.size(); ++i) {
+            if (level[i].output_count != 1) continue;
+            const uint32_t doubled = log_step > level[i].expected_height ? 0u : 1u;  // PirUtil.swift:262-268
+            table.push_back(static_cast<uint32_t>(i));
+            table.push_back((static_cast<uint32_t>(level[i].leaf_slot) << 1) | doubled);
+            ++m.leaf_count;
+        }
+        m.parent_count = level.size() - m.leaf_count;
+        m.gather = m.leaf_count != 0 && m.parent_count != 0;
+        m.parent_offset = table.size();
+        if (m.gather) {
+            uint32_t k = 0;
+            for (size_t i = 0; i < level.size(); ++i) {
+                if (level[i].output_count == 1) continue;
+                table.push_back(static_cast<uint32_t>(i));
+                table.push_back(k++ << 1);
+            }
+        }
+    }
+    const heamd::DeviceContext q_device = q_ctx->impl->device_context();
+    Scratch table_mem(stream), cur_mem(stream), next_mem(stream), parent_mem(stream), rotated_mem(stream),
+        tmp_mem(stream), workspace_mem(stream);
+    HEAMD_HIP_TRY(table_mem.allocate(table.size() * sizeof(uint32_t)));
+    const uint32_t* table_device = static_cast<const uint32_t*>(table_mem.get());
+    if (!table.empty()) {
+        // pageable host memory: wait for the upload here, so that `table` may die when this function returns (the
+        // launches below stay asynchronous)
+        HEAMD_HIP_TRY(hipMemcpyAsync(table_mem.get(), table.data(), table.size() * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice, stream));
+        HEAMD_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, (widest + 1) / 2);
     HEAMD_HIP_TRY(cur_mem.allocate(widest * ct_bytes));
     HEAMD_HIP_TRY(next_mem.allocate(widest * ct_bytes));
     HEAMD_HIP_TRY(parent_mem.allocate(widest * ct_bytes));
     HEAMD_HIP_TRY(rotated_mem.allocate(widest * ct_bytes));
     HEAMD_HIP_TRY(tmp_mem.allocate(widest * ct_bytes));
-    uint64_t* cur = static_cast<uint64_t*>(cur_mem.get());
-    uint64_t* next = static_cast<uint64_t*>(next_mem.get());
-    uint64_t* parents = static_cast<uint64_t*>(parent_mem.get());
+    HEAMD_HIP_TRY(workspace_mem.allocate(workspace_bytes));
+    const uint64_t* cur = ciphertexts;  // level 0 reads the caller's ciphertexts in place
+    uint64_t* buffers[2] = {static_cast<uint64_t*>(cur_mem.get()), static_cast<uint64_t*>(next_mem.get())};
+    uint64_t* gathered = static_cast<uint64_t*>(parent_mem.get());
     uint64_t* rotated = static_cast<uint64_t*>(rotated_mem.get());
     uint64_t* tmp = static_cast<uint64_t*>(tmp_mem.get());
-    HEAMD_HIP_TRY(hipMemcpyAsync(cur, ciphertexts, ciphertext_count * ct_bytes, hipMemcpyDeviceToDevice, stream));
-    for (size_t depth = 0; depth < levels.size(); ++depth) {
+
+    // ---- execute: every stage of a level is one launch over all nodes of all trees at that depth
+    int status = HE_OK;
+    for (size_t depth = 0; depth < levels.size() && status == HE_OK; ++depth) {
         const int log_step = static_cast<int>(depth) + 1;
-        const std::vector<ExpandNode>& level = levels[depth];
-        // leaves of this level go straight to their output slot (PirUtil.swift:262-268)
-        std::vector<size_t> internal;
-        for (size_t i = 0; i < level.size(); ++i) {
-            if (level[i].output_count != 1) {
-                internal.push_back(i);
-                continue;
-            }
-            uint64_t* dst = out + static_cast<size_t>(level[i].leaf_slot) * ct_words;
-            HEAMD_HIP_TRY(hipMemcpyAsync(dst, cur + i * ct_words, ct_bytes, hipMemcpyDeviceToDevice, stream));
-            if (!(log_step > level[i].expected_height))
-                HEAMD_TRY_STATUS(he_poly_add_device(q_ctx, dst, cur + i * ct_words, 2, s));  // output += ciphertext
+        const LevelMoves& m = moves[depth];
+        if (m.leaf_count != 0)
+            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, out, table_device + m.leaf_offset, q_device, m.leaf_count,
+                                                    stream));
+        if (m.parent_count == 0) continue;
+        if (log_step > log_degree) {  // precondition, PirUtil.swift:212
+            status = invalid_argument("logStep exceeds log2(degree)");
+            break;
         }
-        if (internal.empty()) continue;
-        if (log_step > log_degree) return invalid_argument("logStep exceeds log2(degree)");  // precondition :212
-        const size_t batch = internal.size();
-        for (size_t k = 0; k < batch; ++k)  // gather the parents contiguously
-            HEAMD_HIP_TRY(hipMemcpyAsync(parents + k * ct_words, cur + internal[k] * ct_words, ct_bytes,
-                                         hipMemcpyDeviceToDevice, stream));
+        const size_t batch = m.parent_count;
+        const uint64_t* parents = cur;
+        if (m.gather) {
+            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, gathered, table_device + m.parent_offset, q_device, batch,
+                                                    stream));
+            parents = gathered;
+        }
         // expandCiphertextForOneStep (PirUtil.swift:204-236)
         const uint64_t target = (uint64_t(1) << (log_degree - log_step + 1)) + 1;
         long best = -1;
@@ -234,41 +279,25 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
                 best = static_cast<long>(k);
         if (best < 0 || galois_keys[best] == nullptr) {
             heamd::set_last_error("no Galois element <= " + std::to_string(target) + " in the evaluation key");
-            return HE_ERR_MISSING_GALOIS_KEY;
+            status = HE_ERR_MISSING_GALOIS_KEY;
+            break;
         }
         const uint64_t element = galois_elements[best];
         const int applications = 1 << (floor_log2_size(target - 1) - floor_log2_size(element - 1));
-        const uint64_t* source = parents;
-        for (int a = 0; a < applications; ++a) {  // c1.applyGalois(element) repeatedly until x -> x^target
+        const uint64_t* c1 = parents;
+        for (int a = 0; a < applications && status == HE_OK; ++a) {  // applyGalois(element) until x -> x^target
             uint64_t* dst = (a % 2 == 0) ? rotated : tmp;
-            HEAMD_TRY_STATUS(he_bfv_apply_galois_device(ctx, L, source, element, galois_keys[best], dst, batch, nullptr, 0,
-                                                        s));
-            source = dst;
+            status = he_bfv_apply_galois_device(ctx, L, c1, element, galois_keys[best], dst, batch, workspace_mem.get(),
+                                                workspace_bytes, s);
+            c1 = dst;
         }
-        uint64_t* c1 = const_cast<uint64_t*>(source);
-        uint64_t* difference = (c1 == rotated) ? tmp : rotated;
-        // difference = (ciphertext - c1) * x^(-2^(logStep-1)); c1 += ciphertext
-        HEAMD_HIP_TRY(hipMemcpyAsync(next, parents, batch * ct_bytes, hipMemcpyDeviceToDevice, stream));
-        HEAMD_TRY_STATUS(he_poly_sub_device(q_ctx, next, c1, batch * 2, s));
-        HEAMD_TRY_STATUS(he_poly_multiply_power_of_x_device(q_ctx, next, difference, batch * 2,
-                                                            -(int64_t(1) << (log_step - 1)), s));
-        HEAMD_TRY_STATUS(he_poly_add_device(q_ctx, c1, parents, batch * 2, s));
-        // children interleaved as the plan numbered them: child0 = c1 (p0), child1 = difference (p1)
-        for (size_t k = 0; k < batch; ++k) {
-            const ExpandNode& node = level[internal[k]];
-            HEAMD_HIP_TRY(hipMemcpyAsync(next + static_cast<size_t>(node.child0) * ct_words, c1 + k * ct_words, ct_bytes,
-                                         hipMemcpyDeviceToDevice, stream));
-        }
-        // `next` held the subtraction result until multiplyPowerOfX consumed it; child0 copies above overwrite it
-        // only after that kernel (stream order), child1 copies come from `difference`
-        for (size_t k = 0; k < batch; ++k) {
-            const ExpandNode& node = level[internal[k]];
-            HEAMD_HIP_TRY(hipMemcpyAsync(next + static_cast<size_t>(node.child1) * ct_words, difference + k * ct_words,
-                                         ct_bytes, hipMemcpyDeviceToDevice, stream));
-        }
-        uint64_t* swap = cur;
+        if (status != HE_OK) break;
+        // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
+        const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
+        uint64_t* next = buffers[depth % 2];
+        HEAMD_HIP_TRY(heamd::launch_expand_step(parents, c1, next, q_device, shift, batch, stream));
         cur = next;
-        next = swap;
     }
+    if (status != HE_OK) return status;
     return HE_OK;
 }
