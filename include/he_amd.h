@@ -301,7 +301,9 @@ int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32
  * galois_elements[k] and the device pointer galois_keys[k] of that element's key (layout as in
  * he_bfv_apply_galois_device).  Per tree level the largest element <= the target element is applied
  * 2^(log2(target-1) - log2(element-1)) times (PirUtil.swift:217-231); none available -> HE_ERR_MISSING_GALOIS_KEY.
- * The count preconditions of PirUtil.swift:325-326 return HE_ERR_INVALID_ARGUMENT. */
+ * The count preconditions of PirUtil.swift:325-326 return HE_ERR_INVALID_ARGUMENT.
+ * The recursion is planned on the host; the call waits on `s` once, for the upload of that plan (a few KB), and
+ * returns with the levels' launches enqueued. */
 int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
                          size_t output_count, const uint64_t* galois_elements, const uint64_t* const* galois_keys,
                          size_t galois_key_count, uint64_t* out, he_stream s);
