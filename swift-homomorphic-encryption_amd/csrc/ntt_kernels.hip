@@ -43,6 +43,27 @@ __device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
     }
 }
 
+// ABLATE bit 7 (measurement only, wrong results): every transpose becomes the conflict-free linear pattern
+// (lane tid, register r <-> word tid + r * lanes, no padding) -- the LDS time a perfect layout would leave.
+template <int ABLATE, int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void lds_store_a(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* lds) {
+    if constexpr (ABLATE & 128) {
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); ++r) lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))] = v[r];
+    } else {
+        lds_store<LOGN, LOGE, LO, W>(v, tid, lds);
+    }
+}
+template <int ABLATE, int LOGN, int LOGE, int LO, int W>
+__device__ __forceinline__ void lds_load_a(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* lds) {
+    if constexpr (ABLATE & 128) {
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))];
+    } else {
+        lds_load<LOGN, LOGE, LO, W>(v, tid, lds);
+    }
+}
+
 // Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
 // this kernel read it back) is applied to the words as they are loaded.
 //   kSourceSpread  the key-switching decomposition (Bfv+Keys.swift:165-179): output row (poly, j, r) of a
@@ -116,41 +137,41 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ABLATE>(v, tid, tw, p, true);
         stamp<ABLATE>(2, false, false);
         if constexpr (!(ABLATE & 2)) {
-            lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds);
+            lds_store_a<ABLATE, LOGN, LOGE, LO0, LOGE>(v, tid, lds);
             __syncthreads();
         }
         stamp<ABLATE>(3, false, true);
         if constexpr (S::P >= 3) {
             constexpr int LO1 = LOGN - 2 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO1, LOGE>(v, tid, lds);
             stamp<ABLATE>(4, false, true);
             forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             stamp<ABLATE>(5, true, false);
             if constexpr (!(ABLATE & 2)) {
-                lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+                lds_store_a<ABLATE, LOGN, LOGE, LO1, LOGE>(v, tid, lds);
                 lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>();
             }
             stamp<ABLATE>(6, false, true);
         }
         if constexpr (S::P >= 4) {
             constexpr int LO2 = LOGN - 3 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO2, LOGE>(v, tid, lds);
             forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             if constexpr (!(ABLATE & 2)) {
-                lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+                lds_store_a<ABLATE, LOGN, LOGE, LO2, LOGE>(v, tid, lds);
                 lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>();
             }
         }
         if constexpr (S::P >= 5) {
             constexpr int LO3 = LOGN - 4 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO3, LOGE>(v, tid, lds);
             forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
             if constexpr (!(ABLATE & 2)) {
-                lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
+                lds_store_a<ABLATE, LOGN, LOGE, LO3, LOGE>(v, tid, lds);
                 lds_transpose_fence<LOGN, LOGE, LO3, 0>();
             }
         }
-        if constexpr (!(ABLATE & 2)) lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
+        if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, 0, S::R>(v, tid, lds);
         stamp<ABLATE>(7, false, true);
         forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ABLATE>(v, tid, tw, p, false);
         canonicalize_all<MODE>(v, p);
@@ -458,6 +479,7 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 16: return launch_ablation<16>(slab, ctx, mod_base, mod_period, rows, stream);
             case 32: return launch_ablation<32>(slab, ctx, mod_base, mod_period, rows, stream);
             case 64: return launch_ablation<64>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 128: return launch_ablation<128>(slab, ctx, mod_base, mod_period, rows, stream);
             default: return hipErrorInvalidValue;
         }
     }
