@@ -247,7 +247,13 @@ size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t 
  * 2^30 - 20405, mTilde = 2^16 and the 29-bit Bsk primes (ModularArithmetic/Scalar.swift:498-511,
  * RnsTool.swift:30-33).  The handle works with every he_bfv_* / he_rns_* / he_pir_* entry point above and below;
  * slabs stay 8-byte words holding the zero-extended UInt32 values, so results equal the reference's Bfv<UInt32>
- * words exactly.  (Packed 4-byte storage exists for the polynomial layer only: he_*_device_u32.) */
+ * words exactly.  (Packed 4-byte storage exists for the polynomial layer: he_*_device_u32; [UInt32] ciphertexts cross
+ * into this layer through he_words_widen_u32_device / he_words_narrow_u64_device below.) */
+/* Word-size bridge for Swift's Bfv<UInt32>, whose PolyRq arrays are [UInt32]: widen a packed slab to the
+ * zero-extended 8-byte words the scheme layer above computes on, narrow results back (values of a UInt32 context are
+ * < 2^30, so the low half is the word).  `words` counts coefficients; slabs 16-byte aligned; in != out. */
+int he_words_widen_u32_device(const uint32_t* device_in, uint64_t* device_out, size_t words, he_stream s);
+int he_words_narrow_u64_device(const uint64_t* device_in, uint32_t* device_out, size_t words, he_stream s);
 int he_bfv_context_create_u32(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
                               uint32_t moduli_count, he_bfv_context** out);
 

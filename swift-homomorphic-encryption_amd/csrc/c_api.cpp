@@ -441,6 +441,24 @@ int he_ntt_inverse_device_u32(const he_poly_context* ctx, uint32_t* device_slab,
 int he_poly_add_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s) {
     return elementwise32(ctx, heamd::ElementwiseOp::Add, lhs, rhs, batch, s);
 }
+// ---- word-size bridge for Bfv<UInt32> callers
+int he_words_widen_u32_device(const uint32_t* in, uint64_t* out, size_t words, he_stream s) {
+    if (words == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 15u) != 0)
+        return invalid_argument("slabs must be 16-byte aligned");
+    HEAMD_HIP_TRY(heamd::launch_widen_words(in, out, words, as_stream(s)));
+    return HE_OK;
+}
+int he_words_narrow_u64_device(const uint64_t* in, uint32_t* out, size_t words, he_stream s) {
+    if (words == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 15u) != 0)
+        return invalid_argument("slabs must be 16-byte aligned");
+    HEAMD_HIP_TRY(heamd::launch_narrow_words(in, out, words, as_stream(s)));
+    return HE_OK;
+}
+
 int he_poly_sub_device_u32(const he_poly_context* ctx, uint32_t* lhs, const uint32_t* rhs, size_t batch, he_stream s) {
     return elementwise32(ctx, heamd::ElementwiseOp::Sub, lhs, rhs, batch, s);
 }

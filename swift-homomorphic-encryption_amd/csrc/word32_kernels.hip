@@ -410,6 +410,51 @@ hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t*
     return hipGetLastError();
 }
 
+// ---- word-size bridge between packed [UInt32] slabs and the 8-byte words of the Bfv<UInt32> scheme layer -------
+// four words per lane: 16 B in / 32 B out (widen) or 32 B in / 16 B out (narrow); a narrowed word keeps its low half
+// (scheme-layer results of a UInt32 context are < 2^30)
+namespace {
+typedef uint32_t Packed4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(kThreads)
+    widen_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t words) {
+    const size_t quads = words >> 2;
+    for (size_t q = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; q < quads;
+         q += static_cast<size_t>(gridDim.x) * kThreads) {
+        const Packed4 x = reinterpret_cast<const Packed4*>(in)[q];
+        reinterpret_cast<U64x2*>(out)[2 * q] = U64x2{x.x, x.y};
+        reinterpret_cast<U64x2*>(out)[2 * q + 1] = U64x2{x.z, x.w};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (words & 3)) out[(quads << 2) + threadIdx.x] = in[(quads << 2) + threadIdx.x];
+}
+__global__ void __launch_bounds__(kThreads)
+    narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t words) {
+    const size_t quads = words >> 2;
+    for (size_t q = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; q < quads;
+         q += static_cast<size_t>(gridDim.x) * kThreads) {
+        const U64x2 a = reinterpret_cast<const U64x2*>(in)[2 * q], b = reinterpret_cast<const U64x2*>(in)[2 * q + 1];
+        Packed4 y;
+        y.x = static_cast<uint32_t>(a.x);
+        y.y = static_cast<uint32_t>(a.y);
+        y.z = static_cast<uint32_t>(b.x);
+        y.w = static_cast<uint32_t>(b.y);
+        reinterpret_cast<Packed4*>(out)[q] = y;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (words & 3))
+        out[(quads << 2) + threadIdx.x] = static_cast<uint32_t>(in[(quads << 2) + threadIdx.x]);
+}
+}  // namespace
+
+hipError_t launch_widen_words(const uint32_t* in, uint64_t* out, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for((words >> 2) + 1)), dim3(kThreads), 0, stream, in, out, words);
+    return hipGetLastError();
+}
+hipError_t launch_narrow_words(const uint64_t* in, uint32_t* out, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for((words >> 2) + 1)), dim3(kThreads), 0, stream, in, out, words);
+    return hipGetLastError();
+}
+
 hipError_t launch_divide_and_round_q_last32(const uint32_t* in, uint32_t* out, const DeviceContext32& ctx,
                                             uint32_t moduli_count, size_t polys, hipStream_t stream) {
     const size_t total = polys << ctx.log_degree;

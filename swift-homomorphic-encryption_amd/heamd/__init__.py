@@ -15,7 +15,9 @@ from .binding import (  # noqa: F401
     generate_primes,
     library_path,
     load_library,
+    narrow_u64,
     to_device,
     to_host,
     version,
+    widen_u32,
 )

@@ -78,6 +78,8 @@ SIGNATURES = [
     ("he_poly_mul_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
     ("he_poly_mul_scalar_device_u32", ctypes.c_int, [vp, vp, ctypes.POINTER(ctypes.c_uint32), c_size, vp]),
     ("he_poly_divide_and_round_q_last_device_u32", ctypes.c_int, [vp, vp, vp, c_size, vp]),
+    ("he_words_widen_u32_device", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_words_narrow_u64_device", ctypes.c_int, [vp, vp, c_size, vp]),
     ("he_poly_serialization_byte_count", c_size, [vp, ctypes.c_int]),
     ("he_poly_serialize_device", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, vp, vp]),
     ("he_poly_deserialize_device", ctypes.c_int, [vp, vp, c_size, c_size, ctypes.c_int, vp, vp]),
@@ -164,6 +166,26 @@ def device_count():
     n = ctypes.c_int(0)
     _check(load_library().he_device_count(ctypes.byref(n)))
     return n.value
+
+
+def widen_u32(slab32, stream=None):
+    """[UInt32] words (int32 tensor) -> zero-extended 8-byte words (int64 tensor of the same shape), on the device."""
+    import torch
+
+    out = torch.empty(slab32.shape, dtype=torch.int64, device=slab32.device)
+    _check(load_library().he_words_widen_u32_device(vp(slab32.data_ptr()), vp(out.data_ptr()), slab32.numel(),
+                                                    _stream(stream)))
+    return out
+
+
+def narrow_u64(slab64, stream=None):
+    """8-byte words holding UInt32 values -> packed int32 tensor of the same shape."""
+    import torch
+
+    out = torch.empty(slab64.shape, dtype=torch.int32, device=slab64.device)
+    _check(load_library().he_words_narrow_u64_device(vp(slab64.data_ptr()), vp(out.data_ptr()), slab64.numel(),
+                                                     _stream(stream)))
+    return out
 
 
 def generate_primes(bit_counts, preferring_small, ntt_degree=1):
