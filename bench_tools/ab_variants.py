@@ -1,8 +1,8 @@
 """A/B timing of compile-time kernel experiments.
 
-  python bench_tools/ab_variants.py build NAME=-DFLAG=1 [NAME2=-DFLAG=2 ...]   (no GPU needed)
-      recompiles csrc/ntt_kernels.hip with the extra flag, links it with the other objects of the current build into
-      lib/variants/libhe_amd_NAME.so
+  python bench_tools/ab_variants.py build NAME=[FILE.hip:]-DFLAG=1 [NAME2=...]   (no GPU needed)
+      recompiles csrc/FILE.hip (default ntt_kernels.hip) with the extra flag, links it with the other objects of the
+      current build into lib/variants/libhe_amd_NAME.so
   python bench_tools/ab_variants.py run [NAME ...]                              (on the GPU box)
       times forward / inverse NTT (N=8192, L=4, 4096 polynomials) for the production library and every variant, each in
       its own process (HEAMD_LIBRARY), interleaved over three rounds so that clock drift shows up as spread
@@ -36,7 +36,18 @@ for variant in (0, 10):  # production schedule (headroom for these moduli), then
             ctx.ntt_variant_(x, inverse, variant)
         b.record(); b.synchronize()
         out.append(a.elapsed_time(b) / 50)
-print("headroom %%.4f %%.4f   approx %%.4f %%.4f" %% tuple(out))
+try:
+    for _ in range(20):
+        ctx.ntt_variant_(x, False, 11)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(50):
+        ctx.ntt_variant_(x, False, 11)
+    b.record(); b.synchronize()
+    out.append(a.elapsed_time(b) / 50)
+except Exception:
+    out.append(float("nan"))
+print("headroom %%.4f %%.4f   approx %%.4f %%.4f   stream fwd %%.4f" %% tuple(out))
 ''' % PKG
 
 
@@ -45,12 +56,16 @@ def build(specs):
     import build as product_build
     product_build.build()
     os.makedirs(VARIANTS, exist_ok=True)
-    objects = [o for o in glob.glob(os.path.join(PKG, "csrc", "build", "*.o")) if not o.endswith("ntt_kernels.o")]
     for spec in specs:
         name, flag = spec.split("=", 1)
-        obj = os.path.join(VARIANTS, f"ntt_kernels_{name}.o")
+        source = "ntt_kernels.hip"
+        if ".hip:" in flag:
+            source, flag = flag.split(":", 1)
+        stem = os.path.splitext(source)[0]
+        objects = [o for o in glob.glob(os.path.join(PKG, "csrc", "build", "*.o")) if not o.endswith(stem + ".o")]
+        obj = os.path.join(VARIANTS, f"{stem}_{name}.o")
         subprocess.run([product_build._hipcc(), *product_build.FLAGS, *flag.split(), "-c",
-                        os.path.join(PKG, "csrc", "ntt_kernels.hip"), "-o", obj], check=True)
+                        os.path.join(PKG, "csrc", source), "-o", obj], check=True)
         subprocess.run([product_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={product_build.ARCH}", "-o",
                         os.path.join(VARIANTS, f"libhe_amd_{name}.so"), obj, *objects], check=True)
         print("built", name)

@@ -67,6 +67,9 @@ __device__ __forceinline__ uint32_t image_slot(uint32_t element) {
 template <int LOGN, int LOGT>
 __device__ __forceinline__ void prefetch_row(const uint64_t* row, uint32_t tid, uint64_t* lds) {
     using Shape = StreamShape<LOGN, LOGT>;
+#ifdef HEAMD_STREAM_NO_DMA  // measurement only: the transform runs on whatever the tile holds
+    return;
+#endif
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
                                   (__attribute__((address_space(3))) uint64_t*)(lds))) +
@@ -197,6 +200,9 @@ __global__ void __launch_bounds__(1 << LOGT, 8)
             words.y = hi32(v[2 * g]);
             words.z = lo32(v[2 * g + 1]);
             words.w = hi32(v[2 * g + 1]);
+#ifdef HEAMD_STREAM_NO_STORE  // measurement only
+            if (words.x == 0x12345u && words.w == 0x6789u)
+#endif
             asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1"
                          :
                          : "v"(store_bytes), "v"(words), "s"(uniform_pointer(x + register_part<LOGN, LOGE, 0, 1>(2 * g)))
