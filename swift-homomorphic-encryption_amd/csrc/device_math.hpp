@@ -108,6 +108,22 @@ __device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) {
 #endif
 }
 
+// The same for x, m < 2^63, which covers every x < 2m with m <= 2^62: the wrapped difference x + (2^64 - m) is
+// "negative" exactly when x < m, so one 64-bit add, one 32-bit sign test and the select do it -- no borrow chain, no
+// VCC hazard, no copy of m's high word into a VGPR (4 instructions against 7).  Takes neg_m = 2^64 - m.
+// (asm for the add: hipcc otherwise turns it back into the subtract-with-borrow pair and a 64-bit signed compare.)
+// UNIFORM: neg_m is wave-uniform and is read from an SGPR pair.
+template <bool UNIFORM = false>
+__device__ __forceinline__ uint64_t csub63(uint64_t x, uint64_t neg_m) {
+    uint64_t d;
+    if constexpr (UNIFORM) {
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(neg_m));
+    } else {
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "v"(neg_m));
+    }
+    return static_cast<int32_t>(hi32(d)) < 0 ? x : d;
+}
+
 // Shoup multiplication by the constant w (wf = floor(w * 2^64 / p)), `neg_p` = 2^64 - p.
 //   lazy  : result in [0, 2p), exact quotient estimate (4 + 6 multiplies)
 //   lazy4 : result in [0, 4p), quotient estimate low by <= 2 (3 + 6 multiplies); needs 4p < 2^64
@@ -233,7 +249,7 @@ __device__ __forceinline__ uint64_t shoup_headroom_fma(uint64_t addend, uint64_t
 }
 
 __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
-    return csub(shoup_lazy(x, w, wf, 0 - p), p);
+    return csub63(shoup_lazy(x, w, wf, 0 - p), 0 - p);  // lazy < 2p < 2^63
 }
 
 // Shoup multiplication by a wave-uniform constant, canonical result: x < 2^63, w < p <= 2^62 - 1, wf the usual
@@ -266,17 +282,26 @@ __device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, ui
         : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
         : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
     const uint64_t r = pack64(lo32(acc), hi32(acc) + u0 + u3);
-    return csub(csub(r, 2 * p), p);
+    return csub63<true>(csub(r, 2 * p), 0 - p);  // r < 3p may pass 2^63 for a 62-bit p: the first fold stays general
 }
 
-__device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + b, p); }
-__device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t p) { return csub(a + p - b, p); }
-__device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t p) { return csub(p - a, p); }
+// operands canonical, p <= 2^62 - 1: every intermediate is below 2p < 2^63
+__device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t p) { return csub63(a + b, 0 - p); }
+__device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t p) { return csub63(a + p - b, 0 - p); }
+__device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t p) { return csub63(p - a, 0 - p); }
+// the same with a wave-uniform modulus (a kernel-argument table entry)
+__device__ __forceinline__ uint64_t add_mod_uniform(uint64_t a, uint64_t b, uint64_t p) {
+    return csub63<true>(a + b, 0 - p);
+}
+__device__ __forceinline__ uint64_t sub_mod_uniform(uint64_t a, uint64_t b, uint64_t p) {
+    return csub63<true>(a + p - b, 0 - p);
+}
+__device__ __forceinline__ uint64_t neg_mod_uniform(uint64_t a, uint64_t p) { return csub63<true>(p - a, 0 - p); }
 
 // Single-word Barrett: x mod p for any 64-bit x; factor = floor(2^64 / p).  (Modulus.swift:258-263)
 __device__ __forceinline__ uint64_t barrett_reduce64(uint64_t x, uint64_t p, uint64_t factor) {
     const uint64_t q = mulhi64(x, factor);
-    return csub(x - q * p, p);
+    return csub63(x - q * p, 0 - p);
 }
 
 struct U128 {
@@ -360,7 +385,7 @@ __device__ __forceinline__ uint64_t barrett_reduce64_uniform(uint64_t x, uint64_
         : "=&v"(qp), "=&v"(q_high), "=&s"(carry2)
         : "v"(q), "s"(lo32(p)), "s"(hi32(p)));
     const uint64_t q_times_p = pack64(lo32(qp), hi32(qp) + q_high);
-    return csub(x - q_times_p, p);
+    return csub63<true>(x - q_times_p, 0 - p);
 }
 
 // Canonical residue of a ProductSum whose value is < 2^127 (at most 8 products of operands < 2^62):
@@ -370,7 +395,7 @@ __device__ __forceinline__ uint64_t reduce_product_sum(const ProductSum& s, cons
     const U128 v = product_sum_value(s);
     const uint64_t high = shoup_mul_uniform(v.hi, m.two64_mod_p, m.two64_mod_p_shoup, m.p);
     const uint64_t low = barrett_reduce64_uniform(v.lo, m.p, m.barrett64);
-    return add_mod(high, low, m.p);
+    return add_mod_uniform(high, low, m.p);
 }
 
 // Barrett on a product x*y < p^2 (Modulus.swift:349-360): factor = floor(2^(bits(p)+62)/p), shift = bits(p)-2.
@@ -379,7 +404,7 @@ __device__ __forceinline__ uint64_t barrett_mul(uint64_t x, uint64_t y, uint64_t
     // shift in [0, 60]; p >= 2 => bits(p) >= 2
     const uint64_t shifted = shift == 0 ? prod.lo : ((prod.lo >> shift) | (prod.hi << (64 - shift)));
     const uint64_t q = mulhi64(shifted, factor);
-    return csub(prod.lo - q * p, p);
+    return csub63(prod.lo - q * p, 0 - p);
 }
 
 // Double-word Barrett: x mod p for any 128-bit x; factor = floor(2^128 / p) as (lo, hi).  (Modulus.swift:319-325)
@@ -396,7 +421,7 @@ __device__ __forceinline__ uint64_t barrett_reduce128(U128 x, uint64_t p, uint64
     const uint64_t mid2 = mid + hl.lo;
     carry += mid2 < mid ? 1 : 0;
     const uint64_t q_lo = lh.hi + hl.hi + carry + x.hi * f_hi;  // low word of bits [128, 192), wrapping
-    return csub(x.lo - q_lo * p, p);
+    return csub63(x.lo - q_lo * p, 0 - p);
 }
 
 }  // namespace heamd

@@ -226,7 +226,13 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                     v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
                     v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                 } else {
-                    if (fold) sum = csub(sum, bound);
+                    if (fold) {
+                        if constexpr (is_headroom(MODE)) {
+                            sum = csub63<true>(sum, 0 - bound);  // bound = p << 7 < 2^62
+                        } else {
+                            sum = csub(sum, bound);
+                        }
+                    }
                     v[base + o] = sum;
                     if (uniform) {
                         v[base + o + stride] = Lazy<MODE>::template mul<true>(diff, w, neg_p);
@@ -320,7 +326,7 @@ struct HeadroomReducer {
         const uint32_t q = static_cast<uint32_t>(high * scale);
         const uint64_t qp = mad32(q, static_cast<uint32_t>(p),
                                   static_cast<uint64_t>(mullo32(q, static_cast<uint32_t>(p >> 32))) << 32);
-        return csub(x - qp, p);
+        return csub63<true>(x - qp, 0 - p);
     }
 };
 

@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(kThreads)
             // RnsTool.swift:436-446: alpha > m_sk/2 ? (m_sk - alpha) (B mod q) : alpha (-B mod q); the second form is
             // the negation of alpha (B mod q), so one product serves both
             const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
-            const uint64_t adjust = exceeds ? magnitude : neg_mod(magnitude, m.p);
-            dst[row * n] = add_mod(converted, adjust, m.p);
+            const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
+            dst[row * n] = add_mod_uniform(converted, adjust, m.p);
         }
     }
 }
@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(kThreads)
         // centred remainder mod gamma, taken mod t                                                :289-297
         const bool above = mod_gamma > (gamma >> 1);
         const uint64_t reduced = barrett_reduce64_uniform(above ? gamma - mod_gamma : mod_gamma, t.p, t.barrett64);
-        const uint64_t s_gamma = above ? neg_mod(reduced, t.p) : reduced;
-        out[idx] = shoup_mul_pair(sub_mod(converted[0], s_gamma, t.p), final_scale, t.p);          // :298-301
+        const uint64_t s_gamma = above ? neg_mod_uniform(reduced, t.p) : reduced;
+        out[idx] = shoup_mul_pair(sub_mod_uniform(converted[0], s_gamma, t.p), final_scale, t.p);          // :298-301
     }
 }
 
