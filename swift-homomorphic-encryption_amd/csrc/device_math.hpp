@@ -15,9 +15,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef HEAMD_CSUB_BORROW
-#define HEAMD_CSUB_BORROW 1
-#endif
 
 namespace heamd {
 
@@ -96,23 +93,12 @@ __device__ __forceinline__ uint64_t mullo64_sum2(uint64_t a, uint64_t b, uint64_
     return pack64(lo32(acc), high);
 }
 
-// x >= m ? x - m : x   (x < 2m)
-__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) {
-#if HEAMD_CSUB_BORROW
-    // one subtract-with-borrow pair; the borrow itself selects (no separate 64-bit compare)
-    unsigned long d;
-    const bool borrow = __builtin_usubl_overflow(x, m, &d);
-    return borrow ? x : static_cast<uint64_t>(d);
-#else
-    return x >= m ? x - m : x;
-#endif
-}
-
-// The same for x, m < 2^63, which covers every x < 2m with m <= 2^62: the wrapped difference x + (2^64 - m) is
-// "negative" exactly when x < m, so one 64-bit add, one 32-bit sign test and the select do it -- no borrow chain, no
-// VCC hazard, no copy of m's high word into a VGPR (4 instructions against 7).  Takes neg_m = 2^64 - m.
+// x >= m ? x - m : x   for x < 2m, m <= 2^63 (every modulus multiple used here: p <= 2^62 - 1, 2p, and 4p for p < 2^61).
+// The wrapped difference d = x + (2^64 - m) lies in [0, m) when x >= m and in [2^64 - m, 2^64) otherwise, and m <= 2^63
+// puts exactly the second range above 2^63: the top bit of d selects.  One 64-bit add, one 32-bit sign test and the
+// select -- no borrow chain, no VCC hazard, no copy of m's high word into a VGPR (4 instructions against 7).
 // (asm for the add: hipcc otherwise turns it back into the subtract-with-borrow pair and a 64-bit signed compare.)
-// UNIFORM: neg_m is wave-uniform and is read from an SGPR pair.
+// UNIFORM: neg_m = 2^64 - m is wave-uniform and is read from an SGPR pair.
 template <bool UNIFORM = false>
 __device__ __forceinline__ uint64_t csub63(uint64_t x, uint64_t neg_m) {
     uint64_t d;
@@ -123,6 +109,8 @@ __device__ __forceinline__ uint64_t csub63(uint64_t x, uint64_t neg_m) {
     }
     return static_cast<int32_t>(hi32(d)) < 0 ? x : d;
 }
+__device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) { return csub63<false>(x, 0 - m); }
+__device__ __forceinline__ uint64_t csub_uniform(uint64_t x, uint64_t m) { return csub63<true>(x, 0 - m); }
 
 // Shoup multiplication by the constant w (wf = floor(w * 2^64 / p)), `neg_p` = 2^64 - p.
 //   lazy  : result in [0, 2p), exact quotient estimate (4 + 6 multiplies)
@@ -282,7 +270,7 @@ __device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, ui
         : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
         : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
     const uint64_t r = pack64(lo32(acc), hi32(acc) + u0 + u3);
-    return csub63<true>(csub(r, 2 * p), 0 - p);  // r < 3p may pass 2^63 for a 62-bit p: the first fold stays general
+    return csub_uniform(csub_uniform(r, 2 * p), p);
 }
 
 // operands canonical, p <= 2^62 - 1: every intermediate is below 2p < 2^63

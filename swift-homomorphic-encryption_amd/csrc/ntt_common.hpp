@@ -156,7 +156,7 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
             for (int o = 0; o < stride; ++o) {
                 uint64_t x = v[base + o];
                 const uint64_t y = v[base + o + stride];
-                if (!is_headroom(MODE) && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub(x, half_bound);
+                if (!is_headroom(MODE) && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub_uniform(x, half_bound);
                 if constexpr (is_headroom(MODE) || MODE == kModeApprox) {
                     // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
                     uint64_t sum;
@@ -226,13 +226,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                     v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
                     v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                 } else {
-                    if (fold) {
-                        if constexpr (is_headroom(MODE)) {
-                            sum = csub63<true>(sum, 0 - bound);  // bound = p << 7 < 2^62
-                        } else {
-                            sum = csub(sum, bound);
-                        }
-                    }
+                    if (fold) sum = csub_uniform(sum, bound);
                     v[base + o] = sum;
                     if (uniform) {
                         v[base + o + stride] = Lazy<MODE>::template mul<true>(diff, w, neg_p);
@@ -306,9 +300,9 @@ __device__ __forceinline__ const U64x2* twiddle_table(const DeviceContext& ctx, 
 template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
     static_assert(MODE == kModeExact || MODE == kModeApprox, "headroom outputs go through HeadroomReducer");
-    if constexpr (MODE == kModeApprox) x = csub(x, 4 * p);
-    x = csub(x, 2 * p);
-    return csub(x, p);
+    if constexpr (MODE == kModeApprox) x = csub_uniform(x, 4 * p);
+    x = csub_uniform(x, 2 * p);
+    return csub_uniform(x, p);
 }
 
 // x < 64 p, 2^40 <= p < 2^55  ->  x mod p, with the quotient estimated in fp32 from the high words:
