@@ -188,8 +188,11 @@ int BfvContext::build_tool(uint32_t k) {
     const size_t o_q_to_ext = arena.reserve<u64>((L + 2) * L);
     const size_t o_q_mod_bsk = arena.reserve<U64x2>(L + 1);
     const size_t o_inv_mtilde = arena.reserve<U64x2>(L + 1);
+    const size_t o_q_to_bsk_scaled = arena.reserve<u64>((L + 1) * L);
+    const size_t o_q_mod_bsk_scaled = arena.reserve<U64x2>(L + 1);
     const size_t o_inv_q_bsk = arena.reserve<U64x2>(L + 1);
     const size_t o_inv_punct_b = arena.reserve<U64x2>(L);
+    const size_t o_floor_scale_b = arena.reserve<U64x2>(L);
     const size_t o_b_to_msk = arena.reserve<u64>(L);
     const size_t o_b_to_q = arena.reserve<u64>(L * L);
     const size_t o_b_mod_q = arena.reserve<U64x2>(L);
@@ -218,6 +221,9 @@ int BfvContext::build_tool(uint32_t k) {
         u64 inverse = 0;
         if (!inverse_mod(mtilde_ % bsk[j], bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
         arena.at<U64x2>(o_inv_mtilde)[j] = shoup_pair(inverse, bsk[j]);
+        arena.at<U64x2>(o_q_mod_bsk_scaled)[j] = shoup_pair(mul_mod(q_mod, inverse, bsk[j]), bsk[j]);
+        for (size_t i = 0; i < L; ++i)
+            arena.at<u64>(o_q_to_bsk_scaled)[j * L + i] = mul_mod(punctured_product(q, L, i, bsk[j]), inverse, bsk[j]);
         if (!inverse_mod(q_mod, bsk[j], inverse)) return HE_ERR_NOT_INVERTIBLE;
         arena.at<U64x2>(o_inv_q_bsk)[j] = shoup_pair(inverse, bsk[j]);
     }
@@ -225,6 +231,8 @@ int BfvContext::build_tool(uint32_t k) {
         u64 inverse = 0;
         if (!inverse_mod(punctured_product(bsk, L, i, bsk[i]), bsk[i], inverse)) return HE_ERR_NOT_INVERTIBLE;
         arena.at<U64x2>(o_inv_punct_b)[i] = shoup_pair(inverse, bsk[i]);
+        arena.at<U64x2>(o_floor_scale_b)[i] =
+            shoup_pair(mul_mod(arena.at<U64x2>(o_inv_q_bsk)[i].x, inverse, bsk[i]), bsk[i]);
         arena.at<u64>(o_b_to_msk)[i] = punctured_product(bsk, L, i, m_sk);
         for (size_t row = 0; row < L; ++row)
             arena.at<u64>(o_b_to_q)[row * L + i] = punctured_product(bsk, L, i, q[row]);
@@ -288,8 +296,11 @@ int BfvContext::build_tool(uint32_t k) {
     d.q_to_ext = reinterpret_cast<const uint64_t*>(base + o_q_to_ext);
     d.q_mod_bsk = reinterpret_cast<const U64x2*>(base + o_q_mod_bsk);
     d.inv_mtilde_mod_bsk = reinterpret_cast<const U64x2*>(base + o_inv_mtilde);
+    d.q_to_bsk_scaled = reinterpret_cast<const uint64_t*>(base + o_q_to_bsk_scaled);
+    d.q_mod_bsk_scaled = reinterpret_cast<const U64x2*>(base + o_q_mod_bsk_scaled);
     d.inv_q_mod_bsk = reinterpret_cast<const U64x2*>(base + o_inv_q_bsk);
     d.inv_punctured_b = reinterpret_cast<const U64x2*>(base + o_inv_punct_b);
+    d.floor_scale_b = reinterpret_cast<const U64x2*>(base + o_floor_scale_b);
     d.b_to_msk = reinterpret_cast<const uint64_t*>(base + o_b_to_msk);
     d.b_to_q = reinterpret_cast<const uint64_t*>(base + o_b_to_q);
     d.b_mod_q = reinterpret_cast<const U64x2*>(base + o_b_mod_q);

@@ -23,8 +23,14 @@ struct RnsToolDevice {
     const uint64_t* q_to_ext;          // [L+2][L] (Q/q_i) mod ext_j                      RnsBaseConverter.swift:41-54
     const U64x2* q_mod_bsk;            // [L+1]   Q mod Bsk_j                             RnsTool.swift:224-227
     const U64x2* inv_mtilde_mod_bsk;   // [L+1]   mTilde^-1 mod Bsk_j                     RnsTool.swift:228-231
+    // liftQToQBsk ends with "* mTilde^-1 mod Bsk_j" (RnsTool.swift:364); that exact product is folded into the two
+    // constants it distributes over: out_j = sum_i y_i ((Q/q_i) mTilde^-1) + r_centred (Q mTilde^-1)   (mod Bsk_j)
+    const uint64_t* q_to_bsk_scaled;   // [L+1][L] (Q/q_i) mTilde^-1 mod Bsk_j
+    const U64x2* q_mod_bsk_scaled;     // [L+1]   Q mTilde^-1 mod Bsk_j
     const U64x2* inv_q_mod_bsk;        // [L+1]   Q^-1 mod Bsk_j                          RnsTool.swift:241-245
     const U64x2* inv_punctured_b;      // [L]     (B/Bsk_i)^-1 mod Bsk_i
+    const U64x2* floor_scale_b;        // [L]     Q^-1 (B/Bsk_i)^-1 mod Bsk_i: approximateFloor's Q^-1 and the Bsk -> Q
+                                       //         converter's first product are consecutive exact products mod Bsk_i
     const uint64_t* b_to_msk;          // [L]     (B/Bsk_i) mod m_sk
     const uint64_t* b_to_q;            // [L][L]  (B/Bsk_k) mod q_i  (row i, column k)
     const U64x2* b_mod_q;              // [L]     B mod q_i                               RnsTool.swift:211-216

@@ -88,12 +88,11 @@ __global__ void __launch_bounds__(kThreads)
             const DeviceModulus m = tool.ext_moduli[j];
             ProductSum sum = product_sum_zero();
 #pragma unroll
-            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
-            uint64_t v = reduce_product_sum(sum, m);
+            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
+            const uint64_t converted = reduce_product_sum(sum, m);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
-            const U64x2 q_mod = tool.q_mod_bsk[j];
-            v += shoup_mul_pair(centered, q_mod, m.p);                      // RnsTool.swift:363 (v < 2p < 2^63)
-            dst[(L + j) * n] = shoup_mul_pair(v, tool.inv_mtilde_mod_bsk[j], m.p);  // RnsTool.swift:364
+            // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants
+            dst[(L + j) * n] = add_mod_uniform(converted, shoup_mul_pair(centered, tool.q_mod_bsk_scaled[j], m.p), m.p);
         }
     }
 }
@@ -113,26 +112,29 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t y[L];
 #pragma unroll
         for (int i = 0; i < L; ++i) y[i] = shoup_mul_pair(src[i * n], tool.inv_punctured_q[i], tool.q_moduli[i].p);
-        uint64_t f[L + 1];
+        // (x_Bsk_j - conv_j) Q^-1 mod Bsk_j, and for j < L straight on to the Bsk -> Q converter's first product
+        // z_j = f_j (B/Bsk_j)^-1 mod Bsk_j: two exact products mod Bsk_j = one by the product of the constants
+        uint64_t z[L], f_msk = 0;
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
             ProductSum sum = product_sum_zero();
 #pragma unroll
             for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
-            const uint64_t converted = reduce_product_sum(sum, m);
-            f[j] = shoup_mul_pair(src[(L + j) * n] + m.p - converted, tool.inv_q_mod_bsk[j], m.p);
+            const uint64_t difference = src[(L + j) * n] + m.p - reduce_product_sum(sum, m);
+            if (j < L) {
+                z[j] = shoup_mul_pair(difference, tool.floor_scale_b[j], m.p);
+            } else {
+                f_msk = shoup_mul_pair(difference, tool.inv_q_mod_bsk[j], m.p);
+            }
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
         const DeviceModulus msk = tool.ext_moduli[L];
-        uint64_t z[L];
-#pragma unroll
-        for (int i = 0; i < L; ++i) z[i] = shoup_mul_pair(f[i], tool.inv_punctured_b[i], tool.ext_moduli[i].p);
         ProductSum alpha_sum = product_sum_zero();
 #pragma unroll
         for (int i = 0; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
         uint64_t alpha = reduce_product_sum(alpha_sum, msk);
-        alpha = shoup_mul_pair(alpha + msk.p - f[L], tool.inv_b_mod_msk, msk.p);
+        alpha = shoup_mul_pair(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
         for (int row = 0; row < L; ++row) {
