@@ -264,31 +264,32 @@ __global__ void __launch_bounds__(kThreads)
 // ---- key switching, step 2: lazy inner product with the key (Bfv+Keys.swift:180-202) ------------------------------
 // spread: [polys][L][L+1][N] (Eval); key: [L_top][2][L_top+1][N]; out: [polys][2][L+1][N]
 //   out[poly][c][r][k] = ( sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] ) mod ks_modulus[r]
+// blockIdx.y = poly * (L+1) + r, so the modulus, the key row and every address base are wave-uniform (SGPRs) and the
+// sums ride the carry-counting product accumulator (device_math.hpp ProductSum: L <= 8 products < 2^127).
 __global__ void __launch_bounds__(kThreads)
     key_switch_mac_kernel(const uint64_t* __restrict__ spread, const uint64_t* __restrict__ key,
-                          uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, uint32_t top_rows,
-                          size_t polys) {
+                          uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, uint32_t top_rows) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
-    const size_t total = (polys * (L + 1)) << logn;
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
-        const size_t k = idx & (n - 1);
-        const size_t pr = idx >> logn;
-        const size_t poly = pr / (L + 1);
-        const uint32_t r = static_cast<uint32_t>(pr - poly * (L + 1));
-        const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
-        const DeviceModulus m = ks.moduli[r];
-        U128 acc0{0, 0}, acc1{0, 0};
-        for (uint32_t j = 0; j < L; ++j) {
-            const uint64_t x = spread[((poly * L + j) * (L + 1) + r) * n + k];
-            const uint64_t* key_j = key + (size_t(j) * 2 * top_rows + key_row) * n + k;
-            mac128(acc0, x, key_j[0]);
-            mac128(acc1, x, key_j[size_t(top_rows) * n]);
-        }
-        uint64_t* dst = out + (poly * 2 * (L + 1) + r) * n + k;
-        dst[0] = reduce128(acc0, m);
-        dst[size_t(L + 1) * n] = reduce128(acc1, m);
+    const size_t k = blockIdx.x * size_t(kThreads) + threadIdx.x;
+    if (k >= n) return;
+    const size_t pr = blockIdx.y;
+    const size_t poly = pr / (L + 1);
+    const uint32_t r = static_cast<uint32_t>(pr - poly * (L + 1));
+    const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
+    const DeviceModulus m = ks.moduli[r];
+    const uint64_t* __restrict__ x_row = spread + ((poly * L) * (L + 1) + r) * n + k;
+    const uint64_t* __restrict__ key_row0 = key + size_t(key_row) * n + k;
+    ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+    for (uint32_t j = 0; j < L; ++j) {
+        const uint64_t x = x_row[size_t(j) * (L + 1) * n];
+        const uint64_t* key_j = key_row0 + size_t(j) * 2 * top_rows * n;
+        product_sum_add(acc0, x, key_j[0]);
+        product_sum_add(acc1, x, key_j[size_t(top_rows) * n]);
     }
+    uint64_t* dst = out + (poly * 2 * (L + 1) + r) * n + k;
+    dst[0] = reduce_product_sum(acc0, m);
+    dst[size_t(L + 1) * n] = reduce_product_sum(acc1, m);
 }
 
 // ---- key switching, step 4: drop the special modulus and add into the ciphertext (Bfv.swift:216-217) --------------
@@ -310,16 +311,17 @@ __global__ void __launch_bounds__(kThreads)
         const uint64_t* src = prod + pc * (L + 1) * n + k;
         const uint64_t* ct = ct_base + poly * ct_stride + c * L * n + k;
         uint64_t* dst = out + pc * L * n + k;
-        const uint64_t r = add_mod(src[size_t(L) * n], q_last_div2, q_last);
+        const uint64_t r = add_mod_uniform(src[size_t(L) * n], q_last_div2, q_last);
         for (uint32_t row = 0; row < L; ++row) {
             const DeviceModulus m = ks.moduli[row];
             const U64x2 inv = inverse_q_last[row];
-            const uint64_t half_mod_qi = barrett_reduce64(q_last_div2, m.p, m.barrett64);
-            const uint64_t t = barrett_reduce64(r, m.p, m.barrett64);
-            const uint64_t v = shoup_mul(sub_mod(add_mod(src[row * n], half_mod_qi, m.p), t, m.p), inv.x, inv.y, m.p);
+            const uint64_t half_mod_qi = barrett_reduce64_uniform(q_last_div2, m.p, m.barrett64);
+            const uint64_t t = barrett_reduce64_uniform(r, m.p, m.barrett64);
+            const uint64_t v = shoup_mul_uniform(
+                sub_mod_uniform(add_mod_uniform(src[row * n], half_mod_qi, m.p), t, m.p), inv.x, inv.y, m.p);
             // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
             // replaces c1 (Bfv.swift:194-195)
-            dst[row * n] = c < added_polys ? add_mod(ct[row * n], v, m.p) : v;
+            dst[row * n] = c < added_polys ? add_mod_uniform(ct[row * n], v, m.p) : v;
         }
     }
 }
@@ -430,9 +432,20 @@ hipError_t launch_key_switch_spread(const uint64_t* target_base, size_t target_s
 hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                  uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
-    hipLaunchKernelGGL(key_switch_mac_kernel, dim3(grid_for((polys * (L + 1)) << ks.log_degree)), dim3(kThreads), 0,
-                       stream, spread, key, out, ks, L, top_rows, polys);
-    return hipGetLastError();
+    const size_t n = size_t(1) << ks.log_degree;
+    if (L > 8) return hipErrorInvalidValue;  // ProductSum headroom
+    // grid.y carries (polynomial, modulus); it is limited to 65535, so long batches go out in slices
+    const size_t rows_per_poly = L + 1, max_polys = 65535 / rows_per_poly;
+    for (size_t done = 0; done < polys; done += max_polys) {
+        const size_t now = polys - done < max_polys ? polys - done : max_polys;
+        hipLaunchKernelGGL(key_switch_mac_kernel,
+                           dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads), static_cast<unsigned>(now * rows_per_poly)),
+                           dim3(kThreads), 0, stream, spread + done * L * rows_per_poly * n, key,
+                           out + done * 2 * rows_per_poly * n, ks, L, top_rows);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_key_switch_finish(const uint64_t* prod, const uint64_t* ct_base, size_t ct_stride, uint64_t* out,
