@@ -188,23 +188,25 @@ __global__ void __launch_bounds__(kThreads)
 
 // ---- tensor product: (a0, a1) x (b0, b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1), word-wise in Eval form ----------------
 // in: [items][4][rows][N] (a0, a1, b0, b1); out: [items][3][rows][N]
+// blockIdx.y = item * rows + row: the modulus constants are wave-uniform
 __global__ void __launch_bounds__(kThreads)
-    tensor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx, size_t items) {
+    tensor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx) {
     const uint32_t logn = ctx.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t k = blockIdx.x * size_t(kThreads) + threadIdx.x;
+    if (k >= n) return;
     const size_t poly_words = size_t(ctx.moduli_count) << logn;
-    const size_t total = items * poly_words;
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx += size_t(gridDim.x) * kThreads) {
-        const size_t item = idx / poly_words, w = idx - item * poly_words;
-        const DeviceModulus m = ctx.moduli[w >> logn];
-        const uint64_t* src = in + item * 4 * poly_words + w;
-        const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
-        const int shift = static_cast<int>(m.product_shift);
-        uint64_t* dst = out + item * 3 * poly_words + w;
-        dst[0] = barrett_mul(a0, b0, m.p, m.product_factor, shift);
-        dst[poly_words] = add_mod(barrett_mul(a0, b1, m.p, m.product_factor, shift),
-                                  barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p);
-        dst[2 * poly_words] = barrett_mul(a1, b1, m.p, m.product_factor, shift);
-    }
+    const size_t item = blockIdx.y / ctx.moduli_count;
+    const uint32_t row = blockIdx.y - static_cast<uint32_t>(item) * ctx.moduli_count;
+    const DeviceModulus m = ctx.moduli[row];
+    const uint64_t* src = in + item * 4 * poly_words + (size_t(row) << logn) + k;
+    const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
+    const int shift = static_cast<int>(m.product_shift);
+    uint64_t* dst = out + item * 3 * poly_words + (size_t(row) << logn) + k;
+    dst[0] = barrett_mul(a0, b0, m.p, m.product_factor, shift);
+    dst[poly_words] = add_mod_uniform(barrett_mul(a0, b1, m.p, m.product_factor, shift),
+                                      barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p);
+    dst[2 * poly_words] = barrett_mul(a1, b1, m.p, m.product_factor, shift);
 }
 
 // ---- lazy tensor accumulation for Bfv.innerProduct(ct, ct) (Bfv.swift:315-361) -----------------------------------
@@ -408,9 +410,17 @@ hipError_t launch_floor_qbsk_to_q(const uint64_t* in, uint64_t* out, const RnsTo
 hipError_t launch_tensor(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t items,
                          hipStream_t stream) {
     if (items == 0) return hipSuccess;
-    const size_t total = items * (size_t(qbsk.moduli_count) << qbsk.log_degree);
-    hipLaunchKernelGGL(tensor_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk, items);
-    return hipGetLastError();
+    const size_t n = size_t(1) << qbsk.log_degree, rows = qbsk.moduli_count;
+    const size_t max_items = 65535 / rows;  // grid.y carries (item, row)
+    for (size_t done = 0; done < items; done += max_items) {
+        const size_t now = items - done < max_items ? items - done : max_items;
+        hipLaunchKernelGGL(tensor_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads),
+                                               static_cast<unsigned>(now * rows)),
+                           dim3(kThreads), 0, stream, in + done * 4 * rows * n, out + done * 3 * rows * n, qbsk);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_tensor_accumulate(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t count,
