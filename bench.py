@@ -217,7 +217,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntt_forward_tiled<13, 10, 3, 0, false> (forward NTT: one 1024-lane workgroup per residue row, "
+                "kernel": "ntt_forward_tiled<13, 10, 3, 0, 0> (forward NTT: one 1024-lane workgroup per residue row, "
                           "8 words per lane, headroom butterflies)",
                 "achieved": achieved_gbps,
                 "peak": HBM_PEAK_GBPS,
