@@ -24,11 +24,14 @@ enum {
     kNttVariantWidest = 9,  // tiled kernel, 1024 lanes x 8 words (N = 8192 only)
     kNttVariantApprox = 10, // production kernel pinned to the [0, 8p) schedule (no headroom mode)
     kNttVariantStream = 11, // persistent forward kernel with LDS-DMA prefetch of the next row (ntt_stream.hip)
+    kNttVariantPrefetch = 12, // persistent forward kernel, 16 words per lane, next row prefetched into registers
     kNttVariantAblateBase = 16
 };
 bool ntt_stream_supports(const DeviceContext& ctx);
 hipError_t launch_ntt_forward_stream(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                      uint32_t mod_period, size_t rows, uint32_t workgroups, hipStream_t stream);
+hipError_t launch_ntt_forward_prefetch(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+                                       uint32_t mod_period, size_t rows, uint32_t workgroups, hipStream_t stream);
 bool ntt_pipelined_supports(uint32_t log_degree);
 hipError_t launch_ntt_pipelined(bool inverse, bool approx, int flags, uint64_t* slab, const DeviceContext& ctx,
                                 uint32_t mod_base, uint32_t mod_period, size_t rows, hipStream_t stream);

@@ -465,6 +465,10 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         if (inverse || !ntt_stream_supports(ctx)) return hipErrorNotSupported;
         return launch_ntt_forward_stream(slab, ctx, mod_base, mod_period, rows, 2 * compute_unit_count(), stream);
     }
+    if (force_variant == kNttVariantPrefetch) {
+        if (inverse) return hipErrorNotSupported;
+        return launch_ntt_forward_prefetch(slab, ctx, mod_base, mod_period, rows, 2 * compute_unit_count(), stream);
+    }
     if (force_variant >= kNttVariantAblateBase && ctx.log_degree == 13 && !inverse) {
         switch (force_variant - kNttVariantAblateBase) {  // measurement-only kernels: results are NOT an NTT
             case 0: return launch_ablation<0>(slab, ctx, mod_base, mod_period, rows, stream);

@@ -218,6 +218,64 @@ __global__ void __launch_bounds__(1 << LOGT, 8)
     }
 }
 
+// ---- persistent kernel with REGISTER prefetch: 16 words per lane ---------------------------------------------------
+// Two rows per CU is an LDS limit, so with 16 words per lane (512 lanes per row) only 4 waves per SIMD are resident
+// and 128 VGPRs per lane are available where the arithmetic needs ~75: the spare 32 hold the NEXT row, loaded at the
+// top of the current one -- a whole row period of latency tolerance, no asm, no counted waits.  Transposes and
+// butterflies are the tiled kernel's (<LOGN, LOGT> = <13, 9>: passes of 4 + 4 + 4 + 1 stages, three transposes).
+// Measured (profiles/r01i_ntt_prefetch.txt): 0.648 ms against 0.625 ms for the same shape launched one workgroup per
+// row and 0.626 ms for the production kernel; a hashed start delay per workgroup changes nothing.  With the load
+// latency provably hidden and no gain, the 17 % the "no global load" ablation returns is the halved HBM traffic, not
+// latency.  Kept as variant 12 for the record and for parity tests.
+template <int LOGN, int LOGT, int MODE>
+__global__ void __launch_bounds__(1 << LOGT, 4)
+    ntt_forward_prefetch(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
+                         uint32_t rows) {
+    constexpr int LOGE = LOGN - LOGT;
+    constexpr int E = 1 << LOGE;
+    using S = Schedule<LOGN, LOGE>;
+    static_assert(S::P == 4, "written out for four passes");
+    constexpr int LO0 = LOGN - LOGE, LO1 = LOGN - 2 * LOGE, LO2 = LOGN - 3 * LOGE;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const uint32_t lane_id = threadIdx.x;
+    uint32_t row = blockIdx.x;
+    if (row >= rows) return;
+    uint64_t v[E], nxt[E];
+    global_load<LOGN, LOGE, LO0, LOGE>(v, lane_id, slab + (static_cast<size_t>(row) << LOGN));
+    for (;;) {
+        const uint32_t next_row = row + gridDim.x;
+        const bool has_next = next_row < rows;
+        const uint32_t tid = per_row(lane_id);  // keeps the lane-derived addresses out of loop-invariant registers
+        if (has_next) global_load<LOGN, LOGE, LO0, LOGE>(nxt, tid, slab + (static_cast<size_t>(next_row) << LOGN));
+        const uint32_t mi = mod_base + row % mod_period;
+        const DeviceModulus mod = ctx.moduli[mi];
+        const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, false) + (static_cast<size_t>(mi) << LOGN);
+        uint64_t* __restrict__ x = slab + (static_cast<size_t>(row) << LOGN);
+        const uint64_t p = mod.p;
+        forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true>(v, tid, tw, p, true);
+        lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds);
+        __syncthreads();
+        lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+        forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false>(v, tid, tw, p, false);
+        lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
+        lds_transpose_fence<LOGN, LOGE, LO1, LO2>();
+        lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+        forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false>(v, tid, tw, p, false);
+        lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
+        lds_transpose_fence<LOGN, LOGE, LO2, 0>();
+        lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds);
+        forward_pass<LOGN, LOGE, 0, S::R, MODE, false>(v, tid, tw, p, false);
+        canonicalize_all<MODE>(v, p);
+        global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+        if (!has_next) break;
+        // the next row's first transpose crosses waves: every wave must be done with this row's tile first
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = nxt[r];
+        row = next_row;
+    }
+}
+
 }  // namespace
 
 bool ntt_stream_supports(const DeviceContext& ctx) {
@@ -232,6 +290,24 @@ hipError_t launch_ntt_forward_stream(uint64_t* slab, const DeviceContext& ctx, u
     constexpr size_t lds_bytes = ntt::lds_words(1u << LOGN) * sizeof(uint64_t);
     auto kernel = ctx.forward_twiddles_half != nullptr ? ntt_forward_stream<LOGN, LOGT, ntt::kModeHeadroomHalved>
                                                        : ntt_forward_stream<LOGN, LOGT, ntt::kModeHeadroom>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    const unsigned grid = static_cast<unsigned>(rows < workgroups ? rows : workgroups);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, mod_base, mod_period,
+                       static_cast<uint32_t>(rows));
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_forward_prefetch(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+                                       uint32_t mod_period, size_t rows, uint32_t workgroups, hipStream_t stream) {
+    if (ctx.log_degree != 13 || ctx.approx_ok == 0 || rows > 0xffffffffull) return hipErrorNotSupported;
+    if (rows == 0) return hipSuccess;
+    constexpr int LOGN = 13, LOGT = 9;
+    constexpr size_t lds_bytes = ntt::lds_words(1u << LOGN) * sizeof(uint64_t);
+    auto kernel = ctx.headroom_ok == 0                  ? ntt_forward_prefetch<LOGN, LOGT, ntt::kModeApprox>
+                  : ctx.forward_twiddles_half != nullptr ? ntt_forward_prefetch<LOGN, LOGT, ntt::kModeHeadroomHalved>
+                                                         : ntt_forward_prefetch<LOGN, LOGT, ntt::kModeHeadroom>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;

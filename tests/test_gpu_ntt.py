@@ -101,6 +101,21 @@ def test_ntt_stream_kernel_matches_oracle(oracle, bits, batch):
     assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), False, 11)), ref.forward_ntt(slab))
 
 
+@pytest.mark.parametrize("bits,batch", [([55, 55, 55, 55], 1), ([55, 55, 55], 171), ([41, 54], 300), ([61, 61], 300),
+                                        ([55] * 4, 641)])
+def test_ntt_prefetch_kernel_matches_oracle(oracle, bits, batch):
+    """Persistent forward kernel with the next row prefetched into registers (16 words per lane, variant 12): no loop
+    trip, one, ragged and many trips; headroom and [0, 8p) butterflies; moduli change from row to row."""
+    degree = 8192
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(batch + len(bits))
+    slab = _rand_slab(rng, batch, moduli, degree)
+    slab[0, 0, :] = moduli[0] - 1
+    assert np.array_equal(heamd.to_host(ours.ntt_variant_(heamd.to_device(slab), False, 12)), ref.forward_ntt(slab))
+
+
 @pytest.mark.parametrize("degree", [4096, 8192, 16384])
 @pytest.mark.parametrize("bits", [[55, 55, 54], [41, 41], [48, 55]])
 def test_ntt_headroom_mode_extremes(oracle, degree, bits):
