@@ -295,3 +295,46 @@ def test_bfv_uint32_packed_words_round_trip(oracle):
     assert lib.he_words_widen_u32_device(None, None, 4, None) != 0
     misaligned = packed(np.arange(8))
     assert lib.he_words_widen_u32_device(misaligned.data_ptr() + 4, wide.data_ptr(), 4, None) != 0
+
+
+@pytest.mark.parametrize("bits", [[62, 62, 61, 62], [62] * 9, [61, 33, 62, 45, 62]])
+def test_widest_moduli_match_oracle(oracle, bits):
+    """The largest moduli the reference admits (2^62 - 1, MA/Modulus.swift:177-180) and the most rows the kernels are
+    specialised for (8 ciphertext moduli): the carry-counting accumulators, the sign-select conditional subtract
+    (m up to 2^63) and the merged BEHZ constants at their limits, word for word against the oracle on uniform words
+    and on the extreme words 0 and q - 1."""
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    L = ours.L
+    moduli = q[:-1]
+    rng = np.random.default_rng(len(bits))
+    x = _uniform(rng, (4,), moduli, degree)
+    x[0] = 0
+    x[1] = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    tool = ref.rns_tool(L)
+    assert np.array_equal(heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x))),
+                          np.stack([tool.lift_q_to_qbsk(p) for p in x]))
+    qbsk = ref.qbsk_context(L).moduli
+    y = _uniform(rng, (4,), qbsk, degree)
+    y[0] = 0
+    y[1] = np.array(qbsk, dtype=np.uint64)[:, None] - np.uint64(1)
+    assert np.array_equal(heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y))),
+                          np.stack([tool.floor_qbsk_to_q(p) for p in y]))
+    assert np.array_equal(heamd.to_host(ours.scale_and_round(heamd.to_device(x))),
+                          np.stack([tool.scale_and_round(p, 1) for p in x]))
+    lhs, rhs = _uniform(rng, (3, 2), moduli, degree), _uniform(rng, (3, 2), moduli, degree)
+    lhs[0] = np.array(moduli, dtype=np.uint64)[None, :, None] - np.uint64(1)
+    rhs[0] = lhs[0]
+    product = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(product, ref.mul(lhs, rhs))
+    key = _uniform(rng, (L, 2), q, degree)
+    key[0] = np.array(q, dtype=np.uint64)[None, :, None] - np.uint64(1)
+    ct3 = _uniform(rng, (2, 3), moduli, degree)
+    ct3[0] = np.array(moduli, dtype=np.uint64)[None, :, None] - np.uint64(1)
+    assert np.array_equal(heamd.to_host(ours.relinearize(heamd.to_device(ct3), heamd.to_device(key))),
+                          ref.relinearize(ct3, key))
+    switched = heamd.to_host(ours.mod_switch_down(heamd.to_device(lhs), 2))
+    assert np.array_equal(switched, np.stack([np.stack([ref.ciphertext_context().divide_and_round_q_last(p[None])[0]
+                                                        for p in ct]) for ct in lhs]))
