@@ -50,6 +50,10 @@ __device__ __forceinline__ void lds_store_a(const uint64_t (&v)[1 << LOGE], uint
     if constexpr (ABLATE & 128) {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))] = v[r];
+    } else if constexpr (ABLATE & 256) {  // occupancy probe: the padded pattern folded into a 32 KB tile
+        const uint32_t base = lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); ++r) lds[(base + lds_slot(register_part<LOGN, LOGE, LO, W>(r))) & 4095u] = v[r];
     } else {
         lds_store<LOGN, LOGE, LO, W>(v, tid, lds);
     }
@@ -59,6 +63,10 @@ __device__ __forceinline__ void lds_load_a(uint64_t (&v)[1 << LOGE], uint32_t ti
     if constexpr (ABLATE & 128) {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))];
+    } else if constexpr (ABLATE & 256) {
+        const uint32_t base = lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[(base + lds_slot(register_part<LOGN, LOGE, LO, W>(r))) & 4095u];
     } else {
         lds_load<LOGN, LOGE, LO, W>(v, tid, lds);
     }
@@ -365,6 +373,21 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     return hipGetLastError();
 }
 
+// occupancy probe (measurement only, wrong results): the 16-words-per-lane kernel with its transposes folded into a
+// 32 KB tile, so that three rows (register-limited) fit a CU's LDS instead of two (its 73 VGPRs allow six waves per SIMD)
+hipError_t launch_occupancy_probe(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
+                                  size_t rows, bool folded, hipStream_t stream) {
+    if (ctx.forward_twiddles_half == nullptr) return hipErrorInvalidValue;
+    const size_t lds_bytes = folded ? 4096 * sizeof(uint64_t) : lds_words(1u << 13) * sizeof(uint64_t);
+    auto kernel = folded ? ntt_forward_tiled<13, 9, kModeHeadroomHalved, 256> : ntt_forward_tiled<13, 9, kModeHeadroomHalved, 512>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(512), lds_bytes, stream, slab, ctx, mod_base,
+                       mod_period, SpreadSource{nullptr, 0, 0, 0});
+    return hipGetLastError();
+}
+
 template <int ABLATE>
 hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                            size_t rows, hipStream_t stream) {
@@ -484,6 +507,8 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 32: return launch_ablation<32>(slab, ctx, mod_base, mod_period, rows, stream);
             case 64: return launch_ablation<64>(slab, ctx, mod_base, mod_period, rows, stream);
             case 128: return launch_ablation<128>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 256: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, true, stream);
+            case 512: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, false, stream);
             default: return hipErrorInvalidValue;
         }
     }
