@@ -16,7 +16,7 @@ moduli = heamd.generate_primes(bits, False, degree)
 ctx = heamd.PolyContext(degree, moduli)
 bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
 x = torch.randint(0, 1 << 62, (batch, len(moduli), degree), dtype=torch.int64, device="cuda") % bound
-names = {0: "full kernel", 16: "full kernel (again, via ablation entry)", 48: "no global load (store kept)", 80: "no global store (load kept)", 17: "uniform twiddles", 18: "no LDS exchange", 144: "conflict-free linear LDS pattern (wrong transposes)", 528: "16 words per lane, full tile: 2 rows per CU", 272: "16 words per lane, tile folded to 32 KB: 3 rows per CU (wrong transposes)", 19: "no LDS + uniform tw", 20: "no global ld/st",
+names = {0: "full kernel", 16: "full kernel (again, via ablation entry)", 48: "no global load (store kept)", 80: "no global store (load kept)", 17: "uniform twiddles", 18: "no LDS exchange", 144: "conflict-free linear LDS pattern (wrong transposes)", 1040: "memory only: the kernel's loads and stores, no butterflies", 528: "16 words per lane, full tile: 2 rows per CU", 272: "16 words per lane, tile folded to 32 KB: 3 rows per CU (wrong transposes)", 19: "no LDS + uniform tw", 20: "no global ld/st",
          23: "compute only (no mem, no lds, uniform tw)", 24: "no csub", 25: "no csub + uniform tw",
          31: "compute only, no csub"}
 for variant, name in names.items():

@@ -142,6 +142,10 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
             global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
         }
         stamp<ABLATE>(1, true, false);
+        if constexpr (ABLATE & 1024) {  // memory only (measurement): the row goes straight back out, no butterflies
+            global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+            return;
+        }
         forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ABLATE>(v, tid, tw, p, true);
         stamp<ABLATE>(2, false, false);
         if constexpr (!(ABLATE & 2)) {
@@ -507,6 +511,7 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 32: return launch_ablation<32>(slab, ctx, mod_base, mod_period, rows, stream);
             case 64: return launch_ablation<64>(slab, ctx, mod_base, mod_period, rows, stream);
             case 128: return launch_ablation<128>(slab, ctx, mod_base, mod_period, rows, stream);
+            case 1024: return launch_ablation<1024>(slab, ctx, mod_base, mod_period, rows, stream);
             case 256: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, true, stream);
             case 512: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, false, stream);
             default: return hipErrorInvalidValue;
