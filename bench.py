@@ -83,6 +83,47 @@ def time_kernel(torch, fn, reps):
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
+def clocks_under_load(torch, fn, seconds=1.5):
+    """Shader clock (MHz) and socket power (W) reported by rocm-smi while fn() runs back to back; None without rocm-smi.
+    The NTT kernel runs at the socket power cap, so the clock it gets is part of the measurement."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    if shutil.which("rocm-smi") is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
+                                     timeout=10).stdout
+            except Exception:
+                return
+            sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+            power = re.search(r"Power \(W\): ([0-9.]+)", out)
+            if sclk and power:
+                samples.append((int(sclk.group(1)), float(power.group(1))))
+            stop.wait(0.2)
+
+    thread = threading.Thread(target=poll, daemon=True)
+    thread.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(100):
+            fn()
+        torch.cuda.synchronize()
+    stop.set()
+    thread.join(timeout=15)
+    steady = samples[1:] if len(samples) > 2 else samples
+    if not steady:
+        return None
+    return {"sclk_mhz": sum(s[0] for s in steady) / len(steady), "socket_power_w": sum(s[1] for s in steady) / len(steady),
+            "samples": len(steady)}
+
+
 def cpu_baseline(moduli, sample_polys):
     """Times the CPU oracle (port of the reference's NTT) on a bounded sample: forward + inverse of sample_polys."""
     import numpy as np
@@ -180,6 +221,8 @@ def main():
     copy_gbps = 2 * slab.numel() * 8 / copy_s / 1e9
     del scratch
 
+    load_state = clocks_under_load(torch, lambda: ctx.forward_ntt_(slab)) if rank == 0 else None
+
     gather_ms = None
     if distributed and not args.skip_gather:
         # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI)
@@ -230,6 +273,7 @@ def main():
                 "avg_launch_ms": forward_s * 1e3,
                 "copy_rate": copy_gbps,  # measured read + write rate of a plain copy of the same 1 GiB slab
                 "frac_of_copy_rate": achieved_gbps / copy_gbps,
+                "under_load": load_state,  # rocm-smi while the kernel runs back to back: it sits at the power cap
             },
             "extras": {
                 "forward_poly_ntt_per_s": args.batch / forward_s,
