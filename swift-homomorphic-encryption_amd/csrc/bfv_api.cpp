@@ -402,9 +402,17 @@ int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli
         HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
         present_device = static_cast<const uint8_t*>(scratch.get());
     }
+    const uint64_t max_lazy = pc->max_lazy_product_accumulation_count(moduli_count);
+    // the carry-counting accumulator's reduction wants sums below 2^127: at most 2^127 / (p_max - 1)^2 products
+    uint64_t cadence = max_lazy;
+    for (uint32_t i = 0; i < moduli_count; ++i) {
+        const unsigned __int128 below = pc->moduli()[i] - 1;
+        if (below == 0) continue;
+        const unsigned __int128 limit = (static_cast<unsigned __int128>(1) << 127) / (below * below);
+        if (limit < cadence) cadence = static_cast<uint64_t>(limit);
+    }
     HEAMD_HIP_TRY(heamd::launch_inner_product_plain(cts, pts, present_device, out, pc->device_context(), poly_count,
-                                                    count, columns,
-                                                    pc->max_lazy_product_accumulation_count(moduli_count), stream));
+                                                    count, columns, max_lazy, cadence, stream));
     return HE_OK;
 }
 

@@ -68,10 +68,13 @@ hipError_t launch_adding_lazy_product(const uint64_t* lhs, const uint64_t* rhs, 
                                       const DeviceContext& ctx, hipStream_t stream);
 hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, const DeviceContext& ctx,
                                      hipStream_t stream);
-// out[col][poly][L][N] = sum_k cts[k][poly][L][N] * pts[col][k][L][N]  (skip where present[col*count+k] == 0)
+// out[col][poly][L][N] = sum_k cts[k][poly][L][N] * pts[col][k][L][N]  (skip where present[col*count+k] == 0).
+// max_lazy: the reference's reduction cadence (used as is by the 128-bit accumulator kernel for degree < 256);
+// cadence: products between reductions of the carry-counting accumulator: <= max_lazy and sums below 2^127
+// (0 = use the 128-bit kernel).
 hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
                                       uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
-                                      size_t columns, uint64_t max_lazy, hipStream_t stream);
+                                      size_t columns, uint64_t max_lazy, uint64_t cadence, hipStream_t stream);
 
 
 // word32_kernels.hip: PolyRq<UInt32> (4-byte words; every modulus <= 2^30 - 1)

@@ -254,6 +254,80 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// The same inner product on the carry-counting accumulator (device_math.hpp ProductSum: 4 multiply-adds and 3 carry
+// counts per product against ~18 instructions for a 128-bit multiply-add) with the residue row -- hence the modulus
+// -- wave-uniform: blockIdx.y covers kThreads words of ONE row (degree >= kThreads).  `cadence` products at most are
+// summed between reductions, chosen by the launcher so that a sum stays below 2^127 (reduce_product_sum's contract)
+// and never exceeds the reference's own lazy count (Bfv.swift:496-500); the canonical result does not depend on it.
+template <int POLYS, int COLS>
+__global__ void __launch_bounds__(kThreads)
+    inner_product_plain_rows_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
+                                    const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
+                                    const DeviceContext ctx, size_t count, size_t columns, uint64_t cadence) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) << logn;
+    const size_t block_word = blockIdx.y * static_cast<size_t>(kThreads);
+    const size_t word = block_word + threadIdx.x;
+    const size_t col0 = static_cast<size_t>(blockIdx.x) * COLS;
+    const DeviceModulus m = ctx.moduli[block_word >> logn];
+    ProductSum acc[COLS][POLYS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) acc[c][q] = product_sum_zero();
+    uint64_t since_reduce[COLS];
+    bool live[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        since_reduce[c] = 0;
+        live[c] = col0 + c < columns;
+    }
+    const uint64_t* ct_base = cts + word;
+    const uint64_t* pt_lane = pts + word;
+    size_t pt_column[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) pt_column[c] = (live[c] ? col0 + c : columns - 1) * count * words_per_poly;
+    uint64_t x_next[POLYS], y_next[COLS];
+    auto fetch = [&](size_t j) {
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) x_next[q] = ct_base[(j * POLYS + q) * words_per_poly];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) y_next[c] = pt_lane[pt_column[c] + j * words_per_poly];
+    };
+    if (count > 0) fetch(0);
+    for (size_t j = 0; j < count; ++j) {
+        uint64_t x[POLYS], y[COLS];
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) x[q] = x_next[q];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) y[c] = y_next[c];
+        if (j + 1 < count) fetch(j + 1);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            if (!live[c]) continue;
+            if (present != nullptr && present[(col0 + c) * count + j] == 0) continue;  // nil plaintext, Bfv.swift:486-489
+#pragma unroll
+            for (int q = 0; q < POLYS; ++q) product_sum_add(acc[c][q], x[q], y[c]);
+            if (++since_reduce[c] >= cadence) {
+                since_reduce[c] = 0;
+#pragma unroll
+                for (int q = 0; q < POLYS; ++q) {
+                    const uint64_t folded = reduce_product_sum(acc[c][q], m);
+                    acc[c][q] = product_sum_zero();
+                    acc[c][q].t = folded;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        if (!live[c]) continue;
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q)
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] = reduce_product_sum(acc[c][q], m);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_elementwise(ElementwiseOp op, uint64_t* lhs, const uint64_t* rhs, const DeviceContext& ctx,
@@ -308,11 +382,16 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
 template <int POLYS>
 hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
                                             uint64_t* out, const DeviceContext& ctx, size_t count, size_t columns,
-                                            uint64_t max_lazy, hipStream_t stream) {
+                                            uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
     constexpr int kCols = 4;
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
     const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
                     static_cast<unsigned>((words_per_poly + kThreads - 1) / kThreads));
+    if (ctx.degree >= kThreads && cadence != 0) {
+        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
+                           present_device, out, ctx, count, columns, cadence);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
                        present_device, out, ctx, count, columns, max_lazy);
     return hipGetLastError();
@@ -320,18 +399,18 @@ hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t*
 
 hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
                                       uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
-                                      size_t columns, uint64_t max_lazy, hipStream_t stream) {
+                                      size_t columns, uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
     if (columns == 0) return hipSuccess;
     switch (poly_count) {
         case 1:
             return launch_inner_product_plain_polys<1>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       stream);
+                                                       cadence, stream);
         case 2:
             return launch_inner_product_plain_polys<2>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       stream);
+                                                       cadence, stream);
         case 3:
             return launch_inner_product_plain_polys<3>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       stream);
+                                                       cadence, stream);
         default: return hipErrorInvalidValue;
     }
 }

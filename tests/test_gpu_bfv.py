@@ -338,3 +338,34 @@ def test_widest_moduli_match_oracle(oracle, bits):
     switched = heamd.to_host(ours.mod_switch_down(heamd.to_device(lhs), 2))
     assert np.array_equal(switched, np.stack([np.stack([ref.ciphertext_context().divide_and_round_q_last(p[None])[0]
                                                         for p in ct]) for ct in lhs]))
+
+
+@pytest.mark.parametrize("bits", [[62, 62, 62], [62, 45, 61, 62]])
+def test_inner_product_plain_reduction_cadence(oracle, bits):
+    """Bfv.innerProduct(ciphertexts:plaintexts:) where the lazy sum must be reduced inside the loop: with 62-bit moduli
+    at most 8 products fit below 2^127 (and 16 below the reference's own 2^128 bound), so 21 products cross several
+    reductions; degree 256 takes the carry-counting kernel, words at q - 1 maximise every sum, `nil` plaintexts
+    (Bfv.swift:486-489) shift the cadence column by column."""
+    degree = 256
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(len(bits))
+    count, columns = 21, 5
+    cts = _uniform(rng, (count, 2), moduli, degree)
+    pts = _uniform(rng, (columns, count), moduli, degree)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    cts[:, :, :, : degree // 2] = top[None, None, :, :]
+    pts[0] = top[None, :, :]
+    pts[1, :, :, ::2] = top[None, :, :]
+    present = np.ones((columns, count), dtype=np.uint8)
+    present[2, ::3] = 0
+    present[3, 5:] = 0
+    present[4, :] = 0
+    got = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), present, 2, columns))
+    for col in range(columns):
+        assert np.array_equal(got[col], ref.inner_product_plain(cts, pts[col], present[col])), col
+    unmasked = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), None, 2, columns))
+    for col in (0, 1, 4):
+        assert np.array_equal(unmasked[col], ref.inner_product_plain(cts, pts[col], None)), col
