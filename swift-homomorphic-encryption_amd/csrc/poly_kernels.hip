@@ -136,18 +136,25 @@ __global__ void __launch_bounds__(kThreads)
         const uint32_t k = static_cast<uint32_t>(i - poly * pairs_per_row);
         const U64x2* src = reinterpret_cast<const U64x2*>(in) + poly * moduli_count * pairs_per_row + k;
         U64x2* dst = reinterpret_cast<U64x2*>(out) + poly * last * pairs_per_row + k;
-        U64x2 r = src[static_cast<size_t>(last) * pairs_per_row];
-        r.x = add_mod(r.x, q_last_div2, q_last);
-        r.y = add_mod(r.y, q_last_div2, q_last);
+        // r - floor(q_last/2) with r = (x_last + floor(q_last/2)) mod q_last is the centred representative c of x_last
+        // (-q_last/2 <= c < q_last/2), so out_i = (x_i - c) q_last^-1 mod q_i: one reduction of |c| per row instead
+        // of reducing r and floor(q_last/2) separately -- the same canonical word as the reference's three steps
+        const U64x2 last_row = src[static_cast<size_t>(last) * pairs_per_row];
+        const uint64_t r0 = add_mod_uniform(last_row.x, q_last_div2, q_last);
+        const uint64_t r1 = add_mod_uniform(last_row.y, q_last_div2, q_last);
+        const bool negative0 = r0 < q_last_div2, negative1 = r1 < q_last_div2;
+        const uint64_t magnitude0 = negative0 ? q_last_div2 - r0 : r0 - q_last_div2;
+        const uint64_t magnitude1 = negative1 ? q_last_div2 - r1 : r1 - q_last_div2;
         for (uint32_t row = 0; row < last; ++row) {
             const DeviceModulus m = ctx.moduli[row];
             const U64x2 inv = inverse_q_last[row];
-            const uint64_t half_mod_qi = barrett_reduce64(q_last_div2, m.p, m.barrett64);
             U64x2 x = src[static_cast<size_t>(row) * pairs_per_row];
-            const uint64_t t0 = barrett_reduce64(r.x, m.p, m.barrett64);
-            const uint64_t t1 = barrett_reduce64(r.y, m.p, m.barrett64);
-            x.x = shoup_mul(sub_mod(add_mod(x.x, half_mod_qi, m.p), t0, m.p), inv.x, inv.y, m.p);
-            x.y = shoup_mul(sub_mod(add_mod(x.y, half_mod_qi, m.p), t1, m.p), inv.x, inv.y, m.p);
+            const uint64_t t0 = barrett_reduce64_uniform(magnitude0, m.p, m.barrett64);
+            const uint64_t t1 = barrett_reduce64_uniform(magnitude1, m.p, m.barrett64);
+            x.x = shoup_mul_uniform(negative0 ? add_mod_uniform(x.x, t0, m.p) : sub_mod_uniform(x.x, t0, m.p), inv.x,
+                                    inv.y, m.p);
+            x.y = shoup_mul_uniform(negative1 ? add_mod_uniform(x.y, t1, m.p) : sub_mod_uniform(x.y, t1, m.p), inv.x,
+                                    inv.y, m.p);
             dst[static_cast<size_t>(row) * pairs_per_row] = x;
         }
     }

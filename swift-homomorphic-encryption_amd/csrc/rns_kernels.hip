@@ -313,14 +313,18 @@ __global__ void __launch_bounds__(kThreads)
         const uint64_t* src = prod + pc * (L + 1) * n + k;
         const uint64_t* ct = ct_base + poly * ct_stride + c * L * n + k;
         uint64_t* dst = out + pc * L * n + k;
+        // divideAndRoundQLast by the centred representative of the special-modulus word (poly_kernels.hip has the
+        // derivation): out_i = (x_i - c) q_ks^-1 mod q_i
         const uint64_t r = add_mod_uniform(src[size_t(L) * n], q_last_div2, q_last);
+        const bool negative = r < q_last_div2;
+        const uint64_t magnitude = negative ? q_last_div2 - r : r - q_last_div2;
         for (uint32_t row = 0; row < L; ++row) {
             const DeviceModulus m = ks.moduli[row];
             const U64x2 inv = inverse_q_last[row];
-            const uint64_t half_mod_qi = barrett_reduce64_uniform(q_last_div2, m.p, m.barrett64);
-            const uint64_t t = barrett_reduce64_uniform(r, m.p, m.barrett64);
-            const uint64_t v = shoup_mul_uniform(
-                sub_mod_uniform(add_mod_uniform(src[row * n], half_mod_qi, m.p), t, m.p), inv.x, inv.y, m.p);
+            const uint64_t t = barrett_reduce64_uniform(magnitude, m.p, m.barrett64);
+            const uint64_t x = src[row * n];
+            const uint64_t v = shoup_mul_uniform(negative ? add_mod_uniform(x, t, m.p) : sub_mod_uniform(x, t, m.p),
+                                                 inv.x, inv.y, m.p);
             // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
             // replaces c1 (Bfv.swift:194-195)
             dst[row * n] = c < added_polys ? add_mod_uniform(ct[row * n], v, m.p) : v;
