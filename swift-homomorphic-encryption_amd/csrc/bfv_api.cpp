@@ -88,7 +88,7 @@ int drop_extended_base(const RnsToolLevel& tool, uint64_t* eval_qbsk, uint64_t* 
     DeviceContext scaled = tool.qbsk->device_context();
     scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
     const uint32_t rows = tool.qbsk->moduli_count();
-    HEAMD_HIP_TRY(heamd::launch_ntt(true, eval_qbsk, scaled, 0, rows, polys * rows, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(true, eval_qbsk, scaled, rows, polys, stream));
     HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(eval_qbsk, out, tool.device, polys, stream));
     return HE_OK;
 }
@@ -177,7 +177,7 @@ int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const ui
     HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext,
                                                        2 * ext, stream));
     const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(heamd::launch_ntt(false, lifted, qbsk, 0, static_cast<uint32_t>(rows), batch * 4 * rows, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(false, lifted, qbsk, static_cast<uint32_t>(rows), batch * 4, stream));
     HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, qbsk, batch, stream));  // Bfv+Multiply.swift:80-82
     return drop_extended_base(*tool, tensor, out, batch * 3, stream);
 }
@@ -445,7 +445,7 @@ int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count
     HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext,
                                                        2 * ext, stream));
     const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(heamd::launch_ntt(false, lifted, qbsk, 0, static_cast<uint32_t>(rows), count * 4 * rows, stream));
+    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(false, lifted, qbsk, static_cast<uint32_t>(rows), count * 4, stream));
     // maxProductCount = maxLazyProductAccumulationCount() / 2 because poly1 takes two products per pair (Bfv.swift:339)
     const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
     HEAMD_HIP_TRY(heamd::launch_tensor_accumulate(lifted, sum, qbsk, count, max_lazy ? max_lazy : 1, stream));

@@ -40,6 +40,7 @@ struct DeviceContext {
     uint32_t moduli_stride;        // moduli of the full context = row stride of inverse_q_last
     uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
     uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): NTT may trade folds for top bits
+    uint32_t headroom_prefix;      // how many leading moduli are in that range (the Q part of a [Q, Bsk] context)
 };
 
 // Image of a context whose moduli all fit UInt32 (<= 2^30 - 1), for slabs of 4-byte words: the same per-modulus

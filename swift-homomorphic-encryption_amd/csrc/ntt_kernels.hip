@@ -91,15 +91,19 @@ struct SpreadSource {
 template <int LOGN, int LOGT, int MODE, int ABLATE = 0, int SPREAD = kSourceSlab>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
-                      const SpreadSource spread) {
+                      const SpreadSource spread, uint32_t row_period, uint32_t row_offset) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    const size_t row = blockIdx.x;
-    const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
+    // workgroup b transforms row (b / mod_period) * row_period + row_offset + b % mod_period with modulus
+    // mod_base + b % mod_period: a launch covers a band of `mod_period` rows inside records of `row_period` rows
+    // (row_period = 0: the rows are consecutive)
+    const uint32_t within = static_cast<uint32_t>(blockIdx.x % mod_period);
+    const size_t row = row_period == 0 ? blockIdx.x : (blockIdx.x / mod_period) * size_t(row_period) + row_offset + within;
+    const uint32_t mi = mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, false) + (static_cast<size_t>(mi) << LOGN);
     uint64_t* __restrict__ x = slab + (row << LOGN);
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 #pragma unroll
             for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
         } else if constexpr (SPREAD != kSourceSlab) {
-            const size_t group = row / mod_period;  // poly * L + j
+            const size_t group = blockIdx.x / mod_period;  // poly * L + j
             const size_t poly = group / spread.L, j = group - poly * spread.L;
             global_load<LOGN, LOGE, LO0, LOGE>(v, tid, spread.base + poly * spread.stride + (j << LOGN));
             if constexpr (SPREAD == kSourceLift) {
@@ -202,15 +206,17 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 
 template <int LOGN, int LOGT, int MODE>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
-    ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period) {
+    ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
+                      uint32_t row_period, uint32_t row_offset) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    const size_t row = blockIdx.x;
-    const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
+    const uint32_t within = static_cast<uint32_t>(blockIdx.x % mod_period);  // row band as in ntt_forward_tiled
+    const size_t row = row_period == 0 ? blockIdx.x : (blockIdx.x / mod_period) * size_t(row_period) + row_offset + within;
+    const uint32_t mi = mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, true) + (static_cast<size_t>(mi) << LOGN);
     uint64_t* __restrict__ x = slab + (row << LOGN);
@@ -345,7 +351,8 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 
 template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
-                                uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream) {
+                                uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream,
+                                uint32_t row_period = 0, uint32_t row_offset = 0) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
     auto kernel = mode == kModeHeadroomHalved ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroomHalved, 0, SPREAD>
@@ -354,16 +361,18 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
                                               : ntt_forward_tiled<LOGN, LOGT, kModeExact, 0, SPREAD>;
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period, spread);
+                       mod_base, mod_period, spread, row_period, row_offset);
     return hipGetLastError();
 }
 
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
-                        uint32_t mod_period, size_t rows, hipStream_t stream) {
+                        uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
+                        uint32_t row_offset = 0) {
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
-                                                             SpreadSource{nullptr, 0, 0, 0}, stream);
+                                                             SpreadSource{nullptr, 0, 0, 0}, stream, row_period,
+                                                             row_offset);
     }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
@@ -373,7 +382,7 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
                                               : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period);
+                       mod_base, mod_period, row_period, row_offset);
     return hipGetLastError();
 }
 
@@ -388,7 +397,7 @@ hipError_t launch_occupancy_probe(uint64_t* slab, const DeviceContext& ctx, uint
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(512), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period, SpreadSource{nullptr, 0, 0, 0});
+                       mod_period, SpreadSource{nullptr, 0, 0, 0}, 0u, 0u);
     return hipGetLastError();
 }
 
@@ -403,7 +412,7 @@ hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1024), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period, SpreadSource{nullptr, 0, 0, 0});
+                       mod_period, SpreadSource{nullptr, 0, 0, 0}, 0u, 0u);
     return hipGetLastError();
 }
 
@@ -470,6 +479,34 @@ const char* ntt_variant_name(uint32_t log_degree) {
         case 14: return "ntt_tiled<16384, 1024 lanes x 16 words>";
         default: return "generic radix-2";
     }
+}
+
+hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t band_rows,
+                           uint32_t record_rows, uint32_t band_offset, size_t records, int mode, hipStream_t stream) {
+    const size_t rows = records * band_rows;
+    if (rows == 0) return hipSuccess;
+    if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
+    switch (ctx.log_degree) {
+        case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
+        case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
+        case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
+        default: return hipErrorNotSupported;
+    }
+}
+
+// [Q, Bsk] records (BEHZ): the first `headroom_prefix` moduli (the ciphertext moduli, when they are the usual <= 55-bit
+// primes) take the fold-free butterflies, the 61-bit Bsk primes the [0, 8p) ones -- two launches over row bands of
+// the same slab.  Falls back to one launch when the context has no such prefix or no tiled kernel.
+hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
+                            hipStream_t stream) {
+    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || records * record_rows > (size_t(1) << 30))
+        return launch_ntt(inverse, slab, ctx, 0, record_rows, records * record_rows, stream);
+    hipError_t e = launch_ntt_band(inverse, slab, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream);
+    if (e != hipSuccess) return e;
+    return launch_ntt_band(inverse, slab, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox,
+                           stream);
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,

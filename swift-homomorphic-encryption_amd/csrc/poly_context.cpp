@@ -261,13 +261,15 @@ u64 PolyContext::max_lazy_product_accumulation_count(uint32_t count) const {
 DeviceContext PolyContext::device_context(uint32_t count) const {
     DeviceContext d = dev_;
     d.moduli_count = count;
-    uint32_t approx = 1, headroom = 1;
+    uint32_t approx = 1, headroom = 1, prefix = 0;
     for (uint32_t i = 0; i < count; ++i) {
         if (moduli_[i] >= (static_cast<u64>(1) << 61)) approx = 0;
         if (moduli_[i] >= (static_cast<u64>(1) << 55) || moduli_[i] < (static_cast<u64>(1) << 40)) headroom = 0;
+        if (headroom != 0) prefix = i + 1;
     }
     d.approx_ok = approx;
     d.headroom_ok = headroom;
+    d.headroom_prefix = prefix;
     return d;
 }
 
