@@ -178,8 +178,19 @@ int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const ui
                                                        2 * ext, stream));
     const DeviceContext qbsk = tool->qbsk->device_context();
     HEAMD_HIP_TRY(heamd::launch_ntt_mixed(false, lifted, qbsk, static_cast<uint32_t>(rows), batch * 4, stream));
-    HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, qbsk, batch, stream));  // Bfv+Multiply.swift:80-82
-    return drop_extended_base(*tool, tensor, out, batch * 3, stream);
+    // tensor product (Bfv+Multiply.swift:80-82) and dropExtendedBase's inverse NTT: one kernel where the degree has a
+    // tiled transform (the products are formed as the inverse transform loads its row), two otherwise
+    DeviceContext scaled = tool->qbsk->device_context();
+    scaled.moduli = tool->qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
+    hipError_t fused = heamd::launch_ntt_tensor_inverse(lifted, tensor, scaled, static_cast<uint32_t>(rows), batch, stream);
+    if (fused == hipErrorNotSupported) {
+        (void)hipGetLastError();
+        HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, qbsk, batch, stream));
+        return drop_extended_base(*tool, tensor, out, batch * 3, stream);
+    }
+    HEAMD_HIP_TRY(fused);
+    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
+    return HE_OK;
 }
 
 // ------------------------------------------------------------------------------------------ relinearize

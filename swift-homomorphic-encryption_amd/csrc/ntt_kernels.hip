@@ -204,10 +204,14 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     }
 }
 
-template <int LOGN, int LOGT, int MODE>
+// TENSOR: the BEHZ tensor product (Bfv+Multiply.swift:80-82) fused into the load.  The launch covers records
+// (item, c), c in {0, 1, 2}, of `row_period` rows; the words of row r of record (item, c) are computed from the four
+// Eval polynomials (a0, a1, b0, b1) of the item at tensor_source + (item * 4 + k) * row_period * N + r * N as
+// a0 b0 | a0 b1 + a1 b0 | a1 b1 while they are loaded, instead of by a kernel that writes them for this one to read.
+template <int LOGN, int LOGT, int MODE, bool TENSOR = false>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
-                      uint32_t row_period, uint32_t row_offset) {
+                      uint32_t row_period, uint32_t row_offset, const uint64_t* __restrict__ tensor_source) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
@@ -228,7 +232,38 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
-        global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+        if constexpr (TENSOR) {
+            const size_t record = blockIdx.x / mod_period;
+            const size_t item = record / 3;
+            const uint32_t c = static_cast<uint32_t>(record - item * 3);  // wave-uniform
+            const size_t poly_words = static_cast<size_t>(row_period) << LOGN;
+            const uint64_t* const source =
+                tensor_source + item * 4 * poly_words + (static_cast<size_t>(row_offset + within) << LOGN);
+            const uint64_t p = mod.p, factor = mod.product_factor;
+            const int shift = static_cast<int>(mod.product_shift);
+            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
+#pragma unroll
+            for (int r = 0; r < E; r += 2) {
+                const size_t at = register_part<LOGN, LOGE, 0, S::R>(r) + lane_words;
+                if (c != 1) {
+                    const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
+                    const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
+                    v[r] = barrett_mul(a.x, b.x, p, factor, shift);
+                    v[r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
+                } else {
+                    const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
+                    const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
+                    const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
+                    const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
+                    v[r] = add_mod_uniform(barrett_mul(a0.x, b1.x, p, factor, shift),
+                                           barrett_mul(a1.x, b0.x, p, factor, shift), p);
+                    v[r + 1] = add_mod_uniform(barrett_mul(a0.y, b1.y, p, factor, shift),
+                                               barrett_mul(a1.y, b0.y, p, factor, shift), p);
+                }
+            }
+        } else {
+            global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+        }
         inverse_pass<LOGN, LOGE, 0, S::R, MODE>(v, tid, tw, mod, true);
         lds_store<LOGN, LOGE, 0, S::R>(v, tid, lds);
         if constexpr (S::P >= 3) {
@@ -368,7 +403,7 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
-                        uint32_t row_offset = 0) {
+                        uint32_t row_offset = 0, const uint64_t* tensor_source = nullptr) {
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
                                                              SpreadSource{nullptr, 0, 0, 0}, stream, row_period,
@@ -376,13 +411,23 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    auto kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
-                  : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
-                  : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
-                                              : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
+    using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t, uint32_t, uint32_t, const uint64_t*);
+    Kernel kernel;
+    if (tensor_source != nullptr) {
+        if (row_period == 0 || Schedule<LOGN, LOGE>::P == 1) return hipErrorInvalidValue;
+        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, true>
+                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, true>
+                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, true>
+                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, true>;
+    } else {
+        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
+                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
+                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
+                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period, row_period, row_offset);
+                       mod_base, mod_period, row_period, row_offset, tensor_source);
     return hipGetLastError();
 }
 
@@ -482,14 +527,15 @@ const char* ntt_variant_name(uint32_t log_degree) {
 }
 
 hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t band_rows,
-                           uint32_t record_rows, uint32_t band_offset, size_t records, int mode, hipStream_t stream) {
+                           uint32_t record_rows, uint32_t band_offset, size_t records, int mode, hipStream_t stream,
+                           const uint64_t* tensor_source = nullptr) {
     const size_t rows = records * band_rows;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
     switch (ctx.log_degree) {
-        case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
-        case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
-        case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset);
+        case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
+        case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
+        case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
         default: return hipErrorNotSupported;
     }
 }
@@ -507,6 +553,25 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
     if (e != hipSuccess) return e;
     return launch_ntt_band(inverse, slab, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox,
                            stream);
+}
+
+// Tensor product + inverse NTT of BEHZ multiplication in one kernel per row band: lifted [items][4][record_rows][N]
+// (Eval) -> out [items][3][record_rows][N] (Coeff).  hipErrorNotSupported where no tiled kernel exists (the caller
+// then runs launch_tensor + launch_ntt_mixed).
+hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, const DeviceContext& ctx, uint32_t record_rows,
+                                     size_t items, hipStream_t stream) {
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    const size_t records = items * 3;
+    if (!tiled || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
+    if (records == 0) return hipSuccess;
+    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
+    if (prefix == 0 || prefix == record_rows || ctx.approx_ok == 0)
+        return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records,
+                               ctx.approx_ok == 0 ? kModeExact : production_mode(ctx), stream, lifted);
+    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream, lifted);
+    if (e != hipSuccess) return e;
+    return launch_ntt_band(true, out, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox, stream,
+                           lifted);
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
