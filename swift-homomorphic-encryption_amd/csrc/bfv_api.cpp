@@ -206,6 +206,17 @@ hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t
     if (e != hipSuccess) return e;
     return heamd::launch_ntt(false, spread, ks, 0, L + 1, polys * L * (L + 1), stream);
 }
+// Bfv+Keys.swift:180-207: the lazy inner product of the decomposed target with the key, then back to Coeff.  One
+// kernel where the degree has a tiled NTT (the sums are formed as the inverse transform loads its row), two otherwise.
+hipError_t key_mac_to_coeff(const uint64_t* spread, const uint64_t* key, uint64_t* prod, const DeviceContext& ks,
+                            uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+    hipError_t e = heamd::launch_ntt_key_mac_inverse(spread, key, prod, ks, L, top_rows, polys, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
+    if (e != hipSuccess) return e;
+    return heamd::launch_ntt(true, prod, ks, 0, L + 1, polys * 2 * (L + 1), stream);
+}
 }  // namespace
 
 size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
@@ -241,8 +252,7 @@ int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, 
     const size_t ct_stride = 3 * size_t(L) * n;
     // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on poly 2 of every ciphertext
     HEAMD_HIP_TRY(spread_to_eval(ct3 + 2 * size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
+    HEAMD_HIP_TRY(key_mac_to_coeff(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, 2, stream));
     return HE_OK;
 }
@@ -298,9 +308,7 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
     HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
                                              inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
     HEAMD_HIP_TRY(spread_to_eval(rotated + size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_mac(spread, galois_key, prod, ks, L, ctx->impl->top_level() + 1, batch,
-                                               stream));
-    HEAMD_HIP_TRY(heamd::launch_ntt(true, prod, ks, 0, L + 1, batch * 2 * (L + 1), stream));
+    HEAMD_HIP_TRY(key_mac_to_coeff(spread, galois_key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, rotated, ct_stride, out, ks, L, batch, 1, stream));
     return HE_OK;
 }

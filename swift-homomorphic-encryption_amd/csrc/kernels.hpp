@@ -55,6 +55,8 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
                             hipStream_t stream);
 hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, const DeviceContext& ctx, uint32_t record_rows,
                                      size_t items, hipStream_t stream);
+hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
+                                      uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
 // measurement hook: variant 32 of the forward N=8192 kernel stamps phase boundaries into this buffer (16 words/row)
 hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer);

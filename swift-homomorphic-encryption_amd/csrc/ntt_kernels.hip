@@ -208,10 +208,22 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 // (item, c), c in {0, 1, 2}, of `row_period` rows; the words of row r of record (item, c) are computed from the four
 // Eval polynomials (a0, a1, b0, b1) of the item at tensor_source + (item * 4 + k) * row_period * N + r * N as
 // a0 b0 | a0 b1 + a1 b0 | a1 b1 while they are loaded, instead of by a kernel that writes them for this one to read.
-template <int LOGN, int LOGT, int MODE, bool TENSOR = false>
+// KEYMAC: the lazy inner product with the key-switching key (Bfv+Keys.swift:180-202) fused into the load.  Records
+// are (polynomial, c), c in {0, 1}, of row_period = L + 1 rows; word k of row r is
+// sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] mod ks_modulus[r], accumulated in the carry-counting form.
+constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2;
+struct InverseSource {
+    const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
+    const uint64_t* second;  // key MAC: the key
+    uint32_t L, top_rows;    // key MAC: source moduli, rows per key polynomial
+};
+
+template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab>
 __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
-                      uint32_t row_period, uint32_t row_offset, const uint64_t* __restrict__ tensor_source) {
+                      uint32_t row_period, uint32_t row_offset, const InverseSource source_spec) {
+    constexpr bool TENSOR = SOURCE == kInverseFromTensor;
+    const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
@@ -260,6 +272,30 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
                     v[r + 1] = add_mod_uniform(barrett_mul(a0.y, b1.y, p, factor, shift),
                                                barrett_mul(a1.y, b0.y, p, factor, shift), p);
                 }
+            }
+        } else if constexpr (SOURCE == kInverseFromKeyMac) {
+            const size_t record = blockIdx.x / mod_period;  // poly * 2 + c
+            const size_t poly = record >> 1, c = record & 1;
+            const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
+            const uint32_t r = row_offset + within;
+            const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
+            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
+            const uint64_t* const spread_row =
+                source_spec.first + ((poly * L * (L + 1) + r) << LOGN) + lane_words;            // + j (L+1) N
+            const uint64_t* const key_rows =
+                source_spec.second + ((c * top_rows + key_row) << LOGN) + lane_words;           // + j 2 top_rows N
+#pragma unroll
+            for (int q = 0; q < E; q += 2) {
+                const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
+                ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+                for (uint32_t j = 0; j < L; ++j) {
+                    const U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(j) * (L + 1)) << LOGN) + at);
+                    const U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(j) * 2 * top_rows) << LOGN) + at);
+                    product_sum_add(acc0, xs.x, ks.x);
+                    product_sum_add(acc1, xs.y, ks.y);
+                }
+                v[q] = reduce_product_sum(acc0, mod);
+                v[q + 1] = reduce_product_sum(acc1, mod);
             }
         } else {
             global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
@@ -403,7 +439,8 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
-                        uint32_t row_offset = 0, const uint64_t* tensor_source = nullptr) {
+                        uint32_t row_offset = 0, int source = kInverseFromSlab,
+                        const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
                                                              SpreadSource{nullptr, 0, 0, 0}, stream, row_period,
@@ -411,14 +448,19 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t, uint32_t, uint32_t, const uint64_t*);
+    using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t, uint32_t, uint32_t, const InverseSource);
     Kernel kernel;
-    if (tensor_source != nullptr) {
-        if (row_period == 0 || Schedule<LOGN, LOGE>::P == 1) return hipErrorInvalidValue;
-        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, true>
-                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, true>
-                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, true>
-                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, true>;
+    if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
+    if (source == kInverseFromTensor) {
+        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, kInverseFromTensor>
+                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, kInverseFromTensor>
+                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromTensor>
+                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromTensor>;
+    } else if (source == kInverseFromKeyMac) {
+        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, kInverseFromKeyMac>
+                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, kInverseFromKeyMac>
+                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromKeyMac>
+                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromKeyMac>;
     } else {
         kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
                  : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
@@ -427,7 +469,7 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period, row_period, row_offset, tensor_source);
+                       mod_base, mod_period, row_period, row_offset, source_spec);
     return hipGetLastError();
 }
 
@@ -528,14 +570,15 @@ const char* ntt_variant_name(uint32_t log_degree) {
 
 hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t band_rows,
                            uint32_t record_rows, uint32_t band_offset, size_t records, int mode, hipStream_t stream,
-                           const uint64_t* tensor_source = nullptr) {
+                           int source = kInverseFromSlab,
+                           const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
     const size_t rows = records * band_rows;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
     switch (ctx.log_degree) {
-        case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
-        case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
-        case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, tensor_source);
+        case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
+        case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
+        case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
         default: return hipErrorNotSupported;
     }
 }
@@ -567,11 +610,26 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
     const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
     if (prefix == 0 || prefix == record_rows || ctx.approx_ok == 0)
         return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records,
-                               ctx.approx_ok == 0 ? kModeExact : production_mode(ctx), stream, lifted);
-    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream, lifted);
+                               ctx.approx_ok == 0 ? kModeExact : production_mode(ctx), stream, kInverseFromTensor,
+                               InverseSource{lifted, nullptr, 0, 0});
+    const InverseSource spec{lifted, nullptr, 0, 0};
+    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream,
+                                   kInverseFromTensor, spec);
     if (e != hipSuccess) return e;
     return launch_ntt_band(true, out, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox, stream,
-                           lifted);
+                           kInverseFromTensor, spec);
+}
+
+// Key-switching inner product + inverse NTT in one kernel (Bfv+Keys.swift:180-207): spread [polys][L][L+1][N] (Eval),
+// key [top][2][top_rows][N] -> out [polys][2][L+1][N] (Coeff).  hipErrorNotSupported where no tiled kernel exists.
+hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
+                                      uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;
+    const size_t records = polys * 2;
+    if (!tiled || L > 8 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
+    if (records == 0) return hipSuccess;
+    return launch_ntt_band(true, out, ks, 0, L + 1, L + 1, 0, records, production_mode(ks), stream, kInverseFromKeyMac,
+                           InverseSource{spread, key, L, top_rows});
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
