@@ -205,6 +205,14 @@ int BfvContext::build_tool(uint32_t k) {
 
     for (size_t i = 0; i < L; ++i) arena.at<DeviceModulus>(o_q_moduli)[i] = barrett_constants(q[i]);
     for (size_t j = 0; j < L + 2; ++j) arena.at<DeviceModulus>(o_ext_moduli)[j] = barrett_constants(ext[j]);
+    // the lift / floor kernels keep sums of unfolded residues mod a Bsk prime: 6 Bsk_j must stay below 2^63.  The
+    // reference's Bsk primes sit just above 2^60 (2^28 for UInt32 contexts), RnsTool.swift:28-66, so this always holds.
+    for (size_t j = 0; j <= L; ++j) {
+        if (bsk[j] >= (static_cast<u64>(1) << 63) / 6) {
+            set_last_error("Bsk prime too large for the unfolded BEHZ sums");
+            return HE_ERR_UNSUPPORTED;
+        }
+    }
     for (size_t i = 0; i < L; ++i) {
         u64 inverse = 0;
         if (!inverse_mod(punctured_product(q, L, i, q[i]), q[i], inverse)) return HE_ERR_NOT_INVERTIBLE;

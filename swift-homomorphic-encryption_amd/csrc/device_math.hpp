@@ -244,7 +244,8 @@ __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t w
 // floor(w 2^64 / p).  Uses the halved factor so that every partial-product column fits the 64-bit addend of a
 // v_mad_u64_u32 (a0 b1 + a1 b0 + hi(a0 b0) < 2^64 for a < 2^63, b < 2^63): q = floor(x (wf >> 1) / 2^64) exactly,
 // x w - q 2p in [0, 3p).  The constants stay in SGPRs (each instruction reads at most one).
-__device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
+// _lazy: the product before its two folds, in [0, 3p)
+__device__ __forceinline__ uint64_t shoup_mul_uniform_lazy(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
     const uint64_t wf_half = wf >> 1, neg_2p = 0 - 2 * p;
     const uint32_t a0 = lo32(x), a1 = hi32(x), b0 = lo32(wf_half), b1 = hi32(wf_half);
     uint64_t low, cross, q, carry;
@@ -269,8 +270,10 @@ __device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, ui
         "v_add3_u32 %1, %1, %2, %3"
         : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
         : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
-    const uint64_t r = pack64(lo32(acc), hi32(acc) + u0 + u3);
-    return csub_uniform(csub_uniform(r, 2 * p), p);
+    return pack64(lo32(acc), hi32(acc) + u0 + u3);
+}
+__device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
+    return csub_uniform(csub_uniform(shoup_mul_uniform_lazy(x, w, wf, p), 2 * p), p);
 }
 
 // operands canonical, p <= 2^62 - 1: every intermediate is below 2p < 2^63
@@ -357,7 +360,8 @@ __device__ __forceinline__ U128 product_sum_value(const ProductSum& s) {
 
 // x mod p for any 64-bit x with wave-uniform p and factor = floor(2^64 / p).  For p >= 2^32 the factor is a single
 // 32-bit word and the quotient estimate is two multiply-adds; smaller moduli take the general path.
-__device__ __forceinline__ uint64_t barrett_reduce64_uniform(uint64_t x, uint64_t p, uint64_t factor) {
+// _lazy: before the final fold, in [0, 2p)
+__device__ __forceinline__ uint64_t barrett_reduce64_uniform_lazy(uint64_t x, uint64_t p, uint64_t factor) {
     if (hi32(factor) != 0) return barrett_reduce64(x, p, factor);  // uniform branch: p < 2^32
     uint64_t t, qp, carry, carry2;
     uint32_t q_high;
@@ -373,7 +377,10 @@ __device__ __forceinline__ uint64_t barrett_reduce64_uniform(uint64_t x, uint64_
         : "=&v"(qp), "=&v"(q_high), "=&s"(carry2)
         : "v"(q), "s"(lo32(p)), "s"(hi32(p)));
     const uint64_t q_times_p = pack64(lo32(qp), hi32(qp) + q_high);
-    return csub63<true>(x - q_times_p, 0 - p);
+    return x - q_times_p;
+}
+__device__ __forceinline__ uint64_t barrett_reduce64_uniform(uint64_t x, uint64_t p, uint64_t factor) {
+    return csub63<true>(barrett_reduce64_uniform_lazy(x, p, factor), 0 - p);
 }
 
 // Canonical residue of a ProductSum whose value is < 2^127 (at most 8 products of operands < 2^62):
@@ -384,6 +391,14 @@ __device__ __forceinline__ uint64_t reduce_product_sum(const ProductSum& s, cons
     const uint64_t high = shoup_mul_uniform(v.hi, m.two64_mod_p, m.two64_mod_p_shoup, m.p);
     const uint64_t low = barrett_reduce64_uniform(v.lo, m.p, m.barrett64);
     return add_mod_uniform(high, low, m.p);
+}
+// The same residue class, unfolded: a value in [0, 5p) (needs 5p < 2^64; callers that feed it to another exact product
+// or fold a whole sum at once skip four conditional subtracts).
+template <typename Modulus>
+__device__ __forceinline__ uint64_t reduce_product_sum_lazy(const ProductSum& s, const Modulus& m) {
+    const U128 v = product_sum_value(s);
+    return shoup_mul_uniform_lazy(v.hi, m.two64_mod_p, m.two64_mod_p_shoup, m.p) +
+           barrett_reduce64_uniform_lazy(v.lo, m.p, m.barrett64);
 }
 
 // Barrett on a product x*y < p^2 (Modulus.swift:349-360): factor = floor(2^(bits(p)+62)/p), shift = bits(p)-2.

@@ -89,10 +89,13 @@ __global__ void __launch_bounds__(kThreads)
             ProductSum sum = product_sum_zero();
 #pragma unroll
             for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
-            const uint64_t converted = reduce_product_sum(sum, m);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
-            // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants
-            dst[(L + j) * n] = add_mod_uniform(converted, shoup_mul_pair(centered, tool.q_mod_bsk_scaled[j], m.p), m.p);
+            // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
+            // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
+            const U64x2 scaled = tool.q_mod_bsk_scaled[j];
+            const uint64_t unfolded =
+                reduce_product_sum_lazy(sum, m) + shoup_mul_uniform_lazy(centered, scaled.x, scaled.y, m.p);
+            dst[(L + j) * n] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
         }
     }
 }
@@ -121,7 +124,9 @@ __global__ void __launch_bounds__(kThreads)
             ProductSum sum = product_sum_zero();
 #pragma unroll
             for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
-            const uint64_t difference = src[(L + j) * n] + m.p - reduce_product_sum(sum, m);
+            // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
+            // checked when the tool is built), which is all the next exact product needs
+            const uint64_t difference = src[(L + j) * n] + 5 * m.p - reduce_product_sum_lazy(sum, m);
             if (j < L) {
                 z[j] = shoup_mul_pair(difference, tool.floor_scale_b[j], m.p);
             } else {
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(kThreads)
         ProductSum alpha_sum = product_sum_zero();
 #pragma unroll
         for (int i = 0; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
-        uint64_t alpha = reduce_product_sum(alpha_sum, msk);
+        uint64_t alpha = reduce_product_sum_lazy(alpha_sum, msk);  // < 5 m_sk
         alpha = shoup_mul_pair(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
