@@ -369,3 +369,24 @@ def test_inner_product_plain_reduction_cadence(oracle, bits):
     unmasked = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), None, 2, columns))
     for col in (0, 1, 4):
         assert np.array_equal(unmasked[col], ref.inner_product_plain(cts, pts[col], None)), col
+
+
+@pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55])])
+def test_fused_transform_loads_other_degrees(oracle, degree, bits):
+    """The transforms with a fused load stage (key-switching decomposition, plaintext lift, tensor product, key inner
+    product) exist per tiled degree: N = 4096 and 16384 instantiations, headroom and mixed [Q, Bsk] bands, and moduli
+    that force the exact butterflies, word for word against the oracle."""
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli, L = q[:-1], len(q) - 1
+    rng = np.random.default_rng(degree + len(bits))
+    lhs, rhs = _uniform(rng, (1, 2), moduli, degree), _uniform(rng, (1, 2), moduli, degree)
+    product = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(product, ref.mul(lhs, rhs))
+    key = _uniform(rng, (L, 2), q, degree)
+    relin = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key)))
+    assert np.array_equal(relin, ref.relinearize(product, key))
+    values = rng.integers(0, t, size=(2, degree), dtype=np.uint64)
+    lifted = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(values)))
+    assert np.array_equal(lifted, np.concatenate([ref.plaintext_to_eval(v) for v in values]).reshape(lifted.shape))
