@@ -371,7 +371,8 @@ def test_inner_product_plain_reduction_cadence(oracle, bits):
         assert np.array_equal(unmasked[col], ref.inner_product_plain(cts, pts[col], None)), col
 
 
-@pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55])])
+@pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55]),
+                                         (8192, [55, 61, 50, 55])])
 def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     """The transforms with a fused load stage (key-switching decomposition, plaintext lift, tensor product, key inner
     product) exist per tiled degree: N = 4096 and 16384 instantiations, headroom and mixed [Q, Bsk] bands, and moduli
