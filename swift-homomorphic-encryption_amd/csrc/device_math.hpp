@@ -350,6 +350,37 @@ __device__ __forceinline__ void product_sum_add_uniform(ProductSum& s, uint64_t 
         : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "+v"(s.c_carry), "=&s"(carry)
         : "v"(lo32(a)), "v"(hi32(a)), "s"(lo32(b)), "s"(hi32(b)));
 }
+// A sum that starts with its first product (b wave-uniform): no zeroed accumulator to add onto and only the one carry
+// the first product can produce (the cross column).
+__device__ __forceinline__ ProductSum product_sum_first_uniform(uint64_t a, uint64_t b) {
+    ProductSum s;
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %4, %5, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %4, %5, %8, 0\n\t"
+        "v_mad_u64_u32 %1, %4, %6, %7, %1\n\t"
+        "v_addc_co_u32 %3, %4, 0, 0, %4\n\t"
+        "v_mad_u64_u32 %2, %4, %6, %8, 0"
+        : "=&v"(s.t), "=&v"(s.c), "=&v"(s.h), "=&v"(s.c_carry), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "s"(lo32(b)), "s"(hi32(b)));
+    s.t_carry = 0;
+    return s;
+}
+
+// the same with b in VGPRs
+__device__ __forceinline__ ProductSum product_sum_first(uint64_t a, uint64_t b) {
+    ProductSum s;
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %4, %5, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %4, %5, %8, 0\n\t"
+        "v_mad_u64_u32 %1, %4, %6, %7, %1\n\t"
+        "v_addc_co_u32 %3, %4, 0, 0, %4\n\t"
+        "v_mad_u64_u32 %2, %4, %6, %8, 0"
+        : "=&v"(s.t), "=&v"(s.c), "=&v"(s.h), "=&v"(s.c_carry), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "v"(lo32(b)), "v"(hi32(b)));
+    s.t_carry = 0;
+    return s;
+}
+
 // the sum mod 2^128
 __device__ __forceinline__ U128 product_sum_value(const ProductSum& s) {
     U128 r;

@@ -287,8 +287,10 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
 #pragma unroll
             for (int q = 0; q < E; q += 2) {
                 const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
-                ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
-                for (uint32_t j = 0; j < L; ++j) {
+                const U64x2 x0 = *reinterpret_cast<const U64x2*>(spread_row + at);
+                const U64x2 k0 = *reinterpret_cast<const U64x2*>(key_rows + at);
+                ProductSum acc0 = product_sum_first(x0.x, k0.x), acc1 = product_sum_first(x0.y, k0.y);
+                for (uint32_t j = 1; j < L; ++j) {
                     const U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(j) * (L + 1)) << LOGN) + at);
                     const U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(j) * 2 * top_rows) << LOGN) + at);
                     product_sum_add(acc0, xs.x, ks.x);

@@ -73,9 +73,9 @@ __global__ void __launch_bounds__(kThreads)
             y[i] = shoup_mul_pair(x, tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
-        ProductSum acc = product_sum_zero();
+        ProductSum acc = product_sum_first_uniform(y[0], tool.q_to_ext[(L + 1) * L + 0]);
 #pragma unroll
-        for (int i = 0; i < L; ++i) product_sum_add_uniform(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
+        for (int i = 1; i < L; ++i) product_sum_add_uniform(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
         // the (L+2)'th extended modulus is mTilde = 2^32 at the top level; a lower-level tool takes a prefix of
         // [Bsk..., mTilde] and finds a Bsk prime there (the reference's own behaviour, reproduced as is)
         const DeviceModulus last = tool.ext_moduli[L + 1];
@@ -86,9 +86,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            ProductSum sum = product_sum_zero();
+            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_bsk_scaled[j * L + 0]);
 #pragma unroll
-            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
+            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
             // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
             // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            ProductSum sum = product_sum_zero();
+            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_ext[j * L + 0]);
 #pragma unroll
-            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
+            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
             // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
             // checked when the tool is built), which is all the next exact product needs
             const uint64_t difference = src[(L + j) * n] + 5 * m.p - reduce_product_sum_lazy(sum, m);
@@ -135,18 +135,18 @@ __global__ void __launch_bounds__(kThreads)
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
         const DeviceModulus msk = tool.ext_moduli[L];
-        ProductSum alpha_sum = product_sum_zero();
+        ProductSum alpha_sum = product_sum_first_uniform(z[0], tool.b_to_msk[0]);
 #pragma unroll
-        for (int i = 0; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
+        for (int i = 1; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
         uint64_t alpha = reduce_product_sum_lazy(alpha_sum, msk);  // < 5 m_sk
         alpha = shoup_mul_pair(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
         for (int row = 0; row < L; ++row) {
             const DeviceModulus m = tool.q_moduli[row];
-            ProductSum sum = product_sum_zero();
+            ProductSum sum = product_sum_first_uniform(z[0], tool.b_to_q[row * L + 0]);
 #pragma unroll
-            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, z[i], tool.b_to_q[row * L + i]);
+            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, z[i], tool.b_to_q[row * L + i]);
             const uint64_t converted = reduce_product_sum(sum, m);
             // RnsTool.swift:436-446: alpha > m_sk/2 ? (m_sk - alpha) (B mod q) : alpha (-B mod q); the second form is
             // the negation of alpha (B mod q), so one product serves both
@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const DeviceModulus m = tool.t_gamma[j];
-            ProductSum sum = product_sum_zero();
+            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_t_gamma[j * L + 0]);
 #pragma unroll
-            for (int i = 0; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_t_gamma[j * L + i]);
+            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_t_gamma[j * L + i]);
             converted[j] = shoup_mul_pair(reduce_product_sum(sum, m), tool.neg_inv_q_mod_t_gamma[j], m.p);
         }
         const DeviceModulus t = tool.t_gamma[0];
