@@ -295,12 +295,93 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ---- 8 bytes per lane (rows and records 8-byte aligned: degree a multiple of 64, aligned buffers) ------------------
+// The packed row is a big-endian bit stream of `width`-bit fields; byte j of the stream is bits [8j, 8j + 8).
+__device__ __forceinline__ uint64_t byte_swap64(uint64_t v) {
+    return (static_cast<uint64_t>(__builtin_bswap32(static_cast<uint32_t>(v))) << 32) |
+           __builtin_bswap32(static_cast<uint32_t>(v >> 32));
+}
+
+// one lane = 8 output bytes = stream bits [64 c, 64 c + 64) of one row
+__global__ void __launch_bounds__(256)
+    serialize_words_kernel(const uint64_t* __restrict__ slab, uint64_t* __restrict__ words, const SerializeLayout layout,
+                           uint32_t logn, uint32_t skip, size_t total_words) {
+    const uint64_t words_per_poly = layout.byte_offset[layout.rows] >> 3;
+    const uint32_t n = 1u << logn;
+    for (size_t idx = blockIdx.x * size_t(256) + threadIdx.x; idx < total_words; idx += size_t(gridDim.x) * 256) {
+        const size_t poly = idx / words_per_poly;
+        const uint64_t word_in_poly = idx - poly * words_per_poly;
+        const uint32_t r = row_of_byte(layout, word_in_poly << 3);
+        const uint32_t w = layout.width[r];
+        const uint64_t bit = ((word_in_poly << 3) - layout.byte_offset[r]) << 3;
+        uint32_t k = static_cast<uint32_t>(bit / w), offset = static_cast<uint32_t>(bit - uint64_t(k) * w);
+        const uint64_t* row = slab + ((poly * layout.rows + r) << logn);
+        const uint64_t field_mask = w == 64 ? ~uint64_t(0) : ((uint64_t(1) << w) - 1);
+        uint64_t out = 0;
+        uint32_t needed = 64;
+        while (needed > 0 && k < n) {
+            const uint32_t available = w - offset;
+            const uint32_t take = available < needed ? available : needed;
+            const uint64_t value = (row[k] >> skip) & field_mask;
+            const uint64_t piece = (value >> (available - take)) & (take == 64 ? ~uint64_t(0) : ((uint64_t(1) << take) - 1));
+            out = (take == 64 ? 0 : (out << take)) | piece;
+            needed -= take;
+            offset += take;
+            if (offset == w) {
+                offset = 0;
+                ++k;
+            }
+        }
+        out = needed == 64 ? 0 : (out << needed);  // zero padding after the last coefficient
+        words[idx] = byte_swap64(out);
+    }
+}
+
+// one lane = one coefficient, read from the two aligned 8-byte words that hold its field
+__global__ void __launch_bounds__(256)
+    deserialize_words_kernel(const uint64_t* __restrict__ words, uint64_t* __restrict__ slab, const SerializeLayout layout,
+                             uint32_t logn, uint32_t skip, size_t words_per_poly, size_t total_coefficients) {
+    const uint32_t n = 1u << logn;
+    for (size_t idx = blockIdx.x * size_t(256) + threadIdx.x; idx < total_coefficients;
+         idx += size_t(gridDim.x) * 256) {
+        const size_t row_index = idx >> logn;
+        const uint32_t k = static_cast<uint32_t>(idx) & (n - 1);
+        const size_t poly = row_index / layout.rows;
+        const uint32_t r = static_cast<uint32_t>(row_index - poly * layout.rows);
+        const uint32_t w = layout.width[r];
+        const uint64_t row_words = (layout.byte_offset[r + 1] - layout.byte_offset[r]) >> 3;
+        const uint64_t* row = words + poly * words_per_poly + (layout.byte_offset[r] >> 3);
+        const uint64_t bit = uint64_t(k) * w;
+        const uint64_t first = bit >> 6;
+        const uint32_t offset = static_cast<uint32_t>(bit & 63);
+        const uint64_t high = byte_swap64(row[first]);
+        const uint64_t low = first + 1 < row_words ? byte_swap64(row[first + 1]) : 0;  // past the row: zero bits
+        const uint64_t aligned = offset == 0 ? high : ((high << offset) | (low >> (64 - offset)));
+        slab[idx] = (aligned >> (64 - w)) << skip;
+    }
+}
+
+}  // namespace
+
+namespace {
+// every row and the record itself start on an 8-byte boundary of an 8-byte aligned buffer
+bool word_aligned(const SerializeLayout& layout, const void* bytes) {
+    if ((reinterpret_cast<uintptr_t>(bytes) & 7) != 0) return false;
+    for (uint32_t r = 0; r <= layout.rows; ++r)
+        if ((layout.byte_offset[r] & 7) != 0) return false;
+    return true;
+}
 }  // namespace
 
 hipError_t launch_serialize(const uint64_t* slab, uint8_t* bytes, const SerializeLayout& layout, uint32_t log_degree,
                             uint32_t skip_lsbs, size_t batch, hipStream_t stream) {
     const size_t total = batch * layout.byte_offset[layout.rows];
     if (total == 0) return hipSuccess;
+    if (word_aligned(layout, bytes)) {
+        hipLaunchKernelGGL(serialize_words_kernel, dim3(grid_for(total >> 3)), dim3(256), 0, stream, slab,
+                           reinterpret_cast<uint64_t*>(bytes), layout, log_degree, skip_lsbs, total >> 3);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(serialize_kernel, dim3(grid_for(total)), dim3(256), 0, stream, slab, bytes, layout, log_degree,
                        skip_lsbs, total);
     return hipGetLastError();
@@ -310,6 +391,12 @@ hipError_t launch_deserialize(const uint8_t* bytes, uint64_t* slab, const Serial
                               uint32_t skip_lsbs, size_t bytes_per_poly, size_t batch, hipStream_t stream) {
     const size_t total = (batch * layout.rows) << log_degree;
     if (total == 0) return hipSuccess;
+    if (word_aligned(layout, bytes) && (bytes_per_poly & 7) == 0) {
+        hipLaunchKernelGGL(deserialize_words_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint64_t*>(bytes), slab, layout, log_degree, skip_lsbs,
+                           bytes_per_poly >> 3, total);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(deserialize_kernel, dim3(grid_for(total)), dim3(256), 0, stream, bytes, slab, layout, log_degree,
                        skip_lsbs, bytes_per_poly, total);
     return hipGetLastError();
