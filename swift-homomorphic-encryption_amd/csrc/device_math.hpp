@@ -257,20 +257,7 @@ __device__ __forceinline__ uint64_t shoup_mul_uniform_lazy(uint64_t x, uint64_t 
         "v_mad_u64_u32 %2, %3, %5, %7, %1"
         : "=&v"(low), "=&v"(cross), "=&v"(q), "=&s"(carry)
         : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
-    const uint32_t q0 = lo32(q), q1 = hi32(q), w0 = lo32(w), w1 = hi32(w);
-    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
-    uint64_t acc, carry2;
-    uint32_t u0, u1, u2, u3;
-    asm("v_mad_u64_u32 %0, %5, %6, %8, 0\n\t"
-        "v_mul_lo_u32 %1, %6, %9\n\t"
-        "v_mul_lo_u32 %2, %7, %8\n\t"
-        "v_mad_u64_u32 %0, %5, %10, %12, %0\n\t"
-        "v_mul_lo_u32 %3, %10, %13\n\t"
-        "v_mul_lo_u32 %4, %11, %12\n\t"
-        "v_add3_u32 %1, %1, %2, %3"
-        : "=&v"(acc), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&s"(carry2)
-        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(q0), "v"(q1), "s"(n0), "s"(n1));
-    return pack64(lo32(acc), hi32(acc) + u0 + u3);
+    return shoup_low64<true, false>(0, x, w, q, neg_2p);
 }
 __device__ __forceinline__ uint64_t shoup_mul_uniform(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
     return csub_uniform(csub_uniform(shoup_mul_uniform_lazy(x, w, wf, p), 2 * p), p);
