@@ -368,11 +368,22 @@ __device__ __forceinline__ ProductSum product_sum_first(uint64_t a, uint64_t b) 
     return s;
 }
 
-// the sum mod 2^128
+// the sum mod 2^128: lo = t + (c << 32), hi = h + t_carry + (c >> 32) + (c_carry << 32) + carry(lo), as one five-
+// instruction carry chain through an SGPR pair (the C form costs twice that in 64-bit adds, compares and moves)
 __device__ __forceinline__ U128 product_sum_value(const ProductSum& s) {
+    uint32_t lo_high, hi_low, hi_high;
+    uint64_t carry;
+    asm("v_add_co_u32 %0, %3, %4, %5\n\t"          // t_hi + c_lo
+        "v_addc_co_u32 %1, %3, %6, %7, %3\n\t"     // h_lo + c_hi + carry
+        "v_addc_co_u32 %2, %3, %8, %9, %3\n\t"     // h_hi + c_carry + carry
+        "v_add_co_u32 %1, %3, %1, %10\n\t"         // + t_carry
+        "v_addc_co_u32 %2, %3, 0, %2, %3"
+        : "=&v"(lo_high), "=&v"(hi_low), "=&v"(hi_high), "=&s"(carry)
+        : "v"(hi32(s.t)), "v"(lo32(s.c)), "v"(lo32(s.h)), "v"(hi32(s.c)), "v"(hi32(s.h)), "v"(s.c_carry),
+          "v"(s.t_carry));
     U128 r;
-    r.lo = s.t + (s.c << 32);
-    r.hi = s.h + s.t_carry + (s.c >> 32) + (static_cast<uint64_t>(s.c_carry) << 32) + (r.lo < s.t ? 1 : 0);
+    r.lo = pack64(lo32(s.t), lo_high);
+    r.hi = pack64(hi_low, hi_high);
     return r;
 }
 
