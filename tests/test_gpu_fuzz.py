@@ -1,0 +1,47 @@
+"""Seeded sweep over parameter shapes no hand-written case names: random moduli sizes (40..62 bits, mixed), 1..5
+ciphertext moduli, degrees with and without tiled transforms -- NTT, mod-switch, ct x ct and relinearize word for word
+against the oracle.  Catches mode-selection mistakes (headroom / [0, 8p) / exact butterflies, mixed [Q, Bsk] bands, fused
+loads) that depend on how the moduli happen to line up."""
+import random
+
+import numpy as np
+import pytest
+
+import heamd
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [40, 45, 50, 54, 55, 58, 60, 61, 62]
+
+
+def _uniform(rng, prefix, moduli, degree):
+    rows = [rng.integers(0, q, size=tuple(prefix) + (degree,), dtype=np.uint64) for q in moduli]
+    return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
+
+
+@pytest.mark.parametrize("seed", [11, 23, 47])
+def test_random_parameter_shapes(oracle, seed):
+    rnd = random.Random(seed)
+    for trial in range(6):
+        degree = rnd.choice([256, 4096, 8192])
+        L = rnd.randint(1, 5)
+        bits = [rnd.choice(SIZES) for _ in range(L + 1)]
+        q = oracle.generate_primes(bits, False, degree)
+        t = oracle.generate_primes([17], True, degree)[0]
+        ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+        rng = np.random.default_rng(seed * 100 + trial)
+        moduli = q[:-1]
+        label = (degree, bits)
+        x = _uniform(rng, (3,), moduli, degree)
+        pc, rc = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+        assert np.array_equal(heamd.to_host(pc.forward_ntt_(heamd.to_device(x))), rc.forward_ntt(x)), label
+        assert np.array_equal(heamd.to_host(pc.inverse_ntt_(heamd.to_device(x))), rc.inverse_ntt(x)), label
+        if L >= 2:
+            assert np.array_equal(heamd.to_host(pc.divide_and_round_q_last(heamd.to_device(x))),
+                                  rc.divide_and_round_q_last(x)), label
+        lhs, rhs = _uniform(rng, (2, 2), moduli, degree), _uniform(rng, (2, 2), moduli, degree)
+        product = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs)))
+        assert np.array_equal(product, ref.mul(lhs, rhs)), label
+        key = _uniform(rng, (L, 2), q, degree)
+        relin = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key)))
+        assert np.array_equal(relin, ref.relinearize(product, key)), label
