@@ -267,10 +267,12 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
                     const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
                     const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
                     const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
-                    v[r] = add_mod_uniform(barrett_mul(a0.x, b1.x, p, factor, shift),
-                                           barrett_mul(a1.x, b0.x, p, factor, shift), p);
-                    v[r + 1] = add_mod_uniform(barrett_mul(a0.y, b1.y, p, factor, shift),
-                                               barrett_mul(a1.y, b0.y, p, factor, shift), p);
+                    // a0 b1 + a1 b0 as one exact 128-bit sum and one reduction (two products < 2^125)
+                    ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
+                    product_sum_add(cross0, a1.x, b0.x);
+                    product_sum_add(cross1, a1.y, b0.y);
+                    v[r] = reduce_product_sum(cross0, mod);
+                    v[r + 1] = reduce_product_sum(cross1, mod);
                 }
             }
         } else if constexpr (SOURCE == kInverseFromKeyMac) {
