@@ -289,6 +289,14 @@ int BfvContext::build_tool(uint32_t k) {
     d.L = static_cast<uint32_t>(L);
     d.inv_gamma_mod_t = inv_gamma_mod_t;
     d.mtilde = mtilde_;
+    {
+        unsigned __int128 worst = 0;
+        for (size_t i = 0; i < L; ++i) {
+            const unsigned __int128 below = q[i] - 1;
+            if (below * below > worst) worst = below * below;
+        }
+        d.floor_merge_ok = (worst == 0 || (static_cast<unsigned __int128>(1) << 127) / worst > L + 1) ? 1u : 0u;
+    }
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
     d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;
     d.inv_b_mod_msk = inv_b_mod_msk;

@@ -42,6 +42,8 @@ struct RnsToolDevice {
     const U64x2* neg_inv_q_mod_t_gamma;// [2]     -(Q^-1) mod t, mod gamma                          RnsTool.swift:157-160
     uint64_t inv_gamma_mod_t;          //         gamma^-1 mod t                                    RnsTool.swift:150-153
     uint64_t mtilde;                   //         T.mTilde: 2^32 (UInt64) or 2^16 (UInt32)          MA/Scalar.swift:508-525
+    uint32_t floor_merge_ok;           //         (L + 1) (q_max - 1)^2 < 2^127: the alpha correction of the Bsk -> Q
+                                       //         conversion may join that row's product sum (one reduction for both)
     U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169
     U64x2 inv_b_mod_msk;               //         B^-1 mod m_sk                           RnsTool.swift:246-250
 };

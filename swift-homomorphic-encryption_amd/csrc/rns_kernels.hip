@@ -147,12 +147,20 @@ __global__ void __launch_bounds__(kThreads)
             ProductSum sum = product_sum_first_uniform(z[0], tool.b_to_q[row * L + 0]);
 #pragma unroll
             for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, z[i], tool.b_to_q[row * L + i]);
-            const uint64_t converted = reduce_product_sum(sum, m);
-            // RnsTool.swift:436-446: alpha > m_sk/2 ? (m_sk - alpha) (B mod q) : alpha (-B mod q); the second form is
-            // the negation of alpha (B mod q), so one product serves both
-            const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
-            const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
-            dst[row * n] = add_mod_uniform(converted, adjust, m.p);
+            // RnsTool.swift:436-446: + (m_sk - alpha) (B mod q) when alpha > m_sk/2, else + alpha (-B mod q)
+            if (tool.floor_merge_ok != 0) {
+                // the correction is one more product of the same exact sum: one reduction instead of a Shoup product,
+                // a negation and a modular add (uniform branch; the sum stays below 2^127)
+                const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
+                product_sum_add(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
+                dst[row * n] = reduce_product_sum(sum, m);
+            } else {
+                const uint64_t converted = reduce_product_sum(sum, m);
+                // the second form is the negation of alpha (B mod q), so one product serves both
+                const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
+                const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
+                dst[row * n] = add_mod_uniform(converted, adjust, m.p);
+            }
         }
     }
 }
