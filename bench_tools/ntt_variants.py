@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 import heamd  # noqa: E402
 
-NAMES = {0: "auto", 1: "auto-exact", 2: "generic", 3: "tiled-wide", 4: "pipe f0", 5: "pipe f1(pref)", 6: "pipe f2(stag)", 7: "pipe f3(both)", 8: "tiled", 9: "tiled-1024thr", 10: "auto-approx"}
+NAMES = {0: "auto", 1: "auto-exact", 2: "generic", 3: "16 words/lane", 8: "32 words/lane", 10: "auto-approx"}
 
 
 def run(degree, bits, batch, variants=(0, 1, 3), reps=30):
@@ -36,6 +36,6 @@ def run(degree, bits, batch, variants=(0, 1, 3), reps=30):
 
 
 if __name__ == "__main__":
-    run(8192, [55] * 4, 4096, variants=(9, 0, 9, 0, 10, 1, 3, 8))
-    run(4096, [55] * 2, 8192, variants=(0, 10, 1))
+    run(8192, [55] * 4, 4096, variants=(0, 3, 0, 3, 10, 1, 8))
+    run(4096, [55] * 2, 8192, variants=(0, 3, 10, 1))
     run(16384, [55] * 4, 1024, variants=(0, 10, 1))

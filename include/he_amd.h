@@ -328,12 +328,12 @@ int he_poly_context_copy_ntt_tables(const he_poly_context* ctx, uint32_t rns_ind
                                     uint64_t* root_factors, uint64_t* inverse_root_powers,
                                     uint64_t* inverse_root_factors, uint64_t* inverse_degree,
                                     uint64_t* inverse_degree_root);
-/* NTT with a named kernel variant: 0 = auto, 1 = exact-quotient butterflies, 2 = generic radix-2 kernel. */
+/* NTT with a named kernel schedule -- every accepted variant computes the same canonical transform (parity tests
+ * pin each schedule against the oracle): 0 = auto (production), 1 = exact-quotient butterflies, 2 = generic radix-2
+ * kernel, 3 = 16 words per lane, 8 = 32 words per lane, 10 = [0, 8p) butterflies.  Anything else:
+ * HE_ERR_INVALID_ARGUMENT. */
 int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, int inverse, int variant,
                           he_stream stream);
-/* Measurement hook: variant 32 of he_ntt_device_variant (forward, N = 8192) stamps the shader clock at every phase
- * boundary of each workgroup into device_buffer[row * 16 + k] (k = 0..9; word 15 = XCC id << 32 | HW_ID). */
-int he_debug_set_ntt_timeline(uint64_t* device_buffer);
 /* Same host-only construction for the BFV context; he_bfv_copy_bsk_moduli returns the L+1 Bsk primes
  * (RnsTool.swift:28-33). */
 int he_bfv_context_create_host_only(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,

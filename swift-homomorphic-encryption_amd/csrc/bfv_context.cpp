@@ -261,10 +261,7 @@ int BfvContext::build_tool(uint32_t k) {
     for (size_t r = 0; r < 2 * L + 1; ++r) {
         DeviceModulus m = level.qbsk->host_constants()[r];
         const u64 p = m.p;
-        m.inv_degree = mul_mod(m.inv_degree, t_ % p, p);
-        m.inv_degree_shoup = shoup_factor(m.inv_degree, p);
-        m.inv_degree_root = mul_mod(m.inv_degree_root, t_ % p, p);
-        m.inv_degree_root_shoup = shoup_factor(m.inv_degree_root, p);
+        set_inverse_degree_constants(m, mul_mod(m.inv_degree, t_ % p, p), mul_mod(m.inv_degree_root, t_ % p, p));
         arena.at<DeviceModulus>(o_scaled)[r] = m;
     }
 

@@ -257,22 +257,24 @@ int he_ntt_forward(const he_poly_context* ctx, uint64_t* host_slab, size_t batch
 int he_ntt_inverse(const he_poly_context* ctx, uint64_t* host_slab, size_t batch) {
     return ntt_host(ctx, host_slab, batch, true);
 }
-// Test/bench hook: run the transform with a named kernel variant (0 auto, 1 exact butterflies, 2 generic radix-2).
+// The transform with a named kernel schedule: every accepted variant computes the same, canonical NTT; anything
+// else is HE_ERR_INVALID_ARGUMENT.
 int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, int inverse, int variant,
                           he_stream stream) {
     if (ctx == nullptr) return invalid_argument("null context");
     const PolyContext& pc = *ctx->impl;
     if (!pc.all_ntt(pc.moduli_count())) return HE_ERR_INVALID_NTT_MODULUS;
+    switch (variant) {
+        case heamd::kNttVariantAuto: case heamd::kNttVariantExact: case heamd::kNttVariantGeneric:
+        case heamd::kNttVariantWide: case heamd::kNttVariantTiled: case heamd::kNttVariantApprox: break;
+        default: return invalid_argument("unknown NTT variant");
+    }
     if (batch == 0) return HE_OK;
+    if (device_slab == nullptr) return invalid_argument("null slab");
     int status = pc.check_device();
     if (status != HE_OK) return status;
     HEAMD_HIP_TRY(heamd::launch_ntt(inverse != 0, device_slab, pc.device_context(), 0, pc.moduli_count(),
                                     batch * pc.moduli_count(), as_stream(stream), variant));
-    return HE_OK;
-}
-
-int he_debug_set_ntt_timeline(uint64_t* device_buffer) {
-    HEAMD_HIP_TRY(heamd::set_ntt_timeline_buffer(device_buffer));
     return HE_OK;
 }
 

@@ -23,6 +23,12 @@ struct DeviceModulus {
     uint64_t inv_degree_root_shoup;
     uint64_t two64_mod_p;        // 2^64 mod p (+ Shoup factor): folds the high word of a 128-bit sum
     uint64_t two64_mod_p_shoup;
+    // limb-wise Shoup constants of the two N^-1 factors (device_math.hpp split_mul_add): c 2^32 mod p and
+    // floor(c 2^32 / 2p) | floor((c 2^32 mod p) 2^32 / 2p) << 32
+    uint64_t inv_degree_split;
+    uint64_t inv_degree_factors;
+    uint64_t inv_degree_root_split;
+    uint64_t inv_degree_root_factors;
 };
 
 struct DeviceContext {
@@ -30,16 +36,18 @@ struct DeviceContext {
     const U64x2* forward_twiddles; // [L][N]  (w, floor(w 2^64 / p)), bit-reversed order   PolyRq+Ntt.swift:125-143
     const U64x2* inverse_twiddles; // [L][N]  stage-major re-ordered                       PolyRq+Ntt.swift:146-157
     const U64x2* inverse_q_last;   // [L][L]  row k: (q_{k}^-1 mod q_i, Shoup) for i < k   PolyContext.swift:108-111
-    // the same tables with the Shoup factor halved, (w, floor(w 2^63 / p)): what the headroom butterflies multiply by.
-    // Present (non-null) only when every modulus of the context is in [2^40, 2^55).
-    const U64x2* forward_twiddles_half;
-    const U64x2* inverse_twiddles_half;
+    // the same twiddles as limb-wise Shoup constants (device_math.hpp split_mul_add), same order:
+    // pairs (w, w 2^32 mod p), factors floor(w 2^32 / 2p) | floor((w 2^32 mod p) 2^32 / 2p) << 32
+    const U64x2* forward_split_pairs;      // [L][N]
+    const U64x2* inverse_split_pairs;      // [L][N]
+    const uint64_t* forward_split_factors; // [L][N]
+    const uint64_t* inverse_split_factors; // [L][N]
     uint32_t degree;
     uint32_t log_degree;
     uint32_t moduli_count;         // active moduli (a prefix of the context's list)
     uint32_t moduli_stride;        // moduli of the full context = row stride of inverse_q_last
     uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
-    uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): NTT may trade folds for top bits
+    uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): the NTT runs the fold-free split butterflies
     uint32_t headroom_prefix;      // how many leading moduli are in that range (the Q part of a [Q, Bsk] context)
 };
 

@@ -236,6 +236,57 @@ __device__ __forceinline__ uint64_t shoup_headroom_fma(uint64_t addend, uint64_t
     return shoup_low64<UNIFORM, true>(addend, x, w, shoup_quotient<UNIFORM, false>(x, wf_half), neg_2p);
 }
 
+// ---- limb-wise Shoup product ("split" butterflies): 8 multiply-adds, no shift, no carry ------------------------------
+// For y = b0 + b1 2^32 and a constant w with wt = w 2^32 mod p:  w y = b0 w + b1 wt (mod p), a sum below 2^33 p, so its
+// quotient by 2p is a 32-bit word: Q = hi32(b0 f + b1 ft) with the 31-bit factors f = floor(w 2^32 / 2p),
+// ft = floor(wt 2^32 / 2p) -- Shoup's estimate applied per limb; the two products < 2^63 cannot leave 64 bits and Q
+// is at most 3 below the true quotient, hence
+//     addend + b0 w + b1 wt - Q 2p   in   addend + [0, 8p)        for ANY 64-bit y.
+// Its low 64 bits are two column chains of three multiply-adds (2^0 column on top of the addend, 2^32 column of
+// which only the low word matters) and one 32-bit add.  Against the 64-bit Shoup product above: 8 multiplies instead
+// of 9, no 64-bit shift, no bound on the multiplicand.  Constants per twiddle: (w, wt) and (f, ft) = 24 bytes.
+// neg_2p = 2^64 - 2p.  UNIFORM: the constant's words are wave-uniform and stay in SGPRs (one SGPR per instruction).
+template <bool UNIFORM, bool ADD>
+__device__ __forceinline__ uint64_t split_mul_add(uint64_t addend, uint64_t y, uint64_t w, uint64_t wt, uint64_t f_pair,
+                                                 uint64_t neg_2p) {
+    const uint32_t b0 = lo32(y), b1 = hi32(y);
+    const uint32_t w0 = lo32(w), w1 = hi32(w), t0 = lo32(wt), t1 = hi32(wt), f = lo32(f_pair), ft = hi32(f_pair);
+    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
+    uint64_t q, c0, c1, carry;
+#define HEAMD_SPLIT_BODY(FIRST)                       \
+    "v_mad_u64_u32 %0, %3, %4, %10, 0\n\t"            \
+    FIRST                                             \
+    "v_mad_u64_u32 %2, %3, %4, %8, 0\n\t"             \
+    "v_mad_u64_u32 %0, %3, %5, %11, %0\n\t"           \
+    "v_mad_u64_u32 %1, %3, %5, %7, %1\n\t"            \
+    "v_mad_u64_u32 %2, %3, %5, %9, %2"
+    // operands: 0 q, 1 c0, 2 c1, 3 carry | 4 b0, 5 b1, 6 w0, 7 t0, 8 w1, 9 t1, 10 f, 11 ft, 12 addend
+    if constexpr (UNIFORM && ADD) {
+        asm(HEAMD_SPLIT_BODY("v_mad_u64_u32 %1, %3, %4, %6, %12\n\t")
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "s"(w1), "s"(t1), "s"(f), "s"(ft), "v"(addend));
+    } else if constexpr (UNIFORM) {
+        asm(HEAMD_SPLIT_BODY("v_mad_u64_u32 %1, %3, %4, %6, 0\n\t")
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "s"(w1), "s"(t1), "s"(f), "s"(ft));
+    } else if constexpr (ADD) {
+        asm(HEAMD_SPLIT_BODY("v_mad_u64_u32 %1, %3, %4, %6, %12\n\t")
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "v"(w1), "v"(t1), "v"(f), "v"(ft), "v"(addend));
+    } else {
+        asm(HEAMD_SPLIT_BODY("v_mad_u64_u32 %1, %3, %4, %6, 0\n\t")
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "v"(w1), "v"(t1), "v"(f), "v"(ft));
+    }
+#undef HEAMD_SPLIT_BODY
+    uint64_t carry2;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\t"
+        "v_mad_u64_u32 %1, %2, %3, %5, %1"
+        : "+v"(c0), "+v"(c1), "=&s"(carry2)
+        : "v"(hi32(q)), "s"(n0), "s"(n1));
+    return pack64(lo32(c0), opaque32(hi32(c0) + lo32(c1)));
+}
+
 __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
     return csub63(shoup_lazy(x, w, wf, 0 - p), 0 - p);  // lazy < 2p < 2^63
 }

@@ -155,6 +155,16 @@ inline u64 min_primitive_root_of_unity(u64 p, u64 degree) {
 // Shoup constant floor(c * 2^64 / p) (HomomorphicEncryption/Modulus.swift:92-103)
 inline u64 shoup_factor(u64 multiplicand, u64 p) { return static_cast<u64>((static_cast<u128>(multiplicand) << 64) / p); }
 
+// Limb-wise Shoup constants of c mod p (device_math.hpp split_mul_add): c 2^32 mod p, and the two 31-bit quotient
+// factors floor(c 2^32 / 2p), floor((c 2^32 mod p) 2^32 / 2p) packed low | high
+inline u64 split_shifted(u64 c, u64 p) { return static_cast<u64>((static_cast<u128>(c) << 32) % p); }
+inline u64 split_factors(u64 c, u64 p) {
+    const u64 shifted = split_shifted(c, p);
+    const u64 f = static_cast<u64>((static_cast<u128>(c) << 32) / (static_cast<u128>(p) * 2));
+    const u64 ft = static_cast<u64>((static_cast<u128>(shifted) << 32) / (static_cast<u128>(p) * 2));
+    return f | (ft << 32);
+}
+
 // Q mod m for Q = prod(moduli) (HomomorphicEncryption/PolyRq/PolyContext.swift:184-191)
 inline u64 product_mod(const u64* moduli, size_t count, u64 m) {
     u64 prod = 1 % m;

@@ -9,32 +9,16 @@
 
 namespace heamd {
 
-// kernel selection for launch_ntt (tests / benchmarks; production callers pass kNttVariantAuto):
-//   0 auto (tiled kernel, 16 words per lane, where supported)   1 same kernel, exact-quotient butterflies
-//   2 generic radix-2 kernel   3 tiled kernel with 2x wider workgroups   4..7 pipelined kernel with flags 0..3
-//   (bit0 next-row register prefetch, bit1 staggered second wave)   8 tiled (non-persistent) kernel
-//   16+ measurement-only ablations of the tiled forward kernel
+// kernel schedule for launch_ntt (tests pin each against the oracle; production callers pass kNttVariantAuto).  Every
+// variant computes the same canonical transform.
 enum {
-    kNttVariantAuto = 0,
-    kNttVariantExact = 1,
-    kNttVariantGeneric = 2,
-    kNttVariantWide = 3,
-    kNttVariantPipelinedBase = 4,
-    kNttVariantTiled = 8,
-    kNttVariantWidest = 9,  // tiled kernel, 1024 lanes x 8 words (N = 8192 only)
-    kNttVariantApprox = 10, // production kernel pinned to the [0, 8p) schedule (no headroom mode)
-    kNttVariantStream = 11, // persistent forward kernel with LDS-DMA prefetch of the next row (ntt_stream.hip)
-    kNttVariantPrefetch = 12, // persistent forward kernel, 16 words per lane, next row prefetched into registers
-    kNttVariantAblateBase = 16
+    kNttVariantAuto = 0,     // tiled kernel, 8 words per lane where a workgroup of <= 1024 lanes allows it
+    kNttVariantExact = 1,    // same kernel, exact-quotient butterflies (what moduli >= 2^61 get)
+    kNttVariantGeneric = 2,  // radix-2 stage loop (what degrees without a tiled kernel get)
+    kNttVariantWide = 3,     // tiled kernel, 16 words per lane
+    kNttVariantTiled = 8,    // tiled kernel, 32 words per lane
+    kNttVariantApprox = 10   // production kernel pinned to the [0, 8p) butterflies (what 56..61-bit moduli get)
 };
-bool ntt_stream_supports(const DeviceContext& ctx);
-hipError_t launch_ntt_forward_stream(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
-                                     uint32_t mod_period, size_t rows, uint32_t workgroups, hipStream_t stream);
-hipError_t launch_ntt_forward_prefetch(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
-                                       uint32_t mod_period, size_t rows, uint32_t workgroups, hipStream_t stream);
-bool ntt_pipelined_supports(uint32_t log_degree);
-hipError_t launch_ntt_pipelined(bool inverse, bool approx, int flags, uint64_t* slab, const DeviceContext& ctx,
-                                uint32_t mod_base, uint32_t mod_period, size_t rows, hipStream_t stream);
 
 // NTT of `rows` contiguous length-N rows.  Row r uses modulus index mod_base + (r % mod_period).
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
@@ -58,8 +42,6 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
-// measurement hook: variant 32 of the forward N=8192 kernel stamps phase boundaries into this buffer (16 words/row)
-hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer);
 
 enum class ElementwiseOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, MulScalar = 4 };
 // lhs[k] = op(lhs[k], rhs[k]) over `rows` rows of [..][L][N]; rhs may be NULL for Neg.  For MulScalar `rhs` is a

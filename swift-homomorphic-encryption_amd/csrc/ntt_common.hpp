@@ -76,48 +76,103 @@ __device__ __forceinline__ U64x2 load_twiddle(const U64x2* entry) {
     ConstWord* const words = (ConstWord*)(entry);
     return U64x2{words[0], words[1]};
 }
+__device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
+    using ConstWord = const __attribute__((address_space(4))) uint64_t;
+    return *(ConstWord*)(entry);
+}
 
 // Butterfly arithmetic modes (chosen per launch from the moduli the launch covers):
-//   kModeExact    any p <= 2^62 - 1 : exact Shoup quotient, products in [0, 2p), values in [0, 4p)
-//   kModeApprox   p < 2^61          : 3-multiply quotient estimate, products in [0, 4p), values in [0, 8p)
-//   kModeHeadroom 2^40 <= p < 2^55  : shoup_headroom (products in [0, 8p)), and the spare top bits absorb the growth
-//                                     instead of a conditional subtract per butterfly: the forward transform never
-//                                     folds (a word gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62),
-//                                     the inverse folds only once sums could pass 2^7 p (its multiplicand x + B - y
-//                                     must stay < 2^63); one float-estimated quotient brings forward outputs back
-//                                     to [0, p).
-//   kModeHeadroomHalved             : kModeHeadroom reading the context's pre-halved Shoup factors
-constexpr int kModeExact = 0, kModeApprox = 1, kModeHeadroom = 2, kModeHeadroomHalved = 3;
-constexpr bool is_headroom(int mode) { return mode == kModeHeadroom || mode == kModeHeadroomHalved; }
+//   kModeExact   any p <= 2^62 - 1 : exact Shoup quotient, products in [0, 2p), values in [0, 4p)
+//   kModeApprox  p < 2^61          : 3-multiply quotient estimate, products in [0, 4p), values in [0, 8p)
+//   kModeSplit   2^40 <= p < 2^55  : limb-wise Shoup products (split_mul_add, device_math.hpp: 8 multiply-adds, any
+//                                    64-bit multiplicand, products in [0, 8p)) and the spare top bits instead of a
+//                                    conditional subtract per butterfly: the forward transform never folds (a word
+//                                    gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62), the inverse
+//                                    brings its sums back under 2p once their bound reaches 2^9 p (one round for
+//                                    N <= 8192); one float-estimated quotient makes outputs canonical.
+constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3;
+
+using BufferResource = __amdgpu_buffer_rsrc_t;
+typedef unsigned int Dwordx2 __attribute__((ext_vector_type(2)));
+typedef unsigned int Dwordx4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor over `bytes` at a wave-uniform address: loads and stores through it take one 32-bit lane offset
+// plus a scalar offset -- no 64-bit address arithmetic on the vector ALU.
+__device__ __forceinline__ BufferResource make_resource(const void* base, uint32_t bytes) {
+    // `base` must be wave-uniform (kernel arguments and blockIdx only): the descriptor then lives in SGPRs
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+
+// The tables one residue row's butterflies read.  Exact / approx: `pairs` = (w, floor(w 2^64 / p)).
+// Split: `pairs` = (w, w 2^32 mod p), `factors` = floor(w 2^32 / 2p) | floor((w 2^32 mod p) 2^32 / 2p) << 32.
+template <int MODE>
+struct Twiddles {
+    const U64x2* pairs;
+    const uint64_t* factors;
+    BufferResource pair_resource, factor_resource;  // split mode gathers
+    __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree) {
+        const size_t at = static_cast<size_t>(modulus_index) << log_degree;
+        if constexpr (MODE == kModeSplit) {
+            pairs = (inverse ? ctx.inverse_split_pairs : ctx.forward_split_pairs) + at;
+            factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
+            pair_resource = make_resource(pairs, 16u << log_degree);
+            factor_resource = make_resource(factors, 8u << log_degree);
+        } else {
+            pairs = (inverse ? ctx.inverse_twiddles : ctx.forward_twiddles) + at;
+            factors = nullptr;
+        }
+    }
+};
+
+// one twiddle in registers
+struct TwiddleWords {
+    uint64_t w, second, factors;  // second = Shoup factor (exact / approx) or w 2^32 mod p (split)
+};
+template <int MODE, bool UNIFORM>
+__device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, uint32_t lane_index, uint32_t fixed_index) {
+    TwiddleWords t;
+    if constexpr (UNIFORM) {  // lane_index is wave-uniform (held in an SGPR): scalar-cache loads
+        const U64x2 pair = load_twiddle(tw.pairs + fixed_index + lane_index);
+        t.w = pair.x;
+        t.second = pair.y;
+        t.factors = 0;
+        if constexpr (MODE == kModeSplit) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
+    } else if constexpr (MODE == kModeSplit) {
+        const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
+        const Dwordx2 factors = __builtin_amdgcn_raw_buffer_load_b64(tw.factor_resource, lane_index << 3, fixed_index << 3, 0);
+        t.w = pack64(pair.x, pair.y);
+        t.second = pack64(pair.z, pair.w);
+        t.factors = pack64(factors.x, factors.y);
+    } else {
+        const U64x2 pair = load_twiddle(tw.pairs + fixed_index + lane_index);
+        t.w = pair.x;
+        t.second = pair.y;
+        t.factors = 0;
+    }
+    return t;
+}
 
 template <int MODE>
 struct Lazy {
-    static constexpr bool kHeadroom = is_headroom(MODE);
+    static constexpr bool kSplit = MODE == kModeSplit;
     static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;  // products < p << this
-    // cap on stage inputs of the inverse transform, as a shift of p
-    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 7;
-    // twiddle as the butterflies want it: headroom mode multiplies by floor(w 2^63 / p) = wf >> 1
-    __device__ static __forceinline__ U64x2 prepare(U64x2 w) {
-        if constexpr (MODE == kModeHeadroom) w.y >>= 1;  // kModeHeadroomHalved: the table already holds wf >> 1
-        return w;
-    }
-    // `reduction` = 2^64 - p (exact / approx, in VGPRs) or 2^64 - 2p (headroom, uniform)
+    // cap on stage inputs of the inverse transform, as a shift of p (split: sums of two stay below 2^9 p < 2^64)
+    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 8;
+    // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
     template <bool UNIFORM = false>
-    __device__ static __forceinline__ uint64_t mul(uint64_t x, U64x2 w, uint64_t reduction) {
-        if constexpr (kHeadroom && UNIFORM) {
-            return shoup_headroom_uniform(x, w.x, w.y, reduction);
-        } else if constexpr (kHeadroom) {
-            return shoup_headroom(x, w.x, w.y, reduction);
+    __device__ static __forceinline__ uint64_t mul(uint64_t x, const TwiddleWords& w, uint64_t reduction) {
+        if constexpr (kSplit) {
+            return split_mul_add<UNIFORM, false>(0, x, w.w, w.second, w.factors, reduction);
         } else if constexpr (MODE == kModeApprox && UNIFORM) {
-            return shoup_lazy4_uniform(x, w.x, w.y, reduction);
+            return shoup_lazy4_uniform(x, w.w, w.second, reduction);
         } else if constexpr (MODE == kModeApprox) {
-            return shoup_lazy4(x, w.x, w.y, reduction);
+            return shoup_lazy4(x, w.w, w.second, reduction);
         } else {
-            return shoup_lazy(x, w.x, w.y, reduction);
+            return shoup_lazy(x, w.w, w.second, reduction);
         }
     }
     __device__ static __forceinline__ uint64_t reduction_constant(uint64_t p) {
-        if constexpr (kHeadroom) {
+        if constexpr (kSplit) {
             return 0 - 2 * p;
         } else if constexpr (MODE == kModeApprox) {
             return 0 - p;  // asm multiply: the uniform constant is read from SGPRs (or copied once when needed in VGPRs)
@@ -127,56 +182,81 @@ struct Lazy {
     }
 };
 
+// x < 2^10 p, 2^40 <= p < 2^55  ->  x mod p, with the quotient estimated in fp32 from the high words:
+// e = (x >> 32) * (2^32 / p) * (1 - 2^-18).  The dropped low word costs < 2^32 / p <= 2^-8, the down-bias
+// < 2^10 * 2^-18 and fp32 rounding (four roundings, each 2^-24 relative, all dominated by the bias) keeps
+// e <= x / p, so q = floor(e) is floor(x / p) or one less: x - q p lies in [0, 2p) and one conditional subtract
+// finishes.  x - q p is the low 64 bits of x + q (2^64 - p): one multiply-add on top of x, one low product.
+struct LazyReducer {
+    uint64_t neg_p;
+    float scale;
+    __device__ __forceinline__ explicit LazyReducer(uint64_t modulus)
+        : neg_p(0 - modulus), scale((4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus)) {}
+    // [0, 2p)
+    __device__ __forceinline__ uint64_t lazy(uint64_t x) const {
+        float high;  // asm: hipcc otherwise converts through its generic 64-bit path (7 instructions)
+        asm("v_cvt_f32_u32 %0, %1" : "=v"(high) : "v"(hi32(x)));
+        const uint32_t q = static_cast<uint32_t>(high * scale);
+        uint64_t low, carry;
+        uint32_t cross;
+        asm("v_mad_u64_u32 %0, %2, %3, %4, %6\n\t"
+            "v_mul_lo_u32 %1, %3, %5"
+            : "=&v"(low), "=&v"(cross), "=&s"(carry)
+            : "v"(q), "s"(lo32(neg_p)), "s"(hi32(neg_p)), "v"(x));
+        return pack64(lo32(low), opaque32(hi32(low) + cross));
+    }
+    __device__ __forceinline__ uint64_t operator()(uint64_t x) const { return csub63<true>(lazy(x), neg_p); }
+};
+
 // ---- forward pass over element bits [LO, LO+W): stages run from the top bit down --------------------------------
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ABLATE = 0>
-__device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
+__device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              uint64_t p, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
-    static_assert(!is_headroom(MODE) || 1 + 8 * LOGN <= 127, "headroom mode: growth must stay below 2^7 p");
+    static_assert(MODE != kModeSplit || 1 + 8 * LOGN <= 127, "split mode: growth must stay below 2^7 p");
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + W - 1 - j;         // element bit paired by this stage
         const int s = LOGN - 1 - b;           // global stage number; m = 2^s groups
         const int stride = 1 << (b - LO);     // register distance of a pair
         // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint, so the lane part is
-        // one address per stage and the register part an immediate offset.  When the six in-wave lane bits all sit
+        // one offset per stage and the register part an immediate.  When the six in-wave lane bits all sit
         // at or below b the index is the same for the whole wave: read it through the scalar cache into SGPRs.
+#ifdef HEAMD_X_UNIFORM_TW  // experiment (wrong results): every twiddle fetch is a scalar load, no gathers
+        const bool uniform = true;
+#else
         const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+#endif
         uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
         if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
-        const U64x2* const tw_stage = tw + (1u << s) + lane_twiddle;
 #pragma unroll
         for (int base = 0; base < E; base += 2 * stride) {
-            // ABLATE bit 0 (measurement only, wrong results): one wave-uniform twiddle instead of the gather
-            const U64x2 w = Lazy<MODE>::prepare(
-                load_twiddle((ABLATE & 1) ? tw + (1u << s) : tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1))));
+            const uint32_t fixed = (1u << s) + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1));
+            const TwiddleWords w = uniform ? fetch_twiddle<MODE, true>(tw, lane_twiddle, fixed)
+                                           : fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 uint64_t x = v[base + o];
                 const uint64_t y = v[base + o + stride];
-                if (!is_headroom(MODE) && !(first_stage_canonical && j == 0) && !(ABLATE & 8)) x = csub_uniform(x, half_bound);
-                if constexpr (is_headroom(MODE) || MODE == kModeApprox) {
+                if (MODE != kModeSplit && !(first_stage_canonical && j == 0)) x = csub_uniform(x, half_bound);
+                if constexpr (MODE == kModeSplit || MODE == kModeApprox) {
                     // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
                     uint64_t sum;
-                    if constexpr (is_headroom(MODE)) {
-                        sum = (uniform && !(ABLATE & 1)) ? shoup_headroom_fma<true>(x, y, w.x, w.y, neg_p)
-                                                         : shoup_headroom_fma<false>(x, y, w.x, w.y, neg_p);
+                    if constexpr (MODE == kModeSplit) {
+                        sum = uniform ? split_mul_add<true, true>(x, y, w.w, w.second, w.factors, neg_p)
+                                      : split_mul_add<false, true>(x, y, w.w, w.second, w.factors, neg_p);
                     } else {
-                        sum = (uniform && !(ABLATE & 1)) ? shoup_lazy4_fma<true>(x, y, w.x, w.y, neg_p)
-                                                         : shoup_lazy4_fma<false>(x, y, w.x, w.y, neg_p);
+                        sum = uniform ? shoup_lazy4_fma<true>(x, y, w.w, w.second, neg_p)
+                                      : shoup_lazy4_fma<false>(x, y, w.w, w.second, neg_p);
                     }
                     v[base + o] = sum;
                     v[base + o + stride] = ((x << 1) + half_bound) - sum;
                     continue;
                 }
-                uint64_t t;
-                if (uniform && !(ABLATE & 1)) {
-                    t = Lazy<MODE>::template mul<true>(y, w, neg_p);
-                } else {
-                    t = Lazy<MODE>::template mul<false>(y, w, neg_p);
-                }
+                const uint64_t t = uniform ? Lazy<MODE>::template mul<true>(y, w, neg_p)
+                                           : Lazy<MODE>::template mul<false>(y, w, neg_p);
                 v[base + o] = x + t;
                 v[base + o + stride] = x + half_bound - t;
             }
@@ -184,19 +264,36 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
     }
 }
 
+// Inverse transform, split mode: bound (as a shift of p) on the words ENTERING the stage on element bit b.  Canonical
+// input; a product is < 8p; a sum doubles the bound; when a stage's sums would pass the cap they are reduced under 2p.
+template <int MODE>
+constexpr int inverse_in_shift(int b) {
+    constexpr int H = Lazy<MODE>::kInverseCapLog, K = Lazy<MODE>::kProductLog;
+    if constexpr (MODE != kModeSplit) {
+        return b == 0 ? 0 : (b + K - 1 < H ? b + K - 1 : H);
+    } else {
+        int shift = 0;
+        for (int stage = 0; stage < b; ++stage) {
+            const int sums = (shift + 1 > H) ? 1 : shift + 1;
+            shift = sums > K ? sums : K;
+        }
+        return shift;
+    }
+}
+
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
 template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES = false>
-__device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const U64x2* __restrict__ tw,
+__device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
     constexpr uint32_t N = 1u << LOGN;
     const uint64_t p = mod.p;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     // Words entering the stage on element bit b live in [0, p << in_shift(b)): canonical input for b = 0; after
-    // that sums double the bound and products are < p << K (K = Lazy::kProductLog), so in_shift(b) = min(b + K - 1, H);
-    // once it reaches the cap H every sum is folded back under p << H.
-    constexpr int H = Lazy<MODE>::kInverseCapLog, K = Lazy<MODE>::kProductLog;
+    // that sums double the bound and products are < p << K (K = Lazy::kProductLog); exact / approx: once the bound
+    // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
+    constexpr int H = Lazy<MODE>::kInverseCapLog;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + j;
@@ -204,18 +301,20 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
         const uint32_t m = N >> (b + 1);
         const bool last_stage = (b == LOGN - 1);
         const bool canonical_in = first_stage_canonical && j == 0;
-        const int in_shift = canonical_in ? 0 : (b + K - 1 < H ? b + K - 1 : H);
+        const int in_shift = canonical_in ? 0 : inverse_in_shift<MODE>(b);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
         uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
         if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
-        const U64x2* const tw_stage = tw + (N - 2 * m + 1) + lane_twiddle;
 #pragma unroll
         for (int base = 0; base < E; base += 2 * stride) {
-            U64x2 w = {0, 0};
-            if (!last_stage)
-                w = Lazy<MODE>::prepare(load_twiddle(tw_stage + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1))));
+            TwiddleWords w = {0, 0, 0};
+            if (!last_stage) {
+                const uint32_t fixed = (N - 2 * m + 1) + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1));
+                w = uniform ? fetch_twiddle<MODE, true>(tw, lane_twiddle, fixed)
+                            : fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
+            }
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 const uint64_t x = v[base + o];
@@ -223,16 +322,27 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                 uint64_t sum = x + y;
                 const uint64_t diff = x + bound - y;
                 if (last_stage) {
-                    v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
-                    v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
-                } else {
-                    if (fold) sum = csub_uniform(sum, bound);
-                    v[base + o] = sum;
-                    if (uniform) {
-                        v[base + o + stride] = Lazy<MODE>::template mul<true>(diff, w, neg_p);
+                    if constexpr (MODE == kModeSplit) {
+                        const LazyReducer reduce(p);
+                        v[base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
+                                                                        mod.inv_degree_factors, neg_p));
+                        v[base + o + stride] = reduce(split_mul_add<true, false>(
+                            0, diff, mod.inv_degree_root, mod.inv_degree_root_split, mod.inv_degree_root_factors, neg_p));
                     } else {
-                        v[base + o + stride] = Lazy<MODE>::template mul<false>(diff, w, neg_p);
+                        v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
+                        v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                     }
+                } else {
+                    if (fold) {
+                        if constexpr (MODE == kModeSplit) {
+                            sum = LazyReducer(p).lazy(sum);
+                        } else {
+                            sum = csub_uniform(sum, bound);
+                        }
+                    }
+                    v[base + o] = sum;
+                    v[base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
+                                                   : Lazy<MODE>::template mul<false>(diff, w, neg_p);
                 }
             }
         }
@@ -253,81 +363,59 @@ __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid,
     for (int r = 0; r < (1 << LOGE); ++r) v[r] = base[lds_slot(register_part<LOGN, LOGE, LO, W>(r))];
 }
 
-// Global <-> registers.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at
-// a time.  For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
+// Global <-> registers through the row's buffer descriptor: one 32-bit lane offset per pass, the register part is a
+// scalar offset.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at a time.
+// For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
 template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* __restrict__ x) {
+__device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
+    const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
     if constexpr (LO == 0 && W >= 1) {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
-            const U64x2 pair = *reinterpret_cast<const U64x2*>(x + register_part<LOGN, LOGE, LO, W>(r) +
-                                                               lane_part<LOGN, LOGE, LO, W>(tid));
-            v[r] = pair.x;
-            v[r + 1] = pair.y;
+            const Dwordx4 pair =
+                __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+            v[r] = pack64(pair.x, pair.y);
+            v[r + 1] = pack64(pair.z, pair.w);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r)
-            v[r] = (x + register_part<LOGN, LOGE, LO, W>(r))[lane_part<LOGN, LOGE, LO, W>(tid)];
+        for (int r = 0; r < (1 << LOGE); ++r) {
+            const Dwordx2 word =
+                __builtin_amdgcn_raw_buffer_load_b64(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+            v[r] = pack64(word.x, word.y);
+        }
     }
 }
 template <int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* __restrict__ x) {
+__device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
+    const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
     if constexpr (LO == 0 && W >= 1) {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
-            U64x2 pair;
-            pair.x = v[r];
-            pair.y = v[r + 1];
-            *reinterpret_cast<U64x2*>(x + register_part<LOGN, LOGE, LO, W>(r) + lane_part<LOGN, LOGE, LO, W>(tid)) = pair;
+            const Dwordx4 pair = {lo32(v[r]), hi32(v[r]), lo32(v[r + 1]), hi32(v[r + 1])};
+            __builtin_amdgcn_raw_buffer_store_b128(pair, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r)
-            (x + register_part<LOGN, LOGE, LO, W>(r))[lane_part<LOGN, LOGE, LO, W>(tid)] = v[r];
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ const U64x2* twiddle_table(const DeviceContext& ctx, bool inverse) {
-    if constexpr (MODE == kModeHeadroomHalved) {
-        return inverse ? ctx.inverse_twiddles_half : ctx.forward_twiddles_half;
-    } else {
-        return inverse ? ctx.inverse_twiddles : ctx.forward_twiddles;
+        for (int r = 0; r < (1 << LOGE); ++r) {
+            const Dwordx2 word = {lo32(v[r]), hi32(v[r])};
+            __builtin_amdgcn_raw_buffer_store_b64(word, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+        }
     }
 }
 
 template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
-    static_assert(MODE == kModeExact || MODE == kModeApprox, "headroom outputs go through HeadroomReducer");
+    static_assert(MODE == kModeExact || MODE == kModeApprox, "split outputs go through LazyReducer");
     if constexpr (MODE == kModeApprox) x = csub_uniform(x, 4 * p);
     x = csub_uniform(x, 2 * p);
     return csub_uniform(x, p);
 }
 
-// x < 64 p, 2^40 <= p < 2^55  ->  x mod p, with the quotient estimated in fp32 from the high words:
-// e = (x >> 32) * (2^32 / p) * (1 - 2^-18).  The dropped low word costs < 2^32 / p <= 2^-8, the down-bias
-// < 64 * 2^-18 and fp32 rounding (three roundings, each 2^-24 relative, all dominated by the bias) keeps
-// e <= x / p, so q = floor(e) is floor(x / p) or one less and one conditional subtract finishes.
-struct HeadroomReducer {
-    uint64_t p;
-    float scale;
-    __device__ __forceinline__ explicit HeadroomReducer(uint64_t modulus)
-        : p(modulus), scale((4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus)) {}
-    __device__ __forceinline__ uint64_t operator()(uint64_t x) const {
-        float high;  // asm: hipcc otherwise converts through its generic 64-bit path (7 instructions)
-        asm("v_cvt_f32_u32 %0, %1" : "=v"(high) : "v"(hi32(x)));
-        const uint32_t q = static_cast<uint32_t>(high * scale);
-        const uint64_t qp = mad32(q, static_cast<uint32_t>(p),
-                                  static_cast<uint64_t>(mullo32(q, static_cast<uint32_t>(p >> 32))) << 32);
-        return csub63<true>(x - qp, 0 - p);
-    }
-};
-
 template <int MODE, int N>
 __device__ __forceinline__ void canonicalize_all(uint64_t (&v)[N], uint64_t p) {
-    if constexpr (is_headroom(MODE)) {
-        const HeadroomReducer reduce(p);
+    if constexpr (MODE == kModeSplit) {
+        const LazyReducer reduce(p);
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = reduce(v[r]);
     } else {

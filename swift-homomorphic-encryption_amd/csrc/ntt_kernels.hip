@@ -8,13 +8,14 @@
 //
 // Mapping to the machine (DESIGN.md "NTT kernel"):
 //   * one workgroup per residue row; a row of N = 2^LOGN words is held entirely in registers, E = N / T words per
-//     lane (T = 2^LOGT lanes), and is touched in HBM exactly once in and once out;
+//     lane (T = 2^LOGT lanes), and is touched in HBM exactly once in and once out (buffer loads / stores: one 32-bit
+//     lane offset, scalar row offsets -- no 64-bit address arithmetic on the vector ALU);
 //   * log2(N) radix-2 stages are grouped into passes of LOGE stages executed on registers; between passes the row
-//     is transposed through a padded LDS tile (2 transposes for N = 8192: 13 = 5 + 5 + 3);
-//   * pass 0 twiddles are wave-uniform (scalar loads); later passes gather (w, w') pairs from the L2-resident
-//     per-modulus table (128 KiB per modulus per direction at N = 8192, shared by every workgroup of that modulus);
-//   * butterflies are Harvey's with Shoup constants; with every modulus < 2^61 the quotient estimate uses 3 instead
-//     of 4 32-bit multiplies and values live in [0, 8p).
+//     is transposed through a padded LDS tile (4 transposes for N = 8192 with 8 words per lane: 13 = 3+3+3+3+1);
+//   * twiddles of the first two passes are wave-uniform (scalar loads); later passes gather them from the L2-resident
+//     per-modulus tables, shared by every workgroup of that modulus;
+//   * butterflies: limb-wise Shoup products for the usual <= 55-bit moduli (ntt_common.hpp kModeSplit), Harvey
+//     butterflies with a 3- or 4-multiply quotient for moduli up to 2^61 / 2^62.
 #include <hip/hip_runtime.h>
 
 #include "device_context.hpp"
@@ -22,54 +23,74 @@
 #include "kernels.hpp"
 #include "ntt_common.hpp"
 
+// Experiment hooks of the forward kernel (bench_tools/ab_variants.py builds variant libraries with -DHEAMD_X_...; the
+// production build defines none of them and every hook is the plain statement).  Variants that drop work compute
+// WRONG results and exist only in lib/variants/ for timing.
+#ifdef HEAMD_X_NO_LOAD
+#define HEAMD_X_LOAD(statement)                                                     \
+    _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) v[r_] = (tid * 2654435761u + r_) % p
+#else
+#define HEAMD_X_LOAD(statement) statement
+#endif
+#ifdef HEAMD_X_NO_STORE
+#define HEAMD_X_STORE(statement)                                                    \
+    do {                                                                            \
+        uint64_t sum_ = 0;                                                          \
+        _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) sum_ ^= v[r_];             \
+        if (sum_ == 0x123456789ull) statement;                                      \
+    } while (0)
+#else
+#define HEAMD_X_STORE(statement) statement
+#endif
+#ifdef HEAMD_X_NO_LDS
+#define HEAMD_X_LDS(statement) (void)0
+#else
+#define HEAMD_X_LDS(statement) statement
+#endif
+#ifdef HEAMD_X_NO_PASS
+#define HEAMD_X_PASS(statement) (void)0
+#else
+#define HEAMD_X_PASS(statement) statement
+#endif
+#ifdef HEAMD_X_STAGGER  // delay the second workgroup slot of every CU at kernel start (HEAMD_X_STAGGER x 64 x 127 clocks)
+#define HEAMD_X_PROLOGUE()                                                          \
+    if (blockIdx.x >= 256 && blockIdx.x < 512)                                      \
+        for (int k_ = 0; k_ < HEAMD_X_STAGGER; ++k_) __builtin_amdgcn_s_sleep(127)
+#else
+#define HEAMD_X_PROLOGUE() (void)0
+#endif
+
 namespace heamd {
 
 namespace {
 
 using namespace ntt;
 
-// ABLATE (measurement only, results are wrong when non-zero): bit0 uniform twiddles, bit1 skip the LDS exchanges,
-// bit2 skip global load/store, bit3 skip the per-butterfly conditional subtract.
-// Timeline instrumentation (ABLATE bit 4): lane 0 of wave 0 stamps s_memtime at every phase boundary into
-// g_ntt_timeline[block * 16 + k]; results stay correct.
-__device__ uint64_t* g_ntt_timeline = nullptr;
-template <int ABLATE>
-__device__ __forceinline__ void stamp(int k, bool drain_vmem, bool drain_lds) {
-    if constexpr (ABLATE & 16) {
-        if (drain_vmem) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (drain_lds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0 && g_ntt_timeline != nullptr)
-            g_ntt_timeline[static_cast<size_t>(blockIdx.x) * 16 + k] = __builtin_readcyclecounter();
+// Which row a workgroup transforms.  Workgroup b covers row (b / band_rows) * record_rows + band_offset + b % band_rows
+// with modulus mod_base + b % band_rows: a launch covers a band of `band_rows` rows inside records of `record_rows`
+// rows (record_rows = 0: the rows are consecutive and band_rows is the modulus period).  The quotient comes from one
+// scalar multiply-high by band_magic = floor(2^32 / band_rows) + 1 and a fix-up (exact for b < 2^30), so that no
+// vector instruction is spent on it.
+struct RowMap {
+    uint32_t mod_base, band_rows, band_magic, record_rows, band_offset;
+};
+__device__ __forceinline__ void locate(const RowMap& map, uint32_t block, uint32_t& record, uint32_t& within) {
+    if (map.band_rows == 1) {
+        record = block;
+        within = 0;
+        return;
     }
+    uint32_t q = __umulhi(block, map.band_magic);
+    int32_t r = static_cast<int32_t>(block - q * map.band_rows);
+    if (r < 0) {
+        q -= 1;
+        r += static_cast<int32_t>(map.band_rows);
+    }
+    record = q;
+    within = static_cast<uint32_t>(r);
 }
-
-// ABLATE bit 7 (measurement only, wrong results): every transpose becomes the conflict-free linear pattern
-// (lane tid, register r <-> word tid + r * lanes, no padding) -- the LDS time a perfect layout would leave.
-template <int ABLATE, int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void lds_store_a(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* lds) {
-    if constexpr (ABLATE & 128) {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))] = v[r];
-    } else if constexpr (ABLATE & 256) {  // occupancy probe: the padded pattern folded into a 32 KB tile
-        const uint32_t base = lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) lds[(base + lds_slot(register_part<LOGN, LOGE, LO, W>(r))) & 4095u] = v[r];
-    } else {
-        lds_store<LOGN, LOGE, LO, W>(v, tid, lds);
-    }
-}
-template <int ABLATE, int LOGN, int LOGE, int LO, int W>
-__device__ __forceinline__ void lds_load_a(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* lds) {
-    if constexpr (ABLATE & 128) {
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[tid + (static_cast<uint32_t>(r) << (LOGN - LOGE))];
-    } else if constexpr (ABLATE & 256) {
-        const uint32_t base = lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
-#pragma unroll
-        for (int r = 0; r < (1 << LOGE); ++r) v[r] = lds[(base + lds_slot(register_part<LOGN, LOGE, LO, W>(r))) & 4095u];
-    } else {
-        lds_load<LOGN, LOGE, LO, W>(v, tid, lds);
-    }
+RowMap make_row_map(uint32_t mod_base, uint32_t band_rows, uint32_t record_rows, uint32_t band_offset) {
+    return RowMap{mod_base, band_rows, static_cast<uint32_t>((uint64_t(1) << 32) / band_rows) + 1u, record_rows, band_offset};
 }
 
 // Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
@@ -88,25 +109,26 @@ struct SpreadSource {
     uint64_t plaintext_modulus;
 };
 
-template <int LOGN, int LOGT, int MODE, int ABLATE = 0, int SPREAD = kSourceSlab>
-__global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
-    ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
-                      const SpreadSource spread, uint32_t row_period, uint32_t row_offset) {
+constexpr int min_waves_per_simd(int log_words_per_lane) {
+    return log_words_per_lane <= 3 ? 8 : log_words_per_lane <= 4 ? 4 : 2;
+}
+
+template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab>
+__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
+    ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const SpreadSource spread) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    // workgroup b transforms row (b / mod_period) * row_period + row_offset + b % mod_period with modulus
-    // mod_base + b % mod_period: a launch covers a band of `mod_period` rows inside records of `row_period` rows
-    // (row_period = 0: the rows are consecutive)
-    const uint32_t within = static_cast<uint32_t>(blockIdx.x % mod_period);
-    const size_t row = row_period == 0 ? blockIdx.x : (blockIdx.x / mod_period) * size_t(row_period) + row_offset + within;
-    const uint32_t mi = mod_base + within;
+    uint32_t record, within;
+    locate(map, blockIdx.x, record, within);
+    const size_t row = map.record_rows == 0 ? blockIdx.x : size_t(record) * map.record_rows + map.band_offset + within;
+    const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
-    const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, false) + (static_cast<size_t>(mi) << LOGN);
-    uint64_t* __restrict__ x = slab + (row << LOGN);
+    const Twiddles<MODE> tw(ctx, false, mi, LOGN);
+    const BufferResource x = make_resource(slab + (row << LOGN), 8u << LOGN);
     const uint64_t p = mod.p;
     uint64_t v[E];
 
@@ -117,99 +139,61 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
         global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
-        stamp<ABLATE>(0, false, false);
-        if constexpr (ABLATE & 16) {
-            if (threadIdx.x == 0 && g_ntt_timeline != nullptr) {
-                uint32_t hw_id;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-                uint32_t xcc_id;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-                g_ntt_timeline[static_cast<size_t>(blockIdx.x) * 16 + 15] = (static_cast<uint64_t>(xcc_id) << 32) | hw_id;
-            }
-        }
-        if constexpr (ABLATE & (4 | 32)) {  // bit 5: skip the load only
-#pragma unroll
-            for (int r = 0; r < E; ++r) v[r] = (tid * 2654435761u + r) % p;
-        } else if constexpr (SPREAD != kSourceSlab) {
-            const size_t group = blockIdx.x / mod_period;  // poly * L + j
-            const size_t poly = group / spread.L, j = group - poly * spread.L;
-            global_load<LOGN, LOGE, LO0, LOGE>(v, tid, spread.base + poly * spread.stride + (j << LOGN));
+        HEAMD_X_PROLOGUE();
+        if constexpr (SPREAD != kSourceSlab) {
+            const size_t poly = record / spread.L, j = record - poly * spread.L;  // record = poly * L + j
+            global_load<LOGN, LOGE, LO0, LOGE>(
+                v, tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
             if constexpr (SPREAD == kSourceLift) {
                 const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
 #pragma unroll
                 for (int r = 0; r < E; ++r) v[r] = v[r] < threshold ? v[r] : v[r] + increment;
-            } else if (ctx.moduli[j].p > p) {  // uniform: the source row is canonical mod q_j, not mod this row's modulus
+            } else if (ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p)) {
+                // uniform: the source row is canonical mod q_j, not mod this row's modulus (the split butterflies take
+                // any 64-bit multiplicand and have room for an addend below 2p, so they transform such a residue as it is)
 #pragma unroll
                 for (int r = 0; r < E; ++r) v[r] = barrett_reduce64_uniform(v[r], p, mod.barrett64);
             }
         } else {
-            global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
+            HEAMD_X_LOAD((global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x)));
         }
-        stamp<ABLATE>(1, true, false);
-        if constexpr (ABLATE & 1024) {  // memory only (measurement): the row goes straight back out, no butterflies
-            global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
-            return;
-        }
-        forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ABLATE>(v, tid, tw, p, true);
-        stamp<ABLATE>(2, false, false);
-        if constexpr (!(ABLATE & 2)) {
-            lds_store_a<ABLATE, LOGN, LOGE, LO0, LOGE>(v, tid, lds);
-            __syncthreads();
-        }
-        stamp<ABLATE>(3, false, true);
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true>(v, tid, tw, p, true)));
+        HEAMD_X_LDS((lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds)));
+        HEAMD_X_LDS(__syncthreads());
         if constexpr (S::P >= 3) {
             constexpr int LO1 = LOGN - 2 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            stamp<ABLATE>(4, false, true);
-            forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
-            stamp<ABLATE>(5, true, false);
-            if constexpr (!(ABLATE & 2)) {
-                lds_store_a<ABLATE, LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-                lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>();
-            }
-            stamp<ABLATE>(6, false, true);
+            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds)));
+            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false>(v, tid, tw, p, false)));
+            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds)));
+            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>()));
         }
         if constexpr (S::P >= 4) {
             constexpr int LO2 = LOGN - 3 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
-            if constexpr (!(ABLATE & 2)) {
-                lds_store_a<ABLATE, LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-                lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>();
-            }
+            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds)));
+            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false>(v, tid, tw, p, false)));
+            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds)));
+            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>()));
         }
         if constexpr (S::P >= 5) {
             constexpr int LO3 = LOGN - 4 * LOGE;
-            if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-            forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ABLATE>(v, tid, tw, p, false);
-            if constexpr (!(ABLATE & 2)) {
-                lds_store_a<ABLATE, LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-                lds_transpose_fence<LOGN, LOGE, LO3, 0>();
-            }
+            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds)));
+            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false>(v, tid, tw, p, false)));
+            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds)));
+            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO3, 0>()));
         }
-        if constexpr (!(ABLATE & 2)) lds_load_a<ABLATE, LOGN, LOGE, 0, S::R>(v, tid, lds);
-        stamp<ABLATE>(7, false, true);
-        forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ABLATE>(v, tid, tw, p, false);
-        canonicalize_all<MODE>(v, p);
-        stamp<ABLATE>(8, true, false);
-        if constexpr (ABLATE & (4 | 64)) {  // bit 6: skip the store only
-            uint64_t sum = 0;
-#pragma unroll
-            for (int r = 0; r < E; ++r) sum ^= v[r];
-            if (sum == 0x123456789ull) x[tid] = sum;  // keeps the work alive without streaming the row out
-        } else {
-            global_store<LOGN, LOGE, 0, S::R>(v, tid, x);
-        }
-        stamp<ABLATE>(9, true, false);
+        HEAMD_X_LDS((lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds)));
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, 0, S::R, MODE, false>(v, tid, tw, p, false)));
+        HEAMD_X_PASS((canonicalize_all<MODE>(v, p)));
+        HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v, tid, x)));
     }
 }
 
 // TENSOR: the BEHZ tensor product (Bfv+Multiply.swift:80-82) fused into the load.  The launch covers records
-// (item, c), c in {0, 1, 2}, of `row_period` rows; the words of row r of record (item, c) are computed from the four
-// Eval polynomials (a0, a1, b0, b1) of the item at tensor_source + (item * 4 + k) * row_period * N + r * N as
+// (item, c), c in {0, 1, 2}, of `record_rows` rows; the words of row r of record (item, c) are computed from the four
+// Eval polynomials (a0, a1, b0, b1) of the item at tensor_source + (item * 4 + k) * record_rows * N + r * N as
 // a0 b0 | a0 b1 + a1 b0 | a1 b1 while they are loaded, instead of by a kernel that writes them for this one to read.
 // KEYMAC: the lazy inner product with the key-switching key (Bfv+Keys.swift:180-202) fused into the load.  Records
-// are (polynomial, c), c in {0, 1}, of row_period = L + 1 rows; word k of row r is
+// are (polynomial, c), c in {0, 1}, of record_rows = L + 1 rows; word k of row r is
 // sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] mod ks_modulus[r], accumulated in the carry-counting form.
 constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2;
 struct InverseSource {
@@ -219,9 +203,9 @@ struct InverseSource {
 };
 
 template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab>
-__global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - LOGT) <= 4 ? 4 : 2))
-    ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, uint32_t mod_base, uint32_t mod_period,
-                      uint32_t row_period, uint32_t row_offset, const InverseSource source_spec) {
+__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
+    ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map,
+                      const InverseSource source_spec) {
     constexpr bool TENSOR = SOURCE == kInverseFromTensor;
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -230,12 +214,13 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t within = static_cast<uint32_t>(blockIdx.x % mod_period);  // row band as in ntt_forward_tiled
-    const size_t row = row_period == 0 ? blockIdx.x : (blockIdx.x / mod_period) * size_t(row_period) + row_offset + within;
-    const uint32_t mi = mod_base + within;
+    uint32_t record, within;
+    locate(map, blockIdx.x, record, within);
+    const size_t row = map.record_rows == 0 ? blockIdx.x : size_t(record) * map.record_rows + map.band_offset + within;
+    const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
-    const U64x2* __restrict__ tw = twiddle_table<MODE>(ctx, true) + (static_cast<size_t>(mi) << LOGN);
-    uint64_t* __restrict__ x = slab + (row << LOGN);
+    const Twiddles<MODE> tw(ctx, true, mi, LOGN);
+    const BufferResource x = make_resource(slab + (row << LOGN), 8u << LOGN);
     uint64_t v[E];
 
     if constexpr (S::P == 1) {
@@ -245,12 +230,11 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
         if constexpr (TENSOR) {
-            const size_t record = blockIdx.x / mod_period;
             const size_t item = record / 3;
             const uint32_t c = static_cast<uint32_t>(record - item * 3);  // wave-uniform
-            const size_t poly_words = static_cast<size_t>(row_period) << LOGN;
+            const size_t poly_words = static_cast<size_t>(map.record_rows) << LOGN;
             const uint64_t* const source =
-                tensor_source + item * 4 * poly_words + (static_cast<size_t>(row_offset + within) << LOGN);
+                tensor_source + item * 4 * poly_words + (static_cast<size_t>(map.band_offset + within) << LOGN);
             const uint64_t p = mod.p, factor = mod.product_factor;
             const int shift = static_cast<int>(mod.product_shift);
             const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
@@ -276,10 +260,9 @@ __global__ void __launch_bounds__(1 << LOGT, ((LOGN - LOGT) <= 3 ? 8 : (LOGN - L
                 }
             }
         } else if constexpr (SOURCE == kInverseFromKeyMac) {
-            const size_t record = blockIdx.x / mod_period;  // poly * 2 + c
-            const size_t poly = record >> 1, c = record & 1;
+            const size_t poly = record >> 1, c = record & 1;  // record = poly * 2 + c
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
-            const uint32_t r = row_offset + within;
+            const uint32_t r = map.band_offset + within;
             const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
             const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
             const uint64_t* const spread_row =
@@ -430,13 +413,12 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    auto kernel = mode == kModeHeadroomHalved ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroomHalved, 0, SPREAD>
-                  : mode == kModeHeadroom     ? ntt_forward_tiled<LOGN, LOGT, kModeHeadroom, 0, SPREAD>
-                  : mode == kModeApprox       ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, 0, SPREAD>
-                                              : ntt_forward_tiled<LOGN, LOGT, kModeExact, 0, SPREAD>;
+    auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD>
+                  : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD>
+                                        : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD>;
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period, spread, row_period, row_offset);
+                       make_row_map(mod_base, mod_period, row_period, row_offset), spread);
     return hipGetLastError();
 }
 
@@ -452,77 +434,33 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     }
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    using Kernel = void (*)(uint64_t*, const DeviceContext, uint32_t, uint32_t, uint32_t, uint32_t, const InverseSource);
+    using Kernel = void (*)(uint64_t*, const DeviceContext, const RowMap, const InverseSource);
     Kernel kernel;
     if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
     if (source == kInverseFromTensor) {
-        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, kInverseFromTensor>
-                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, kInverseFromTensor>
-                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromTensor>
-                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromTensor>;
+        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, kInverseFromTensor>
+                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromTensor>
+                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromTensor>;
     } else if (source == kInverseFromKeyMac) {
-        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved, kInverseFromKeyMac>
-                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom, kInverseFromKeyMac>
-                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromKeyMac>
-                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromKeyMac>;
+        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, kInverseFromKeyMac>
+                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromKeyMac>
+                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromKeyMac>;
     } else {
-        kernel = mode == kModeHeadroomHalved ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroomHalved>
-                 : mode == kModeHeadroom     ? ntt_inverse_tiled<LOGN, LOGT, kModeHeadroom>
-                 : mode == kModeApprox       ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
-                                             : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
+        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit>
+                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
+                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
     }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period, row_period, row_offset, source_spec);
+                       make_row_map(mod_base, mod_period, row_period, row_offset), source_spec);
     return hipGetLastError();
-}
-
-// occupancy probe (measurement only, wrong results): the 16-words-per-lane kernel with its transposes folded into a
-// 32 KB tile, so that three rows (register-limited) fit a CU's LDS instead of two (its 73 VGPRs allow six waves per SIMD)
-hipError_t launch_occupancy_probe(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
-                                  size_t rows, bool folded, hipStream_t stream) {
-    if (ctx.forward_twiddles_half == nullptr) return hipErrorInvalidValue;
-    const size_t lds_bytes = folded ? 4096 * sizeof(uint64_t) : lds_words(1u << 13) * sizeof(uint64_t);
-    auto kernel = folded ? ntt_forward_tiled<13, 9, kModeHeadroomHalved, 256> : ntt_forward_tiled<13, 9, kModeHeadroomHalved, 512>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(512), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period, SpreadSource{nullptr, 0, 0, 0}, 0u, 0u);
-    return hipGetLastError();
-}
-
-template <int ABLATE>
-hipError_t launch_ablation(uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
-                           size_t rows, hipStream_t stream) {
-    // the production configuration for N = 8192 (1024 lanes, headroom butterflies on the pre-halved tables)
-    constexpr size_t lds_bytes = lds_words(1u << 13) * sizeof(uint64_t);
-    if (ctx.forward_twiddles_half == nullptr) return hipErrorInvalidValue;
-    auto kernel = ntt_forward_tiled<13, 10, kModeHeadroomHalved, ABLATE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1024), lds_bytes, stream, slab, ctx, mod_base,
-                       mod_period, SpreadSource{nullptr, 0, 0, 0}, 0u, 0u);
-    return hipGetLastError();
-}
-
-uint32_t compute_unit_count() {
-    static const uint32_t count = [] {
-        int device = 0, units = 0;
-        if (hipGetDevice(&device) != hipSuccess ||
-            hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || units <= 0)
-            return 256u;
-        return static_cast<uint32_t>(units);
-    }();
-    return count;
 }
 
 // the production butterfly schedule for a context (what kNttVariantAuto picks)
 int production_mode(const DeviceContext& ctx) {
     if (ctx.approx_ok == 0) return kModeExact;
-    if (ctx.headroom_ok == 0) return kModeApprox;
-    return ctx.forward_twiddles_half != nullptr ? kModeHeadroomHalved : kModeHeadroom;
+    if (ctx.headroom_ok == 0 || ctx.forward_split_pairs == nullptr) return kModeApprox;
+    return kModeSplit;
 }
 
 }  // namespace
@@ -559,10 +497,6 @@ hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulu
     }
 }
 
-hipError_t set_ntt_timeline_buffer(uint64_t* device_buffer) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_timeline), &device_buffer, sizeof(device_buffer));
-}
-
 const char* ntt_variant_name(uint32_t log_degree) {
     switch (log_degree) {
         case 12: return "ntt_tiled<4096, 512 lanes x 8 words>";
@@ -588,15 +522,16 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
 }
 
 // [Q, Bsk] records (BEHZ): the first `headroom_prefix` moduli (the ciphertext moduli, when they are the usual <= 55-bit
-// primes) take the fold-free butterflies, the 61-bit Bsk primes the [0, 8p) ones -- two launches over row bands of
+// primes) take the fold-free split butterflies, the 61-bit Bsk primes the [0, 8p) ones -- two launches over row bands of
 // the same slab.  Falls back to one launch when the context has no such prefix or no tiled kernel.
 hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
                             hipStream_t stream) {
     const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
     const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
-    if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || records * record_rows > (size_t(1) << 30))
+    if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr ||
+        records * record_rows > (size_t(1) << 30))
         return launch_ntt(inverse, slab, ctx, 0, record_rows, records * record_rows, stream);
-    hipError_t e = launch_ntt_band(inverse, slab, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream);
+    hipError_t e = launch_ntt_band(inverse, slab, ctx, 0, prefix, record_rows, 0, records, kModeSplit, stream);
     if (e != hipSuccess) return e;
     return launch_ntt_band(inverse, slab, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox,
                            stream);
@@ -612,12 +547,11 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
     if (!tiled || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
     const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
-    if (prefix == 0 || prefix == record_rows || ctx.approx_ok == 0)
-        return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records,
-                               ctx.approx_ok == 0 ? kModeExact : production_mode(ctx), stream, kInverseFromTensor,
-                               InverseSource{lifted, nullptr, 0, 0});
+    if (prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr)
+        return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records, production_mode(ctx), stream,
+                               kInverseFromTensor, InverseSource{lifted, nullptr, 0, 0});
     const InverseSource spec{lifted, nullptr, 0, 0};
-    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeHeadroom, stream,
+    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeSplit, stream,
                                    kInverseFromTensor, spec);
     if (e != hipSuccess) return e;
     return launch_ntt_band(true, out, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox, stream,
@@ -652,55 +586,19 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
         }
         return hipSuccess;
     }
-    if (force_variant == kNttVariantStream) {
-        if (inverse || !ntt_stream_supports(ctx)) return hipErrorNotSupported;
-        return launch_ntt_forward_stream(slab, ctx, mod_base, mod_period, rows, 2 * compute_unit_count(), stream);
+    switch (force_variant) {
+        case kNttVariantAuto: case kNttVariantExact: case kNttVariantGeneric: case kNttVariantWide:
+        case kNttVariantTiled: case kNttVariantApprox: break;
+        default: return hipErrorInvalidValue;
     }
-    if (force_variant == kNttVariantPrefetch) {
-        if (inverse) return hipErrorNotSupported;
-        return launch_ntt_forward_prefetch(slab, ctx, mod_base, mod_period, rows, 2 * compute_unit_count(), stream);
-    }
-    if (force_variant >= kNttVariantAblateBase && ctx.log_degree == 13 && !inverse) {
-        switch (force_variant - kNttVariantAblateBase) {  // measurement-only kernels: results are NOT an NTT
-            case 0: return launch_ablation<0>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 1: return launch_ablation<1>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 2: return launch_ablation<2>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 3: return launch_ablation<3>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 4: return launch_ablation<4>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 7: return launch_ablation<7>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 8: return launch_ablation<8>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 9: return launch_ablation<9>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 15: return launch_ablation<15>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 16: return launch_ablation<16>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 32: return launch_ablation<32>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 64: return launch_ablation<64>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 128: return launch_ablation<128>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 1024: return launch_ablation<1024>(slab, ctx, mod_base, mod_period, rows, stream);
-            case 256: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, true, stream);
-            case 512: return launch_occupancy_probe(slab, ctx, mod_base, mod_period, rows, false, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    const bool approx = ctx.approx_ok != 0 && force_variant != kNttVariantExact && force_variant != kNttVariantGeneric;
-    // kNttVariantApprox pins the [0, 8p) schedule even when the moduli leave headroom (measurement / tests)
-    const int mode = !approx ? kModeExact
-                     : (ctx.headroom_ok != 0 && force_variant != kNttVariantApprox)
-                         ? (ctx.forward_twiddles_half != nullptr && force_variant != kNttVariantWidest
-                                ? kModeHeadroomHalved
-                                : kModeHeadroom)
-                                                                                     : kModeApprox;
-    if (ntt_pipelined_supports(ctx.log_degree) && force_variant >= kNttVariantPipelinedBase &&
-        force_variant < kNttVariantPipelinedBase + 4) {
-        // persistent / software-prefetching kernels: kept as measured alternatives (they lose to plain occupancy,
-        // see profiles/r01_ntt_variants*.txt)
-        return launch_ntt_pipelined(inverse, approx, force_variant - kNttVariantPipelinedBase, slab, ctx, mod_base,
-                                    mod_period, rows, stream);
-    }
+    // kNttVariantExact / kNttVariantApprox pin the butterfly schedule (tests); every variant computes the same transform
+    const int mode = (ctx.approx_ok == 0 || force_variant == kNttVariantExact || force_variant == kNttVariantGeneric)
+                         ? kModeExact
+                         : (force_variant == kNttVariantApprox ? kModeApprox : production_mode(ctx));
     // production choice (auto): 8 words per lane wherever a workgroup of <= 1024 lanes allows it.  Two rows fit the
     // CU's LDS at a time, so the waves per CU -- what hides the global/LDS latencies -- are set by the lanes per row:
-    // 32 waves per CU with 8 words per lane against 16 with 16 words (measured: profiles/r01c_ntt_variants.txt).
-    if (force_variant == kNttVariantAuto || force_variant == kNttVariantExact || force_variant == kNttVariantApprox ||
-        force_variant == kNttVariantWidest) {
+    // 32 waves per CU with 8 words per lane against 16 with 16 words.
+    if (force_variant == kNttVariantAuto || force_variant == kNttVariantExact || force_variant == kNttVariantApprox) {
         switch (ctx.log_degree) {
             case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
@@ -716,8 +614,8 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             default: break;
         }
     }
-    if (force_variant != kNttVariantGeneric) {
-        switch (ctx.log_degree) {  // kNttVariantTiled: 32 words per lane
+    if (force_variant == kNttVariantTiled) {  // 32 words per lane
+        switch (ctx.log_degree) {
             case 12: return launch_tiled<12, 7>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 13: return launch_tiled<13, 8>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 14: return launch_tiled<14, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);

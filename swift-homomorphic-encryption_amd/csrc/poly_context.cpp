@@ -66,6 +66,17 @@ static DeviceModulus make_constants(u64 p) {
     return m;
 }
 
+void set_inverse_degree_constants(DeviceModulus& m, u64 inverse_degree, u64 inverse_degree_root) {
+    m.inv_degree = inverse_degree;
+    m.inv_degree_shoup = shoup_factor(inverse_degree, m.p);
+    m.inv_degree_root = inverse_degree_root;
+    m.inv_degree_root_shoup = shoup_factor(inverse_degree_root, m.p);
+    m.inv_degree_split = split_shifted(inverse_degree, m.p);
+    m.inv_degree_factors = split_factors(inverse_degree, m.p);
+    m.inv_degree_root_split = split_shifted(inverse_degree_root, m.p);
+    m.inv_degree_root_factors = split_factors(inverse_degree_root, m.p);
+}
+
 int PolyContext::create(uint32_t degree, const uint64_t* moduli, uint32_t count, std::unique_ptr<PolyContext>& out,
                         bool host_only) {
     out.reset();
@@ -131,10 +142,7 @@ int PolyContext::create(uint32_t degree, const uint64_t* moduli, uint32_t count,
             if (!inverse_mod(degree % p, p, inverse_degree)) return HE_ERR_NOT_INVERTIBLE;
             const u64 inverse_degree_root = mul_mod(inverse_degree, inverse[n - 1].x, p);  // PolyRq+Ntt.swift:162-168
             m.has_ntt = 1;
-            m.inv_degree = inverse_degree;
-            m.inv_degree_shoup = shoup_factor(inverse_degree, p);
-            m.inv_degree_root = inverse_degree_root;
-            m.inv_degree_root_shoup = shoup_factor(inverse_degree_root, p);
+            set_inverse_degree_constants(m, inverse_degree, inverse_degree_root);
         }
         ctx->host_moduli_[i] = m;
     }
@@ -157,10 +165,9 @@ int PolyContext::upload() {
     const size_t bytes_moduli = round_up(count * sizeof(DeviceModulus));
     const size_t bytes_twiddles = round_up(count * n * sizeof(U64x2));
     const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
-    bool all_headroom = count > 0;
-    for (u64 q : moduli_)
-        if (q >= (static_cast<u64>(1) << 55) || q < (static_cast<u64>(1) << 40)) all_headroom = false;
-    const size_t total = bytes_moduli + (all_headroom ? 4 : 2) * bytes_twiddles + bytes_inverse_q_last;
+    // limb-wise Shoup form of both twiddle tables: pairs (16 B) and quotient factors (8 B) per entry
+    const size_t bytes_factors = round_up(count * n * sizeof(u64));
+    const size_t total = bytes_moduli + 4 * bytes_twiddles + bytes_inverse_q_last + 2 * bytes_factors;
     HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
     char* base = static_cast<char*>(device_block_);
     HEAMD_HIP_TRY(hipMemcpy(base, host_moduli_.data(), count * sizeof(DeviceModulus), hipMemcpyHostToDevice));
@@ -171,20 +178,33 @@ int PolyContext::upload() {
     HEAMD_HIP_TRY(hipMemcpy(inverse, host_inverse_.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
     HEAMD_HIP_TRY(hipMemcpy(inverse_q_last, host_inverse_q_last_.data(), count * count * sizeof(U64x2),
                             hipMemcpyHostToDevice));
-    dev_.forward_twiddles_half = nullptr;
-    dev_.inverse_twiddles_half = nullptr;
-    if (all_headroom) {
-        // (w, floor(w 2^63 / p)) = (w, wf >> 1): the factor the headroom butterflies use (ntt_common.hpp)
-        char* forward_half = inverse_q_last + bytes_inverse_q_last;
-        char* inverse_half = forward_half + bytes_twiddles;
-        std::vector<U64x2> halved(count * n);
-        for (size_t k = 0; k < count * n; ++k) halved[k] = U64x2{host_forward_[k].x, host_forward_[k].y >> 1};
-        HEAMD_HIP_TRY(hipMemcpy(forward_half, halved.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
-        for (size_t k = 0; k < count * n; ++k) halved[k] = U64x2{host_inverse_[k].x, host_inverse_[k].y >> 1};
-        HEAMD_HIP_TRY(hipMemcpy(inverse_half, halved.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
-        dev_.forward_twiddles_half = reinterpret_cast<const U64x2*>(forward_half);
-        dev_.inverse_twiddles_half = reinterpret_cast<const U64x2*>(inverse_half);
+    char* forward_pairs = inverse_q_last + bytes_inverse_q_last;
+    char* inverse_pairs = forward_pairs + bytes_twiddles;
+    char* forward_factors = inverse_pairs + bytes_twiddles;
+    char* inverse_factors = forward_factors + bytes_factors;
+    {
+        std::vector<U64x2> pairs(count * n);
+        std::vector<u64> factors(count * n);
+        for (int direction = 0; direction < 2; ++direction) {
+            const std::vector<U64x2>& table = direction == 0 ? host_forward_ : host_inverse_;
+            for (size_t i = 0; i < count; ++i) {
+                const u64 p = moduli_[i];
+                for (size_t k = 0; k < n; ++k) {
+                    const u64 w = table[i * n + k].x;
+                    pairs[i * n + k] = U64x2{w, split_shifted(w, p)};
+                    factors[i * n + k] = split_factors(w, p);
+                }
+            }
+            HEAMD_HIP_TRY(hipMemcpy(direction == 0 ? forward_pairs : inverse_pairs, pairs.data(),
+                                    count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+            HEAMD_HIP_TRY(hipMemcpy(direction == 0 ? forward_factors : inverse_factors, factors.data(),
+                                    count * n * sizeof(u64), hipMemcpyHostToDevice));
+        }
     }
+    dev_.forward_split_pairs = reinterpret_cast<const U64x2*>(forward_pairs);
+    dev_.inverse_split_pairs = reinterpret_cast<const U64x2*>(inverse_pairs);
+    dev_.forward_split_factors = reinterpret_cast<const u64*>(forward_factors);
+    dev_.inverse_split_factors = reinterpret_cast<const u64*>(inverse_factors);
     dev_.moduli = reinterpret_cast<const DeviceModulus*>(base);
     dev_.forward_twiddles = reinterpret_cast<const U64x2*>(forward);
     dev_.inverse_twiddles = reinterpret_cast<const U64x2*>(inverse);

@@ -77,6 +77,9 @@ class PolyContext {
     mutable DeviceContext32 dev32_{};
 };
 
+// N^-1 and N^-1 psi^(-N/2) of a modulus with every derived constant (64-bit and limb-wise Shoup forms)
+void set_inverse_degree_constants(DeviceModulus& m, u64 inverse_degree, u64 inverse_degree_root);
+
 // Validation of one chain element (designated init) -- shared with the BFV context builder.
 int validate_poly_context_prefix(uint32_t degree, const uint64_t* moduli, uint32_t count, bool has_next);
 

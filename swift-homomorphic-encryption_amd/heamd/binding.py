@@ -116,7 +116,6 @@ SIGNATURES = [
     ("he_poly_context_create_host_only", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_poly_context_copy_ntt_tables", ctypes.c_int, [vp, c_u32, U64P, U64P, U64P, U64P, U64P, U64P]),
     ("he_ntt_device_variant", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, ctypes.c_int, vp]),
-    ("he_debug_set_ntt_timeline", ctypes.c_int, [vp]),
     ("he_bfv_context_create_host_only", ctypes.c_int, [c_u32, c_u64, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_bfv_copy_bsk_moduli", ctypes.c_int, [vp, U64P]),
 ]
