@@ -208,38 +208,99 @@ struct LazyReducer {
     __device__ __forceinline__ uint64_t operator()(uint64_t x) const { return csub63<true>(lazy(x), neg_p); }
 };
 
-// ---- forward pass over element bits [LO, LO+W): stages run from the top bit down --------------------------------
+// ---- register passes ---------------------------------------------------------------------------------------------
+// A pass runs W radix-2 stages on the 2^LOGE words a lane holds of each of ROWS residue rows of ONE modulus: every
+// twiddle is fetched once and serves the butterflies of all rows (two rows per workgroup halve the gathers, scalar
+// loads and address arithmetic per row).  The 2^W - 1 twiddles of a pass are walked in butterfly order and requested
+// one step ahead -- the gather of twiddle k + 1 is in flight while the butterflies of twiddle k run; the first one is
+// requested by the caller BEFORE the LDS exchange that precedes the pass (pass_first_twiddle).
+// Twiddles per lane: forward stage j of a pass (stride 2^(W-1-j) registers) has 2^(LOGE-W+j) of them, inverse stage j
+// (stride 2^j) has 2^(LOGE-1-j); they are walked stage by stage.
+template <int LOGE, int W, bool INVERSE>
+constexpr int pass_twiddle_count() {
+    int count = 0;
+    for (int j = 0; j < W; ++j) count += INVERSE ? (1 << (LOGE - 1 - j)) : (1 << (LOGE - W + j));
+    return count;
+}
+template <int LOGE, int W, bool INVERSE>
+struct PassWalk {
+    static constexpr int kCount = pass_twiddle_count<LOGE, W, INVERSE>();
+    struct Table {
+        int stage[kCount > 0 ? kCount : 1];
+        int index[kCount > 0 ? kCount : 1];
+    };
+    static constexpr Table make() {
+        Table t{};
+        int k = 0;
+        for (int j = 0; j < W; ++j) {
+            const int here = INVERSE ? (1 << (LOGE - 1 - j)) : (1 << (LOGE - W + j));
+            for (int i = 0; i < here; ++i, ++k) {
+                t.stage[k] = j;
+                t.index[k] = i;
+            }
+        }
+        return t;
+    }
+    static constexpr Table kTable = make();
+};
+template <int LOGE, int W, bool INVERSE>
+constexpr int pass_stage_of(int k) { return PassWalk<LOGE, W, INVERSE>::kTable.stage[k]; }
+template <int LOGE, int W, bool INVERSE>
+constexpr int pass_index_in_stage(int k) { return PassWalk<LOGE, W, INVERSE>::kTable.index[k]; }
+
+template <int LOGN, int LOGE, int LO, int W, bool UNIFORM_TWIDDLES>
+constexpr bool stage_is_uniform(int b) {
+#ifdef HEAMD_X_UNIFORM_TW  // experiment (wrong results): every twiddle fetch is a scalar load, no gathers
+    return true;
+#else
+    // When the six in-wave lane bits all sit at or below b the twiddle index is the same for the whole wave: read it
+    // through the scalar cache into SGPRs.
+    return UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
+#endif
+}
+
+// k-th twiddle of a forward pass (stages from the top bit of the pass down)
 template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
-__device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                             uint64_t p, bool first_stage_canonical) {
-    constexpr int E = 1 << LOGE;
+__device__ __forceinline__ TwiddleWords forward_twiddle(const Twiddles<MODE>& tw, uint32_t lane_elements, int k) {
+    const int j = pass_stage_of<LOGE, W, false>(k), idx = pass_index_in_stage<LOGE, W, false>(k);
+    const int b = LO + W - 1 - j;      // element bit paired by this stage
+    const int s = LOGN - 1 - b;        // global stage number; m = 2^s groups
+    const int stride = 1 << (b - LO);  // register distance of a pair
+    // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint bit fields
+    const uint32_t fixed = (1u << s) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
+    uint32_t lane_twiddle = lane_elements >> (b + 1);
+    if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
+        return fetch_twiddle<MODE, true>(tw, __builtin_amdgcn_readfirstlane(lane_twiddle), fixed);
+    return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
+}
+
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS>
+__device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                             uint64_t p, bool first_stage_canonical, TwiddleWords first) {
+    constexpr int COUNT = pass_twiddle_count<LOGE, W, false>();
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
     static_assert(MODE != kModeSplit || 1 + 8 * LOGN <= 127, "split mode: growth must stay below 2^7 p");
+    const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
+    TwiddleWords pending = first;
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const int b = LO + W - 1 - j;         // element bit paired by this stage
-        const int s = LOGN - 1 - b;           // global stage number; m = 2^s groups
-        const int stride = 1 << (b - LO);     // register distance of a pair
-        // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint, so the lane part is
-        // one offset per stage and the register part an immediate.  When the six in-wave lane bits all sit
-        // at or below b the index is the same for the whole wave: read it through the scalar cache into SGPRs.
-#ifdef HEAMD_X_UNIFORM_TW  // experiment (wrong results): every twiddle fetch is a scalar load, no gathers
-        const bool uniform = true;
-#else
-        const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
-#endif
-        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
-        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+    for (int k = 0; k < COUNT; ++k) {
+        const int j = pass_stage_of<LOGE, W, false>(k), idx = pass_index_in_stage<LOGE, W, false>(k);
+        const int b = LO + W - 1 - j;
+        const int stride = 1 << (b - LO);
+        const int base = idx * 2 * stride;
+        const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
+        const TwiddleWords w = pending;
+        if (k + 1 < COUNT) {
+            pending = forward_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
+            __builtin_amdgcn_sched_barrier(0);  // the request stays ahead of the butterflies below
+        }
 #pragma unroll
-        for (int base = 0; base < E; base += 2 * stride) {
-            const uint32_t fixed = (1u << s) + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1));
-            const TwiddleWords w = uniform ? fetch_twiddle<MODE, true>(tw, lane_twiddle, fixed)
-                                           : fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
+        for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
-                uint64_t x = v[base + o];
-                const uint64_t y = v[base + o + stride];
+                uint64_t x = v[row][base + o];
+                const uint64_t y = v[row][base + o + stride];
                 if (MODE != kModeSplit && !(first_stage_canonical && j == 0)) x = csub_uniform(x, half_bound);
                 if constexpr (MODE == kModeSplit || MODE == kModeApprox) {
                     // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
@@ -251,17 +312,23 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                         sum = uniform ? shoup_lazy4_fma<true>(x, y, w.w, w.second, neg_p)
                                       : shoup_lazy4_fma<false>(x, y, w.w, w.second, neg_p);
                     }
-                    v[base + o] = sum;
-                    v[base + o + stride] = ((x << 1) + half_bound) - sum;
+                    v[row][base + o] = sum;
+                    v[row][base + o + stride] = ((x << 1) + half_bound) - sum;
                     continue;
                 }
                 const uint64_t t = uniform ? Lazy<MODE>::template mul<true>(y, w, neg_p)
                                            : Lazy<MODE>::template mul<false>(y, w, neg_p);
-                v[base + o] = x + t;
-                v[base + o + stride] = x + half_bound - t;
+                v[row][base + o] = x + t;
+                v[row][base + o + stride] = x + half_bound - t;
             }
         }
+        if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
     }
+}
+// the first twiddle of a forward pass: request it before the LDS exchange that feeds the pass
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
+__device__ __forceinline__ TwiddleWords forward_first_twiddle(const Twiddles<MODE>& tw, uint32_t tid) {
+    return forward_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid), 0);
 }
 
 // Inverse transform, split mode: bound (as a shift of p) on the words ENTERING the stage on element bit b.  Canonical
@@ -281,56 +348,72 @@ constexpr int inverse_in_shift(int b) {
     }
 }
 
+// k-th twiddle of an inverse pass (stages from the low bit of the pass up); the very last stage of the transform
+// (bit LOGN-1) multiplies by the two N^-1 constants instead
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
+__device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw, uint32_t lane_elements, int k) {
+    constexpr uint32_t N = 1u << LOGN;
+    const int j = pass_stage_of<LOGE, W, true>(k), idx = pass_index_in_stage<LOGE, W, true>(k);
+    const int b = LO + j;
+    if (b == LOGN - 1) return TwiddleWords{0, 0, 0};
+    const int stride = 1 << (b - LO);
+    const uint32_t m = N >> (b + 1);
+    const uint32_t fixed = (N - 2 * m + 1) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
+    uint32_t lane_twiddle = lane_elements >> (b + 1);
+    if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
+        return fetch_twiddle<MODE, true>(tw, __builtin_amdgcn_readfirstlane(lane_twiddle), fixed);
+    return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
+}
+
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES = false>
-__device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                             const DeviceModulus& mod, bool first_stage_canonical) {
-    constexpr int E = 1 << LOGE;
-    constexpr uint32_t N = 1u << LOGN;
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS>
+__device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                             const DeviceModulus& mod, bool first_stage_canonical, TwiddleWords first) {
+    constexpr int COUNT = pass_twiddle_count<LOGE, W, true>();
     const uint64_t p = mod.p;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     // Words entering the stage on element bit b live in [0, p << in_shift(b)): canonical input for b = 0; after
     // that sums double the bound and products are < p << K (K = Lazy::kProductLog); exact / approx: once the bound
     // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
     constexpr int H = Lazy<MODE>::kInverseCapLog;
+    const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
+    TwiddleWords pending = first;
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
+    for (int k = 0; k < COUNT; ++k) {
+        const int j = pass_stage_of<LOGE, W, true>(k), idx = pass_index_in_stage<LOGE, W, true>(k);
         const int b = LO + j;
         const int stride = 1 << (b - LO);
-        const uint32_t m = N >> (b + 1);
+        const int base = idx * 2 * stride;
         const bool last_stage = (b == LOGN - 1);
         const bool canonical_in = first_stage_canonical && j == 0;
         const int in_shift = canonical_in ? 0 : inverse_in_shift<MODE>(b);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
-        const bool uniform = UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
-        uint32_t lane_twiddle = lane_part<LOGN, LOGE, LO, W>(tid) >> (b + 1);
-        if (uniform) lane_twiddle = __builtin_amdgcn_readfirstlane(lane_twiddle);
+        const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
+        const TwiddleWords w = pending;
+        if (k + 1 < COUNT) {
+            pending = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int base = 0; base < E; base += 2 * stride) {
-            TwiddleWords w = {0, 0, 0};
-            if (!last_stage) {
-                const uint32_t fixed = (N - 2 * m + 1) + (register_part<LOGN, LOGE, LO, W>(base) >> (b + 1));
-                w = uniform ? fetch_twiddle<MODE, true>(tw, lane_twiddle, fixed)
-                            : fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
-            }
+        for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
-                const uint64_t x = v[base + o];
-                const uint64_t y = v[base + o + stride];
+                const uint64_t x = v[row][base + o];
+                const uint64_t y = v[row][base + o + stride];
                 uint64_t sum = x + y;
                 const uint64_t diff = x + bound - y;
                 if (last_stage) {
                     if constexpr (MODE == kModeSplit) {
                         const LazyReducer reduce(p);
-                        v[base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
-                                                                        mod.inv_degree_factors, neg_p));
-                        v[base + o + stride] = reduce(split_mul_add<true, false>(
+                        v[row][base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
+                                                                             mod.inv_degree_factors, neg_p));
+                        v[row][base + o + stride] = reduce(split_mul_add<true, false>(
                             0, diff, mod.inv_degree_root, mod.inv_degree_root_split, mod.inv_degree_root_factors, neg_p));
                     } else {
-                        v[base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
-                        v[base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
+                        v[row][base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
+                        v[row][base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                     }
                 } else {
                     if (fold) {
@@ -340,13 +423,18 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[1 << LOGE], uint32_t 
                             sum = csub_uniform(sum, bound);
                         }
                     }
-                    v[base + o] = sum;
-                    v[base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
-                                                   : Lazy<MODE>::template mul<false>(diff, w, neg_p);
+                    v[row][base + o] = sum;
+                    v[row][base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
+                                                        : Lazy<MODE>::template mul<false>(diff, w, neg_p);
                 }
             }
         }
+        if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
+__device__ __forceinline__ TwiddleWords inverse_first_twiddle(const Twiddles<MODE>& tw, uint32_t tid) {
+    return inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid), 0);
 }
 
 template <int LOGN, int LOGE, int LO, int W>
@@ -412,15 +500,18 @@ __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
     return csub_uniform(x, p);
 }
 
-template <int MODE, int N>
-__device__ __forceinline__ void canonicalize_all(uint64_t (&v)[N], uint64_t p) {
-    if constexpr (MODE == kModeSplit) {
-        const LazyReducer reduce(p);
+template <int MODE, int ROWS, int N>
+__device__ __forceinline__ void canonicalize_all(uint64_t (&v)[ROWS][N], uint64_t p) {
 #pragma unroll
-        for (int r = 0; r < N; ++r) v[r] = reduce(v[r]);
-    } else {
+    for (int row = 0; row < ROWS; ++row) {
+        if constexpr (MODE == kModeSplit) {
+            const LazyReducer reduce(p);
 #pragma unroll
-        for (int r = 0; r < N; ++r) v[r] = canonicalize<MODE>(v[r], p);
+            for (int r = 0; r < N; ++r) v[row][r] = reduce(v[row][r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < N; ++r) v[row][r] = canonicalize<MODE>(v[row][r], p);
+        }
     }
 }
 

@@ -28,7 +28,7 @@
 // WRONG results and exist only in lib/variants/ for timing.
 #ifdef HEAMD_X_NO_LOAD
 #define HEAMD_X_LOAD(statement)                                                     \
-    _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) v[r_] = (tid * 2654435761u + r_) % p
+    _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) v[k][r_] = (tid * 2654435761u + r_ + k) % p
 #else
 #define HEAMD_X_LOAD(statement) statement
 #endif
@@ -36,7 +36,7 @@
 #define HEAMD_X_STORE(statement)                                                    \
     do {                                                                            \
         uint64_t sum_ = 0;                                                          \
-        _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) sum_ ^= v[r_];             \
+        _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) sum_ ^= v[k][r_];          \
         if (sum_ == 0x123456789ull) statement;                                      \
     } while (0)
 #else
@@ -73,6 +73,7 @@ using namespace ntt;
 // vector instruction is spent on it.
 struct RowMap {
     uint32_t mod_base, band_rows, band_magic, record_rows, band_offset;
+    uint32_t record_base;  // records before the first one of this launch (the odd record after a launch of pairs)
 };
 __device__ __forceinline__ void locate(const RowMap& map, uint32_t block, uint32_t& record, uint32_t& within) {
     if (map.band_rows == 1) {
@@ -89,8 +90,22 @@ __device__ __forceinline__ void locate(const RowMap& map, uint32_t block, uint32
     record = q;
     within = static_cast<uint32_t>(r);
 }
-RowMap make_row_map(uint32_t mod_base, uint32_t band_rows, uint32_t record_rows, uint32_t band_offset) {
-    return RowMap{mod_base, band_rows, static_cast<uint32_t>((uint64_t(1) << 32) / band_rows) + 1u, record_rows, band_offset};
+RowMap make_row_map(uint32_t mod_base, uint32_t band_rows, uint32_t record_rows, uint32_t band_offset,
+                    uint32_t record_base = 0) {
+    return RowMap{mod_base, band_rows, static_cast<uint32_t>((uint64_t(1) << 32) / band_rows) + 1u, record_rows, band_offset,
+                  record_base};
+}
+// A workgroup transforms ROWS rows of one modulus: the same band row of ROWS consecutive records.
+template <int ROWS>
+__device__ __forceinline__ void locate_rows(const RowMap& map, uint32_t block, size_t (&rows)[ROWS], uint32_t& record,
+                                            uint32_t& within) {
+    uint32_t group;
+    locate(map, block, group, within);
+    record = map.record_base + group * ROWS;
+    const size_t stride = map.record_rows == 0 ? map.band_rows : map.record_rows;
+    const size_t first = size_t(record) * stride + (map.record_rows == 0 ? 0 : map.band_offset) + within;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) rows[k] = first + k * stride;
 }
 
 // Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
@@ -113,78 +128,149 @@ constexpr int min_waves_per_simd(int log_words_per_lane) {
     return log_words_per_lane <= 3 ? 8 : log_words_per_lane <= 4 ? 4 : 2;
 }
 
-template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab>
+// ROWS rows of one modulus through ONE LDS tile, one after the other: a row's words leave in the layout of pass FROM
+// and come back in the layout of pass TO.  Between two rows every reader of the first must be done before the
+// second is written (the same fence the exchange itself needs: wave-private once a wave owns its slice of the row).
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS>
+__device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
+#ifndef HEAMD_X_NO_LDS
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row) {
+        if (row > 0) lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
+        lds_store<LOGN, LOGE, LO_FROM, W_FROM>(v[row], tid, lds);
+        lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
+        lds_load<LOGN, LOGE, LO_TO, W_TO>(v[row], tid, lds);
+    }
+#endif
+}
+
+// ROWS residue rows of one modulus, registers to registers: in -- the words of the top pass
+// (element_index<LOGN, LOGE, LOGN - LOGE, LOGE>), out -- the canonical transforms in the layout of the last pass
+// (element_index<LOGN, LOGE, 0, Schedule::R>).  The first twiddle of a pass is requested before the exchange that
+// feeds the pass.
+template <int LOGN, int LOGE, int MODE, int ROWS>
+__device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                            uint64_t p, uint64_t* lds) {
+    using S = Schedule<LOGN, LOGE>;
+    constexpr int LO0 = LOGN - LOGE;
+#ifndef HEAMD_X_NO_PASS
+    forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS>(
+        v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
+#endif
+    if constexpr (S::P >= 3) {
+        constexpr int LO1 = LOGN - 2 * LOGE;
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO0, LOGE, LO1, LOGE, ROWS>(v, tid, lds);
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+    }
+    if constexpr (S::P >= 4) {
+        constexpr int LO1 = LOGN - 2 * LOGE, LO2 = LOGN - 3 * LOGE;
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, tid, lds);
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+    }
+    if constexpr (S::P >= 5) {
+        constexpr int LO2 = LOGN - 3 * LOGE, LO3 = LOGN - 4 * LOGE;
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, tid, lds);
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+    }
+    {
+        constexpr int LO_PREVIOUS = LOGN - (S::P - 1) * LOGE;
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO_PREVIOUS, LOGE, 0, S::R, ROWS>(v, tid, lds);
+        HEAMD_X_PASS((forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+    }
+    HEAMD_X_PASS((canonicalize_all<MODE>(v, p)));
+}
+
+// ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
+// (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
+template <int LOGN, int LOGE, int MODE, int ROWS>
+__device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                            const DeviceModulus& mod, uint64_t* lds) {
+    using S = Schedule<LOGN, LOGE>;
+    inverse_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(
+        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, tid));
+    if constexpr (S::P >= 3) {
+        constexpr int LO1 = S::R;
+        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, 0, S::R, LO1, LOGE, ROWS>(v, tid, lds);
+        inverse_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
+    }
+    if constexpr (S::P >= 4) {
+        constexpr int LO1 = S::R, LO2 = S::R + LOGE;
+        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, tid, lds);
+        inverse_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
+    }
+    if constexpr (S::P >= 5) {
+        constexpr int LO2 = S::R + LOGE, LO3 = S::R + 2 * LOGE;
+        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, tid);
+        exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, tid, lds);
+        inverse_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
+    }
+    {
+        constexpr int LOL = LOGN - LOGE, LO_PREVIOUS = S::P == 2 ? 0 : LOL - LOGE;
+        constexpr int W_PREVIOUS = S::P == 2 ? S::R : LOGE;
+        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LOL, LOGE, MODE, true>(tw, tid);
+        exchange<LOGN, LOGE, LO_PREVIOUS, W_PREVIOUS, LOL, LOGE, ROWS>(v, tid, lds);
+        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true, ROWS>(v, tid, tw, mod, false, first);  // top bits: uniform twiddles
+    }
+}
+
+template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab, int ROWS = 1>
 __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const SpreadSource spread) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
+    static_assert(ROWS == 1 || (SPREAD == kSourceSlab && S::P >= 2), "row pairs: plain slabs through the LDS tile");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
-    locate(map, blockIdx.x, record, within);
-    const size_t row = map.record_rows == 0 ? blockIdx.x : size_t(record) * map.record_rows + map.band_offset + within;
+    size_t rows[ROWS];
+    locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> tw(ctx, false, mi, LOGN);
-    const BufferResource x = make_resource(slab + (row << LOGN), 8u << LOGN);
     const uint64_t p = mod.p;
-    uint64_t v[E];
+    uint64_t v[ROWS][E];
 
     if constexpr (S::P == 1) {
-        global_load<LOGN, LOGE, 0, LOGN>(v, tid, x);
-        forward_pass<LOGN, LOGE, 0, LOGN, MODE, true>(v, tid, tw, p, true);
+        const BufferResource x = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
+        global_load<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
+        forward_pass<LOGN, LOGE, 0, LOGN, MODE, true, 1>(v, tid, tw, p, true,
+                                                        forward_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, true>(tw, tid));
         canonicalize_all<MODE>(v, p);
-        global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
+        global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
         HEAMD_X_PROLOGUE();
         if constexpr (SPREAD != kSourceSlab) {
             const size_t poly = record / spread.L, j = record - poly * spread.L;  // record = poly * L + j
             global_load<LOGN, LOGE, LO0, LOGE>(
-                v, tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
+                v[0], tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
             if constexpr (SPREAD == kSourceLift) {
                 const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
 #pragma unroll
-                for (int r = 0; r < E; ++r) v[r] = v[r] < threshold ? v[r] : v[r] + increment;
+                for (int r = 0; r < E; ++r) v[0][r] = v[0][r] < threshold ? v[0][r] : v[0][r] + increment;
             } else if (ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p)) {
                 // uniform: the source row is canonical mod q_j, not mod this row's modulus (the split butterflies take
                 // any 64-bit multiplicand and have room for an addend below 2p, so they transform such a residue as it is)
 #pragma unroll
-                for (int r = 0; r < E; ++r) v[r] = barrett_reduce64_uniform(v[r], p, mod.barrett64);
+                for (int r = 0; r < E; ++r) v[0][r] = barrett_reduce64_uniform(v[0][r], p, mod.barrett64);
             }
         } else {
-            HEAMD_X_LOAD((global_load<LOGN, LOGE, LO0, LOGE>(v, tid, x)));
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                HEAMD_X_LOAD((global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
         }
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true>(v, tid, tw, p, true)));
-        HEAMD_X_LDS((lds_store<LOGN, LOGE, LO0, LOGE>(v, tid, lds)));
-        HEAMD_X_LDS(__syncthreads());
-        if constexpr (S::P >= 3) {
-            constexpr int LO1 = LOGN - 2 * LOGE;
-            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds)));
-            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false>(v, tid, tw, p, false)));
-            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds)));
-            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO1, (S::P >= 4 ? LOGN - 3 * LOGE : 0)>()));
-        }
-        if constexpr (S::P >= 4) {
-            constexpr int LO2 = LOGN - 3 * LOGE;
-            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds)));
-            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false>(v, tid, tw, p, false)));
-            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds)));
-            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO2, (S::P >= 5 ? LOGN - 4 * LOGE : 0)>()));
-        }
-        if constexpr (S::P >= 5) {
-            constexpr int LO3 = LOGN - 4 * LOGE;
-            HEAMD_X_LDS((lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds)));
-            HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false>(v, tid, tw, p, false)));
-            HEAMD_X_LDS((lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds)));
-            HEAMD_X_LDS((lds_transpose_fence<LOGN, LOGE, LO3, 0>()));
-        }
-        HEAMD_X_LDS((lds_load<LOGN, LOGE, 0, S::R>(v, tid, lds)));
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, 0, S::R, MODE, false>(v, tid, tw, p, false)));
-        HEAMD_X_PASS((canonicalize_all<MODE>(v, p)));
-        HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v, tid, x)));
+        forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, p, lds);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
     }
 }
 
@@ -202,11 +288,12 @@ struct InverseSource {
     uint32_t L, top_rows;    // key MAC: source moduli, rows per key polynomial
 };
 
-template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab>
+template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab, int ROWS = 1>
 __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map,
                       const InverseSource source_spec) {
     constexpr bool TENSOR = SOURCE == kInverseFromTensor;
+    static_assert(ROWS == 1 || SOURCE == kInverseFromSlab, "row pairs: plain slabs");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
@@ -215,18 +302,19 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
-    locate(map, blockIdx.x, record, within);
-    const size_t row = map.record_rows == 0 ? blockIdx.x : size_t(record) * map.record_rows + map.band_offset + within;
+    size_t rows[ROWS];
+    locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> tw(ctx, true, mi, LOGN);
-    const BufferResource x = make_resource(slab + (row << LOGN), 8u << LOGN);
-    uint64_t v[E];
+    uint64_t v[ROWS][E];
 
     if constexpr (S::P == 1) {
-        global_load<LOGN, LOGE, 0, LOGN>(v, tid, x);
-        inverse_pass<LOGN, LOGE, 0, LOGN, MODE>(v, tid, tw, mod, true);
-        global_store<LOGN, LOGE, 0, LOGN>(v, tid, x);
+        const BufferResource x = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
+        global_load<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
+        inverse_pass<LOGN, LOGE, 0, LOGN, MODE, false, 1>(v, tid, tw, mod, true,
+                                                         inverse_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, false>(tw, tid));
+        global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
         if constexpr (TENSOR) {
@@ -244,8 +332,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
                 if (c != 1) {
                     const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
                     const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
-                    v[r] = barrett_mul(a.x, b.x, p, factor, shift);
-                    v[r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
+                    v[0][r] = barrett_mul(a.x, b.x, p, factor, shift);
+                    v[0][r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
                 } else {
                     const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
                     const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
@@ -255,8 +343,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
                     ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
                     product_sum_add(cross0, a1.x, b0.x);
                     product_sum_add(cross1, a1.y, b0.y);
-                    v[r] = reduce_product_sum(cross0, mod);
-                    v[r + 1] = reduce_product_sum(cross1, mod);
+                    v[0][r] = reduce_product_sum(cross0, mod);
+                    v[0][r + 1] = reduce_product_sum(cross1, mod);
                 }
             }
         } else if constexpr (SOURCE == kInverseFromKeyMac) {
@@ -281,40 +369,19 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
                     product_sum_add(acc0, xs.x, ks.x);
                     product_sum_add(acc1, xs.y, ks.y);
                 }
-                v[q] = reduce_product_sum(acc0, mod);
-                v[q + 1] = reduce_product_sum(acc1, mod);
+                v[0][q] = reduce_product_sum(acc0, mod);
+                v[0][q + 1] = reduce_product_sum(acc1, mod);
             }
         } else {
-            global_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                global_load<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         }
-        inverse_pass<LOGN, LOGE, 0, S::R, MODE>(v, tid, tw, mod, true);
-        lds_store<LOGN, LOGE, 0, S::R>(v, tid, lds);
-        if constexpr (S::P >= 3) {
-            lds_transpose_fence<LOGN, LOGE, 0, S::R>();
-            constexpr int LO1 = S::R;
-            lds_load<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO1, LOGE, MODE>(v, tid, tw, mod, false);
-            lds_store<LOGN, LOGE, LO1, LOGE>(v, tid, lds);
-        }
-        if constexpr (S::P >= 4) {
-            lds_transpose_fence<LOGN, LOGE, S::R, S::R + LOGE>();
-            constexpr int LO2 = S::R + LOGE;
-            lds_load<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO2, LOGE, MODE>(v, tid, tw, mod, false);
-            lds_store<LOGN, LOGE, LO2, LOGE>(v, tid, lds);
-        }
-        if constexpr (S::P >= 5) {
-            lds_transpose_fence<LOGN, LOGE, S::R + LOGE, S::R + 2 * LOGE>();
-            constexpr int LO3 = S::R + 2 * LOGE;
-            lds_load<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-            inverse_pass<LOGN, LOGE, LO3, LOGE, MODE>(v, tid, tw, mod, false);
-            lds_store<LOGN, LOGE, LO3, LOGE>(v, tid, lds);
-        }
-        __syncthreads();
+        inverse_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, mod, lds);
         constexpr int LOL = LOGN - LOGE;
-        lds_load<LOGN, LOGE, LOL, LOGE>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true>(v, tid, tw, mod, false);  // top bits: wave-uniform twiddles
-        global_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
     }
 }
 
@@ -407,18 +474,57 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
                                static_cast<int>(lds_bytes));
 }
 
+// Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
+// consecutive records -- one modulus, every twiddle fetched once for both.
+template <int LOGN, int LOGT>
+constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? 2 : 1;
+
+template <int LOGN, int LOGT, int SPREAD, int ROWS>
+hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
+                                 const SpreadSource& spread, hipStream_t stream) {
+    constexpr int LOGE = LOGN - LOGT;
+    constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
+    auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD, ROWS>
+                  : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD, ROWS>
+                                        : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD, ROWS>;
+    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
+                       spread);
+    return hipGetLastError();
+}
+
 template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                 uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream,
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
+    size_t paired_records = 0;
+    if constexpr (SPREAD == kSourceSlab && kRowsPerWorkgroup<LOGN, LOGT> == 2) {
+        paired_records = (rows / mod_period) & ~size_t(1);
+        if (paired_records != 0) {
+            hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, 2>(
+                mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset), paired_records / 2 * mod_period,
+                spread, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    const size_t rest = rows - paired_records * mod_period;
+    if (rest == 0) return hipSuccess;
+    return launch_forward_kernel<LOGN, LOGT, SPREAD, 1>(
+        mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(paired_records)),
+        rest, spread, stream);
+}
+
+template <int LOGN, int LOGT, int SOURCE, int ROWS>
+hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
+                                 const InverseSource& source_spec, hipStream_t stream) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD>
-                  : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD>
-                                        : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD>;
+    auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
+                  : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
+                                        : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       make_row_map(mod_base, mod_period, row_period, row_offset), spread);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
+                       source_spec);
     return hipGetLastError();
 }
 
@@ -433,27 +539,27 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
                                                              row_offset);
     }
     constexpr int LOGE = LOGN - LOGT;
-    constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    using Kernel = void (*)(uint64_t*, const DeviceContext, const RowMap, const InverseSource);
-    Kernel kernel;
     if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
-    if (source == kInverseFromTensor) {
-        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, kInverseFromTensor>
-                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromTensor>
-                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromTensor>;
-    } else if (source == kInverseFromKeyMac) {
-        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, kInverseFromKeyMac>
-                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, kInverseFromKeyMac>
-                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact, kInverseFromKeyMac>;
-    } else {
-        kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit>
-                 : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox>
-                                       : ntt_inverse_tiled<LOGN, LOGT, kModeExact>;
+    const RowMap map = make_row_map(mod_base, mod_period, row_period, row_offset);
+    if (source == kInverseFromTensor)
+        return launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map, rows, source_spec, stream);
+    if (source == kInverseFromKeyMac)
+        return launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map, rows, source_spec, stream);
+    size_t paired_records = 0;
+    if constexpr (kRowsPerWorkgroup<LOGN, LOGT> == 2) {
+        paired_records = (rows / mod_period) & ~size_t(1);
+        if (paired_records != 0) {
+            hipError_t e = launch_inverse_kernel<LOGN, LOGT, kInverseFromSlab, 2>(mode, slab, ctx, map,
+                                                                                 paired_records / 2 * mod_period, source_spec,
+                                                                                 stream);
+            if (e != hipSuccess) return e;
+        }
     }
-    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       make_row_map(mod_base, mod_period, row_period, row_offset), source_spec);
-    return hipGetLastError();
+    const size_t rest = rows - paired_records * mod_period;
+    if (rest == 0) return hipSuccess;
+    return launch_inverse_kernel<LOGN, LOGT, kInverseFromSlab, 1>(
+        mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(paired_records)), rest,
+        source_spec, stream);
 }
 
 // the production butterfly schedule for a context (what kNttVariantAuto picks)
