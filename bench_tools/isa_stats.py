@@ -25,7 +25,7 @@ SLOTS = {
 def assemble(source):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                    "-I" + CSRC, "-o", out, source], check=True, stderr=subprocess.DEVNULL)
+                    "-I" + CSRC, *os.environ.get("HEAMD_ISA_FLAGS", "").split(), "-o", out, source], check=True, stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)
     return text

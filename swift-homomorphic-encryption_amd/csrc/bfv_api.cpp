@@ -87,6 +87,7 @@ int resolve_workspace(void* workspace, size_t workspace_bytes, size_t needed, Sc
 int drop_extended_base(const RnsToolLevel& tool, uint64_t* eval_qbsk, uint64_t* out, size_t polys, hipStream_t stream) {
     DeviceContext scaled = tool.qbsk->device_context();
     scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
+    scaled.scaled_inverse_degree = 1;
     const uint32_t rows = tool.qbsk->moduli_count();
     HEAMD_HIP_TRY(heamd::launch_ntt_mixed(true, eval_qbsk, scaled, rows, polys, stream));
     HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(eval_qbsk, out, tool.device, polys, stream));
@@ -182,6 +183,7 @@ int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const ui
     // tiled transform (the products are formed as the inverse transform loads its row), two otherwise
     DeviceContext scaled = tool->qbsk->device_context();
     scaled.moduli = tool->qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
+    scaled.scaled_inverse_degree = 1;
     hipError_t fused = heamd::launch_ntt_tensor_inverse(lifted, tensor, scaled, static_cast<uint32_t>(rows), batch, stream);
     if (fused == hipErrorNotSupported) {
         (void)hipGetLastError();

@@ -262,6 +262,7 @@ int BfvContext::build_tool(uint32_t k) {
         DeviceModulus m = level.qbsk->host_constants()[r];
         const u64 p = m.p;
         set_inverse_degree_constants(m, mul_mod(m.inv_degree, t_ % p, p), mul_mod(m.inv_degree_root, t_ % p, p));
+        if (m.has_ntt) m.has_ntt = kNttScaledInverseDegree;  // the last inverse stage multiplies by t N^-1, not by N^-1
         arena.at<DeviceModulus>(o_scaled)[r] = m;
     }
 

@@ -9,6 +9,10 @@ namespace heamd {
 
 // Per-modulus constants (one per RNS row).  Loaded through the scalar cache: every lane of a workgroup reads the
 // same entry.  Sources: HomomorphicEncryption/Modulus.swift:24-45 (Barrett), PolyRq/PolyRq+Ntt.swift:159-168 (N^-1).
+// DeviceModulus::has_ntt: with kNttPlainInverseDegree inv_degree is N^-1 itself (the inverse transform divides by N
+// exactly, ntt_common.hpp divide_by_degree); with kNttScaledInverseDegree it carries another factor (t N^-1 in BEHZ's
+// dropExtendedBase) and the last stage takes the Shoup product.
+constexpr uint32_t kNttPlainInverseDegree = 1, kNttScaledInverseDegree = 2;
 struct DeviceModulus {
     uint64_t p;
     uint64_t barrett64;        // floor(2^64 / p)
@@ -16,7 +20,7 @@ struct DeviceModulus {
     uint64_t barrett128_hi;    //                   high word
     uint64_t product_factor;   // floor(2^(bits(p)+62) / p)
     uint32_t product_shift;    // bits(p) - 2
-    uint32_t has_ntt;          // 1 when p is an NTT modulus for this degree
+    uint32_t has_ntt;          // 0: not an NTT modulus for this degree; kNttPlainInverseDegree; kNttScaledInverseDegree
     uint64_t inv_degree;       // N^-1 mod p                  (+ Shoup factor)
     uint64_t inv_degree_shoup;
     uint64_t inv_degree_root;  // N^-1 * psi^(-N/2) mod p     (+ Shoup factor)
@@ -49,6 +53,8 @@ struct DeviceContext {
     uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
     uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): the NTT runs the fold-free split butterflies
     uint32_t headroom_prefix;      // how many leading moduli are in that range (the Q part of a [Q, Bsk] context)
+    uint32_t scaled_inverse_degree;  // 1 when `moduli` is a table whose N^-1 constants carry another factor
+                                     // (kNttScaledInverseDegree): the inverse transform must not divide by N exactly
 };
 
 // Image of a context whose moduli all fit UInt32 (<= 2^30 - 1), for slabs of 4-byte words: the same per-modulus

@@ -187,6 +187,28 @@ struct Lazy {
 // < 2^10 * 2^-18 and fp32 rounding (four roundings, each 2^-24 relative, all dominated by the bias) keeps
 // e <= x / p, so q = floor(e) is floor(x / p) or one less: x - q p lies in [0, 2p) and one conditional subtract
 // finishes.  x - q p is the low 64 bits of x + q (2^64 - p): one multiply-add on top of x, one low product.
+// x 2^-LOGN mod p without a Shoup product, for the N^-1 factor of the inverse transform's last stage: every NTT modulus
+// is 1 mod 2N, so p = P 2^LOGN + 1 and, with m = 2^LOGN - (x mod 2^LOGN) in [1, 2^LOGN], x + m p is a multiple of
+// 2^LOGN:  (x + m p) / 2^LOGN = floor(x / 2^LOGN) + 1 + m P  =  x 2^-LOGN (mod p),  below x / 2^LOGN + p + 1.
+// m = (~x & (2^LOGN - 1)) + 1, hence the value is floor(x / 2^LOGN) + (~x & mask) P + (P + 1): one 64-bit shift, one bit
+// operation, one multiply-add by the low word of P, one 24-bit multiply-add by its high word (P < 2^50, mask < 2^15) and
+// one add; x < 2^LOGN p makes the result < 2p and one conditional subtract canonical (8 + 5 issue slots against 28 for
+// the Shoup product and its float-estimated reduction).
+template <int LOGN>
+__device__ __forceinline__ uint64_t divide_by_degree(uint64_t x, uint64_t p) {
+    static_assert(LOGN >= 10 && LOGN <= 15, "x < 2^9 p must land below 2p; the mask must fit 24 bits");
+    const uint64_t P = (p - 1) >> LOGN;
+    const uint32_t low_bits = ~lo32(x) & ((1u << LOGN) - 1u);
+    const uint64_t shifted = x >> LOGN;
+    uint64_t acc, carry;
+    uint32_t high_word;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(acc), "=&s"(carry) : "v"(low_bits), "s"(lo32(P)), "v"(shifted));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(high_word) : "v"(low_bits), "s"(hi32(P)), "v"(hi32(acc)));
+    uint64_t lazy;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(lazy) : "v"(pack64(lo32(acc), high_word)), "s"(P + 1));
+    return csub63<true>(lazy, 0 - p);
+}
+
 struct LazyReducer {
     uint64_t neg_p;
     float scale;
@@ -197,13 +219,13 @@ struct LazyReducer {
         float high;  // asm: hipcc otherwise converts through its generic 64-bit path (7 instructions)
         asm("v_cvt_f32_u32 %0, %1" : "=v"(high) : "v"(hi32(x)));
         const uint32_t q = static_cast<uint32_t>(high * scale);
+        // high word: q * hi32(neg_p) taken as signed 24-bit factors (q < 2^10; hi32(2^64 - p) = -(hi32(p - 1) + 1) >= -2^23
+        // for p < 2^55) -- one full-rate multiply-add instead of a 32-bit multiply and an add
         uint64_t low, carry;
-        uint32_t cross;
-        asm("v_mad_u64_u32 %0, %2, %3, %4, %6\n\t"
-            "v_mul_lo_u32 %1, %3, %5"
-            : "=&v"(low), "=&v"(cross), "=&s"(carry)
-            : "v"(q), "s"(lo32(neg_p)), "s"(hi32(neg_p)), "v"(x));
-        return pack64(lo32(low), opaque32(hi32(low) + cross));
+        uint32_t high_word;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(low), "=&s"(carry) : "v"(q), "s"(lo32(neg_p)), "v"(x));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(high_word) : "v"(q), "s"(hi32(neg_p)), "v"(hi32(low)));
+        return pack64(lo32(low), high_word);
     }
     __device__ __forceinline__ uint64_t operator()(uint64_t x) const { return csub63<true>(lazy(x), neg_p); }
 };
@@ -367,7 +389,9 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
 
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS>
+// SCALED: mod.inv_degree carries a factor besides N^-1 (DeviceModulus::has_ntt == kNttScaledInverseDegree): the last
+// stage's sums take the Shoup product; otherwise they are divided by N exactly (divide_by_degree).
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, bool SCALED = false>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, bool first_stage_canonical, TwiddleWords first) {
     constexpr int COUNT = pass_twiddle_count<LOGE, W, true>();
@@ -377,6 +401,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // that sums double the bound and products are < p << K (K = Lazy::kProductLog); exact / approx: once the bound
     // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
     constexpr int H = Lazy<MODE>::kInverseCapLog;
+#ifdef HEAMD_X_LATE_TID
+    asm volatile("" : "+v"(tid));
+#endif
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
     TwiddleWords pending = first;
 #pragma unroll
@@ -391,11 +418,17 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
+#ifdef HEAMD_X_INVERSE_NO_AHEAD
+        if (k > 0) __builtin_amdgcn_sched_barrier(0);
+        const TwiddleWords w = k == 0 ? pending : inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k);
+        if (k > 0) __builtin_amdgcn_sched_barrier(0);
+#else
         const TwiddleWords w = pending;
         if (k + 1 < COUNT) {
             pending = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
@@ -407,12 +440,16 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
                 if (last_stage) {
                     if constexpr (MODE == kModeSplit) {
                         const LazyReducer reduce(p);
-                        v[row][base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
-                                                                             mod.inv_degree_factors, neg_p));
+                        if constexpr (SCALED)
+                            v[row][base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
+                                                                                 mod.inv_degree_factors, neg_p));
+                        else
+                            v[row][base + o] = divide_by_degree<LOGN>(sum, p);  // sum < 2^9 p (inverse_in_shift)
                         v[row][base + o + stride] = reduce(split_mul_add<true, false>(
                             0, diff, mod.inv_degree_root, mod.inv_degree_root_split, mod.inv_degree_root_factors, neg_p));
                     } else {
-                        v[row][base + o] = shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p);
+                        v[row][base + o] = SCALED ? shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p)
+                                                  : divide_by_degree<LOGN>(sum, p);  // sum < 8p
                         v[row][base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                     }
                 } else {
@@ -427,6 +464,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
                     v[row][base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
                                                         : Lazy<MODE>::template mul<false>(diff, w, neg_p);
                 }
+#ifdef HEAMD_X_BUTTERFLY_FENCE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
@@ -454,6 +494,16 @@ __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid,
 // Global <-> registers through the row's buffer descriptor: one 32-bit lane offset per pass, the register part is a
 // scalar offset.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at a time.
 // For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
+#ifdef HEAMD_X_NT_LOAD  // experiment: row data loaded non-temporally (keeps the vector L1 for the twiddle gathers)
+constexpr int kLoadPolicy = 2;
+#else
+constexpr int kLoadPolicy = 0;
+#endif
+#ifdef HEAMD_X_NT_STORE
+constexpr int kStorePolicy = 2;
+#else
+constexpr int kStorePolicy = 0;
+#endif
 template <int LOGN, int LOGE, int LO, int W>
 __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
     const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
@@ -461,7 +511,7 @@ __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t t
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
             const Dwordx4 pair =
-                __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+                __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kLoadPolicy);
             v[r] = pack64(pair.x, pair.y);
             v[r + 1] = pack64(pair.z, pair.w);
         }
@@ -469,7 +519,7 @@ __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t t
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) {
             const Dwordx2 word =
-                __builtin_amdgcn_raw_buffer_load_b64(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+                __builtin_amdgcn_raw_buffer_load_b64(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kLoadPolicy);
             v[r] = pack64(word.x, word.y);
         }
     }
@@ -481,13 +531,13 @@ __device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uin
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
             const Dwordx4 pair = {lo32(v[r]), hi32(v[r]), lo32(v[r + 1]), hi32(v[r + 1])};
-            __builtin_amdgcn_raw_buffer_store_b128(pair, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pair, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kStorePolicy);
         }
     } else {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) {
             const Dwordx2 word = {lo32(v[r]), hi32(v[r])};
-            __builtin_amdgcn_raw_buffer_store_b64(word, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(word, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kStorePolicy);
         }
     }
 }

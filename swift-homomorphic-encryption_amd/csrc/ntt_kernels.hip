@@ -108,6 +108,31 @@ __device__ __forceinline__ void locate_rows(const RowMap& map, uint32_t block, s
     for (int k = 0; k < ROWS; ++k) rows[k] = first + k * stride;
 }
 
+// Kernels whose workgroups come in sets of `replicas` that read the SAME source rows (the L + 1 key-switching rows spread
+// from one ciphertext row, the three tensor-product polynomials of one [Q, Bsk] row, the two key polynomials of one
+// spread row): workgroup b is dispatched to XCD b % 8, so the members of a set take dispatch slots s, s + 1, ... of ONE
+// XCD -- the first one's read fills that XCD's L2 and the others hit there instead of going back to HBM.  Sets beyond
+// the last multiple of 8 keep the plain order.  Performance only: any placement computes the same thing.
+__device__ __forceinline__ void locate_replica(uint32_t block, uint32_t sets, uint32_t replicas, uint32_t& set,
+                                               uint32_t& replica) {
+#ifdef HEAMD_X_NO_XCD_SETS
+    set = block / replicas;
+    replica = block - set * replicas;
+#else
+    constexpr uint32_t kXcds = 8;
+    const uint32_t full = sets & ~(kXcds - 1);
+    if (block < full * replicas) {
+        const uint32_t slot = block / kXcds, xcd = block % kXcds, round = slot / replicas;
+        replica = slot - round * replicas;
+        set = round * kXcds + xcd;
+    } else {
+        const uint32_t rest = block - full * replicas, q = rest / replicas;
+        set = full + q;
+        replica = rest - q * replicas;
+    }
+#endif
+}
+
 // Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
 // this kernel read it back) is applied to the words as they are loaded.
 //   kSourceSpread  the key-switching decomposition (Bfv+Keys.swift:165-179): output row (poly, j, r) of a
@@ -124,8 +149,9 @@ struct SpreadSource {
     uint64_t plaintext_modulus;
 };
 
-constexpr int min_waves_per_simd(int log_words_per_lane) {
-    return log_words_per_lane <= 3 ? 8 : log_words_per_lane <= 4 ? 4 : 2;
+constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
+    const int words = rows << log_words_per_lane;  // 64-bit words of row data a lane holds
+    return words <= 16 ? 8 : words <= 32 ? 4 : 2;
 }
 
 // ROWS rows of one modulus through ONE LDS tile, one after the other: a row's words leave in the layout of pass FROM
@@ -184,43 +210,45 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
     HEAMD_X_PASS((canonicalize_all<MODE>(v, p)));
 }
 
+// One inverse pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout of pass
+// (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
+// transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
+// doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab.txt).
+#ifdef HEAMD_X_INVERSE_EARLY_FIRST
+constexpr bool kInverseFirstTwiddleEarly = true;
+#else
+constexpr bool kInverseFirstTwiddleEarly = false;
+#endif
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED>
+__device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                             const DeviceModulus& mod, uint64_t* lds) {
+    TwiddleWords first{0, 0, 0};
+    if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
+    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS>(v, tid, lds);
+    if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
+    HEAMD_X_PASS((inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first)));
+}
+
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
-template <int LOGN, int LOGE, int MODE, int ROWS>
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             const DeviceModulus& mod, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
-    inverse_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(
-        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, tid));
-    if constexpr (S::P >= 3) {
-        constexpr int LO1 = S::R;
-        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, 0, S::R, LO1, LOGE, ROWS>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
-    }
-    if constexpr (S::P >= 4) {
-        constexpr int LO1 = S::R, LO2 = S::R + LOGE;
-        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
-    }
-    if constexpr (S::P >= 5) {
-        constexpr int LO2 = S::R + LOGE, LO3 = S::R + 2 * LOGE;
-        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, mod, false, first);
-    }
-    {
-        constexpr int LOL = LOGN - LOGE, LO_PREVIOUS = S::P == 2 ? 0 : LOL - LOGE;
-        constexpr int W_PREVIOUS = S::P == 2 ? S::R : LOGE;
-        const TwiddleWords first = inverse_first_twiddle<LOGN, LOGE, LOL, LOGE, MODE, true>(tw, tid);
-        exchange<LOGN, LOGE, LO_PREVIOUS, W_PREVIOUS, LOL, LOGE, ROWS>(v, tid, lds);
-        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true, ROWS>(v, tid, tw, mod, false, first);  // top bits: uniform twiddles
-    }
+    constexpr int R = S::R, LOL = LOGN - LOGE;
+    HEAMD_X_PASS((inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS>(
+        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid))));
+    if constexpr (S::P >= 3) inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
+    if constexpr (S::P >= 4) inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
+    if constexpr (S::P >= 5)
+        inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
+    // into the top pass (uniform twiddles; its last stage folds in N^-1)
+    if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
+    else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
 }
 
 template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab, int ROWS = 1>
-__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
+__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROWS))
     ntt_forward_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const SpreadSource spread) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
@@ -231,7 +259,13 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
-    locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
+    if constexpr (SPREAD != kSourceSlab) {
+        // the band_rows output rows of a record are transforms of one source row: one replica set per record
+        locate_replica(blockIdx.x, gridDim.x / map.band_rows, map.band_rows, record, within);
+        rows[0] = size_t(record) * map.band_rows + within;
+    } else {
+        locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
+    }
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> tw(ctx, false, mi, LOGN);
@@ -281,7 +315,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
 // KEYMAC: the lazy inner product with the key-switching key (Bfv+Keys.swift:180-202) fused into the load.  Records
 // are (polynomial, c), c in {0, 1}, of record_rows = L + 1 rows; word k of row r is
 // sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] mod ks_modulus[r], accumulated in the carry-counting form.
-constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2;
+// kInverseFromSlabScaled: a plain slab whose context carries t N^-1 (dropExtendedBase without the fused tensor load)
+constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2, kInverseFromSlabScaled = 3;
 struct InverseSource {
     const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
     const uint64_t* second;  // key MAC: the key
@@ -289,10 +324,12 @@ struct InverseSource {
 };
 
 template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab, int ROWS = 1>
-__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
+__global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROWS))
     ntt_inverse_tiled(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map,
                       const InverseSource source_spec) {
     constexpr bool TENSOR = SOURCE == kInverseFromTensor;
+    constexpr bool SCALED = SOURCE == kInverseFromTensor || SOURCE == kInverseFromSlabScaled;
+    constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
     static_assert(ROWS == 1 || SOURCE == kInverseFromSlab, "row pairs: plain slabs");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -303,7 +340,17 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
-    locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
+    if constexpr (!FROM_SLAB) {
+        // records (item, c) of one item read the same source rows: one replica set per (item, band row)
+        constexpr uint32_t REPLICAS = TENSOR ? 3 : 2;
+        uint32_t set, c, item;
+        locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, c);
+        locate(map, set, item, within);
+        record = item * REPLICAS + c;
+        rows[0] = size_t(record) * map.record_rows + map.band_offset + within;
+    } else {
+        locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
+    }
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> tw(ctx, true, mi, LOGN);
@@ -312,8 +359,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
     if constexpr (S::P == 1) {
         const BufferResource x = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
         global_load<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
-        inverse_pass<LOGN, LOGE, 0, LOGN, MODE, false, 1>(v, tid, tw, mod, true,
-                                                         inverse_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, false>(tw, tid));
+        inverse_pass<LOGN, LOGE, 0, LOGN, MODE, false, 1, SCALED>(
+            v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, false>(tw, tid));
         global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
@@ -373,15 +420,16 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT))
                 v[0][q + 1] = reduce_product_sum(acc1, mod);
             }
         } else {
+            [[maybe_unused]] const uint64_t p = mod.p;
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
-                global_load<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+                HEAMD_X_LOAD((global_load<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
         }
-        inverse_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, mod, lds);
+        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED>(v, tid, tw, mod, lds);
         constexpr int LOL = LOGN - LOGE;
 #pragma unroll
         for (int k = 0; k < ROWS; ++k)
-            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+            HEAMD_X_STORE((global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
     }
 }
 
@@ -476,8 +524,11 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
+#ifndef HEAMD_X_ROWS
+#define HEAMD_X_ROWS 2
+#endif
 template <int LOGN, int LOGT>
-constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? 2 : 1;
+constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? HEAMD_X_ROWS : 1;
 
 template <int LOGN, int LOGT, int SPREAD, int ROWS>
 hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
@@ -497,13 +548,14 @@ template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                 uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream,
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
-    size_t paired_records = 0;
-    if constexpr (SPREAD == kSourceSlab && kRowsPerWorkgroup<LOGN, LOGT> == 2) {
-        paired_records = (rows / mod_period) & ~size_t(1);
+    size_t paired_records = 0;  // records covered by the launch of row groups
+    constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+    if constexpr (SPREAD == kSourceSlab && GROUP > 1) {
+        paired_records = (rows / mod_period) / GROUP * GROUP;
         if (paired_records != 0) {
-            hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, 2>(
-                mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset), paired_records / 2 * mod_period,
-                spread, stream);
+            hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, GROUP>(
+                mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                paired_records / GROUP * mod_period, spread, stream);
             if (e != hipSuccess) return e;
         }
     }
@@ -541,17 +593,24 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     constexpr int LOGE = LOGN - LOGT;
     if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
     const RowMap map = make_row_map(mod_base, mod_period, row_period, row_offset);
+    if (ctx.scaled_inverse_degree != 0) {
+        if (source == kInverseFromKeyMac) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
+        if (source == kInverseFromSlab)
+            return launch_inverse_kernel<LOGN, LOGT, kInverseFromSlabScaled, 1>(mode, slab, ctx, map, rows, source_spec, stream);
+    } else if (source == kInverseFromTensor) {
+        return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
+    }
     if (source == kInverseFromTensor)
         return launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map, rows, source_spec, stream);
     if (source == kInverseFromKeyMac)
         return launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map, rows, source_spec, stream);
     size_t paired_records = 0;
-    if constexpr (kRowsPerWorkgroup<LOGN, LOGT> == 2) {
-        paired_records = (rows / mod_period) & ~size_t(1);
+    constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+    if constexpr (GROUP > 1) {
+        paired_records = (rows / mod_period) / GROUP * GROUP;
         if (paired_records != 0) {
-            hipError_t e = launch_inverse_kernel<LOGN, LOGT, kInverseFromSlab, 2>(mode, slab, ctx, map,
-                                                                                 paired_records / 2 * mod_period, source_spec,
-                                                                                 stream);
+            hipError_t e = launch_inverse_kernel<LOGN, LOGT, kInverseFromSlab, GROUP>(
+                mode, slab, ctx, map, paired_records / GROUP * mod_period, source_spec, stream);
             if (e != hipSuccess) return e;
         }
     }

@@ -141,7 +141,7 @@ int PolyContext::create(uint32_t degree, const uint64_t* moduli, uint32_t count,
             u64 inverse_degree = 0;
             if (!inverse_mod(degree % p, p, inverse_degree)) return HE_ERR_NOT_INVERTIBLE;
             const u64 inverse_degree_root = mul_mod(inverse_degree, inverse[n - 1].x, p);  // PolyRq+Ntt.swift:162-168
-            m.has_ntt = 1;
+            m.has_ntt = kNttPlainInverseDegree;
             set_inverse_degree_constants(m, inverse_degree, inverse_degree_root);
         }
         ctx->host_moduli_[i] = m;
