@@ -1102,8 +1102,14 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
         free(qbsk_moduli);
         if (status) TOOL_FAIL(status);
     }
+    /* RnsTool.swift:240-250 with the shared RnsToolContext (:44-62): mSkContext holds the TOP level's m_sk for every
+     * level, so rnsConvertBtoMSk converts B to the top m_sk and bModMSk is B mod the top m_sk, while the multiplicand's
+     * inverse and the MultiplyConstantModulus are taken mod this level's m_sk (the same prime only at the top level).
+     * inverseMod (HE/Scalar.swift:76-96) is given a value that may exceed its modulus; orc_inverse_mod restates its
+     * loop statement by statement, so it returns what the reference computes. */
+    const uint64_t top_m_sk = bsk_mtilde[bsk_mtilde_count - 2];
     {
-        orc_modulus m = modulus_init(m_sk);
+        orc_modulus m = modulus_init(top_m_sk);
         uint64_t b_mod_msk = q_remainder_n(bsk, L, &m);
         uint64_t inverse;
         status = orc_inverse_mod(b_mod_msk, m_sk, &inverse);
@@ -1114,7 +1120,7 @@ static int rns_tool_create_shared(const orc_poly_context* input, uint64_t t, con
     if (status) TOOL_FAIL(status);
     status = base_converter_init(&tool->q_to_bsk_mtilde, input->moduli, L, tool->ext_moduli, L + 2);
     if (status) TOOL_FAIL(status);
-    status = base_converter_init(&tool->b_to_msk, bsk, L, &m_sk, 1);
+    status = base_converter_init(&tool->b_to_msk, bsk, L, &top_m_sk, 1);
     if (status) TOOL_FAIL(status);
     status = base_converter_init(&tool->b_to_q, bsk, L, input->moduli, L);
     if (status) TOOL_FAIL(status);

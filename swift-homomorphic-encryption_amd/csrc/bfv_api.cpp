@@ -429,7 +429,9 @@ int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli
     for (uint32_t i = 0; i < moduli_count; ++i) {
         const unsigned __int128 below = pc->moduli()[i] - 1;
         if (below == 0) continue;
-        const unsigned __int128 limit = (static_cast<unsigned __int128>(1) << 127) / (below * below);
+        // a window starts from the previous window's folded residue (< p), so cadence (p - 1)^2 + p - 1 must stay
+        // below 2^127
+        const unsigned __int128 limit = ((static_cast<unsigned __int128>(1) << 127) - pc->moduli()[i]) / (below * below);
         if (limit < cadence) cadence = static_cast<uint64_t>(limit);
     }
     HEAMD_HIP_TRY(heamd::launch_inner_product_plain(cts, pts, present_device, out, pc->device_context(), poly_count,

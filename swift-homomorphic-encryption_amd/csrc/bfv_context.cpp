@@ -166,6 +166,11 @@ int BfvContext::build_tool(uint32_t k) {
     const u64* ext = level.ext_moduli.data();
     const u64* bsk = ext;  // L+1 entries; B = bsk[0..L), m_sk = bsk[L]
     const u64 m_sk = bsk[L];
+    // The shared RnsToolContext holds ONE mSkContext, built from the top level's m_sk (RnsTool.swift:44-62): at every
+    // level rnsConvertBtoMSk converts B to that prime and inverseBModMSk is (B mod top m_sk)^-1 taken mod this level's
+    // m_sk (RnsTool.swift:240-250).  The two primes coincide only at the top level; below it this restates what the
+    // reference computes word for word (as the oracle does), not the textbook conversion.
+    const u64 top_m_sk = bsk_mtilde_[bsk_mtilde_.size() - 2];
 
     // qBskContext (RnsTool.swift:234-239): validates the appended moduli and uniqueness
     std::vector<u64> qbsk(q, q + L);
@@ -202,9 +207,11 @@ int BfvContext::build_tool(uint32_t k) {
     const size_t o_q_to_tg = arena.reserve<u64>(2 * L);
     const size_t o_tg_moduli = arena.reserve<DeviceModulus>(2);
     const size_t o_neg_inv_q_tg = arena.reserve<U64x2>(2);
+    const size_t o_alpha_modulus = arena.reserve<DeviceModulus>(1);
 
     for (size_t i = 0; i < L; ++i) arena.at<DeviceModulus>(o_q_moduli)[i] = barrett_constants(q[i]);
     for (size_t j = 0; j < L + 2; ++j) arena.at<DeviceModulus>(o_ext_moduli)[j] = barrett_constants(ext[j]);
+    arena.at<DeviceModulus>(o_alpha_modulus)[0] = barrett_constants(top_m_sk);
     // the lift / floor kernels keep sums of unfolded residues mod a Bsk prime: 6 Bsk_j must stay below 2^63.  The
     // reference's Bsk primes sit just above 2^60 (2^28 for UInt32 contexts), RnsTool.swift:28-66, so this always holds.
     for (size_t j = 0; j <= L; ++j) {
@@ -241,7 +248,7 @@ int BfvContext::build_tool(uint32_t k) {
         arena.at<U64x2>(o_inv_punct_b)[i] = shoup_pair(inverse, bsk[i]);
         arena.at<U64x2>(o_floor_scale_b)[i] =
             shoup_pair(mul_mod(arena.at<U64x2>(o_inv_q_bsk)[i].x, inverse, bsk[i]), bsk[i]);
-        arena.at<u64>(o_b_to_msk)[i] = punctured_product(bsk, L, i, m_sk);
+        arena.at<u64>(o_b_to_msk)[i] = punctured_product(bsk, L, i, top_m_sk);
         for (size_t row = 0; row < L; ++row)
             arena.at<u64>(o_b_to_q)[row * L + i] = punctured_product(bsk, L, i, q[row]);
         const u64 b_mod_qi = product_mod(bsk, L, q[i]);
@@ -253,7 +260,7 @@ int BfvContext::build_tool(uint32_t k) {
         u64 inverse = 0;
         if (!inverse_mod(product_mod(q, L, mtilde_), mtilde_, inverse)) return HE_ERR_NOT_INVERTIBLE;
         neg_inv_q_mod_mtilde = shoup_pair(neg_mod(inverse, mtilde_), mtilde_);
-        if (!inverse_mod(product_mod(bsk, L, m_sk), m_sk, inverse)) return HE_ERR_NOT_INVERTIBLE;
+        if (!inverse_mod(product_mod(bsk, L, top_m_sk), m_sk, inverse)) return HE_ERR_NOT_INVERTIBLE;
         inv_b_mod_msk = shoup_pair(inverse, m_sk);
     }
     // dropExtendedBase multiplies by t before the inverse NTT (Bfv+Multiply.swift:41-44); both are exact maps mod
@@ -288,16 +295,18 @@ int BfvContext::build_tool(uint32_t k) {
     d.inv_gamma_mod_t = inv_gamma_mod_t;
     d.mtilde = mtilde_;
     {
-        unsigned __int128 worst = 0;
-        for (size_t i = 0; i < L; ++i) {
-            const unsigned __int128 below = q[i] - 1;
-            if (below * below > worst) worst = below * below;
-        }
+        // the merged sum of a Q row is sum_i z_i (B/Bsk_i mod q) + alpha' (+-B mod q) with z_i < Bsk_i and
+        // alpha' < m_sk: at most (L + 1) products of a Bsk prime by a residue mod q
+        u64 bsk_max = 0, q_max = 0;
+        for (size_t j = 0; j <= L; ++j) bsk_max = bsk[j] > bsk_max ? bsk[j] : bsk_max;
+        for (size_t i = 0; i < L; ++i) q_max = q[i] > q_max ? q[i] : q_max;
+        const unsigned __int128 worst = static_cast<unsigned __int128>(bsk_max - 1) * (q_max - 1);
         d.floor_merge_ok = (worst == 0 || (static_cast<unsigned __int128>(1) << 127) / worst > L + 1) ? 1u : 0u;
     }
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
     d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;
     d.inv_b_mod_msk = inv_b_mod_msk;
+    d.alpha_modulus_is_msk = top_m_sk == m_sk ? 1u : 0u;
     if (host_only_) return HE_OK;
 
     HEAMD_HIP_TRY(hipMalloc(&level.device_block, arena.size()));
@@ -324,6 +333,7 @@ int BfvContext::build_tool(uint32_t k) {
     d.q_to_t_gamma = reinterpret_cast<const uint64_t*>(base + o_q_to_tg);
     d.t_gamma = reinterpret_cast<const DeviceModulus*>(base + o_tg_moduli);
     d.neg_inv_q_mod_t_gamma = reinterpret_cast<const U64x2*>(base + o_neg_inv_q_tg);
+    d.alpha_modulus = reinterpret_cast<const DeviceModulus*>(base + o_alpha_modulus);
     return HE_OK;
 }
 

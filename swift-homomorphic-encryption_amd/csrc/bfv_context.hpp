@@ -31,7 +31,9 @@ struct RnsToolDevice {
     const U64x2* inv_punctured_b;      // [L]     (B/Bsk_i)^-1 mod Bsk_i
     const U64x2* floor_scale_b;        // [L]     Q^-1 (B/Bsk_i)^-1 mod Bsk_i: approximateFloor's Q^-1 and the Bsk -> Q
                                        //         converter's first product are consecutive exact products mod Bsk_i
-    const uint64_t* b_to_msk;          // [L]     (B/Bsk_i) mod m_sk
+    const uint64_t* b_to_msk;          // [L]     (B/Bsk_i) mod the TOP level's m_sk (the shared mSkContext, RnsTool.swift:44-62)
+    const DeviceModulus* alpha_modulus;//         Barrett constants of that prime
+    uint32_t alpha_modulus_is_msk;     //         1 at the top level, where it is this level's m_sk = ext_moduli[L]
     const uint64_t* b_to_q;            // [L][L]  (B/Bsk_k) mod q_i  (row i, column k)
     const U64x2* b_mod_q;              // [L]     B mod q_i                               RnsTool.swift:211-216
     const U64x2* neg_b_mod_q;          // [L]     -B mod q_i                              RnsTool.swift:217-223
@@ -42,10 +44,10 @@ struct RnsToolDevice {
     const U64x2* neg_inv_q_mod_t_gamma;// [2]     -(Q^-1) mod t, mod gamma                          RnsTool.swift:157-160
     uint64_t inv_gamma_mod_t;          //         gamma^-1 mod t                                    RnsTool.swift:150-153
     uint64_t mtilde;                   //         T.mTilde: 2^32 (UInt64) or 2^16 (UInt32)          MA/Scalar.swift:508-525
-    uint32_t floor_merge_ok;           //         (L + 1) (q_max - 1)^2 < 2^127: the alpha correction of the Bsk -> Q
+    uint32_t floor_merge_ok;           //         (L + 1) (Bsk_max - 1) (q_max - 1) < 2^127: the alpha correction of the Bsk -> Q
                                        //         conversion may join that row's product sum (one reduction for both)
     U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169
-    U64x2 inv_b_mod_msk;               //         B^-1 mod m_sk                           RnsTool.swift:246-250
+    U64x2 inv_b_mod_msk;               //         (B mod top m_sk)^-1 mod this level's m_sk  RnsTool.swift:246-250
 };
 
 struct RnsToolLevel {

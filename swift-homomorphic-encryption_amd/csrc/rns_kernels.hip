@@ -138,7 +138,10 @@ __global__ void __launch_bounds__(kThreads)
         ProductSum alpha_sum = product_sum_first_uniform(z[0], tool.b_to_msk[0]);
 #pragma unroll
         for (int i = 1; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
-        uint64_t alpha = reduce_product_sum_lazy(alpha_sum, msk);  // < 5 m_sk
+        // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
+        // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
+        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? reduce_product_sum_lazy(alpha_sum, msk)  // < 5 m_sk
+                                                        : reduce_product_sum(alpha_sum, tool.alpha_modulus[0]);
         alpha = shoup_mul_pair(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll

@@ -13,7 +13,6 @@
 // AES (FIPS-197) uses one 1 KiB T-table in LDS (the other three are byte rotations of it).
 #include <hip/hip_runtime.h>
 
-#include <mutex>
 
 #include "device_context.hpp"
 #include "device_math.hpp"
@@ -23,7 +22,38 @@ namespace heamd {
 
 namespace {
 
-__device__ uint32_t g_aes_te0[256];  // Te0[x] = (2 S[x], S[x], S[x], 3 S[x]) as a big-endian word
+// Te0[x] = (2 S[x], S[x], S[x], 3 S[x]) as a big-endian word, FIPS-197 5.1.1 / 5.1.3: built at compile time, so the
+// library has no table upload (nothing to synchronise inside a stream capture) and no mutable device state.
+struct AesTable {
+    uint32_t te0[256];
+};
+constexpr uint32_t gf256_mul(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+    while (b) {
+        if (b & 1) r ^= a;
+        a = ((a << 1) ^ ((a & 0x80) ? 0x1b : 0)) & 0xff;
+        b >>= 1;
+    }
+    return r;
+}
+constexpr AesTable make_aes_table() {
+    AesTable t{};
+    for (uint32_t x = 0; x < 256; ++x) {
+        // the inverse in GF(2^8) is x^254 (0 -> 0)
+        uint32_t inverse = 1, power = x;
+        for (int bit = 1; bit < 8; ++bit) {
+            power = gf256_mul(power, power);  // x^(2^bit)
+            inverse = gf256_mul(inverse, power);
+        }
+        uint32_t s = inverse;
+        for (int k = 1; k <= 4; ++k) s ^= ((inverse << k) | (inverse >> (8 - k))) & 0xff;
+        s ^= 0x63;
+        t.te0[x] = (gf256_mul(s, 2) << 24) | (s << 16) | (s << 8) | gf256_mul(s, 3);
+    }
+    return t;
+}
+__device__ constexpr AesTable g_aes_table = make_aes_table();
+static_assert(g_aes_table.te0[0] == 0xc66363a5u && g_aes_table.te0[1] == 0xf87c7c84u, "FIPS-197 S-box: S[0] = 0x63, S[1] = 0x7c");
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int k) { return (x >> k) | (x << (32 - k)); }
 __device__ __forceinline__ uint32_t sbox(const uint32_t* te0, uint32_t x) { return (te0[x] >> 8) & 0xffu; }
@@ -101,7 +131,7 @@ __global__ void __launch_bounds__(64 * kSeedsPerBlock)
     seeded_uniform_kernel(const uint8_t* __restrict__ seeds, uint64_t* __restrict__ out, const DeviceContext ctx,
                           size_t batch) {
     __shared__ uint32_t te0[256];
-    te0[threadIdx.x] = g_aes_te0[threadIdx.x];
+    te0[threadIdx.x] = g_aes_table.te0[threadIdx.x];
     __syncthreads();
     const size_t seed_index = static_cast<size_t>(blockIdx.x) * kSeedsPerBlock + (threadIdx.x >> 6);
     if (seed_index >= batch) return;
@@ -155,53 +185,11 @@ __global__ void __launch_bounds__(64 * kSeedsPerBlock)
     }
 }
 
-// Te0 from the S-box (FIPS-197 5.1.1: inverse in GF(2^8), then the affine map)
-void build_te0(uint32_t (&te0)[256]) {
-    auto mul = [](uint32_t a, uint32_t b) {
-        uint32_t r = 0;
-        while (b) {
-            if (b & 1) r ^= a;
-            a = ((a << 1) ^ ((a & 0x80) ? 0x1b : 0)) & 0xff;
-            b >>= 1;
-        }
-        return r;
-    };
-    for (uint32_t x = 0; x < 256; ++x) {
-        uint32_t inverse = 0;
-        if (x != 0)
-            for (uint32_t y = 1; y < 256; ++y)
-                if (mul(x, y) == 1) {
-                    inverse = y;
-                    break;
-                }
-        uint32_t s = inverse;
-        for (int k = 1; k <= 4; ++k) s ^= ((inverse << k) | (inverse >> (8 - k))) & 0xff;
-        s ^= 0x63;
-        te0[x] = (mul(s, 2) << 24) | (s << 16) | (s << 8) | mul(s, 3);
-    }
-}
-
 }  // namespace
 
 hipError_t launch_seeded_uniform(const uint8_t* seeds, uint64_t* out, const DeviceContext& ctx, size_t batch,
                                  hipStream_t stream) {
     if (batch == 0) return hipSuccess;
-    // one table upload per device per process
-    static std::mutex lock;
-    static bool uploaded[64] = {false};
-    int device = 0;
-    hipError_t e = hipGetDevice(&device);
-    if (e != hipSuccess) return e;
-    {
-        std::lock_guard<std::mutex> guard(lock);
-        if (device < 64 && !uploaded[device]) {
-            uint32_t te0[256];
-            build_te0(te0);
-            e = hipMemcpyToSymbol(HIP_SYMBOL(g_aes_te0), te0, sizeof(te0));
-            if (e != hipSuccess) return e;
-            uploaded[device] = true;
-        }
-    }
     const size_t blocks = (batch + kSeedsPerBlock - 1) / kSeedsPerBlock;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(seeded_uniform_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64 * kSeedsPerBlock), 0, stream,

@@ -119,6 +119,36 @@ def test_convert_approximate_bsk_to_q_is_exact(oracle, degree, bits):
         assert _column(out, k) == crt_decompose(expected, moduli)
 
 
+def test_convert_approximate_bsk_to_q_below_the_top_level_uses_the_shared_msk_context(oracle):
+    """RnsTool.swift:44-62, 240-250: one mSkContext (the TOP level's m_sk) serves every level's tool, so below the top
+    level rnsConvertBtoMSk converts B to the top m_sk and inverseBModMSk is (B mod top m_sk)^-1 mod the level's m_sk.
+    Restated here with Python integers, statement by statement of :402-450, and compared with the oracle's words."""
+    degree = 16
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([40, 40, 40, 41], False, degree)
+    ctx = oracle.BfvContext(degree, t, q)
+    top_msk = ctx.rns_tool(ctx.L).bsk[-1]
+    for level in (ctx.L, ctx.L - 1, 1):
+        tool = ctx.rns_tool(level)
+        moduli = ctx.ciphertext_context(level).moduli
+        bsk = tool.bsk
+        b_moduli, m_sk = bsk[:-1], bsk[-1]
+        assert (m_sk == top_msk) == (level == ctx.L)
+        b = _prod(b_moduli)
+        inverse_b = pow(b % top_msk, -1, m_sk)
+        rng = random.Random(70 + level)
+        rows = [[rng.randrange(m) for _ in range(degree)] for m in bsk]
+        out = tool.convert_approximate_bsk_to_q(np.array(rows, dtype=np.uint64))
+        for k in range(degree):
+            products = [rows[i][k] * pow(b // b_moduli[i], -1, b_moduli[i]) % b_moduli[i] for i in range(level)]
+            alpha = sum(products[i] * ((b // b_moduli[i]) % top_msk) for i in range(level)) % top_msk
+            alpha = (alpha + m_sk - rows[level][k]) * inverse_b % m_sk
+            for row, qi in enumerate(moduli):
+                converted = sum(products[i] * ((b // b_moduli[i]) % qi) for i in range(level)) % qi
+                adjust = (b % qi) * (m_sk - alpha) % qi if alpha > m_sk >> 1 else (qi - b % qi) % qi * alpha % qi
+                assert int(out[row][k]) == (converted + adjust) % qi
+
+
 def test_convert_approximate_set_valued(oracle):
     # RnsBaseConverterTests.swift:20-65
     degree = 8
