@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X-native BFV PolyRq/NTT engine.
+"""bench.py -- benchmark of the MI355X-native BFV PolyRq/NTT engine.
 
-Workload at N GPUs (BASELINE.json configs[1], weak scaling: the same batch on every GPU):
-    batched forward + inverse negacyclic NTT, N = 8192, L = 4 RNS moduli (55-bit), 4096 polynomials per GPU
-    (1 GiB device-resident slab per GPU), synthetic uniform residues.
-One "step" = one forward NTT of the whole batch followed by one inverse NTT of the whole batch, i.e.
+Default workload (`--workload c2`, BASELINE.json configs[1], the headline): batched forward + inverse negacyclic NTT,
+N = 8192, L = 4 RNS moduli (55-bit), 4096 polynomials per GPU (1 GiB device-resident slab per GPU), synthetic uniform
+residues.  One "step" = one forward NTT of the whole batch followed by one inverse NTT of the whole batch, i.e.
 2 x 4096 polynomial transforms per GPU.  `value` = polynomial transforms per second over all GPUs, inputs resident in
 HBM when the timed region starts.
 
-The same JSON line carries
-  * roofline     -- achieved algorithmic HBM bytes/s of the dominant kernel (forward NTT), timed live with HIP events
-                    on the launch stream, against the 8 TB/s HBM3E peak;
-  * cpu_baseline -- the CPU oracle (a C port of the reference's Harvey NTT, oracle/he_oracle.c) timed on this box's
-                    host cores on a bounded sample of the same workload;
-  * extras       -- forward / inverse / ct x ct rates measured separately (not part of `value`).
+The other BASELINE.json configs run the same contract (weak scaling: the same per-GPU work on every rank, units sharded
+by rank with heamd.sharding, no data-path collective; the RCCL all-gather of the result shards is timed separately):
+    --workload c3   Bfv ct x ct + relinearize, N=8192, 4 moduli, 1024 ciphertext pairs per GPU     (configs[2])
+    --workload c4   divideAndRoundQLast, N=16384, 6 -> 5 moduli, 8192 polynomials per GPU           (configs[3])
+    --workload c5   PIR dim-0: 1024 query ciphertexts x 128 database columns per GPU (2^17 ct x pt products, 34 GB of
+                    plaintexts per GPU); 8 GPUs = the 2^20 products of configs[4], the database sharded by column as
+                    PirUtil.computeResponseForOneChunk groups columns (IndexPir/PirUtil.swift:427-445)
+
+The JSON line carries
+  * roofline     -- achieved algorithmic HBM bytes/s of the workload's dominant kernel, timed live with HIP events on
+                    the launch stream, against the 8 TB/s HBM3E peak; `traffic` = the HBM bytes rocprofv3's counters
+                    saw for the same launch (committed under profiles/), at this run's launch time;
+  * cpu_baseline -- (c2, one GPU) the CPU oracle (a C port of the reference's Harvey NTT, oracle/he_oracle.c) timed
+                    on this box's host cores on a bounded sample of the same workload, plus BASELINE configs[0]
+                    (forwardNtt N=4096, 2 moduli, one thread);
+  * extras       -- separately measured rates (not part of `value`).
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
@@ -32,6 +41,7 @@ DEGREE = 8192
 MODULI_BITS = [55, 55, 55, 55]
 BATCH = 4096
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse_args():
@@ -39,7 +49,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="polynomials per GPU")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="units per GPU (c2: polynomials, c3: ciphertext pairs, c4: polynomials, c5: database columns); "
+                         "0 = the BASELINE.json size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="polynomials in the CPU sample (0 = auto)")
     ap.add_argument("--skip-gather", action="store_true")
@@ -47,27 +60,23 @@ def parse_args():
     return ap.parse_args()
 
 
-def synthetic_slab(torch, moduli, batch, degree, seed):
-    """Uniform residues in [0, q_i): counter-based generator on the device."""
+def synthetic_slab(torch, moduli, prefix, degree, seed):
+    """Uniform residues in [0, q_i), shape prefix + [L][N]: counter-based generator on the device."""
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
-    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
-    x = torch.randint(0, 1 << 62, (batch, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(*([1] * len(prefix)), len(moduli), 1)
+    x = torch.randint(0, 1 << 62, tuple(prefix) + (len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen)
     return x % bound
 
 
-def pmc_traffic_gbps(batch, forward_seconds):
-    """HBM traffic of one forward launch as counted by the PMC passes committed under profiles/ (bench.py cannot
-    run rocprofv3 around itself); None when the committed profile was taken at another batch size."""
-    path = os.path.join(ROOT, "profiles", "r01h_pmc_ntt_traffic.json")
+def profiled_traffic(key):
+    """HBM bytes per unit (and per launch of the dominant kernel) counted by the rocprofv3 --pmc passes committed under
+    profiles/ (bench.py cannot run rocprofv3 around itself); None when there is no entry."""
     try:
-        with open(path) as f:
-            profile = json.load(f)
+        with open(TRAFFIC_PROFILE) as f:
+            return json.load(f).get(key)
     except OSError:
         return None
-    if profile.get("batch") != batch or profile.get("degree") != DEGREE:
-        return None
-    return profile["hbm_bytes_per_launch"] / forward_seconds / 1e9
 
 
 def time_kernel(torch, fn, reps):
@@ -125,7 +134,8 @@ def clocks_under_load(torch, fn, seconds=1.5):
 
 
 def cpu_baseline(moduli, sample_polys):
-    """Times the CPU oracle (port of the reference's NTT) on a bounded sample: forward + inverse of sample_polys."""
+    """Times the CPU oracle (port of the reference's NTT) on a bounded sample: forward + inverse of sample_polys at the
+    headline shape, and BASELINE configs[0] (PolyBenchmark forwardNtt, N=4096, 2 moduli, one thread)."""
     import numpy as np
 
     import oracle
@@ -152,6 +162,15 @@ def cpu_baseline(moduli, sample_polys):
     one = slab[: max(16, sample_polys // (4 * threads))].copy()
     ctx.forward_ntt_inplace(one, threads=1)
     single = one.shape[0] / (time.perf_counter() - t0)
+    # BASELINE configs[0]: Benchmarks/PolyBenchmark/PolyBenchmark.swift:148-158 (forwardNtt of one polynomial, degree
+    # 4096, two moduli, single thread)
+    small_degree = 4096
+    small_moduli = oracle.generate_primes([55, 55], False, small_degree)
+    small_ctx = oracle.PolyContext(small_degree, small_moduli)
+    small = np.stack([rng.integers(0, q, size=(512, small_degree), dtype=np.uint64) for q in small_moduli], axis=1).copy()
+    t0 = time.perf_counter()
+    small_ctx.forward_ntt_inplace(small, threads=1)
+    config0 = small.shape[0] / (time.perf_counter() - t0)
     return {
         "value": 2 * sample_polys / elapsed,
         "unit": "poly-NTT/s",
@@ -161,7 +180,308 @@ def cpu_baseline(moduli, sample_polys):
                   f"{threads} host threads, one polynomial per thread; C port of the reference's Harvey NTT "
                   f"(oracle/he_oracle.c), not the Swift binary",
         "single_thread_forward_poly_ntt_per_s": single,
+        "config0_forward_ntt_n4096_l2_single_thread_per_s": config0,
+        "config0_sample": "BASELINE configs[0]: forwardNtt N=4096, 2 x 55-bit moduli, 512 polynomials on one thread (port)",
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Workloads.  Each builds this rank's shard of device-resident synthetic inputs and exposes:
+#   step()            one pass of the hot path over the shard (enqueue only)
+#   units             units this rank processes per step
+#   result()          the tensor holding this rank's results, dim 0 = units (what the final gather moves)
+#   describe(world)   metric / unit / dtype / config for the JSON line
+#   roofline(steps)   the dominant kernel timed on its own
+class NttWorkload:
+    """c2: BASELINE configs[1]."""
+    key = "c2"
+
+    def __init__(self, torch, heamd, sharding, args, rank, world):
+        self.torch, self.heamd = torch, heamd
+        self.batch = args.batch or BATCH
+        self.moduli = heamd.generate_primes(MODULI_BITS, False, DEGREE)
+        self.ctx = heamd.PolyContext(DEGREE, self.moduli)
+        # weak scaling: the job is batch * world polynomials, rank r owns the contiguous shard [begin, end)
+        self.total = self.batch * world
+        begin, end = sharding.shard_bounds(self.total, world, rank)
+        self.slab = synthetic_slab(torch, self.moduli, (end - begin,), DEGREE, seed=0x5EED + rank)
+        self.units = 2 * (end - begin)
+        self.bytes_per_transform = 2 * len(self.moduli) * DEGREE * 8  # read + write each word once (SURVEY.md 8d)
+
+    def step(self):
+        self.ctx.forward_ntt_(self.slab)
+        self.ctx.inverse_ntt_(self.slab)
+
+    def result(self):
+        return self.slab, self.total
+
+    def describe(self, world):
+        return {
+            "metric": "polynomial NTT throughput (forward+inverse, N=8192, L=4 RNS moduli)",
+            "unit": "poly-NTT/s",
+            "dtype": "u64",
+            "config": {
+                "workload": "BASELINE configs[1]: batched forward+inverse negacyclic NTT, N=8192, 4 RNS moduli "
+                            "(55-bit), %d polynomials per GPU, device-resident" % self.batch,
+                "degree": DEGREE,
+                "moduli": self.moduli,
+                "batch_per_gpu": self.batch,
+                "parallelism": "batch sharded over %d GPU(s), no data-path collective" % world,
+            },
+        }
+
+    def roofline(self, steps, rank):
+        torch, ctx, slab = self.torch, self.ctx, self.slab
+        forward_s = time_kernel(torch, lambda: ctx.forward_ntt_(slab), max(5, steps))
+        inverse_s = time_kernel(torch, lambda: ctx.inverse_ntt_(slab), max(5, steps))
+        polys = slab.shape[0]
+        achieved = self.bytes_per_transform * polys / forward_s / 1e9
+        # the attainable figure next to the nominal peak (SURVEY.md 8d): a device-to-device copy of the same slab
+        scratch = torch.empty_like(slab)
+        copy_s = time_kernel(torch, lambda: scratch.copy_(slab), max(5, steps))
+        copy_gbps = 2 * slab.numel() * 8 / copy_s / 1e9
+        del scratch
+        load_state = clocks_under_load(torch, lambda: ctx.forward_ntt_(slab)) if rank == 0 else None
+        profile = profiled_traffic("c2_forward_ntt")
+        traffic = None
+        if profile and profile.get("units_per_launch") == polys:
+            traffic = profile["hbm_bytes_per_launch"] / forward_s / 1e9
+        roofline = {
+            "bound": "hbm",
+            "kernel": "ntt_forward_tiled<13, 10, 3, 0, 2> (forward NTT: one 1024-lane workgroup per pair of residue rows "
+                      "of one modulus, 8 words per lane per row, limb-wise Shoup butterflies)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "traffic_source": (profile or {}).get("source"),
+            "algorithmic_bytes_per_launch": self.bytes_per_transform * polys,
+            "avg_launch_ms": forward_s * 1e3,
+            "copy_rate": copy_gbps,  # measured read + write rate of a plain copy of the same 1 GiB slab
+            "frac_of_copy_rate": achieved / copy_gbps,
+            "under_load": load_state,  # rocm-smi while the kernel runs back to back: it sits at the power cap
+        }
+        extras = {
+            "forward_poly_ntt_per_s": polys / forward_s,
+            "inverse_poly_ntt_per_s": polys / inverse_s,
+            "forward_residue_ntt_per_s": polys * len(self.moduli) / forward_s,
+            "inverse_avg_launch_ms": inverse_s * 1e3,
+            "inverse_achieved_GBps": self.bytes_per_transform * polys / inverse_s / 1e9,
+            "inverse_frac_of_8TBps": self.bytes_per_transform * polys / inverse_s / 1e9 / HBM_PEAK_GBPS,
+        }
+        return roofline, extras
+
+
+class CtMulWorkload:
+    """c3: BASELINE configs[2] -- Bfv.mulAssign(ct, ct) + relinearize."""
+    key = "c3"
+    COMPULSORY = 1_572_864  # read 2 cts x 2 polys, write 2 polys (SURVEY.md 8d)
+
+    def __init__(self, torch, heamd, sharding, args, rank, world):
+        self.torch = torch
+        self.batch = args.batch or 1024
+        q = heamd.generate_primes([55] * 5, False, DEGREE)
+        self.q = q
+        self.ctx = heamd.BfvContext(DEGREE, 557057, q)
+        moduli = q[:-1]
+        self.total = self.batch * world
+        begin, end = sharding.shard_bounds(self.total, world, rank)
+        mine = end - begin
+        self.lhs = synthetic_slab(torch, moduli, (mine, 2), DEGREE, 100 + rank)
+        self.rhs = synthetic_slab(torch, moduli, (mine, 2), DEGREE, 200 + rank)
+        self.key_ = synthetic_slab(torch, q, (self.ctx.L, 2), DEGREE, 3)  # the evaluation key is replicated
+        self.ws_mul = torch.empty(self.ctx.mul_workspace_bytes(mine) // 8, dtype=torch.int64, device="cuda")
+        self.ws_relin = torch.empty(self.ctx.relinearize_workspace_bytes(mine) // 8, dtype=torch.int64, device="cuda")
+        self.units = mine
+        self.out = None
+
+    def step(self):
+        product = self.ctx.mul(self.lhs, self.rhs, workspace=self.ws_mul)
+        self.out = self.ctx.relinearize(product, self.key_, workspace=self.ws_relin)
+
+    def result(self):
+        return self.out, self.total
+
+    def describe(self, world):
+        return {
+            "metric": "ciphertext-mul/s (Bfv ct x ct + relinearize, N=8192, L=4)",
+            "unit": "ciphertext-mul/s",
+            "dtype": "u64",
+            "config": {
+                "workload": "BASELINE configs[2]: Bfv<UInt64> ct x ct (lift, NTT, tensor, iNTT, floor) + relinearize, "
+                            "N=8192, 4 ciphertext moduli + 1 key-switching modulus (55-bit), %d ciphertext pairs per "
+                            "GPU, device-resident" % self.batch,
+                "degree": DEGREE,
+                "moduli": self.q,
+                "batch_per_gpu": self.batch,
+                "parallelism": "ciphertext pairs sharded over %d GPU(s), key replicated, no data-path collective" % world,
+            },
+        }
+
+    def roofline(self, steps, rank):
+        torch, ctx = self.torch, self.ctx
+        state = {}
+
+        def mul():
+            state["p"] = ctx.mul(self.lhs, self.rhs, workspace=self.ws_mul)
+
+        def relin():
+            ctx.relinearize(state["p"], self.key_, workspace=self.ws_relin)
+
+        reps = max(3, steps // 4)
+        mul()
+        t_mul = time_kernel(torch, mul, reps)
+        t_relin = time_kernel(torch, relin, reps)
+        t_both = t_mul + t_relin
+        achieved = self.COMPULSORY * self.units / t_both / 1e9
+        profile = profiled_traffic("c3_ct_mul_relinearize")
+        traffic = profile["hbm_bytes_per_unit"] * self.units / t_both / 1e9 if profile else None
+        roofline = {
+            "bound": "hbm",
+            "kernel": "pipeline of 10 kernels (lift x2, [Q,Bsk] forward NTT x2 bands, tensor + inverse NTT x2 bands, "
+                      "floor, spread + forward NTT, key MAC + inverse NTT, finish); achieved = compulsory bytes / time",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "traffic_bytes_per_unit": (profile or {}).get("hbm_bytes_per_unit"),
+            "traffic_source": (profile or {}).get("source"),
+            "algorithmic_bytes_per_unit": self.COMPULSORY,
+            "avg_launch_ms": t_both * 1e3,
+        }
+        extras = {"ct_mul_per_s": self.units / t_mul, "relinearize_per_s": self.units / t_relin}
+        return roofline, extras
+
+
+class ModSwitchWorkload:
+    """c4: BASELINE configs[3] -- divideAndRoundQLast."""
+    key = "c4"
+    DEGREE = 16384
+
+    def __init__(self, torch, heamd, sharding, args, rank, world):
+        self.torch = torch
+        self.batch = args.batch or 8192
+        self.moduli = heamd.generate_primes([55] * 6, False, self.DEGREE)
+        self.ctx = heamd.PolyContext(self.DEGREE, self.moduli)
+        self.total = self.batch * world
+        begin, end = sharding.shard_bounds(self.total, world, rank)
+        self.x = synthetic_slab(torch, self.moduli, (end - begin,), self.DEGREE, 400 + rank)
+        self.units = end - begin
+        self.bytes_per_poly = (6 + 5) * self.DEGREE * 8
+        self.out = None
+
+    def step(self):
+        self.out = self.ctx.divide_and_round_q_last(self.x)
+
+    def result(self):
+        return self.out, self.total
+
+    def describe(self, world):
+        return {
+            "metric": "RNS modulus-switch throughput (divideAndRoundQLast, N=16384, 6 -> 5 moduli)",
+            "unit": "poly/s",
+            "dtype": "u64",
+            "config": {
+                "workload": "BASELINE configs[3]: divideAndRoundQLast, N=16384, 6 -> 5 moduli (55-bit), %d polynomials "
+                            "per GPU, device-resident" % self.batch,
+                "degree": self.DEGREE,
+                "moduli": self.moduli,
+                "batch_per_gpu": self.batch,
+                "parallelism": "polynomials sharded over %d GPU(s), no data-path collective" % world,
+            },
+        }
+
+    def roofline(self, steps, rank):
+        t = time_kernel(self.torch, self.step, max(5, steps))
+        achieved = self.bytes_per_poly * self.units / t / 1e9
+        profile = profiled_traffic("c4_mod_switch")
+        traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
+        return {
+            "bound": "hbm",
+            "kernel": "divide_and_round_q_last_kernel (16 B per lane, grid-stride)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "traffic_source": (profile or {}).get("source"),
+            "algorithmic_bytes_per_launch": self.bytes_per_poly * self.units,
+            "avg_launch_ms": t * 1e3,
+        }, {}
+
+
+class PirDim0Workload:
+    """c5: the per-GPU column shard of BASELINE configs[4] (PirUtil.swift:427-445: per database column, the inner
+    product of the expanded dim-0 query with the column's plaintexts)."""
+    key = "c5"
+    D0 = 1024
+
+    def __init__(self, torch, heamd, sharding, args, rank, world):
+        self.torch = torch
+        self.columns_per_gpu = args.batch or 128
+        q = heamd.generate_primes([55] * 5, False, DEGREE)
+        self.q = q
+        self.ctx = heamd.BfvContext(DEGREE, 557057, q)
+        moduli = q[:-1]
+        self.total_columns = self.columns_per_gpu * world
+        begin, end = sharding.shard_bounds(self.total_columns, world, rank)
+        self.columns = end - begin
+        self.query = synthetic_slab(torch, moduli, (self.D0, 2), DEGREE, 5)  # replicated on every rank (same seed)
+        # this rank's columns of the database: plaintext k of column c at [c][k] (MulPir.swift:547-555)
+        self.database = synthetic_slab(torch, moduli, (self.columns, self.D0), DEGREE, 600 + rank)
+        self.units = self.columns * self.D0
+        self.db_bytes = self.units * len(moduli) * DEGREE * 8
+        self.out = None
+
+    def step(self):
+        self.out = self.ctx.inner_product_plain(self.query, self.database, None, 2, self.columns)
+
+    def result(self):
+        return self.out, self.total_columns
+
+    def describe(self, world):
+        return {
+            "metric": "PIR dim-0 ciphertext x plaintext multiply-accumulates per second (N=8192, L=4)",
+            "unit": "ct-pt-mac/s",
+            "dtype": "u64",
+            "config": {
+                "workload": "BASELINE configs[4]: PIR server dim-0 inner products, %d query ciphertexts x %d database "
+                            "columns per GPU (%d ct x pt products, %.1f GB of Eval plaintexts per GPU); 8 GPUs = the "
+                            "2^20 products of the config" % (self.D0, self.columns_per_gpu,
+                                                              self.D0 * self.columns_per_gpu, self.db_bytes / 1e9),
+                "degree": DEGREE,
+                "moduli": self.q,
+                "rows": self.D0,
+                "columns_per_gpu": self.columns_per_gpu,
+                "parallelism": "database sharded by column over %d GPU(s), query replicated, no data-path collective; "
+                               "the all-gather of the column results is timed separately" % world,
+            },
+        }
+
+    def roofline(self, steps, rank):
+        t = time_kernel(self.torch, self.step, max(3, steps // 4))
+        achieved = self.db_bytes / t / 1e9
+        profile = profiled_traffic("c5_inner_product_plain")
+        traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
+        return {
+            "bound": "hbm",
+            "kernel": "inner_product_plain_rows_kernel (each lane owns one word of 4 output columns and streams the "
+                      "rows' (ciphertext, plaintext) pairs into carry-counting accumulators)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "traffic_source": (profile or {}).get("source"),
+            "algorithmic_bytes_per_launch": self.db_bytes,
+            "avg_launch_ms": t * 1e3,
+            "database_GBps_per_gpu": achieved,
+        }, {}
+
+
+WORKLOADS = {w.key: w for w in (NttWorkload, CtMulWorkload, ModSwitchWorkload, PirDim0Workload)}
 
 
 def main():
@@ -183,64 +503,64 @@ def main():
     if args.gpus != world and rank == 0 and distributed:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    moduli = heamd.generate_primes(MODULI_BITS, False, DEGREE)
-    ctx = heamd.PolyContext(DEGREE, moduli)
-    # weak scaling: the job is batch * world polynomials, rank r owns the contiguous shard [begin, end)
-    total_polys = args.batch * world
-    begin, end = sharding.shard_bounds(total_polys, world, rank)
-    slab = synthetic_slab(torch, moduli, end - begin, DEGREE, seed=0x5EED + rank)
+    job = WORKLOADS[args.workload](torch, heamd, sharding, args, rank, world)
 
-    def step():
-        ctx.forward_ntt_(slab)
-        ctx.inverse_ntt_(slab)
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
+        job.step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        job.step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
         dist.barrier()
         elapsed = sharding.max_over_ranks(elapsed, device="cuda")
+    units_all_ranks = job.units
+    if distributed:
+        counter = torch.tensor([job.units], dtype=torch.int64, device="cuda")
+        dist.all_reduce(counter)
+        units_all_ranks = int(counter.item())
 
-    # ---- separately timed kernels (rank 0 reports): forward is the dominant kernel for the roofline figure
-    forward_s = time_kernel(torch, lambda: ctx.forward_ntt_(slab), max(5, args.steps))
-    inverse_s = time_kernel(torch, lambda: ctx.inverse_ntt_(slab), max(5, args.steps))
-    bytes_per_transform = 2 * len(moduli) * DEGREE * 8  # read + write each word once
-    achieved_gbps = bytes_per_transform * args.batch / forward_s / 1e9
+    # ---- separately timed kernels: the workload's dominant kernel for the roofline figure
+    roofline, extras = job.roofline(args.steps, rank)
 
-    # the attainable figure next to the nominal peak: a device-to-device copy of the same slab
-    scratch = torch.empty_like(slab)
-    copy_s = time_kernel(torch, lambda: scratch.copy_(slab), max(5, args.steps))
-    copy_gbps = 2 * slab.numel() * 8 / copy_s / 1e9
-    del scratch
-
-    load_state = clocks_under_load(torch, lambda: ctx.forward_ntt_(slab)) if rank == 0 else None
-
-    gather_ms = None
+    gather_ms = with_gather_elapsed = None
     if distributed and not args.skip_gather:
-        # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI)
-        out = sharding.gather_shards(slab, total_polys)
+        # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI); also the same
+        # K steps with the gather after every step, max over ranks
+        local, total = job.result()
+        out = sharding.gather_shards(local, total)
         torch.cuda.synchronize()
         del out
+        barrier()
         t1 = time.perf_counter()
-        out = sharding.gather_shards(slab, total_polys)
+        out = sharding.gather_shards(local, total)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        gather_ms = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda") * 1e3
+        del out
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            job.step()
+            local, total = job.result()
+            out = sharding.gather_shards(local, total)
+        torch.cuda.synchronize()
+        with_gather_elapsed = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
         del out
 
     if rank == 0:
-        total_transforms = 2 * args.batch * args.steps * world
+        description = job.describe(world)
         result = {
-            "metric": "polynomial NTT throughput (forward+inverse, N=8192, L=4 RNS moduli)",
-            "value": total_transforms / elapsed,
-            "unit": "poly-NTT/s",
+            "metric": description["metric"],
+            "value": units_all_ranks * args.steps / elapsed,
+            "unit": description["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -248,52 +568,25 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": description["dtype"],
             "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[1]: batched forward+inverse negacyclic NTT, N=8192, 4 RNS moduli "
-                            "(55-bit), %d polynomials per GPU, device-resident" % args.batch,
-                "degree": DEGREE,
-                "moduli": moduli,
-                "batch_per_gpu": args.batch,
-                "parallelism": "batch sharded over %d GPU(s), no data-path collective" % world,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "ntt_forward_tiled<13, 10, 3, 0, 0> (forward NTT: one 1024-lane workgroup per residue row, "
-                          "8 words per lane, headroom butterflies)",
-                "achieved": achieved_gbps,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic_gbps(args.batch, forward_s),
-                "traffic_source": "profiles/r01h_pmc_ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                  "gfx950 FETCH_SIZE x2 correction), bytes per launch / this run's launch time",
-                "algorithmic_bytes_per_launch": bytes_per_transform * args.batch,
-                "avg_launch_ms": forward_s * 1e3,
-                "copy_rate": copy_gbps,  # measured read + write rate of a plain copy of the same 1 GiB slab
-                "frac_of_copy_rate": achieved_gbps / copy_gbps,
-                "under_load": load_state,  # rocm-smi while the kernel runs back to back: it sits at the power cap
-            },
-            "extras": {
-                "forward_poly_ntt_per_s": args.batch / forward_s,
-                "inverse_poly_ntt_per_s": args.batch / inverse_s,
-                "forward_residue_ntt_per_s": args.batch * len(moduli) / forward_s,
-                "inverse_achieved_GBps": bytes_per_transform * args.batch / inverse_s / 1e9,
-                "all_gather_ms": gather_ms,
-                "library": heamd.version(),
-            },
+            "config": description["config"],
+            "roofline": roofline,
+            "extras": dict(extras, all_gather_ms=gather_ms,
+                           value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed
+                                                  if with_gather_elapsed else None),
+                           library=heamd.version()),
         }
-        if world == 1 and not args.skip_other_configs:
+        if args.workload == "c2" and world == 1 and not args.skip_other_configs:
             # the other BASELINE.json configs on this GPU (ciphertext-mul/s, mod-switch, PIR inner loop); not `value`
             sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
             import path_bench
 
-            del slab
+            del job
             torch.cuda.empty_cache()
             result["extras"]["other_configs"] = path_bench.run_all(quick=False)
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(moduli, args.cpu_sample)
+        if args.workload == "c2" and not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(heamd.generate_primes(MODULI_BITS, False, DEGREE), args.cpu_sample)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))

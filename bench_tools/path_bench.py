@@ -35,6 +35,29 @@ def _uniform(torch, moduli, prefix, degree, seed):
     return x % bound
 
 
+def _profiled(key):
+    """HBM bytes per unit from the committed rocprofv3 counter passes (profiles/r02_pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            return json.load(f).get(key)
+    except OSError:
+        return None
+
+
+def config1_ntt(torch, heamd, batch=8192, reps=10):
+    """Forward / inverse NTT at BASELINE configs[0]'s shape on the GPU: N=4096, 2 moduli (55-bit), `batch` polynomials."""
+    degree = 4096
+    moduli = heamd.generate_primes([55, 55], False, degree)
+    ctx = heamd.PolyContext(degree, moduli)
+    x = _uniform(torch, moduli, (batch,), degree, 11)
+    forward = _timed(torch, lambda: ctx.forward_ntt_(x), reps)
+    inverse = _timed(torch, lambda: ctx.inverse_ntt_(x), reps)
+    bytes_per_poly = 2 * 2 * degree * 8
+    return {"batch": batch, "forward_poly_ntt_per_s": batch / forward, "inverse_poly_ntt_per_s": batch / inverse,
+            "forward_GBps": bytes_per_poly * batch / forward / 1e9, "inverse_GBps": bytes_per_poly * batch / inverse / 1e9,
+            "forward_frac_of_8TBps": bytes_per_poly * batch / forward / 8e12}
+
+
 def config3_ct_mul(torch, heamd, batch=1024, reps=5):
     """ct x ct + relinearize, N=8192, 4 ciphertext moduli + 1 key-switching modulus (BASELINE configs[2])."""
     degree = 8192
@@ -69,6 +92,10 @@ def config3_ct_mul(torch, heamd, batch=1024, reps=5):
         "ct_mul_relinearize_per_s": batch / t_both,
         "compulsory_GBps": compulsory * batch / t_both / 1e9,
         "frac_of_8TBps_at_compulsory_bytes": compulsory * batch / t_both / 8e12,
+        # counter-measured HBM bytes per product (rocprofv3 --pmc passes, profiles/) at this run's rate
+        "measured_bytes_per_product": (_profiled("c3_ct_mul_relinearize") or {}).get("hbm_bytes_per_unit"),
+        "traffic_GBps": ((_profiled("c3_ct_mul_relinearize") or {}).get("hbm_bytes_per_unit", 0) * batch / t_both / 1e9
+                         or None),
     }
 
 
@@ -80,8 +107,10 @@ def config4_mod_switch(torch, heamd, batch=8192, reps=5):
     x = _uniform(torch, moduli, (batch,), degree, 4)
     t = _timed(torch, lambda: ctx.divide_and_round_q_last(x), reps)
     bytes_per_poly = (6 + 5) * degree * 8
+    measured = (_profiled("c4_mod_switch") or {}).get("hbm_bytes_per_unit")
     return {"batch": batch, "poly_per_s": batch / t, "GBps": bytes_per_poly * batch / t / 1e9,
-            "frac_of_8TBps": bytes_per_poly * batch / t / 8e12}
+            "frac_of_8TBps": bytes_per_poly * batch / t / 8e12,
+            "traffic_GBps": measured * batch / t / 1e9 if measured else None}
 
 
 def config5_inner_product(torch, heamd, count=256, columns=64, reps=3):
@@ -95,8 +124,9 @@ def config5_inner_product(torch, heamd, count=256, columns=64, reps=3):
     t = _timed(torch, lambda: ctx.inner_product_plain(cts, pts, None, 2, columns), reps)
     macs = count * columns
     db_bytes = macs * 4 * degree * 8
+    measured = (_profiled("c5_inner_product_plain") or {}).get("hbm_bytes_per_unit")
     return {"count": count, "columns": columns, "ct_pt_mac_per_s": macs / t, "database_GBps": db_bytes / t / 1e9,
-            "frac_of_8TBps": db_bytes / t / 8e12}
+            "frac_of_8TBps": db_bytes / t / 8e12, "traffic_GBps": measured * macs / t / 1e9 if measured else None}
 
 
 def config5_pir_chunk(torch, heamd, d0=256, d1=64, reps=3):
@@ -122,6 +152,7 @@ def run_all(quick=False):
     import heamd
 
     out = {}
+    out["config1_ntt_n4096_l2"] = config1_ntt(torch, heamd, batch=1024 if quick else 8192)
     out["config3_ct_mul"] = config3_ct_mul(torch, heamd, batch=256 if quick else 1024)
     out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
     # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)

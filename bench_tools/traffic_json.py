@@ -1,0 +1,68 @@
+"""Builds profiles/r02_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
+bench_tools/pmc_traffic.py leaves in the PMC pass directories of the four workloads.
+
+  python bench_tools/traffic_json.py <ntt-dir> <c3-dir> <c4-dir> <c5-dir> <out.json>
+
+Units: c2 = one forward launch over 4096 polynomials; c3 = one ct x ct + relinearize; c4 = one polynomial; c5 = one
+ct x pt multiply-accumulate.  Bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 correction as in
+/opt/skills/guides/MI355X_MICROARCH.md.
+"""
+import json
+import sys
+
+
+def load(path):
+    with open(path + "/traffic.json") as f:
+        return json.load(f)
+
+
+def bytes_per_dispatch(report, needle, exclude=()):
+    total = 0.0
+    hits = []
+    for kernel, row in report.items():
+        if kernel.startswith("_") or needle not in kernel or any(x in kernel for x in exclude):
+            continue
+        total += (row["fetch_KiB_per_dispatch"] + row["write_KiB_per_dispatch"]) * 1024.0
+        hits.append(kernel)
+    return total, hits
+
+
+def main():
+    ntt_dir, c3_dir, c4_dir, c5_dir, out = sys.argv[1:6]
+    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r02_*.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
+    result = {}
+    ntt = load(ntt_dir)
+    forward, names = bytes_per_dispatch(ntt, "ntt_forward_tiled")
+    inverse, _ = bytes_per_dispatch(ntt, "ntt_inverse_tiled")
+    result["c2_forward_ntt"] = {"kernel": names, "units_per_launch": 4096, "hbm_bytes_per_launch": forward,
+                                "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8 * 4096,
+                                "inverse_hbm_bytes_per_launch": inverse, "source": source}
+    c3 = load(c3_dir)
+    mul_kernels = ["lift_kernel", "floor_kernel"]
+    per_batch = 0.0
+    detail = {}
+    for kernel, row in c3.items():
+        if kernel.startswith("_") or "at::" in kernel or "rocclr" in kernel:
+            continue
+        b = (row["fetch_KiB_per_dispatch"] + row["write_KiB_per_dispatch"]) * 1024.0
+        times = 2 if "lift_kernel" in kernel else 1  # two lift launches per product batch
+        per_batch += b * times
+        detail[kernel] = b * times / 1024
+    result["c3_ct_mul_relinearize"] = {"hbm_bytes_per_unit": per_batch / 1024, "algorithmic_bytes_per_unit": 1572864,
+                                       "per_kernel_bytes_per_unit": detail, "batch": 1024, "source": source}
+    c4 = load(c4_dir)
+    b, names = bytes_per_dispatch(c4, "divide_and_round")
+    result["c4_mod_switch"] = {"kernel": names, "hbm_bytes_per_unit": b / 8192,
+                               "algorithmic_bytes_per_unit": 11 * 16384 * 8, "batch": 8192, "source": source}
+    c5 = load(c5_dir)
+    b, names = bytes_per_dispatch(c5, "inner_product_plain")
+    result["c5_inner_product_plain"] = {"kernel": names, "hbm_bytes_per_unit": b / (1024 * 128),
+                                        "algorithmic_bytes_per_unit": 4 * 8192 * 8, "rows": 1024, "columns": 128,
+                                        "source": source}
+    with open(out, "w") as f:
+        json.dump(result, f, indent=1)
+    print(json.dumps(result, indent=1))
+
+
+if __name__ == "__main__":
+    main()

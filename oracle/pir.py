@@ -53,6 +53,35 @@ def compute_response_for_one_chunk(bfv, dimensions, dim0_query_eval, remaining_q
 # Query expansion (PirUtil.swift:196-355), restated with the same recursion and output order.
 
 
+def dim0_columns(bfv, dim0_query_eval, database_columns, present=None):
+    """PirUtil.swift:428-446 for a range of columns: database_columns [columns][d0][L][N] Eval -> [columns][2][L][N]
+    Coeff.  What one member of a column-sharded deployment computes (he_pir_dim0_columns_device)."""
+    qctx = bfv.ciphertext_context()
+    out = []
+    for c, column in enumerate(np.asarray(database_columns, dtype=np.uint64)):
+        mask = None if present is None else np.asarray(present, dtype=np.uint8)[c]
+        product = bfv.inner_product_plain(dim0_query_eval, column, present=mask, poly_count=2)
+        out.append(qctx.inverse_ntt(product[None])[0])
+    return np.stack(out)
+
+
+def remaining_dimensions(bfv, dimensions, intermediate, remaining_query, relinearization_key=None):
+    """PirUtil.swift:448-485 on all columns' dim-0 results (he_pir_remaining_dimensions_device)."""
+    L, n = bfv.L, bfv.degree
+    results = list(np.asarray(intermediate, dtype=np.uint64))
+    cursor = 0
+    for d in [int(x) for x in dimensions[1:]]:
+        query = np.asarray(remaining_query, dtype=np.uint64).reshape(-1, 2, L, n)[cursor:cursor + d]
+        results = [bfv.relinearize(bfv.inner_product(query, np.stack(results[start:start + d]))[None],
+                                   relinearization_key)[0] for start in range(0, len(results), d)]
+        cursor += d
+    assert len(results) == 1
+    ct = results[0][None]
+    for level in range(L, 1, -1):
+        ct = bfv.mod_switch_down(ct, poly_count=2, moduli_count=level)
+    return ct[0]
+
+
 def _log2(x):
     return x.bit_length() - 1
 

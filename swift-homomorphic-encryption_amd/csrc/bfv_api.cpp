@@ -403,26 +403,12 @@ int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, ui
     return HE_OK;
 }
 
-int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
-                                      const uint64_t* cts, const uint64_t* pts, const uint8_t* present, size_t count,
-                                      size_t columns, uint64_t* out, he_stream s) {
-    const RnsToolLevel* tool = nullptr;
-    int status = check_level(ctx, moduli_count, &tool);
-    if (status != HE_OK) return status;
-    if (count == 0) return invalid_argument("empty ciphertext vector");  // precondition, Bfv.swift:481-483
-    if (columns == 0) return HE_OK;
-    if (cts == nullptr || pts == nullptr || out == nullptr) return invalid_argument("null operand");
-    if (poly_count < 1 || poly_count > 3) return invalid_argument("poly_count must be 1..3");
-    hipStream_t stream = as_stream(s);
+namespace {
+// Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv/Bfv.swift:476-505) with the nil-plaintext mask resident on the device
+int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const uint64_t* cts,
+                        const uint64_t* pts, const uint8_t* present_device, size_t count, size_t columns, uint64_t* out,
+                        hipStream_t stream) {
     const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
-    Scratch scratch(stream);
-    const uint8_t* present_device = nullptr;
-    if (present != nullptr) {
-        HEAMD_HIP_TRY(scratch.allocate(count * columns));
-        HEAMD_HIP_TRY(hipMemcpyAsync(scratch.get(), present, count * columns, hipMemcpyHostToDevice, stream));
-        HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
-        present_device = static_cast<const uint8_t*>(scratch.get());
-    }
     const uint64_t max_lazy = pc->max_lazy_product_accumulation_count(moduli_count);
     // the carry-counting accumulator's reduction wants sums below 2^127: at most 2^127 / (p_max - 1)^2 products
     uint64_t cadence = max_lazy;
@@ -437,6 +423,49 @@ int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli
     HEAMD_HIP_TRY(heamd::launch_inner_product_plain(cts, pts, present_device, out, pc->device_context(), poly_count,
                                                     count, columns, max_lazy, cadence, stream));
     return HE_OK;
+}
+int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const uint64_t* cts,
+                              const uint64_t* pts, size_t count, size_t columns, const uint64_t* out, bool* nothing_to_do) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    *nothing_to_do = false;
+    if (count == 0) return invalid_argument("empty ciphertext vector");  // precondition, Bfv.swift:481-483
+    if (columns == 0) {
+        *nothing_to_do = true;
+        return HE_OK;
+    }
+    if (cts == nullptr || pts == nullptr || out == nullptr) return invalid_argument("null operand");
+    if (poly_count < 1 || poly_count > 3) return invalid_argument("poly_count must be 1..3");
+    return HE_OK;
+}
+}  // namespace
+
+int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                      const uint64_t* cts, const uint64_t* pts, const uint8_t* present, size_t count,
+                                      size_t columns, uint64_t* out, he_stream s) {
+    bool nothing = false;
+    int status = check_inner_product_plain(ctx, moduli_count, poly_count, cts, pts, count, columns, out, &nothing);
+    if (status != HE_OK || nothing) return status;
+    hipStream_t stream = as_stream(s);
+    Scratch scratch(stream);
+    const uint8_t* present_device = nullptr;
+    if (present != nullptr) {
+        HEAMD_HIP_TRY(scratch.allocate(count * columns));
+        HEAMD_HIP_TRY(hipMemcpyAsync(scratch.get(), present, count * columns, hipMemcpyHostToDevice, stream));
+        HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
+        present_device = static_cast<const uint8_t*>(scratch.get());
+    }
+    return inner_product_plain(ctx, moduli_count, poly_count, cts, pts, present_device, count, columns, out, stream);
+}
+
+int he_bfv_inner_product_plain_resident_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                               const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
+                                               size_t count, size_t columns, uint64_t* out, he_stream s) {
+    bool nothing = false;
+    int status = check_inner_product_plain(ctx, moduli_count, poly_count, cts, pts, count, columns, out, &nothing);
+    if (status != HE_OK || nothing) return status;
+    return inner_product_plain(ctx, moduli_count, poly_count, cts, pts, present_device, count, columns, out, as_stream(s));
 }
 
 // ------------------------------------------------------------------------------------------ inner product ct . ct

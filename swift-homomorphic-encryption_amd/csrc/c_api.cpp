@@ -152,6 +152,82 @@ int he_stream_synchronize(he_stream stream) {
     HEAMD_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return HE_OK;
 }
+int he_stream_create(he_stream* out) {
+    if (out == nullptr) return invalid_argument("null out");
+    hipStream_t stream = nullptr;
+    HEAMD_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    *out = stream;
+    return HE_OK;
+}
+int he_stream_destroy(he_stream stream) {
+    if (stream == nullptr) return HE_OK;
+    HEAMD_HIP_TRY(hipStreamDestroy(as_stream(stream)));
+    return HE_OK;
+}
+
+// ---- completion primitives for the reference's `...Async` twins (HeSchemeAsync.swift:16-141): a Swift `async`
+// wrapper enqueues the `_device` call and suspends on he_stream_add_callback (or polls / waits on an event) instead of
+// blocking a thread of the cooperative pool in he_stream_synchronize.
+int he_event_create(he_event* out) {
+    if (out == nullptr) return invalid_argument("null out");
+    hipEvent_t event = nullptr;
+    HEAMD_HIP_TRY(hipEventCreateWithFlags(&event, hipEventDisableTiming));
+    *out = event;
+    return HE_OK;
+}
+int he_event_destroy(he_event event) {
+    if (event == nullptr) return HE_OK;
+    HEAMD_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return HE_OK;
+}
+int he_event_record(he_event event, he_stream stream) {
+    if (event == nullptr) return invalid_argument("null event");
+    HEAMD_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), as_stream(stream)));
+    return HE_OK;
+}
+int he_event_synchronize(he_event event) {
+    if (event == nullptr) return invalid_argument("null event");
+    HEAMD_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return HE_OK;
+}
+int he_event_query(he_event event, int* out_done) {
+    if (event == nullptr || out_done == nullptr) return invalid_argument("null event");
+    const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *out_done = 0;
+        return HE_OK;
+    }
+    HEAMD_HIP_TRY(e);
+    *out_done = 1;
+    return HE_OK;
+}
+int he_stream_wait_event(he_stream stream, he_event event) {
+    if (event == nullptr) return invalid_argument("null event");
+    HEAMD_HIP_TRY(hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(event), 0));
+    return HE_OK;
+}
+namespace {
+struct HostCallback {
+    he_host_callback function;
+    void* user_data;
+};
+void run_host_callback(void* raw) {
+    HostCallback* call = static_cast<HostCallback*>(raw);
+    call->function(call->user_data);
+    delete call;
+}
+}  // namespace
+int he_stream_add_callback(he_stream stream, he_host_callback callback, void* user_data) {
+    if (callback == nullptr) return invalid_argument("null callback");
+    HostCallback* call = new HostCallback{callback, user_data};
+    const hipError_t e = hipLaunchHostFunc(as_stream(stream), run_host_callback, call);
+    if (e != hipSuccess) {
+        delete call;
+        return heamd::device_failure(e, "hipLaunchHostFunc");
+    }
+    return HE_OK;
+}
 
 // ------------------------------------------------------------------------------------------ PolyContext
 static int poly_context_create(uint32_t degree, const uint64_t* moduli, uint32_t moduli_count, bool host_only,

@@ -22,6 +22,43 @@ struct alignas(16) U64x2 {
     uint64_t x, y;
 };
 
+// 16-byte loads / stores of words that are touched once per launch (polynomial slabs streamed through a kernel):
+// non-temporal, so that they pass the caches without displacing what other workgroups re-read (constant tables,
+// shared operand tiles).  HEAMD_X_CACHED_STREAMS (experiment) restores the default policy.
+typedef unsigned long long StreamWords __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ U64x2 stream_load(const U64x2* p) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    return *p;
+#else
+    const StreamWords v = __builtin_nontemporal_load(reinterpret_cast<const StreamWords*>(p));
+    return U64x2{v.x, v.y};
+#endif
+}
+__device__ __forceinline__ void stream_store(U64x2* p, U64x2 value) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    *p = value;
+#else
+    const StreamWords v = {value.x, value.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<StreamWords*>(p));
+#endif
+}
+
+// the 8-byte forms (one word per lane: the per-coefficient BEHZ kernels)
+__device__ __forceinline__ uint64_t stream_load(const uint64_t* p) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void stream_store(uint64_t* p, uint64_t value) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    *p = value;
+#else
+    __builtin_nontemporal_store(value, p);
+#endif
+}
+
 __device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
 __device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }
 

@@ -494,24 +494,24 @@ __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid,
 // Global <-> registers through the row's buffer descriptor: one 32-bit lane offset per pass, the register part is a
 // scalar offset.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at a time.
 // For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
-#ifdef HEAMD_X_NT_LOAD  // experiment: row data loaded non-temporally (keeps the vector L1 for the twiddle gathers)
-constexpr int kLoadPolicy = 2;
+// Row data is touched once per launch: loaded and stored non-temporally it does not displace the twiddle tables from
+// the vector L1 / L2 that every workgroup gathers from (forward 0.566 -> 0.525 ms, inverse 0.622 -> 0.586 ms per launch,
+// profiles/r02e_ntt_ab_nt_policy.txt).  aux bit 1 = nt on gfx940+.
+#ifdef HEAMD_X_CACHED_ROWS  // experiment: the default cache policy
+constexpr int kLoadPolicy = 0, kStorePolicy = 0;
 #else
-constexpr int kLoadPolicy = 0;
+constexpr int kLoadPolicy = 2, kStorePolicy = 2;
 #endif
-#ifdef HEAMD_X_NT_STORE
-constexpr int kStorePolicy = 2;
-#else
-constexpr int kStorePolicy = 0;
-#endif
-template <int LOGN, int LOGE, int LO, int W>
+// POLICY: kLoadPolicy for rows nobody else reads; 0 (cached) for source rows that several workgroups of a replica set
+// read (ntt_kernels.hip locate_replica: the others are meant to hit in L2)
+template <int LOGN, int LOGE, int LO, int W, int POLICY = kLoadPolicy>
 __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
     const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
     if constexpr (LO == 0 && W >= 1) {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
             const Dwordx4 pair =
-                __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kLoadPolicy);
+                __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, POLICY);
             v[r] = pack64(pair.x, pair.y);
             v[r + 1] = pack64(pair.z, pair.w);
         }
@@ -519,7 +519,7 @@ __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t t
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) {
             const Dwordx2 word =
-                __builtin_amdgcn_raw_buffer_load_b64(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kLoadPolicy);
+                __builtin_amdgcn_raw_buffer_load_b64(row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, POLICY);
             v[r] = pack64(word.x, word.y);
         }
     }

@@ -22,6 +22,7 @@
 #include "device_math.hpp"
 #include "kernels.hpp"
 #include "ntt_common.hpp"
+#include "placement.hpp"
 
 // Experiment hooks of the forward kernel (bench_tools/ab_variants.py builds variant libraries with -DHEAMD_X_...; the
 // production build defines none of them and every hook is the plain statement).  Variants that drop work compute
@@ -108,31 +109,6 @@ __device__ __forceinline__ void locate_rows(const RowMap& map, uint32_t block, s
     for (int k = 0; k < ROWS; ++k) rows[k] = first + k * stride;
 }
 
-// Kernels whose workgroups come in sets of `replicas` that read the SAME source rows (the L + 1 key-switching rows spread
-// from one ciphertext row, the three tensor-product polynomials of one [Q, Bsk] row, the two key polynomials of one
-// spread row): workgroup b is dispatched to XCD b % 8, so the members of a set take dispatch slots s, s + 1, ... of ONE
-// XCD -- the first one's read fills that XCD's L2 and the others hit there instead of going back to HBM.  Sets beyond
-// the last multiple of 8 keep the plain order.  Performance only: any placement computes the same thing.
-__device__ __forceinline__ void locate_replica(uint32_t block, uint32_t sets, uint32_t replicas, uint32_t& set,
-                                               uint32_t& replica) {
-#ifdef HEAMD_X_NO_XCD_SETS
-    set = block / replicas;
-    replica = block - set * replicas;
-#else
-    constexpr uint32_t kXcds = 8;
-    const uint32_t full = sets & ~(kXcds - 1);
-    if (block < full * replicas) {
-        const uint32_t slot = block / kXcds, xcd = block % kXcds, round = slot / replicas;
-        replica = slot - round * replicas;
-        set = round * kXcds + xcd;
-    } else {
-        const uint32_t rest = block - full * replicas, q = rest / replicas;
-        set = full + q;
-        replica = rest - q * replicas;
-    }
-#endif
-}
-
 // Row sources of the forward transform other than the slab itself: the step that would otherwise write the slab (and
 // this kernel read it back) is applied to the words as they are loaded.
 //   kSourceSpread  the key-switching decomposition (Bfv+Keys.swift:165-179): output row (poly, j, r) of a
@@ -159,6 +135,10 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // second is written (the same fence the exchange itself needs: wave-private once a wave owns its slice of the row).
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS>
 __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
+#ifdef HEAMD_X_LATE_LDS_ADDRESS  // experiment: the tile addresses are derived here, not at the top of the kernel
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(tid));
+#endif
 #ifndef HEAMD_X_NO_LDS
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
@@ -284,7 +264,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         HEAMD_X_PROLOGUE();
         if constexpr (SPREAD != kSourceSlab) {
             const size_t poly = record / spread.L, j = record - poly * spread.L;  // record = poly * L + j
-            global_load<LOGN, LOGE, LO0, LOGE>(
+            global_load<LOGN, LOGE, LO0, LOGE, 0>(  // cached: the other rows of this record read the same words
                 v[0], tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
             if constexpr (SPREAD == kSourceLift) {
                 const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;

@@ -23,45 +23,70 @@ using heamd::Scratch;
         if (status_ != HE_OK) return status_; \
     } while (0)
 
-extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
-                                                    uint32_t dimension_count, const uint64_t* dim0_query_eval,
-                                                    const uint64_t* remaining_query, size_t remaining_query_count,
-                                                    const uint64_t* database,
-                                                    const uint8_t* present, const uint64_t* relinearization_key,
-                                                    uint64_t* out, he_stream s) {
+namespace {
+
+struct ChunkShape {
+    uint32_t L = 0;
+    size_t n = 0, d0 = 0, columns = 0, per_chunk = 0, consumed = 0;
+    const he_poly_context* q_ctx = nullptr;
+};
+
+// the reference's preconditions on (dimensions, query) -- PirUtil.swift:420-422 and the slices taken at :454
+int chunk_shape(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                const uint64_t* remaining_query, size_t remaining_query_count, ChunkShape& shape) {
     if (ctx == nullptr) return invalid_argument("null context");
     if (dimensions == nullptr || dimension_count == 0) return invalid_argument("empty dimensions");
+    shape.L = he_bfv_ciphertext_moduli_count(ctx);
+    shape.q_ctx = he_bfv_ciphertext_context(ctx, shape.L);
+    if (shape.q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
+    shape.n = he_poly_context_degree(shape.q_ctx);
+    shape.per_chunk = 1;
+    for (uint32_t i = 0; i < dimension_count; ++i) {
+        if (dimensions[i] == 0) return invalid_argument("zero dimension");
+        shape.per_chunk *= dimensions[i];
+        if (i > 0) shape.consumed += dimensions[i];
+    }
+    shape.d0 = dimensions[0];
+    shape.columns = shape.per_chunk / shape.d0;
+    if (shape.consumed > 0 && remaining_query == nullptr) return invalid_argument("null remaining query");
+    if (!(shape.columns == 1 || shape.columns == remaining_query_count) || shape.consumed > remaining_query_count)
+        return invalid_argument("dimensions do not match the query");
+    return HE_OK;
+}
+
+}  // namespace
+
+extern "C" int he_pir_dim0_columns_device(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0,
+                                          const uint64_t* database, const uint8_t* present_device, size_t columns,
+                                          uint64_t* out, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    if (columns == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
     const uint32_t L = he_bfv_ciphertext_moduli_count(ctx);
     const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
     if (q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
-    const size_t n = he_poly_context_degree(q_ctx);
-    size_t per_chunk = 1, consumed = 0;
-    for (uint32_t i = 0; i < dimension_count; ++i) {
-        if (dimensions[i] == 0) return invalid_argument("zero dimension");
-        per_chunk *= dimensions[i];
-        if (i > 0) consumed += dimensions[i];
-    }
-    const size_t d0 = dimensions[0], columns = per_chunk / d0;
-    if (consumed > 0 && remaining_query == nullptr) return invalid_argument("null remaining query");
-    // precondition of the reference (PirUtil.swift:422), and the slices taken at :454 must exist
-    if (!(columns == 1 || columns == remaining_query_count) || consumed > remaining_query_count)
-        return invalid_argument("dimensions do not match the query");
-    hipStream_t stream = as_stream(s);
-    const size_t poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
+    // every column's ct . pt inner product in one launch (PirUtil.swift:428-437), then back to Coeff (:438)
+    HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(ctx, L, 2, dim0_query_eval, database, present_device, d0,
+                                                                columns, out, s));
+    return he_ntt_inverse_device(q_ctx, out, columns * 2, s);
+}
 
-    // results[columns][2][L][N]; `next` receives each dimension's relinearized products; products[items][3][L][N]
-    Scratch results_mem(stream), next_mem(stream), products_mem(stream), level_mem(stream);
-    HEAMD_HIP_TRY(results_mem.allocate(columns * ct2 * sizeof(uint64_t)));
-    uint64_t* results = static_cast<uint64_t*>(results_mem.get());
-    // 1. dim-0: every column's ct . pt inner product in one launch, then back to Coeff
-    HEAMD_TRY_STATUS(he_bfv_inner_product_plain_device(ctx, L, 2, dim0_query_eval, database, present, d0, columns, results,
-                                                       s));
-    HEAMD_TRY_STATUS(he_ntt_inverse_device(q_ctx, results, columns * 2, s));
-    // 2. remaining dimensions
-    size_t count = columns, cursor = 0;
+extern "C" int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                  uint32_t dimension_count, uint64_t* intermediate,
+                                                  const uint64_t* remaining_query, size_t remaining_query_count,
+                                                  const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (intermediate == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = shape.L;
+    const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
+    uint64_t* results = intermediate;
+    Scratch next_mem(stream), products_mem(stream), level_mem(stream);
+    // remaining dimensions (PirUtil.swift:448-479): `next` receives each dimension's relinearized products
+    size_t count = shape.columns, cursor = 0;
     if (dimension_count > 1) {
-        const size_t max_items = columns / dimensions[1];
+        const size_t max_items = shape.columns / dimensions[1];
         HEAMD_HIP_TRY(next_mem.allocate((max_items ? max_items : 1) * ct2 * sizeof(uint64_t)));
         HEAMD_HIP_TRY(products_mem.allocate((max_items ? max_items : 1) * ct3 * sizeof(uint64_t)));
     }
@@ -82,7 +107,7 @@ extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, c
         cursor += d;
     }
     if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
-    // 3. modSwitchDownToSingle: L - 1 divideAndRoundQLast steps on the 2-poly ciphertext
+    // modSwitchDownToSingle (:483): L - 1 divideAndRoundQLast steps on the 2-poly ciphertext
     if (L == 1) {
         HEAMD_HIP_TRY(hipMemcpyAsync(out, results, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
         return HE_OK;
@@ -97,6 +122,97 @@ extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, c
         current = target;
     }
     return HE_OK;
+}
+
+namespace {
+// one chunk with a device-resident mask, enqueue-only
+int response_chunk_resident(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                            const ChunkShape& shape, const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                            size_t remaining_query_count, const uint64_t* database, const uint8_t* present_device,
+                            const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+    Scratch results_mem(as_stream(s));
+    HEAMD_HIP_TRY(results_mem.allocate(shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t)));
+    uint64_t* results = static_cast<uint64_t*>(results_mem.get());
+    HEAMD_TRY_STATUS(he_pir_dim0_columns_device(ctx, dim0_query_eval, shape.d0, database, present_device, shape.columns,
+                                                results, s));
+    return he_pir_remaining_dimensions_device(ctx, dimensions, dimension_count, results, remaining_query,
+                                              remaining_query_count, relinearization_key, out, s);
+}
+}  // namespace
+
+extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                    uint32_t dimension_count, const uint64_t* dim0_query_eval,
+                                                    const uint64_t* remaining_query, size_t remaining_query_count,
+                                                    const uint64_t* database,
+                                                    const uint8_t* present, const uint64_t* relinearization_key,
+                                                    uint64_t* out, he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    Scratch mask_mem(stream);
+    const uint8_t* present_device = nullptr;
+    if (present != nullptr) {
+        HEAMD_HIP_TRY(mask_mem.allocate(shape.per_chunk));
+        HEAMD_HIP_TRY(hipMemcpyAsync(mask_mem.get(), present, shape.per_chunk, hipMemcpyHostToDevice, stream));
+        HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
+        present_device = static_cast<const uint8_t*>(mask_mem.get());
+    }
+    return response_chunk_resident(ctx, dimensions, dimension_count, shape, dim0_query_eval, remaining_query,
+                                   remaining_query_count, database, present_device, relinearization_key, out, s);
+}
+
+extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                              uint32_t dimension_count, const uint64_t* dim0_query_eval,
+                                              const uint64_t* remaining_query, size_t remaining_query_count,
+                                              const uint64_t* database, const uint8_t* present_device,
+                                              size_t chunk_count, const uint64_t* relinearization_key, uint64_t* out,
+                                              he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (chunk_count == 0) return HE_OK;
+    if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    const size_t chunk_words = shape.per_chunk * size_t(shape.L) * shape.n, out_words = 2 * shape.n;
+    // fork: up to four internal streams wait for everything already enqueued on `s`; join: `s` waits for all of them
+    const size_t lanes = chunk_count < 4 ? chunk_count : 4;
+    std::vector<hipStream_t> streams(lanes, nullptr);
+    std::vector<hipEvent_t> done(lanes, nullptr);
+    hipEvent_t fork = nullptr;
+    auto release = [&]() {
+        for (hipStream_t t : streams)
+            if (t != nullptr) (void)hipStreamDestroy(t);  // returns at once; the stream's work still completes
+        for (hipEvent_t e : done)
+            if (e != nullptr) (void)hipEventDestroy(e);
+        if (fork != nullptr) (void)hipEventDestroy(fork);
+    };
+    int status = HE_OK;
+    do {
+        hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+        for (size_t k = 0; k < lanes && e == hipSuccess; ++k) {
+            e = hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventRecord(fork, stream);
+        for (size_t k = 0; k < lanes && e == hipSuccess; ++k) e = hipStreamWaitEvent(streams[k], fork, 0);
+        if (e != hipSuccess) {
+            status = heamd::device_failure(e, "he_pir_compute_response_device fork");
+            break;
+        }
+        for (size_t chunk = 0; chunk < chunk_count && status == HE_OK; ++chunk)
+            status = response_chunk_resident(ctx, dimensions, dimension_count, shape, dim0_query_eval, remaining_query,
+                                             remaining_query_count, database + chunk * chunk_words,
+                                             present_device ? present_device + chunk * shape.per_chunk : nullptr,
+                                             relinearization_key, out + chunk * out_words, streams[chunk % lanes]);
+        // join even after a failed enqueue, so that nothing already enqueued outlives the caller's view of `s`
+        for (size_t k = 0; k < lanes; ++k) {
+            hipError_t j = hipEventRecord(done[k], streams[k]);
+            if (j == hipSuccess) j = hipStreamWaitEvent(stream, done[k], 0);
+            if (j != hipSuccess && status == HE_OK) status = heamd::device_failure(j, "he_pir_compute_response_device join");
+        }
+    } while (false);
+    release();
+    return status;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 #include "device_context.hpp"
 #include "device_math.hpp"
 #include "kernels.hpp"
+#include "placement.hpp"
 
 namespace heamd {
 
@@ -46,17 +47,17 @@ __global__ void __launch_bounds__(kThreads)
          i += static_cast<size_t>(gridDim.x) * kThreads) {
         const uint32_t mi = static_cast<uint32_t>((i >> log_pairs_per_row) % ctx.moduli_count);
         const DeviceModulus m = ctx.moduli[mi];
-        U64x2 a = reinterpret_cast<U64x2*>(lhs)[i];
+        U64x2 a = stream_load(reinterpret_cast<const U64x2*>(lhs) + i);
         U64x2 b = {0, 0};
         U64x2 scalar = {0, 0};
         if constexpr (OP == ElementwiseOp::MulScalar) {
             scalar = reinterpret_cast<const U64x2*>(rhs)[mi];
         } else if constexpr (OP != ElementwiseOp::Neg) {
-            b = reinterpret_cast<const U64x2*>(rhs)[i];
+            b = stream_load(reinterpret_cast<const U64x2*>(rhs) + i);
         }
         a.x = apply<OP>(a.x, b.x, m, scalar);
         a.y = apply<OP>(a.y, b.y, m, scalar);
-        reinterpret_cast<U64x2*>(lhs)[i] = a;
+        stream_store(reinterpret_cast<U64x2*>(lhs) + i, a);
     }
 }
 
@@ -107,13 +108,13 @@ __global__ void __launch_bounds__(kThreads)
         const size_t b = i / pairs_per_poly, k = i - b * pairs_per_poly;
         const uint32_t mi = static_cast<uint32_t>(k >> log_pairs_per_row);
         const DeviceModulus m = ctx.moduli[mi];
-        const U64x2 y = reinterpret_cast<const U64x2*>(pt)[i];
+        const U64x2 y = stream_load(reinterpret_cast<const U64x2*>(pt) + i);
         for (uint32_t c = 0; c < poly_count; ++c) {
             U64x2* slot = reinterpret_cast<U64x2*>(ct) + (b * poly_count + c) * pairs_per_poly + k;
-            U64x2 x = *slot;
+            U64x2 x = stream_load(slot);
             x.x = barrett_mul(x.x, y.x, m.p, m.product_factor, static_cast<int>(m.product_shift));
             x.y = barrett_mul(x.y, y.y, m.p, m.product_factor, static_cast<int>(m.product_shift));
-            *slot = x;
+            stream_store(slot, x);
         }
     }
 }
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(kThreads)
         // r - floor(q_last/2) with r = (x_last + floor(q_last/2)) mod q_last is the centred representative c of x_last
         // (-q_last/2 <= c < q_last/2), so out_i = (x_i - c) q_last^-1 mod q_i: one reduction of |c| per row instead
         // of reducing r and floor(q_last/2) separately -- the same canonical word as the reference's three steps
-        const U64x2 last_row = src[static_cast<size_t>(last) * pairs_per_row];
+        const U64x2 last_row = stream_load(src + static_cast<size_t>(last) * pairs_per_row);
         const uint64_t r0 = add_mod_uniform(last_row.x, q_last_div2, q_last);
         const uint64_t r1 = add_mod_uniform(last_row.y, q_last_div2, q_last);
         const bool negative0 = r0 < q_last_div2, negative1 = r1 < q_last_div2;
@@ -148,14 +149,14 @@ __global__ void __launch_bounds__(kThreads)
         for (uint32_t row = 0; row < last; ++row) {
             const DeviceModulus m = ctx.moduli[row];
             const U64x2 inv = inverse_q_last[row];
-            U64x2 x = src[static_cast<size_t>(row) * pairs_per_row];
+            U64x2 x = stream_load(src + static_cast<size_t>(row) * pairs_per_row);
             const uint64_t t0 = barrett_reduce64_uniform(magnitude0, m.p, m.barrett64);
             const uint64_t t1 = barrett_reduce64_uniform(magnitude1, m.p, m.barrett64);
             x.x = shoup_mul_uniform(negative0 ? add_mod_uniform(x.x, t0, m.p) : sub_mod_uniform(x.x, t0, m.p), inv.x,
                                     inv.y, m.p);
             x.y = shoup_mul_uniform(negative1 ? add_mod_uniform(x.y, t1, m.p) : sub_mod_uniform(x.y, t1, m.p), inv.x,
                                     inv.y, m.p);
-            dst[static_cast<size_t>(row) * pairs_per_row] = x;
+            stream_store(dst + static_cast<size_t>(row) * pairs_per_row, x);
         }
     }
 }
@@ -270,12 +271,17 @@ template <int POLYS, int COLS>
 __global__ void __launch_bounds__(kThreads)
     inner_product_plain_rows_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
                                     const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
-                                    const DeviceContext ctx, size_t count, size_t columns, uint64_t cadence) {
+                                    const DeviceContext ctx, size_t count, size_t columns, uint64_t cadence,
+                                    uint32_t column_groups) {
     const uint32_t logn = ctx.log_degree;
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) << logn;
-    const size_t block_word = blockIdx.y * static_cast<size_t>(kThreads);
+    // the column groups of one word block stream the same ciphertext words: one replica set per word block, so that
+    // they run on one XCD and all but the first read the ciphertexts from its L2 (placement.hpp)
+    uint32_t word_block, column_group;
+    locate_replica(blockIdx.x, static_cast<uint32_t>(words_per_poly / kThreads), column_groups, word_block, column_group);
+    const size_t block_word = word_block * static_cast<size_t>(kThreads);
     const size_t word = block_word + threadIdx.x;
-    const size_t col0 = static_cast<size_t>(blockIdx.x) * COLS;
+    const size_t col0 = static_cast<size_t>(column_group) * COLS;
     const DeviceModulus m = ctx.moduli[block_word >> logn];
     ProductSum acc[COLS][POLYS];
 #pragma unroll
@@ -299,7 +305,8 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int q = 0; q < POLYS; ++q) x_next[q] = ct_base[(j * POLYS + q) * words_per_poly];
 #pragma unroll
-        for (int c = 0; c < COLS; ++c) y_next[c] = pt_lane[pt_column[c] + j * words_per_poly];
+        for (int c = 0; c < COLS; ++c)  // the database is read once: streamed past the caches (non-temporal)
+            y_next[c] = __builtin_nontemporal_load(pt_lane + pt_column[c] + j * words_per_poly);
     };
     if (count > 0) fetch(0);
     for (size_t j = 0; j < count; ++j) {
@@ -394,9 +401,10 @@ hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t*
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
     const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
                     static_cast<unsigned>((words_per_poly + kThreads - 1) / kThreads));
-    if (ctx.degree >= kThreads && cadence != 0) {
-        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
-                           present_device, out, ctx, count, columns, cadence);
+    if (ctx.degree >= kThreads && cadence != 0 && static_cast<size_t>(grid.x) * grid.y < (size_t(1) << 31)) {
+        // one-dimensional grid: the kernel places the column groups of a word block on one XCD itself
+        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols>), dim3(grid.x * grid.y), dim3(kThreads), 0,
+                           stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,

@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t y[L];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const uint64_t x = src[i * n];
-            dst[i * n] = x;  // rows [0, L): the input itself (RnsTool.swift:329-330)
+            const uint64_t x = stream_load(src + i * n);
+            stream_store(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
             y[i] = shoup_mul_pair(x, tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kThreads)
             const U64x2 scaled = tool.q_mod_bsk_scaled[j];
             const uint64_t unfolded =
                 reduce_product_sum_lazy(sum, m) + shoup_mul_uniform_lazy(centered, scaled.x, scaled.y, m.p);
-            dst[(L + j) * n] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
+            stream_store(dst + (L + j) * n, csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p));
         }
     }
 }
@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(kThreads)
         // approximateFloor (RnsTool.swift:378-398)
         uint64_t y[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) y[i] = shoup_mul_pair(src[i * n], tool.inv_punctured_q[i], tool.q_moduli[i].p);
+        for (int i = 0; i < L; ++i)
+            y[i] = shoup_mul_pair(stream_load(src + i * n), tool.inv_punctured_q[i], tool.q_moduli[i].p);
         // (x_Bsk_j - conv_j) Q^-1 mod Bsk_j, and for j < L straight on to the Bsk -> Q converter's first product
         // z_j = f_j (B/Bsk_j)^-1 mod Bsk_j: two exact products mod Bsk_j = one by the product of the constants
         uint64_t z[L], f_msk = 0;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(kThreads)
             for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
             // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
             // checked when the tool is built), which is all the next exact product needs
-            const uint64_t difference = src[(L + j) * n] + 5 * m.p - reduce_product_sum_lazy(sum, m);
+            const uint64_t difference = stream_load(src + (L + j) * n) + 5 * m.p - reduce_product_sum_lazy(sum, m);
             if (j < L) {
                 z[j] = shoup_mul_pair(difference, tool.floor_scale_b[j], m.p);
             } else {
@@ -156,13 +157,13 @@ __global__ void __launch_bounds__(kThreads)
                 // a negation and a modular add (uniform branch; the sum stays below 2^127)
                 const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
                 product_sum_add(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
-                dst[row * n] = reduce_product_sum(sum, m);
+                stream_store(dst + row * n, reduce_product_sum(sum, m));
             } else {
                 const uint64_t converted = reduce_product_sum(sum, m);
                 // the second form is the negation of alpha (B mod q), so one product serves both
                 const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
                 const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
-                dst[row * n] = add_mod_uniform(converted, adjust, m.p);
+                stream_store(dst + row * n, add_mod_uniform(converted, adjust, m.p));
             }
         }
     }
@@ -331,19 +332,19 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t* dst = out + pc * L * n + k;
         // divideAndRoundQLast by the centred representative of the special-modulus word (poly_kernels.hip has the
         // derivation): out_i = (x_i - c) q_ks^-1 mod q_i
-        const uint64_t r = add_mod_uniform(src[size_t(L) * n], q_last_div2, q_last);
+        const uint64_t r = add_mod_uniform(stream_load(src + size_t(L) * n), q_last_div2, q_last);
         const bool negative = r < q_last_div2;
         const uint64_t magnitude = negative ? q_last_div2 - r : r - q_last_div2;
         for (uint32_t row = 0; row < L; ++row) {
             const DeviceModulus m = ks.moduli[row];
             const U64x2 inv = inverse_q_last[row];
             const uint64_t t = barrett_reduce64_uniform(magnitude, m.p, m.barrett64);
-            const uint64_t x = src[row * n];
+            const uint64_t x = stream_load(src + row * n);
             const uint64_t v = shoup_mul_uniform(negative ? add_mod_uniform(x, t, m.p) : sub_mod_uniform(x, t, m.p),
                                                  inv.x, inv.y, m.p);
             // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
             // replaces c1 (Bfv.swift:194-195)
-            dst[row * n] = c < added_polys ? add_mod_uniform(ct[row * n], v, m.p) : v;
+            stream_store(dst + row * n, c < added_polys ? add_mod_uniform(stream_load(ct + row * n), v, m.p) : v);
         }
     }
 }

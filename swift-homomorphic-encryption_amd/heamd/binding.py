@@ -11,6 +11,7 @@ _LIB_PATH = os.environ.get("HEAMD_LIBRARY") or os.path.join(_PKG, "lib", "libhe_
 
 U64P = ctypes.POINTER(ctypes.c_uint64)
 vp = ctypes.c_void_p
+HOST_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 c_u64 = ctypes.c_uint64
 c_u32 = ctypes.c_uint32
 c_size = ctypes.c_size_t
@@ -45,6 +46,15 @@ SIGNATURES = [
     ("he_memcpy_h2d", ctypes.c_int, [vp, vp, c_size, vp]),
     ("he_memcpy_d2h", ctypes.c_int, [vp, vp, c_size, vp]),
     ("he_stream_synchronize", ctypes.c_int, [vp]),
+    ("he_stream_create", ctypes.c_int, [ctypes.POINTER(vp)]),
+    ("he_stream_destroy", ctypes.c_int, [vp]),
+    ("he_event_create", ctypes.c_int, [ctypes.POINTER(vp)]),
+    ("he_event_destroy", ctypes.c_int, [vp]),
+    ("he_event_record", ctypes.c_int, [vp, vp]),
+    ("he_event_synchronize", ctypes.c_int, [vp]),
+    ("he_event_query", ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int)]),
+    ("he_stream_wait_event", ctypes.c_int, [vp, vp]),
+    ("he_stream_add_callback", ctypes.c_int, [vp, HOST_CALLBACK, vp]),
     ("he_poly_context_create", ctypes.c_int, [c_u32, U64P, c_u32, ctypes.POINTER(vp)]),
     ("he_poly_context_destroy", None, [vp]),
     ("he_poly_context_degree", c_u32, [vp]),
@@ -102,6 +112,8 @@ SIGNATURES = [
     ("he_bfv_mul_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_inner_product_plain_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, ctypes.POINTER(ctypes.c_uint8), c_size, c_size, vp, vp]),
+    ("he_bfv_inner_product_plain_resident_device", ctypes.c_int,
+     [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
     ("he_bfv_apply_galois_workspace_bytes", c_size, [vp, c_u32, c_size]),
     ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
@@ -110,6 +122,11 @@ SIGNATURES = [
     ("he_bfv_plaintext_to_coeff_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_pir_compute_response_chunk_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, ctypes.POINTER(ctypes.c_uint8), vp, vp, vp]),
+    ("he_pir_dim0_columns_device", ctypes.c_int, [vp, vp, c_size, vp, vp, c_size, vp, vp]),
+    ("he_pir_remaining_dimensions_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, vp]),
+    ("he_pir_compute_response_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
     ("he_pir_expand_device", ctypes.c_int,
      [vp, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp]),
     # diagnostics / test hooks
@@ -626,6 +643,42 @@ class BfvContext:
                                                                    _stream(stream)))
         return out
 
+    def pir_dim0_columns(self, dim0_query_eval, database, present_device=None, stream=None):
+        """PirUtil.swift:428-446 for a column shard: database [columns][d0][L][N] Eval -> [columns][2][L][N] Coeff.
+        present_device: uint8 device tensor [columns][d0] or None.  Enqueue-only."""
+        d0 = dim0_query_eval.numel() // (2 * self.L * self.degree)
+        columns = database.numel() // (d0 * self.L * self.degree)
+        out = self._empty((columns, 2, self.L, self.degree), dim0_query_eval)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_dim0_columns_device(self.h, _ptr(dim0_query_eval), d0, _ptr(database), mask,
+                                                         columns, _ptr(out), _stream(stream)))
+        return out
+
+    def pir_remaining_dimensions(self, dimensions, intermediate, remaining_query, relinearization_key=None, stream=None):
+        """PirUtil.swift:448-485 on all columns' dim-0 results ([columns][2][L][N] Coeff, consumed) -> [2][1][N]."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = self._empty((2, 1, self.degree), intermediate)
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        _check(load_library().he_pir_remaining_dimensions_device(self.h, dims, len(dimensions), _ptr(intermediate), rest,
+                                                                 rest_count, key, _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response(self, dimensions, dim0_query_eval, remaining_query, database, chunk_count,
+                             present_device=None, relinearization_key=None, stream=None):
+        """PirUtil.computeResponse's chunk loop for one query: database [chunks][prod(dims)][L][N] -> [chunks][2][1][N]."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = self._empty((chunk_count, 2, 1, self.degree), dim0_query_eval)
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_device(self.h, dims, len(dimensions), _ptr(dim0_query_eval), rest,
+                                                             rest_count, _ptr(database), mask, chunk_count, key,
+                                                             _ptr(out), _stream(stream)))
+        return out
+
     def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):
         L = self._L(moduli_count)
         batch = ct.numel() // (poly_count * L * self.degree)
@@ -652,6 +705,18 @@ class BfvContext:
             pres = pres_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
         _check(load_library().he_bfv_inner_product_plain_device(self.h, L, poly_count, _ptr(cts), _ptr(pts), pres,
                                                                 count, columns, _ptr(out), _stream(stream)))
+        return out
+
+    def inner_product_plain_resident(self, cts, pts, present_device=None, poly_count=2, columns=1, moduli_count=None,
+                                     stream=None):
+        """inner_product_plain with the nil-plaintext mask as a uint8 DEVICE tensor [columns][count]: enqueue-only."""
+        L = self._L(moduli_count)
+        count = cts.numel() // (poly_count * L * self.degree)
+        out = self._empty((columns, poly_count, L, self.degree), cts)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_bfv_inner_product_plain_resident_device(self.h, L, poly_count, _ptr(cts), _ptr(pts),
+                                                                         mask, count, columns, _ptr(out),
+                                                                         _stream(stream)))
         return out
 
     def inner_product(self, lhs, rhs, moduli_count=None, stream=None):

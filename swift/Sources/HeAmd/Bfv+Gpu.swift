@@ -1,0 +1,99 @@
+// Level B3 of include/he_amd.h behind Bfv<UInt64>: the scheme operations on the hot path as batched, device-resident
+// pipelines.  Each function is the batched form of one HeScheme requirement and performs the reference's own metadata
+// checks on the Swift side (they never cross the boundary):
+//   mulAssign(ct, ct)        Sources/HomomorphicEncryption/Bfv/Bfv+Multiply.swift:18-85
+//   relinearize              Bfv/Bfv.swift:201-219, Bfv/Bfv+Keys.swift:123-208
+//   modSwitchDown            Bfv/Bfv.swift:163-171
+//   innerProduct(cts, pts)   Bfv/Bfv.swift:476-505
+import CHeAmd
+import HomomorphicEncryption
+
+/// An evaluation key's key-switching key resident on the device in the layout he_bfv_relinearize_device /
+/// he_bfv_apply_galois_device take: [L][2][L+1][N] Eval -- the ciphertexts of `_KeySwitchKey` (Keys.swift:66-91) back
+/// to back, each two polynomials over the key-switching context.
+public final class DeviceKeySwitchKey: @unchecked Sendable {
+    public let buffer: DeviceBuffer
+
+    public init(_ key: _KeySwitchKey<Bfv<UInt64>>, on stream: HeAmdStream) throws {
+        let ciphertexts = key._ciphertexts
+        let words = ciphertexts.reduce(0) { sum, ct in sum + ct.polys.reduce(0) { $0 + $1.data.count } }
+        buffer = try DeviceBuffer(count: words)
+        var cursor = 0
+        for ciphertext in ciphertexts {
+            try buffer.upload(ciphertext, at: cursor, on: stream)
+            cursor += ciphertext.polys.reduce(0) { $0 + $1.data.count }
+        }
+    }
+}
+
+extension Bfv where T == UInt64 {
+    /// `lhs[i] *= rhs[i]` followed by `relinearize(using:)` for a whole batch: one upload, ten kernel launches, one
+    /// download.  The async form suspends on the stream's completion callback instead of blocking.
+    public static func gpuMultiplyRelinearize(_ lhs: inout [CanonicalCiphertext], _ rhs: [CanonicalCiphertext],
+                                              using evaluationKey: EvaluationKey<Bfv<UInt64>>) async throws
+    {
+        guard let first = lhs.first else { return }
+        guard lhs.count == rhs.count else {
+            throw HeError.incompatibleCiphertextCount("lhs \(lhs.count) != rhs \(rhs.count)")
+        }
+        // the checks of Bfv+Multiply.swift:62-76
+        for (left, right) in zip(lhs, rhs) {
+            guard left.polys.count == 2, right.polys.count == 2, left.correctionFactor == 1,
+                  right.correctionFactor == 1
+            else {
+                throw HeError.invalidCiphertext("ct x ct wants two polynomials and correction factor 1")
+            }
+            guard left.context == right.context,
+                  left.polys[0].context.moduli.count == right.polys[0].context.moduli.count
+            else {
+                throw HeError.incompatibleCiphertexts("contexts or levels differ")
+            }
+        }
+        guard let relinearizationKey = evaluationKey._relinearizationKey else {
+            throw HeError.missingRelinearizationKey // Bfv.swift:208-210
+        }
+        let context = first.context
+        let polyContext = first.polys[0].context
+        let handle = try context.gpu
+        let level = UInt32(polyContext.moduli.count)
+        let polyWords = polyContext.moduli.count * polyContext.degree
+        let batch = lhs.count
+        let stream = try HeAmdStream()
+        let left = try DeviceBuffer(count: batch * 2 * polyWords), right = try DeviceBuffer(count: batch * 2 * polyWords)
+        let product = try DeviceBuffer(count: batch * 3 * polyWords), out = try DeviceBuffer(count: batch * 2 * polyWords)
+        for index in 0..<batch {
+            try left.upload(lhs[index], at: index * 2 * polyWords, on: stream)
+            try right.upload(rhs[index], at: index * 2 * polyWords, on: stream)
+        }
+        let key = try DeviceKeySwitchKey(relinearizationKey._keySwitchKey, on: stream)
+        try heAmdCheck(he_bfv_mul_device(handle, level, left.pointer, right.pointer, product.pointer, batch, nil, 0,
+                                         stream.raw))
+        try heAmdCheck(he_bfv_relinearize_device(handle, level, product.pointer, key.buffer.pointer, out.pointer, batch,
+                                                 nil, 0, stream.raw))
+        try await stream.completion()
+        for index in 0..<batch {
+            lhs[index] = try out.downloadCiphertext(context: context, polyContext: polyContext, polyCount: 2,
+                                                    at: index * 2 * polyWords, on: stream)
+        }
+    }
+
+    /// `Bfv.modSwitchDown` (Bfv.swift:163-171) on resident ciphertexts: [batch][polyCount][L][N] -> [..][L-1][N].
+    public static func gpuModSwitchDown(context: Context<Bfv<UInt64>>, moduliCount: Int, polyCount: Int,
+                                        input: DeviceBuffer, output: DeviceBuffer, batch: Int,
+                                        on stream: HeAmdStream) throws
+    {
+        try heAmdCheck(he_bfv_mod_switch_down_device(context.gpu, UInt32(moduliCount), UInt32(polyCount), input.pointer,
+                                                     output.pointer, batch, stream.raw))
+    }
+
+    /// `Bfv.innerProduct(ciphertexts:plaintexts:)` (Bfv.swift:476-505) for `columns` outputs that share the ciphertext
+    /// vector; `presentMask` is the nil-plaintext mask resident on the device ([columns][count] bytes) or nil.
+    public static func gpuInnerProduct(context: Context<Bfv<UInt64>>, moduliCount: Int, ciphertexts: DeviceBuffer,
+                                       plaintexts: DeviceBuffer, presentMask: UnsafePointer<UInt8>?, count: Int,
+                                       columns: Int, output: DeviceBuffer, on stream: HeAmdStream) throws
+    {
+        try heAmdCheck(he_bfv_inner_product_plain_resident_device(context.gpu, UInt32(moduliCount), 2,
+                                                                  ciphertexts.pointer, plaintexts.pointer, presentMask,
+                                                                  count, columns, output.pointer, stream.raw))
+    }
+}

@@ -391,3 +391,64 @@ def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     values = rng.integers(0, t, size=(2, degree), dtype=np.uint64)
     lifted = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(values)))
     assert np.array_equal(lifted, np.concatenate([ref.plaintext_to_eval(v) for v in values]).reshape(lifted.shape))
+
+
+@pytest.mark.parametrize("bits,count", [([62, 62, 62], 21), ([62, 45, 61, 62], 9), ([62] * 9, 17)])
+def test_inner_product_ct_ct_reduction_cadence(oracle, bits, count):
+    """Bfv.innerProduct(ct, ct) where the [Q, Bsk] accumulators must be reduced inside the loop (Bfv.swift:339-353):
+    maxLazyProductAccumulationCount() / 2 is 8 with 62-bit moduli, so 9, 17 and 21 pairs cross one, two and two
+    reductions; words at q - 1 maximise every partial sum."""
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(count)
+    lhs, rhs = _uniform(rng, (count, 2), moduli, degree), _uniform(rng, (count, 2), moduli, degree)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    lhs[:, :, :, : degree // 2] = top[None, None, :, :]
+    rhs[:, :, :, : degree // 4] = top[None, None, :, :]
+    got = heamd.to_host(ours.inner_product(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(got, ref.inner_product(lhs, rhs))
+
+
+def test_inner_product_ct_ct_config3_shape(oracle, config3):
+    """Bfv.innerProduct(ct, ct) on BASELINE config 3's ring (N=8192, L=4), 12 pairs of uniform ciphertexts: every word
+    equals the oracle's (the PIR second dimension at a realistic size)."""
+    ours, ref = config3
+    rng = np.random.default_rng(66)
+    moduli = ref.ciphertext_context().moduli
+    lhs, rhs = _uniform(rng, (12, 2), moduli, ours.degree), _uniform(rng, (12, 2), moduli, ours.degree)
+    got = heamd.to_host(ours.inner_product(heamd.to_device(lhs), heamd.to_device(rhs)))
+    assert np.array_equal(got, ref.inner_product(lhs, rhs))
+
+
+def test_mul_and_relinearize_full_batch_properties(oracle, config3):
+    """BASELINE config 3 at its full batch (1024 ciphertext pairs, generated on the device): every output word is
+    canonical, items sampled across the batch (first, last, a middle one and the one straddling the odd workgroup tail)
+    equal the oracle word for word, and the batch result does not depend on the batch it was computed in."""
+    import torch
+
+    ours, ref = config3
+    moduli = ref.ciphertext_context().moduli
+    batch, degree, L = 1024, ours.degree, ours.L
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(67)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, 1, L, 1)
+    lhs = torch.randint(0, 1 << 62, (batch, 2, L, degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    rhs = torch.randint(0, 1 << 62, (batch, 2, L, degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    rng = np.random.default_rng(68)
+    key = _uniform(rng, (L, 2), ref.key_switching_context().moduli, degree)
+    key_dev = heamd.to_device(key)
+    product = ours.mul(lhs, rhs)
+    relin = ours.relinearize(product, key_dev)
+    assert bool((product < bound).all()) and bool((relin < bound).all())
+    sample = [0, 511, 1022, 1023]
+    host_lhs, host_rhs = heamd.to_host(lhs[sample].contiguous()), heamd.to_host(rhs[sample].contiguous())
+    expected_product = ref.mul(host_lhs, host_rhs)
+    assert np.array_equal(heamd.to_host(product[sample].contiguous()), expected_product)
+    assert np.array_equal(heamd.to_host(relin[sample].contiguous()), ref.relinearize(expected_product, key))
+    # an odd sub-batch (the ragged tail of the row-pair launches) gives the same words as the full batch
+    sub = slice(513, 1020)
+    again = ours.relinearize(ours.mul(lhs[sub].contiguous(), rhs[sub].contiguous()), key_dev)
+    assert torch.equal(again, relin[sub])

@@ -155,3 +155,104 @@ def test_pir_one_dimension_single_modulus(oracle):
     expected = oracle.pir.compute_response_for_one_chunk(ref, [3], dim0, None, database, None, None)
     got = heamd.to_host(ours.pir_compute_response_chunk([3], heamd.to_device(dim0), None, heamd.to_device(database)))
     assert np.array_equal(got, expected)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# column shards (PirUtil.swift:427-445: columns are grouped over tasks; here: over GPUs), chunk loop (:533-563)
+@pytest.mark.parametrize("shards", [2, 3])
+def test_column_sharded_response_equals_unsharded(oracle, small, shards):
+    """The dim-0 inner products of each column shard (what one GPU of a column-sharded deployment computes, sharding by
+    heamd.sharding.shard_bounds), concatenated as the RCCL all-gather leaves them, followed by the remaining dimensions,
+    is word for word the unsharded chunk response -- including a ragged and a masked shard."""
+    import torch
+
+    from heamd import sharding
+
+    ours, ref, client = small
+    rng = np.random.default_rng(63 + shards)
+    dims = [4, 5]
+    moduli = ref.ciphertext_context().moduli
+    dim0 = _uniform(rng, (dims[0], 2), moduli, ours.degree)
+    rest = _uniform(rng, (dims[1], 2), moduli, ours.degree)
+    database = _uniform(rng, (dims[0] * dims[1],), moduli, ours.degree)
+    present = np.ones(dims[0] * dims[1], dtype=np.uint8)
+    present[[2, 9, 17]] = 0
+    key = client.relinearization_key()
+    dim0_dev, rest_dev, key_dev = heamd.to_device(dim0), heamd.to_device(rest), heamd.to_device(key)
+    whole = heamd.to_host(ours.pir_compute_response_chunk(dims, dim0_dev, rest_dev, heamd.to_device(database), present,
+                                                          key_dev))
+    assert np.array_equal(whole, oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database, present, key))
+    columns = database.reshape(dims[1], dims[0], ours.L, ours.degree)
+    masks = present.reshape(dims[1], dims[0])
+    parts = []
+    for rank in range(shards):
+        begin, end = sharding.shard_bounds(dims[1], shards, rank)
+        if end == begin:
+            continue
+        mask_dev = torch.from_numpy(masks[begin:end].copy()).cuda()
+        parts.append(ours.pir_dim0_columns(dim0_dev, heamd.to_device(columns[begin:end].copy()), mask_dev))
+    gathered = torch.cat(parts, dim=0).contiguous()
+    unsharded = ours.pir_dim0_columns(dim0_dev, heamd.to_device(columns.copy()), torch.from_numpy(masks.copy()).cuda())
+    assert torch.equal(gathered, unsharded)
+    got = heamd.to_host(ours.pir_remaining_dimensions(dims, gathered, rest_dev, key_dev))
+    assert np.array_equal(got, whole)
+
+
+def test_multi_chunk_response_matches_oracle(oracle, small):
+    """PirUtil.computeResponse's chunk loop (PirUtil.swift:533-563): three chunks of one database answered with one
+    query, each chunk word for word the oracle's computeResponseForOneChunk; nil plaintexts in the second chunk."""
+    import torch
+
+    ours, ref, client = small
+    rng = random.Random(71)
+    dims, chunks = [4, 3], 3
+    per_chunk = 12
+    entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(per_chunk * chunks)]
+    database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64)).reshape(chunks, per_chunk, ref.L, ref.degree)
+    present = np.ones((chunks, per_chunk), dtype=np.uint8)
+    present[1, [0, 7]] = 0
+    qctx = ref.ciphertext_context()
+    key = client.relinearization_key()
+    one, zero = [1] + [0] * (ref.degree - 1), [0] * ref.degree
+    selection = [2, 1]
+    dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == selection[0] else zero)) for k in range(dims[0])])
+    rest = np.stack([client.encrypt(one if k == selection[1] else zero) for k in range(dims[1])])
+    got = heamd.to_host(ours.pir_compute_response(dims, heamd.to_device(dim0), heamd.to_device(rest),
+                                                  heamd.to_device(database), chunks,
+                                                  present_device=torch.from_numpy(present).cuda(),
+                                                  relinearization_key=heamd.to_device(key)))
+    index = selection[0] + dims[0] * selection[1]
+    for chunk in range(chunks):
+        expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database[chunk], present[chunk], key)
+        assert np.array_equal(got[chunk], expected), chunk
+        want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
+        assert client.decrypt(got[chunk], moduli_count=1) == want
+
+
+def test_column_shard_at_the_benchmark_row_count(oracle):
+    """BASELINE configs[4]'s ring and row count (N=8192, L=4, d0 = 1024 query ciphertexts), two columns: the sampled
+    output words equal the oracle's lazy inner product, every word is canonical, and the two-column launch equals two
+    one-column launches (a column's result does not depend on its shard)."""
+    import torch
+
+    degree, d0, columns = 8192, 1024, 2
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(64)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, 1, len(moduli), 1)
+    cts = torch.randint(0, 1 << 62, (d0, 2, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    pts = torch.randint(0, 1 << 62, (columns, d0, len(moduli), degree), dtype=torch.int64, device="cuda",
+                        generator=gen) % bound.view(1, 1, len(moduli), 1)
+    both = ours.inner_product_plain_resident(cts, pts, None, 2, columns)
+    for c in range(columns):
+        assert torch.equal(both[c], ours.inner_product_plain_resident(cts, pts[c:c + 1].contiguous(), None, 2, 1)[0])
+    assert bool((both < bound).all())
+    # sampled words against Python integers: out[c][poly][r][k] = sum_j cts[j][poly][r][k] * pts[c][j][r][k] mod q_r
+    host_cts, host_pts, host_out = heamd.to_host(cts), heamd.to_host(pts), heamd.to_host(both)
+    rng = random.Random(65)
+    for _ in range(40):
+        c, poly, r, k = rng.randrange(columns), rng.randrange(2), rng.randrange(len(moduli)), rng.randrange(degree)
+        want = sum(int(host_cts[j, poly, r, k]) * int(host_pts[c, j, r, k]) for j in range(d0)) % moduli[r]
+        assert int(host_out[c, poly, r, k]) == want

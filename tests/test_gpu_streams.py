@@ -88,3 +88,89 @@ def test_mul_relinearize_pipeline_in_a_hip_graph(oracle):
         torch.cuda.synchronize()
         expected = ref.relinearize(ref.mul(lhs, rhs), key)
         assert np.array_equal(heamd.to_host(out_static), expected), trial
+
+
+def test_masked_inner_product_is_enqueue_only_and_graph_capturable(oracle):
+    """With the nil-plaintext mask resident on the device, Bfv.innerProduct(ciphertexts:plaintexts:) never synchronises:
+    it can be captured into a HIP graph and replayed on new operands and a new mask; the host-mask form gives the same
+    words."""
+    import torch
+
+    degree = 1024
+    q = oracle.generate_primes([40, 40, 41], False, degree)
+    t = oracle.generate_primes([17], True, degree)[0]
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    rng = np.random.default_rng(92)
+    moduli = q[:-1]
+    count, columns = 6, 3
+
+    def uniform(prefix):
+        rows = [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in moduli]
+        return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
+
+    cts_static = heamd.to_device(uniform((count, 2)))
+    pts_static = heamd.to_device(uniform((columns, count)))
+    mask_static = torch.ones((columns, count), dtype=torch.uint8, device="cuda")
+    ours.inner_product_plain_resident(cts_static, pts_static, mask_static, 2, columns)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_static = ours.inner_product_plain_resident(cts_static, pts_static, mask_static, 2, columns)
+    for trial in range(2):
+        cts, pts = uniform((count, 2)), uniform((columns, count))
+        mask = (rng.integers(0, 4, size=(columns, count)) != 0).astype(np.uint8)
+        cts_static.copy_(heamd.to_device(cts))
+        pts_static.copy_(heamd.to_device(pts))
+        mask_static.copy_(torch.from_numpy(mask).cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        via_host_mask = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), mask, 2, columns))
+        assert np.array_equal(heamd.to_host(out_static), via_host_mask), trial
+        for c in range(columns):
+            expected = ref.inner_product_plain(cts, pts[c], mask[c])
+            assert np.array_equal(via_host_mask[c], expected), (trial, c)
+
+
+def test_events_and_stream_callbacks(oracle):
+    """The completion primitives the `...Async` twins await (HeSchemeAsync.swift:16-141): an event recorded after an
+    enqueued transform reports completion, a second stream can wait on it, and a host callback fires after the work."""
+    import ctypes
+    import threading as th
+
+    import torch
+
+    from heamd import binding
+
+    lib = binding.load_library()
+    degree = 4096
+    moduli = oracle.generate_primes([55, 55], False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(93)
+    x = _slab(rng, 4, moduli, degree)
+    slab = heamd.to_device(x)
+    torch.cuda.synchronize()
+    producer, consumer, event = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.he_stream_create(ctypes.byref(producer)) == 0 and lib.he_stream_create(ctypes.byref(consumer)) == 0
+    assert lib.he_event_create(ctypes.byref(event)) == 0
+    fired = th.Event()
+    seen = []
+
+    def on_done(user_data):
+        seen.append(user_data)
+        fired.set()
+
+    callback = binding.HOST_CALLBACK(on_done)
+    assert lib.he_ntt_forward_device(ours.h, ctypes.c_void_p(slab.data_ptr()), 4, producer) == 0
+    assert lib.he_event_record(event, producer) == 0
+    assert lib.he_stream_wait_event(consumer, event) == 0
+    assert lib.he_ntt_inverse_device(ours.h, ctypes.c_void_p(slab.data_ptr()), 4, consumer) == 0  # after the forward
+    assert lib.he_stream_add_callback(consumer, callback, ctypes.c_void_p(0x5EED)) == 0
+    assert fired.wait(timeout=30), "the stream callback never fired"
+    assert seen == [0x5EED]
+    done = ctypes.c_int(0)
+    assert lib.he_event_query(event, ctypes.byref(done)) == 0 and done.value == 1
+    assert lib.he_event_synchronize(event) == 0
+    assert np.array_equal(heamd.to_host(slab), x)  # forward then inverse, ordered across the two streams by the event
+    assert np.array_equal(heamd.to_host(ours.forward_ntt_(slab)), ref.forward_ntt(x))
+    assert lib.he_event_destroy(event) == 0
+    assert lib.he_stream_destroy(producer) == 0 and lib.he_stream_destroy(consumer) == 0

@@ -73,6 +73,54 @@ def test_two_rank_sharded_ntt_matches_unsharded(total):
     assert covered[0][0] == 0 and covered[0][1] == covered[1][0] and covered[1][1] == total
 
 
+def _pir_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from heamd import sharding
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        degree, dims = 32, [3, 5]
+        t = oracle.generate_primes([17], True, degree)[0]
+        q = oracle.generate_primes([40, 40, 41], False, degree)
+        bfv = oracle.BfvContext(degree, t, q)
+        moduli = bfv.ciphertext_context().moduli
+        rng = np.random.default_rng(77)  # every rank draws the same job; it keeps only its column shard of the database
+
+        def uniform(prefix, mods):
+            return np.ascontiguousarray(np.stack(
+                [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in mods], axis=len(prefix)))
+
+        dim0, rest = uniform((dims[0], 2), moduli), uniform((dims[1], 2), moduli)
+        database = uniform((dims[1], dims[0]), moduli)  # [column][row]
+        key = uniform((bfv.L, 2), q)
+        begin, end = sharding.shard_bounds(dims[1], world, rank)  # this rank's columns (bench.py --workload c5)
+        mine = oracle.pir.dim0_columns(bfv, dim0, database[begin:end])
+        gathered = sharding.gather_shards(torch.from_numpy(mine.view(np.int64)), dims[1]).numpy().view(np.uint64)
+        response = oracle.pir.remaining_dimensions(bfv, dims, gathered, rest, key)
+        whole = oracle.pir.compute_response_for_one_chunk(bfv, dims, dim0, rest, database.reshape(-1, bfv.L, degree),
+                                                          None, key)
+        results[rank] = (bool(np.array_equal(response, whole)), (begin, end))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_column_sharded_pir_response_matches_unsharded():
+    """BASELINE configs[4]'s partitioning on CPU: the database is sharded by column over two gloo ranks, each computes
+    its columns' dim-0 inner products (PirUtil.swift:427-445), the shards are all-gathered (ragged: 3 + 2 columns) and
+    the remaining dimensions give the unsharded chunk response word for word."""
+    import torch.multiprocessing as mp
+
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_pir_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    assert results[0] == (True, (0, 3)) and results[1] == (True, (3, 5))
+
+
 def test_shard_bounds_partition():
     from heamd import sharding
 
