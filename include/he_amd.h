@@ -268,17 +268,50 @@ size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t 
 
 /* Context<Bfv<UInt32>> (scheme layer): the word type fixes the largest modulus (2^30 - 1), gamma =
  * 2^30 - 20405, mTilde = 2^16 and the 29-bit Bsk primes (ModularArithmetic/Scalar.swift:498-511,
- * RnsTool.swift:30-33).  The handle works with every he_bfv_* / he_rns_* / he_pir_* entry point above and below;
- * slabs stay 8-byte words holding the zero-extended UInt32 values, so results equal the reference's Bfv<UInt32>
- * words exactly.  (Packed 4-byte storage exists for the polynomial layer: he_*_device_u32; [UInt32] ciphertexts cross
- * into this layer through he_words_widen_u32_device / he_words_narrow_u64_device below.) */
-/* Word-size bridge for Swift's Bfv<UInt32>, whose PolyRq arrays are [UInt32]: widen a packed slab to the
- * zero-extended 8-byte words the scheme layer above computes on, narrow results back (values of a UInt32 context are
- * < 2^30, so the low half is the word).  `words` counts coefficients; slabs 16-byte aligned; in != out. */
-int he_words_widen_u32_device(const uint32_t* device_in, uint64_t* device_out, size_t words, he_stream s);
-int he_words_narrow_u64_device(const uint64_t* device_in, uint32_t* device_out, size_t words, he_stream s);
+ * RnsTool.swift:30-33).  Results equal the reference's Bfv<UInt32> words exactly. */
 int he_bfv_context_create_u32(uint32_t degree, uint64_t plaintext_modulus, const uint64_t* coefficient_moduli,
                               uint32_t moduli_count, he_bfv_context** out);
+/* The scheme operations on PACKED [UInt32] slabs -- what Swift's Bfv<UInt32> holds (its PolyRq arrays are [UInt32]).
+ * Same layouts, arguments, errors and citations as the entry points of the same name without the suffix, every slab
+ * (ciphertexts, keys, plaintexts, workspaces) in 4-byte words; the context must come from he_bfv_context_create_u32.
+ * The BEHZ / key-switching / inner-product kernels are the 8-byte ones instantiated on 4-byte slabs (a word is widened
+ * in its register, never in memory); the transforms are the 4-byte NTT kernels (he_ntt_*_device_u32).  Workspaces: half
+ * the bytes the he_bfv_*_workspace_bytes functions report, or NULL for stream-ordered scratch. */
+int he_rns_lift_q_to_qbsk_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in, uint32_t* out,
+                                     size_t batch, he_stream s);
+int he_rns_floor_qbsk_to_q_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in,
+                                      uint32_t* out, size_t batch, he_stream s);
+int he_rns_scale_and_round_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in,
+                                      uint64_t scaling_factor, uint32_t* out, size_t batch, he_stream s);
+int he_bfv_mul_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs, const uint32_t* rhs,
+                          uint32_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s);
+int he_bfv_relinearize_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* ct3,
+                                  const uint32_t* key, uint32_t* out, size_t batch, void* workspace,
+                                  size_t workspace_bytes, he_stream s);
+int he_bfv_apply_galois_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* ct, uint64_t element,
+                                   const uint32_t* galois_key, uint32_t* out, size_t batch, void* workspace,
+                                   size_t workspace_bytes, he_stream s);
+int he_bfv_mod_switch_down_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                      const uint32_t* in, uint32_t* out, size_t batch, he_stream s);
+int he_bfv_mul_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* pt, size_t batch, he_stream s);
+int he_bfv_inner_product_plain_resident_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                                   const uint32_t* cts, const uint32_t* pts,
+                                                   const uint8_t* present_device, size_t count, size_t columns,
+                                                   uint32_t* out, he_stream s);
+int he_bfv_inner_product_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs,
+                                    const uint32_t* rhs, size_t count, uint32_t* out, void* workspace,
+                                    size_t workspace_bytes, he_stream s);
+int he_bfv_plaintext_to_eval_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext,
+                                        uint32_t* out, size_t batch, he_stream s);
+int he_bfv_plaintext_to_coeff_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext_eval,
+                                         uint32_t* out, size_t batch, he_stream s);
+/* A Bfv<UInt32> context also works with every 8-byte entry point (he_bfv_*, he_rns_*, he_pir_*) on slabs of
+ * zero-extended words; the PIR hooks (he_pir_*) exist in that form only.  Word-size bridge: widen a packed slab to
+ * zero-extended 8-byte words and narrow results back (values of a UInt32 context are < 2^30, so the low half is the
+ * word).  `words` counts coefficients; slabs 16-byte aligned; in != out. */
+int he_words_widen_u32_device(const uint32_t* device_in, uint64_t* device_out, size_t words, he_stream s);
+int he_words_narrow_u64_device(const uint64_t* device_in, uint32_t* device_out, size_t words, he_stream s);
 
 /* ---- "next" rows of the scope table ---- */
 /* Bfv.applyGalois(ciphertext:element:using:) (Bfv/Bfv.swift:174-198): ct [batch][2][L][N] Coeff,

@@ -83,15 +83,153 @@ int resolve_workspace(void* workspace, size_t workspace_bytes, size_t needed, Sc
     return HE_OK;
 }
 
+// ---- transforms by slab word type: 8-byte words run the tiled kernels with fused loads (ntt_kernels.hip), 4-byte words
+// (Bfv<UInt32>: every modulus, Bsk primes included, is <= 2^30 - 1) the 4-byte kernels of word32_kernels.hip ------------
+hipError_t ntt_records(bool inverse, uint64_t* slab, const PolyContext& pc, const DeviceContext& dc, uint32_t record_rows,
+                       size_t records, hipStream_t stream) {
+    (void)pc;
+    return heamd::launch_ntt_mixed(inverse, slab, dc, record_rows, records, stream);
+}
+hipError_t ntt_records(bool inverse, uint32_t* slab, const PolyContext& pc, const DeviceContext& dc, uint32_t record_rows,
+                       size_t records, hipStream_t stream) {
+    heamd::DeviceContext32 dc32{};
+    if (pc.device_context32(record_rows, dc32) != HE_OK) return hipErrorInvalidValue;
+    dc32.moduli = dc.moduli;  // the caller may have substituted constants (t N^-1)
+    return heamd::launch_ntt32(inverse, slab, dc32, 0, record_rows, records * record_rows, stream);
+}
+
 // Eval form over [Q, Bsk] -> Coeff over Q: (x t) -> inverse NTT -> floorQBskToQ  (Bfv+Multiply.swift:31-48)
-int drop_extended_base(const RnsToolLevel& tool, uint64_t* eval_qbsk, uint64_t* out, size_t polys, hipStream_t stream) {
+template <typename W>
+int drop_extended_base(const RnsToolLevel& tool, W* eval_qbsk, W* out, size_t polys, hipStream_t stream) {
     DeviceContext scaled = tool.qbsk->device_context();
     scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
     scaled.scaled_inverse_degree = 1;
     const uint32_t rows = tool.qbsk->moduli_count();
-    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(true, eval_qbsk, scaled, rows, polys, stream));
+    HEAMD_HIP_TRY(ntt_records(true, eval_qbsk, *tool.qbsk, scaled, rows, polys, stream));
     HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(eval_qbsk, out, tool.device, polys, stream));
     return HE_OK;
+}
+
+// tensor product (Bfv+Multiply.swift:80-82) and dropExtendedBase's inverse NTT: one kernel where the degree has a tiled
+// 8-byte transform (the products are formed as the inverse transform loads its row), two launches otherwise
+int tensor_and_inverse(const RnsToolLevel& tool, uint64_t* lifted, uint64_t* tensor, size_t batch, hipStream_t stream,
+                       bool* in_coeff_form) {
+    DeviceContext scaled = tool.qbsk->device_context();
+    scaled.moduli = tool.qbsk_moduli_scaled_by_t;
+    scaled.scaled_inverse_degree = 1;
+    const uint32_t rows = tool.qbsk->moduli_count();
+    hipError_t fused = heamd::launch_ntt_tensor_inverse(lifted, tensor, scaled, rows, batch, stream);
+    if (fused == hipErrorNotSupported) {
+        (void)hipGetLastError();
+        HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, tool.qbsk->device_context(), batch, stream));
+        *in_coeff_form = false;
+        return HE_OK;
+    }
+    HEAMD_HIP_TRY(fused);
+    *in_coeff_form = true;
+    return HE_OK;
+}
+int tensor_and_inverse(const RnsToolLevel& tool, uint32_t* lifted, uint32_t* tensor, size_t batch, hipStream_t stream,
+                       bool* in_coeff_form) {
+    HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, tool.qbsk->device_context(), batch, stream));
+    *in_coeff_form = false;
+    return HE_OK;
+}
+
+// Bfv.mulAssign(ct, ct) (Bfv/Bfv+Multiply.swift:18-85) on slabs of W
+template <typename W>
+int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L, const W* lhs, const W* rhs, W* out,
+                 size_t batch, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    Scratch scratch(stream);
+    uint64_t* raw = nullptr;
+    int status = resolve_workspace(workspace, workspace_bytes, batch * 7 * ext * sizeof(W), scratch, &raw);
+    if (status != HE_OK) return status;
+    W* ws = reinterpret_cast<W*>(raw);
+    W* lifted = ws;                   // [batch][4][2L+1][N]  (a0, a1, b0, b1)
+    W* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
+    // computeBehzPolys (Bfv+Multiply.swift:51-57): lift each of the four polynomials, then forward NTT.  Two strided
+    // launches (lhs polys -> slots 0,1; rhs polys -> slots 2,3) so that item b owns lifted[b][0..3].
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 0, stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 2 * ext,
+                                                       stream));
+    const DeviceContext qbsk = tool->qbsk->device_context();
+    HEAMD_HIP_TRY(ntt_records(false, lifted, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), batch * 4, stream));
+    bool in_coeff_form = false;
+    status = tensor_and_inverse(*tool, lifted, tensor, batch, stream, &in_coeff_form);
+    if (status != HE_OK) return status;
+    if (!in_coeff_form) return drop_extended_base(*tool, tensor, out, batch * 3, stream);
+    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
+    return HE_OK;
+}
+
+// Bfv+Keys.swift:165-179: decompose the target over q_0..q_{L-1}, lift each piece to every key-switching modulus
+// and take it to Eval.  One fused kernel where the degree has a tiled 8-byte NTT, two launches otherwise.
+hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t* spread, const PolyContext& ks_ctx,
+                          uint32_t L, size_t polys, hipStream_t stream) {
+    const DeviceContext ks = ks_ctx.device_context();
+    hipError_t e = heamd::launch_ntt_spread(target, target_stride, L, polys, spread, ks, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
+    if (e != hipSuccess) return e;
+    return heamd::launch_ntt(false, spread, ks, 0, L + 1, polys * L * (L + 1), stream);
+}
+hipError_t spread_to_eval(const uint32_t* target, size_t target_stride, uint32_t* spread, const PolyContext& ks_ctx,
+                          uint32_t L, size_t polys, hipStream_t stream) {
+    const DeviceContext ks = ks_ctx.device_context();
+    hipError_t e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
+    if (e != hipSuccess) return e;
+    return ntt_records(false, spread, ks_ctx, ks, L + 1, polys * L, stream);
+}
+// Bfv+Keys.swift:180-207: the lazy inner product of the decomposed target with the key, then back to Coeff.  One
+// kernel where the degree has a tiled 8-byte NTT (the sums are formed as the inverse transform loads its row).
+hipError_t key_mac_to_coeff(const uint64_t* spread, const uint64_t* key, uint64_t* prod, const PolyContext& ks_ctx,
+                            uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+    const DeviceContext ks = ks_ctx.device_context();
+    hipError_t e = heamd::launch_ntt_key_mac_inverse(spread, key, prod, ks, L, top_rows, polys, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
+    if (e != hipSuccess) return e;
+    return heamd::launch_ntt(true, prod, ks, 0, L + 1, polys * 2 * (L + 1), stream);
+}
+hipError_t key_mac_to_coeff(const uint32_t* spread, const uint32_t* key, uint32_t* prod, const PolyContext& ks_ctx,
+                            uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+    const DeviceContext ks = ks_ctx.device_context();
+    hipError_t e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
+    if (e != hipSuccess) return e;
+    return ntt_records(true, prod, ks_ctx, ks, L + 1, polys * 2, stream);
+}
+
+// _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on polynomial `target` of every item, then
+// out[item][c] = (c < added_polys ? ct[item][c] : 0) + update[item][c]  (relinearize: added 2; applyGalois: added 1)
+template <typename W>
+int key_switch_pipeline(const he_bfv_context* ctx, uint32_t L, const W* target, size_t target_stride, const W* ct_base,
+                        size_t ct_stride, const W* key, W* out, size_t batch, uint32_t added_polys, W* spread, W* prod,
+                        hipStream_t stream) {
+    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
+    HEAMD_HIP_TRY(spread_to_eval(target, target_stride, spread, *ks_ctx, L, batch, stream));
+    HEAMD_HIP_TRY(key_mac_to_coeff(spread, key, prod, *ks_ctx, L, ctx->impl->top_level() + 1, batch, stream));
+    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct_base, ct_stride, out, ks_ctx->device_context(), L, batch,
+                                                  added_polys, stream));
+    return HE_OK;
+}
+
+template <typename W>
+int relinearize_pipeline(const he_bfv_context* ctx, uint32_t L, const W* ct3, const W* key, W* out, size_t batch,
+                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t n = ctx->impl->degree();
+    Scratch scratch(stream);
+    uint64_t* raw = nullptr;
+    const size_t words = batch * (size_t(L) * (L + 1) + 2 * (L + 1)) * n;
+    int status = resolve_workspace(workspace, workspace_bytes, words * sizeof(W), scratch, &raw);
+    if (status != HE_OK) return status;
+    W* spread = reinterpret_cast<W*>(raw);                // [batch][L][L+1][N]
+    W* prod = spread + batch * L * (L + 1) * n;           // [batch][2][L+1][N]
+    const size_t ct_stride = 3 * size_t(L) * n;
+    return key_switch_pipeline(ctx, L, ct3 + 2 * size_t(L) * n, ct_stride, ct3, ct_stride, key, out, batch, 2, spread, prod,
+                               stream);
 }
 
 }  // namespace
@@ -155,111 +293,71 @@ size_t he_bfv_mul_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_cou
     return batch * 7 * qbsk_poly_words(*ctx->impl, moduli_count) * sizeof(uint64_t);  // 4 lifted + 3 tensor polys
 }
 
-int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
-                      uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s) {
+extern "C++" {
+namespace {
+template <typename W>
+int mul_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W* lhs, const W* rhs, W* out, size_t batch,
+              void* workspace, size_t workspace_bytes, he_stream s) {
     const RnsToolLevel* tool = nullptr;
     int status = check_level(ctx, moduli_count, &tool);
     if (status != HE_OK) return status;
+    if (sizeof(W) == 4 && ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
     if (batch == 0) return HE_OK;
     if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
-    hipStream_t stream = as_stream(s);
-    const uint32_t L = moduli_count;
-    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
-    Scratch scratch(stream);
-    uint64_t* ws = nullptr;
-    status = resolve_workspace(workspace, workspace_bytes, he_bfv_mul_workspace_bytes(ctx, L, batch), scratch, &ws);
-    if (status != HE_OK) return status;
-    uint64_t* lifted = ws;                   // [batch][4][2L+1][N]  (a0, a1, b0, b1)
-    uint64_t* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
-    // computeBehzPolys (Bfv+Multiply.swift:51-57): lift each of the four polynomials, then forward NTT.  Two strided
-    // launches (lhs polys -> slots 0,1; rhs polys -> slots 2,3) so that item b owns lifted[b][0..3].
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 0,
-                                                       stream));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext,
-                                                       2 * ext, stream));
-    const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(false, lifted, qbsk, static_cast<uint32_t>(rows), batch * 4, stream));
-    // tensor product (Bfv+Multiply.swift:80-82) and dropExtendedBase's inverse NTT: one kernel where the degree has a
-    // tiled transform (the products are formed as the inverse transform loads its row), two otherwise
-    DeviceContext scaled = tool->qbsk->device_context();
-    scaled.moduli = tool->qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
-    scaled.scaled_inverse_degree = 1;
-    hipError_t fused = heamd::launch_ntt_tensor_inverse(lifted, tensor, scaled, static_cast<uint32_t>(rows), batch, stream);
-    if (fused == hipErrorNotSupported) {
-        (void)hipGetLastError();
-        HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, qbsk, batch, stream));
-        return drop_extended_base(*tool, tensor, out, batch * 3, stream);
-    }
-    HEAMD_HIP_TRY(fused);
-    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
-    return HE_OK;
+    return mul_pipeline(ctx, tool, moduli_count, lhs, rhs, out, batch, workspace, workspace_bytes, as_stream(s));
+}
+}  // namespace
+}  // extern "C++"
+
+int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
+                      uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s) {
+    return mul_entry(ctx, moduli_count, lhs, rhs, out, batch, workspace, workspace_bytes, s);
+}
+int he_bfv_mul_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs, const uint32_t* rhs,
+                          uint32_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s) {
+    return mul_entry(ctx, moduli_count, lhs, rhs, out, batch, workspace, workspace_bytes, s);
 }
 
 // ------------------------------------------------------------------------------------------ relinearize
-namespace {
-// Bfv+Keys.swift:165-179: decompose the target over q_0..q_{L-1}, lift each piece to every key-switching modulus
-// and take it to Eval.  One fused kernel where the degree has a tiled NTT, two launches otherwise.
-hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t* spread, const DeviceContext& ks,
-                          uint32_t L, size_t polys, hipStream_t stream) {
-    hipError_t e = heamd::launch_ntt_spread(target, target_stride, L, polys, spread, ks, stream);
-    if (e != hipErrorNotSupported) return e;
-    (void)hipGetLastError();
-    e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
-    if (e != hipSuccess) return e;
-    return heamd::launch_ntt(false, spread, ks, 0, L + 1, polys * L * (L + 1), stream);
-}
-// Bfv+Keys.swift:180-207: the lazy inner product of the decomposed target with the key, then back to Coeff.  One
-// kernel where the degree has a tiled NTT (the sums are formed as the inverse transform loads its row), two otherwise.
-hipError_t key_mac_to_coeff(const uint64_t* spread, const uint64_t* key, uint64_t* prod, const DeviceContext& ks,
-                            uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
-    hipError_t e = heamd::launch_ntt_key_mac_inverse(spread, key, prod, ks, L, top_rows, polys, stream);
-    if (e != hipErrorNotSupported) return e;
-    (void)hipGetLastError();
-    e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
-    if (e != hipSuccess) return e;
-    return heamd::launch_ntt(true, prod, ks, 0, L + 1, polys * 2 * (L + 1), stream);
-}
-}  // namespace
-
 size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
     if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
     const size_t L = moduli_count, n = ctx->impl->degree();
     return batch * (L * (L + 1) + 2 * (L + 1)) * n * sizeof(uint64_t);
 }
 
-int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct3,
-                              const uint64_t* key, uint64_t* out, size_t batch, void* workspace,
-                              size_t workspace_bytes, he_stream s) {
+extern "C++" {
+namespace {
+template <typename W>
+int relinearize_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W* ct3, const W* key, W* out, size_t batch,
+                      void* workspace, size_t workspace_bytes, he_stream s) {
     const RnsToolLevel* tool = nullptr;
     int status = check_level(ctx, moduli_count, &tool);
     if (status != HE_OK) return status;
+    if (sizeof(W) == 4 && ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
     if (key == nullptr || !ctx->impl->has_key_switching()) {
         heamd::set_last_error("no relinearization key");
         return HE_ERR_MISSING_RELINEARIZATION_KEY;  // Bfv.swift:208-210
     }
     if (batch == 0) return HE_OK;
     if (ct3 == nullptr || out == nullptr) return invalid_argument("null ciphertext");
-    hipStream_t stream = as_stream(s);
-    const uint32_t L = moduli_count;
-    const size_t n = ctx->impl->degree();
-    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
-    const DeviceContext ks = ks_ctx->device_context();
-    Scratch scratch(stream);
-    uint64_t* ws = nullptr;
-    status = resolve_workspace(workspace, workspace_bytes, he_bfv_relinearize_workspace_bytes(ctx, L, batch), scratch,
-                               &ws);
-    if (status != HE_OK) return status;
-    uint64_t* spread = ws;                              // [batch][L][L+1][N]
-    uint64_t* prod = ws + batch * L * (L + 1) * n;      // [batch][2][L+1][N]
-    const size_t ct_stride = 3 * size_t(L) * n;
-    // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on poly 2 of every ciphertext
-    HEAMD_HIP_TRY(spread_to_eval(ct3 + 2 * size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(key_mac_to_coeff(spread, key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct3, ct_stride, out, ks, L, batch, 2, stream));
-    return HE_OK;
+    return relinearize_pipeline(ctx, moduli_count, ct3, key, out, batch, workspace, workspace_bytes, as_stream(s));
+}
+}  // namespace
+}  // extern "C++"
+
+int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct3,
+                              const uint64_t* key, uint64_t* out, size_t batch, void* workspace,
+                              size_t workspace_bytes, he_stream s) {
+    return relinearize_entry(ctx, moduli_count, ct3, key, out, batch, workspace, workspace_bytes, s);
+}
+int he_bfv_relinearize_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* ct3,
+                                  const uint32_t* key, uint32_t* out, size_t batch, void* workspace,
+                                  size_t workspace_bytes, he_stream s) {
+    return relinearize_entry(ctx, moduli_count, ct3, key, out, batch, workspace, workspace_bytes, s);
 }
 
 // ------------------------------------------------------------------------------------------ Galois automorphism
+extern "C++" {
 namespace {
 bool is_valid_galois_element(uint64_t element, uint64_t degree) {  // Galois.swift:100-105
     return degree != 0 && (degree & (degree - 1)) == 0 && (element & 1) == 1 && element < (degree << 1) && element > 1;
@@ -271,6 +369,7 @@ uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
     return static_cast<uint32_t>(x & (modulus - 1));
 }
 }  // namespace
+}  // extern "C++"
 
 size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
     if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
@@ -278,12 +377,15 @@ size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t m
     return batch * (2 * L + L * (L + 1) + 2 * (L + 1)) * n * sizeof(uint64_t);
 }
 
-int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct, uint64_t element,
-                               const uint64_t* galois_key, uint64_t* out, size_t batch, void* workspace,
-                               size_t workspace_bytes, he_stream s) {
+extern "C++" {
+namespace {
+template <typename W>
+int apply_galois_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W* ct, uint64_t element, const W* galois_key,
+                       W* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s) {
     const RnsToolLevel* tool = nullptr;
     int status = check_level(ctx, moduli_count, &tool);
     if (status != HE_OK) return status;
+    if (sizeof(W) == 4 && ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
     if (galois_key == nullptr || !ctx->impl->has_key_switching()) {
         heamd::set_last_error("no Galois key for this element");
         return HE_ERR_MISSING_GALOIS_KEY;  // Bfv.swift:184-189
@@ -294,25 +396,34 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
     hipStream_t stream = as_stream(s);
     const uint32_t L = moduli_count;
     const size_t n = ctx->impl->degree();
-    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
     const PolyContext* q_ctx = ctx->impl->ciphertext(L);
-    const DeviceContext ks = ks_ctx->device_context();
     Scratch scratch(stream);
-    uint64_t* ws = nullptr;
-    status = resolve_workspace(workspace, workspace_bytes, he_bfv_apply_galois_workspace_bytes(ctx, L, batch), scratch,
-                               &ws);
+    uint64_t* raw = nullptr;
+    const size_t words = batch * (2 * size_t(L) + size_t(L) * (L + 1) + 2 * (L + 1)) * n;
+    status = resolve_workspace(workspace, workspace_bytes, words * sizeof(W), scratch, &raw);
     if (status != HE_OK) return status;
-    uint64_t* rotated = ws;                                     // [batch][2][L][N]
-    uint64_t* spread = rotated + batch * 2 * L * n;             // [batch][L][L+1][N]
-    uint64_t* prod = spread + batch * L * (L + 1) * n;          // [batch][2][L+1][N]
+    W* rotated = reinterpret_cast<W*>(raw);                // [batch][2][L][N]
+    W* spread = rotated + batch * 2 * L * n;               // [batch][L][L+1][N]
+    W* prod = spread + batch * L * (L + 1) * n;            // [batch][2][L+1][N]
     const size_t ct_stride = 2 * size_t(L) * n;
     // Bfv.swift:190-196: c0' = galois(c0) + update0, c1' = update1, update = keySwitch(galois(c1))
     HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
                                              inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
-    HEAMD_HIP_TRY(spread_to_eval(rotated + size_t(L) * n, ct_stride, spread, ks, L, batch, stream));
-    HEAMD_HIP_TRY(key_mac_to_coeff(spread, galois_key, prod, ks, L, ctx->impl->top_level() + 1, batch, stream));
-    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, rotated, ct_stride, out, ks, L, batch, 1, stream));
-    return HE_OK;
+    return key_switch_pipeline(ctx, L, static_cast<const W*>(rotated) + size_t(L) * n, ct_stride,
+                               static_cast<const W*>(rotated), ct_stride, galois_key, out, batch, 1, spread, prod, stream);
+}
+}  // namespace
+}  // extern "C++"
+
+int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct, uint64_t element,
+                               const uint64_t* galois_key, uint64_t* out, size_t batch, void* workspace,
+                               size_t workspace_bytes, he_stream s) {
+    return apply_galois_entry(ctx, moduli_count, ct, element, galois_key, out, batch, workspace, workspace_bytes, s);
+}
+int he_bfv_apply_galois_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* ct, uint64_t element,
+                                   const uint32_t* galois_key, uint32_t* out, size_t batch, void* workspace,
+                                   size_t workspace_bytes, he_stream s) {
+    return apply_galois_entry(ctx, moduli_count, ct, element, galois_key, out, batch, workspace, workspace_bytes, s);
 }
 
 // ------------------------------------------------------------------------------------------ scaleAndRound
@@ -403,11 +514,12 @@ int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, ui
     return HE_OK;
 }
 
+extern "C++" {
 namespace {
 // Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv/Bfv.swift:476-505) with the nil-plaintext mask resident on the device
-int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const uint64_t* cts,
-                        const uint64_t* pts, const uint8_t* present_device, size_t count, size_t columns, uint64_t* out,
-                        hipStream_t stream) {
+template <typename W>
+int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const W* cts, const W* pts,
+                        const uint8_t* present_device, size_t count, size_t columns, W* out, hipStream_t stream) {
     const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
     const uint64_t max_lazy = pc->max_lazy_product_accumulation_count(moduli_count);
     // the carry-counting accumulator's reduction wants sums below 2^127: at most 2^127 / (p_max - 1)^2 products
@@ -424,8 +536,8 @@ int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32
                                                     count, columns, max_lazy, cadence, stream));
     return HE_OK;
 }
-int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const uint64_t* cts,
-                              const uint64_t* pts, size_t count, size_t columns, const uint64_t* out, bool* nothing_to_do) {
+int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const void* cts,
+                              const void* pts, size_t count, size_t columns, const void* out, bool* nothing_to_do) {
     const RnsToolLevel* tool = nullptr;
     int status = check_level(ctx, moduli_count, &tool);
     if (status != HE_OK) return status;
@@ -440,6 +552,7 @@ int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, 
     return HE_OK;
 }
 }  // namespace
+}  // extern "C++"
 
 int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
                                       const uint64_t* cts, const uint64_t* pts, const uint8_t* present, size_t count,
@@ -474,6 +587,33 @@ size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t 
     return (count * 4 + 3) * qbsk_poly_words(*ctx->impl, moduli_count) * sizeof(uint64_t);
 }
 
+extern "C++" {
+namespace {
+// Bfv.innerProduct(_: [CanonicalCiphertext], _: [CanonicalCiphertext]) (Bfv/Bfv.swift:315-361)
+template <typename W>
+int inner_product_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L, const W* lhs, const W* rhs,
+                           size_t count, W* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    Scratch scratch(stream);
+    uint64_t* raw = nullptr;
+    int status = resolve_workspace(workspace, workspace_bytes, (count * 4 + 3) * ext * sizeof(W), scratch, &raw);
+    if (status != HE_OK) return status;
+    W* lifted = reinterpret_cast<W*>(raw);   // [count][4][2L+1][N]
+    W* sum = lifted + count * 4 * ext;       // [3][2L+1][N]
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 0, stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 2 * ext,
+                                                       stream));
+    const DeviceContext qbsk = tool->qbsk->device_context();
+    HEAMD_HIP_TRY(ntt_records(false, lifted, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), count * 4, stream));
+    // maxProductCount = maxLazyProductAccumulationCount() / 2 because poly1 takes two products per pair (Bfv.swift:339)
+    const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
+    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate(static_cast<const W*>(lifted), sum, qbsk, count, max_lazy ? max_lazy : 1,
+                                                  stream));
+    return drop_extended_base(*tool, sum, out, 3, stream);
+}
+}  // namespace
+}  // extern "C++"
+
 int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
                                 const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,
                                 size_t workspace_bytes, he_stream s) {
@@ -482,26 +622,138 @@ int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count
     if (status != HE_OK) return status;
     if (count == 0) return invalid_argument("empty ciphertext vector");
     if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
-    hipStream_t stream = as_stream(s);
-    const uint32_t L = moduli_count;
-    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
-    Scratch scratch(stream);
-    uint64_t* ws = nullptr;
-    status = resolve_workspace(workspace, workspace_bytes, he_bfv_inner_product_workspace_bytes(ctx, L, count), scratch,
-                               &ws);
+    return inner_product_pipeline(ctx, tool, moduli_count, lhs, rhs, count, out, workspace, workspace_bytes, as_stream(s));
+}
+
+// ------------------------------------------------------------------------------------------ Bfv<UInt32> on 4-byte slabs
+// The remaining entry points of this file on packed [UInt32] slabs: the same kernels instantiated on 4-byte words
+// (widened in registers), the transforms through word32_kernels.hip.  The context must come from
+// he_bfv_context_create_u32.
+extern "C++" {
+namespace {
+int check_level_u32(const he_bfv_context* ctx, uint32_t moduli_count, const RnsToolLevel** tool) {
+    const int status = check_level(ctx, moduli_count, tool);
     if (status != HE_OK) return status;
-    uint64_t* lifted = ws;                    // [count][4][2L+1][N]
-    uint64_t* sum = ws + count * 4 * ext;     // [3][2L+1][N]
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 0,
-                                                       stream));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext,
-                                                       2 * ext, stream));
-    const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(heamd::launch_ntt_mixed(false, lifted, qbsk, static_cast<uint32_t>(rows), count * 4, stream));
-    // maxProductCount = maxLazyProductAccumulationCount() / 2 because poly1 takes two products per pair (Bfv.swift:339)
-    const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
-    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate(lifted, sum, qbsk, count, max_lazy ? max_lazy : 1, stream));
-    return drop_extended_base(*tool, sum, out, 3, stream);
+    if (ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
+    return HE_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int he_rns_lift_q_to_qbsk_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in, uint32_t* out,
+                                     size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk(in, out, tool->device, batch, as_stream(s)));
+    return HE_OK;
+}
+int he_rns_floor_qbsk_to_q_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in,
+                                      uint32_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null slab");
+    HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(in, out, tool->device, batch, as_stream(s)));
+    return HE_OK;
+}
+int he_rns_scale_and_round_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* in,
+                                      uint64_t scaling_factor, uint32_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null polynomial");
+    const uint64_t t = ctx->impl->plaintext_modulus();
+    if (scaling_factor >= t) return invalid_argument("scaling factor not reduced mod t");
+    const uint64_t scaled = heamd::mul_mod(tool->device.inv_gamma_mod_t, scaling_factor, t);
+    const heamd::U64x2 final_scale{scaled, heamd::shoup_factor(scaled, t)};
+    HEAMD_HIP_TRY(heamd::launch_scale_and_round(in, out, tool->device, final_scale, batch, as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_plaintext_to_eval_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext,
+                                        uint32_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (plaintext == nullptr || out == nullptr) return invalid_argument("null plaintext");
+    hipStream_t stream = as_stream(s);
+    const PolyContext* q_ctx = ctx->impl->ciphertext(moduli_count);
+    const DeviceContext dc = q_ctx->device_context(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_plaintext_lift(plaintext, out, dc, ctx->impl->plaintext_modulus(), batch, stream));
+    HEAMD_HIP_TRY(ntt_records(false, out, *q_ctx, dc, moduli_count, batch, stream));
+    return HE_OK;
+}
+int he_bfv_plaintext_to_coeff_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext_eval,
+                                         uint32_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0) return HE_OK;
+    if (plaintext_eval == nullptr || out == nullptr) return invalid_argument("null plaintext");
+    hipStream_t stream = as_stream(s);
+    const PolyContext* q_ctx = ctx->impl->ciphertext(moduli_count);
+    const DeviceContext dc = q_ctx->device_context(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_first_rows(plaintext_eval, out, dc, batch, stream));
+    HEAMD_HIP_TRY(ntt_records(true, out, *q_ctx, dc, 1, batch, stream));  // row 0 only (Plaintext.swift:176-191)
+    HEAMD_HIP_TRY(heamd::launch_plaintext_unlift(out, q_ctx->moduli()[0], ctx->impl->plaintext_modulus(),
+                                                 batch * ctx->impl->degree(), stream));
+    return HE_OK;
+}
+
+int he_bfv_mod_switch_down_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                      const uint32_t* in, uint32_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (moduli_count < 2) return HE_ERR_INVALID_POLY_CONTEXT;  // PolyRq.swift:366-368
+    if (batch == 0 || poly_count == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    heamd::DeviceContext32 dc32{};
+    status = pc->device_context32(moduli_count, dc32);
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(heamd::launch_divide_and_round_q_last32(in, out, dc32, moduli_count, batch * poly_count, as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_mul_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* pt, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0 || poly_count == 0) return HE_OK;
+    if (ct == nullptr || pt == nullptr) return invalid_argument("null operand");
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_mul_plain32(ct, pt, pc->device_context(), poly_count, batch, as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_inner_product_plain_resident_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                                   const uint32_t* cts, const uint32_t* pts,
+                                                   const uint8_t* present_device, size_t count, size_t columns,
+                                                   uint32_t* out, he_stream s) {
+    if (ctx != nullptr && ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
+    bool nothing = false;
+    int status = check_inner_product_plain(ctx, moduli_count, poly_count, cts, pts, count, columns, out, &nothing);
+    if (status != HE_OK || nothing) return status;
+    return inner_product_plain(ctx, moduli_count, poly_count, cts, pts, present_device, count, columns, out, as_stream(s));
+}
+
+int he_bfv_inner_product_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs,
+                                    const uint32_t* rhs, size_t count, uint32_t* out, void* workspace,
+                                    size_t workspace_bytes, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (count == 0) return invalid_argument("empty ciphertext vector");
+    if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    return inner_product_pipeline(ctx, tool, moduli_count, lhs, rhs, count, out, workspace, workspace_bytes, as_stream(s));
 }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ class BfvContext {
     const RnsToolLevel* tool(uint32_t k) const { return valid(k) ? &tools_[k] : nullptr; }
     bool valid(uint32_t k) const { return k >= 1 && k <= L_; }
     bool host_only() const { return host_only_; }
+    int word_bits() const { return word_bits_; }  // 64: Context<Bfv<UInt64>>, 32: Context<Bfv<UInt32>>
 
   private:
     BfvContext() = default;

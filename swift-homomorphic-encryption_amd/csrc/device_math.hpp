@@ -58,6 +58,21 @@ __device__ __forceinline__ void stream_store(uint64_t* p, uint64_t value) {
     __builtin_nontemporal_store(value, p);
 #endif
 }
+// 4-byte slabs (PolyRq<UInt32> / Bfv<UInt32>): the word is widened in the register, never in memory
+__device__ __forceinline__ uint64_t stream_load(const uint32_t* p) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void stream_store(uint32_t* p, uint64_t value) {
+#ifdef HEAMD_X_CACHED_STREAMS
+    *p = static_cast<uint32_t>(value);
+#else
+    __builtin_nontemporal_store(static_cast<uint32_t>(value), p);
+#endif
+}
 
 __device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
 __device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }

@@ -33,7 +33,8 @@ inline unsigned grid_for(size_t work_items) {
 // multiplication by a power of x, which differ only in how the doubled index i in [0, 2N) is derived from j.
 //   automorphism:  i = j * g^-1 mod 2N     (then i g = j or j + N mod 2N)
 //   x^s:           i = (j - s) mod 2N
-__device__ __forceinline__ uint64_t signed_gather(const uint64_t* __restrict__ row, uint32_t doubled_index, uint32_t n,
+template <typename W>
+__device__ __forceinline__ uint64_t signed_gather(const W* __restrict__ row, uint32_t doubled_index, uint32_t n,
                                                   uint64_t p) {
     const bool negate = doubled_index >= n;
     const uint64_t v = row[negate ? doubled_index - n : doubled_index];
@@ -42,10 +43,10 @@ __device__ __forceinline__ uint64_t signed_gather(const uint64_t* __restrict__ r
 
 enum class CoeffMap { Galois, PowerOfX };
 
-template <CoeffMap MAP>
+template <CoeffMap MAP, typename W>
 __global__ void __launch_bounds__(kThreads)
-    coeff_permute_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
-                         uint32_t parameter, size_t words) {
+    coeff_permute_kernel(const W* __restrict__ in, W* __restrict__ out, const DeviceContext ctx, uint32_t parameter,
+                         size_t words) {
     const uint32_t logn = ctx.log_degree, n = ctx.degree, mask2n = 2 * n - 1;
     for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
          idx += static_cast<size_t>(gridDim.x) * kThreads) {
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(kThreads)
         const uint32_t j = static_cast<uint32_t>(idx) & (n - 1);
         const uint64_t p = ctx.moduli[row % ctx.moduli_count].p;
         const uint32_t i = (MAP == CoeffMap::Galois ? j * parameter : j + 2 * n - parameter) & mask2n;
-        out[idx] = signed_gather(in + (row << logn), i, n, p);
+        out[idx] = static_cast<W>(signed_gather(in + (row << logn), i, n, p));
     }
 }
 
@@ -73,9 +74,10 @@ __global__ void __launch_bounds__(kThreads)
 }
 
 // plaintext [batch][N] (values < t) -> out [batch][L][N]: x < (t+1)/2 ? x : x + (q_i - t)      Plaintext.swift:157-167
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    plaintext_lift_kernel(const uint64_t* __restrict__ plaintext, uint64_t* __restrict__ out, const DeviceContext ctx,
-                          uint64_t t, size_t words) {
+    plaintext_lift_kernel(const W* __restrict__ plaintext, W* __restrict__ out, const DeviceContext ctx, uint64_t t,
+                          size_t words) {
     const uint32_t logn = ctx.log_degree, n = ctx.degree;
     const uint64_t threshold = (t + 1) >> 1;
     for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
@@ -84,25 +86,26 @@ __global__ void __launch_bounds__(kThreads)
         const size_t poly = row / ctx.moduli_count;
         const uint32_t mi = static_cast<uint32_t>(row - poly * ctx.moduli_count);
         const uint64_t x = plaintext[(poly << logn) + (idx & (n - 1))];
-        out[idx] = x < threshold ? x : x + (ctx.moduli[mi].p - t);
+        out[idx] = static_cast<W>(x < threshold ? x : x + (ctx.moduli[mi].p - t));
     }
 }
 
 // first residue rows, Coeff form, [batch][N] in place: x >= (t+1)/2 ? x - (q_0 - t) : x          Plaintext.swift:181-186
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    plaintext_unlift_kernel(uint64_t* __restrict__ rows, uint64_t q0, uint64_t t, size_t words) {
+    plaintext_unlift_kernel(W* __restrict__ rows, uint64_t q0, uint64_t t, size_t words) {
     const uint64_t threshold = (t + 1) >> 1, increment = q0 - t;
     for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
          idx += static_cast<size_t>(gridDim.x) * kThreads) {
         const uint64_t x = rows[idx];
-        rows[idx] = x >= threshold ? x - increment : x;
+        rows[idx] = static_cast<W>(x >= threshold ? x - increment : x);
     }
 }
 
 // copies residue row 0 of every polynomial: in [batch][L][N] -> out [batch][N]
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    first_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t logn, uint32_t rows_per_poly,
-                     size_t words) {
+    first_row_kernel(const W* __restrict__ in, W* __restrict__ out, uint32_t logn, uint32_t rows_per_poly, size_t words) {
     for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
          idx += static_cast<size_t>(gridDim.x) * kThreads) {
         const size_t poly = idx >> logn;
@@ -172,21 +175,26 @@ hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,
-                               size_t rows, hipStream_t stream) {
+template <typename W>
+hipError_t launch_galois_coeff(const W* in, W* out, const DeviceContext& ctx, uint32_t inverse_element, size_t rows,
+                               hipStream_t stream) {
     const size_t words = rows << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(coeff_permute_kernel<CoeffMap::Galois>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out,
-                       ctx, inverse_element, words);
+    hipLaunchKernelGGL((coeff_permute_kernel<CoeffMap::Galois, W>), dim3(grid_for(words)), dim3(kThreads), 0, stream, in,
+                       out, ctx, inverse_element, words);
     return hipGetLastError();
 }
+template hipError_t launch_galois_coeff<uint64_t>(const uint64_t*, uint64_t*, const DeviceContext&, uint32_t, size_t,
+                                                  hipStream_t);
+template hipError_t launch_galois_coeff<uint32_t>(const uint32_t*, uint32_t*, const DeviceContext&, uint32_t, size_t,
+                                                  hipStream_t);
 
 hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
                                       size_t rows, hipStream_t stream) {
     const size_t words = rows << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(coeff_permute_kernel<CoeffMap::PowerOfX>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in,
-                       out, ctx, shift, words);
+    hipLaunchKernelGGL((coeff_permute_kernel<CoeffMap::PowerOfX, uint64_t>), dim3(grid_for(words)), dim3(kThreads), 0,
+                       stream, in, out, ctx, shift, words);
     return hipGetLastError();
 }
 
@@ -199,29 +207,38 @@ hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceCon
     return hipGetLastError();
 }
 
-hipError_t launch_plaintext_lift(const uint64_t* plaintext, uint64_t* out, const DeviceContext& ctx, uint64_t t,
-                                 size_t batch, hipStream_t stream) {
+template <typename W>
+hipError_t launch_plaintext_lift(const W* plaintext, W* out, const DeviceContext& ctx, uint64_t t, size_t batch,
+                                 hipStream_t stream) {
     const size_t words = (batch * ctx.moduli_count) << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(plaintext_lift_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, plaintext, out, ctx, t,
+    hipLaunchKernelGGL(plaintext_lift_kernel<W>, dim3(grid_for(words)), dim3(kThreads), 0, stream, plaintext, out, ctx, t,
                        words);
     return hipGetLastError();
 }
 
-hipError_t launch_plaintext_unlift(uint64_t* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream) {
+template <typename W>
+hipError_t launch_plaintext_unlift(W* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream) {
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(plaintext_unlift_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, rows, q0, t, words);
+    hipLaunchKernelGGL(plaintext_unlift_kernel<W>, dim3(grid_for(words)), dim3(kThreads), 0, stream, rows, q0, t, words);
     return hipGetLastError();
 }
 
-hipError_t launch_first_rows(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, size_t batch,
-                             hipStream_t stream) {
+template <typename W>
+hipError_t launch_first_rows(const W* in, W* out, const DeviceContext& ctx, size_t batch, hipStream_t stream) {
     const size_t words = batch << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(first_row_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, ctx.log_degree,
+    hipLaunchKernelGGL(first_row_kernel<W>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, ctx.log_degree,
                        ctx.moduli_count, words);
     return hipGetLastError();
 }
+#define HEAMD_INSTANTIATE_PLAINTEXT(W)                                                                              \
+    template hipError_t launch_plaintext_lift<W>(const W*, W*, const DeviceContext&, uint64_t, size_t, hipStream_t); \
+    template hipError_t launch_plaintext_unlift<W>(W*, uint64_t, uint64_t, size_t, hipStream_t);                     \
+    template hipError_t launch_first_rows<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);
+HEAMD_INSTANTIATE_PLAINTEXT(uint64_t)
+HEAMD_INSTANTIATE_PLAINTEXT(uint32_t)
+#undef HEAMD_INSTANTIATE_PLAINTEXT
 
 }  // namespace heamd
 

@@ -62,9 +62,14 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
 // max_lazy: the reference's reduction cadence (used as is by the 128-bit accumulator kernel for degree < 256);
 // cadence: products between reductions of the carry-counting accumulator: <= max_lazy and sums below 2^127
 // (0 = use the 128-bit kernel).
-hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
-                                      uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
-                                      size_t columns, uint64_t max_lazy, uint64_t cadence, hipStream_t stream);
+// (W: uint64_t or uint32_t slabs)
+template <typename W>
+hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t* present_device, W* out,
+                                      const DeviceContext& ctx, uint32_t poly_count, size_t count, size_t columns,
+                                      uint64_t max_lazy, uint64_t cadence, hipStream_t stream);
+// ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words
+hipError_t launch_mul_plain32(uint32_t* ct, const uint32_t* pt, const DeviceContext& ctx, uint32_t poly_count, size_t batch,
+                              hipStream_t stream);
 
 
 // word32_kernels.hip: PolyRq<UInt32> (4-byte words; every modulus <= 2^30 - 1)
@@ -97,8 +102,10 @@ hipError_t launch_deserialize(const uint8_t* bytes, uint64_t* slab, const Serial
 
 // ---- galois_kernels.hip (in and out must not alias) ------------------------------------------------------------
 // f(x) -> f(x^g) on Coeff rows; `inverse_element` = g^-1 mod 2N
-hipError_t launch_galois_coeff(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t inverse_element,
-                               size_t rows, hipStream_t stream);
+// (W: uint64_t or uint32_t slabs)
+template <typename W>
+hipError_t launch_galois_coeff(const W* in, W* out, const DeviceContext& ctx, uint32_t inverse_element, size_t rows,
+                               hipStream_t stream);
 // f(x) -> f(x^g) on Eval (bit-reversed) rows
 hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t element,
                               size_t rows, hipStream_t stream);
@@ -112,12 +119,14 @@ hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t
 hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
                                       size_t rows, hipStream_t stream);
 // plaintext [batch][N] mod t -> centered lift into every row of [batch][L][N] (L = ctx.moduli_count)
-hipError_t launch_plaintext_lift(const uint64_t* plaintext, uint64_t* out, const DeviceContext& ctx, uint64_t t,
-                                 size_t batch, hipStream_t stream);
+template <typename W>
+hipError_t launch_plaintext_lift(const W* plaintext, W* out, const DeviceContext& ctx, uint64_t t, size_t batch,
+                                 hipStream_t stream);
 // rows [words] over q0, Coeff form: undo the centered lift in place
-hipError_t launch_plaintext_unlift(uint64_t* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream);
+template <typename W>
+hipError_t launch_plaintext_unlift(W* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream);
 // residue row 0 of every polynomial: [batch][L][N] -> [batch][N]
-hipError_t launch_first_rows(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, size_t batch,
-                             hipStream_t stream);
+template <typename W>
+hipError_t launch_first_rows(const W* in, W* out, const DeviceContext& ctx, size_t batch, hipStream_t stream);
 
 }  // namespace heamd

@@ -190,10 +190,10 @@ __global__ void __launch_bounds__(kThreads)
 // (ciphertext, plaintext) pairs, accumulating in 128 bits (Bfv.swift:476-505).  The ciphertext words are shared by
 // the COLS columns held in registers and, through L2/MALL, by the workgroups of neighbouring columns (blockIdx.x is
 // the column group, so concurrently-resident workgroups read the same ciphertext tile).
-template <int POLYS, int COLS>
+template <int POLYS, int COLS, typename W>
 __global__ void __launch_bounds__(kThreads)
-    inner_product_plain_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
-                               const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
+    inner_product_plain_kernel(const W* __restrict__ cts, const W* __restrict__ pts,
+                               const uint8_t* __restrict__ present, W* __restrict__ out,
                                const DeviceContext ctx, size_t count, size_t columns, uint64_t max_lazy) {
     // One lane = one word of COLS output columns (8-byte streams: the width the copy probe runs fastest at, and half
     // the accumulator registers of a 16-byte lane, so twice the waves hide the latency of the plaintext stream).
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(kThreads)
     }
     // every stream is "uniform base + this lane's word": the uniform part stays in SGPRs.  A column past the end
     // re-reads the last real column (its products are never stored).
-    const uint64_t* ct_base = cts + word;
-    const uint64_t* pt_lane = pts + word;
+    const W* ct_base = cts + word;
+    const W* pt_lane = pts + word;
     size_t pt_column[COLS];  // uniform word offsets of the columns' first plaintexts
 #pragma unroll
     for (int c = 0; c < COLS; ++c) pt_column[c] = (live[c] ? col0 + c : columns - 1) * count * words_per_poly;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int q = 0; q < POLYS; ++q)
             out[((col0 + c) * POLYS + q) * words_per_poly + word] =
-                barrett_reduce128(acc[c][q], m.p, m.barrett128_lo, m.barrett128_hi);
+                static_cast<W>(barrett_reduce128(acc[c][q], m.p, m.barrett128_lo, m.barrett128_hi));
     }
 }
 
@@ -267,10 +267,10 @@ __global__ void __launch_bounds__(kThreads)
 // -- wave-uniform: blockIdx.y covers kThreads words of ONE row (degree >= kThreads).  `cadence` products at most are
 // summed between reductions, chosen by the launcher so that a sum stays below 2^127 (reduce_product_sum's contract)
 // and never exceeds the reference's own lazy count (Bfv.swift:496-500); the canonical result does not depend on it.
-template <int POLYS, int COLS>
+template <int POLYS, int COLS, typename W>
 __global__ void __launch_bounds__(kThreads)
-    inner_product_plain_rows_kernel(const uint64_t* __restrict__ cts, const uint64_t* __restrict__ pts,
-                                    const uint8_t* __restrict__ present, uint64_t* __restrict__ out,
+    inner_product_plain_rows_kernel(const W* __restrict__ cts, const W* __restrict__ pts,
+                                    const uint8_t* __restrict__ present, W* __restrict__ out,
                                     const DeviceContext ctx, size_t count, size_t columns, uint64_t cadence,
                                     uint32_t column_groups) {
     const uint32_t logn = ctx.log_degree;
@@ -295,8 +295,8 @@ __global__ void __launch_bounds__(kThreads)
         since_reduce[c] = 0;
         live[c] = col0 + c < columns;
     }
-    const uint64_t* ct_base = cts + word;
-    const uint64_t* pt_lane = pts + word;
+    const W* ct_base = cts + word;
+    const W* pt_lane = pts + word;
     size_t pt_column[COLS];
 #pragma unroll
     for (int c = 0; c < COLS; ++c) pt_column[c] = (live[c] ? col0 + c : columns - 1) * count * words_per_poly;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(kThreads)
         if (!live[c]) continue;
 #pragma unroll
         for (int q = 0; q < POLYS; ++q)
-            out[((col0 + c) * POLYS + q) * words_per_poly + word] = reduce_product_sum(acc[c][q], m);
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(reduce_product_sum(acc[c][q], m));
     }
 }
 
@@ -393,28 +393,29 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
     return hipGetLastError();
 }
 
-template <int POLYS>
-hipError_t launch_inner_product_plain_polys(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
-                                            uint64_t* out, const DeviceContext& ctx, size_t count, size_t columns,
-                                            uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
+template <int POLYS, typename W>
+hipError_t launch_inner_product_plain_polys(const W* cts, const W* pts, const uint8_t* present_device, W* out,
+                                            const DeviceContext& ctx, size_t count, size_t columns, uint64_t max_lazy,
+                                            uint64_t cadence, hipStream_t stream) {
     constexpr int kCols = 4;
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
     const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
                     static_cast<unsigned>((words_per_poly + kThreads - 1) / kThreads));
     if (ctx.degree >= kThreads && cadence != 0 && static_cast<size_t>(grid.x) * grid.y < (size_t(1) << 31)) {
         // one-dimensional grid: the kernel places the column groups of a word block on one XCD itself
-        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols>), dim3(grid.x * grid.y), dim3(kThreads), 0,
+        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols, W>), dim3(grid.x * grid.y), dim3(kThreads), 0,
                            stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols>), grid, dim3(kThreads), 0, stream, cts, pts,
+    hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols, W>), grid, dim3(kThreads), 0, stream, cts, pts,
                        present_device, out, ctx, count, columns, max_lazy);
     return hipGetLastError();
 }
 
-hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
-                                      uint64_t* out, const DeviceContext& ctx, uint32_t poly_count, size_t count,
-                                      size_t columns, uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
+template <typename W>
+hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t* present_device, W* out,
+                                      const DeviceContext& ctx, uint32_t poly_count, size_t count, size_t columns,
+                                      uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
     if (columns == 0) return hipSuccess;
     switch (poly_count) {
         case 1:
@@ -428,6 +429,40 @@ hipError_t launch_inner_product_plain(const uint64_t* cts, const uint64_t* pts, 
                                                        cadence, stream);
         default: return hipErrorInvalidValue;
     }
+}
+template hipError_t launch_inner_product_plain<uint64_t>(const uint64_t*, const uint64_t*, const uint8_t*, uint64_t*,
+                                                         const DeviceContext&, uint32_t, size_t, size_t, uint64_t,
+                                                         uint64_t, hipStream_t);
+template hipError_t launch_inner_product_plain<uint32_t>(const uint32_t*, const uint32_t*, const uint8_t*, uint32_t*,
+                                                         const DeviceContext&, uint32_t, size_t, size_t, uint64_t,
+                                                         uint64_t, hipStream_t);
+
+// ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words (one word per lane)
+namespace {
+__global__ void __launch_bounds__(kThreads)
+    mul_plain_kernel32(uint32_t* __restrict__ ct, const uint32_t* __restrict__ pt, const DeviceContext ctx,
+                       uint32_t poly_count, size_t words_per_poly, size_t batch) {
+    const size_t total = words_per_poly * batch;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t b = i / words_per_poly, k = i - b * words_per_poly;
+        const DeviceModulus m = ctx.moduli[k >> ctx.log_degree];
+        const uint64_t y = stream_load(pt + i);
+        for (uint32_t c = 0; c < poly_count; ++c) {
+            uint32_t* slot = ct + (b * poly_count + c) * words_per_poly + k;
+            stream_store(slot, barrett_mul(stream_load(slot), y, m.p, m.product_factor, static_cast<int>(m.product_shift)));
+        }
+    }
+}
+}  // namespace
+
+hipError_t launch_mul_plain32(uint32_t* ct, const uint32_t* pt, const DeviceContext& ctx, uint32_t poly_count, size_t batch,
+                              hipStream_t stream) {
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
+    if (words_per_poly * batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(mul_plain_kernel32, dim3(grid_for(words_per_poly * batch)), dim3(kThreads), 0, stream, ct, pt, ctx,
+                       poly_count, words_per_poly, batch);
+    return hipGetLastError();
 }
 
 }  // namespace heamd

@@ -50,9 +50,11 @@ struct LiftLayout {
     size_t polys_per_item, in_item_stride, out_item_stride;
 };
 
-template <int L>
+// W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
+// widened when loaded and narrowed when stored; the arithmetic is the same code for both.
+template <int L, typename W>
 __global__ void __launch_bounds__(kThreads)
-    lift_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool, size_t polys,
+    lift_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys,
                 const LiftLayout layout) {
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
@@ -63,8 +65,8 @@ __global__ void __launch_bounds__(kThreads)
     for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
         const size_t item = poly / layout.polys_per_item, c = poly - item * layout.polys_per_item;
-        const uint64_t* src = in + item * layout.in_item_stride + c * L * n + k;
-        uint64_t* dst = out + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
+        const W* src = in + item * layout.in_item_stride + c * L * n + k;
+        W* dst = out + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
         uint64_t y[L];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -101,16 +103,16 @@ __global__ void __launch_bounds__(kThreads)
 }
 
 // ---- floorQBskToQ: in [polys][2L+1][N] -> out [polys][L][N] ------------------------------------------------------
-template <int L>
+template <int L, typename W>
 __global__ void __launch_bounds__(kThreads)
-    floor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool, size_t polys) {
+    floor_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys) {
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
     for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
-        const uint64_t* src = in + poly * (2 * L + 1) * n + k;
-        uint64_t* dst = out + poly * L * n + k;
+        const W* src = in + poly * (2 * L + 1) * n + k;
+        W* dst = out + poly * L * n + k;
         // approximateFloor (RnsTool.swift:378-398)
         uint64_t y[L];
 #pragma unroll
@@ -170,19 +172,20 @@ __global__ void __launch_bounds__(kThreads)
 }
 
 // ---- scaleAndRound: in [polys][L][N] (Coeff over Q) -> out [polys][N] (mod t)        RnsTool.swift:272-302 ----------
-template <int L>
+template <int L, typename W>
 __global__ void __launch_bounds__(kThreads)
-    scale_and_round_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const RnsToolDevice tool,
+    scale_and_round_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool,
                            const U64x2 final_scale, size_t polys) {
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
     for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
-        const uint64_t* src = in + poly * L * n + k;
+        const W* src = in + poly * L * n + k;
         uint64_t y[L];
 #pragma unroll
-        for (int i = 0; i < L; ++i) y[i] = shoup_mul_pair(src[i * n], tool.scale_round_scale[i], tool.q_moduli[i].p);
+        for (int i = 0; i < L; ++i)
+            y[i] = shoup_mul_pair(stream_load(src + i * n), tool.scale_round_scale[i], tool.q_moduli[i].p);
         uint64_t converted[2];  // (gamma t x) converted to base [t, gamma], times -(Q^-1)          :279-282
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -199,15 +202,16 @@ __global__ void __launch_bounds__(kThreads)
         const bool above = mod_gamma > (gamma >> 1);
         const uint64_t reduced = barrett_reduce64_uniform(above ? gamma - mod_gamma : mod_gamma, t.p, t.barrett64);
         const uint64_t s_gamma = above ? neg_mod_uniform(reduced, t.p) : reduced;
-        out[idx] = shoup_mul_pair(sub_mod_uniform(converted[0], s_gamma, t.p), final_scale, t.p);          // :298-301
+        stream_store(out + idx, shoup_mul_pair(sub_mod_uniform(converted[0], s_gamma, t.p), final_scale, t.p));  // :298-301
     }
 }
 
 // ---- tensor product: (a0, a1) x (b0, b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1), word-wise in Eval form ----------------
 // in: [items][4][rows][N] (a0, a1, b0, b1); out: [items][3][rows][N]
 // blockIdx.y = item * rows + row: the modulus constants are wave-uniform
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    tensor_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx) {
+    tensor_kernel(const W* __restrict__ in, W* __restrict__ out, const DeviceContext ctx) {
     const uint32_t logn = ctx.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t k = blockIdx.x * size_t(kThreads) + threadIdx.x;
@@ -216,21 +220,22 @@ __global__ void __launch_bounds__(kThreads)
     const size_t item = blockIdx.y / ctx.moduli_count;
     const uint32_t row = blockIdx.y - static_cast<uint32_t>(item) * ctx.moduli_count;
     const DeviceModulus m = ctx.moduli[row];
-    const uint64_t* src = in + item * 4 * poly_words + (size_t(row) << logn) + k;
+    const W* src = in + item * 4 * poly_words + (size_t(row) << logn) + k;
     const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
     const int shift = static_cast<int>(m.product_shift);
-    uint64_t* dst = out + item * 3 * poly_words + (size_t(row) << logn) + k;
-    dst[0] = barrett_mul(a0, b0, m.p, m.product_factor, shift);
-    dst[poly_words] = add_mod_uniform(barrett_mul(a0, b1, m.p, m.product_factor, shift),
-                                      barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p);
-    dst[2 * poly_words] = barrett_mul(a1, b1, m.p, m.product_factor, shift);
+    W* dst = out + item * 3 * poly_words + (size_t(row) << logn) + k;
+    dst[0] = static_cast<W>(barrett_mul(a0, b0, m.p, m.product_factor, shift));
+    dst[poly_words] = static_cast<W>(add_mod_uniform(barrett_mul(a0, b1, m.p, m.product_factor, shift),
+                                                     barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p));
+    dst[2 * poly_words] = static_cast<W>(barrett_mul(a1, b1, m.p, m.product_factor, shift));
 }
 
 // ---- lazy tensor accumulation for Bfv.innerProduct(ct, ct) (Bfv.swift:315-361) -----------------------------------
 // in: [count][4][rows][N]; out: [3][rows][N] = reduce(sum_k tensor_k)
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    tensor_accumulate_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
-                             size_t count, uint64_t max_lazy) {
+    tensor_accumulate_kernel(const W* __restrict__ in, W* __restrict__ out, const DeviceContext ctx, size_t count,
+                             uint64_t max_lazy) {
     const uint32_t logn = ctx.log_degree;
     const size_t poly_words = size_t(ctx.moduli_count) << logn;
     for (size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x; w < poly_words; w += size_t(gridDim.x) * kThreads) {
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(kThreads)
         U128 d0{0, 0}, d1{0, 0}, d2{0, 0};
         uint64_t since = 0;
         for (size_t item = 0; item < count; ++item) {
-            const uint64_t* src = in + item * 4 * poly_words + w;
+            const W* src = in + item * 4 * poly_words + w;
             const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
             mac128(d0, a0, b0);
             mac128(d1, a0, b1);
@@ -251,18 +256,19 @@ __global__ void __launch_bounds__(kThreads)
                 d2 = U128{reduce128(d2, m), 0};
             }
         }
-        out[w] = reduce128(d0, m);
-        out[poly_words + w] = reduce128(d1, m);
-        out[2 * poly_words + w] = reduce128(d2, m);
+        out[w] = static_cast<W>(reduce128(d0, m));
+        out[poly_words + w] = static_cast<W>(reduce128(d1, m));
+        out[2 * poly_words + w] = static_cast<W>(reduce128(d2, m));
     }
 }
 
 // ---- key switching, step 1: decompose-and-spread (Bfv+Keys.swift:165-172) ----------------------------------------
 // target: row j of polynomial `poly` at  target_base + poly * target_stride + j * N   (Coeff, mod q_j)
 // out: [polys][L][L+1][N]: word (poly, j, r, k) = target[j][k] mod ks_modulus[r]  (reduced only when q_j > modulus r)
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    key_switch_spread_kernel(const uint64_t* __restrict__ target_base, size_t target_stride,
-                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys) {
+    key_switch_spread_kernel(const W* __restrict__ target_base, size_t target_stride, W* __restrict__ out,
+                             const DeviceContext ks, uint32_t L, size_t polys) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = (polys * L) << logn;
@@ -272,10 +278,10 @@ __global__ void __launch_bounds__(kThreads)
         const size_t poly = pj / L, j = pj - poly * L;
         const uint64_t x = target_base[poly * target_stride + j * n + k];
         const uint64_t qj = ks.moduli[j].p;
-        uint64_t* dst = out + (pj * (L + 1)) * n + k;
+        W* dst = out + (pj * (L + 1)) * n + k;
         for (uint32_t r = 0; r <= L; ++r) {
             const DeviceModulus m = ks.moduli[r];
-            dst[r * n] = qj > m.p ? barrett_reduce64(x, m.p, m.barrett64) : x;
+            dst[r * n] = static_cast<W>(qj > m.p ? barrett_reduce64(x, m.p, m.barrett64) : x);
         }
     }
 }
@@ -285,9 +291,10 @@ __global__ void __launch_bounds__(kThreads)
 //   out[poly][c][r][k] = ( sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] ) mod ks_modulus[r]
 // blockIdx.y = poly * (L+1) + r, so the modulus, the key row and every address base are wave-uniform (SGPRs) and the
 // sums ride the carry-counting product accumulator (device_math.hpp ProductSum: L <= 8 products < 2^127).
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    key_switch_mac_kernel(const uint64_t* __restrict__ spread, const uint64_t* __restrict__ key,
-                          uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, uint32_t top_rows) {
+    key_switch_mac_kernel(const W* __restrict__ spread, const W* __restrict__ key, W* __restrict__ out,
+                          const DeviceContext ks, uint32_t L, uint32_t top_rows) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t k = blockIdx.x * size_t(kThreads) + threadIdx.x;
@@ -297,26 +304,27 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t r = static_cast<uint32_t>(pr - poly * (L + 1));
     const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
     const DeviceModulus m = ks.moduli[r];
-    const uint64_t* __restrict__ x_row = spread + ((poly * L) * (L + 1) + r) * n + k;
-    const uint64_t* __restrict__ key_row0 = key + size_t(key_row) * n + k;
+    const W* __restrict__ x_row = spread + ((poly * L) * (L + 1) + r) * n + k;
+    const W* __restrict__ key_row0 = key + size_t(key_row) * n + k;
     ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
     for (uint32_t j = 0; j < L; ++j) {
         const uint64_t x = x_row[size_t(j) * (L + 1) * n];
-        const uint64_t* key_j = key_row0 + size_t(j) * 2 * top_rows * n;
+        const W* key_j = key_row0 + size_t(j) * 2 * top_rows * n;
         product_sum_add(acc0, x, key_j[0]);
         product_sum_add(acc1, x, key_j[size_t(top_rows) * n]);
     }
-    uint64_t* dst = out + (poly * 2 * (L + 1) + r) * n + k;
-    dst[0] = reduce_product_sum(acc0, m);
-    dst[size_t(L + 1) * n] = reduce_product_sum(acc1, m);
+    W* dst = out + (poly * 2 * (L + 1) + r) * n + k;
+    dst[0] = static_cast<W>(reduce_product_sum(acc0, m));
+    dst[size_t(L + 1) * n] = static_cast<W>(reduce_product_sum(acc1, m));
 }
 
 // ---- key switching, step 4: drop the special modulus and add into the ciphertext (Bfv.swift:216-217) --------------
 // prod: [polys][2][L+1][N] Coeff over (q_0..q_{L-1}, q_ks); ct: poly c of item at ct_base + item*ct_stride + c*L*N;
 // out: [polys][2][L][N] = ct + divideAndRoundQLast(prod)
+template <typename W>
 __global__ void __launch_bounds__(kThreads)
-    key_switch_finish_kernel(const uint64_t* __restrict__ prod, const uint64_t* __restrict__ ct_base, size_t ct_stride,
-                             uint64_t* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
+    key_switch_finish_kernel(const W* __restrict__ prod, const W* __restrict__ ct_base, size_t ct_stride,
+                             W* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
                              uint32_t added_polys) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
@@ -327,9 +335,9 @@ __global__ void __launch_bounds__(kThreads)
         const size_t k = idx & (n - 1);
         const size_t pc = idx >> logn;  // poly * 2 + c
         const size_t poly = pc >> 1, c = pc & 1;
-        const uint64_t* src = prod + pc * (L + 1) * n + k;
-        const uint64_t* ct = ct_base + poly * ct_stride + c * L * n + k;
-        uint64_t* dst = out + pc * L * n + k;
+        const W* src = prod + pc * (L + 1) * n + k;
+        const W* ct = ct_base + poly * ct_stride + c * L * n + k;
+        W* dst = out + pc * L * n + k;
         // divideAndRoundQLast by the centred representative of the special-modulus word (poly_kernels.hip has the
         // derivation): out_i = (x_i - c) q_ks^-1 mod q_i
         const uint64_t r = add_mod_uniform(stream_load(src + size_t(L) * n), q_last_div2, q_last);
@@ -367,19 +375,21 @@ static_assert(kMaxL == 8, "dispatch_L covers 1..8");
 
 template <int L>
 struct LiftLauncher {
-    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
-                          const LiftLayout& layout, hipStream_t s) {
+    template <typename W>
+    static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, const LiftLayout& layout,
+                          hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(lift_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
+        hipLaunchKernelGGL((lift_kernel<L, W>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
                            tool, polys, layout);
         return hipGetLastError();
     }
 };
 template <int L>
 struct FloorLauncher {
-    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
+    template <typename W>
+    static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(floor_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
+        hipLaunchKernelGGL((floor_kernel<L, W>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
                            tool, polys);
         return hipGetLastError();
     }
@@ -387,11 +397,12 @@ struct FloorLauncher {
 
 template <int L>
 struct ScaleAndRoundLauncher {
-    static hipError_t run(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
+    template <typename W>
+    static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
                           hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(scale_and_round_kernel<L>, dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
-                           in, out, tool, final_scale, polys);
+        hipLaunchKernelGGL((scale_and_round_kernel<L, W>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0,
+                           s, in, out, tool, final_scale, polys);
         return hipGetLastError();
     }
 };
@@ -400,21 +411,23 @@ struct ScaleAndRoundLauncher {
 
 uint32_t rns_max_supported_moduli() { return kMaxL; }
 
-hipError_t launch_scale_and_round(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, U64x2 final_scale,
-                                  size_t polys, hipStream_t stream) {
+template <typename W>
+hipError_t launch_scale_and_round(const W* in, W* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
+                                  hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     return dispatch_L<ScaleAndRoundLauncher>(tool.L, in, out, tool, final_scale, polys, stream);
 }
 
-hipError_t launch_lift_q_to_qbsk(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
-                                 hipStream_t stream) {
+template <typename W>
+hipError_t launch_lift_q_to_qbsk(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const size_t n = size_t(1) << tool.log_degree;
     const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n};
     return dispatch_L<LiftLauncher>(tool.L, in, out, tool, polys, layout, stream);
 }
 
-hipError_t launch_lift_q_to_qbsk_strided(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t items,
+template <typename W>
+hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevice& tool, size_t items,
                                          size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
                                          size_t out_offset, hipStream_t stream) {
     if (items == 0 || polys_per_item == 0) return hipSuccess;
@@ -422,21 +435,21 @@ hipError_t launch_lift_q_to_qbsk_strided(const uint64_t* in, uint64_t* out, cons
     return dispatch_L<LiftLauncher>(tool.L, in, out + out_offset, tool, items * polys_per_item, layout, stream);
 }
 
-hipError_t launch_floor_qbsk_to_q(const uint64_t* in, uint64_t* out, const RnsToolDevice& tool, size_t polys,
-                                  hipStream_t stream) {
+template <typename W>
+hipError_t launch_floor_qbsk_to_q(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     return dispatch_L<FloorLauncher>(tool.L, in, out, tool, polys, stream);
 }
 
-hipError_t launch_tensor(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t items,
-                         hipStream_t stream) {
+template <typename W>
+hipError_t launch_tensor(const W* in, W* out, const DeviceContext& qbsk, size_t items, hipStream_t stream) {
     if (items == 0) return hipSuccess;
     const size_t n = size_t(1) << qbsk.log_degree, rows = qbsk.moduli_count;
     const size_t max_items = 65535 / rows;  // grid.y carries (item, row)
     for (size_t done = 0; done < items; done += max_items) {
         const size_t now = items - done < max_items ? items - done : max_items;
-        hipLaunchKernelGGL(tensor_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads),
-                                               static_cast<unsigned>(now * rows)),
+        hipLaunchKernelGGL(tensor_kernel<W>, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads),
+                                                  static_cast<unsigned>(now * rows)),
                            dim3(kThreads), 0, stream, in + done * 4 * rows * n, out + done * 3 * rows * n, qbsk);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -444,24 +457,27 @@ hipError_t launch_tensor(const uint64_t* in, uint64_t* out, const DeviceContext&
     return hipSuccess;
 }
 
-hipError_t launch_tensor_accumulate(const uint64_t* in, uint64_t* out, const DeviceContext& qbsk, size_t count,
-                                    uint64_t max_lazy, hipStream_t stream) {
+template <typename W>
+hipError_t launch_tensor_accumulate(const W* in, W* out, const DeviceContext& qbsk, size_t count, uint64_t max_lazy,
+                                    hipStream_t stream) {
     const size_t total = size_t(qbsk.moduli_count) << qbsk.log_degree;
-    hipLaunchKernelGGL(tensor_accumulate_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk, count,
-                       max_lazy);
+    hipLaunchKernelGGL(tensor_accumulate_kernel<W>, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk,
+                       count, max_lazy);
     return hipGetLastError();
 }
 
-hipError_t launch_key_switch_spread(const uint64_t* target_base, size_t target_stride, uint64_t* out,
-                                    const DeviceContext& ks, uint32_t L, size_t polys, hipStream_t stream) {
+template <typename W>
+hipError_t launch_key_switch_spread(const W* target_base, size_t target_stride, W* out, const DeviceContext& ks,
+                                    uint32_t L, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
-    hipLaunchKernelGGL(key_switch_spread_kernel, dim3(grid_for((polys * L) << ks.log_degree)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(key_switch_spread_kernel<W>, dim3(grid_for((polys * L) << ks.log_degree)), dim3(kThreads), 0,
                        stream, target_base, target_stride, out, ks, L, polys);
     return hipGetLastError();
 }
 
-hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
-                                 uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
+template <typename W>
+hipError_t launch_key_switch_mac(const W* spread, const W* key, W* out, const DeviceContext& ks, uint32_t L,
+                                 uint32_t top_rows, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const size_t n = size_t(1) << ks.log_degree;
     if (L > 8) return hipErrorInvalidValue;  // ProductSum headroom
@@ -469,7 +485,7 @@ hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, ui
     const size_t rows_per_poly = L + 1, max_polys = 65535 / rows_per_poly;
     for (size_t done = 0; done < polys; done += max_polys) {
         const size_t now = polys - done < max_polys ? polys - done : max_polys;
-        hipLaunchKernelGGL(key_switch_mac_kernel,
+        hipLaunchKernelGGL(key_switch_mac_kernel<W>,
                            dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads), static_cast<unsigned>(now * rows_per_poly)),
                            dim3(kThreads), 0, stream, spread + done * L * rows_per_poly * n, key,
                            out + done * 2 * rows_per_poly * n, ks, L, top_rows);
@@ -479,13 +495,32 @@ hipError_t launch_key_switch_mac(const uint64_t* spread, const uint64_t* key, ui
     return hipSuccess;
 }
 
-hipError_t launch_key_switch_finish(const uint64_t* prod, const uint64_t* ct_base, size_t ct_stride, uint64_t* out,
-                                    const DeviceContext& ks, uint32_t L, size_t polys, uint32_t added_polys,
-                                    hipStream_t stream) {
+template <typename W>
+hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
+                                    uint32_t L, size_t polys, uint32_t added_polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
-    hipLaunchKernelGGL(key_switch_finish_kernel, dim3(grid_for((polys * 2) << ks.log_degree)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(key_switch_finish_kernel<W>, dim3(grid_for((polys * 2) << ks.log_degree)), dim3(kThreads), 0,
                        stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys);
     return hipGetLastError();
 }
+
+// the two slab word types of the library: Bfv<UInt64> and Bfv<UInt32>
+#define HEAMD_INSTANTIATE_RNS(W)                                                                                          \
+    template hipError_t launch_scale_and_round<W>(const W*, W*, const RnsToolDevice&, U64x2, size_t, hipStream_t);        \
+    template hipError_t launch_lift_q_to_qbsk<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);                \
+    template hipError_t launch_lift_q_to_qbsk_strided<W>(const W*, W*, const RnsToolDevice&, size_t, size_t, size_t,      \
+                                                         size_t, size_t, hipStream_t);                                    \
+    template hipError_t launch_floor_qbsk_to_q<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);               \
+    template hipError_t launch_tensor<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);                        \
+    template hipError_t launch_tensor_accumulate<W>(const W*, W*, const DeviceContext&, size_t, uint64_t, hipStream_t);   \
+    template hipError_t launch_key_switch_spread<W>(const W*, size_t, W*, const DeviceContext&, uint32_t, size_t,         \
+                                                    hipStream_t);                                                         \
+    template hipError_t launch_key_switch_mac<W>(const W*, const W*, W*, const DeviceContext&, uint32_t, uint32_t,        \
+                                                 size_t, hipStream_t);                                                    \
+    template hipError_t launch_key_switch_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t,       \
+                                                    size_t, uint32_t, hipStream_t);
+HEAMD_INSTANTIATE_RNS(uint64_t)
+HEAMD_INSTANTIATE_RNS(uint32_t)
+#undef HEAMD_INSTANTIATE_RNS
 
 }  // namespace heamd

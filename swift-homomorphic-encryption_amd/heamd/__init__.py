@@ -9,6 +9,7 @@ Names follow the reference (Sources/HomomorphicEncryption): PolyContext.forwardN
 """
 from .binding import (  # noqa: F401
     BfvContext,
+    BfvContext32,
     HeError,
     PolyContext,
     device_count,
@@ -17,7 +18,9 @@ from .binding import (  # noqa: F401
     load_library,
     narrow_u64,
     to_device,
+    to_device32,
     to_host,
+    to_host32,
     version,
     widen_u32,
 )

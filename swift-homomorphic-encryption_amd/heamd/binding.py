@@ -115,6 +115,20 @@ SIGNATURES = [
     ("he_bfv_inner_product_plain_resident_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    # Bfv<UInt32> on packed 4-byte slabs
+    ("he_rns_lift_q_to_qbsk_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_rns_floor_qbsk_to_q_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_rns_scale_and_round_device_u32", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, c_size, vp]),
+    ("he_bfv_mul_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_relinearize_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_apply_galois_device_u32", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
+    ("he_bfv_mod_switch_down_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_mul_plain_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_inner_product_plain_resident_device_u32", ctypes.c_int,
+     [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
+    ("he_bfv_inner_product_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    ("he_bfv_plaintext_to_eval_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_plaintext_to_coeff_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_apply_galois_workspace_bytes", c_size, [vp, c_u32, c_size]),
     ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
     ("he_rns_scale_and_round_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, c_size, vp]),
@@ -227,6 +241,25 @@ def to_device(array, device="cuda"):
 def to_host(tensor):
     """torch int64 tensor -> numpy uint64 array (same words)."""
     return tensor.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def to_device32(array, device="cuda"):
+    """numpy array of values < 2^32 -> torch int32 CUDA tensor holding them as packed UInt32 words."""
+    import torch
+
+    a = np.ascontiguousarray(array, dtype=np.uint64).astype(np.uint32)
+    return torch.from_numpy(a.view(np.int32)).to(device)
+
+
+def to_host32(tensor):
+    """torch int32 tensor of packed UInt32 words -> numpy uint64 array of the values."""
+    return tensor.detach().cpu().contiguous().numpy().view(np.uint32).astype(np.uint64)
+
+
+def _ptr32(tensor):
+    if not tensor.is_cuda or not tensor.is_contiguous() or tensor.element_size() != 4:
+        raise ValueError("expected a contiguous CUDA tensor of 32-bit words (int32 storage)")
+    return vp(tensor.data_ptr())
 
 
 def _ptr(tensor):
@@ -725,4 +758,120 @@ class BfvContext:
         out = self._empty((3, L, self.degree), lhs)
         _check(load_library().he_bfv_inner_product_device(self.h, L, _ptr(lhs), _ptr(rhs), count, _ptr(out), vp(), 0,
                                                           _stream(stream)))
+        return out
+
+
+class BfvContext32(BfvContext):
+    """Context<Bfv<UInt32>> on PACKED [UInt32] slabs (int32 tensors): the `_u32` entry points of include/he_amd.h.
+    Same shapes as BfvContext's methods; nothing is widened in memory."""
+
+    def __init__(self, degree, plaintext_modulus, coefficient_moduli, host_only=False):
+        super().__init__(degree, plaintext_modulus, coefficient_moduli, host_only=host_only, word_bits=32)
+
+    def _empty32(self, shape, like):
+        import torch
+
+        return torch.empty(shape, dtype=torch.int32, device=like.device)
+
+    @staticmethod
+    def _ws(workspace):
+        return (vp(workspace.data_ptr()), workspace.numel() * workspace.element_size()) if workspace is not None else (vp(), 0)
+
+    def lift_q_to_qbsk(self, polys, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = polys.numel() // (L * self.degree)
+        out = self._empty32((batch, 2 * L + 1, self.degree), polys)
+        _check(load_library().he_rns_lift_q_to_qbsk_device_u32(self.h, L, _ptr32(polys), _ptr32(out), batch, _stream(stream)))
+        return out
+
+    def floor_qbsk_to_q(self, polys, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = polys.numel() // ((2 * L + 1) * self.degree)
+        out = self._empty32((batch, L, self.degree), polys)
+        _check(load_library().he_rns_floor_qbsk_to_q_device_u32(self.h, L, _ptr32(polys), _ptr32(out), batch, _stream(stream)))
+        return out
+
+    def scale_and_round(self, poly, scaling_factor=1, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = poly.numel() // (L * self.degree)
+        out = self._empty32((batch, self.degree), poly)
+        _check(load_library().he_rns_scale_and_round_device_u32(self.h, L, _ptr32(poly), int(scaling_factor), _ptr32(out),
+                                                                batch, _stream(stream)))
+        return out
+
+    def mul(self, lhs, rhs, moduli_count=None, stream=None, workspace=None):
+        L = self._L(moduli_count)
+        batch = lhs.numel() // (2 * L * self.degree)
+        out = self._empty32((batch, 3, L, self.degree), lhs)
+        ws_ptr, ws_bytes = self._ws(workspace)
+        _check(load_library().he_bfv_mul_device_u32(self.h, L, _ptr32(lhs), _ptr32(rhs), _ptr32(out), batch, ws_ptr,
+                                                    ws_bytes, _stream(stream)))
+        return out
+
+    def relinearize(self, ct3, key, moduli_count=None, stream=None, workspace=None):
+        L = self._L(moduli_count)
+        batch = ct3.numel() // (3 * L * self.degree)
+        out = self._empty32((batch, 2, L, self.degree), ct3)
+        ws_ptr, ws_bytes = self._ws(workspace)
+        _check(load_library().he_bfv_relinearize_device_u32(self.h, L, _ptr32(ct3), _ptr32(key), _ptr32(out), batch,
+                                                            ws_ptr, ws_bytes, _stream(stream)))
+        return out
+
+    def apply_galois(self, ct, element, key, moduli_count=None, stream=None, workspace=None):
+        L = self._L(moduli_count)
+        batch = ct.numel() // (2 * L * self.degree)
+        out = self._empty32((batch, 2, L, self.degree), ct)
+        ws_ptr, ws_bytes = self._ws(workspace)
+        _check(load_library().he_bfv_apply_galois_device_u32(self.h, L, _ptr32(ct), int(element), _ptr32(key), _ptr32(out),
+                                                             batch, ws_ptr, ws_bytes, _stream(stream)))
+        return out
+
+    def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = ct.numel() // (poly_count * L * self.degree)
+        out = self._empty32((batch, poly_count, L - 1, self.degree), ct)
+        _check(load_library().he_bfv_mod_switch_down_device_u32(self.h, L, poly_count, _ptr32(ct), _ptr32(out), batch,
+                                                                _stream(stream)))
+        return out
+
+    def mul_plain_(self, ct, pt, poly_count, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = pt.numel() // (L * self.degree)
+        _check(load_library().he_bfv_mul_plain_device_u32(self.h, L, poly_count, _ptr32(ct), _ptr32(pt), batch,
+                                                          _stream(stream)))
+        return ct
+
+    def inner_product_plain_resident(self, cts, pts, present_device=None, poly_count=2, columns=1, moduli_count=None,
+                                     stream=None):
+        L = self._L(moduli_count)
+        count = cts.numel() // (poly_count * L * self.degree)
+        out = self._empty32((columns, poly_count, L, self.degree), cts)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_bfv_inner_product_plain_resident_device_u32(self.h, L, poly_count, _ptr32(cts),
+                                                                             _ptr32(pts), mask, count, columns,
+                                                                             _ptr32(out), _stream(stream)))
+        return out
+
+    def inner_product(self, lhs, rhs, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        count = lhs.numel() // (2 * L * self.degree)
+        out = self._empty32((3, L, self.degree), lhs)
+        _check(load_library().he_bfv_inner_product_device_u32(self.h, L, _ptr32(lhs), _ptr32(rhs), count, _ptr32(out), vp(),
+                                                              0, _stream(stream)))
+        return out
+
+    def plaintext_to_eval(self, plaintext, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = plaintext.numel() // self.degree
+        out = self._empty32((batch, L, self.degree), plaintext)
+        _check(load_library().he_bfv_plaintext_to_eval_device_u32(self.h, L, _ptr32(plaintext), _ptr32(out), batch,
+                                                                  _stream(stream)))
+        return out
+
+    def plaintext_to_coeff(self, plaintext_eval, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = plaintext_eval.numel() // (L * self.degree)
+        out = self._empty32((batch, self.degree), plaintext_eval)
+        _check(load_library().he_bfv_plaintext_to_coeff_device_u32(self.h, L, _ptr32(plaintext_eval), _ptr32(out), batch,
+                                                                   _stream(stream)))
         return out

@@ -144,3 +144,13 @@ def test_bfv_context_errors(oracle):
     lib = heamd.load_library()
     status = lib.he_bfv_mul_device(ctx.h, 1, None, None, None, 1, None, 0, None)
     assert heamd.binding.STATUS_NAMES[status] == "deviceError"
+
+
+def test_swift_package_carries_the_same_header():
+    """swift/Sources/CHeAmd/include/he_amd.h is the header the SwiftPM C target exposes; it must be the library's."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "he_amd.h")) as ours, \
+            open(os.path.join(root, "swift", "Sources", "CHeAmd", "include", "he_amd.h")) as copy:
+        assert ours.read() == copy.read(), "run: cp include/he_amd.h swift/Sources/CHeAmd/include/he_amd.h"

@@ -452,3 +452,83 @@ def test_mul_and_relinearize_full_batch_properties(oracle, config3):
     sub = slice(513, 1020)
     again = ours.relinearize(ours.mul(lhs[sub].contiguous(), rhs[sub].contiguous()), key_dev)
     assert torch.equal(again, relin[sub])
+
+
+def test_bfv_uint32_packed_slabs_match_oracle(oracle):
+    """Bfv<UInt32> on packed [UInt32] slabs (he_*_device_u32): no word is widened in memory.  Every scheme operation
+    word for word against the 32-bit oracle -- lift / floor / scaleAndRound at two levels, ct x ct, relinearize,
+    applyGalois, mod-switch, ct x pt, both inner products, plaintext <-> Eval -- and the decrypt checks; the 8-byte
+    path on the same context gives the same words."""
+    import torch
+
+    degree = 64
+    t = oracle.generate_primes([10], True, degree, word_bits=32)[0]
+    q = oracle.generate_primes([27, 28, 28, 29], False, degree, word_bits=32)
+    ours = heamd.BfvContext32(degree, t, q)
+    ref = oracle.BfvContext(degree, t, q, word_bits=32)
+    client = BfvClient(oracle, ref, seed=111)
+    rng = np.random.default_rng(112)
+    moduli = q[:-1]
+    dev, host = heamd.to_device32, heamd.to_host32
+    for level in (ours.L, ours.L - 1):
+        x = _uniform(rng, (4,), moduli[:level], degree)
+        tool = ref.rns_tool(level)
+        assert np.array_equal(host(ours.lift_q_to_qbsk(dev(x), level)), np.stack([tool.lift_q_to_qbsk(p) for p in x]))
+        y = _uniform(rng, (4,), ref.qbsk_context(level).moduli, degree)
+        assert np.array_equal(host(ours.floor_qbsk_to_q(dev(y), level)), np.stack([tool.floor_qbsk_to_q(p) for p in y]))
+        assert np.array_equal(host(ours.scale_and_round(dev(x), 1, moduli_count=level)),
+                              np.stack([tool.scale_and_round(p, 1) for p in x]))
+    r = random.Random(113)
+    m1 = [r.randrange(t) for _ in range(degree)]
+    m2 = [r.randrange(t) for _ in range(degree)]
+    ct1 = np.stack([client.encrypt(m1), client.encrypt(m2)])
+    ct2 = np.stack([client.encrypt(m2), client.encrypt(m2)])
+    product = ours.mul(dev(ct1), dev(ct2))
+    expected_product = ref.mul(ct1, ct2)
+    assert np.array_equal(host(product), expected_product)
+    key = client.relinearization_key()
+    relin = ours.relinearize(product, dev(key))
+    expected_relin = ref.relinearize(expected_product, key)
+    assert np.array_equal(host(relin), expected_relin)
+    assert client.decrypt(host(relin)[0]) == negacyclic_multiply(m1, m2, t)
+    # the 8-byte entry points on zero-extended words agree
+    wide = heamd.BfvContext.relinearize(ours, heamd.BfvContext.mul(ours, heamd.to_device(ct1), heamd.to_device(ct2)),
+                                        heamd.to_device(key))
+    assert np.array_equal(heamd.to_host(wide), expected_relin)
+    # applyGalois
+    element = 3
+    galois_key = client.galois_key(element)
+    rotated = ours.apply_galois(dev(ct1), element, dev(galois_key))
+    assert np.array_equal(host(rotated), ref.apply_galois(ct1, element, galois_key))
+    # mod switch, then a product below the top level
+    lower = ours.mod_switch_down(relin, 2)
+    expected_lower = ref.mod_switch_down(expected_relin, poly_count=2)
+    assert np.array_equal(host(lower), expected_lower)
+    assert client.decrypt(host(lower)[0], moduli_count=ours.L - 1) == negacyclic_multiply(m1, m2, t)
+    assert np.array_equal(host(ours.mul(lower, lower, moduli_count=ours.L - 1)),
+                          ref.mul(expected_lower, expected_lower, moduli_count=ours.L - 1))
+    # plaintexts and ct x pt
+    pts = np.array([[r.randrange(t) for _ in range(degree)] for _ in range(3)], dtype=np.uint64)
+    pt_eval = ours.plaintext_to_eval(dev(pts))
+    expected_eval = ref.plaintext_to_eval(pts)
+    assert np.array_equal(host(pt_eval), expected_eval)
+    assert np.array_equal(host(ours.plaintext_to_coeff(pt_eval)), pts)
+    qctx = ref.ciphertext_context()
+    cts_eval = np.stack([np.stack([qctx.forward_ntt(p[None])[0] for p in client.encrypt(m)]) for m in (m1, m2, m1)])
+    mask = np.array([[1, 0, 1], [1, 1, 1]], dtype=np.uint8)
+    columns = np.stack([expected_eval, expected_eval[::-1].copy()])
+    got = ours.inner_product_plain_resident(dev(cts_eval), dev(columns), torch.from_numpy(mask).cuda(), 2, 2)
+    for c in range(2):
+        assert np.array_equal(host(got)[c], ref.inner_product_plain(cts_eval, columns[c], mask[c]))
+    scaled = dev(cts_eval[:1].copy())
+    ours.mul_plain_(scaled, dev(expected_eval[:1].copy()), 2)
+    assert np.array_equal(host(scaled)[0], ref.inner_product_plain(cts_eval[:1], expected_eval[:1], None))
+    # ct . ct inner product
+    assert np.array_equal(host(ours.inner_product(dev(ct1), dev(ct2))), ref.inner_product(ct1, ct2))
+    # a Bfv<UInt64> context refuses 4-byte slabs
+    wide_q = oracle.generate_primes([40, 40, 41], False, degree)
+    wide_ctx = heamd.BfvContext(degree, oracle.generate_primes([17], True, degree)[0], wide_q)
+    zeros = dev(np.zeros((1, 2 * wide_ctx.L + 1, degree), dtype=np.uint64))
+    status = heamd.load_library().he_rns_lift_q_to_qbsk_device_u32(wide_ctx.h, wide_ctx.L, zeros.data_ptr(),
+                                                                    zeros.data_ptr(), 1, None)
+    assert status == 16  # HE_ERR_INVALID_ARGUMENT
