@@ -59,6 +59,14 @@ def main():
     report("N2", "PirUtil.expand 1 -> 1024 ciphertexts, per output ciphertext", outputs, t, 2 * POLY_BYTES,
            "1023 Galois key switches, level-batched; bytes: the output ciphertexts")
 
+    # the same for 16 queries at once (two clients' keys alternate): every level is one batch over all queries
+    key_sets = [keys, {e: _uniform(torch, Q, (L, 2), DEGREE, 200 + i) for i, e in enumerate(elements)}]
+    batch_queries = _uniform(torch, MODULI, (16, 1, 2), DEGREE, 15)
+    per_query = [key_sets[(i // 4) % 2] for i in range(16)]
+    t16 = _timed(torch, lambda: bfv.pir_expand_batch(batch_queries, outputs, per_query), 3)
+    report("N2", "PirUtil.expand, 16 queries x 1024 outputs in one call, per output ciphertext", 16 * outputs, t16,
+           2 * POLY_BYTES, "%.1f x the single-query rate" % ((16 * outputs / t16) / (outputs / t)))
+
     # ---- N3: wire format and seeded polynomials
     t = _timed(torch, lambda: poly.serialize(slab), 10)
     packed = poly.serialization_byte_count()

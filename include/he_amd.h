@@ -321,6 +321,18 @@ int he_words_narrow_u64_device(const uint64_t* device_in, uint32_t* device_out, 
 int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct,
                                uint64_t element, const uint64_t* galois_key, uint64_t* out, size_t batch,
                                void* workspace, size_t workspace_bytes, he_stream s);
+/* GaloisElement.swappingRows(degree:) and GaloisElement.rotatingColumns(by:degree:) (PolyRq/Galois.swift:174-212): the
+ * elements Bfv.swapRows / Bfv.rotateColumns hand to applyGalois (HeScheme.swift:1047-1094).  step > 0 rotates right,
+ * < 0 left, |step| in [1, N/2 - 1] (else HE_ERR_INVALID_ARGUMENT = invalidRotationStep); degree a power of two. */
+int he_galois_element_swapping_rows(uint64_t degree, uint64_t* out_element);
+int he_galois_element_rotating_columns(int64_t step, uint64_t degree, uint64_t* out_element);
+/* Bfv.applyGalois on a batch whose items belong to different evaluation keys: `groups` runs of `group_size` consecutive
+ * ciphertexts, group g under galois_keys[g] (host array of device pointers, he_bfv_apply_galois_device's key layout).
+ * Workspace as he_bfv_apply_galois_workspace_bytes(ctx, moduli_count, groups * group_size). */
+int he_bfv_apply_galois_grouped_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct,
+                                       uint64_t element, const uint64_t* const* galois_keys, size_t groups,
+                                       size_t group_size, uint64_t* out, void* workspace, size_t workspace_bytes,
+                                       he_stream s);
 size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
 /* _RnsTool.scaleAndRound(poly:scalingFactor:) (RnsTool.swift:272-302), the RNS step of Bfv.decrypt
  * (Bfv/Bfv+Decrypt.swift): in [batch][L][N] Coeff (c0 + c1 s [+ c2 s^2]) -> out [batch][N], values < t.
@@ -396,6 +408,16 @@ int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* di
 int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
                          size_t output_count, const uint64_t* galois_elements, const uint64_t* const* galois_keys,
                          size_t galois_key_count, uint64_t* out, he_stream s);
+/* `queries` independent expansions of one shape in one call (several clients' queries answered together): every tree
+ * level is one batch over all queries, so the first levels -- 1, 2, 4, ... ciphertexts per query -- fill the chip too.
+ *   ciphertexts  [queries][ciphertext_count][2][L][N]      out  [queries][output_count][2][L][N]
+ *   galois_keys  host array [queries][galois_key_count] of device pointers: query q's key of galois_elements[k] at
+ *                [q * galois_key_count + k] (queries of one client repeat the pointer; only the inner product with the
+ *                key is launched per run of equal keys)
+ * he_pir_expand_device is this call with queries = 1. */
+int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t queries,
+                               size_t ciphertext_count, size_t output_count, const uint64_t* galois_elements,
+                               const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out, he_stream s);
 
 /* =====================================================================================================
  * Diagnostics and test hooks (not part of the reference's surface)

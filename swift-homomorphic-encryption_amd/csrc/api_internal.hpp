@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <string>
 
 #include "../../include/he_amd.h"
@@ -26,6 +27,26 @@ inline int invalid_argument(const char* what) {
     return HE_ERR_INVALID_ARGUMENT;
 }
 
+// Stream-ordered scratch comes from the current device's default memory pool.  With the pool's default release
+// threshold (0) every freed block goes back to the driver at the next synchronisation and the next call pays for mapping
+// it again -- seconds for the tens of gigabytes a batched query expansion takes.  The first scratch allocation on a
+// device therefore raises the threshold so that freed scratch stays cached in the pool (what a caller of
+// hipMallocAsync is expected to configure; callers that want fixed memory pass workspaces instead).
+inline void keep_scratch_cached() {
+    static std::atomic<uint64_t> configured{0};  // bit per device ordinal < 64
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return;
+    const uint64_t bit = uint64_t(1) << device;
+    if (configured.load(std::memory_order_relaxed) & bit) return;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr) {
+        uint64_t threshold = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+    }
+    (void)hipGetLastError();
+    configured.fetch_or(bit, std::memory_order_relaxed);
+}
+
 // Stream-ordered scratch buffer (hipMallocAsync / hipFreeAsync on the same stream).
 class Scratch {
   public:
@@ -35,7 +56,10 @@ class Scratch {
     }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
-    hipError_t allocate(size_t bytes) { return hipMallocAsync(&ptr_, bytes ? bytes : 1, stream_); }
+    hipError_t allocate(size_t bytes) {
+        keep_scratch_cached();
+        return hipMallocAsync(&ptr_, bytes ? bytes : 1, stream_);
+    }
     void* get() const { return ptr_; }
 
   private:

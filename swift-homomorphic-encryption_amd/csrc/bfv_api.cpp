@@ -216,6 +216,30 @@ int key_switch_pipeline(const he_bfv_context* ctx, uint32_t L, const W* target, 
     return HE_OK;
 }
 
+// The same with one key per group of `group_size` consecutive items (ciphertexts of different clients in one batch):
+// decomposition and finish run over the whole batch, only the inner product with the key is launched per run of equal
+// keys.
+template <typename W>
+int key_switch_pipeline_grouped(const he_bfv_context* ctx, uint32_t L, const W* target, size_t target_stride,
+                                const W* ct_base, size_t ct_stride, const W* const* keys, size_t groups, size_t group_size,
+                                W* out, uint32_t added_polys, W* spread, W* prod, hipStream_t stream) {
+    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
+    const size_t n = ctx->impl->degree(), batch = groups * group_size;
+    HEAMD_HIP_TRY(spread_to_eval(target, target_stride, spread, *ks_ctx, L, batch, stream));
+    for (size_t g = 0; g < groups;) {
+        size_t run = 1;
+        while (g + run < groups && keys[g + run] == keys[g]) ++run;
+        const size_t first = g * group_size, polys = run * group_size;
+        HEAMD_HIP_TRY(key_mac_to_coeff(static_cast<const W*>(spread) + first * L * (L + 1) * n, keys[g],
+                                       prod + first * 2 * (L + 1) * n, *ks_ctx, L, ctx->impl->top_level() + 1, polys,
+                                       stream));
+        g += run;
+    }
+    HEAMD_HIP_TRY(heamd::launch_key_switch_finish(static_cast<const W*>(prod), ct_base, ct_stride, out,
+                                                  ks_ctx->device_context(), L, batch, added_polys, stream));
+    return HE_OK;
+}
+
 template <typename W>
 int relinearize_pipeline(const he_bfv_context* ctx, uint32_t L, const W* ct3, const W* key, W* out, size_t batch,
                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -371,6 +395,31 @@ uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
 }  // namespace
 }  // extern "C++"
 
+// GaloisElement.swappingRows(degree:) / rotatingColumns(by:degree:) (PolyRq/Galois.swift:174-212): the elements that
+// Bfv.swapRows / rotateColumns pass to applyGalois (HeScheme.swift:1047-1094)
+int he_galois_element_swapping_rows(uint64_t degree, uint64_t* out_element) {
+    if (out_element == nullptr) return invalid_argument("null out");
+    *out_element = (degree << 1) - 1;
+    return HE_OK;
+}
+int he_galois_element_rotating_columns(int64_t step, uint64_t degree, uint64_t* out_element) {
+    if (out_element == nullptr) return invalid_argument("null out");
+    if (degree == 0 || (degree & (degree - 1)) != 0) return HE_ERR_INVALID_DEGREE;
+    uint64_t positive = static_cast<uint64_t>(step < 0 ? -step : step);
+    if (!(positive < (degree >> 1) && positive > 0)) return invalid_argument("rotation step out of range");  // invalidRotationStep
+    positive &= (degree << 1) - 1;
+    if (step > 0) positive = (degree >> 1) - positive;
+    // GaloisElementGenerator.value = 3, to the power `positive` mod 2N
+    const uint64_t modulus = degree << 1;
+    uint64_t result = 1, base = 3 % modulus;
+    for (uint64_t e = positive; e != 0; e >>= 1) {
+        if (e & 1) result = result * base % modulus;
+        base = base * base % modulus;
+    }
+    *out_element = result;
+    return HE_OK;
+}
+
 size_t he_bfv_apply_galois_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch) {
     if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;
     const size_t L = moduli_count, n = ctx->impl->degree();
@@ -419,6 +468,43 @@ int he_bfv_apply_galois_device(const he_bfv_context* ctx, uint32_t moduli_count,
                                const uint64_t* galois_key, uint64_t* out, size_t batch, void* workspace,
                                size_t workspace_bytes, he_stream s) {
     return apply_galois_entry(ctx, moduli_count, ct, element, galois_key, out, batch, workspace, workspace_bytes, s);
+}
+int he_bfv_apply_galois_grouped_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct,
+                                       uint64_t element, const uint64_t* const* galois_keys, size_t groups,
+                                       size_t group_size, uint64_t* out, void* workspace, size_t workspace_bytes,
+                                       he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (galois_keys == nullptr || !ctx->impl->has_key_switching()) {
+        heamd::set_last_error("no Galois key for this element");
+        return HE_ERR_MISSING_GALOIS_KEY;
+    }
+    for (size_t g = 0; g < groups; ++g)
+        if (galois_keys[g] == nullptr) {
+            heamd::set_last_error("no Galois key for this element");
+            return HE_ERR_MISSING_GALOIS_KEY;
+        }
+    if (!is_valid_galois_element(element, ctx->impl->degree())) return invalid_argument("invalid Galois element");
+    const size_t batch = groups * group_size;
+    if (batch == 0) return HE_OK;
+    if (ct == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = moduli_count;
+    const size_t n = ctx->impl->degree();
+    const PolyContext* q_ctx = ctx->impl->ciphertext(L);
+    Scratch scratch(stream);
+    uint64_t* ws = nullptr;
+    status = resolve_workspace(workspace, workspace_bytes, he_bfv_apply_galois_workspace_bytes(ctx, L, batch), scratch, &ws);
+    if (status != HE_OK) return status;
+    uint64_t* rotated = ws;                                     // [batch][2][L][N]
+    uint64_t* spread = rotated + batch * 2 * L * n;             // [batch][L][L+1][N]
+    uint64_t* prod = spread + batch * L * (L + 1) * n;          // [batch][2][L+1][N]
+    const size_t ct_stride = 2 * size_t(L) * n;
+    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
+                                             inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
+    return key_switch_pipeline_grouped<uint64_t>(ctx, L, rotated + size_t(L) * n, ct_stride, rotated, ct_stride,
+                                                 galois_keys, groups, group_size, out, 1, spread, prod, stream);
 }
 int he_bfv_apply_galois_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* ct, uint64_t element,
                                    const uint32_t* galois_key, uint32_t* out, size_t batch, void* workspace,

@@ -140,18 +140,21 @@ __global__ void __launch_bounds__(kThreads)
 
 // table entry k = (source ciphertext index, destination index << 1 | doubled): dst[destination] = src[source], times
 // two when `doubled` (a leaf above its tree's height is emitted as ciphertext + ciphertext, PirUtil.swift:262-268)
+// The same table serves `queries` independent expansions of one shape: query q reads src + q * src_stride ciphertexts
+// and writes dst + q * dst_stride ciphertexts (strides in ciphertexts).
 __global__ void __launch_bounds__(kThreads)
     expand_move_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, const uint32_t* __restrict__ table,
-                       const DeviceContext ctx, size_t words) {
+                       const DeviceContext ctx, size_t count, size_t src_stride, size_t dst_stride, size_t words) {
     const uint32_t logn = ctx.log_degree;
     const size_t ct_words = (size_t(2) * ctx.moduli_count) << logn;
     for (size_t idx = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; idx < words;
          idx += static_cast<size_t>(gridDim.x) * kThreads) {
-        const size_t k = idx / ct_words, w = idx - k * ct_words;
+        const size_t item = idx / ct_words, w = idx - item * ct_words;
+        const size_t query = item / count, k = item - query * count;
         const uint32_t source = table[2 * k], packed = table[2 * k + 1];
-        const uint64_t x = src[source * ct_words + w];
+        const uint64_t x = src[(query * src_stride + source) * ct_words + w];
         const uint64_t p = ctx.moduli[(w >> logn) % ctx.moduli_count].p;
-        dst[static_cast<size_t>(packed >> 1) * ct_words + w] = (packed & 1u) ? add_mod(x, x, p) : x;
+        dst[(query * dst_stride + static_cast<size_t>(packed >> 1)) * ct_words + w] = (packed & 1u) ? add_mod(x, x, p) : x;
     }
 }
 
@@ -167,11 +170,11 @@ hipError_t launch_expand_step(const uint64_t* parents, const uint64_t* c1, uint6
 }
 
 hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t* table, const DeviceContext& ctx,
-                              size_t count, hipStream_t stream) {
-    const size_t words = (count * 2 * ctx.moduli_count) << ctx.log_degree;
+                              size_t count, size_t queries, size_t src_stride, size_t dst_stride, hipStream_t stream) {
+    const size_t words = (queries * count * 2 * ctx.moduli_count) << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_move_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, src, dst, table, ctx,
-                       words);
+    hipLaunchKernelGGL(expand_move_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, src, dst, table, ctx, count,
+                       src_stride, dst_stride, words);
     return hipGetLastError();
 }
 

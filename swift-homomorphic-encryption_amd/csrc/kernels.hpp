@@ -114,8 +114,9 @@ hipError_t launch_galois_eval(const uint64_t* in, uint64_t* out, const DeviceCon
 hipError_t launch_expand_step(const uint64_t* parents, const uint64_t* c1, uint64_t* next, const DeviceContext& ctx,
                               uint32_t shift, size_t batch, hipStream_t stream);
 // dst[table[2k+1] >> 1] = src[table[2k]] (doubled mod q when table[2k+1] & 1), whole ciphertexts [2][L][N]
+// for `queries` expansions of one shape: query q moves src + q * src_stride -> dst + q * dst_stride (in ciphertexts)
 hipError_t launch_expand_move(const uint64_t* src, uint64_t* dst, const uint32_t* table, const DeviceContext& ctx,
-                              size_t count, hipStream_t stream);
+                              size_t count, size_t queries, size_t src_stride, size_t dst_stride, hipStream_t stream);
 hipError_t launch_multiply_power_of_x(const uint64_t* in, uint64_t* out, const DeviceContext& ctx, uint32_t shift,
                                       size_t rows, hipStream_t stream);
 // plaintext [batch][N] mod t -> centered lift into every row of [batch][L][N] (L = ctx.moduli_count)

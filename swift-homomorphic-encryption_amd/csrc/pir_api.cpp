@@ -257,11 +257,13 @@ void leaf_order(const std::vector<std::vector<ExpandNode>>& levels, size_t depth
 
 }  // namespace
 
-extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
-                                    size_t output_count, const uint64_t* galois_elements,
-                                    const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out,
-                                    he_stream s) {
+extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t queries,
+                                          size_t ciphertext_count, size_t output_count, const uint64_t* galois_elements,
+                                          const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out,
+                                          he_stream s) {
     if (ctx == nullptr) return invalid_argument("null context");
+    if (queries == 0) return HE_OK;
+
     const uint32_t L = he_bfv_ciphertext_moduli_count(ctx);
     const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
     if (q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
@@ -354,12 +356,13 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
                                      hipMemcpyHostToDevice, stream));
         HEAMD_HIP_TRY(hipStreamSynchronize(stream));
     }
-    const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, (widest + 1) / 2);
-    HEAMD_HIP_TRY(cur_mem.allocate(widest * ct_bytes));
-    HEAMD_HIP_TRY(next_mem.allocate(widest * ct_bytes));
-    HEAMD_HIP_TRY(parent_mem.allocate(widest * ct_bytes));
-    HEAMD_HIP_TRY(rotated_mem.allocate(widest * ct_bytes));
-    HEAMD_HIP_TRY(tmp_mem.allocate(widest * ct_bytes));
+    // every level runs over all queries at once: buffers hold [query][node of the level]
+    const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, queries * ((widest + 1) / 2));
+    HEAMD_HIP_TRY(cur_mem.allocate(queries * widest * ct_bytes));
+    HEAMD_HIP_TRY(next_mem.allocate(queries * widest * ct_bytes));
+    HEAMD_HIP_TRY(parent_mem.allocate(queries * widest * ct_bytes));
+    HEAMD_HIP_TRY(rotated_mem.allocate(queries * widest * ct_bytes));
+    HEAMD_HIP_TRY(tmp_mem.allocate(queries * widest * ct_bytes));
     HEAMD_HIP_TRY(workspace_mem.allocate(workspace_bytes));
     const uint64_t* cur = ciphertexts;  // level 0 reads the caller's ciphertexts in place
     uint64_t* buffers[2] = {static_cast<uint64_t*>(cur_mem.get()), static_cast<uint64_t*>(next_mem.get())};
@@ -367,14 +370,17 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
     uint64_t* rotated = static_cast<uint64_t*>(rotated_mem.get());
     uint64_t* tmp = static_cast<uint64_t*>(tmp_mem.get());
 
-    // ---- execute: every stage of a level is one launch over all nodes of all trees at that depth
+    // ---- execute: every stage of a level is one launch over all nodes of all trees of all queries at that depth
+    // (the inner product with the Galois key alone runs per run of queries that share a key)
     int status = HE_OK;
+    std::vector<const uint64_t*> level_keys(queries);
     for (size_t depth = 0; depth < levels.size() && status == HE_OK; ++depth) {
         const int log_step = static_cast<int>(depth) + 1;
         const LevelMoves& m = moves[depth];
+        const size_t level_nodes = levels[depth].size();
         if (m.leaf_count != 0)
-            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, out, table_device + m.leaf_offset, q_device, m.leaf_count,
-                                                    stream));
+            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, out, table_device + m.leaf_offset, q_device, m.leaf_count, queries,
+                                                    level_nodes, output_count, stream));
         if (m.parent_count == 0) continue;
         if (log_step > log_degree) {  // precondition, PirUtil.swift:212
             status = invalid_argument("logStep exceeds log2(degree)");
@@ -383,8 +389,8 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
         const size_t batch = m.parent_count;
         const uint64_t* parents = cur;
         if (m.gather) {
-            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, gathered, table_device + m.parent_offset, q_device, batch,
-                                                    stream));
+            HEAMD_HIP_TRY(heamd::launch_expand_move(cur, gathered, table_device + m.parent_offset, q_device, batch, queries,
+                                                    level_nodes, batch, stream));
             parents = gathered;
         }
         // expandCiphertextForOneStep (PirUtil.swift:204-236)
@@ -393,7 +399,12 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
         for (size_t k = 0; k < galois_key_count; ++k)
             if (galois_elements[k] <= target && (best < 0 || galois_elements[k] > galois_elements[best]))
                 best = static_cast<long>(k);
-        if (best < 0 || galois_keys[best] == nullptr) {
+        bool have_keys = best >= 0;
+        for (size_t q = 0; have_keys && q < queries; ++q) {
+            level_keys[q] = galois_keys[q * galois_key_count + static_cast<size_t>(best)];
+            have_keys = level_keys[q] != nullptr;
+        }
+        if (!have_keys) {
             heamd::set_last_error("no Galois element <= " + std::to_string(target) + " in the evaluation key");
             status = HE_ERR_MISSING_GALOIS_KEY;
             break;
@@ -403,17 +414,25 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
         const uint64_t* c1 = parents;
         for (int a = 0; a < applications && status == HE_OK; ++a) {  // applyGalois(element) until x -> x^target
             uint64_t* dst = (a % 2 == 0) ? rotated : tmp;
-            status = he_bfv_apply_galois_device(ctx, L, c1, element, galois_keys[best], dst, batch, workspace_mem.get(),
-                                                workspace_bytes, s);
+            status = he_bfv_apply_galois_grouped_device(ctx, L, c1, element, level_keys.data(), queries, batch, dst,
+                                                        workspace_mem.get(), workspace_bytes, s);
             c1 = dst;
         }
         if (status != HE_OK) break;
         // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
         const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
         uint64_t* next = buffers[depth % 2];
-        HEAMD_HIP_TRY(heamd::launch_expand_step(parents, c1, next, q_device, shift, batch, stream));
+        HEAMD_HIP_TRY(heamd::launch_expand_step(parents, c1, next, q_device, shift, queries * batch, stream));
         cur = next;
     }
     if (status != HE_OK) return status;
     return HE_OK;
+}
+
+extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
+                                    size_t output_count, const uint64_t* galois_elements,
+                                    const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out,
+                                    he_stream s) {
+    return he_pir_expand_batch_device(ctx, ciphertexts, 1, ciphertext_count, output_count, galois_elements, galois_keys,
+                                      galois_key_count, out, s);
 }

@@ -13,6 +13,8 @@ from .binding import (  # noqa: F401
     HeError,
     PolyContext,
     device_count,
+    galois_element_rotating_columns,
+    galois_element_swapping_rows,
     generate_primes,
     library_path,
     load_library,

@@ -129,6 +129,8 @@ SIGNATURES = [
     ("he_bfv_inner_product_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_eval_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_coeff_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
+    ("he_galois_element_swapping_rows", ctypes.c_int, [c_u64, U64P]),
+    ("he_galois_element_rotating_columns", ctypes.c_int, [ctypes.c_int64, c_u64, U64P]),
     ("he_bfv_apply_galois_workspace_bytes", c_size, [vp, c_u32, c_size]),
     ("he_bfv_apply_galois_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
     ("he_rns_scale_and_round_device", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, c_size, vp]),
@@ -141,6 +143,10 @@ SIGNATURES = [
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, vp]),
     ("he_pir_compute_response_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
+    ("he_pir_expand_batch_device", ctypes.c_int,
+     [vp, vp, c_size, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp]),
+    ("he_bfv_apply_galois_grouped_device", ctypes.c_int,
+     [vp, c_u32, vp, c_u64, ctypes.POINTER(vp), c_size, c_size, vp, vp, c_size, vp]),
     ("he_pir_expand_device", ctypes.c_int,
      [vp, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp]),
     # diagnostics / test hooks
@@ -216,6 +222,18 @@ def narrow_u64(slab64, stream=None):
     _check(load_library().he_words_narrow_u64_device(vp(slab64.data_ptr()), vp(out.data_ptr()), slab64.numel(),
                                                      _stream(stream)))
     return out
+
+
+def galois_element_swapping_rows(degree):
+    out = ctypes.c_uint64(0)
+    _check(load_library().he_galois_element_swapping_rows(degree, ctypes.byref(out)))
+    return out.value
+
+
+def galois_element_rotating_columns(step, degree):
+    out = ctypes.c_uint64(0)
+    _check(load_library().he_galois_element_rotating_columns(step, degree, ctypes.byref(out)))
+    return out.value
 
 
 def generate_primes(bit_counts, preferring_small, ntt_degree=1):
@@ -656,6 +674,21 @@ class BfvContext:
         _check(load_library().he_pir_expand_device(self.h, _ptr(ciphertexts), count, output_count,
                                                    element_array.ctypes.data_as(U64P), key_array, len(elements),
                                                    _ptr(out), _stream(stream)))
+        return out
+
+    def pir_expand_batch(self, ciphertexts, output_count, galois_keys_per_query, stream=None):
+        """`queries` expansions of one shape: ciphertexts [queries][count][2][L][N]; galois_keys_per_query: one
+        {element: key tensor} dict per query (the same elements in each) -> [queries][output_count][2][L][N]."""
+        queries = len(galois_keys_per_query)
+        count = ciphertexts.numel() // (queries * 2 * self.L * self.degree)
+        out = self._empty((queries, output_count, 2, self.L, self.degree), ciphertexts)
+        elements = sorted(galois_keys_per_query[0])
+        element_array = _u64(elements)
+        pointers = [vp(keys[e].data_ptr()) for keys in galois_keys_per_query for e in elements]
+        key_array = (vp * max(len(pointers), 1))(*pointers)
+        _check(load_library().he_pir_expand_batch_device(self.h, _ptr(ciphertexts), queries, count, output_count,
+                                                         element_array.ctypes.data_as(U64P), key_array, len(elements),
+                                                         _ptr(out), _stream(stream)))
         return out
 
     def pir_compute_response_chunk(self, dimensions, dim0_query_eval, remaining_query, database, present=None,

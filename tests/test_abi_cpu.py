@@ -154,3 +154,29 @@ def test_swift_package_carries_the_same_header():
     with open(os.path.join(root, "include", "he_amd.h")) as ours, \
             open(os.path.join(root, "swift", "Sources", "CHeAmd", "include", "he_amd.h")) as copy:
         assert ours.read() == copy.read(), "run: cp include/he_amd.h swift/Sources/CHeAmd/include/he_amd.h"
+
+
+def test_galois_element_helpers():
+    """GaloisElement.rotatingColumns / swappingRows (PolyRq/Galois.swift:174-212) with the reference's own vectors
+    (GaloisTests.swift:103-109: degree 8, elements 3, 9, 11 are right rotations by 3, 2, 1) and its round-trip property
+    (:77-85: a rotation by s composed with one by N/2 - s is the identity, i.e. the elements multiply to 1 mod 2N)."""
+    import heamd
+
+    assert heamd.galois_element_swapping_rows(8) == 15 and heamd.galois_element_swapping_rows(8192) == 16383
+    assert [heamd.galois_element_rotating_columns(s, 8) for s in (3, 2, 1)] == [3, 9, 11]
+    for degree in (16, 32, 1024, 8192):
+        seen = set()
+        for step in range(1, degree // 2):
+            forward = heamd.galois_element_rotating_columns(step, degree)
+            backward = heamd.galois_element_rotating_columns(degree // 2 - step, degree)
+            assert forward % 2 == 1 and forward * backward % (2 * degree) == 1
+            assert heamd.galois_element_rotating_columns(-step, degree) == backward  # left by s = right by N/2 - s
+            seen.add(forward)
+        assert len(seen) == degree // 2 - 1
+    for bad_step, degree in ((0, 8), (4, 8), (-4, 8), (1, 2)):
+        with pytest.raises(heamd.HeError) as err:
+            heamd.galois_element_rotating_columns(bad_step, degree)
+        assert err.value.name == "invalidArgument"
+    with pytest.raises(heamd.HeError) as err:
+        heamd.galois_element_rotating_columns(1, 12)
+    assert err.value.name == "invalidDegree"

@@ -256,3 +256,26 @@ def test_column_shard_at_the_benchmark_row_count(oracle):
         c, poly, r, k = rng.randrange(columns), rng.randrange(2), rng.randrange(len(moduli)), rng.randrange(degree)
         want = sum(int(host_cts[j, poly, r, k]) * int(host_pts[c, j, r, k]) for j in range(d0)) % moduli[r]
         assert int(host_out[c, poly, r, k]) == want
+
+
+@pytest.mark.parametrize("total", [8, 13, 1])
+def test_pir_expand_batch_of_queries_from_two_clients(oracle, small, total):
+    """he_pir_expand_batch_device: four queries of one shape expanded level by level together -- queries 0, 1 under one
+    client's Galois keys, 2, 3 under another's -- each query's outputs word for word the oracle's expand under its own
+    keys (ragged totals put leaves on two levels, which exercises the per-query strides of the leaf / parent moves)."""
+    ours, ref, client = small
+    other = BfvClient(oracle, ref, seed=161)
+    n = ref.degree
+    shifts = list(range(0, max((total - 1).bit_length(), 1)))
+    clients = [client, client, other, other]
+    key_sets = {id(c): {(n >> k) + 1: c.galois_key((n >> k) + 1) for k in shifts} for c in (client, other)}
+    device_sets = {cid: {e: heamd.to_device(k) for e, k in keys.items()} for cid, keys in key_sets.items()}
+    ones = [[0], [total - 1], [total // 2], [0, total - 1] if total > 1 else [0]]
+    queries = np.stack([c.encrypt(_compressed_query(ref, total, o))[None] for c, o in zip(clients, ones)])
+    got = heamd.to_host(ours.pir_expand_batch(heamd.to_device(queries), total, [device_sets[id(c)] for c in clients]))
+    assert got.shape == (4, total, 2, ref.L, n)
+    for q, (c, o) in enumerate(zip(clients, ones)):
+        expected = oracle.pir.expand(ref, queries[q], total, key_sets[id(c)])
+        assert np.array_equal(got[q], expected), q
+        for index in range(total):
+            assert c.decrypt(got[q, index]) == [1 if index in o else 0] + [0] * (n - 1), (q, index)
