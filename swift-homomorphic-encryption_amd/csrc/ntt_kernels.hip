@@ -18,6 +18,8 @@
 //     butterflies with a 3- or 4-multiply quotient for moduli up to 2^61 / 2^62.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_context.hpp"
 #include "device_math.hpp"
 #include "kernels.hpp"
@@ -234,15 +236,19 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
-    static_assert(ROWS == 1 || (SPREAD == kSourceSlab && S::P >= 2), "row pairs: plain slabs through the LDS tile");
+    static_assert(ROWS == 1 || S::P >= 2, "row groups go through the LDS tile");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
     if constexpr (SPREAD != kSourceSlab) {
-        // the band_rows output rows of a record are transforms of one source row: one replica set per record
-        locate_replica(blockIdx.x, gridDim.x / map.band_rows, map.band_rows, record, within);
-        rows[0] = size_t(record) * map.band_rows + within;
+        // the band_rows output rows of a record are transforms of one source row: one replica set per group of ROWS
+        // consecutive records (a workgroup transforms the same band row of each of them)
+        uint32_t group;
+        locate_replica(blockIdx.x, gridDim.x / map.band_rows, map.band_rows, group, within);
+        record = map.record_base + group * ROWS;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) rows[k] = size_t(record + k) * map.band_rows + within;
     } else {
         locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
     }
@@ -263,18 +269,33 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         constexpr int LO0 = LOGN - LOGE;
         HEAMD_X_PROLOGUE();
         if constexpr (SPREAD != kSourceSlab) {
-            const size_t poly = record / spread.L, j = record - poly * spread.L;  // record = poly * L + j
-            global_load<LOGN, LOGE, LO0, LOGE, 0>(  // cached: the other rows of this record read the same words
-                v[0], tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
+            bool reduce[ROWS];  // uniform: the source row is canonical mod a larger modulus than this row's
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const size_t poly = (record + k) / spread.L, j = (record + k) - poly * spread.L;  // record = poly * L + j
+                global_load<LOGN, LOGE, LO0, LOGE, 0>(  // cached: the other rows of this record read the same words
+                    v[k], tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
+                // the split butterflies take any 64-bit multiplicand and have room for an addend below 2p, so they
+                // transform a residue below 2p as it is
+                reduce[k] = SPREAD == kSourceSpread && ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p);
+            }
             if constexpr (SPREAD == kSourceLift) {
                 const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
 #pragma unroll
-                for (int r = 0; r < E; ++r) v[0][r] = v[0][r] < threshold ? v[0][r] : v[0][r] + increment;
-            } else if (ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p)) {
-                // uniform: the source row is canonical mod q_j, not mod this row's modulus (the split butterflies take
-                // any 64-bit multiplicand and have room for an addend below 2p, so they transform such a residue as it is)
+                for (int k = 0; k < ROWS; ++k)
 #pragma unroll
-                for (int r = 0; r < E; ++r) v[0][r] = barrett_reduce64_uniform(v[0][r], p, mod.barrett64);
+                    for (int r = 0; r < E; ++r) v[k][r] = v[k][r] < threshold ? v[k][r] : v[k][r] + increment;
+            } else {
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k) any |= reduce[k];
+                if (any) {  // rare (moduli of very different sizes): kept out of the straight-line path
+#pragma unroll
+                    for (int k = 0; k < ROWS; ++k)
+#pragma unroll
+                        for (int r = 0; r < E; ++r)
+                            v[k][r] = reduce[k] ? barrett_reduce64_uniform(v[k][r], p, mod.barrett64) : v[k][r];
+                }
             }
         } else {
 #pragma unroll
@@ -310,7 +331,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr bool TENSOR = SOURCE == kInverseFromTensor;
     constexpr bool SCALED = SOURCE == kInverseFromTensor || SOURCE == kInverseFromSlabScaled;
     constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
-    static_assert(ROWS == 1 || SOURCE == kInverseFromSlab, "row pairs: plain slabs");
+    static_assert(ROWS == 1 || SOURCE != kInverseFromSlabScaled, "scaled plain slabs go one row per workgroup");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
@@ -321,13 +342,16 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     uint32_t record, within;
     size_t rows[ROWS];
     if constexpr (!FROM_SLAB) {
-        // records (item, c) of one item read the same source rows: one replica set per (item, band row)
+        // records (item, c) of one item read the same source rows: one replica set per (group of ROWS consecutive
+        // items, band row); the workgroup transforms record (item + k, c) for k < ROWS
         constexpr uint32_t REPLICAS = TENSOR ? 3 : 2;
-        uint32_t set, c, item;
+        uint32_t set, c, group;
         locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, c);
-        locate(map, set, item, within);
-        record = item * REPLICAS + c;
-        rows[0] = size_t(record) * map.record_rows + map.band_offset + within;
+        locate(map, set, group, within);
+        record = (map.record_base + group * ROWS) * REPLICAS + c;  // of the first item; record_base counts items here
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            rows[k] = size_t(record + k * REPLICAS) * map.record_rows + map.band_offset + within;
     } else {
         locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
     }
@@ -345,59 +369,65 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
         if constexpr (TENSOR) {
-            const size_t item = record / 3;
-            const uint32_t c = static_cast<uint32_t>(record - item * 3);  // wave-uniform
+            const size_t first_item = record / 3;
+            const uint32_t c = static_cast<uint32_t>(record - first_item * 3);  // wave-uniform
             const size_t poly_words = static_cast<size_t>(map.record_rows) << LOGN;
-            const uint64_t* const source =
-                tensor_source + item * 4 * poly_words + (static_cast<size_t>(map.band_offset + within) << LOGN);
             const uint64_t p = mod.p, factor = mod.product_factor;
             const int shift = static_cast<int>(mod.product_shift);
             const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
 #pragma unroll
-            for (int r = 0; r < E; r += 2) {
-                const size_t at = register_part<LOGN, LOGE, 0, S::R>(r) + lane_words;
-                if (c != 1) {
-                    const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
-                    const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
-                    v[0][r] = barrett_mul(a.x, b.x, p, factor, shift);
-                    v[0][r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
-                } else {
-                    const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
-                    const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
-                    const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
-                    const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
-                    // a0 b1 + a1 b0 as one exact 128-bit sum and one reduction (two products < 2^125)
-                    ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
-                    product_sum_add(cross0, a1.x, b0.x);
-                    product_sum_add(cross1, a1.y, b0.y);
-                    v[0][r] = reduce_product_sum(cross0, mod);
-                    v[0][r + 1] = reduce_product_sum(cross1, mod);
+            for (int k = 0; k < ROWS; ++k) {
+                const uint64_t* const source = tensor_source + (first_item + k) * 4 * poly_words +
+                                               (static_cast<size_t>(map.band_offset + within) << LOGN);
+#pragma unroll
+                for (int r = 0; r < E; r += 2) {
+                    const size_t at = register_part<LOGN, LOGE, 0, S::R>(r) + lane_words;
+                    if (c != 1) {
+                        const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
+                        const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
+                        v[k][r] = barrett_mul(a.x, b.x, p, factor, shift);
+                        v[k][r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
+                    } else {
+                        const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
+                        const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
+                        const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
+                        const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
+                        // a0 b1 + a1 b0 as one exact 128-bit sum and one reduction (two products < 2^125)
+                        ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
+                        product_sum_add(cross0, a1.x, b0.x);
+                        product_sum_add(cross1, a1.y, b0.y);
+                        v[k][r] = reduce_product_sum(cross0, mod);
+                        v[k][r + 1] = reduce_product_sum(cross1, mod);
+                    }
                 }
             }
         } else if constexpr (SOURCE == kInverseFromKeyMac) {
-            const size_t poly = record >> 1, c = record & 1;  // record = poly * 2 + c
+            const size_t first_poly = record >> 1, c = record & 1;  // record = poly * 2 + c
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
             const uint32_t r = map.band_offset + within;
             const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
             const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
-            const uint64_t* const spread_row =
-                source_spec.first + ((poly * L * (L + 1) + r) << LOGN) + lane_words;            // + j (L+1) N
             const uint64_t* const key_rows =
                 source_spec.second + ((c * top_rows + key_row) << LOGN) + lane_words;           // + j 2 top_rows N
 #pragma unroll
-            for (int q = 0; q < E; q += 2) {
-                const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
-                const U64x2 x0 = *reinterpret_cast<const U64x2*>(spread_row + at);
-                const U64x2 k0 = *reinterpret_cast<const U64x2*>(key_rows + at);
-                ProductSum acc0 = product_sum_first(x0.x, k0.x), acc1 = product_sum_first(x0.y, k0.y);
-                for (uint32_t j = 1; j < L; ++j) {
-                    const U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(j) * (L + 1)) << LOGN) + at);
-                    const U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(j) * 2 * top_rows) << LOGN) + at);
-                    product_sum_add(acc0, xs.x, ks.x);
-                    product_sum_add(acc1, xs.y, ks.y);
+            for (int k = 0; k < ROWS; ++k) {
+                const uint64_t* const spread_row =
+                    source_spec.first + (((first_poly + k) * L * (L + 1) + r) << LOGN) + lane_words;  // + j (L+1) N
+#pragma unroll
+                for (int q = 0; q < E; q += 2) {
+                    const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
+                    const U64x2 x0 = *reinterpret_cast<const U64x2*>(spread_row + at);
+                    const U64x2 k0 = *reinterpret_cast<const U64x2*>(key_rows + at);
+                    ProductSum acc0 = product_sum_first(x0.x, k0.x), acc1 = product_sum_first(x0.y, k0.y);
+                    for (uint32_t j = 1; j < L; ++j) {
+                        const U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(j) * (L + 1)) << LOGN) + at);
+                        const U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(j) * 2 * top_rows) << LOGN) + at);
+                        product_sum_add(acc0, xs.x, ks.x);
+                        product_sum_add(acc1, xs.y, ks.y);
+                    }
+                    v[k][q] = reduce_product_sum(acc0, mod);
+                    v[k][q + 1] = reduce_product_sum(acc1, mod);
                 }
-                v[0][q] = reduce_product_sum(acc0, mod);
-                v[0][q + 1] = reduce_product_sum(acc1, mod);
             }
         } else {
             [[maybe_unused]] const uint64_t p = mod.p;
@@ -510,6 +540,22 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 template <int LOGN, int LOGT>
 constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? HEAMD_X_ROWS : 1;
 
+// Rows per workgroup of the fused-load inverse kernels.  Their loads hold far more registers than a plain row load (the
+// key MAC's carry-counting sums, the tensor's four operand streams), so a second row spills: measured on ct x ct +
+// relinearize (profiles/r02i_c3_fused_row_groups.txt), two rows lose 6 % on the key MAC (104 bytes of scratch per lane)
+// and gain nothing on the tensor load -- one row each.  (The fused FORWARD loads -- spread, lift -- are plain row loads
+// and do run two rows per workgroup: relinearize +7 %, convertToEvalFormat +21 %.)
+#ifndef HEAMD_X_TENSOR_ROWS
+#define HEAMD_X_TENSOR_ROWS 1
+#endif
+#ifndef HEAMD_X_KEYMAC_ROWS
+#define HEAMD_X_KEYMAC_ROWS 1
+#endif
+template <int LOGN, int LOGT>
+constexpr int kTensorRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? HEAMD_X_TENSOR_ROWS : 1;
+template <int LOGN, int LOGT>
+constexpr int kKeyMacRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? HEAMD_X_KEYMAC_ROWS : 1;
+
 template <int LOGN, int LOGT, int SPREAD, int ROWS>
 hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
                                  const SpreadSource& spread, hipStream_t stream) {
@@ -530,7 +576,7 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
     size_t paired_records = 0;  // records covered by the launch of row groups
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
-    if constexpr (SPREAD == kSourceSlab && GROUP > 1) {
+    if constexpr (GROUP > 1) {
         paired_records = (rows / mod_period) / GROUP * GROUP;
         if (paired_records != 0) {
             hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, GROUP>(
@@ -580,12 +626,34 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     } else if (source == kInverseFromTensor) {
         return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
     }
-    if (source == kInverseFromTensor)
-        return launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map, rows, source_spec, stream);
-    if (source == kInverseFromKeyMac)
-        return launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map, rows, source_spec, stream);
-    size_t paired_records = 0;
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+    if (source == kInverseFromTensor || source == kInverseFromKeyMac) {
+        // records are (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the odd items at
+        // the end go one per workgroup.  record_base counts items for these kernels.
+        const bool tensor = source == kInverseFromTensor;
+        const size_t replicas = tensor ? 3 : 2;
+        const size_t items = rows / mod_period / replicas;
+        const size_t group = tensor ? kTensorRows<LOGN, LOGT> : kKeyMacRows<LOGN, LOGT>;
+        const size_t grouped = group > 1 ? items / group * group : 0;
+        auto map_from = [&](size_t first_item) {
+            return make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(first_item));
+        };
+        if (grouped != 0) {
+            const size_t workgroups = grouped / group * replicas * mod_period;
+            hipError_t e = tensor ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, kTensorRows<LOGN, LOGT>>(
+                                        mode, slab, ctx, map_from(0), workgroups, source_spec, stream)
+                                  : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, kKeyMacRows<LOGN, LOGT>>(
+                                        mode, slab, ctx, map_from(0), workgroups, source_spec, stream);
+            if (e != hipSuccess) return e;
+        }
+        if (items == grouped) return hipSuccess;
+        const size_t workgroups = (items - grouped) * replicas * mod_period;
+        return tensor ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map_from(grouped),
+                                                                                workgroups, source_spec, stream)
+                      : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map_from(grouped),
+                                                                                workgroups, source_spec, stream);
+    }
+    size_t paired_records = 0;
     if constexpr (GROUP > 1) {
         paired_records = (rows / mod_period) / GROUP * GROUP;
         if (paired_records != 0) {

@@ -29,6 +29,10 @@ __device__ __forceinline__ void locate_replica(uint32_t block, uint32_t sets, ui
         replica = rest - q * replicas;
     }
 #endif
+    // the divisions by a run-time count go through the vector ALU: hand the (wave-uniform) results back to scalar
+    // registers explicitly, so that everything derived from them (moduli, table bases, row offsets) stays scalar
+    set = __builtin_amdgcn_readfirstlane(set);
+    replica = __builtin_amdgcn_readfirstlane(replica);
 }
 
 }  // namespace heamd
