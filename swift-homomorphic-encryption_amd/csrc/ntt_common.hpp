@@ -495,16 +495,21 @@ __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid,
 // scalar offset.  For a pass on the low bits each lane owns runs of 2^W contiguous words: move them 16 B at a time.
 // For the top pass consecutive lanes own consecutive words (8 B each, 512 B per wave instruction).
 // Row data is touched once per launch: loaded and stored non-temporally it does not displace the twiddle tables from
-// the vector L1 / L2 that every workgroup gathers from (forward 0.566 -> 0.525 ms, inverse 0.622 -> 0.586 ms per launch,
-// profiles/r02e_ntt_ab_nt_policy.txt).  aux bit 1 = nt on gfx940+.
-#ifdef HEAMD_X_CACHED_ROWS  // experiment: the default cache policy
-constexpr int kLoadPolicy = 0, kStorePolicy = 0;
+// the vector L1 / L2 that every workgroup gathers from -- at N = 8192: forward 0.566 -> 0.525 ms, inverse 0.622 ->
+// 0.586 ms per launch (profiles/r02e_ntt_ab_nt_policy.txt); N = 16384: 0.399 -> 0.376 ms.  At N = 4096 (half the
+// table, 512-lane workgroups, four of them per CU) it is the other way round: 0.326 -> 0.391 ms, so those rows keep the
+// default policy (profiles/r02j_ntt_policy_by_degree.txt).  aux bit 1 = nt on gfx940+.
+template <int LOGN>
+constexpr int row_policy() {
+#ifdef HEAMD_X_CACHED_ROWS  // experiment: the default cache policy everywhere
+    return 0;
 #else
-constexpr int kLoadPolicy = 2, kStorePolicy = 2;
+    return LOGN >= 13 ? 2 : 0;
 #endif
-// POLICY: kLoadPolicy for rows nobody else reads; 0 (cached) for source rows that several workgroups of a replica set
+}
+// POLICY: row_policy<LOGN>() for rows nobody else reads; 0 (cached) for source rows that several workgroups of a replica set
 // read (ntt_kernels.hip locate_replica: the others are meant to hit in L2)
-template <int LOGN, int LOGE, int LO, int W, int POLICY = kLoadPolicy>
+template <int LOGN, int LOGE, int LO, int W, int POLICY = row_policy<LOGN>()>
 __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
     const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
     if constexpr (LO == 0 && W >= 1) {
@@ -531,13 +536,13 @@ __device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uin
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r += 2) {
             const Dwordx4 pair = {lo32(v[r]), hi32(v[r]), lo32(v[r + 1]), hi32(v[r + 1])};
-            __builtin_amdgcn_raw_buffer_store_b128(pair, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kStorePolicy);
+            __builtin_amdgcn_raw_buffer_store_b128(pair, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, row_policy<LOGN>());
         }
     } else {
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); ++r) {
             const Dwordx2 word = {lo32(v[r]), hi32(v[r])};
-            __builtin_amdgcn_raw_buffer_store_b64(word, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, kStorePolicy);
+            __builtin_amdgcn_raw_buffer_store_b64(word, row, lane_bytes, register_part<LOGN, LOGE, LO, W>(r) << 3, row_policy<LOGN>());
         }
     }
 }
