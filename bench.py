@@ -484,47 +484,43 @@ class PirDim0Workload:
 WORKLOADS = {w.key: w for w in (NttWorkload, CtMulWorkload, ModSwitchWorkload, PirDim0Workload)}
 
 
-def main():
-    args = parse_args()
+def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
+    """The timed part of the contract, independent of the workload and of the device: W warm-up steps, a barrier, exactly
+    K steps bracketed by synchronisation, max over ranks, the units of all ranks; then the workload's roofline leg and the
+    result gather.  `dist` is torch.distributed (initialised) when world > 1.  Returns the JSON line's dict on rank 0,
+    None elsewhere.  (tests/test_sharding_gloo.py drives this function with two gloo ranks and a CPU workload.)"""
     import torch
 
-    import heamd
     from heamd import sharding
 
-    rank, local_rank, world = sharding.rank_and_world()
     distributed = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
+    on_gpu = device == "cuda"
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and distributed:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
-    job = WORKLOADS[args.workload](torch, heamd, sharding, args, rank, world)
+    def synchronize():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        synchronize()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        synchronize()
 
+    job = make_job()
     for _ in range(args.warmup):
         job.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
-    torch.cuda.synchronize()
+    synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
         dist.barrier()
-        elapsed = sharding.max_over_ranks(elapsed, device="cuda")
+        elapsed = sharding.max_over_ranks(elapsed, device=device)
     units_all_ranks = job.units
     if distributed:
-        counter = torch.tensor([job.units], dtype=torch.int64, device="cuda")
+        counter = torch.tensor([job.units], dtype=torch.int64, device=device)
         dist.all_reduce(counter)
         units_all_ranks = int(counter.item())
 
@@ -537,13 +533,13 @@ def main():
         # K steps with the gather after every step, max over ranks
         local, total = job.result()
         out = sharding.gather_shards(local, total)
-        torch.cuda.synchronize()
+        synchronize()
         del out
         barrier()
         t1 = time.perf_counter()
         out = sharding.gather_shards(local, total)
-        torch.cuda.synchronize()
-        gather_ms = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda") * 1e3
+        synchronize()
+        gather_ms = sharding.max_over_ranks(time.perf_counter() - t1, device=device) * 1e3
         del out
         barrier()
         t1 = time.perf_counter()
@@ -551,38 +547,63 @@ def main():
             job.step()
             local, total = job.result()
             out = sharding.gather_shards(local, total)
-        torch.cuda.synchronize()
-        with_gather_elapsed = sharding.max_over_ranks(time.perf_counter() - t1, device="cuda")
+        synchronize()
+        with_gather_elapsed = sharding.max_over_ranks(time.perf_counter() - t1, device=device)
         del out
 
+    if rank != 0:
+        return None
+    description = job.describe(world)
+    return {
+        "metric": description["metric"],
+        "value": units_all_ranks * args.steps / elapsed,
+        "unit": description["unit"],
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": description["dtype"],
+        "data": "synthetic",
+        "config": description["config"],
+        "roofline": roofline,
+        "extras": dict(extras, all_gather_ms=gather_ms,
+                       value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed
+                                              if with_gather_elapsed else None)),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    import heamd
+    from heamd import sharding
+
+    rank, local_rank, world = sharding.rank_and_world()
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and distributed:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    result = run_benchmark(args, lambda: WORKLOADS[args.workload](torch, heamd, sharding, args, rank, world), rank, world,
+                           "cuda", dist)
     if rank == 0:
-        description = job.describe(world)
-        result = {
-            "metric": description["metric"],
-            "value": units_all_ranks * args.steps / elapsed,
-            "unit": description["unit"],
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": description["dtype"],
-            "data": "synthetic",
-            "config": description["config"],
-            "roofline": roofline,
-            "extras": dict(extras, all_gather_ms=gather_ms,
-                           value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed
-                                                  if with_gather_elapsed else None),
-                           library=heamd.version()),
-        }
+        result["extras"]["library"] = heamd.version()
         if args.workload == "c2" and world == 1 and not args.skip_other_configs:
             # the other BASELINE.json configs on this GPU (ciphertext-mul/s, mod-switch, PIR inner loop); not `value`
             sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
             import path_bench
 
-            del job
             torch.cuda.empty_cache()
             result["extras"]["other_configs"] = path_bench.run_all(quick=False)
         if args.workload == "c2" and not args.no_cpu_baseline and world == 1:

@@ -121,6 +121,83 @@ def test_two_rank_column_sharded_pir_response_matches_unsharded():
     assert results[0] == (True, (0, 3)) and results[1] == (True, (3, 5))
 
 
+def _bench_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import argparse
+    import importlib.util
+
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from heamd import sharding
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        degree, total_polys = 64, 7
+        begin, end = sharding.shard_bounds(total_polys, world, rank)
+        per_rank = end - begin  # ragged shards: 4 and 3 polynomials
+        moduli = oracle.generate_primes([40, 41], False, degree)
+        ctx = oracle.PolyContext(degree, moduli)
+
+        class CpuJob:  # the workload interface of bench.py on CPU tensors (the oracle stands in for the kernels)
+            def __init__(self):
+                self.total = total_polys
+                rng = np.random.default_rng(5 + rank)
+                self.slab = np.stack([rng.integers(0, q, size=(per_rank, degree), dtype=np.uint64) for q in moduli], axis=1)
+                self.units = 2 * per_rank
+                self.steps_run = 0
+
+            def step(self):
+                ctx.forward_ntt_inplace(self.slab, threads=1)
+                ctx.inverse_ntt_inplace(self.slab, threads=1)
+                self.steps_run += 1
+
+            def result(self):
+                return torch.from_numpy(self.slab.view(np.int64)), self.total
+
+            def describe(self, w):
+                return {"metric": "m", "unit": "u", "dtype": "u64", "config": {"workload": "cpu dry run", "world": w}}
+
+            def roofline(self, steps, r):
+                return {"bound": "hbm", "frac": 0.0}, {"note": "dry run"}
+
+        jobs = []
+
+        def make_job():
+            jobs.append(CpuJob())
+            return jobs[-1]
+
+        args = argparse.Namespace(steps=3, warmup=2, skip_gather=False)
+        line = bench.run_benchmark(args, make_job, rank, world, device="cpu", dist=dist)
+        results[rank] = (line, jobs[0].steps_run, jobs[0].units)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_contract_with_two_ranks():
+    """bench.py's timed contract (warm-up, barrier, exactly K steps, max over ranks, units of all ranks, gather after
+    the steps) driven by two gloo ranks with ragged shards: rank 0 alone reports, `value` counts every rank's units."""
+    import torch.multiprocessing as mp
+
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_bench_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    line0, steps0, units0 = results[0]
+    line1, steps1, units1 = results[1]
+    assert line1 is None and line0 is not None
+    assert (units0, units1) == (8, 6)
+    assert steps0 == steps1 == 2 + 3 + 3  # warm-up, timed steps, the steps repeated with the gather
+    assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
+    assert abs(line0["value"] * line0["ms_per_step"] * 1e-3 - (units0 + units1)) < 1e-6  # (8 + 6) units per step
+    assert line0["extras"]["all_gather_ms"] > 0 and line0["extras"]["value_with_all_gather"] > 0
+    assert line0["higher_is_better"] is True and line0["config"]["world"] == 2
+
+
 def test_shard_bounds_partition():
     from heamd import sharding
 
