@@ -507,9 +507,18 @@ constexpr int row_policy() {
     return LOGN >= 13 ? 2 : 0;
 #endif
 }
+// loads may take another policy than stores (experiment hook; production: the same)
+template <int LOGN>
+constexpr int row_load_policy() {
+#ifdef HEAMD_X_ROW_LOAD_POLICY
+    return HEAMD_X_ROW_LOAD_POLICY;
+#else
+    return row_policy<LOGN>();
+#endif
+}
 // POLICY: row_policy<LOGN>() for rows nobody else reads; 0 (cached) for source rows that several workgroups of a replica set
 // read (ntt_kernels.hip locate_replica: the others are meant to hit in L2)
-template <int LOGN, int LOGE, int LO, int W, int POLICY = row_policy<LOGN>()>
+template <int LOGN, int LOGE, int LO, int W, int POLICY = row_load_policy<LOGN>()>
 __device__ __forceinline__ void global_load(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row) {
     const uint32_t lane_bytes = lane_part<LOGN, LOGE, LO, W>(tid) << 3;
     if constexpr (LO == 0 && W >= 1) {

@@ -279,3 +279,37 @@ def test_pir_expand_batch_of_queries_from_two_clients(oracle, small, total):
         assert np.array_equal(got[q], expected), q
         for index in range(total):
             assert c.decrypt(got[q, index]) == [1 if index in o else 0] + [0] * (n - 1), (q, index)
+
+
+def test_new_pir_entry_points_edge_cases(small):
+    """Empty and malformed calls of the column-shard / chunk-loop / batch-expand entry points: nothing to do is HE_OK,
+    a shape the reference would trap on (PirUtil.swift:420-422, :325-326) or a null operand is invalidArgument."""
+    import ctypes
+
+    import torch
+
+    ours, ref, _ = small
+    lib = heamd.load_library()
+    L, n = ours.L, ours.degree
+    dims = (ctypes.c_uint32 * 2)(2, 3)
+    dim0 = heamd.to_device(np.zeros((2, 2, L, n), dtype=np.uint64))
+    rest = heamd.to_device(np.zeros((3, 2, L, n), dtype=np.uint64))
+    database = heamd.to_device(np.zeros((2, 6, L, n), dtype=np.uint64))
+    key = heamd.to_device(np.zeros((L, 2, L + 1, n), dtype=np.uint64))
+    out = torch.zeros((2, 2, 1, n), dtype=torch.int64, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    # zero columns / zero chunks / zero queries: nothing to do
+    assert lib.he_pir_dim0_columns_device(ours.h, p(dim0), 2, p(database), None, 0, p(out), None) == 0
+    assert lib.he_pir_compute_response_device(ours.h, dims, 2, p(dim0), p(rest), 3, p(database), None, 0, p(key), p(out),
+                                              None) == 0
+    assert lib.he_pir_expand_batch_device(ours.h, p(dim0), 0, 1, 4, None, None, 0, p(out), None) == 0
+    # null operands, mismatched query, empty dimensions
+    assert lib.he_pir_dim0_columns_device(ours.h, None, 2, p(database), None, 3, p(out), None) == 16
+    assert lib.he_pir_compute_response_device(ours.h, dims, 2, p(dim0), p(rest), 2, p(database), None, 2, p(key), p(out),
+                                              None) == 16  # 3 columns, 2 remaining query ciphertexts
+    assert lib.he_pir_remaining_dimensions_device(ours.h, dims, 0, p(database), p(rest), 3, p(key), p(out), None) == 16
+    assert lib.he_pir_expand_batch_device(ours.h, p(dim0), 2, 1, n + 1, None, None, 0, p(out), None) == 16  # > N outputs
+    # the chunk loop answers chunk by chunk what the one-chunk call answers (all-zero operands: zero response)
+    got = ours.pir_compute_response([2, 3], dim0, rest, database, 2, relinearization_key=key)
+    torch.cuda.synchronize()
+    assert got.shape == (2, 2, 1, n) and int(got.abs().sum()) == 0
