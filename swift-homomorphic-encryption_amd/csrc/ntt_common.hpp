@@ -401,9 +401,6 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // that sums double the bound and products are < p << K (K = Lazy::kProductLog); exact / approx: once the bound
     // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
     constexpr int H = Lazy<MODE>::kInverseCapLog;
-#ifdef HEAMD_X_LATE_TID
-    asm volatile("" : "+v"(tid));
-#endif
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
     TwiddleWords pending = first;
 #pragma unroll
@@ -418,17 +415,11 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
-#ifdef HEAMD_X_INVERSE_NO_AHEAD
-        if (k > 0) __builtin_amdgcn_sched_barrier(0);
-        const TwiddleWords w = k == 0 ? pending : inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k);
-        if (k > 0) __builtin_amdgcn_sched_barrier(0);
-#else
         const TwiddleWords w = pending;
         if (k + 1 < COUNT) {
             pending = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
@@ -464,9 +455,6 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
                     v[row][base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
                                                         : Lazy<MODE>::template mul<false>(diff, w, neg_p);
                 }
-#ifdef HEAMD_X_BUTTERFLY_FENCE
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);

@@ -137,10 +137,6 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // second is written (the same fence the exchange itself needs: wave-private once a wave owns its slice of the row).
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS>
 __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
-#ifdef HEAMD_X_LATE_LDS_ADDRESS  // experiment: the tile addresses are derived here, not at the top of the kernel
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(tid));
-#endif
 #ifndef HEAMD_X_NO_LDS
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
