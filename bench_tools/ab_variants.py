@@ -55,7 +55,8 @@ def build(specs):
         obj = os.path.join(VARIANTS, f"{stem}_{name}.o")
         subprocess.run([product_build._hipcc(), *product_build.FLAGS, *flag.split(), "-c",
                         os.path.join(PKG, "csrc", source), "-o", obj], check=True)
-        subprocess.run([product_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={product_build.ARCH}", "-o",
+        subprocess.run([product_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={product_build.ARCH}",
+                        f"-Wl,--version-script={product_build.EXPORTS}", "-o",
                         os.path.join(VARIANTS, f"libhe_amd_{name}.so"), obj, *objects], check=True)
         os.unlink(obj)
         print("built", name, flush=True)

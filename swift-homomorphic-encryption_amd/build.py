@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhe_amd.so")
+EXPORTS = os.path.join(CSRC, "exports.map")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -61,7 +62,9 @@ def build(force=False, verbose=False):
     objects = [obj for obj, _ in results]
     rebuilt = any(changed for _, changed in results)
     if rebuilt or not os.path.exists(LIB_PATH):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objects]
+        # only the C ABI (he_*) is exported: the C++ launchers behind it stay internal
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={EXPORTS}", "-o", LIB_PATH,
+               *objects]
         result = subprocess.run(cmd, capture_output=True, text=True)
         if result.returncode != 0:
             raise RuntimeError(f"link failed:\n{result.stdout}\n{result.stderr}")

@@ -180,3 +180,21 @@ def test_galois_element_helpers():
     with pytest.raises(heamd.HeError) as err:
         heamd.galois_element_rotating_columns(1, 12)
     assert err.value.name == "invalidDegree"
+
+
+def test_library_exports_only_the_c_abi():
+    """`nm -D libhe_amd.so`: every defined text symbol is an entry point of include/he_amd.h (no C++ launcher, no
+    measurement hook, nothing that is not declared in the header)."""
+    import re
+    import subprocess
+
+    import heamd
+
+    out = subprocess.run(["nm", "-D", "--defined-only", heamd.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert exported and all(name.startswith("he_") for name in exported), sorted(n for n in exported if not n.startswith("he_"))
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "he_amd.h")) as f:
+        declared = set(re.findall(r"\b(he_[a-z0-9_]+)\s*\(", f.read()))
+    assert exported <= declared, sorted(exported - declared)
