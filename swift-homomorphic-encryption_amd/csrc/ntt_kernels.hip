@@ -191,7 +191,7 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // One inverse pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout of pass
 // (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
 // transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
-// doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab.txt).
+// doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
 #ifdef HEAMD_X_INVERSE_EARLY_FIRST
 constexpr bool kInverseFirstTwiddleEarly = true;
 #else
