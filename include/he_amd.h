@@ -265,6 +265,12 @@ int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count
                                 const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,
                                 size_t workspace_bytes, he_stream s);
 size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count);
+/* `items` such inner products that share their left vector -- the remaining-dimension step of a PIR response over all
+ * result groups of all chunks (PirUtil.swift:448-479): lhs [count][2][L][N], rhs [items][count][2][L][N] Coeff ->
+ * out [items][3][L][N] Coeff.  Item i equals he_bfv_inner_product_device(lhs, rhs + i * count ciphertexts); every stage is
+ * one launch over all items and the left vector is lifted and transformed once.  Stream-ordered scratch. */
+int he_bfv_inner_product_shared_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
+                                       const uint64_t* rhs, size_t count, size_t items, uint64_t* out, he_stream s);
 
 /* Context<Bfv<UInt32>> (scheme layer): the word type fixes the largest modulus (2^30 - 1), gamma =
  * 2^30 - 20405, mTilde = 2^16 and the 29-bit Bsk primes (ModularArithmetic/Scalar.swift:498-511,
@@ -387,10 +393,10 @@ int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, const uint32_t
                                        he_stream s);
 /* PirUtilProtocol.computeResponse's chunk loop for one query (PirUtil.swift:533-563): the database holds `chunk_count`
  * chunks of prod(dimensions) plaintexts each ([chunk][prod(dimensions)][L][N] Eval), the same expanded query serves
- * every chunk, out [chunk_count][2][1][N].  The chunks are independent (the reference maps them over tasks); they
- * are enqueued round-robin on a few internal streams forked from and joined back into `s` with events, so that one
- * chunk's small later stages overlap another chunk's dim-0 stream.  present_device: DEVICE [chunk][prod(dimensions)] or
- * NULL.  Enqueue-only. */
+ * every chunk, out [chunk_count][2][1][N].  The chunks are independent (the reference maps them over tasks) and are
+ * answered together: one dim-0 launch over the columns of all chunks, then every stage of every remaining dimension as
+ * one batch over the result groups of all chunks (he_bfv_inner_product_shared_device), in groups of chunks that keep the
+ * intermediate ciphertexts under about 1 GiB.  present_device: DEVICE [chunk][prod(dimensions)] or NULL.  Enqueue-only. */
 int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                                    const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
                                    size_t remaining_query_count, const uint64_t* database, const uint8_t* present_device,

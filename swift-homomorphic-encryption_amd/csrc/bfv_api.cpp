@@ -697,8 +697,41 @@ int inner_product_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, 
                                                   stream));
     return drop_extended_base(*tool, sum, out, 3, stream);
 }
+
+// `items` inner products that share the left vector: lhs [count][2][L][N], rhs [items][count][2][L][N] -> out
+// [items][3][L][N].  Every stage is one launch over all items (the left vector is lifted and transformed once).
+template <typename W>
+int inner_product_shared_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L, const W* lhs,
+                                  const W* rhs, size_t count, size_t items, W* out, hipStream_t stream) {
+    const size_t ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    Scratch scratch(stream);
+    HEAMD_HIP_TRY(scratch.allocate((count * 2 + items * count * 2 + items * 3) * ext * sizeof(W)));
+    W* lifted_l = static_cast<W*>(scratch.get());      // [count][2][2L+1][N]
+    W* lifted_r = lifted_l + count * 2 * ext;           // [items][count][2][2L+1][N]
+    W* sum = lifted_r + items * count * 2 * ext;        // [items][3][2L+1][N]
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk(lhs, lifted_l, tool->device, count * 2, stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk(rhs, lifted_r, tool->device, items * count * 2, stream));
+    const DeviceContext qbsk = tool->qbsk->device_context();
+    // lifted_l and lifted_r are adjacent: one transform launch over both
+    HEAMD_HIP_TRY(ntt_records(false, lifted_l, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), (1 + items) * count * 2, stream));
+    const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
+    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate_shared(static_cast<const W*>(lifted_l), static_cast<const W*>(lifted_r), sum,
+                                                         qbsk, count, items, max_lazy ? max_lazy : 1, stream));
+    return drop_extended_base(*tool, sum, out, items * 3, stream);
+}
 }  // namespace
 }  // extern "C++"
+
+int he_bfv_inner_product_shared_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
+                                       const uint64_t* rhs, size_t count, size_t items, uint64_t* out, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (count == 0) return invalid_argument("empty ciphertext vector");
+    if (items == 0) return HE_OK;
+    if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    return inner_product_shared_pipeline(ctx, tool, moduli_count, lhs, rhs, count, items, out, as_stream(s));
+}
 
 int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
                                 const uint64_t* rhs, size_t count, uint64_t* out, void* workspace,

@@ -71,22 +71,20 @@ extern "C" int he_pir_dim0_columns_device(const he_bfv_context* ctx, const uint6
     return he_ntt_inverse_device(q_ctx, out, columns * 2, s);
 }
 
-extern "C" int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, const uint32_t* dimensions,
-                                                  uint32_t dimension_count, uint64_t* intermediate,
-                                                  const uint64_t* remaining_query, size_t remaining_query_count,
-                                                  const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
-    ChunkShape shape;
-    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
-    if (intermediate == nullptr || out == nullptr) return invalid_argument("null operand");
+namespace {
+// PirUtil.swift:448-485 for `chunks` chunks at once: intermediate [chunks][columns][2][L][N] Coeff (consumed) ->
+// out [chunks][2][1][N].  The result groups of all chunks share each dimension's query slice, so every stage of a
+// dimension is one batch over chunks x groups.
+int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                         const ChunkShape& shape, size_t chunks, uint64_t* results, const uint64_t* remaining_query,
+                         const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
     hipStream_t stream = as_stream(s);
     const uint32_t L = shape.L;
     const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
-    uint64_t* results = intermediate;
     Scratch next_mem(stream), products_mem(stream), level_mem(stream);
-    // remaining dimensions (PirUtil.swift:448-479): `next` receives each dimension's relinearized products
-    size_t count = shape.columns, cursor = 0;
+    size_t count = shape.columns, cursor = 0;  // ciphertexts per chunk
     if (dimension_count > 1) {
-        const size_t max_items = shape.columns / dimensions[1];
+        const size_t max_items = chunks * (shape.columns / dimensions[1]);
         HEAMD_HIP_TRY(next_mem.allocate((max_items ? max_items : 1) * ct2 * sizeof(uint64_t)));
         HEAMD_HIP_TRY(products_mem.allocate((max_items ? max_items : 1) * ct3 * sizeof(uint64_t)));
     }
@@ -95,50 +93,60 @@ extern "C" int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, con
     for (uint32_t i = 1; i < dimension_count; ++i) {
         const size_t d = dimensions[i];
         if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
-        const size_t items = count / d;
+        const size_t items = chunks * (count / d);  // groups of d consecutive results, chunk after chunk
         const uint64_t* query = remaining_query + cursor * ct2;
-        for (size_t j = 0; j < items; ++j)
-            HEAMD_TRY_STATUS(he_bfv_inner_product_device(ctx, L, query, results + j * d * ct2, d, products + j * ct3,
-                                                         nullptr, 0, s));
+        HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device(ctx, L, query, results, d, items, products, s));
         HEAMD_TRY_STATUS(he_bfv_relinearize_device(ctx, L, products, relinearization_key, next, items, nullptr, 0, s));
         // the relinearized products become the next dimension's operands
         HEAMD_HIP_TRY(hipMemcpyAsync(results, next, items * ct2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
-        count = items;
+        count /= d;
         cursor += d;
     }
     if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
-    // modSwitchDownToSingle (:483): L - 1 divideAndRoundQLast steps on the 2-poly ciphertext
+    // modSwitchDownToSingle (:483): L - 1 divideAndRoundQLast steps on the chunks' 2-poly ciphertexts
     if (L == 1) {
-        HEAMD_HIP_TRY(hipMemcpyAsync(out, results, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+        HEAMD_HIP_TRY(hipMemcpyAsync(out, results, chunks * 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
         return HE_OK;
     }
-    HEAMD_HIP_TRY(level_mem.allocate(2 * ct2 * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(level_mem.allocate(2 * chunks * ct2 * sizeof(uint64_t)));
     uint64_t* ping = static_cast<uint64_t*>(level_mem.get());
-    uint64_t* pong = ping + ct2;
+    uint64_t* pong = ping + chunks * ct2;
     const uint64_t* current = results;
     for (uint32_t level = L; level > 1; --level) {
         uint64_t* target = level == 2 ? out : (current == ping ? pong : ping);
-        HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device(ctx, level, 2, current, target, 1, s));
+        HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device(ctx, level, 2, current, target, chunks, s));
         current = target;
     }
     return HE_OK;
 }
 
-namespace {
-// one chunk with a device-resident mask, enqueue-only
-int response_chunk_resident(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
-                            const ChunkShape& shape, const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
-                            size_t remaining_query_count, const uint64_t* database, const uint8_t* present_device,
-                            const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+// `chunks` chunks with a device-resident mask, enqueue-only: one dim-0 launch over the columns of all chunks, then the
+// remaining dimensions of all chunks together
+int response_chunks_resident(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                             const ChunkShape& shape, size_t chunks, const uint64_t* dim0_query_eval,
+                             const uint64_t* remaining_query, const uint64_t* database, const uint8_t* present_device,
+                             const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
     Scratch results_mem(as_stream(s));
-    HEAMD_HIP_TRY(results_mem.allocate(shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(results_mem.allocate(chunks * shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t)));
     uint64_t* results = static_cast<uint64_t*>(results_mem.get());
-    HEAMD_TRY_STATUS(he_pir_dim0_columns_device(ctx, dim0_query_eval, shape.d0, database, present_device, shape.columns,
-                                                results, s));
-    return he_pir_remaining_dimensions_device(ctx, dimensions, dimension_count, results, remaining_query,
-                                              remaining_query_count, relinearization_key, out, s);
+    // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
+    HEAMD_TRY_STATUS(he_pir_dim0_columns_device(ctx, dim0_query_eval, shape.d0, database, present_device,
+                                                chunks * shape.columns, results, s));
+    return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
+                                relinearization_key, out, s);
 }
 }  // namespace
+
+extern "C" int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                  uint32_t dimension_count, uint64_t* intermediate,
+                                                  const uint64_t* remaining_query, size_t remaining_query_count,
+                                                  const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (intermediate == nullptr || out == nullptr) return invalid_argument("null operand");
+    return remaining_dimensions(ctx, dimensions, dimension_count, shape, 1, intermediate, remaining_query,
+                                relinearization_key, out, s);
+}
 
 extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
                                                     uint32_t dimension_count, const uint64_t* dim0_query_eval,
@@ -158,8 +166,8 @@ extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, c
         HEAMD_HIP_TRY(hipStreamSynchronize(stream));  // `present` is a borrowed pageable host buffer
         present_device = static_cast<const uint8_t*>(mask_mem.get());
     }
-    return response_chunk_resident(ctx, dimensions, dimension_count, shape, dim0_query_eval, remaining_query,
-                                   remaining_query_count, database, present_device, relinearization_key, out, s);
+    return response_chunks_resident(ctx, dimensions, dimension_count, shape, 1, dim0_query_eval, remaining_query, database,
+                                    present_device, relinearization_key, out, s);
 }
 
 extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* dimensions,
@@ -172,47 +180,21 @@ extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const u
     HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
     if (chunk_count == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
-    hipStream_t stream = as_stream(s);
     const size_t chunk_words = shape.per_chunk * size_t(shape.L) * shape.n, out_words = 2 * shape.n;
-    // fork: up to four internal streams wait for everything already enqueued on `s`; join: `s` waits for all of them
-    const size_t lanes = chunk_count < 4 ? chunk_count : 4;
-    std::vector<hipStream_t> streams(lanes, nullptr);
-    std::vector<hipEvent_t> done(lanes, nullptr);
-    hipEvent_t fork = nullptr;
-    auto release = [&]() {
-        for (hipStream_t t : streams)
-            if (t != nullptr) (void)hipStreamDestroy(t);  // returns at once; the stream's work still completes
-        for (hipEvent_t e : done)
-            if (e != nullptr) (void)hipEventDestroy(e);
-        if (fork != nullptr) (void)hipEventDestroy(fork);
-    };
-    int status = HE_OK;
-    do {
-        hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-        for (size_t k = 0; k < lanes && e == hipSuccess; ++k) {
-            e = hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
-        }
-        if (e == hipSuccess) e = hipEventRecord(fork, stream);
-        for (size_t k = 0; k < lanes && e == hipSuccess; ++k) e = hipStreamWaitEvent(streams[k], fork, 0);
-        if (e != hipSuccess) {
-            status = heamd::device_failure(e, "he_pir_compute_response_device fork");
-            break;
-        }
-        for (size_t chunk = 0; chunk < chunk_count && status == HE_OK; ++chunk)
-            status = response_chunk_resident(ctx, dimensions, dimension_count, shape, dim0_query_eval, remaining_query,
-                                             remaining_query_count, database + chunk * chunk_words,
-                                             present_device ? present_device + chunk * shape.per_chunk : nullptr,
-                                             relinearization_key, out + chunk * out_words, streams[chunk % lanes]);
-        // join even after a failed enqueue, so that nothing already enqueued outlives the caller's view of `s`
-        for (size_t k = 0; k < lanes; ++k) {
-            hipError_t j = hipEventRecord(done[k], streams[k]);
-            if (j == hipSuccess) j = hipStreamWaitEvent(stream, done[k], 0);
-            if (j != hipSuccess && status == HE_OK) status = heamd::device_failure(j, "he_pir_compute_response_device join");
-        }
-    } while (false);
-    release();
-    return status;
+    // The chunks are independent (the reference maps them over tasks, PirUtil.swift:533-563) and share the query: they are
+    // answered together, `group` chunks per pass -- one dim-0 launch over all their columns, one batch per stage of
+    // every remaining dimension -- with the group sized to keep the intermediate ciphertexts under ~1 GiB.
+    const size_t intermediate_bytes = shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t);
+    size_t group = (size_t(1) << 30) / (intermediate_bytes ? intermediate_bytes : 1);
+    group = group == 0 ? 1 : group;
+    for (size_t first = 0; first < chunk_count; first += group) {
+        const size_t now = chunk_count - first < group ? chunk_count - first : group;
+        HEAMD_TRY_STATUS(response_chunks_resident(
+            ctx, dimensions, dimension_count, shape, now, dim0_query_eval, remaining_query, database + first * chunk_words,
+            present_device ? present_device + first * shape.per_chunk : nullptr, relinearization_key,
+            out + first * out_words, s));
+    }
+    return HE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -262,6 +262,43 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// The same for `items` inner products that share their left vector (the PIR remaining-dimension step of every
+// result group of every chunk, PirUtil.swift:448-479): lhs [count][2][rows][N], rhs [items][count][2][rows][N] (both
+// lifted, Eval) -> out [items][3][rows][N].  blockIdx.y = item.
+template <typename W>
+__global__ void __launch_bounds__(kThreads)
+    tensor_accumulate_shared_kernel(const W* __restrict__ lhs, const W* __restrict__ rhs, W* __restrict__ out,
+                                    const DeviceContext ctx, size_t count, uint64_t max_lazy) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t poly_words = size_t(ctx.moduli_count) << logn;
+    const size_t item = blockIdx.y;
+    const W* __restrict__ right = rhs + item * count * 2 * poly_words;
+    W* __restrict__ sum = out + item * 3 * poly_words;
+    for (size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x; w < poly_words; w += size_t(gridDim.x) * kThreads) {
+        const DeviceModulus m = ctx.moduli[w >> logn];
+        U128 d0{0, 0}, d1{0, 0}, d2{0, 0};
+        uint64_t since = 0;
+        for (size_t k = 0; k < count; ++k) {
+            const W* a = lhs + k * 2 * poly_words + w;
+            const W* b = right + k * 2 * poly_words + w;
+            const uint64_t a0 = a[0], a1 = a[poly_words], b0 = b[0], b1 = b[poly_words];
+            mac128(d0, a0, b0);
+            mac128(d1, a0, b1);
+            mac128(d1, a1, b0);
+            mac128(d2, a1, b1);
+            if (++since >= max_lazy) {  // reduceInPlace cadence, Bfv.swift:349-353
+                since = 0;
+                d0 = U128{reduce128(d0, m), 0};
+                d1 = U128{reduce128(d1, m), 0};
+                d2 = U128{reduce128(d2, m), 0};
+            }
+        }
+        sum[w] = static_cast<W>(reduce128(d0, m));
+        sum[poly_words + w] = static_cast<W>(reduce128(d1, m));
+        sum[2 * poly_words + w] = static_cast<W>(reduce128(d2, m));
+    }
+}
+
 // ---- key switching, step 1: decompose-and-spread (Bfv+Keys.swift:165-172) ----------------------------------------
 // target: row j of polynomial `poly` at  target_base + poly * target_stride + j * N   (Coeff, mod q_j)
 // out: [polys][L][L+1][N]: word (poly, j, r, k) = target[j][k] mod ks_modulus[r]  (reduced only when q_j > modulus r)
@@ -467,6 +504,23 @@ hipError_t launch_tensor_accumulate(const W* in, W* out, const DeviceContext& qb
 }
 
 template <typename W>
+hipError_t launch_tensor_accumulate_shared(const W* lhs, const W* rhs, W* out, const DeviceContext& qbsk, size_t count,
+                                           size_t items, uint64_t max_lazy, hipStream_t stream) {
+    if (items == 0) return hipSuccess;
+    const size_t total = size_t(qbsk.moduli_count) << qbsk.log_degree;
+    const size_t blocks = (total + kThreads - 1) / kThreads;
+    for (size_t done = 0; done < items; done += 65535) {  // grid.y carries the item
+        const size_t now = items - done < 65535 ? items - done : 65535;
+        hipLaunchKernelGGL(tensor_accumulate_shared_kernel<W>, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(now)),
+                           dim3(kThreads), 0, stream, lhs, rhs + done * count * 2 * total, out + done * 3 * total, qbsk,
+                           count, max_lazy);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <typename W>
 hipError_t launch_key_switch_spread(const W* target_base, size_t target_stride, W* out, const DeviceContext& ks,
                                     uint32_t L, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
@@ -513,6 +567,8 @@ hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_s
     template hipError_t launch_floor_qbsk_to_q<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);               \
     template hipError_t launch_tensor<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);                        \
     template hipError_t launch_tensor_accumulate<W>(const W*, W*, const DeviceContext&, size_t, uint64_t, hipStream_t);   \
+    template hipError_t launch_tensor_accumulate_shared<W>(const W*, const W*, W*, const DeviceContext&, size_t, size_t,  \
+                                                           uint64_t, hipStream_t);                                        \
     template hipError_t launch_key_switch_spread<W>(const W*, size_t, W*, const DeviceContext&, uint32_t, size_t,         \
                                                     hipStream_t);                                                         \
     template hipError_t launch_key_switch_mac<W>(const W*, const W*, W*, const DeviceContext&, uint32_t, uint32_t,        \

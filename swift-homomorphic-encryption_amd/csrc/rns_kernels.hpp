@@ -32,6 +32,10 @@ hipError_t launch_tensor(const W* in, W* out, const DeviceContext& qbsk, size_t 
 template <typename W>
 hipError_t launch_tensor_accumulate(const W* in, W* out, const DeviceContext& qbsk, size_t count, uint64_t max_lazy,
                                     hipStream_t stream);
+// `items` sums that share lhs: lhs [count][2][rows][N], rhs [items][count][2][rows][N] -> out [items][3][rows][N]
+template <typename W>
+hipError_t launch_tensor_accumulate_shared(const W* lhs, const W* rhs, W* out, const DeviceContext& qbsk, size_t count,
+                                           size_t items, uint64_t max_lazy, hipStream_t stream);
 template <typename W>
 hipError_t launch_key_switch_spread(const W* target_base, size_t target_stride, W* out, const DeviceContext& ks,
                                     uint32_t L, size_t polys, hipStream_t stream);

@@ -115,6 +115,7 @@ SIGNATURES = [
     ("he_bfv_inner_product_plain_resident_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    ("he_bfv_inner_product_shared_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, c_size, vp, vp]),
     # Bfv<UInt32> on packed 4-byte slabs
     ("he_rns_lift_q_to_qbsk_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_rns_floor_qbsk_to_q_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
@@ -791,6 +792,16 @@ class BfvContext:
         out = self._empty((3, L, self.degree), lhs)
         _check(load_library().he_bfv_inner_product_device(self.h, L, _ptr(lhs), _ptr(rhs), count, _ptr(out), vp(), 0,
                                                           _stream(stream)))
+        return out
+
+    def inner_product_shared(self, lhs, rhs, moduli_count=None, stream=None):
+        """rhs [items][count][2][L][N]: `items` inner products with the same left vector -> [items][3][L][N]."""
+        L = self._L(moduli_count)
+        count = lhs.numel() // (2 * L * self.degree)
+        items = rhs.numel() // (count * 2 * L * self.degree)
+        out = self._empty((items, 3, L, self.degree), lhs)
+        _check(load_library().he_bfv_inner_product_shared_device(self.h, L, _ptr(lhs), _ptr(rhs), count, items, _ptr(out),
+                                                                 _stream(stream)))
         return out
 
 

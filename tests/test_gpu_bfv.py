@@ -412,6 +412,40 @@ def test_inner_product_ct_ct_reduction_cadence(oracle, bits, count):
     assert np.array_equal(got, ref.inner_product(lhs, rhs))
 
 
+@pytest.mark.parametrize("bits,count,items", [([62, 62, 62], 21, 3), ([62, 45, 61, 62], 9, 5), ([50, 50, 50], 4, 1)])
+def test_inner_product_shared_left_vector(oracle, bits, count, items):
+    """he_bfv_inner_product_shared_device (the PIR remaining-dimension step over all result groups at once): item i is
+    Bfv.innerProduct(lhs, rhs[i]) word for word -- the oracle's and the per-item entry point's -- across the in-loop
+    accumulator reductions of Bfv.swift:339-353 (words at q - 1 in the shared left vector maximise every partial sum)."""
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(100 * count + items)
+    lhs, rhs = _uniform(rng, (count, 2), moduli, degree), _uniform(rng, (items, count, 2), moduli, degree)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    lhs[:, :, :, : degree // 2] = top[None, None, :, :]
+    rhs[:, :, :, :, : degree // 4] = top[None, None, None, :, :]
+    left = heamd.to_device(lhs)
+    got = heamd.to_host(ours.inner_product_shared(left, heamd.to_device(rhs)))
+    assert got.shape[0] == items
+    for i in range(items):
+        assert np.array_equal(got[i], ref.inner_product(lhs, rhs[i]))
+        assert np.array_equal(got[i], heamd.to_host(ours.inner_product(left, heamd.to_device(rhs[i]))))
+
+
+def test_inner_product_shared_config3_shape(oracle, config3):
+    """The same on BASELINE config 3's ring (N=8192, L=4): 4 result groups of 6 ciphertexts against one query slice."""
+    ours, ref = config3
+    rng = np.random.default_rng(69)
+    moduli = ref.ciphertext_context().moduli
+    lhs, rhs = _uniform(rng, (6, 2), moduli, ours.degree), _uniform(rng, (4, 6, 2), moduli, ours.degree)
+    got = heamd.to_host(ours.inner_product_shared(heamd.to_device(lhs), heamd.to_device(rhs)))
+    for i in range(4):
+        assert np.array_equal(got[i], ref.inner_product(lhs, rhs[i]))
+
+
 def test_inner_product_ct_ct_config3_shape(oracle, config3):
     """Bfv.innerProduct(ct, ct) on BASELINE config 3's ring (N=8192, L=4), 12 pairs of uniform ciphertexts: every word
     equals the oracle's (the PIR second dimension at a realistic size)."""
