@@ -76,8 +76,8 @@ def main():
     report("N3", "PolyRq(deserialize:), per polynomial", batch, t, POLY_BYTES + packed)
     seeds = torch.randint(0, 256, (batch, 32), dtype=torch.uint8, device="cuda")
     t = _timed(torch, lambda: poly.random_from_seeds(seeds), 3)
-    report("N3", "seeded polynomial (NIST CTR_DRBG AES-128, rejection sampling), per polynomial", batch, t, POLY_BYTES,
-           "one wave per seed: the DRBG stream is sequential per seed")
+    report("N3", "seeded polynomial (NIST CTR_DRBG AES-128, 128 bits per coefficient), per polynomial", batch, t, POLY_BYTES,
+           "AES-bound: re-key chain on 8 lanes per seed, then one wavefront per 4 KiB chunk")
 
     # ---- N4: plaintext lift / unlift and scaleAndRound
     values = torch.randint(0, T, (batch, DEGREE), dtype=torch.int64, device="cuda")

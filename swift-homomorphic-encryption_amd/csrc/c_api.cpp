@@ -596,7 +596,10 @@ int he_poly_random_from_seeds_device(const he_poly_context* ctx, const uint8_t* 
     if (device_seeds == nullptr || device_slab == nullptr) return invalid_argument("null buffer");
     int status = pc.check_device();
     if (status != HE_OK) return status;
-    HEAMD_HIP_TRY(heamd::launch_seeded_uniform(device_seeds, device_slab, pc.device_context(), batch, as_stream(s)));
+    heamd::Scratch chain(as_stream(s));
+    HEAMD_HIP_TRY(chain.allocate(heamd::seeded_uniform_scratch_bytes(pc.device_context(), batch)));
+    HEAMD_HIP_TRY(heamd::launch_seeded_uniform(device_seeds, device_slab, pc.device_context(), batch, chain.get(),
+                                               as_stream(s)));
     return HE_OK;
 }
 

@@ -381,6 +381,107 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ---- one wavefront per 128 coefficients (degree a multiple of 128, 16-byte aligned buffers) -------------------------
+// 128 fields of `w` bits are exactly 2 w stream words, so a row tiles into (128 coefficients <-> w 16-byte pairs) and a
+// tile never shares a word with its neighbours.  The wavefront reads its side with one 16-byte access per lane, passes
+// the words through a wave-private LDS tile and writes the other side 16 bytes per lane: both directions are coalesced
+// in full lines, and the only division is a 32-bit one by the row's width.
+constexpr uint32_t kTileCoefficients = 128;
+constexpr uint32_t kTileWaves = 4;
+
+__device__ __forceinline__ void wave_private_tile_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 64 stream bits starting inside field k at bit `offset` (from the field's top) of a tile of w-bit fields
+__device__ __forceinline__ uint64_t gather_stream_word(const uint64_t* fields, uint32_t w, uint32_t& k, uint32_t& offset) {
+    uint64_t out = 0;
+    uint32_t needed = 64;
+    while (needed > 0) {
+        const uint32_t available = w - offset;
+        const uint32_t take = available < needed ? available : needed;
+        const uint64_t piece = (fields[k] >> (available - take)) & (take == 64 ? ~uint64_t(0) : ((uint64_t(1) << take) - 1));
+        out = (take == 64 ? 0 : (out << take)) | piece;
+        needed -= take;
+        offset += take;
+        if (offset == w) {
+            offset = 0;
+            ++k;
+        }
+    }
+    return out;
+}
+
+// one workgroup per residue row: the width, the row's place in the record and each lane's place in a tile are fixed
+__global__ void __launch_bounds__(kTileWaves * 64)
+    serialize_tiles_kernel(const uint64_t* __restrict__ slab, uint8_t* __restrict__ bytes, const SerializeLayout layout,
+                           uint32_t logn, uint32_t skip) {
+    __shared__ uint64_t tiles[kTileWaves][kTileCoefficients];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t* fields = tiles[wave];
+    const size_t row_index = blockIdx.x, poly = row_index / layout.rows;
+    const uint32_t r = static_cast<uint32_t>(row_index - poly * layout.rows);
+    const uint32_t w = layout.width[r], tiles_per_row = 1u << (logn - 7);
+    const uint64_t mask = w == 64 ? ~uint64_t(0) : ((uint64_t(1) << w) - 1);
+    const U64x2* in = reinterpret_cast<const U64x2*>(slab + (row_index << logn)) + lane;
+    U64x2* out = reinterpret_cast<U64x2*>(bytes + poly * layout.byte_offset[layout.rows] + layout.byte_offset[r]) + lane;
+    // stream pair `lane` of a tile is bits [128 lane, 128 lane + 128): it starts in field k0 at bit offset0
+    const uint32_t k0 = (128 * lane) / w, offset0 = 128 * lane - k0 * w;
+    for (uint32_t t = wave; t < tiles_per_row; t += kTileWaves) {
+        const U64x2 pair = stream_load(in + size_t(t) * (kTileCoefficients / 2));
+        fields[2 * lane] = (pair.x >> skip) & mask;
+        fields[2 * lane + 1] = (pair.y >> skip) & mask;
+        wave_private_tile_fence();
+        if (lane < w) {
+            uint32_t k = k0, offset = offset0;
+            U64x2 packed;
+            packed.x = byte_swap64(gather_stream_word(fields, w, k, offset));
+            packed.y = byte_swap64(gather_stream_word(fields, w, k, offset));
+            stream_store(out + size_t(t) * w, packed);
+        }
+        wave_private_tile_fence();
+    }
+}
+
+__global__ void __launch_bounds__(kTileWaves * 64)
+    deserialize_tiles_kernel(const uint8_t* __restrict__ bytes, uint64_t* __restrict__ slab, const SerializeLayout layout,
+                             uint32_t logn, uint32_t skip, size_t bytes_per_poly) {
+    __shared__ uint64_t tiles[kTileWaves][kTileCoefficients + 2];  // the word after the last one may be read, never used
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t* words = tiles[wave];
+    const size_t row_index = blockIdx.x, poly = row_index / layout.rows;
+    const uint32_t r = static_cast<uint32_t>(row_index - poly * layout.rows);
+    const uint32_t w = layout.width[r], tiles_per_row = 1u << (logn - 7);
+    const U64x2* in = reinterpret_cast<const U64x2*>(bytes + poly * bytes_per_poly + layout.byte_offset[r]) + lane;
+    U64x2* out = reinterpret_cast<U64x2*>(slab + (row_index << logn)) + lane;
+    // coefficients 2 lane and 2 lane + 1 of a tile: the stream word each starts in and its bit offset there
+    const uint32_t bit_x = 2 * lane * w, bit_y = bit_x + w;
+    const uint32_t first_x = bit_x >> 6, offset_x = bit_x & 63, first_y = bit_y >> 6, offset_y = bit_y & 63;
+    for (uint32_t t = wave; t < tiles_per_row; t += kTileWaves) {
+        if (lane < w) {
+            const U64x2 pair = stream_load(in + size_t(t) * w);
+            words[2 * lane] = byte_swap64(pair.x);
+            words[2 * lane + 1] = byte_swap64(pair.y);
+        }
+        wave_private_tile_fence();
+        U64x2 value;
+        {
+            const uint64_t high = words[first_x], low = words[first_x + 1];
+            const uint64_t aligned = offset_x == 0 ? high : ((high << offset_x) | (low >> (64 - offset_x)));
+            value.x = (aligned >> (64 - w)) << skip;
+        }
+        {
+            const uint64_t high = words[first_y], low = words[first_y + 1];
+            const uint64_t aligned = offset_y == 0 ? high : ((high << offset_y) | (low >> (64 - offset_y)));
+            value.y = (aligned >> (64 - w)) << skip;
+        }
+        stream_store(out + size_t(t) * (kTileCoefficients / 2), value);
+        wave_private_tile_fence();
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -391,12 +492,27 @@ bool word_aligned(const SerializeLayout& layout, const void* bytes) {
         if ((layout.byte_offset[r] & 7) != 0) return false;
     return true;
 }
+// whole 128-coefficient tiles, every row, the record and both buffers on 16-byte boundaries
+bool tile_aligned(const SerializeLayout& layout, const void* bytes, const void* slab, uint32_t log_degree) {
+    if (log_degree < 7) return false;
+    if (((reinterpret_cast<uintptr_t>(bytes) | reinterpret_cast<uintptr_t>(slab)) & 15) != 0) return false;
+    for (uint32_t r = 0; r <= layout.rows; ++r)
+        if ((layout.byte_offset[r] & 15) != 0) return false;
+    for (uint32_t r = 0; r < layout.rows; ++r)
+        if (layout.width[r] == 0 || layout.width[r] > 64) return false;
+    return true;
+}
 }  // namespace
 
 hipError_t launch_serialize(const uint64_t* slab, uint8_t* bytes, const SerializeLayout& layout, uint32_t log_degree,
                             uint32_t skip_lsbs, size_t batch, hipStream_t stream) {
     const size_t total = batch * layout.byte_offset[layout.rows];
     if (total == 0) return hipSuccess;
+    if (tile_aligned(layout, bytes, slab, log_degree) && batch * layout.rows <= 0x7fffffffull) {
+        hipLaunchKernelGGL(serialize_tiles_kernel, dim3(static_cast<unsigned>(batch * layout.rows)), dim3(kTileWaves * 64), 0,
+                           stream, slab, bytes, layout, log_degree, skip_lsbs);
+        return hipGetLastError();
+    }
     if (word_aligned(layout, bytes)) {
         hipLaunchKernelGGL(serialize_words_kernel, dim3(grid_for(total >> 3)), dim3(256), 0, stream, slab,
                            reinterpret_cast<uint64_t*>(bytes), layout, log_degree, skip_lsbs, total >> 3);
@@ -411,6 +527,11 @@ hipError_t launch_deserialize(const uint8_t* bytes, uint64_t* slab, const Serial
                               uint32_t skip_lsbs, size_t bytes_per_poly, size_t batch, hipStream_t stream) {
     const size_t total = (batch * layout.rows) << log_degree;
     if (total == 0) return hipSuccess;
+    if (tile_aligned(layout, bytes, slab, log_degree) && (bytes_per_poly & 15) == 0 && batch * layout.rows <= 0x7fffffffull) {
+        hipLaunchKernelGGL(deserialize_tiles_kernel, dim3(static_cast<unsigned>(batch * layout.rows)), dim3(kTileWaves * 64),
+                           0, stream, bytes, slab, layout, log_degree, skip_lsbs, bytes_per_poly);
+        return hipGetLastError();
+    }
     if (word_aligned(layout, bytes) && (bytes_per_poly & 7) == 0) {
         hipLaunchKernelGGL(deserialize_words_kernel, dim3(grid_for(total)), dim3(256), 0, stream,
                            reinterpret_cast<const uint64_t*>(bytes), slab, layout, log_degree, skip_lsbs,

@@ -85,8 +85,10 @@ hipError_t launch_divide_and_round_q_last32(const uint32_t* in, uint32_t* out, c
                                             uint32_t moduli_count, size_t polys, hipStream_t stream);
 
 // seeded_kernels.hip: out[b] = PolyRq.random(context, NistAes128Ctr(seed: seeds[b])), seeds [batch][32] bytes
+// scratch: seeded_uniform_scratch_bytes(ctx, batch) bytes (the per-chunk round keys of every seed's re-key chain)
+size_t seeded_uniform_scratch_bytes(const DeviceContext& ctx, size_t batch);
 hipError_t launch_seeded_uniform(const uint8_t* seeds, uint64_t* out, const DeviceContext& ctx, size_t batch,
-                                 hipStream_t stream);
+                                 void* scratch, hipStream_t stream);
 
 // wire format of a polynomial: per residue row, the serialized bit width and the byte offset of the row
 constexpr uint32_t kMaxSerializedRows = 64;

@@ -226,7 +226,8 @@ def test_serialize_known_answers(kats):
 
 
 @pytest.mark.parametrize("degree,bits", [(32, [14, 16, 21, 22, 27]), (8192, [55, 55, 55, 55]), (4096, [27, 28, 28]),
-                                         (64, [62, 33, 8])])
+                                         (64, [62, 33, 8]), (128, [62, 33, 8]), (256, [9, 17, 40, 62]),
+                                         (1024, [62, 61, 50])])
 def test_serialize_matches_oracle(oracle, degree, bits):
     import torch
 
@@ -247,6 +248,34 @@ def test_serialize_matches_oracle(oracle, degree, bits):
             assert np.array_equal(back, slab)
 
 
+@pytest.mark.parametrize("misalignment", [8, 1])
+def test_serialize_into_misaligned_buffers(oracle, misalignment):
+    """The 16-byte tile kernels need aligned buffers; records at 8-byte and at odd addresses take the word and the byte
+    kernels and must give the same bytes (PolyRq+Serialize.swift:69-99 knows nothing of alignment)."""
+    import ctypes
+
+    import torch
+
+    degree, moduli = 256, oracle.generate_primes([55, 40], False, 1)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    slab = _uniform(np.random.default_rng(5), (2,), moduli, degree)
+    expected = ref.serialize(slab, 0)
+    per_poly = ours.serialization_byte_count(0)
+    lib = heamd.load_library()
+    device_slab = heamd.to_device(slab)
+    buffer = torch.zeros(2 * per_poly + 64, dtype=torch.uint8, device="cuda")
+    view = buffer[misalignment: misalignment + 2 * per_poly]
+    assert lib.he_poly_serialize_device(ours.h, ctypes.c_void_p(device_slab.data_ptr()), 2, 0,
+                                        ctypes.c_void_p(view.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(view.cpu().numpy().reshape(2, per_poly), expected)
+    back = torch.zeros_like(device_slab)
+    assert lib.he_poly_deserialize_device(ours.h, ctypes.c_void_p(view.data_ptr()), per_poly, 2, 0,
+                                          ctypes.c_void_p(back.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(heamd.to_host(back), slab)
+
+
 def test_deserialize_rejects_short_records(oracle):
     import torch
 
@@ -264,7 +293,7 @@ def test_deserialize_rejects_short_records(oracle):
 
 
 @pytest.mark.parametrize("degree,bits,batch", [(512, [55, 40, 20], 5), (16, [20, 21], 3), (8192, [55, 55, 55, 55], 3),
-                                                (4096, [27, 28, 28], 9)])
+                                                (4096, [27, 28, 28], 9), (64, [30, 31, 33], 70)])
 def test_seeded_polynomials_match_oracle(oracle, degree, bits, batch):
     """`a` of a seeded ciphertext (SerializedCiphertext.swift:53-58): AES-128 CTR_DRBG stream, 4096-byte refills,
     128 bits per coefficient reduced mod q_i -- word-exact against the oracle (itself pinned by the NIST vectors)."""
