@@ -168,7 +168,7 @@ int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L
 hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t* spread, const PolyContext& ks_ctx,
                           uint32_t L, size_t polys, hipStream_t stream) {
     const DeviceContext ks = ks_ctx.device_context();
-    hipError_t e = heamd::launch_ntt_spread(target, target_stride, L, polys, spread, ks, stream);
+    hipError_t e = heamd::launch_ntt_spread(target, target_stride, L, polys, spread, ks, 0, stream);
     if (e != hipErrorNotSupported) return e;
     (void)hipGetLastError();
     e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
@@ -240,6 +240,38 @@ int key_switch_pipeline_grouped(const he_bfv_context* ctx, uint32_t L, const W* 
     return HE_OK;
 }
 
+// g^-1 mod 2N for odd g (Newton iteration doubles the correct low bits)
+uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
+    uint64_t x = g;  // correct to 3 bits
+    for (int k = 0; k < 6; ++k) x *= 2 - g * x;
+    return static_cast<uint32_t>(x & (modulus - 1));
+}
+
+// Bfv.applyGalois (Bfv.swift:174-198) without a rotated copy of the ciphertext: the automorphism of c1 happens as the
+// decomposition's transform loads its rows, that of c0 as the last kernel adds it to the update; expand_shift != 0
+// turns that last kernel into one step of PirUtil.expand (rns_kernels.hpp, launch_galois_finish).  One key per group of
+// `group_size` consecutive ciphertexts.  hipErrorNotSupported (nothing launched): the degree has no tiled transform.
+hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* ct, uint32_t galois_inverse,
+                               const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* out,
+                               uint32_t expand_shift, uint64_t* spread, uint64_t* prod, hipStream_t stream) {
+    const PolyContext* ks_ctx = ctx->impl->key_switching(L);
+    const DeviceContext ks = ks_ctx->device_context();
+    const size_t n = ctx->impl->degree(), batch = groups * group_size, ct_stride = 2 * size_t(L) * n;
+    hipError_t e = heamd::launch_ntt_spread(ct + size_t(L) * n, ct_stride, L, batch, spread, ks, galois_inverse, stream);
+    if (e != hipSuccess) return e;
+    for (size_t g = 0; g < groups;) {
+        size_t run = 1;
+        while (g + run < groups && keys[g + run] == keys[g]) ++run;
+        const size_t first = g * group_size, polys = run * group_size;
+        e = key_mac_to_coeff(static_cast<const uint64_t*>(spread) + first * L * (L + 1) * n, keys[g],
+                             prod + first * 2 * (L + 1) * n, *ks_ctx, L, ctx->impl->top_level() + 1, polys, stream);
+        if (e != hipSuccess) return e;
+        g += run;
+    }
+    return heamd::launch_galois_finish(static_cast<const uint64_t*>(prod), ct, ct_stride, out, ks, L, batch,
+                                       galois_inverse, expand_shift, stream);
+}
+
 template <typename W>
 int relinearize_pipeline(const he_bfv_context* ctx, uint32_t L, const W* ct3, const W* key, W* out, size_t batch,
                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -257,6 +289,30 @@ int relinearize_pipeline(const he_bfv_context* ctx, uint32_t L, const W* ct3, co
 }
 
 }  // namespace
+
+namespace heamd {
+// One level of PirUtil.expand (PirUtil.swift:204-236) for parents whose Galois element has its own key: the children
+// (parent + applyGalois(parent), (parent - applyGalois(parent)) x^shift) leave the key switch's last kernel directly.
+// Returns kExpandStepUnavailable when the degree has no tiled transform (the caller composes the step from
+// he_bfv_apply_galois_grouped_device and the expand-step kernel instead).
+int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* parents, uint64_t element,
+                          const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* next, uint32_t shift,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t n = ctx->impl->degree(), batch = groups * group_size;
+    if (batch == 0) return HE_OK;
+    if (workspace_bytes < he_bfv_apply_galois_workspace_bytes(ctx, L, batch)) return invalid_argument("workspace too small");
+    uint64_t* spread = static_cast<uint64_t*>(workspace);    // [batch][L][L+1][N]
+    uint64_t* prod = spread + batch * L * (L + 1) * n;       // [batch][2][L+1][N]
+    const hipError_t e = galois_switch_fused(ctx, L, parents, inverse_mod_power_of_two(element, 2 * n), keys, groups,
+                                             group_size, next, shift, spread, prod, stream);
+    if (e == hipErrorNotSupported) {
+        (void)hipGetLastError();
+        return kExpandStepUnavailable;
+    }
+    HEAMD_HIP_TRY(e);
+    return HE_OK;
+}
+}  // namespace heamd
 
 extern "C" {
 
@@ -386,12 +442,6 @@ namespace {
 bool is_valid_galois_element(uint64_t element, uint64_t degree) {  // Galois.swift:100-105
     return degree != 0 && (degree & (degree - 1)) == 0 && (element & 1) == 1 && element < (degree << 1) && element > 1;
 }
-// g^-1 mod 2N for odd g (Newton iteration doubles the correct low bits)
-uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
-    uint64_t x = g;  // correct to 3 bits
-    for (int k = 0; k < 6; ++k) x *= 2 - g * x;
-    return static_cast<uint32_t>(x & (modulus - 1));
-}
 }  // namespace
 }  // extern "C++"
 
@@ -456,8 +506,20 @@ int apply_galois_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W
     W* prod = spread + batch * L * (L + 1) * n;            // [batch][2][L+1][N]
     const size_t ct_stride = 2 * size_t(L) * n;
     // Bfv.swift:190-196: c0' = galois(c0) + update0, c1' = update1, update = keySwitch(galois(c1))
-    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
-                                             inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
+    const uint32_t galois_inverse = inverse_mod_power_of_two(element, 2 * n);
+    if constexpr (sizeof(W) == 8) {
+        if (static_cast<const void*>(ct) != static_cast<const void*>(out)) {  // the fused kernels read ct to the end
+            const uint64_t* key = reinterpret_cast<const uint64_t*>(galois_key);
+            const hipError_t e = galois_switch_fused(ctx, L, reinterpret_cast<const uint64_t*>(ct), galois_inverse, &key, 1,
+                                                     batch, reinterpret_cast<uint64_t*>(out), 0,
+                                                     reinterpret_cast<uint64_t*>(spread), reinterpret_cast<uint64_t*>(prod),
+                                                     stream);
+            if (e == hipSuccess) return HE_OK;
+            if (e != hipErrorNotSupported) HEAMD_HIP_TRY(e);
+            (void)hipGetLastError();
+        }
+    }
+    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L), galois_inverse, batch * 2 * L, stream));
     return key_switch_pipeline(ctx, L, static_cast<const W*>(rotated) + size_t(L) * n, ct_stride,
                                static_cast<const W*>(rotated), ct_stride, galois_key, out, batch, 1, spread, prod, stream);
 }
@@ -501,8 +563,15 @@ int he_bfv_apply_galois_grouped_device(const he_bfv_context* ctx, uint32_t modul
     uint64_t* spread = rotated + batch * 2 * L * n;             // [batch][L][L+1][N]
     uint64_t* prod = spread + batch * L * (L + 1) * n;          // [batch][2][L+1][N]
     const size_t ct_stride = 2 * size_t(L) * n;
-    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L),
-                                             inverse_mod_power_of_two(element, 2 * n), batch * 2 * L, stream));
+    const uint32_t galois_inverse = inverse_mod_power_of_two(element, 2 * n);
+    if (ct != out) {
+        const hipError_t e =
+            galois_switch_fused(ctx, L, ct, galois_inverse, galois_keys, groups, group_size, out, 0, spread, prod, stream);
+        if (e == hipSuccess) return HE_OK;
+        if (e != hipErrorNotSupported) HEAMD_HIP_TRY(e);
+        (void)hipGetLastError();
+    }
+    HEAMD_HIP_TRY(heamd::launch_galois_coeff(ct, rotated, q_ctx->device_context(L), galois_inverse, batch * 2 * L, stream));
     return key_switch_pipeline_grouped<uint64_t>(ctx, L, rotated + size_t(L) * n, ct_stride, rotated, ct_stride,
                                                  galois_keys, groups, group_size, out, 1, spread, prod, stream);
 }

@@ -25,10 +25,11 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
                       size_t rows, hipStream_t stream, int force_variant = kNttVariantAuto);
 // Key-switching decomposition fused into the forward NTT (Bfv+Keys.swift:165-179): spread [polys][L][L+1][N] row
 // (poly, j, r) = NTT_{ks modulus r}( source row j of polynomial `poly`, reduced mod r when q_j > modulus r ), read
-// from source + poly * poly_stride + j * N.  hipErrorNotSupported for degrees without a tiled kernel (the caller
-// then runs launch_key_switch_spread + launch_ntt).
+// from source + poly * poly_stride + j * N.  galois_inverse = g^-1 mod 2N: the source polynomial is first taken through
+// f(x) -> f(x^g) (Coeff form, PolyRq/Galois.swift:115-143) as its rows are loaded; 0: as it is.
+// hipErrorNotSupported for degrees without a tiled kernel (the caller then runs launch_key_switch_spread + launch_ntt).
 hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
-                             uint64_t* spread, const DeviceContext& ks_ctx, hipStream_t stream);
+                             uint64_t* spread, const DeviceContext& ks_ctx, uint32_t galois_inverse, hipStream_t stream);
 // Plaintext.convertToEvalFormat fused into the forward NTT (Plaintext.swift:149-170): out [polys][L][N] row (poly, r)
 // = NTT_{q_r}(centred lift of plaintexts[poly][N] mod q_r).  hipErrorNotSupported for degrees without a tiled kernel.
 hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulus, size_t polys, uint64_t* out,

@@ -115,7 +115,9 @@ __device__ __forceinline__ void locate_rows(const RowMap& map, uint32_t block, s
 // this kernel read it back) is applied to the words as they are loaded.
 //   kSourceSpread  the key-switching decomposition (Bfv+Keys.swift:165-179): output row (poly, j, r) of a
 //                  [polys][L][L+1][N] slab is the transform mod ks_modulus[r] of row j of polynomial `poly`, read
-//                  straight from the ciphertext and reduced mod r first when q_j > modulus r;
+//                  straight from the ciphertext and reduced mod r first when q_j > modulus r; with galois_inverse
+//                  set, of row j of the polynomial's image under the automorphism (Bfv.applyGalois key-switches
+//                  galois(c1), Bfv.swift:190-196): the row is read in order and permuted through the LDS tile;
 //   kSourceLift    Plaintext.convertToEvalFormat (Plaintext.swift:149-170): output row (poly, r) of a [polys][L][N]
 //                  slab is the transform mod q_r of the centred lift of plaintext `poly` ([N] values < t):
 //                  x < (t + 1) / 2 ? x : x + (q_r - t).
@@ -125,6 +127,9 @@ struct SpreadSource {
     size_t stride;
     uint32_t L;            // source rows per polynomial (1 for a plaintext)
     uint64_t plaintext_modulus;
+    // kSourceSpread only: g^-1 mod 2N when the source polynomial is to be taken through f(x) -> f(x^g) first
+    // (PolyRq/Galois.swift:115-143), 0 otherwise
+    uint32_t galois_inverse;
 };
 
 constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
@@ -274,6 +279,26 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 // the split butterflies take any 64-bit multiplicand and have room for an addend below 2p, so they
                 // transform a residue below 2p as it is
                 reduce[k] = SPREAD == kSourceSpread && ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p);
+                if constexpr (SPREAD == kSourceSpread) {
+                    if (spread.galois_inverse != 0) {
+                        // output coefficient e takes source coefficient i = e g^-1 mod 2N, negated mod q_j when i >= N.
+                        // The row sits in the tile in order; consecutive lanes read words an odd stride apart, which
+                        // spreads over all banks.
+                        const uint64_t source_modulus = ctx.moduli[j].p;
+                        if (k > 0) __syncthreads();
+#pragma unroll
+                        for (int r = 0; r < E; ++r) lds[element_index<LOGN, LOGE, LO0, LOGE>(r, tid)] = v[k][r];
+                        __syncthreads();
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            const uint32_t doubled = (element_index<LOGN, LOGE, LO0, LOGE>(r, tid) * spread.galois_inverse) &
+                                                     ((2u << LOGN) - 1u);
+                            const uint64_t x = lds[doubled & ((1u << LOGN) - 1u)];
+                            v[k][r] = (doubled >> LOGN) != 0 && x != 0 ? source_modulus - x : x;
+                        }
+                        if (k + 1 == ROWS) __syncthreads();  // the transform's exchanges reuse the tile
+                    }
+                }
             }
             if constexpr (SPREAD == kSourceLift) {
                 const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
@@ -609,7 +634,7 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
                         const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
-                                                             SpreadSource{nullptr, 0, 0, 0}, stream, row_period,
+                                                             SpreadSource{nullptr, 0, 0, 0, 0}, stream, row_period,
                                                              row_offset);
     }
     constexpr int LOGE = LOGN - LOGT;
@@ -675,12 +700,12 @@ int production_mode(const DeviceContext& ctx) {
 }  // namespace
 
 hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
-                             uint64_t* spread, const DeviceContext& ks_ctx, hipStream_t stream) {
+                             uint64_t* spread, const DeviceContext& ks_ctx, uint32_t galois_inverse, hipStream_t stream) {
     const uint32_t period = source_moduli + 1;
     const size_t rows = polys * source_moduli * period;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30) || ks_ctx.moduli_count < period) return hipErrorInvalidValue;
-    const SpreadSource src{source, poly_stride, source_moduli, 0};
+    const SpreadSource src{source, poly_stride, source_moduli, 0, galois_inverse};
     const int mode = production_mode(ks_ctx);
     switch (ks_ctx.log_degree) {
         case 12: return launch_forward_tiled<12, 9, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
@@ -696,7 +721,7 @@ hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulu
     const size_t rows = polys * period;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
-    const SpreadSource src{plaintexts, size_t(1) << ctx.log_degree, 1, plaintext_modulus};
+    const SpreadSource src{plaintexts, size_t(1) << ctx.log_degree, 1, plaintext_modulus, 0};
     const int mode = production_mode(ctx);
     switch (ctx.log_degree) {
         case 12: return launch_forward_tiled<12, 9, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);

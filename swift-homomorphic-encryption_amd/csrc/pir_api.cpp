@@ -393,6 +393,19 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
         }
         const uint64_t element = galois_elements[best];
         const int applications = 1 << (floor_log2_size(target - 1) - floor_log2_size(element - 1));
+        // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
+        const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
+        uint64_t* next = buffers[depth % 2];
+        if (applications == 1) {  // the element has its own key: the children leave the key switch directly
+            status = heamd::bfv_expand_step_fused(ctx, L, parents, element, level_keys.data(), queries, batch, next, shift,
+                                                  workspace_mem.get(), workspace_bytes, stream);
+            if (status == HE_OK) {
+                cur = next;
+                continue;
+            }
+            if (status != heamd::kExpandStepUnavailable) break;
+            status = HE_OK;
+        }
         const uint64_t* c1 = parents;
         for (int a = 0; a < applications && status == HE_OK; ++a) {  // applyGalois(element) until x -> x^target
             uint64_t* dst = (a % 2 == 0) ? rotated : tmp;
@@ -401,9 +414,6 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
             c1 = dst;
         }
         if (status != HE_OK) break;
-        // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
-        const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
-        uint64_t* next = buffers[depth % 2];
         HEAMD_HIP_TRY(heamd::launch_expand_step(parents, c1, next, q_device, shift, queries * batch, stream));
         cur = next;
     }

@@ -358,11 +358,18 @@ __global__ void __launch_bounds__(kThreads)
 // ---- key switching, step 4: drop the special modulus and add into the ciphertext (Bfv.swift:216-217) --------------
 // prod: [polys][2][L+1][N] Coeff over (q_0..q_{L-1}, q_ks); ct: poly c of item at ct_base + item*ct_stride + c*L*N;
 // out: [polys][2][L][N] = ct + divideAndRoundQLast(prod)
-template <typename W>
+// MODE kFinishGalois: the ciphertext is the one BEFORE the automorphism and its c0 term is read through it here
+// (Bfv.swift:190-196: c0' = galois(c0) + update0, c1' = update1) -- coefficient k takes source coefficient
+// i = k g^-1 mod 2N, negated when i >= N (PolyRq/Galois.swift:115-143).
+// MODE kFinishExpand: on top of that, one step of PirUtil.expand (PirUtil.swift:204-236): with c' = applyGalois(ct),
+// out [2 polys][2][L][N] holds the children ct + c' and (ct - c') x^shift, interleaved; the second one is written
+// where its coefficient lands (k + shift mod 2N, negated past N) instead of being gathered by another kernel.
+constexpr int kFinishPlain = 0, kFinishGalois = 1, kFinishExpand = 2;
+template <typename W, int MODE>
 __global__ void __launch_bounds__(kThreads)
     key_switch_finish_kernel(const W* __restrict__ prod, const W* __restrict__ ct_base, size_t ct_stride,
                              W* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
-                             uint32_t added_polys) {
+                             uint32_t added_polys, uint32_t galois_inverse, uint32_t expand_shift) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = (polys * 2) << logn;
@@ -373,8 +380,25 @@ __global__ void __launch_bounds__(kThreads)
         const size_t pc = idx >> logn;  // poly * 2 + c
         const size_t poly = pc >> 1, c = pc & 1;
         const W* src = prod + pc * (L + 1) * n + k;
-        const W* ct = ct_base + poly * ct_stride + c * L * n + k;
-        W* dst = out + pc * L * n + k;
+        const W* ct_poly = ct_base + poly * ct_stride + c * L * n;
+        const W* ct = ct_poly + k;
+        W* dst = out + (MODE == kFinishExpand ? (2 * poly * 2 + c) : pc) * L * n + k;
+        // the automorphism's source coefficient and sign for this k (used for c0 only)
+        [[maybe_unused]] uint32_t galois_source = 0;
+        [[maybe_unused]] bool galois_negate = false;
+        if constexpr (MODE != kFinishPlain) {
+            const uint32_t doubled = (static_cast<uint32_t>(k) * galois_inverse) & static_cast<uint32_t>(2 * n - 1);
+            galois_negate = doubled >= n;
+            galois_source = doubled & static_cast<uint32_t>(n - 1);
+        }
+        // where coefficient k of (ct - c') x^shift lands, and whether it changes sign on the way
+        [[maybe_unused]] size_t moved = 0;
+        [[maybe_unused]] bool moved_negate = false;
+        if constexpr (MODE == kFinishExpand) {
+            const uint32_t doubled = (static_cast<uint32_t>(k) + expand_shift) & static_cast<uint32_t>(2 * n - 1);
+            moved_negate = doubled >= n;
+            moved = doubled & static_cast<uint32_t>(n - 1);
+        }
         // divideAndRoundQLast by the centred representative of the special-modulus word (poly_kernels.hip has the
         // derivation): out_i = (x_i - c) q_ks^-1 mod q_i
         const uint64_t r = add_mod_uniform(stream_load(src + size_t(L) * n), q_last_div2, q_last);
@@ -387,9 +411,26 @@ __global__ void __launch_bounds__(kThreads)
             const uint64_t x = stream_load(src + row * n);
             const uint64_t v = shoup_mul_uniform(negative ? add_mod_uniform(x, t, m.p) : sub_mod_uniform(x, t, m.p),
                                                  inv.x, inv.y, m.p);
-            // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
-            // replaces c1 (Bfv.swift:194-195)
-            stream_store(dst + row * n, c < added_polys ? add_mod_uniform(stream_load(ct + row * n), v, m.p) : v);
+            if constexpr (MODE == kFinishPlain) {
+                // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
+                // replaces c1 (Bfv.swift:194-195)
+                stream_store(dst + row * n, c < added_polys ? add_mod_uniform(stream_load(ct + row * n), v, m.p) : v);
+            } else {
+                uint64_t rotated = v;  // c' = applyGalois(ct), polynomial c, coefficient k
+                if (c == 0) {
+                    const uint64_t word = ct_poly[row * n + galois_source];
+                    rotated = add_mod_uniform(galois_negate ? neg_mod_uniform(word, m.p) : word, v, m.p);
+                }
+                if constexpr (MODE == kFinishGalois) {
+                    stream_store(dst + row * n, rotated);
+                } else {
+                    const uint64_t own = ct[row * n];
+                    stream_store(dst + row * n, add_mod_uniform(own, rotated, m.p));
+                    const uint64_t difference = sub_mod_uniform(own, rotated, m.p);
+                    stream_store(dst + (2 * L + row) * n - k + moved,
+                                 moved_negate ? neg_mod_uniform(difference, m.p) : difference);
+                }
+            }
         }
     }
 }
@@ -553,8 +594,23 @@ template <typename W>
 hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                     uint32_t L, size_t polys, uint32_t added_polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
-    hipLaunchKernelGGL(key_switch_finish_kernel<W>, dim3(grid_for((polys * 2) << ks.log_degree)), dim3(kThreads), 0,
-                       stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys);
+    hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishPlain>), dim3(grid_for((polys * 2) << ks.log_degree)),
+                       dim3(kThreads), 0, stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys, 0u, 0u);
+    return hipGetLastError();
+}
+
+template <typename W>
+hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
+                                uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
+                                hipStream_t stream) {
+    if (polys == 0) return hipSuccess;
+    const dim3 grid(grid_for((polys * 2) << ks.log_degree));
+    if (expand_shift != 0)
+        hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishExpand>), grid, dim3(kThreads), 0, stream, prod, ct_base,
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, expand_shift);
+    else
+        hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishGalois>), grid, dim3(kThreads), 0, stream, prod, ct_base,
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, 0u);
     return hipGetLastError();
 }
 
@@ -574,7 +630,9 @@ hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_s
     template hipError_t launch_key_switch_mac<W>(const W*, const W*, W*, const DeviceContext&, uint32_t, uint32_t,        \
                                                  size_t, hipStream_t);                                                    \
     template hipError_t launch_key_switch_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t,       \
-                                                    size_t, uint32_t, hipStream_t);
+                                                    size_t, uint32_t, hipStream_t);                                       \
+    template hipError_t launch_galois_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t, size_t,   \
+                                                uint32_t, uint32_t, hipStream_t);
 HEAMD_INSTANTIATE_RNS(uint64_t)
 HEAMD_INSTANTIATE_RNS(uint32_t)
 #undef HEAMD_INSTANTIATE_RNS

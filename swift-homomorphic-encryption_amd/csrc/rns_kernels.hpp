@@ -50,5 +50,13 @@ hipError_t launch_scale_and_round(const W* in, W* out, const RnsToolDevice& tool
 template <typename W>
 hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                     uint32_t L, size_t polys, uint32_t added_polys, hipStream_t stream);
+// The same for Bfv.applyGalois with `ct` the ciphertext BEFORE the automorphism (Bfv.swift:190-196):
+// c' = (galois(ct.c0) + update0, update1), galois_inverse = g^-1 mod 2N.  expand_shift = 0: out [polys][2][L][N] = c';
+// otherwise one PirUtil.expand step (PirUtil.swift:204-236): out [2 polys][2][L][N] = the children
+// ct + c' and (ct - c') x^expand_shift, interleaved.  out must not alias ct.
+template <typename W>
+hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
+                                uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
+                                hipStream_t stream);
 
 }  // namespace heamd

@@ -126,6 +126,32 @@ def test_bfv_apply_galois_config3_shape(oracle):
     assert np.array_equal(got, ref.apply_galois(cts, element, key))
 
 
+@pytest.mark.parametrize("degree,bits", [(4096, [50, 55, 45, 55]), (8192, [55, 41, 55]), (16384, [55, 55, 48, 55])])
+def test_bfv_apply_galois_fused_path(oracle, degree, bits):
+    """Degrees with a tiled transform take Bfv.applyGalois without a rotated copy (the automorphism rides the
+    decomposition's loads and the last kernel's c0 term): every word equals the oracle's for elements that only flip
+    signs (N + 1), reverse (2N - 1) and scatter (3, N/2 + 1), with ciphertext moduli above and below the key-switching
+    ones; the in-place call (out = ct, which keeps the rotated copy) gives the same words."""
+    import ctypes
+
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, 65537, q), oracle.BfvContext(degree, 65537, q)
+    rng = np.random.default_rng(degree)
+    cts = _uniform(rng, (3, 2), q[:-1], degree)
+    cts[0, :, :, :5] = 0
+    key = _uniform(rng, (ours.L, 2), q, degree)
+    device_key = heamd.to_device(key)
+    for element in (degree + 1, 2 * degree - 1, 3, degree // 2 + 1):
+        expected = ref.apply_galois(cts, element, key)
+        got = heamd.to_host(ours.apply_galois(heamd.to_device(cts), element, device_key))
+        assert np.array_equal(got, expected), element
+    in_place = heamd.to_device(cts)
+    ptr = ctypes.c_void_p(in_place.data_ptr())
+    assert heamd.load_library().he_bfv_apply_galois_device(ours.h, ours.L, ptr, 3, ctypes.c_void_p(device_key.data_ptr()), ptr,
+                                                           3, None, 0, None) == 0
+    assert np.array_equal(heamd.to_host(in_place), ref.apply_galois(cts, 3, key))
+
+
 def test_plaintext_conversions_match_oracle(oracle, small):
     ours, ref, client = small
     rng = np.random.default_rng(53)

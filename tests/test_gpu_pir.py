@@ -116,6 +116,27 @@ def test_pir_expand_matches_oracle_and_decrypts(oracle, small, total, ones, key_
             assert client.decrypt(got[index]) == [1 if index in ones else 0] + [0] * (n - 1), index
 
 
+@pytest.mark.parametrize("total,key_shifts", [(6, None), (13, None), (8, [2])])
+def test_pir_expand_fused_levels(oracle, total, key_shifts):
+    """PirUtil.expand on a ring with a tiled transform (N=4096): levels whose Galois element has its own key leave the
+    key switch as children directly (no rotated copy, no separate step kernel); with key_shifts=[2] the first levels
+    reach their element by repeated application and take the composed path.  Uniform words, word-exact against the
+    oracle's recursion; the same for two queries with different keys in one call."""
+    degree = 4096
+    q = oracle.generate_primes([50, 45, 55], False, degree)
+    ours, ref = heamd.BfvContext(degree, 65537, q), oracle.BfvContext(degree, 65537, q)
+    rng = np.random.default_rng(100 + total)
+    shifts = key_shifts if key_shifts is not None else list(range(0, (total - 1).bit_length()))
+    queries = _uniform(rng, (2, 1, 2), q[:-1], degree)
+    keys = [{(degree >> k) + 1: _uniform(rng, (ours.L, 2), q, degree) for k in shifts} for _ in range(2)]
+    expected = [oracle.pir.expand(ref, queries[i], total, keys[i]) for i in range(2)]
+    device_keys = [{e: heamd.to_device(k) for e, k in keys[i].items()} for i in range(2)]
+    got = heamd.to_host(ours.pir_expand(heamd.to_device(queries[0]), total, device_keys[0]))
+    assert np.array_equal(got, expected[0])
+    both = heamd.to_host(ours.pir_expand_batch(heamd.to_device(queries), total, device_keys))
+    assert np.array_equal(both[0], expected[0]) and np.array_equal(both[1], expected[1])
+
+
 def test_pir_expand_two_query_ciphertexts(oracle, small):
     """More outputs than one ciphertext can carry: the second ciphertext expands the remainder (PirUtil.swift:327-333)."""
     ours, ref, client = small
