@@ -14,9 +14,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "swift-homomorphic-encryption_amd"))
 
 
-def _timed(torch, fn, reps, warmup=2):
+def _timed(torch, fn, reps, warmup=2, settle_s=0.03):
+    """Seconds per call.  The first calls after another kernel mix run at whatever clocks that mix left behind (N=4096
+    NTTs measured 18 % slow over 12 launches): warm up for at least `settle_s` of GPU time, and time at least as long."""
+    import time
+
     for _ in range(warmup):
         fn()
+    torch.cuda.synchronize()
+    begin, extra = time.perf_counter(), 0
+    while time.perf_counter() - begin < settle_s:
+        fn()
+        torch.cuda.synchronize()
+        extra += 1
+    per_call = (time.perf_counter() - begin) / max(extra, 1)
+    reps = max(reps, int(2 * settle_s / max(per_call, 1e-6)))
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     start.record()
