@@ -51,7 +51,8 @@ inline void keep_scratch_cached() {
 constexpr int kExpandStepUnavailable = -1;
 int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* parents, uint64_t element,
                           const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* next, uint32_t shift,
-                          void* workspace, size_t workspace_bytes, hipStream_t stream);
+                          const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream);
 
 // Stream-ordered scratch buffer (hipMallocAsync / hipFreeAsync on the same stream).
 class Scratch {

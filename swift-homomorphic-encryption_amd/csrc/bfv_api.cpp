@@ -253,7 +253,8 @@ uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
 // `group_size` consecutive ciphertexts.  hipErrorNotSupported (nothing launched): the degree has no tiled transform.
 hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* ct, uint32_t galois_inverse,
                                const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* out,
-                               uint32_t expand_shift, uint64_t* spread, uint64_t* prod, hipStream_t stream) {
+                               uint32_t expand_shift, const heamd::ExpandTargets& targets, uint64_t* spread, uint64_t* prod,
+                               hipStream_t stream) {
     const PolyContext* ks_ctx = ctx->impl->key_switching(L);
     const DeviceContext ks = ks_ctx->device_context();
     const size_t n = ctx->impl->degree(), batch = groups * group_size, ct_stride = 2 * size_t(L) * n;
@@ -269,7 +270,7 @@ hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint
         g += run;
     }
     return heamd::launch_galois_finish(static_cast<const uint64_t*>(prod), ct, ct_stride, out, ks, L, batch,
-                                       galois_inverse, expand_shift, stream);
+                                       galois_inverse, expand_shift, targets, stream);
 }
 
 template <typename W>
@@ -293,18 +294,22 @@ int relinearize_pipeline(const he_bfv_context* ctx, uint32_t L, const W* ct3, co
 namespace heamd {
 // One level of PirUtil.expand (PirUtil.swift:204-236) for parents whose Galois element has its own key: the children
 // (parent + applyGalois(parent), (parent - applyGalois(parent)) x^shift) leave the key switch's last kernel directly.
+// leaf_table != nullptr: the children are leaves and go to their output slots in `next` = the expansion's output
+// (rns_kernels.hpp, ExpandTargets; leaf_stride = outputs per query).
 // Returns kExpandStepUnavailable when the degree has no tiled transform (the caller composes the step from
 // he_bfv_apply_galois_grouped_device and the expand-step kernel instead).
 int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* parents, uint64_t element,
                           const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* next, uint32_t shift,
-                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                          const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
     const size_t n = ctx->impl->degree(), batch = groups * group_size;
     if (batch == 0) return HE_OK;
     if (workspace_bytes < he_bfv_apply_galois_workspace_bytes(ctx, L, batch)) return invalid_argument("workspace too small");
     uint64_t* spread = static_cast<uint64_t*>(workspace);    // [batch][L][L+1][N]
     uint64_t* prod = spread + batch * L * (L + 1) * n;       // [batch][2][L+1][N]
     const hipError_t e = galois_switch_fused(ctx, L, parents, inverse_mod_power_of_two(element, 2 * n), keys, groups,
-                                             group_size, next, shift, spread, prod, stream);
+                                             group_size, next, shift, heamd::ExpandTargets{leaf_table, group_size, leaf_stride},
+                                             spread, prod, stream);
     if (e == hipErrorNotSupported) {
         (void)hipGetLastError();
         return kExpandStepUnavailable;
@@ -512,8 +517,8 @@ int apply_galois_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W
             const uint64_t* key = reinterpret_cast<const uint64_t*>(galois_key);
             const hipError_t e = galois_switch_fused(ctx, L, reinterpret_cast<const uint64_t*>(ct), galois_inverse, &key, 1,
                                                      batch, reinterpret_cast<uint64_t*>(out), 0,
-                                                     reinterpret_cast<uint64_t*>(spread), reinterpret_cast<uint64_t*>(prod),
-                                                     stream);
+                                                     heamd::ExpandTargets{nullptr, 1, 0}, reinterpret_cast<uint64_t*>(spread),
+                                                     reinterpret_cast<uint64_t*>(prod), stream);
             if (e == hipSuccess) return HE_OK;
             if (e != hipErrorNotSupported) HEAMD_HIP_TRY(e);
             (void)hipGetLastError();
@@ -566,7 +571,8 @@ int he_bfv_apply_galois_grouped_device(const he_bfv_context* ctx, uint32_t modul
     const uint32_t galois_inverse = inverse_mod_power_of_two(element, 2 * n);
     if (ct != out) {
         const hipError_t e =
-            galois_switch_fused(ctx, L, ct, galois_inverse, galois_keys, groups, group_size, out, 0, spread, prod, stream);
+            galois_switch_fused(ctx, L, ct, galois_inverse, galois_keys, groups, group_size, out, 0,
+                                heamd::ExpandTargets{nullptr, 1, 0}, spread, prod, stream);
         if (e == hipSuccess) return HE_OK;
         if (e != hipErrorNotSupported) HEAMD_HIP_TRY(e);
         (void)hipGetLastError();

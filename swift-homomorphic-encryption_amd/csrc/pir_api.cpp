@@ -397,9 +397,15 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
         const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
         uint64_t* next = buffers[depth % 2];
         if (applications == 1) {  // the element has its own key: the children leave the key switch directly
-            status = heamd::bfv_expand_step_fused(ctx, L, parents, element, level_keys.data(), queries, batch, next, shift,
-                                                  workspace_mem.get(), workspace_bytes, stream);
+            // ... and when all of them are leaves, for their output slots (the next level's leaf table is in node order)
+            const bool to_outputs = depth + 1 < levels.size() && moves[depth + 1].parent_count == 0 &&
+                                    moves[depth + 1].leaf_count == 2 * batch;
+            status = heamd::bfv_expand_step_fused(
+                ctx, L, parents, element, level_keys.data(), queries, batch, to_outputs ? out : next, shift,
+                to_outputs ? table_device + moves[depth + 1].leaf_offset : nullptr, output_count, workspace_mem.get(),
+                workspace_bytes, stream);
             if (status == HE_OK) {
+                if (to_outputs) break;  // nothing below this level
                 cur = next;
                 continue;
             }

@@ -363,13 +363,15 @@ __global__ void __launch_bounds__(kThreads)
 // i = k g^-1 mod 2N, negated when i >= N (PolyRq/Galois.swift:115-143).
 // MODE kFinishExpand: on top of that, one step of PirUtil.expand (PirUtil.swift:204-236): with c' = applyGalois(ct),
 // out [2 polys][2][L][N] holds the children ct + c' and (ct - c') x^shift, interleaved; the second one is written
-// where its coefficient lands (k + shift mod 2N, negated past N) instead of being gathered by another kernel.
+// where its coefficient lands (k + shift mod 2N, negated past N) instead of being gathered by another kernel.  With
+// `targets` the children are leaves of the expansion and go straight to their output slots (ExpandTargets).
 constexpr int kFinishPlain = 0, kFinishGalois = 1, kFinishExpand = 2;
 template <typename W, int MODE>
 __global__ void __launch_bounds__(kThreads)
     key_switch_finish_kernel(const W* __restrict__ prod, const W* __restrict__ ct_base, size_t ct_stride,
                              W* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
-                             uint32_t added_polys, uint32_t galois_inverse, uint32_t expand_shift) {
+                             uint32_t added_polys, uint32_t galois_inverse, uint32_t expand_shift,
+                             const ExpandTargets targets) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = (polys * 2) << logn;
@@ -382,7 +384,21 @@ __global__ void __launch_bounds__(kThreads)
         const W* src = prod + pc * (L + 1) * n + k;
         const W* ct_poly = ct_base + poly * ct_stride + c * L * n;
         const W* ct = ct_poly + k;
-        W* dst = out + (MODE == kFinishExpand ? (2 * poly * 2 + c) : pc) * L * n + k;
+        // the ciphertext(s) this polynomial's words go to
+        size_t first_ct = MODE == kFinishExpand ? 2 * poly : poly, second_ct = 2 * poly + 1;
+        [[maybe_unused]] bool first_doubled = false, second_doubled = false;
+        if constexpr (MODE == kFinishExpand) {
+            if (targets.table != nullptr) {
+                const size_t group = poly / targets.group_size, parent = poly - group * targets.group_size;
+                const uint32_t first = targets.table[4 * parent + 1], second = targets.table[4 * parent + 3];
+                first_ct = group * targets.group_stride + (first >> 1);
+                second_ct = group * targets.group_stride + (second >> 1);
+                first_doubled = (first & 1u) != 0;
+                second_doubled = (second & 1u) != 0;
+            }
+        }
+        W* dst = out + (first_ct * 2 + c) * L * n + k;
+        [[maybe_unused]] W* moved_dst = out + (second_ct * 2 + c) * L * n;
         // the automorphism's source coefficient and sign for this k (used for c0 only)
         [[maybe_unused]] uint32_t galois_source = 0;
         [[maybe_unused]] bool galois_negate = false;
@@ -425,10 +441,12 @@ __global__ void __launch_bounds__(kThreads)
                     stream_store(dst + row * n, rotated);
                 } else {
                     const uint64_t own = ct[row * n];
-                    stream_store(dst + row * n, add_mod_uniform(own, rotated, m.p));
-                    const uint64_t difference = sub_mod_uniform(own, rotated, m.p);
-                    stream_store(dst + (2 * L + row) * n - k + moved,
-                                 moved_negate ? neg_mod_uniform(difference, m.p) : difference);
+                    const uint64_t sum = add_mod_uniform(own, rotated, m.p);
+                    stream_store(dst + row * n, first_doubled ? add_mod_uniform(sum, sum, m.p) : sum);
+                    uint64_t difference = sub_mod_uniform(own, rotated, m.p);
+                    difference = moved_negate ? neg_mod_uniform(difference, m.p) : difference;
+                    stream_store(moved_dst + row * n + moved,
+                                 second_doubled ? add_mod_uniform(difference, difference, m.p) : difference);
                 }
             }
         }
@@ -595,22 +613,23 @@ hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_s
                                     uint32_t L, size_t polys, uint32_t added_polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishPlain>), dim3(grid_for((polys * 2) << ks.log_degree)),
-                       dim3(kThreads), 0, stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys, 0u, 0u);
+                       dim3(kThreads), 0, stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys, 0u, 0u,
+                       ExpandTargets{nullptr, 1, 0});
     return hipGetLastError();
 }
 
 template <typename W>
 hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                 uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
-                                hipStream_t stream) {
+                                const ExpandTargets& targets, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const dim3 grid(grid_for((polys * 2) << ks.log_degree));
     if (expand_shift != 0)
         hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishExpand>), grid, dim3(kThreads), 0, stream, prod, ct_base,
-                           ct_stride, out, ks, L, polys, 1u, galois_inverse, expand_shift);
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, expand_shift, targets);
     else
         hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishGalois>), grid, dim3(kThreads), 0, stream, prod, ct_base,
-                           ct_stride, out, ks, L, polys, 1u, galois_inverse, 0u);
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, 0u, ExpandTargets{nullptr, 1, 0});
     return hipGetLastError();
 }
 
@@ -632,7 +651,7 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
     template hipError_t launch_key_switch_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t,       \
                                                     size_t, uint32_t, hipStream_t);                                       \
     template hipError_t launch_galois_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t, size_t,   \
-                                                uint32_t, uint32_t, hipStream_t);
+                                                uint32_t, uint32_t, const ExpandTargets&, hipStream_t);
 HEAMD_INSTANTIATE_RNS(uint64_t)
 HEAMD_INSTANTIATE_RNS(uint32_t)
 #undef HEAMD_INSTANTIATE_RNS

@@ -50,6 +50,14 @@ hipError_t launch_scale_and_round(const W* in, W* out, const RnsToolDevice& tool
 template <typename W>
 hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                     uint32_t L, size_t polys, uint32_t added_polys, hipStream_t stream);
+// Where the children of an expand step go when they are leaves of the expansion (PirUtil.swift:262-299): parent p of
+// group g (= one query's parents, group_size of them) has children 2p and 2p + 1 in its level; table entries
+// (node, slot << 1 | doubled) of that level in node order send child i to ciphertext g * group_stride + slot of `out`,
+// added to itself when `doubled`.  table = nullptr: children 2 poly, 2 poly + 1 of `out`.
+struct ExpandTargets {
+    const uint32_t* table;
+    size_t group_size, group_stride;
+};
 // The same for Bfv.applyGalois with `ct` the ciphertext BEFORE the automorphism (Bfv.swift:190-196):
 // c' = (galois(ct.c0) + update0, update1), galois_inverse = g^-1 mod 2N.  expand_shift = 0: out [polys][2][L][N] = c';
 // otherwise one PirUtil.expand step (PirUtil.swift:204-236): out [2 polys][2][L][N] = the children
@@ -57,6 +65,6 @@ hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_s
 template <typename W>
 hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                 uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
-                                hipStream_t stream);
+                                const ExpandTargets& targets, hipStream_t stream);
 
 }  // namespace heamd
