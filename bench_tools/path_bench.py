@@ -125,20 +125,26 @@ def config4_mod_switch(torch, heamd, batch=8192, reps=5):
             "traffic_GBps": measured * batch / t / 1e9 if measured else None}
 
 
-def config5_inner_product(torch, heamd, count=256, columns=64, reps=3):
-    """PIR dim-0 shape on one GPU: `columns` outputs, each sum of `count` ct x pt products, N=8192, L=4."""
+def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1, masked=False):
+    """PIR dim-0 shape on one GPU: `columns` outputs, each sum of `count` ct x pt products, N=8192, L=4.  queries > 1:
+    that many queries' ciphertext vectors side by side share the database stream (poly_count = 2 queries)."""
     degree = 8192
     q = heamd.generate_primes([55] * 5, False, degree)
     ctx = heamd.BfvContext(degree, 557057, q)
     moduli = q[:-1]
-    cts = _uniform(torch, moduli, (count, 2), degree, 5)
+    cts = _uniform(torch, moduli, (count, 2 * queries), degree, 5)
     pts = _uniform(torch, moduli, (columns, count), degree, 6)
-    t = _timed(torch, lambda: ctx.inner_product_plain(cts, pts, None, 2, columns), reps)
+    if masked:  # a device-resident nil-plaintext mask (the last rows of a real database are padding): 1 in 64 nil
+        present = (torch.arange(columns * count, device="cuda") % 64 != 63).to(torch.uint8)
+        t = _timed(torch, lambda: ctx.inner_product_plain_resident(cts, pts, present, 2 * queries, columns), reps)
+    else:
+        t = _timed(torch, lambda: ctx.inner_product_plain(cts, pts, None, 2 * queries, columns), reps)
     macs = count * columns
     db_bytes = macs * 4 * degree * 8
-    measured = (_profiled("c5_inner_product_plain") or {}).get("hbm_bytes_per_unit")
-    return {"count": count, "columns": columns, "ct_pt_mac_per_s": macs / t, "database_GBps": db_bytes / t / 1e9,
-            "frac_of_8TBps": db_bytes / t / 8e12, "traffic_GBps": measured * macs / t / 1e9 if measured else None}
+    measured = (_profiled("c5_inner_product_plain") or {}).get("hbm_bytes_per_unit") if queries == 1 else None
+    return {"count": count, "columns": columns, "queries": queries, "masked": masked, "ct_pt_mac_per_s": queries * macs / t,
+            "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12,
+            "traffic_GBps": measured * macs / t / 1e9 if measured else None}
 
 
 def config5_pir_chunk(torch, heamd, d0=256, d1=64, reps=3):
@@ -173,6 +179,23 @@ def config5_pir_chunk_loop(torch, heamd, d0=256, d1=64, chunks=8, reps=3):
     db_bytes = chunks * d0 * d1 * 4 * degree * 8
     return {"dimensions": [d0, d1], "chunks": chunks, "database_GB": db_bytes / 1e9, "ms_per_chunk": t / chunks * 1e3,
             "chunk_responses_per_s": chunks / t, "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12}
+
+
+def config5_pir_queries(torch, heamd, d0=256, d1=64, chunks=8, queries=4, reps=3):
+    """`queries` queries over the same `chunks` x (d0 x d1) database in one call (he_pir_compute_response_queries_device):
+    chunk responses per second over all queries, and the database rate one query's share of the call amounts to."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    dim0 = _uniform(torch, moduli, (d0, queries, 2), degree, 7)
+    rest = _uniform(torch, moduli, (queries, d1, 2), degree, 8)
+    database = _uniform(torch, moduli, (chunks, d0 * d1), degree, 9)
+    keys = [_uniform(torch, q, (ctx.L, 2), degree, 10 + i) for i in range(queries)]
+    t = _timed(torch, lambda: ctx.pir_compute_response_queries([d0, d1], dim0, rest, database, chunks, keys), reps)
+    db_bytes = chunks * d0 * d1 * 4 * degree * 8
+    return {"dimensions": [d0, d1], "chunks": chunks, "queries": queries, "ms_per_chunk_per_query": t / chunks / queries * 1e3,
+            "chunk_responses_per_s": chunks * queries / t, "database_GBps_per_query_share": db_bytes * queries / t / 1e9}
 
 
 def run_all(quick=False):

@@ -685,7 +685,9 @@ int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32
     const uint64_t max_lazy = pc->max_lazy_product_accumulation_count(moduli_count);
     // the carry-counting accumulator's reduction wants sums below 2^127: at most 2^127 / (p_max - 1)^2 products
     uint64_t cadence = max_lazy;
+    bool narrow_moduli = true;  // every modulus below 2^56
     for (uint32_t i = 0; i < moduli_count; ++i) {
+        narrow_moduli = narrow_moduli && (pc->moduli()[i] >> 56) == 0;
         const unsigned __int128 below = pc->moduli()[i] - 1;
         if (below == 0) continue;
         // a window starts from the previous window's folded residue (< p), so cadence (p - 1)^2 + p - 1 must stay
@@ -694,7 +696,7 @@ int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32
         if (limit < cadence) cadence = static_cast<uint64_t>(limit);
     }
     HEAMD_HIP_TRY(heamd::launch_inner_product_plain(cts, pts, present_device, out, pc->device_context(), poly_count,
-                                                    count, columns, max_lazy, cadence, stream));
+                                                    count, columns, max_lazy, cadence, narrow_moduli, stream));
     return HE_OK;
 }
 int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const void* cts,
@@ -709,7 +711,8 @@ int check_inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, 
         return HE_OK;
     }
     if (cts == nullptr || pts == nullptr || out == nullptr) return invalid_argument("null operand");
-    if (poly_count < 1 || poly_count > 3) return invalid_argument("poly_count must be 1..3");
+    if (poly_count < 1 || poly_count > 8 || poly_count == 5 || poly_count == 7)
+        return invalid_argument("poly_count must be 1, 2, 3, 4, 6 or 8");
     return HE_OK;
 }
 }  // namespace

@@ -427,6 +427,138 @@ __device__ __forceinline__ void product_sum_add(ProductSum& s, uint64_t a, uint6
         : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "+v"(s.c_carry), "=&s"(carry)
         : "v"(lo32(a)), "v"(hi32(a)), "v"(lo32(b)), "v"(hi32(b)));
 }
+// Two or three sums that take products with the SAME b, instruction by instruction side by side: inside one sum every
+// instruction waits for the carry its predecessor leaves in an SGPR pair, and a wavefront issues in order; neighbours
+// with their own carry registers fill the gaps.
+// NARROW: both operands are below 2^56 (canonical residues of moduli below 2^56), so a cross term a0 b1 + a1 b0 is below
+// 2^57 and the middle column takes 127 products before it can wrap: its two carry counts are dropped (5 instructions
+// per product instead of 7); the caller folds the sum at least every kNarrowProductSumCadence products.
+constexpr uint64_t kNarrowProductSumCadence = 64;
+template <bool NARROW>
+__device__ __forceinline__ void product_sum_add_one(ProductSum& s, uint64_t a, uint64_t b) {
+    if constexpr (!NARROW) {
+        product_sum_add(s, a, b);
+    } else {
+        uint64_t carry;
+        asm("v_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+            "v_addc_co_u32 %3, %4, 0, %3, %4\n\t"
+            "v_mad_u64_u32 %1, %4, %5, %8, %1\n\t"
+            "v_mad_u64_u32 %1, %4, %6, %7, %1\n\t"
+            "v_mad_u64_u32 %2, %4, %6, %8, %2"
+            : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "=&s"(carry)
+            : "v"(lo32(a)), "v"(hi32(a)), "v"(lo32(b)), "v"(hi32(b)));
+    }
+}
+template <bool NARROW>
+__device__ __forceinline__ void product_sum_add_pair(ProductSum& s0, ProductSum& s1, uint64_t a0, uint64_t a1, uint64_t b) {
+    uint64_t carry0, carry1;
+    if constexpr (!NARROW) {
+        asm("v_mad_u64_u32 %0, %10, %12, %16, %0\n\t"
+            "v_mad_u64_u32 %5, %11, %14, %16, %5\n\t"
+            "v_addc_co_u32 %3, %10, 0, %3, %10\n\t"
+            "v_addc_co_u32 %8, %11, 0, %8, %11\n\t"
+            "v_mad_u64_u32 %1, %10, %12, %17, %1\n\t"
+            "v_mad_u64_u32 %6, %11, %14, %17, %6\n\t"
+            "v_addc_co_u32 %4, %10, 0, %4, %10\n\t"
+            "v_addc_co_u32 %9, %11, 0, %9, %11\n\t"
+            "v_mad_u64_u32 %1, %10, %13, %16, %1\n\t"
+            "v_mad_u64_u32 %6, %11, %15, %16, %6\n\t"
+            "v_addc_co_u32 %4, %10, 0, %4, %10\n\t"
+            "v_addc_co_u32 %9, %11, 0, %9, %11\n\t"
+            "v_mad_u64_u32 %2, %10, %13, %17, %2\n\t"
+            "v_mad_u64_u32 %7, %11, %15, %17, %7"
+            : "+v"(s0.t), "+v"(s0.c), "+v"(s0.h), "+v"(s0.t_carry), "+v"(s0.c_carry),  // 0-4
+              "+v"(s1.t), "+v"(s1.c), "+v"(s1.h), "+v"(s1.t_carry), "+v"(s1.c_carry),  // 5-9
+              "=&s"(carry0), "=&s"(carry1)                                              // 10, 11
+            : "v"(lo32(a0)), "v"(hi32(a0)), "v"(lo32(a1)), "v"(hi32(a1)), "v"(lo32(b)), "v"(hi32(b)));  // 12-17
+    } else {
+        asm("v_mad_u64_u32 %0, %8, %10, %14, %0\n\t"
+            "v_mad_u64_u32 %4, %9, %12, %14, %4\n\t"
+            "v_addc_co_u32 %3, %8, 0, %3, %8\n\t"
+            "v_addc_co_u32 %7, %9, 0, %7, %9\n\t"
+            "v_mad_u64_u32 %1, %8, %10, %15, %1\n\t"
+            "v_mad_u64_u32 %5, %9, %12, %15, %5\n\t"
+            "v_mad_u64_u32 %1, %8, %11, %14, %1\n\t"
+            "v_mad_u64_u32 %5, %9, %13, %14, %5\n\t"
+            "v_mad_u64_u32 %2, %8, %11, %15, %2\n\t"
+            "v_mad_u64_u32 %6, %9, %13, %15, %6"
+            : "+v"(s0.t), "+v"(s0.c), "+v"(s0.h), "+v"(s0.t_carry),  // 0-3
+              "+v"(s1.t), "+v"(s1.c), "+v"(s1.h), "+v"(s1.t_carry),  // 4-7
+              "=&s"(carry0), "=&s"(carry1)                            // 8, 9
+            : "v"(lo32(a0)), "v"(hi32(a0)), "v"(lo32(a1)), "v"(hi32(a1)), "v"(lo32(b)), "v"(hi32(b)));  // 10-15
+    }
+}
+template <bool NARROW>
+__device__ __forceinline__ void product_sum_add_triple(ProductSum& s0, ProductSum& s1, ProductSum& s2, uint64_t a0,
+                                                       uint64_t a1, uint64_t a2, uint64_t b) {
+    uint64_t carry0, carry1, carry2;
+    if constexpr (!NARROW) {
+        asm("v_mad_u64_u32 %0, %15, %18, %24, %0\n\t"
+            "v_mad_u64_u32 %5, %16, %20, %24, %5\n\t"
+            "v_mad_u64_u32 %10, %17, %22, %24, %10\n\t"
+            "v_addc_co_u32 %3, %15, 0, %3, %15\n\t"
+            "v_addc_co_u32 %8, %16, 0, %8, %16\n\t"
+            "v_addc_co_u32 %13, %17, 0, %13, %17\n\t"
+            "v_mad_u64_u32 %1, %15, %18, %25, %1\n\t"
+            "v_mad_u64_u32 %6, %16, %20, %25, %6\n\t"
+            "v_mad_u64_u32 %11, %17, %22, %25, %11\n\t"
+            "v_addc_co_u32 %4, %15, 0, %4, %15\n\t"
+            "v_addc_co_u32 %9, %16, 0, %9, %16\n\t"
+            "v_addc_co_u32 %14, %17, 0, %14, %17\n\t"
+            "v_mad_u64_u32 %1, %15, %19, %24, %1\n\t"
+            "v_mad_u64_u32 %6, %16, %21, %24, %6\n\t"
+            "v_mad_u64_u32 %11, %17, %23, %24, %11\n\t"
+            "v_addc_co_u32 %4, %15, 0, %4, %15\n\t"
+            "v_addc_co_u32 %9, %16, 0, %9, %16\n\t"
+            "v_addc_co_u32 %14, %17, 0, %14, %17\n\t"
+            "v_mad_u64_u32 %2, %15, %19, %25, %2\n\t"
+            "v_mad_u64_u32 %7, %16, %21, %25, %7\n\t"
+            "v_mad_u64_u32 %12, %17, %23, %25, %12"
+            : "+v"(s0.t), "+v"(s0.c), "+v"(s0.h), "+v"(s0.t_carry), "+v"(s0.c_carry),  // 0-4
+              "+v"(s1.t), "+v"(s1.c), "+v"(s1.h), "+v"(s1.t_carry), "+v"(s1.c_carry),  // 5-9
+              "+v"(s2.t), "+v"(s2.c), "+v"(s2.h), "+v"(s2.t_carry), "+v"(s2.c_carry),  // 10-14
+              "=&s"(carry0), "=&s"(carry1), "=&s"(carry2)                               // 15-17
+            : "v"(lo32(a0)), "v"(hi32(a0)), "v"(lo32(a1)), "v"(hi32(a1)), "v"(lo32(a2)), "v"(hi32(a2)),  // 18-23
+              "v"(lo32(b)), "v"(hi32(b)));                                                              // 24, 25
+    } else {
+        asm("v_mad_u64_u32 %0, %12, %15, %21, %0\n\t"
+            "v_mad_u64_u32 %4, %13, %17, %21, %4\n\t"
+            "v_mad_u64_u32 %8, %14, %19, %21, %8\n\t"
+            "v_addc_co_u32 %3, %12, 0, %3, %12\n\t"
+            "v_addc_co_u32 %7, %13, 0, %7, %13\n\t"
+            "v_addc_co_u32 %11, %14, 0, %11, %14\n\t"
+            "v_mad_u64_u32 %1, %12, %15, %22, %1\n\t"
+            "v_mad_u64_u32 %5, %13, %17, %22, %5\n\t"
+            "v_mad_u64_u32 %9, %14, %19, %22, %9\n\t"
+            "v_mad_u64_u32 %1, %12, %16, %21, %1\n\t"
+            "v_mad_u64_u32 %5, %13, %18, %21, %5\n\t"
+            "v_mad_u64_u32 %9, %14, %20, %21, %9\n\t"
+            "v_mad_u64_u32 %2, %12, %16, %22, %2\n\t"
+            "v_mad_u64_u32 %6, %13, %18, %22, %6\n\t"
+            "v_mad_u64_u32 %10, %14, %20, %22, %10"
+            : "+v"(s0.t), "+v"(s0.c), "+v"(s0.h), "+v"(s0.t_carry),  // 0-3
+              "+v"(s1.t), "+v"(s1.c), "+v"(s1.h), "+v"(s1.t_carry),  // 4-7
+              "+v"(s2.t), "+v"(s2.c), "+v"(s2.h), "+v"(s2.t_carry),  // 8-11
+              "=&s"(carry0), "=&s"(carry1), "=&s"(carry2)             // 12-14
+            : "v"(lo32(a0)), "v"(hi32(a0)), "v"(lo32(a1)), "v"(hi32(a1)), "v"(lo32(a2)), "v"(hi32(a2)),  // 15-20
+              "v"(lo32(b)), "v"(hi32(b)));                                                              // 21, 22
+    }
+}
+// POLYS sums against one b, side by side in groups of three and two
+template <int POLYS, bool NARROW>
+__device__ __forceinline__ void product_sum_add_all(ProductSum (&s)[POLYS], const uint64_t (&a)[POLYS], uint64_t b) {
+    constexpr int kTriples = POLYS % 3 == 0 ? POLYS / 3 : POLYS % 3 == 2 ? POLYS / 3 : POLYS >= 4 ? POLYS / 3 - 1 : 0;
+    constexpr int kPairs = (POLYS - 3 * kTriples) / 2;
+#pragma unroll
+    for (int g = 0; g < kTriples; ++g)
+        product_sum_add_triple<NARROW>(s[3 * g], s[3 * g + 1], s[3 * g + 2], a[3 * g], a[3 * g + 1], a[3 * g + 2], b);
+#pragma unroll
+    for (int g = 0; g < kPairs; ++g) {
+        constexpr int base = 3 * kTriples;
+        product_sum_add_pair<NARROW>(s[base + 2 * g], s[base + 2 * g + 1], a[base + 2 * g], a[base + 2 * g + 1], b);
+    }
+    if constexpr (3 * kTriples + 2 * kPairs < POLYS) product_sum_add_one<NARROW>(s[POLYS - 1], a[POLYS - 1], b);
+}
 // b wave-uniform (a table constant): stays in SGPRs
 __device__ __forceinline__ void product_sum_add_uniform(ProductSum& s, uint64_t a, uint64_t b) {
     uint64_t carry;

@@ -62,12 +62,13 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
 // out[col][poly][L][N] = sum_k cts[k][poly][L][N] * pts[col][k][L][N]  (skip where present[col*count+k] == 0).
 // max_lazy: the reference's reduction cadence (used as is by the 128-bit accumulator kernel for degree < 256);
 // cadence: products between reductions of the carry-counting accumulator: <= max_lazy and sums below 2^127
-// (0 = use the 128-bit kernel).
+// (0 = use the 128-bit kernel).  narrow_moduli: every modulus of ctx is below 2^56 (canonical operands then let the
+// accumulator drop two of its three carry counts; the cadence is cut to kNarrowProductSumCadence).
 // (W: uint64_t or uint32_t slabs)
 template <typename W>
 hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t* present_device, W* out,
                                       const DeviceContext& ctx, uint32_t poly_count, size_t count, size_t columns,
-                                      uint64_t max_lazy, uint64_t cadence, hipStream_t stream);
+                                      uint64_t max_lazy, uint64_t cadence, bool narrow_moduli, hipStream_t stream);
 // ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words
 hipError_t launch_mul_plain32(uint32_t* ct, const uint32_t* pt, const DeviceContext& ctx, uint32_t poly_count, size_t batch,
                               hipStream_t stream);

@@ -197,6 +197,56 @@ extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const u
     return HE_OK;
 }
 
+// Several queries over the same database in one call: the dim-0 inner products of all of them stream the database once
+// (their ciphertext vectors side by side, he_amd.h he_bfv_inner_product_plain_device with polys = 2 x queries); the
+// remaining dimensions, which involve only query ciphertexts and intermediate results, then run query by query.
+extern "C" int he_pir_compute_response_queries_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                      uint32_t dimension_count, size_t queries,
+                                                      const uint64_t* dim0_queries_eval, const uint64_t* remaining_queries,
+                                                      size_t remaining_query_count, const uint64_t* database,
+                                                      const uint8_t* present_device, size_t chunk_count,
+                                                      const uint64_t* const* relinearization_keys, uint64_t* out,
+                                                      he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_queries, remaining_query_count, shape));
+    if (queries == 0 || chunk_count == 0) return HE_OK;
+    if (queries > 4) return invalid_argument("at most 4 queries share one pass over the database");
+    if (dim0_queries_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    if (dimension_count > 1 && relinearization_keys == nullptr) return invalid_argument("null relinearization keys");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = shape.L;
+    const size_t ct_words = 2 * size_t(L) * shape.n, ct_bytes = ct_words * sizeof(uint64_t);
+    const size_t chunk_words = shape.per_chunk * size_t(L) * shape.n, out_words = 2 * shape.n;
+    // groups of chunks that keep the intermediate ciphertexts of all queries under ~1 GiB
+    const size_t intermediate_bytes = shape.columns * queries * ct_bytes;
+    size_t group = (size_t(1) << 30) / (intermediate_bytes ? intermediate_bytes : 1);
+    group = group == 0 ? 1 : (group < chunk_count ? group : chunk_count);
+    Scratch all_mem(stream), one_mem(stream);
+    HEAMD_HIP_TRY(all_mem.allocate(group * shape.columns * queries * ct_bytes));
+    HEAMD_HIP_TRY(one_mem.allocate(group * shape.columns * ct_bytes));
+    uint64_t* all = static_cast<uint64_t*>(all_mem.get());  // [chunk][column][query][2][L][N]
+    uint64_t* one = static_cast<uint64_t*>(one_mem.get());  // [chunk][column][2][L][N] of one query
+    for (size_t first = 0; first < chunk_count; first += group) {
+        const size_t now = chunk_count - first < group ? chunk_count - first : group;
+        const size_t columns = now * shape.columns;
+        // PirUtil.swift:428-438 for every query at once
+        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(
+            ctx, L, static_cast<uint32_t>(2 * queries), dim0_queries_eval, database + first * chunk_words,
+            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, columns, all, s));
+        HEAMD_TRY_STATUS(he_ntt_inverse_device(shape.q_ctx, all, columns * 2 * queries, s));
+        for (size_t q = 0; q < queries; ++q) {
+            // this query's results, column after column (a strided copy: they sit `queries` ciphertexts apart)
+            HEAMD_HIP_TRY(hipMemcpy2DAsync(one, ct_bytes, all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
+                                           hipMemcpyDeviceToDevice, stream));
+            HEAMD_TRY_STATUS(remaining_dimensions(
+                ctx, dimensions, dimension_count, shape, now, one,
+                remaining_queries ? remaining_queries + q * remaining_query_count * ct_words : nullptr,
+                relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words, s));
+        }
+    }
+    return HE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // PirUtil.expand (PirUtil.swift:196-355): oblivious expansion of query ciphertexts into encrypted selection bits.
 // The reference recurses per ciphertext (expandCiphertext -> expandCiphertextForOneStep); every node of one tree

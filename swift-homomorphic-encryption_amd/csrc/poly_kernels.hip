@@ -267,7 +267,12 @@ __global__ void __launch_bounds__(kThreads)
 // -- wave-uniform: blockIdx.y covers kThreads words of ONE row (degree >= kThreads).  `cadence` products at most are
 // summed between reductions, chosen by the launcher so that a sum stays below 2^127 (reduce_product_sum's contract)
 // and never exceeds the reference's own lazy count (Bfv.swift:496-500); the canonical result does not depend on it.
-template <int POLYS, int COLS, typename W>
+// NARROW: every modulus is below 2^56 and `cadence` at most kNarrowProductSumCadence (device_math.hpp): the middle
+// column's carry counts are not kept.
+// MASKED: `present` is not null.  Every load is issued unconditionally (the item after the last one re-reads the last
+// one), the mask byte of an item travels with its plaintext words one item ahead: the loads in flight at each point are
+// then a fixed number and no wait drains the queue (a branch around a load makes the compiler wait for all of them).
+template <int POLYS, int COLS, bool NARROW, bool MASKED, typename W>
 __global__ void __launch_bounds__(kThreads)
     inner_product_plain_rows_kernel(const W* __restrict__ cts, const W* __restrict__ pts,
                                     const uint8_t* __restrict__ present, W* __restrict__ out,
@@ -297,31 +302,42 @@ __global__ void __launch_bounds__(kThreads)
     }
     const W* ct_base = cts + word;
     const W* pt_lane = pts + word;
-    size_t pt_column[COLS];
+    size_t pt_column[COLS], mask_column[COLS];
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) pt_column[c] = (live[c] ? col0 + c : columns - 1) * count * words_per_poly;
+    for (int c = 0; c < COLS; ++c) {
+        const size_t column = live[c] ? col0 + c : columns - 1;  // a column past the end re-reads the last one
+        pt_column[c] = column * count * words_per_poly;
+        mask_column[c] = column * count;
+    }
     uint64_t x_next[POLYS], y_next[COLS];
+    [[maybe_unused]] uint8_t mask_next[COLS];
     auto fetch = [&](size_t j) {
 #pragma unroll
         for (int q = 0; q < POLYS; ++q) x_next[q] = ct_base[(j * POLYS + q) * words_per_poly];
 #pragma unroll
-        for (int c = 0; c < COLS; ++c)  // the database is read once: streamed past the caches (non-temporal)
+        for (int c = 0; c < COLS; ++c) {  // the database is read once: streamed past the caches (non-temporal)
             y_next[c] = __builtin_nontemporal_load(pt_lane + pt_column[c] + j * words_per_poly);
+            if constexpr (MASKED) mask_next[c] = present[mask_column[c] + j];
+        }
     };
     if (count > 0) fetch(0);
     for (size_t j = 0; j < count; ++j) {
         uint64_t x[POLYS], y[COLS];
+        [[maybe_unused]] uint8_t mask[COLS];
 #pragma unroll
         for (int q = 0; q < POLYS; ++q) x[q] = x_next[q];
 #pragma unroll
-        for (int c = 0; c < COLS; ++c) y[c] = y_next[c];
-        if (j + 1 < count) fetch(j + 1);
+        for (int c = 0; c < COLS; ++c) {
+            y[c] = y_next[c];
+            if constexpr (MASKED) mask[c] = mask_next[c];
+        }
+        fetch(j + 1 < count ? j + 1 : j);
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {
-            if (!live[c]) continue;
-            if (present != nullptr && present[(col0 + c) * count + j] == 0) continue;  // nil plaintext, Bfv.swift:486-489
-#pragma unroll
-            for (int q = 0; q < POLYS; ++q) product_sum_add(acc[c][q], x[q], y[c]);
+            bool active = live[c];
+            if constexpr (MASKED) active = active && mask[c] != 0;  // nil plaintext, Bfv.swift:486-489
+            if (!active) continue;
+            product_sum_add_all<POLYS, NARROW>(acc[c], x, y[c]);
             if (++since_reduce[c] >= cadence) {
                 since_reduce[c] = 0;
 #pragma unroll
@@ -332,6 +348,145 @@ __global__ void __launch_bounds__(kThreads)
                 }
             }
         }
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        if (!live[c]) continue;
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q)
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(reduce_product_sum(acc[c][q], m));
+    }
+}
+
+// ---- wide ciphertexts: several queries' ciphertext vectors side by side over one database ---------------------------
+// With POLYS >= 4 the single-lane register tile above runs out of registers before it runs out of memory pipe: its
+// POLYS + COLS operand loads per POLYS x COLS products are 8-byte gathers through the texture path, and what bounds it
+// is that path, not HBM.  Here the four wavefronts of a workgroup take the SAME 64 words and different columns: the
+// ciphertext words of a chunk of 4 or 8 vector items are fetched once per workgroup into LDS (double-buffered, one
+// barrier per chunk) and read from there by all four wavefronts; only the plaintext words -- the database, read once
+// from HBM whatever the number of queries -- still come through the vector memory path.  Per product: 8 / POLYS bytes
+// of database and 2 / COLS bytes of ciphertexts, against 8 / POLYS + 8 / COLS above.
+constexpr int kTileWords = 64, kTileWavefronts = 4;
+
+template <int POLYS, int COLS, bool NARROW, bool MASKED, typename W>
+__global__ void __launch_bounds__(kTileWords * kTileWavefronts)
+    inner_product_plain_tile_kernel(const W* __restrict__ cts, const W* __restrict__ pts,
+                                    const uint8_t* __restrict__ present, W* __restrict__ out, const DeviceContext ctx,
+                                    size_t count, size_t columns, uint64_t cadence, uint32_t column_groups) {
+    constexpr int kChunk = POLYS <= 4 ? 8 : 4;                  // vector items per chunk: 24 or 32 rows of 512 bytes
+    constexpr int kRows = kChunk * POLYS;                       // ciphertext rows of a chunk: (item, polynomial)
+    constexpr int kRowsPerWave = kRows / kTileWavefronts;       // each wavefront fetches this many of them
+    static_assert(kRows % kTileWavefronts == 0, "the wavefronts share the chunk's rows evenly");
+    __shared__ uint64_t tile[2][kRows][kTileWords];
+    const uint32_t logn = ctx.log_degree;
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) << logn;
+    uint32_t word_block, column_group;
+    locate_replica(blockIdx.x, static_cast<uint32_t>(words_per_poly / kTileWords), column_groups, word_block, column_group);
+    const uint32_t lane = threadIdx.x & (kTileWords - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kTileWords);
+    const size_t block_word = word_block * static_cast<size_t>(kTileWords);
+    const size_t word = block_word + lane;
+    const size_t col0 = (static_cast<size_t>(column_group) * kTileWavefronts + wave) * COLS;
+    const DeviceModulus m = ctx.moduli[block_word >> logn];
+    ProductSum acc[COLS][POLYS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) acc[c][q] = product_sum_zero();
+    uint64_t since_reduce[COLS];
+    bool live[COLS];
+    size_t pt_column[COLS], mask_column[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        since_reduce[c] = 0;
+        live[c] = col0 + c < columns;
+        const size_t column = live[c] ? col0 + c : columns - 1;  // a column past the end re-reads the last one
+        pt_column[c] = column * count * words_per_poly;
+        mask_column[c] = column * count;
+    }
+    const W* ct_lane = cts + word;
+    const W* pt_lane = pts + word;
+    // Every load below is issued unconditionally (indices past the end are clamped to the last item and their words
+    // never used): the number of loads in flight at each point is then fixed, and a wait names exactly the load it
+    // needs instead of draining the queue.
+    const size_t last = count - 1;
+    // this wavefront's share of a chunk's ciphertext rows: row = (item in chunk) * POLYS + polynomial
+    uint64_t staged[kRowsPerWave];
+    auto fetch_chunk = [&](size_t first) {
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const size_t row = static_cast<size_t>(wave) * kRowsPerWave + i;
+            const size_t item = first + row / POLYS < count ? first + row / POLYS : last;
+            staged[i] = ct_lane[(item * POLYS + row % POLYS) * words_per_poly];
+        }
+    };
+    auto store_chunk = [&](int buffer) {
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) tile[buffer][wave * kRowsPerWave + i][lane] = staged[i];
+    };
+    if (count == 0) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            if (!live[c]) continue;
+#pragma unroll
+            for (int q = 0; q < POLYS; ++q) out[((col0 + c) * POLYS + q) * words_per_poly + word] = 0;
+        }
+        return;
+    }
+    fetch_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    // the plaintext words (and mask bytes) of the next kDepth vector items are in flight
+    constexpr int kDepth = 4;
+    static_assert(kChunk % kDepth == 0, "ring slots are compile-time indices inside a chunk");
+    uint64_t y_ring[kDepth][COLS];
+    [[maybe_unused]] uint8_t mask_ring[kDepth][COLS];
+    auto fetch_plain = [&](int slot, size_t j) {
+        const size_t item = j < count ? j : last;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {  // the database is read once: streamed past the caches (non-temporal)
+            y_ring[slot][c] = __builtin_nontemporal_load(pt_lane + pt_column[c] + item * words_per_poly);
+            if constexpr (MASKED) mask_ring[slot][c] = present[mask_column[c] + item];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) fetch_plain(d, d);
+    int buffer = 0;
+    for (size_t first = 0; first < count; first += kChunk, buffer ^= 1) {
+        fetch_chunk(first + kChunk);  // in flight while this chunk is multiplied
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            const size_t j = first + k;
+            uint64_t y[COLS];
+            [[maybe_unused]] uint8_t mask[COLS];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                y[c] = y_ring[k % kDepth][c];
+                if constexpr (MASKED) mask[c] = mask_ring[k % kDepth][c];
+            }
+            fetch_plain(k % kDepth, j + kDepth);
+            uint64_t x[POLYS];
+#pragma unroll
+            for (int q = 0; q < POLYS; ++q) x[q] = tile[buffer][k * POLYS + q][lane];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                bool active = live[c] && j < count;
+                if constexpr (MASKED) active = active && mask[c] != 0;  // nil plaintext, Bfv.swift:486-489
+                if (!active) continue;
+                product_sum_add_all<POLYS, NARROW>(acc[c], x, y[c]);
+                if (++since_reduce[c] >= cadence) {
+                    since_reduce[c] = 0;
+#pragma unroll
+                    for (int q = 0; q < POLYS; ++q) {
+                        const uint64_t folded = reduce_product_sum(acc[c][q], m);
+                        acc[c][q] = product_sum_zero();
+                        acc[c][q].t = folded;
+                    }
+                }
+            }
+        }
+        store_chunk(buffer ^ 1);  // that buffer was last read before the barrier that ended the previous chunk
+        __syncthreads();
     }
 #pragma unroll
     for (int c = 0; c < COLS; ++c) {
@@ -393,21 +548,45 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
     return hipGetLastError();
 }
 
-template <int POLYS, typename W>
+// A workgroup accumulates POLYS x COLS sums of one word block: each ciphertext word serves COLS columns and each
+// plaintext word POLYS polynomials.  POLYS x COLS = 8 accumulators of 8 registers fill the lane's budget, so wider
+// ciphertexts (several queries' ciphertexts side by side, which then share every plaintext word they stream) take
+// fewer columns.
+template <int POLYS, int COLS, bool NARROW, typename W>
 hipError_t launch_inner_product_plain_polys(const W* cts, const W* pts, const uint8_t* present_device, W* out,
                                             const DeviceContext& ctx, size_t count, size_t columns, uint64_t max_lazy,
                                             uint64_t cadence, hipStream_t stream) {
-    constexpr int kCols = 4;
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
-    const dim3 grid(static_cast<unsigned>((columns + kCols - 1) / kCols),
+    const dim3 grid(static_cast<unsigned>((columns + COLS - 1) / COLS),
                     static_cast<unsigned>((words_per_poly + kThreads - 1) / kThreads));
+    if constexpr (POLYS >= 4) {
+        // several queries side by side: ciphertext words through LDS, four column sets per workgroup
+        const size_t column_groups = (columns + COLS * kTileWavefronts - 1) / (COLS * kTileWavefronts);
+        const size_t blocks = column_groups * (words_per_poly / kTileWords);
+        if (ctx.degree >= kThreads && cadence != 0 && blocks < (size_t(1) << 31)) {
+            const dim3 tile_grid(static_cast<unsigned>(blocks)), tile_block(kTileWords * kTileWavefronts);
+            if (present_device != nullptr)
+                hipLaunchKernelGGL((inner_product_plain_tile_kernel<POLYS, COLS, NARROW, true, W>), tile_grid, tile_block, 0,
+                                   stream, cts, pts, present_device, out, ctx, count, columns, cadence,
+                                   static_cast<uint32_t>(column_groups));
+            else
+                hipLaunchKernelGGL((inner_product_plain_tile_kernel<POLYS, COLS, NARROW, false, W>), tile_grid, tile_block, 0,
+                                   stream, cts, pts, present_device, out, ctx, count, columns, cadence,
+                                   static_cast<uint32_t>(column_groups));
+            return hipGetLastError();
+        }
+    }
     if (ctx.degree >= kThreads && cadence != 0 && static_cast<size_t>(grid.x) * grid.y < (size_t(1) << 31)) {
         // one-dimensional grid: the kernel places the column groups of a word block on one XCD itself
-        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols, W>), dim3(grid.x * grid.y), dim3(kThreads), 0,
-                           stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
+        if (present_device != nullptr)
+            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, true, W>), dim3(grid.x * grid.y),
+                               dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
+        else
+            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, false, W>), dim3(grid.x * grid.y),
+                               dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, kCols, W>), grid, dim3(kThreads), 0, stream, cts, pts,
+    hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, COLS, W>), grid, dim3(kThreads), 0, stream, cts, pts,
                        present_device, out, ctx, count, columns, max_lazy);
     return hipGetLastError();
 }
@@ -415,27 +594,33 @@ hipError_t launch_inner_product_plain_polys(const W* cts, const W* pts, const ui
 template <typename W>
 hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t* present_device, W* out,
                                       const DeviceContext& ctx, uint32_t poly_count, size_t count, size_t columns,
-                                      uint64_t max_lazy, uint64_t cadence, hipStream_t stream) {
+                                      uint64_t max_lazy, uint64_t cadence, bool narrow_moduli, hipStream_t stream) {
     if (columns == 0) return hipSuccess;
+    const bool narrow = narrow_moduli && cadence != 0;
+    if (narrow && cadence > kNarrowProductSumCadence) cadence = kNarrowProductSumCadence;
+#define HEAMD_INNER_PRODUCT_CASE(POLYS, COLS)                                                                              \
+    case POLYS:                                                                                                            \
+        return narrow ? launch_inner_product_plain_polys<POLYS, COLS, true>(cts, pts, present_device, out, ctx, count,     \
+                                                                            columns, max_lazy, cadence, stream)            \
+                      : launch_inner_product_plain_polys<POLYS, COLS, false>(cts, pts, present_device, out, ctx, count,    \
+                                                                             columns, max_lazy, cadence, stream)
     switch (poly_count) {
-        case 1:
-            return launch_inner_product_plain_polys<1>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       cadence, stream);
-        case 2:
-            return launch_inner_product_plain_polys<2>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       cadence, stream);
-        case 3:
-            return launch_inner_product_plain_polys<3>(cts, pts, present_device, out, ctx, count, columns, max_lazy,
-                                                       cadence, stream);
+        HEAMD_INNER_PRODUCT_CASE(1, 4);
+        HEAMD_INNER_PRODUCT_CASE(2, 4);
+        HEAMD_INNER_PRODUCT_CASE(3, 4);
+        HEAMD_INNER_PRODUCT_CASE(4, 2);
+        HEAMD_INNER_PRODUCT_CASE(6, 1);
+        HEAMD_INNER_PRODUCT_CASE(8, 1);
         default: return hipErrorInvalidValue;
     }
+#undef HEAMD_INNER_PRODUCT_CASE
 }
 template hipError_t launch_inner_product_plain<uint64_t>(const uint64_t*, const uint64_t*, const uint8_t*, uint64_t*,
                                                          const DeviceContext&, uint32_t, size_t, size_t, uint64_t,
-                                                         uint64_t, hipStream_t);
+                                                         uint64_t, bool, hipStream_t);
 template hipError_t launch_inner_product_plain<uint32_t>(const uint32_t*, const uint32_t*, const uint8_t*, uint32_t*,
                                                          const DeviceContext&, uint32_t, size_t, size_t, uint64_t,
-                                                         uint64_t, hipStream_t);
+                                                         uint64_t, bool, hipStream_t);
 
 // ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words (one word per lane)
 namespace {

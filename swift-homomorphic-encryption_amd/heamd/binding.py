@@ -144,6 +144,8 @@ SIGNATURES = [
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, vp]),
     ("he_pir_compute_response_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
+    ("he_pir_compute_response_queries_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, c_size, vp, vp, c_size, vp, vp, c_size, ctypes.POINTER(vp), vp, vp]),
     ("he_pir_expand_batch_device", ctypes.c_int,
      [vp, vp, c_size, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp]),
     ("he_bfv_apply_galois_grouped_device", ctypes.c_int,
@@ -744,6 +746,25 @@ class BfvContext:
         _check(load_library().he_pir_compute_response_device(self.h, dims, len(dimensions), _ptr(dim0_query_eval), rest,
                                                              rest_count, _ptr(database), mask, chunk_count, key,
                                                              _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_queries(self, dimensions, dim0_queries_eval, remaining_queries, database, chunk_count,
+                                     relinearization_keys, present_device=None, stream=None):
+        """`queries` queries over one database in one call: dim0_queries_eval [d0][queries][2][L][N] Eval,
+        remaining_queries [queries][rest][2][L][N] (or None), relinearization_keys: one tensor per query (or None)
+        -> [queries][chunks][2][1][N]."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        queries = dim0_queries_eval.numel() // (int(dimensions[0]) * 2 * self.L * self.degree)
+        out = self._empty((queries, chunk_count, 2, 1, self.degree), dim0_queries_eval)
+        rest = vp() if remaining_queries is None else _ptr(remaining_queries)
+        rest_count = 0 if remaining_queries is None else remaining_queries.numel() // (queries * 2 * self.L * self.degree)
+        keys = None
+        if relinearization_keys is not None:
+            keys = (vp * queries)(*[vp(k.data_ptr()) for k in relinearization_keys])
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_queries_device(
+            self.h, dims, len(dimensions), queries, _ptr(dim0_queries_eval), rest, rest_count, _ptr(database), mask,
+            chunk_count, keys, _ptr(out), _stream(stream)))
         return out
 
     def mod_switch_down(self, ct, poly_count, moduli_count=None, stream=None):

@@ -201,6 +201,38 @@ def test_inner_product_plain_pir_shape(oracle, config3):
         assert np.array_equal(got[col], ref.inner_product_plain(cts, pts[col], None))
 
 
+@pytest.mark.parametrize("queries", [2, 3, 4])
+def test_inner_product_plain_queries_side_by_side(oracle, small, config3, queries):
+    """poly_count = 2 x queries: the ciphertext vectors of several queries laid side by side ([count][query][2][L][N])
+    share every plaintext word; query q's slice of the output is its own Bfv.innerProduct(ciphertexts:plaintexts:)
+    (Bfv.swift:476-505) word for word -- the oracle's on the small ring (nil plaintexts included) and the single-query
+    kernel's on BASELINE config 5's ring."""
+    ours, ref, _ = small
+    moduli = ref.ciphertext_context().moduli
+    rng = np.random.default_rng(200 + queries)
+    count, columns = 7, 5
+    cts = _uniform(rng, (count, queries, 2), moduli, ours.degree)
+    pts = _uniform(rng, (columns, count), moduli, ours.degree)
+    present = rng.integers(0, 2, size=(columns, count), dtype=np.uint8)
+    present[0, :] = 1
+    got = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), present, 2 * queries, columns))
+    got = got.reshape(columns, queries, 2, ours.L, ours.degree)
+    for q in range(queries):
+        own = np.ascontiguousarray(cts[:, q])
+        for col in range(columns):
+            assert np.array_equal(got[col, q], ref.inner_product_plain(own, pts[col], present[col])), (q, col)
+    big, big_ref = config3
+    moduli = big_ref.ciphertext_context().moduli
+    count, columns = 12, 6
+    cts = _uniform(rng, (count, queries, 2), moduli, big.degree)
+    pts = heamd.to_device(_uniform(rng, (columns, count), moduli, big.degree))
+    got = heamd.to_host(big.inner_product_plain(heamd.to_device(cts), pts, None, 2 * queries, columns))
+    got = got.reshape(columns, queries, 2, big.L, big.degree)
+    for q in range(queries):
+        single = heamd.to_host(big.inner_product_plain(heamd.to_device(np.ascontiguousarray(cts[:, q])), pts, None, 2, columns))
+        assert np.array_equal(got[:, q], single.reshape(columns, 2, big.L, big.degree)), q
+
+
 def test_single_modulus_context(oracle):
     """One coefficient modulus: no key-switching modulus (Context.swift:102-107); ct x ct still works."""
     degree = 32
@@ -369,6 +401,36 @@ def test_inner_product_plain_reduction_cadence(oracle, bits):
     unmasked = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), None, 2, columns))
     for col in (0, 1, 4):
         assert np.array_equal(unmasked[col], ref.inner_product_plain(cts, pts[col], None)), col
+
+
+@pytest.mark.parametrize("bits,polys", [([56, 56, 56], 2), ([56, 40, 55, 56], 2), ([56, 56, 56], 4), ([56, 56, 56], 6),
+                                        ([56, 55, 56], 8), ([57, 56, 57], 8)])
+def test_inner_product_plain_narrow_moduli(oracle, bits, polys):
+    """Moduli below 2^56 take the accumulator without the middle column's carry counts (device_math.hpp NARROW), folded
+    every 64 products: 150 products of words at q - 1 -- the largest cross terms a canonical operand can make -- cross
+    the fold twice, for one query and for 2, 3 and 4 queries side by side; a 57-bit modulus keeps the full accumulator.
+    Word-exact against the oracle's Bfv.innerProduct(ciphertexts:plaintexts:) per query."""
+    degree = 256
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(polys + len(bits))
+    count, columns, queries = 150, 3, polys // 2
+    cts = _uniform(rng, (count, queries, 2), moduli, degree)
+    pts = _uniform(rng, (columns, count), moduli, degree)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    cts[:, :, :, :, : degree // 2] = top[None, None, None, :, :]
+    pts[0] = top[None, :, :]
+    pts[1, :, :, ::2] = top[None, :, :]
+    present = np.ones((columns, count), dtype=np.uint8)
+    present[2, ::3] = 0
+    got = heamd.to_host(ours.inner_product_plain(heamd.to_device(cts), heamd.to_device(pts), present, polys, columns))
+    got = got.reshape(columns, queries, 2, ours.L, degree)
+    for query in range(queries):
+        own = np.ascontiguousarray(cts[:, query])
+        for col in range(columns):
+            assert np.array_equal(got[col, query], ref.inner_product_plain(own, pts[col], present[col])), (query, col)
 
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55]),

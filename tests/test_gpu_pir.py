@@ -250,6 +250,63 @@ def test_multi_chunk_response_matches_oracle(oracle, small):
         assert client.decrypt(got[chunk], moduli_count=1) == want
 
 
+@pytest.mark.parametrize("queries", [2, 3, 4])
+def test_queries_share_one_pass_over_the_database(oracle, small, queries):
+    """he_pir_compute_response_queries_device: the dim-0 inner products of several queries stream the database once;
+    every query's responses are the oracle's computeResponseForOneChunk for that query alone (different selections,
+    different clients' relinearization keys), nil plaintexts included, and decrypt to the selected entries."""
+    import torch
+
+    ours, ref, client = small
+    rng = random.Random(300 + queries)
+    dims, chunks, per_chunk = [4, 3], 2, 12
+    entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(per_chunk * chunks)]
+    database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64)).reshape(chunks, per_chunk, ref.L, ref.degree)
+    present = np.ones((chunks, per_chunk), dtype=np.uint8)
+    present[1, [3, 10]] = 0
+    qctx = ref.ciphertext_context()
+    key = client.relinearization_key()
+    one, zero = [1] + [0] * (ref.degree - 1), [0] * ref.degree
+    selections = [(q % dims[0], (q + 1) % dims[1]) for q in range(queries)]
+    dim0 = np.stack([np.stack([qctx.forward_ntt(client.encrypt(one if k == sel[0] else zero)) for sel in selections])
+                     for k in range(dims[0])])                                     # [d0][queries][2][L][N]
+    rest = np.stack([np.stack([client.encrypt(one if k == sel[1] else zero) for k in range(dims[1])])
+                     for sel in selections])                                       # [queries][d1][2][L][N]
+    device_key = heamd.to_device(key)
+    got = heamd.to_host(ours.pir_compute_response_queries(dims, heamd.to_device(dim0), heamd.to_device(rest),
+                                                          heamd.to_device(database), chunks, [device_key] * queries,
+                                                          present_device=torch.from_numpy(present).cuda()))
+    for q, sel in enumerate(selections):
+        own_dim0 = np.ascontiguousarray(dim0[:, q])
+        index = sel[0] + dims[0] * sel[1]
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, own_dim0, rest[q], database[chunk],
+                                                                 present[chunk], key)
+            assert np.array_equal(got[q, chunk], expected), (q, chunk)
+            want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
+            assert client.decrypt(got[q, chunk], moduli_count=1) == want
+
+
+def test_queries_share_one_pass_config_shape(oracle):
+    """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
+    8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours = heamd.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(77)
+    dims, chunks, queries = [8, 4], 2, 3
+    moduli = q[:-1]
+    dim0 = heamd.to_device(_uniform(rng, (dims[0], queries, 2), moduli, degree))
+    rest = heamd.to_device(_uniform(rng, (queries, dims[1], 2), moduli, degree))
+    database = heamd.to_device(_uniform(rng, (chunks, dims[0] * dims[1]), moduli, degree))
+    keys = [heamd.to_device(_uniform(rng, (ours.L, 2), q, degree)) for _ in range(queries)]
+    got = ours.pir_compute_response_queries(dims, dim0, rest, database, chunks, keys)
+    for query in range(queries):
+        single = ours.pir_compute_response(dims, dim0[:, query].contiguous(), rest[query], database, chunks,
+                                           relinearization_key=keys[query])
+        assert bool((got[query] == single).all()), query
+
+
 def test_column_shard_at_the_benchmark_row_count(oracle):
     """BASELINE configs[4]'s ring and row count (N=8192, L=4, d0 = 1024 query ciphertexts), two columns: the sampled
     output words equal the oracle's lazy inner product, every word is canonical, and the two-column launch equals two
