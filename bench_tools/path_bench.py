@@ -214,6 +214,9 @@ def run_all(quick=False):
                                                                 d1=16 if quick else 64)
     out["config5_pir_chunk_loop_1gpu"] = config5_pir_chunk_loop(torch, heamd, d0=64 if quick else 256,
                                                                 d1=16 if quick else 64, chunks=2 if quick else 8)
+    # four queries that share one pass over the same database (not a BASELINE line: the reference answers one at a time)
+    out["config5_pir_4_queries_1gpu"] = config5_pir_queries(torch, heamd, d0=64 if quick else 256, d1=16 if quick else 64,
+                                                            chunks=2 if quick else 8, queries=4)
     return out
 
 
