@@ -34,4 +34,6 @@ f=$(find $O/c3_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/c3_kernel_
 timeout 600 python bench_tools/next_rows_bench.py > $O/next_rows.txt 2>&1
 timeout 600 python bench_tools/word32_scheme_bench.py > $O/word32_scheme.json 2>&1
 timeout 600 python bench_tools/ntt_variants.py > $O/ntt_variants.txt 2>&1
+timeout 600 python bench_tools/expand_batch_profile_target.py > $O/expand_batch.txt 2>&1
+timeout 600 python bench_tools/wire_format_bench.py > $O/wire_format.json 2>&1
 rm -rf $O/bench_stats $O/c3_stats $O/pmc_c2/*/ $O/pmc_c3/*/ $O/pmc_c4/*/ $O/pmc_c5/*/
