@@ -125,7 +125,7 @@ def config4_mod_switch(torch, heamd, batch=8192, reps=5):
             "traffic_GBps": measured * batch / t / 1e9 if measured else None}
 
 
-def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1, masked=False):
+def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1, masked=False, packed=False):
     """PIR dim-0 shape on one GPU: `columns` outputs, each sum of `count` ct x pt products, N=8192, L=4.  queries > 1:
     that many queries' ciphertext vectors side by side share the database stream (poly_count = 2 queries)."""
     degree = 8192
@@ -134,7 +134,11 @@ def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1
     moduli = q[:-1]
     cts = _uniform(torch, moduli, (count, 2 * queries), degree, 5)
     pts = _uniform(torch, moduli, (columns, count), degree, 6)
-    if masked:  # a device-resident nil-plaintext mask (the last rows of a real database are padding): 1 in 64 nil
+    if packed:  # the database without the zero top bits of its words (55 of 64 bits)
+        database = ctx.pack_plaintexts(pts)
+        del pts
+        t = _timed(torch, lambda: ctx.inner_product_plain_packed(cts, database, None, 2, columns), reps)
+    elif masked:  # a device-resident nil-plaintext mask (the last rows of a real database are padding): 1 in 64 nil
         present = (torch.arange(columns * count, device="cuda") % 64 != 63).to(torch.uint8)
         t = _timed(torch, lambda: ctx.inner_product_plain_resident(cts, pts, present, 2 * queries, columns), reps)
     else:
@@ -142,7 +146,8 @@ def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1
     macs = count * columns
     db_bytes = macs * 4 * degree * 8
     measured = (_profiled("c5_inner_product_plain") or {}).get("hbm_bytes_per_unit") if queries == 1 else None
-    return {"count": count, "columns": columns, "queries": queries, "masked": masked, "ct_pt_mac_per_s": queries * macs / t,
+    return {"count": count, "columns": columns, "queries": queries, "masked": masked, "packed": packed,
+            "ct_pt_mac_per_s": queries * macs / t,
             "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12,
             "traffic_GBps": measured * macs / t / 1e9 if measured else None}
 

@@ -262,6 +262,20 @@ int he_bfv_inner_product_plain_device(const he_bfv_context* ctx, uint32_t moduli
 int he_bfv_inner_product_plain_resident_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
                                                const uint64_t* cts, const uint64_t* pts, const uint8_t* present_device,
                                                size_t count, size_t columns, uint64_t* out, he_stream s);
+/* The plaintexts without the zero top bits of their words -- a layout private to this library for databases that stay
+ * resident in HBM (the ct x pt inner product is bound by the bytes of plaintext it streams): row r of a plaintext is a
+ * little-endian bit stream of N fields of bits(q_r) bits, rows in whole 8-byte words; a 55-bit modulus takes 6.875 bytes
+ * per word instead of 8.  Degree >= 256, at most 8 moduli.
+ *   he_bfv_packed_plaintext_words     8-byte words per packed plaintext (0: unsupported parameters)
+ *   he_bfv_pack_plaintexts_device     plaintexts_eval [count][L][N] -> packed [count][words]
+ *   he_bfv_inner_product_plain_packed_device   he_bfv_inner_product_plain_resident_device with pts packed
+ *       ([columns][count][words]; polys 1..3); the same words out. */
+size_t he_bfv_packed_plaintext_words(const he_bfv_context* ctx, uint32_t moduli_count);
+int he_bfv_pack_plaintexts_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintexts_eval,
+                                  size_t count, uint64_t* packed, he_stream s);
+int he_bfv_inner_product_plain_packed_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                             const uint64_t* cts, const uint64_t* packed_pts, const uint8_t* present_device,
+                                             size_t count, size_t columns, uint64_t* out, he_stream s);
 /* Bfv.innerProduct(_: [CanonicalCiphertext], _: [CanonicalCiphertext]) (Bfv/Bfv.swift:315-361):
  * lhs, rhs [count][2][L][N] Coeff -> out [3][L][N] Coeff. */
 int he_bfv_inner_product_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs,
@@ -417,6 +431,17 @@ int he_pir_compute_response_queries_device(const he_bfv_context* ctx, const uint
                                            const uint64_t* remaining_queries, size_t remaining_query_count,
                                            const uint64_t* database, const uint8_t* present_device, size_t chunk_count,
                                            const uint64_t* const* relinearization_keys, uint64_t* out, he_stream s);
+/* The same two with the database packed (he_bfv_pack_plaintexts_device at the top level: [chunk][prod(dimensions)]
+ * [he_bfv_packed_plaintext_words] words): the dim-0 pass, which is bound by the
+ * database bytes it streams, reads bits(q) / 64 of them.  Same responses, word for word. */
+int he_pir_dim0_columns_packed_device(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0,
+                                      const uint64_t* packed_database, const uint8_t* present_device, size_t columns,
+                                      uint64_t* out, he_stream s);
+int he_pir_compute_response_packed_device(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                                          const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                                          size_t remaining_query_count, const uint64_t* packed_database,
+                                          const uint8_t* present_device, size_t chunk_count,
+                                          const uint64_t* relinearization_key, uint64_t* out, he_stream s);
 
 /* PirUtil.expand(ciphertexts:outputCount:using:) (PrivateInformationRetrieval/IndexPir/PirUtil.swift:196-355):
  * oblivious expansion of `ciphertext_count` query ciphertexts [..][2][L][N] (Coeff, top level) into `output_count`

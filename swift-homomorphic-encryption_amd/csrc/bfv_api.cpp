@@ -745,6 +745,79 @@ int he_bfv_inner_product_plain_resident_device(const he_bfv_context* ctx, uint32
     return inner_product_plain(ctx, moduli_count, poly_count, cts, pts, present_device, count, columns, out, as_stream(s));
 }
 
+// ------------------------------------------------------------------------------------------ packed plaintexts
+extern "C++" {
+namespace {
+// bits(q_r) per word, rows in whole 8-byte words (degree a multiple of 64)
+int packed_layout(const he_bfv_context* ctx, uint32_t moduli_count, heamd::PackedLayout& layout) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    if (moduli_count > heamd::kMaxPackedRows || pc->degree() < 256) {
+        heamd::set_last_error("packed plaintexts need degree >= 256 and at most 8 moduli");
+        return HE_ERR_UNSUPPORTED;
+    }
+    layout.rows = moduli_count;
+    layout.word_offset[0] = 0;
+    for (uint32_t r = 0; r < moduli_count; ++r) {
+        layout.width[r] = static_cast<uint32_t>(64 - __builtin_clzll(pc->moduli()[r]));
+        layout.word_offset[r + 1] = layout.word_offset[r] + static_cast<uint32_t>(pc->degree() / 64 * layout.width[r]);
+    }
+    return HE_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+size_t he_bfv_packed_plaintext_words(const he_bfv_context* ctx, uint32_t moduli_count) {
+    heamd::PackedLayout layout{};
+    if (ctx == nullptr || packed_layout(ctx, moduli_count, layout) != HE_OK) return 0;
+    return layout.word_offset[layout.rows];
+}
+
+int he_bfv_pack_plaintexts_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* plaintexts_eval,
+                                  size_t count, uint64_t* packed, he_stream s) {
+    heamd::PackedLayout layout{};
+    int status = packed_layout(ctx, moduli_count, layout);
+    if (status != HE_OK) return status;
+    if (count == 0) return HE_OK;
+    if (plaintexts_eval == nullptr || packed == nullptr) return invalid_argument("null operand");
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    HEAMD_HIP_TRY(heamd::launch_pack_rows(plaintexts_eval, packed, layout, pc->device_context().log_degree, count,
+                                          as_stream(s)));
+    return HE_OK;
+}
+
+int he_bfv_inner_product_plain_packed_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                             const uint64_t* cts, const uint64_t* packed_pts, const uint8_t* present_device,
+                                             size_t count, size_t columns, uint64_t* out, he_stream s) {
+    bool nothing = false;
+    int status = check_inner_product_plain(ctx, moduli_count, poly_count, cts, packed_pts, count, columns, out, &nothing);
+    if (status != HE_OK || nothing) return status;
+    if (poly_count > 3) return invalid_argument("packed plaintexts take poly_count 1..3");
+    heamd::PackedLayout layout{};
+    status = packed_layout(ctx, moduli_count, layout);
+    if (status != HE_OK) return status;
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    uint64_t cadence = pc->max_lazy_product_accumulation_count(moduli_count);
+    bool narrow_moduli = true;
+    for (uint32_t i = 0; i < moduli_count; ++i) {  // as in inner_product_plain above
+        narrow_moduli = narrow_moduli && (pc->moduli()[i] >> 56) == 0;
+        const unsigned __int128 below = pc->moduli()[i] - 1;
+        if (below == 0) continue;
+        const unsigned __int128 limit = ((static_cast<unsigned __int128>(1) << 127) - pc->moduli()[i]) / (below * below);
+        if (limit < cadence) cadence = static_cast<uint64_t>(limit);
+    }
+    if (cadence == 0) {
+        heamd::set_last_error("moduli too wide for the packed inner product");
+        return HE_ERR_UNSUPPORTED;
+    }
+    HEAMD_HIP_TRY(heamd::launch_inner_product_plain_packed(cts, packed_pts, layout, present_device, out,
+                                                           pc->device_context(), poly_count, count, columns, cadence,
+                                                           narrow_moduli, as_stream(s)));
+    return HE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ inner product ct . ct
 size_t he_bfv_inner_product_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t count) {
     if (ctx == nullptr || !ctx->impl->valid(moduli_count)) return 0;

@@ -482,6 +482,34 @@ __global__ void __launch_bounds__(kTileWaves * 64)
     }
 }
 
+// ---- packed residue rows (kernels.hpp PackedLayout): one wavefront per 64 coefficients = `width` stream words ---------
+__global__ void __launch_bounds__(kTileWaves * 64)
+    pack_rows_kernel(const uint64_t* __restrict__ slab, uint64_t* __restrict__ packed, const PackedLayout layout,
+                     uint32_t logn) {
+    __shared__ uint64_t tiles[kTileWaves][64 + 2];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t* fields = tiles[wave];
+    const size_t row_index = blockIdx.x, poly = row_index / layout.rows;
+    const uint32_t r = static_cast<uint32_t>(row_index - poly * layout.rows);
+    const uint32_t w = layout.width[r], tiles_per_row = 1u << (logn - 6);
+    const uint64_t* in = slab + (row_index << logn) + lane;
+    uint64_t* out = packed + poly * layout.word_offset[layout.rows] + layout.word_offset[r] + lane;
+    if (lane < 2) fields[64 + lane] = 0;  // read (and shifted out of range) by the last words of a tile
+    // stream word `lane` of a tile is bits [64 lane, 64 lane + 64): it starts inside field k0, `consumed0` bits in
+    const uint32_t k0 = (64 * lane) / w, consumed0 = 64 * lane - k0 * w;
+    for (uint32_t t = wave; t < tiles_per_row; t += kTileWaves) {
+        fields[lane] = stream_load(in + size_t(t) * 64);
+        wave_private_tile_fence();
+        if (lane < w) {
+            uint32_t k = k0;
+            uint64_t word = fields[k] >> consumed0;
+            for (uint32_t filled = w - consumed0; filled < 64; filled += w) word |= fields[++k] << filled;
+            stream_store(out + size_t(t) * w, word);
+        }
+        wave_private_tile_fence();
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -503,6 +531,16 @@ bool tile_aligned(const SerializeLayout& layout, const void* bytes, const void* 
     return true;
 }
 }  // namespace
+
+hipError_t launch_pack_rows(const uint64_t* slab, uint64_t* packed, const PackedLayout& layout, uint32_t log_degree,
+                            size_t polys, hipStream_t stream) {
+    const size_t rows = polys * layout.rows;
+    if (rows == 0) return hipSuccess;
+    if (log_degree < 6 || rows > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(kTileWaves * 64), 0, stream, slab, packed,
+                       layout, log_degree);
+    return hipGetLastError();
+}
 
 hipError_t launch_serialize(const uint64_t* slab, uint8_t* bytes, const SerializeLayout& layout, uint32_t log_degree,
                             uint32_t skip_lsbs, size_t batch, hipStream_t stream) {

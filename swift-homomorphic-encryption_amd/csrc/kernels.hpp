@@ -69,6 +69,27 @@ template <typename W>
 hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t* present_device, W* out,
                                       const DeviceContext& ctx, uint32_t poly_count, size_t count, size_t columns,
                                       uint64_t max_lazy, uint64_t cadence, bool narrow_moduli, hipStream_t stream);
+
+// ---- packed residue rows: the resident PIR database without the zero top bits of its words -------------------------
+// A library-private layout (nothing in the reference's wire format): row r of a polynomial is a little-endian bit
+// stream of N fields of width[r] = bits(q_r) bits -- coefficient i occupies stream bits [i width, (i + 1) width), stream
+// word j is bits [64 j, 64 j + 64) -- and starts at 8-byte word word_offset[r] of the polynomial (degree a multiple of
+// 64: whole words).  A 55-bit modulus stores 6.875 bytes per word instead of 8.
+constexpr uint32_t kMaxPackedRows = 8;
+struct PackedLayout {
+    uint32_t rows;
+    uint32_t width[kMaxPackedRows];
+    uint32_t word_offset[kMaxPackedRows + 1];  // [rows] = 8-byte words per packed polynomial
+};
+// slab [polys][rows][N] -> packed [polys][word_offset[rows]] words
+hipError_t launch_pack_rows(const uint64_t* slab, uint64_t* packed, const PackedLayout& layout, uint32_t log_degree,
+                            size_t polys, hipStream_t stream);
+// launch_inner_product_plain with the plaintexts packed: pts [columns][count][word_offset[rows]] words.  poly_count 1..3,
+// degree >= 256.
+hipError_t launch_inner_product_plain_packed(const uint64_t* cts, const uint64_t* packed_pts, const PackedLayout& layout,
+                                             const uint8_t* present_device, uint64_t* out, const DeviceContext& ctx,
+                                             uint32_t poly_count, size_t count, size_t columns, uint64_t cadence,
+                                             bool narrow_moduli, hipStream_t stream);
 // ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words
 hipError_t launch_mul_plain32(uint32_t* ct, const uint32_t* pt, const DeviceContext& ctx, uint32_t poly_count, size_t batch,
                               hipStream_t stream);

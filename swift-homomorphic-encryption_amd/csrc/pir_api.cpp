@@ -56,19 +56,36 @@ int chunk_shape(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t 
 
 }  // namespace
 
-extern "C" int he_pir_dim0_columns_device(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0,
-                                          const uint64_t* database, const uint8_t* present_device, size_t columns,
-                                          uint64_t* out, he_stream s) {
+namespace {
+// every column's ct . pt inner product in one launch (PirUtil.swift:428-437), then back to Coeff (:438); packed: the
+// database holds packed plaintexts (he_amd.h he_bfv_pack_plaintexts_device)
+int dim0_columns(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0, const uint64_t* database, bool packed,
+                 const uint8_t* present_device, size_t columns, uint64_t* out, he_stream s) {
     if (ctx == nullptr) return invalid_argument("null context");
     if (columns == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
     const uint32_t L = he_bfv_ciphertext_moduli_count(ctx);
     const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
     if (q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
-    // every column's ct . pt inner product in one launch (PirUtil.swift:428-437), then back to Coeff (:438)
-    HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(ctx, L, 2, dim0_query_eval, database, present_device, d0,
-                                                                columns, out, s));
+    if (packed)
+        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_packed_device(ctx, L, 2, dim0_query_eval, database, present_device, d0,
+                                                                  columns, out, s));
+    else
+        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(ctx, L, 2, dim0_query_eval, database, present_device,
+                                                                    d0, columns, out, s));
     return he_ntt_inverse_device(q_ctx, out, columns * 2, s);
+}
+}  // namespace
+
+extern "C" int he_pir_dim0_columns_device(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0,
+                                          const uint64_t* database, const uint8_t* present_device, size_t columns,
+                                          uint64_t* out, he_stream s) {
+    return dim0_columns(ctx, dim0_query_eval, d0, database, false, present_device, columns, out, s);
+}
+extern "C" int he_pir_dim0_columns_packed_device(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0,
+                                                 const uint64_t* packed_database, const uint8_t* present_device,
+                                                 size_t columns, uint64_t* out, he_stream s) {
+    return dim0_columns(ctx, dim0_query_eval, d0, packed_database, true, present_device, columns, out, s);
 }
 
 namespace {
@@ -124,14 +141,15 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
 // remaining dimensions of all chunks together
 int response_chunks_resident(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                              const ChunkShape& shape, size_t chunks, const uint64_t* dim0_query_eval,
-                             const uint64_t* remaining_query, const uint64_t* database, const uint8_t* present_device,
-                             const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+                             const uint64_t* remaining_query, const uint64_t* database, bool packed,
+                             const uint8_t* present_device, const uint64_t* relinearization_key, uint64_t* out,
+                             he_stream s) {
     Scratch results_mem(as_stream(s));
     HEAMD_HIP_TRY(results_mem.allocate(chunks * shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t)));
     uint64_t* results = static_cast<uint64_t*>(results_mem.get());
     // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
-    HEAMD_TRY_STATUS(he_pir_dim0_columns_device(ctx, dim0_query_eval, shape.d0, database, present_device,
-                                                chunks * shape.columns, results, s));
+    HEAMD_TRY_STATUS(dim0_columns(ctx, dim0_query_eval, shape.d0, database, packed, present_device, chunks * shape.columns,
+                                  results, s));
     return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
                                 relinearization_key, out, s);
 }
@@ -167,20 +185,24 @@ extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, c
         present_device = static_cast<const uint8_t*>(mask_mem.get());
     }
     return response_chunks_resident(ctx, dimensions, dimension_count, shape, 1, dim0_query_eval, remaining_query, database,
-                                    present_device, relinearization_key, out, s);
+                                    false, present_device, relinearization_key, out, s);
 }
 
-extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* dimensions,
-                                              uint32_t dimension_count, const uint64_t* dim0_query_eval,
-                                              const uint64_t* remaining_query, size_t remaining_query_count,
-                                              const uint64_t* database, const uint8_t* present_device,
-                                              size_t chunk_count, const uint64_t* relinearization_key, uint64_t* out,
-                                              he_stream s) {
+namespace {
+int compute_response(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                     const uint64_t* dim0_query_eval, const uint64_t* remaining_query, size_t remaining_query_count,
+                     const uint64_t* database, bool packed, const uint8_t* present_device, size_t chunk_count,
+                     const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
     ChunkShape shape;
     HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
     if (chunk_count == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
-    const size_t chunk_words = shape.per_chunk * size_t(shape.L) * shape.n, out_words = 2 * shape.n;
+    size_t plaintext_words = size_t(shape.L) * shape.n;
+    if (packed) {
+        plaintext_words = he_bfv_packed_plaintext_words(ctx, shape.L);
+        if (plaintext_words == 0) return HE_ERR_UNSUPPORTED;
+    }
+    const size_t chunk_words = shape.per_chunk * plaintext_words, out_words = 2 * shape.n;
     // The chunks are independent (the reference maps them over tasks, PirUtil.swift:533-563) and share the query: they are
     // answered together, `group` chunks per pass -- one dim-0 launch over all their columns, one batch per stage of
     // every remaining dimension -- with the group sized to keep the intermediate ciphertexts under ~1 GiB.
@@ -191,10 +213,30 @@ extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const u
         const size_t now = chunk_count - first < group ? chunk_count - first : group;
         HEAMD_TRY_STATUS(response_chunks_resident(
             ctx, dimensions, dimension_count, shape, now, dim0_query_eval, remaining_query, database + first * chunk_words,
-            present_device ? present_device + first * shape.per_chunk : nullptr, relinearization_key,
+            packed, present_device ? present_device + first * shape.per_chunk : nullptr, relinearization_key,
             out + first * out_words, s));
     }
     return HE_OK;
+}
+}  // namespace
+
+extern "C" int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                              uint32_t dimension_count, const uint64_t* dim0_query_eval,
+                                              const uint64_t* remaining_query, size_t remaining_query_count,
+                                              const uint64_t* database, const uint8_t* present_device,
+                                              size_t chunk_count, const uint64_t* relinearization_key, uint64_t* out,
+                                              he_stream s) {
+    return compute_response(ctx, dimensions, dimension_count, dim0_query_eval, remaining_query, remaining_query_count,
+                            database, false, present_device, chunk_count, relinearization_key, out, s);
+}
+extern "C" int he_pir_compute_response_packed_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                     uint32_t dimension_count, const uint64_t* dim0_query_eval,
+                                                     const uint64_t* remaining_query, size_t remaining_query_count,
+                                                     const uint64_t* packed_database, const uint8_t* present_device,
+                                                     size_t chunk_count, const uint64_t* relinearization_key,
+                                                     uint64_t* out, he_stream s) {
+    return compute_response(ctx, dimensions, dimension_count, dim0_query_eval, remaining_query, remaining_query_count,
+                            packed_database, true, present_device, chunk_count, relinearization_key, out, s);
 }
 
 // Several queries over the same database in one call: the dim-0 inner products of all of them stream the database once

@@ -272,12 +272,15 @@ __global__ void __launch_bounds__(kThreads)
 // MASKED: `present` is not null.  Every load is issued unconditionally (the item after the last one re-reads the last
 // one), the mask byte of an item travels with its plaintext words one item ahead: the loads in flight at each point are
 // then a fixed number and no wait drains the queue (a branch around a load makes the compiler wait for all of them).
-template <int POLYS, int COLS, bool NARROW, bool MASKED, typename W>
+// PACKED: `pts` holds packed residue rows (kernels.hpp PackedLayout, 8-byte slabs only): a lane fetches the two stream
+// words its field may straddle and shifts the field out -- 6.875 bytes of database per word at 55 bits instead of 8.
+template <int POLYS, int COLS, bool NARROW, bool MASKED, bool PACKED, typename W>
 __global__ void __launch_bounds__(kThreads)
     inner_product_plain_rows_kernel(const W* __restrict__ cts, const W* __restrict__ pts,
                                     const uint8_t* __restrict__ present, W* __restrict__ out,
                                     const DeviceContext ctx, size_t count, size_t columns, uint64_t cadence,
-                                    uint32_t column_groups) {
+                                    uint32_t column_groups, const PackedLayout packed) {
+    static_assert(!PACKED || sizeof(W) == 8, "packed plaintexts are 8-byte slabs");
     const uint32_t logn = ctx.log_degree;
     const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) << logn;
     // the column groups of one word block stream the same ciphertext words: one replica set per word block, so that
@@ -301,12 +304,32 @@ __global__ void __launch_bounds__(kThreads)
         live[c] = col0 + c < columns;
     }
     const W* ct_base = cts + word;
+    // one plaintext's words in `pts`, and this lane's place among them
+    size_t pt_stride = words_per_poly;
     const W* pt_lane = pts + word;
+    [[maybe_unused]] uint32_t field_shift = 0, first_word_lane = 0;
+    // per wavefront and column: 64 stream words and the one a last field's second word index may name (never used)
+    __shared__ uint64_t unpack_tile[PACKED ? kThreads / 64 : 1][PACKED ? COLS : 1][PACKED ? 66 : 1];
+    [[maybe_unused]] uint64_t field_mask = ~uint64_t(0);
+    if constexpr (PACKED) {
+        // The 64 fields of a wavefront are exactly `width` stream words: lane l < width fetches word l of that span (the
+        // others repeat the last one: no extra line, no divergent load) and every lane then takes the two words its field
+        // may lie in from the wavefront's LDS slice -- the vector-memory path carries the packed bytes and nothing else.
+        const uint32_t row = static_cast<uint32_t>(block_word >> logn), width = packed.width[row];
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t first_field = (static_cast<uint32_t>(word) & ((1u << logn) - 1u)) - lane;  // a multiple of 64
+        const uint32_t bit = lane * width;
+        pt_stride = packed.word_offset[packed.rows];
+        pt_lane = pts + packed.word_offset[row] + size_t(first_field / 64) * width + (lane < width ? lane : width - 1);
+        field_shift = bit & 63u;
+        first_word_lane = bit >> 6;  // index of the field's first word in the wavefront's span (the one after it: + 1)
+        field_mask = width == 64 ? ~uint64_t(0) : ((uint64_t(1) << width) - 1);
+    }
     size_t pt_column[COLS], mask_column[COLS];
 #pragma unroll
     for (int c = 0; c < COLS; ++c) {
         const size_t column = live[c] ? col0 + c : columns - 1;  // a column past the end re-reads the last one
-        pt_column[c] = column * count * words_per_poly;
+        pt_column[c] = column * count * pt_stride;
         mask_column[c] = column * count;
     }
     uint64_t x_next[POLYS], y_next[COLS];
@@ -316,7 +339,10 @@ __global__ void __launch_bounds__(kThreads)
         for (int q = 0; q < POLYS; ++q) x_next[q] = ct_base[(j * POLYS + q) * words_per_poly];
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {  // the database is read once: streamed past the caches (non-temporal)
-            y_next[c] = __builtin_nontemporal_load(pt_lane + pt_column[c] + j * words_per_poly);
+            // a packed span (64 fields = `width` words) does not end on a cache line: its neighbours re-read the line
+            // it shares with them, which has to come from L2 then, not from HBM a second time
+            if constexpr (PACKED) y_next[c] = pt_lane[pt_column[c] + j * pt_stride];
+            else y_next[c] = __builtin_nontemporal_load(pt_lane + pt_column[c] + j * pt_stride);
             if constexpr (MASKED) mask_next[c] = present[mask_column[c] + j];
         }
     };
@@ -329,6 +355,26 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {
             y[c] = y_next[c];
+            if constexpr (PACKED) {
+                // through the wavefront's slice of LDS: its `width` words in, every lane's two words out in one read;
+                // the LDS serves a wavefront's instructions in order, the fences only pin the compiler
+                uint64_t* span = unpack_tile[threadIdx.x >> 6][c];
+                span[threadIdx.x & 63u] = y[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint64_t first = span[first_word_lane], second = span[first_word_lane + 1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // the bits(q) bits starting at bit field_shift of (first, second): two 32-bit funnel shifts over the
+                // three double-words they touch
+                const bool upper = field_shift >= 32;
+                const uint32_t d0 = upper ? hi32(first) : lo32(first), d1 = upper ? lo32(second) : hi32(first),
+                               d2 = upper ? hi32(second) : lo32(second);
+                const uint32_t low = __builtin_amdgcn_alignbit(d1, d0, field_shift & 31u);
+                const uint32_t high = __builtin_amdgcn_alignbit(d2, d1, field_shift & 31u);
+                y[c] = pack64(low, high) & field_mask;
+            }
             if constexpr (MASKED) mask[c] = mask_next[c];
         }
         fetch(j + 1 < count ? j + 1 : j);
@@ -579,11 +625,13 @@ hipError_t launch_inner_product_plain_polys(const W* cts, const W* pts, const ui
     if (ctx.degree >= kThreads && cadence != 0 && static_cast<size_t>(grid.x) * grid.y < (size_t(1) << 31)) {
         // one-dimensional grid: the kernel places the column groups of a word block on one XCD itself
         if (present_device != nullptr)
-            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, true, W>), dim3(grid.x * grid.y),
-                               dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
+            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, true, false, W>),
+                               dim3(grid.x * grid.y), dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count,
+                               columns, cadence, grid.x, PackedLayout{});
         else
-            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, false, W>), dim3(grid.x * grid.y),
-                               dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count, columns, cadence, grid.x);
+            hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, COLS, NARROW, false, false, W>),
+                               dim3(grid.x * grid.y), dim3(kThreads), 0, stream, cts, pts, present_device, out, ctx, count,
+                               columns, cadence, grid.x, PackedLayout{});
         return hipGetLastError();
     }
     hipLaunchKernelGGL((inner_product_plain_kernel<POLYS, COLS, W>), grid, dim3(kThreads), 0, stream, cts, pts,
@@ -621,6 +669,50 @@ template hipError_t launch_inner_product_plain<uint64_t>(const uint64_t*, const 
 template hipError_t launch_inner_product_plain<uint32_t>(const uint32_t*, const uint32_t*, const uint8_t*, uint32_t*,
                                                          const DeviceContext&, uint32_t, size_t, size_t, uint64_t,
                                                          uint64_t, bool, hipStream_t);
+
+namespace {
+template <int POLYS, bool NARROW>
+hipError_t launch_packed_polys(const uint64_t* cts, const uint64_t* packed_pts, const PackedLayout& layout,
+                               const uint8_t* present_device, uint64_t* out, const DeviceContext& ctx, size_t count,
+                               size_t columns, uint64_t cadence, hipStream_t stream) {
+    constexpr int kCols = 4;
+    const size_t words_per_poly = static_cast<size_t>(ctx.moduli_count) * ctx.degree;
+    const size_t column_groups = (columns + kCols - 1) / kCols, blocks = column_groups * (words_per_poly / kThreads);
+    if (blocks >= (size_t(1) << 31)) return hipErrorInvalidValue;
+    const dim3 grid(static_cast<unsigned>(blocks));
+    if (present_device != nullptr)
+        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols, NARROW, true, true, uint64_t>), grid,
+                           dim3(kThreads), 0, stream, cts, packed_pts, present_device, out, ctx, count, columns, cadence,
+                           static_cast<uint32_t>(column_groups), layout);
+    else
+        hipLaunchKernelGGL((inner_product_plain_rows_kernel<POLYS, kCols, NARROW, false, true, uint64_t>), grid,
+                           dim3(kThreads), 0, stream, cts, packed_pts, present_device, out, ctx, count, columns, cadence,
+                           static_cast<uint32_t>(column_groups), layout);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_inner_product_plain_packed(const uint64_t* cts, const uint64_t* packed_pts, const PackedLayout& layout,
+                                             const uint8_t* present_device, uint64_t* out, const DeviceContext& ctx,
+                                             uint32_t poly_count, size_t count, size_t columns, uint64_t cadence,
+                                             bool narrow_moduli, hipStream_t stream) {
+    if (columns == 0) return hipSuccess;
+    if (ctx.degree < kThreads || cadence == 0 || layout.rows != ctx.moduli_count) return hipErrorInvalidValue;
+    if (narrow_moduli && cadence > kNarrowProductSumCadence) cadence = kNarrowProductSumCadence;
+#define HEAMD_PACKED_CASE(POLYS)                                                                                          \
+    case POLYS:                                                                                                           \
+        return narrow_moduli ? launch_packed_polys<POLYS, true>(cts, packed_pts, layout, present_device, out, ctx, count,  \
+                                                                columns, cadence, stream)                                 \
+                             : launch_packed_polys<POLYS, false>(cts, packed_pts, layout, present_device, out, ctx, count, \
+                                                                 columns, cadence, stream)
+    switch (poly_count) {
+        HEAMD_PACKED_CASE(1);
+        HEAMD_PACKED_CASE(2);
+        HEAMD_PACKED_CASE(3);
+        default: return hipErrorInvalidValue;
+    }
+#undef HEAMD_PACKED_CASE
+}
 
 // ct [batch][polys][L][N] *= pt [batch][L][N] on 4-byte words (one word per lane)
 namespace {

@@ -116,6 +116,12 @@ SIGNATURES = [
      [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
     ("he_bfv_inner_product_shared_device", ctypes.c_int, [vp, c_u32, vp, vp, c_size, c_size, vp, vp]),
+    ("he_bfv_packed_plaintext_words", c_size, [vp, c_u32]),
+    ("he_bfv_pack_plaintexts_device", ctypes.c_int, [vp, c_u32, vp, c_size, vp, vp]),
+    ("he_bfv_inner_product_plain_packed_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
+    ("he_pir_dim0_columns_packed_device", ctypes.c_int, [vp, vp, c_size, vp, vp, c_size, vp, vp]),
+    ("he_pir_compute_response_packed_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
     # Bfv<UInt32> on packed 4-byte slabs
     ("he_rns_lift_q_to_qbsk_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_rns_floor_qbsk_to_q_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
@@ -805,6 +811,45 @@ class BfvContext:
         _check(load_library().he_bfv_inner_product_plain_resident_device(self.h, L, poly_count, _ptr(cts), _ptr(pts),
                                                                          mask, count, columns, _ptr(out),
                                                                          _stream(stream)))
+        return out
+
+    def packed_plaintext_words(self, moduli_count=None):
+        return int(load_library().he_bfv_packed_plaintext_words(self.h, self._L(moduli_count)))
+
+    def pack_plaintexts(self, plaintexts_eval, moduli_count=None, stream=None):
+        """[...][L][N] Eval plaintexts -> [count * words + 1] packed words (one word of padding: the kernels read 8 bytes
+        past the last field)."""
+        import torch
+
+        L = self._L(moduli_count)
+        count = plaintexts_eval.numel() // (L * self.degree)
+        words = self.packed_plaintext_words(L)
+        out = torch.zeros(count * words + 1, dtype=torch.int64, device=plaintexts_eval.device)
+        _check(load_library().he_bfv_pack_plaintexts_device(self.h, L, _ptr(plaintexts_eval), count, _ptr(out),
+                                                            _stream(stream)))
+        return out
+
+    def inner_product_plain_packed(self, cts, packed_pts, present_device=None, poly_count=2, columns=1, moduli_count=None,
+                                   stream=None):
+        L = self._L(moduli_count)
+        count = cts.numel() // (poly_count * L * self.degree)
+        out = self._empty((columns, poly_count, L, self.degree), cts)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_bfv_inner_product_plain_packed_device(self.h, L, poly_count, _ptr(cts), _ptr(packed_pts),
+                                                                       mask, count, columns, _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_packed(self, dimensions, dim0_query_eval, remaining_query, packed_database, chunk_count,
+                                    present_device=None, relinearization_key=None, stream=None):
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = self._empty((chunk_count, 2, 1, self.degree), dim0_query_eval)
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_packed_device(self.h, dims, len(dimensions), _ptr(dim0_query_eval),
+                                                                    rest, rest_count, _ptr(packed_database), mask,
+                                                                    chunk_count, key, _ptr(out), _stream(stream)))
         return out
 
     def inner_product(self, lhs, rhs, moduli_count=None, stream=None):

@@ -307,6 +307,82 @@ def test_queries_share_one_pass_config_shape(oracle):
         assert bool((got[query] == single).all()), query
 
 
+def _unpack_rows(packed, moduli, degree, count):
+    """Host restatement of the packed layout (kernels.hpp PackedLayout): per row a little-endian stream of N fields of
+    bits(q) bits, rows in whole 8-byte words."""
+    widths = [int(m).bit_length() for m in moduli]
+    words = sum(degree // 64 * w for w in widths)
+    out = np.zeros((count, len(moduli), degree), dtype=np.uint64)
+    data = [int(v) for v in packed[: count * words]]
+    for p in range(count):
+        at = p * words
+        for r, w in enumerate(widths):
+            row_words = degree // 64 * w
+            stream = 0
+            for j in range(row_words):
+                stream |= data[at + j] << (64 * j)
+            mask = (1 << w) - 1
+            for i in range(degree):
+                out[p, r, i] = (stream >> (i * w)) & mask
+            at += row_words
+    return out
+
+
+@pytest.mark.parametrize("bits", [[55, 55, 55], [40, 56, 33, 55], [62, 61, 62]])
+def test_packed_database_matches_plain(oracle, bits):
+    """The packed plaintext layout (bits(q) bits per word, he_bfv_pack_plaintexts_device): the packed words unpack to the
+    plaintexts on the host, and the inner products and the whole chunk loop over the packed database equal the ones over
+    8-byte words word for word -- masks included, moduli of mixed widths, 62-bit moduli (full accumulator)."""
+    import torch
+
+    degree = 256
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours = heamd.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(len(bits))
+    dims, chunks = [5, 3], 2
+    database = _uniform(rng, (chunks, dims[0] * dims[1]), moduli, degree)
+    database[0, 0] = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    database[0, 1] = 0
+    device_db = heamd.to_device(database)
+    packed = ours.pack_plaintexts(device_db)
+    assert packed.numel() == chunks * 15 * ours.packed_plaintext_words() + 1
+    assert np.array_equal(_unpack_rows(heamd.to_host(packed), moduli, degree, chunks * 15), database.reshape(-1, len(moduli), degree))
+    present = np.ones((chunks, 15), dtype=np.uint8)
+    present[1, [2, 14]] = 0
+    mask = torch.from_numpy(present).cuda()
+    dim0 = heamd.to_device(_uniform(rng, (dims[0], 2), moduli, degree))
+    rest = heamd.to_device(_uniform(rng, (dims[1], 2), moduli, degree))
+    key = heamd.to_device(_uniform(rng, (ours.L, 2), q, degree))
+    # the inner product alone: the first chunk's columns ([column][d0] plaintexts)
+    plain = ours.inner_product_plain_resident(dim0, device_db[0], mask[0], 2, dims[1])
+    from_packed = ours.inner_product_plain_packed(dim0, packed, mask[0], 2, dims[1])
+    assert bool((plain == from_packed).all())
+    want = ours.pir_compute_response(dims, dim0, rest, device_db, chunks, present_device=mask, relinearization_key=key)
+    got = ours.pir_compute_response_packed(dims, dim0, rest, packed, chunks, present_device=mask, relinearization_key=key)
+    assert bool((want == got).all())
+
+
+def test_packed_database_config_shape(oracle):
+    """BASELINE config 5's ring (N=8192, L=4, 55-bit moduli: 56 320 bytes per row instead of 65 536): 16 x 4 database,
+    packed and plain inner products agree on every word, and one column equals the oracle's."""
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    assert ours.packed_plaintext_words() == 4 * 8192 * 55 // 64
+    rng = np.random.default_rng(88)
+    count, columns = 16, 4
+    cts = _uniform(rng, (count, 2), moduli, degree)
+    pts = _uniform(rng, (columns, count), moduli, degree)
+    device_cts, device_pts = heamd.to_device(cts), heamd.to_device(pts)
+    packed = ours.pack_plaintexts(device_pts)
+    got = ours.inner_product_plain_packed(device_cts, packed, None, 2, columns)
+    assert bool((got == ours.inner_product_plain_resident(device_cts, device_pts, None, 2, columns)).all())
+    assert np.array_equal(heamd.to_host(got)[3], ref.inner_product_plain(cts, pts[3], None))
+
+
 def test_column_shard_at_the_benchmark_row_count(oracle):
     """BASELINE configs[4]'s ring and row count (N=8192, L=4, d0 = 1024 query ciphertexts), two columns: the sampled
     output words equal the oracle's lazy inner product, every word is canonical, and the two-column launch equals two
