@@ -251,6 +251,7 @@ int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, ui
  *   pts      [columns][count][L][N]         Eval plaintexts over the ciphertext context
  *   present  HOST [columns][count] bytes, 0 = nil plaintext (skipped, Bfv.swift:494); NULL = all present
  *   out      [columns][polys][L][N]         Eval
+ * Every word must be a canonical residue (< q_i), as the reference's polynomials are: the accumulators count on it.
  * polys = 1, 2 or 3 polynomials per ciphertext -- or 4, 6, 8: the ciphertext vectors of 2, 3 or 4 QUERIES laid side by
  * side ([count][query][2][L][N]), which then share every plaintext word the kernel streams (out [columns][query][2]
  * [L][N]): a server that answers several queries over one database reads the database once for all of them. */
