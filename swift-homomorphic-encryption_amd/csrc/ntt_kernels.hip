@@ -55,14 +55,6 @@
 #else
 #define HEAMD_X_PASS(statement) statement
 #endif
-#ifdef HEAMD_X_STAGGER  // delay the second workgroup slot of every CU at kernel start (HEAMD_X_STAGGER x 64 x 127 clocks)
-#define HEAMD_X_PROLOGUE()                                                          \
-    if (blockIdx.x >= 256 && blockIdx.x < 512)                                      \
-        for (int k_ = 0; k_ < HEAMD_X_STAGGER; ++k_) __builtin_amdgcn_s_sleep(127)
-#else
-#define HEAMD_X_PROLOGUE() (void)0
-#endif
-
 namespace heamd {
 
 namespace {
@@ -268,7 +260,6 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
-        HEAMD_X_PROLOGUE();
         if constexpr (SPREAD != kSourceSlab) {
             bool reduce[ROWS];  // uniform: the source row is canonical mod a larger modulus than this row's
 #pragma unroll
