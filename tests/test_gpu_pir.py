@@ -287,6 +287,33 @@ def test_queries_share_one_pass_over_the_database(oracle, small, queries):
             assert client.decrypt(got[q, chunk], moduli_count=1) == want
 
 
+def test_queries_over_a_one_dimensional_database(oracle, small):
+    """One dimension: no remaining query, no relinearization key (PirUtil.swift:448 loop is empty); three queries in one
+    call each equal the single-query chunk response; five queries are refused."""
+    ours, ref, client = small
+    rng = random.Random(311)
+    dims, chunks = [5], 2
+    entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(5 * chunks)]
+    database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64)).reshape(chunks, 5, ref.L, ref.degree)
+    qctx = ref.ciphertext_context()
+    one, zero = [1] + [0] * (ref.degree - 1), [0] * ref.degree
+    picks = [4, 0, 2]
+    dim0 = np.stack([np.stack([qctx.forward_ntt(client.encrypt(one if k == pick else zero)) for pick in picks])
+                     for k in range(dims[0])])
+    device_db = heamd.to_device(database)
+    got = heamd.to_host(ours.pir_compute_response_queries(dims, heamd.to_device(dim0), None, device_db, chunks, None))
+    for q, pick in enumerate(picks):
+        single = heamd.to_host(ours.pir_compute_response(dims, heamd.to_device(np.ascontiguousarray(dim0[:, q])), None,
+                                                         device_db, chunks))
+        assert np.array_equal(got[q], single)
+        for chunk in range(chunks):
+            assert client.decrypt(got[q, chunk], moduli_count=1) == entries[chunk * 5 + pick]
+    five = heamd.to_device(np.zeros((dims[0], 5, 2, ref.L, ref.degree), dtype=np.uint64))
+    with pytest.raises(heamd.HeError) as err:
+        ours.pir_compute_response_queries(dims, five, None, device_db, chunks, None)
+    assert err.value.name == "invalidArgument"
+
+
 def test_queries_share_one_pass_config_shape(oracle):
     """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
     8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
