@@ -203,6 +203,26 @@ def config5_pir_queries(torch, heamd, d0=256, d1=64, chunks=8, queries=4, reps=3
             "chunk_responses_per_s": chunks * queries / t, "database_GBps_per_query_share": db_bytes * queries / t / 1e9}
 
 
+def config5_pir_whole_query(torch, heamd, d0=256, d1=64, chunks=8, indices=1, reps=3):
+    """The whole server side of one Query (he_pir_compute_response_to_query_device = PirUtil.computeResponse with one
+    database): expansion of one query ciphertext into (d0 + d1) x indices selection ciphertexts, dim-0 to Eval, every
+    chunk answered.  Uniform words and keys (the arithmetic does not depend on the values)."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    total = (d0 + d1) * indices
+    query = _uniform(torch, moduli, (1, 2), degree, 7)
+    elements = sorted({(degree >> level) + 1 for level in range(max((total - 1).bit_length(), 1))})
+    galois = {e: _uniform(torch, q, (ctx.L, 2), degree, 20 + i) for i, e in enumerate(elements)}
+    relin = _uniform(torch, q, (ctx.L, 2), degree, 10)
+    database = _uniform(torch, moduli, (chunks, d0 * d1), degree, 9)
+    t = _timed(torch, lambda: ctx.pir_compute_response_to_query([d0, d1], query, indices, galois, relin, database, chunks),
+               reps)
+    return {"dimensions": [d0, d1], "chunks": chunks, "indices": indices, "ms_per_query": t * 1e3,
+            "ms_per_index": t / indices * 1e3, "chunk_responses_per_s": chunks * indices / t}
+
+
 def run_all(quick=False):
     import torch
 
@@ -222,6 +242,8 @@ def run_all(quick=False):
     # four queries that share one pass over the same database (not a BASELINE line: the reference answers one at a time)
     out["config5_pir_4_queries_1gpu"] = config5_pir_queries(torch, heamd, d0=64 if quick else 256, d1=16 if quick else 64,
                                                             chunks=2 if quick else 8, queries=4)
+    out["config5_pir_whole_query_1gpu"] = config5_pir_whole_query(torch, heamd, d0=64 if quick else 256,
+                                                                  d1=16 if quick else 64, chunks=2 if quick else 8, indices=1)
     return out
 
 

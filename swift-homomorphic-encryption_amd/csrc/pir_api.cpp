@@ -242,13 +242,13 @@ extern "C" int he_pir_compute_response_packed_device(const he_bfv_context* ctx, 
 // Several queries over the same database in one call: the dim-0 inner products of all of them stream the database once
 // (their ciphertext vectors side by side, he_amd.h he_bfv_inner_product_plain_device with polys = 2 x queries); the
 // remaining dimensions, which involve only query ciphertexts and intermediate results, then run query by query.
-extern "C" int he_pir_compute_response_queries_device(const he_bfv_context* ctx, const uint32_t* dimensions,
-                                                      uint32_t dimension_count, size_t queries,
-                                                      const uint64_t* dim0_queries_eval, const uint64_t* remaining_queries,
-                                                      size_t remaining_query_count, const uint64_t* database,
-                                                      const uint8_t* present_device, size_t chunk_count,
-                                                      const uint64_t* const* relinearization_keys, uint64_t* out,
-                                                      he_stream s) {
+namespace {
+// remaining_stride: ciphertexts from one query's remaining ciphertexts to the next query's
+int compute_response_queries(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count, size_t queries,
+                             const uint64_t* dim0_queries_eval, const uint64_t* remaining_queries,
+                             size_t remaining_query_count, size_t remaining_stride, const uint64_t* database,
+                             const uint8_t* present_device, size_t chunk_count,
+                             const uint64_t* const* relinearization_keys, uint64_t* out, he_stream s) {
     ChunkShape shape;
     HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_queries, remaining_query_count, shape));
     if (queries == 0 || chunk_count == 0) return HE_OK;
@@ -282,11 +282,24 @@ extern "C" int he_pir_compute_response_queries_device(const he_bfv_context* ctx,
                                            hipMemcpyDeviceToDevice, stream));
             HEAMD_TRY_STATUS(remaining_dimensions(
                 ctx, dimensions, dimension_count, shape, now, one,
-                remaining_queries ? remaining_queries + q * remaining_query_count * ct_words : nullptr,
+                remaining_queries ? remaining_queries + q * remaining_stride * ct_words : nullptr,
                 relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words, s));
         }
     }
     return HE_OK;
+}
+}  // namespace
+
+extern "C" int he_pir_compute_response_queries_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                      uint32_t dimension_count, size_t queries,
+                                                      const uint64_t* dim0_queries_eval, const uint64_t* remaining_queries,
+                                                      size_t remaining_query_count, const uint64_t* database,
+                                                      const uint8_t* present_device, size_t chunk_count,
+                                                      const uint64_t* const* relinearization_keys, uint64_t* out,
+                                                      he_stream s) {
+    return compute_response_queries(ctx, dimensions, dimension_count, queries, dim0_queries_eval, remaining_queries,
+                                    remaining_query_count, remaining_query_count, database, present_device, chunk_count,
+                                    relinearization_keys, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -525,4 +538,60 @@ extern "C" int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* c
                                     he_stream s) {
     return he_pir_expand_batch_device(ctx, ciphertexts, 1, ciphertext_count, output_count, galois_elements, galois_keys,
                                       galois_key_count, out, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PirUtilProtocol.computeResponse(to:using:databases:parameter:context:callOptions:) with one database
+// (PirUtil.swift:490-568): expand the query's ciphertexts into expandedQueryCount = sum(dimensions) selection
+// ciphertexts per queried index (:500-505, :565-566), take each index's first dimensions[0] of them to Eval
+// (:520-533), and answer every chunk (:545-563).  The indices of one Query share the database: up to four of them at
+// a time share one pass over it.
+extern "C" int he_pir_compute_response_to_query_device(
+    const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count, const uint64_t* query_ciphertexts,
+    size_t query_ciphertext_count, size_t indices_count, const uint64_t* galois_elements,
+    const uint64_t* const* galois_keys, size_t galois_key_count, const uint64_t* relinearization_key,
+    const uint64_t* database, const uint8_t* present_device, size_t chunk_count, uint64_t* out, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    if (dimensions == nullptr || dimension_count == 0) return invalid_argument("empty dimensions");
+    size_t expanded_count = 0;
+    for (uint32_t i = 0; i < dimension_count; ++i) expanded_count += dimensions[i];
+    const size_t remaining_count = expanded_count - dimensions[0];
+    ChunkShape shape;
+    // the remaining query is checked against the shape below; a placeholder stands in for it here
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_count ? query_ciphertexts : nullptr,
+                                 remaining_count, shape));
+    if (indices_count == 0 || chunk_count == 0) return HE_OK;
+    if (query_ciphertexts == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    const size_t ct_words = 2 * size_t(shape.L) * shape.n, ct_bytes = ct_words * sizeof(uint64_t);
+    const size_t total = expanded_count * indices_count, out_words = 2 * shape.n;
+    Scratch expanded_mem(stream), side_mem(stream);
+    HEAMD_HIP_TRY(expanded_mem.allocate(total * ct_bytes));
+    uint64_t* expanded = static_cast<uint64_t*>(expanded_mem.get());  // [index][sum(dimensions)][2][L][N] Coeff
+    HEAMD_TRY_STATUS(he_pir_expand_device(ctx, query_ciphertexts, query_ciphertext_count, total, galois_elements,
+                                          galois_keys, galois_key_count, expanded, s));
+    constexpr size_t kTogether = 4;
+    HEAMD_HIP_TRY(side_mem.allocate(shape.d0 * kTogether * ct_bytes));
+    uint64_t* side = static_cast<uint64_t*>(side_mem.get());  // [dimensions[0]][indices of a group][2][L][N]
+    const uint64_t* keys[kTogether] = {relinearization_key, relinearization_key, relinearization_key, relinearization_key};
+    for (size_t first = 0; first < indices_count; first += kTogether) {
+        const size_t now = indices_count - first < kTogether ? indices_count - first : kTogether;
+        // the group's dim-0 ciphertexts side by side, then to Eval (convertToEvalFormat, PirUtil.swift:520-533)
+        for (size_t q = 0; q < now; ++q)
+            HEAMD_HIP_TRY(hipMemcpy2DAsync(side + q * ct_words, now * ct_bytes, expanded + (first + q) * expanded_count * ct_words,
+                                           ct_bytes, ct_bytes, shape.d0, hipMemcpyDeviceToDevice, stream));
+        HEAMD_TRY_STATUS(he_ntt_forward_device(shape.q_ctx, side, shape.d0 * now * 2, s));
+        const uint64_t* rest = remaining_count ? expanded + (first * expanded_count + shape.d0) * ct_words : nullptr;
+        uint64_t* group_out = out + first * chunk_count * out_words;
+        if (now == 1) {
+            HEAMD_TRY_STATUS(he_pir_compute_response_device(ctx, dimensions, dimension_count, side, rest, remaining_count,
+                                                            database, present_device, chunk_count, relinearization_key,
+                                                            group_out, s));
+        } else {
+            HEAMD_TRY_STATUS(compute_response_queries(ctx, dimensions, dimension_count, now, side, rest, remaining_count,
+                                                      expanded_count, database, present_device, chunk_count,
+                                                      dimension_count > 1 ? keys : nullptr, group_out, s));
+        }
+    }
+    return HE_OK;
 }

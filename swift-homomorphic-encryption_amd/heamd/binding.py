@@ -120,6 +120,8 @@ SIGNATURES = [
     ("he_bfv_pack_plaintexts_device", ctypes.c_int, [vp, c_u32, vp, c_size, vp, vp]),
     ("he_bfv_inner_product_plain_packed_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_pir_dim0_columns_packed_device", ctypes.c_int, [vp, vp, c_size, vp, vp, c_size, vp, vp]),
+    ("he_pir_compute_response_to_query_device", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp, vp, c_size, vp, vp]),
     ("he_pir_compute_response_packed_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
     # Bfv<UInt32> on packed 4-byte slabs
@@ -752,6 +754,24 @@ class BfvContext:
         _check(load_library().he_pir_compute_response_device(self.h, dims, len(dimensions), _ptr(dim0_query_eval), rest,
                                                              rest_count, _ptr(database), mask, chunk_count, key,
                                                              _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_to_query(self, dimensions, query_ciphertexts, indices_count, galois_keys, relinearization_key,
+                                      database, chunk_count, present_device=None, stream=None):
+        """PirUtil.computeResponse for one database: Query.ciphertexts [count][2][L][N] Coeff + the evaluation key
+        ({element: Galois key tensor}, relinearization key tensor or None) -> [indices][chunks][2][1][N]."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        count = query_ciphertexts.numel() // (2 * self.L * self.degree)
+        out = self._empty((indices_count, chunk_count, 2, 1, self.degree), query_ciphertexts)
+        elements = sorted(galois_keys)
+        element_array = _u64(elements)
+        key_array = (vp * max(len(elements), 1))(*[vp(galois_keys[e].data_ptr()) for e in elements])
+        relin = vp() if relinearization_key is None else _ptr(relinearization_key)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_to_query_device(
+            self.h, dims, len(dimensions), _ptr(query_ciphertexts), count, indices_count,
+            element_array.ctypes.data_as(U64P), key_array, len(elements), relin, _ptr(database), mask, chunk_count,
+            _ptr(out), _stream(stream)))
         return out
 
     def pir_compute_response_queries(self, dimensions, dim0_queries_eval, remaining_queries, database, chunk_count,

@@ -45,7 +45,8 @@ public enum GpuPirUtil: PirUtilProtocol {
         // the chunk: plaintext k of column c at index c * d0 + k (MulPir.swift:547-555); nil plaintexts are masked out.
         // A server that answers many queries keeps this slab resident and uploads it once (he_pir_compute_response_device
         // takes all chunks of a database at once, he_pir_compute_response_queries_device up to four queries that then
-        // share one pass over it); it is uploaded per call here to keep the protocol's signature.
+        // share one pass over it, he_pir_compute_response_to_query_device the whole computeResponse(to:...) of a
+        // Query); it is uploaded per call here to keep the protocol's signature.
         let database = try DeviceBuffer(count: perChunk * polyWords)
         var present = [UInt8](repeating: 0, count: perChunk)
         for (index, plaintext) in dataChunk.enumerated() where index < perChunk {

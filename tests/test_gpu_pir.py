@@ -314,6 +314,51 @@ def test_queries_over_a_one_dimensional_database(oracle, small):
     assert err.value.name == "invalidArgument"
 
 
+@pytest.mark.parametrize("indices", [1, 3, 6])
+def test_whole_query_response(oracle, small, indices):
+    """he_pir_compute_response_to_query_device = PirUtil.computeResponse with one database (PirUtil.swift:490-568): the
+    query ciphertext expands into sum(dimensions) selection ciphertexts per index, each index's first dimensions[0] go to
+    Eval, every chunk is answered.  Word for word the composition of the oracle's expand and chunk responses, for 1, 3
+    and 6 indices in one Query (6: a group of four sharing the database pass, then two), and the responses decrypt to
+    the selected entries."""
+    import torch
+
+    ours, ref, client = small
+    n = ref.degree
+    rng = random.Random(400 + indices)
+    dims, chunks, per_chunk = [4, 3], 2, 12
+    expanded_count = sum(dims)
+    total = expanded_count * indices
+    entries = [[rng.randrange(ref.t) for _ in range(n)] for _ in range(per_chunk * chunks)]
+    database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64)).reshape(chunks, per_chunk, ref.L, n)
+    present = np.ones((chunks, per_chunk), dtype=np.uint8)
+    present[0, 5] = 0
+    selections = [(rng.randrange(dims[0]), rng.randrange(dims[1])) for _ in range(indices)]
+    ones = []
+    for i, (a, b) in enumerate(selections):
+        ones += [i * expanded_count + a, i * expanded_count + dims[0] + b]
+    query = client.encrypt(_compressed_query(ref, total, ones))[None]
+    shifts = range(0, max((total - 1).bit_length(), 1))
+    galois = {(n >> k) + 1: client.galois_key((n >> k) + 1) for k in shifts}
+    relin = client.relinearization_key()
+    got = heamd.to_host(ours.pir_compute_response_to_query(
+        dims, heamd.to_device(query), indices, {e: heamd.to_device(k) for e, k in galois.items()}, heamd.to_device(relin),
+        heamd.to_device(database), chunks, present_device=torch.from_numpy(present).cuda()))
+    expanded = oracle.pir.expand(ref, query, total, galois)
+    qctx = ref.ciphertext_context()
+    zero = [0] * n
+    for i, (a, b) in enumerate(selections):
+        mine = expanded[i * expanded_count: (i + 1) * expanded_count]
+        dim0 = np.stack([qctx.forward_ntt(ct) for ct in mine[: dims[0]]])
+        index = a + dims[0] * b
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, mine[dims[0]:], database[chunk],
+                                                                 present[chunk], relin)
+            assert np.array_equal(got[i, chunk], expected), (i, chunk)
+            want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
+            assert client.decrypt(got[i, chunk], moduli_count=1) == want
+
+
 def test_queries_share_one_pass_config_shape(oracle):
     """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
     8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
