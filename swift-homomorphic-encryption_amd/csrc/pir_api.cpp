@@ -571,27 +571,34 @@ extern "C" int he_pir_compute_response_to_query_device(
     HEAMD_TRY_STATUS(he_pir_expand_device(ctx, query_ciphertexts, query_ciphertext_count, total, galois_elements,
                                           galois_keys, galois_key_count, expanded, s));
     constexpr size_t kTogether = 4;
-    HEAMD_HIP_TRY(side_mem.allocate(shape.d0 * kTogether * ct_bytes));
-    uint64_t* side = static_cast<uint64_t*>(side_mem.get());  // [dimensions[0]][indices of a group][2][L][N]
+    const size_t widest = indices_count < kTogether ? indices_count : kTogether;
+    uint64_t* side = nullptr;  // [dimensions[0]][indices of a group][2][L][N]
+    if (widest > 1) {
+        HEAMD_HIP_TRY(side_mem.allocate(shape.d0 * widest * ct_bytes));
+        side = static_cast<uint64_t*>(side_mem.get());
+    }
     const uint64_t* keys[kTogether] = {relinearization_key, relinearization_key, relinearization_key, relinearization_key};
     for (size_t first = 0; first < indices_count; first += kTogether) {
         const size_t now = indices_count - first < kTogether ? indices_count - first : kTogether;
-        // the group's dim-0 ciphertexts side by side, then to Eval (convertToEvalFormat, PirUtil.swift:520-533)
-        for (size_t q = 0; q < now; ++q)
-            HEAMD_HIP_TRY(hipMemcpy2DAsync(side + q * ct_words, now * ct_bytes, expanded + (first + q) * expanded_count * ct_words,
-                                           ct_bytes, ct_bytes, shape.d0, hipMemcpyDeviceToDevice, stream));
-        HEAMD_TRY_STATUS(he_ntt_forward_device(shape.q_ctx, side, shape.d0 * now * 2, s));
-        const uint64_t* rest = remaining_count ? expanded + (first * expanded_count + shape.d0) * ct_words : nullptr;
+        uint64_t* mine = expanded + first * expanded_count * ct_words;  // this group's selection ciphertexts
+        const uint64_t* rest = remaining_count ? mine + shape.d0 * ct_words : nullptr;
         uint64_t* group_out = out + first * chunk_count * out_words;
         if (now == 1) {
-            HEAMD_TRY_STATUS(he_pir_compute_response_device(ctx, dimensions, dimension_count, side, rest, remaining_count,
+            // convertToEvalFormat (PirUtil.swift:520-533) where the expansion left the dim-0 ciphertexts
+            HEAMD_TRY_STATUS(he_ntt_forward_device(shape.q_ctx, mine, shape.d0 * 2, s));
+            HEAMD_TRY_STATUS(he_pir_compute_response_device(ctx, dimensions, dimension_count, mine, rest, remaining_count,
                                                             database, present_device, chunk_count, relinearization_key,
                                                             group_out, s));
-        } else {
-            HEAMD_TRY_STATUS(compute_response_queries(ctx, dimensions, dimension_count, now, side, rest, remaining_count,
-                                                      expanded_count, database, present_device, chunk_count,
-                                                      dimension_count > 1 ? keys : nullptr, group_out, s));
+            continue;
         }
+        // the group's dim-0 ciphertexts side by side, then to Eval
+        for (size_t q = 0; q < now; ++q)
+            HEAMD_HIP_TRY(hipMemcpy2DAsync(side + q * ct_words, now * ct_bytes, mine + q * expanded_count * ct_words,
+                                           ct_bytes, ct_bytes, shape.d0, hipMemcpyDeviceToDevice, stream));
+        HEAMD_TRY_STATUS(he_ntt_forward_device(shape.q_ctx, side, shape.d0 * now * 2, s));
+        HEAMD_TRY_STATUS(compute_response_queries(ctx, dimensions, dimension_count, now, side, rest, remaining_count,
+                                                  expanded_count, database, present_device, chunk_count,
+                                                  dimension_count > 1 ? keys : nullptr, group_out, s));
     }
     return HE_OK;
 }
