@@ -454,7 +454,7 @@ int he_pir_compute_response_packed_device(const he_bfv_context* ctx, const uint3
  *   relinearization_key device key (NULL for one-dimensional databases)
  *   database            [chunk_count][prod(dimensions)][L][N] Eval, present_device as above
  *   out                 [indices_count][chunk_count][2][1][N]  (Response.ciphertexts)
- * Synchronises once (the expansion plan's upload), then enqueue-only. */
+ * Enqueue-only once the context has seen the query's shape (he_pir_expand_device). */
 int he_pir_compute_response_to_query_device(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                                             const uint64_t* query_ciphertexts, size_t query_ciphertext_count,
                                             size_t indices_count, const uint64_t* galois_elements,
@@ -469,8 +469,8 @@ int he_pir_compute_response_to_query_device(const he_bfv_context* ctx, const uin
  * he_bfv_apply_galois_device).  Per tree level the largest element <= the target element is applied
  * 2^(log2(target-1) - log2(element-1)) times (PirUtil.swift:217-231); none available -> HE_ERR_MISSING_GALOIS_KEY.
  * The count preconditions of PirUtil.swift:325-326 return HE_ERR_INVALID_ARGUMENT.
- * The recursion is planned on the host; the call waits on `s` once, for the upload of that plan (a few KB), and
- * returns with the levels' launches enqueued. */
+ * The recursion is planned on the host once per (ciphertext_count, output_count) and context: the first call of a shape
+ * uploads the plan (a blocking copy of a few KB, kept by the context); every later one is enqueue-only. */
 int he_pir_expand_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t ciphertext_count,
                          size_t output_count, const uint64_t* galois_elements, const uint64_t* const* galois_keys,
                          size_t galois_key_count, uint64_t* out, he_stream s);

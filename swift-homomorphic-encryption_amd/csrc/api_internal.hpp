@@ -4,7 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/he_amd.h"
 #include "poly_context.hpp"
@@ -46,6 +51,45 @@ inline void keep_scratch_cached() {
     (void)hipGetLastError();
     configured.fetch_or(bit, std::memory_order_relaxed);
 }
+
+// The recursion tree of PirUtil.expand for one (ciphertext count, output count) on one ring: the data movement of every
+// level (pir_api.cpp).  Planned on the first use, kept by the context with its table on the device, so that later
+// expansions of the same shape neither plan nor copy nor wait.
+struct ExpandPlan {
+    struct Level {
+        size_t nodes = 0, leaf_offset = 0, leaf_count = 0, parent_offset = 0, parent_count = 0;
+        bool gather = false;
+    };
+    std::vector<Level> levels;
+    size_t widest = 0;
+    uint32_t* table_device = nullptr;
+    ExpandPlan() = default;
+    ExpandPlan(const ExpandPlan&) = delete;
+    ExpandPlan& operator=(const ExpandPlan&) = delete;
+    ~ExpandPlan() {
+        if (table_device != nullptr) (void)hipFree(table_device);
+    }
+};
+class ExpandPlanCache {
+  public:
+    using Key = std::pair<size_t, size_t>;  // (ciphertext count, output count)
+    std::shared_ptr<const ExpandPlan> find(const Key& key) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        auto it = plans_.find(key);
+        return it == plans_.end() ? nullptr : it->second;
+    }
+    std::shared_ptr<const ExpandPlan> insert(const Key& key, std::shared_ptr<const ExpandPlan> plan) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (plans_.size() >= 64) plans_.clear();  // shapes in use are few; plans still referenced live on with their users
+        return plans_.emplace(key, std::move(plan)).first->second;
+    }
+
+  private:
+    std::mutex mutex_;
+    std::map<Key, std::shared_ptr<const ExpandPlan>> plans_;
+};
+// bfv_api.cpp: the cache a context owns
+ExpandPlanCache& expand_plans(const he_bfv_context* ctx);
 
 // bfv_api.cpp: one PirUtil.expand level through the fused Galois key switch (not exported)
 constexpr int kExpandStepUnavailable = -1;

@@ -21,7 +21,12 @@ struct he_bfv_context {
     std::unique_ptr<BfvContext> impl;
     // non-owning he_poly_context views handed out by he_bfv_*_context(), index = ciphertext moduli count
     std::vector<std::unique_ptr<he_poly_context>> ciphertext, key_switching, qbsk;
+    mutable heamd::ExpandPlanCache expand_plans;  // PirUtil.expand shapes seen so far (api_internal.hpp)
 };
+
+namespace heamd {
+ExpandPlanCache& expand_plans(const he_bfv_context* ctx) { return ctx->expand_plans; }
+}  // namespace heamd
 
 namespace {
 

@@ -342,30 +342,14 @@ void leaf_order(const std::vector<std::vector<ExpandNode>>& levels, size_t depth
     for (size_t k = second.size(); k < first.size(); ++k) out.push_back(first[k]);
 }
 
-}  // namespace
-
-extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t queries,
-                                          size_t ciphertext_count, size_t output_count, const uint64_t* galois_elements,
-                                          const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out,
-                                          he_stream s) {
-    if (ctx == nullptr) return invalid_argument("null context");
-    if (queries == 0) return HE_OK;
-
-    const uint32_t L = he_bfv_ciphertext_moduli_count(ctx);
-    const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
-    if (q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
-    const size_t n = he_poly_context_degree(q_ctx);
-    // preconditions of PirUtil.expand (PirUtil.swift:325-326)
-    if (ciphertext_count == 0 || !((ciphertext_count - 1) * n < output_count && ciphertext_count * n >= output_count))
-        return invalid_argument("output count does not match the number of query ciphertexts");
-    if (ciphertexts == nullptr || out == nullptr) return invalid_argument("null ciphertexts");
-    if (galois_key_count > 0 && (galois_elements == nullptr || galois_keys == nullptr))
-        return invalid_argument("null Galois keys");
-    hipStream_t stream = as_stream(s);
-    const size_t ct_words = 2 * size_t(L) * n, ct_bytes = ct_words * sizeof(uint64_t);
-    const int log_degree = floor_log2_size(n);
-
-    // ---- plan: the recursion tree of every input ciphertext, level by level
+// plans (or finds) the expansion of `ciphertext_count` ciphertexts of degree n into `output_count`
+int expand_plan(const he_bfv_context* ctx, size_t n, size_t ciphertext_count, size_t output_count,
+                std::shared_ptr<const heamd::ExpandPlan>& out) {
+    heamd::ExpandPlanCache& cache = heamd::expand_plans(ctx);
+    const heamd::ExpandPlanCache::Key key(ciphertext_count, output_count);
+    out = cache.find(key);
+    if (out) return HE_OK;
+    if (output_count > 0x7fffffffull) return invalid_argument("too many outputs");
     std::vector<std::vector<ExpandNode>> levels(1);
     size_t remaining = output_count;
     for (size_t i = 0; i < ciphertext_count; ++i) {
@@ -395,22 +379,17 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
         for (size_t slot = 0; slot < order.size(); ++slot)
             levels[order[slot].first][order[slot].second].leaf_slot = static_cast<long>(slot);
     }
-
-    // ---- upload the data movement of every level in one table: per level its leaves (-> output slot, doubled when
-    // the leaf sits above its tree's height) and, when leaves and internal nodes mix, the gather of the parents
-    struct LevelMoves {
-        size_t leaf_offset = 0, leaf_count = 0, parent_offset = 0, parent_count = 0;
-        bool gather = false;
-    };
-    std::vector<LevelMoves> moves(levels.size());
+    // the data movement of every level in one table: per level its leaves (-> output slot, doubled when the leaf sits
+    // above its tree's height) and, when leaves and internal nodes mix, the gather of the parents
+    auto plan = std::make_shared<heamd::ExpandPlan>();
+    plan->levels.resize(levels.size());
     std::vector<uint32_t> table;
-    size_t widest = 0;
-    if (output_count > 0x7fffffffull) return invalid_argument("too many outputs");
     for (size_t depth = 0; depth < levels.size(); ++depth) {
         const std::vector<ExpandNode>& level = levels[depth];
-        widest = level.size() > widest ? level.size() : widest;
+        plan->widest = level.size() > plan->widest ? level.size() : plan->widest;
         const int log_step = static_cast<int>(depth) + 1;
-        LevelMoves& m = moves[depth];
+        heamd::ExpandPlan::Level& m = plan->levels[depth];
+        m.nodes = level.size();
         m.leaf_offset = table.size();
         for (size_t i = 0; i < level.size(); ++i) {
             if (level[i].output_count != 1) continue;
@@ -431,18 +410,46 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
             }
         }
     }
+    // the table stays with the plan: one blocking upload per shape
+    HEAMD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&plan->table_device), (table.size() + 1) * sizeof(uint32_t)));
+    if (!table.empty())
+        HEAMD_HIP_TRY(hipMemcpy(plan->table_device, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    out = cache.insert(key, std::move(plan));
+    return HE_OK;
+}
+
+}  // namespace
+
+extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint64_t* ciphertexts, size_t queries,
+                                          size_t ciphertext_count, size_t output_count, const uint64_t* galois_elements,
+                                          const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out,
+                                          he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    if (queries == 0) return HE_OK;
+
+    const uint32_t L = he_bfv_ciphertext_moduli_count(ctx);
+    const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
+    if (q_ctx == nullptr) return invalid_argument("context has no ciphertext level");
+    const size_t n = he_poly_context_degree(q_ctx);
+    // preconditions of PirUtil.expand (PirUtil.swift:325-326)
+    if (ciphertext_count == 0 || !((ciphertext_count - 1) * n < output_count && ciphertext_count * n >= output_count))
+        return invalid_argument("output count does not match the number of query ciphertexts");
+    if (ciphertexts == nullptr || out == nullptr) return invalid_argument("null ciphertexts");
+    if (galois_key_count > 0 && (galois_elements == nullptr || galois_keys == nullptr))
+        return invalid_argument("null Galois keys");
+    hipStream_t stream = as_stream(s);
+    const size_t ct_words = 2 * size_t(L) * n, ct_bytes = ct_words * sizeof(uint64_t);
+    const int log_degree = floor_log2_size(n);
+
+    // ---- plan: the recursion tree of every input ciphertext, level by level (once per shape and context)
+    std::shared_ptr<const heamd::ExpandPlan> plan;
+    HEAMD_TRY_STATUS(expand_plan(ctx, n, ciphertext_count, output_count, plan));
+    const std::vector<heamd::ExpandPlan::Level>& moves = plan->levels;
+    const uint32_t* table_device = plan->table_device;
+    const size_t widest = plan->widest;
     const heamd::DeviceContext q_device = q_ctx->impl->device_context();
-    Scratch table_mem(stream), cur_mem(stream), next_mem(stream), parent_mem(stream), rotated_mem(stream),
-        tmp_mem(stream), workspace_mem(stream);
-    HEAMD_HIP_TRY(table_mem.allocate(table.size() * sizeof(uint32_t)));
-    const uint32_t* table_device = static_cast<const uint32_t*>(table_mem.get());
-    if (!table.empty()) {
-        // pageable host memory: wait for the upload here, so that `table` may die when this function returns (the
-        // launches below stay asynchronous)
-        HEAMD_HIP_TRY(hipMemcpyAsync(table_mem.get(), table.data(), table.size() * sizeof(uint32_t),
-                                     hipMemcpyHostToDevice, stream));
-        HEAMD_HIP_TRY(hipStreamSynchronize(stream));
-    }
+    Scratch cur_mem(stream), next_mem(stream), parent_mem(stream), rotated_mem(stream), tmp_mem(stream),
+        workspace_mem(stream);
     // every level runs over all queries at once: buffers hold [query][node of the level]
     const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, queries * ((widest + 1) / 2));
     HEAMD_HIP_TRY(cur_mem.allocate(queries * widest * ct_bytes));
@@ -461,10 +468,10 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
     // (the inner product with the Galois key alone runs per run of queries that share a key)
     int status = HE_OK;
     std::vector<const uint64_t*> level_keys(queries);
-    for (size_t depth = 0; depth < levels.size() && status == HE_OK; ++depth) {
+    for (size_t depth = 0; depth < moves.size() && status == HE_OK; ++depth) {
         const int log_step = static_cast<int>(depth) + 1;
-        const LevelMoves& m = moves[depth];
-        const size_t level_nodes = levels[depth].size();
+        const heamd::ExpandPlan::Level& m = moves[depth];
+        const size_t level_nodes = m.nodes;
         if (m.leaf_count != 0)
             HEAMD_HIP_TRY(heamd::launch_expand_move(cur, out, table_device + m.leaf_offset, q_device, m.leaf_count, queries,
                                                     level_nodes, output_count, stream));
@@ -503,7 +510,7 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
         uint64_t* next = buffers[depth % 2];
         if (applications == 1) {  // the element has its own key: the children leave the key switch directly
             // ... and when all of them are leaves, for their output slots (the next level's leaf table is in node order)
-            const bool to_outputs = depth + 1 < levels.size() && moves[depth + 1].parent_count == 0 &&
+            const bool to_outputs = depth + 1 < moves.size() && moves[depth + 1].parent_count == 0 &&
                                     moves[depth + 1].leaf_count == 2 * batch;
             status = heamd::bfv_expand_step_fused(
                 ctx, L, parents, element, level_keys.data(), queries, batch, to_outputs ? out : next, shift,
