@@ -420,7 +420,7 @@ int he_pir_compute_response_device(const he_bfv_context* ctx, const uint32_t* di
                                    size_t remaining_query_count, const uint64_t* database, const uint8_t* present_device,
                                    size_t chunk_count, const uint64_t* relinearization_key, uint64_t* out, he_stream s);
 /* The same for `queries` (1..4) queries over the same database in one call: their dim-0 inner products share one pass
- * over the database (the plaintexts are read from HBM once for all queries; 1.8-2.1 x the single-query rate per query
+ * over the database (the plaintexts are read from HBM once for all queries; 1.7-2.1 x the single-query rate per query
  * at 2-4 queries), the remaining dimensions run query by query.
  *   dim0_queries_eval   [dimensions[0]][queries][2][L][N] Eval  (the queries' dim-0 ciphertexts side by side)
  *   remaining_queries   [queries][remaining_query_count][2][L][N] Coeff

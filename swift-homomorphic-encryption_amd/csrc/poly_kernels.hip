@@ -595,9 +595,8 @@ hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, c
 }
 
 // A workgroup accumulates POLYS x COLS sums of one word block: each ciphertext word serves COLS columns and each
-// plaintext word POLYS polynomials.  POLYS x COLS = 8 accumulators of 8 registers fill the lane's budget, so wider
-// ciphertexts (several queries' ciphertexts side by side, which then share every plaintext word they stream) take
-// fewer columns.
+// plaintext word POLYS polynomials.  One query: 2 x 4 accumulators per lane; several queries' ciphertexts side by side
+// (which then share every plaintext word they stream) take two columns per wavefront of the LDS-tiled kernel.
 template <int POLYS, int COLS, bool NARROW, typename W>
 hipError_t launch_inner_product_plain_polys(const W* cts, const W* pts, const uint8_t* present_device, W* out,
                                             const DeviceContext& ctx, size_t count, size_t columns, uint64_t max_lazy,
@@ -657,8 +656,8 @@ hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t*
         HEAMD_INNER_PRODUCT_CASE(2, 4);
         HEAMD_INNER_PRODUCT_CASE(3, 4);
         HEAMD_INNER_PRODUCT_CASE(4, 2);
-        HEAMD_INNER_PRODUCT_CASE(6, 1);
-        HEAMD_INNER_PRODUCT_CASE(8, 1);
+        HEAMD_INNER_PRODUCT_CASE(6, 2);  // two columns per wavefront: half the LDS reads per product (one column:
+        HEAMD_INNER_PRODUCT_CASE(8, 2);  // 41.8 / 46.6 M MAC/s at 3 / 4 queries, two: 47.6 / 48.8, bench_tools/ab_queries.py)
         default: return hipErrorInvalidValue;
     }
 #undef HEAMD_INNER_PRODUCT_CASE
