@@ -6,7 +6,7 @@ import sys
 sys.path[:0]=["%s/swift-homomorphic-encryption_amd","%s/bench_tools"]
 import torch, heamd, path_bench as pb
 out=[]
-for q in (3,4):
+for q in (2,3,4):
     r=pb.config5_inner_product(torch, heamd, count=256, columns=64, queries=q)
     out.append(round(r["ct_pt_mac_per_s"]/1e6,2))
 print(out)

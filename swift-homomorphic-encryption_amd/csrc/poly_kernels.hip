@@ -655,7 +655,7 @@ hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t*
         HEAMD_INNER_PRODUCT_CASE(1, 4);
         HEAMD_INNER_PRODUCT_CASE(2, 4);
         HEAMD_INNER_PRODUCT_CASE(3, 4);
-        HEAMD_INNER_PRODUCT_CASE(4, 2);
+        HEAMD_INNER_PRODUCT_CASE(4, 4);  // 16 accumulators per lane again (two columns: 36.0 M MAC/s, four: 37.9)
         HEAMD_INNER_PRODUCT_CASE(6, 2);  // two columns per wavefront: half the LDS reads per product (one column:
         HEAMD_INNER_PRODUCT_CASE(8, 2);  // 41.8 / 46.6 M MAC/s at 3 / 4 queries, two: 47.6 / 48.8, bench_tools/ab_queries.py)
         default: return hipErrorInvalidValue;
