@@ -1,6 +1,7 @@
 """Seeded sweep over parameter shapes no hand-written case names: random moduli sizes (40..62 bits, mixed), 1..5
-ciphertext moduli, degrees with and without tiled transforms -- NTT, mod-switch, ct x ct and relinearize word for word
-against the oracle.  Catches mode-selection mistakes (headroom / [0, 8p) / exact butterflies, mixed [Q, Bsk] bands, fused
+ciphertext moduli, degrees with and without tiled transforms -- NTT, mod-switch, ct x ct, relinearize, the Galois key
+switch (fused and composed paths), the ct x pt inner product for one and several queries, masked, from 8-byte and from
+packed plaintexts -- word for word against the oracle.  Catches mode-selection mistakes (headroom / [0, 8p) / exact butterflies, mixed [Q, Bsk] bands, fused
 loads) that depend on how the moduli happen to line up."""
 import random
 
@@ -45,3 +46,28 @@ def test_random_parameter_shapes(oracle, seed):
         key = _uniform(rng, (L, 2), q, degree)
         relin = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key)))
         assert np.array_equal(relin, ref.relinearize(product, key)), label
+        # Bfv.applyGalois: sign-only, reversing and scattering elements (fused path on the tiled degrees)
+        element = rnd.choice([degree + 1, 2 * degree - 1, 3, degree // 2 + 1, 2 * rnd.randrange(1, degree) + 1])
+        cts = _uniform(rng, (2, 2), moduli, degree)
+        rotated = heamd.to_host(ours.apply_galois(heamd.to_device(cts), element, heamd.to_device(key)))
+        assert np.array_equal(rotated, ref.apply_galois(cts, element, key)), (label, element)
+        # Bfv.innerProduct(ciphertexts:plaintexts:) with nil plaintexts, for 1..4 queries side by side
+        queries = rnd.choice([1, 2, 3, 4])
+        count, columns = rnd.randint(1, 70), rnd.randint(1, 9)
+        vector = _uniform(rng, (count, queries, 2), moduli, degree)
+        plaintexts = _uniform(rng, (columns, count), moduli, degree)
+        present = rng.integers(0, 4, size=(columns, count), dtype=np.uint8).clip(0, 1)
+        device_pts = heamd.to_device(plaintexts)
+        got = heamd.to_host(ours.inner_product_plain(heamd.to_device(vector), device_pts, present, 2 * queries, columns))
+        got = got.reshape(columns, queries, 2, L, degree)
+        query, column = rnd.randrange(queries), rnd.randrange(columns)
+        own = np.ascontiguousarray(vector[:, query])
+        expected = ref.inner_product_plain(own, plaintexts[column], present[column])
+        assert np.array_equal(got[column, query], expected), (label, queries, count, columns)
+        if queries == 1 and all(b <= 61 for b in bits[:-1]):  # the packed path wants sums of two products below 2^127
+            import torch
+
+            packed = ours.pack_plaintexts(device_pts)
+            from_packed = ours.inner_product_plain_packed(heamd.to_device(own), packed, torch.from_numpy(present).cuda(), 2,
+                                                          columns)
+            assert np.array_equal(heamd.to_host(from_packed)[column], expected), (label, "packed")
