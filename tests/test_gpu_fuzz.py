@@ -3,6 +3,7 @@ ciphertext moduli, degrees with and without tiled transforms -- NTT, mod-switch,
 switch (fused and composed paths), the ct x pt inner product for one and several queries, masked, from 8-byte and from
 packed plaintexts -- word for word against the oracle.  Catches mode-selection mistakes (headroom / [0, 8p) / exact butterflies, mixed [Q, Bsk] bands, fused
 loads) that depend on how the moduli happen to line up."""
+import os
 import random
 
 import numpy as np
@@ -20,7 +21,11 @@ def _uniform(rng, prefix, moduli, degree):
     return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
 
 
-@pytest.mark.parametrize("seed", [11, 23, 47])
+# HEAMD_FUZZ_SEEDS="1,2,3,..." widens the sweep for a one-off hunt
+SEEDS = [int(v) for v in os.environ.get("HEAMD_FUZZ_SEEDS", "11,23,47").split(",")]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_parameter_shapes(oracle, seed):
     rnd = random.Random(seed)
     for trial in range(6):
@@ -71,3 +76,27 @@ def test_random_parameter_shapes(oracle, seed):
             from_packed = ours.inner_product_plain_packed(heamd.to_device(own), packed, torch.from_numpy(present).cuda(), 2,
                                                           columns)
             assert np.array_equal(heamd.to_host(from_packed)[column], expected), (label, "packed")
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_expansions(oracle, seed):
+    """PirUtil.expand over random output counts and random subsets of Galois keys (levels with their own key take the
+    fused path, the others reach their element by repeated application; leaves at every depth, doubled or not), one and
+    two queries per call, on a ring with a tiled transform: the same words and order as the oracle's recursion."""
+    rnd = random.Random(seed)
+    degree = 4096
+    q = oracle.generate_primes([rnd.choice(SIZES), rnd.choice(SIZES), 55], False, degree)
+    ours, ref = heamd.BfvContext(degree, 65537, q), oracle.BfvContext(degree, 65537, q)
+    rng = np.random.default_rng(seed)
+    for trial in range(3):
+        total = rnd.randint(1, 40)
+        height = max((total - 1).bit_length(), 1)
+        shifts = {height - 1} | {k for k in range(height) if rnd.random() < 0.6}  # the deepest level's element always
+        queries = _uniform(rng, (2, 1, 2), q[:-1], degree)
+        keys = [{(degree >> k) + 1: _uniform(rng, (ours.L, 2), q, degree) for k in shifts} for _ in range(2)]
+        device_keys = [{e: heamd.to_device(k) for e, k in keys[i].items()} for i in range(2)]
+        expected = [oracle.pir.expand(ref, queries[i], total, keys[i]) for i in range(2)]
+        got = heamd.to_host(ours.pir_expand(heamd.to_device(queries[0]), total, device_keys[0]))
+        assert np.array_equal(got, expected[0]), (total, sorted(shifts))
+        both = heamd.to_host(ours.pir_expand_batch(heamd.to_device(queries), total, device_keys))
+        assert np.array_equal(both[0], expected[0]) and np.array_equal(both[1], expected[1]), (total, sorted(shifts))
