@@ -100,3 +100,51 @@ def test_random_expansions(oracle, seed):
         assert np.array_equal(got, expected[0]), (total, sorted(shifts))
         both = heamd.to_host(ours.pir_expand_batch(heamd.to_device(queries), total, device_keys))
         assert np.array_equal(both[0], expected[0]) and np.array_equal(both[1], expected[1]), (total, sorted(shifts))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_pir_shapes(oracle, seed):
+    """PIR responses over random database shapes (1-3 dimensions, 1-3 chunks, nil plaintexts), for one query and for 2-4
+    queries sharing the database pass, from 8-byte and from packed plaintexts: every response equals the oracle's
+    computeResponseForOneChunk for that query and chunk."""
+    import torch
+
+    rnd = random.Random(seed)
+    degree = 256
+    L = rnd.randint(2, 3)
+    q = oracle.generate_primes([rnd.choice(SIZES[:7]) for _ in range(L + 1)], False, degree)
+    t = oracle.generate_primes([17], True, degree)[0]
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    rng = np.random.default_rng(seed)
+    moduli = q[:-1]
+    for trial in range(3):
+        # the reference asks for columns == 1 or columns == remaining query count (PirUtil.swift:422): one or two
+        # dimensions, or [d0, 2, 2]
+        dims = [rnd.randint(1, 6)] + rnd.choice([[], [rnd.randint(1, 4)], [rnd.randint(1, 4)], [2, 2]])
+        per_chunk, chunks, queries = int(np.prod(dims)), rnd.randint(1, 3), rnd.randint(1, 4)
+        rest_count = sum(dims[1:])
+        database = _uniform(rng, (chunks, per_chunk), moduli, degree)
+        present = rng.integers(0, 5, size=(chunks, per_chunk), dtype=np.uint8).clip(0, 1)
+        dim0 = _uniform(rng, (dims[0], queries, 2), moduli, degree)
+        rest = _uniform(rng, (queries, max(rest_count, 1), 2), moduli, degree)[:, :rest_count]
+        keys = [_uniform(rng, (ours.L, 2), q, degree) for _ in range(queries)]
+        device_db, mask = heamd.to_device(database), torch.from_numpy(present).cuda()
+        device_keys = [heamd.to_device(k) for k in keys] if rest_count else None
+        label = (dims, chunks, queries)
+        got = heamd.to_host(ours.pir_compute_response_queries(
+            dims, heamd.to_device(dim0), heamd.to_device(np.ascontiguousarray(rest)) if rest_count else None, device_db,
+            chunks, device_keys, present_device=mask))
+        query = rnd.randrange(queries)
+        own_dim0 = np.ascontiguousarray(dim0[:, query])
+        own_rest = np.ascontiguousarray(rest[query])
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, own_dim0, own_rest, database[chunk],
+                                                                 present[chunk], keys[query] if rest_count else None)
+            assert np.array_equal(got[query, chunk], expected), (label, query, chunk)
+        single_args = (dims, heamd.to_device(own_dim0), heamd.to_device(own_rest) if rest_count else None)
+        single_key = heamd.to_device(keys[query]) if rest_count else None
+        single = ours.pir_compute_response(*single_args, device_db, chunks, present_device=mask, relinearization_key=single_key)
+        assert np.array_equal(heamd.to_host(single), got[query]), label
+        packed = ours.pir_compute_response_packed(*single_args, ours.pack_plaintexts(device_db), chunks, present_device=mask,
+                                                  relinearization_key=single_key)
+        assert bool((packed == single).all()), label
