@@ -148,3 +148,34 @@ def test_random_pir_shapes(oracle, seed):
         packed = ours.pir_compute_response_packed(*single_args, ours.pack_plaintexts(device_db), chunks, present_device=mask,
                                                   relinearization_key=single_key)
         assert bool((packed == single).all()), label
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_wire_formats(oracle, seed):
+    """PolyRq.serialize / deserialize over random field widths (8..62-bit moduli, skipLSBs 0..3), degrees on both sides
+    of the tiled kernels' threshold and batch sizes; seeded polynomials over random batches: byte for byte / word for
+    word against the oracle."""
+    import torch
+
+    rnd = random.Random(seed)
+    for trial in range(4):
+        degree = rnd.choice([32, 64, 128, 256, 1024, 4096])
+        bits = [rnd.randint(8, 62) for _ in range(rnd.randint(1, 4))]
+        moduli = oracle.generate_primes(bits, False, 1)
+        ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+        rng = np.random.default_rng(seed * 10 + trial)
+        batch = rnd.randint(1, 5)
+        slab = _uniform(rng, (batch,), moduli, degree)
+        skip = rnd.randint(0, min(3, min(bits) - 2))
+        label = (degree, bits, skip, batch)
+        packed = ours.serialize(heamd.to_device(slab), skip)
+        expected = ref.serialize(slab, skip)
+        assert np.array_equal(packed.cpu().numpy(), expected), label
+        back = heamd.to_host(ours.deserialize(torch.from_numpy(expected).cuda(), skip))
+        assert np.array_equal(back, ref.deserialize(expected, skip)), label
+    degree = rnd.choice([64, 512, 4096])
+    moduli = oracle.generate_primes([rnd.randint(20, 62) for _ in range(rnd.randint(1, 3))], False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    seeds = np.random.default_rng(seed).integers(0, 256, size=(rnd.randint(1, 20), 32), dtype=np.uint8)
+    got = heamd.to_host(ours.random_from_seeds(torch.from_numpy(seeds).cuda()))
+    assert np.array_equal(got, ref.random_from_seeds(seeds)), (degree, len(seeds))
