@@ -444,23 +444,28 @@ int he_pir_compute_response_packed_device(const he_bfv_context* ctx, const uint3
                                           const uint8_t* present_device, size_t chunk_count,
                                           const uint64_t* relinearization_key, uint64_t* out, he_stream s);
 
-/* PirUtilProtocol.computeResponse(to:using:databases:parameter:context:callOptions:) for one database
- * (PirUtil.swift:490-568) -- the whole server side of a Query in one call: expand its ciphertexts into
- * sum(dimensions) selection ciphertexts per queried index (he_pir_expand_device), take each index's first dimensions[0]
- * of them to Eval, answer every chunk.  The indices of a Query share the database: four at a time share one pass over it.
+/* PirUtilProtocol.computeResponse(to:using:databases:parameter:context:callOptions:) (PirUtil.swift:490-568) -- the whole
+ * server side of a Query in one call: expand its ciphertexts into sum(dimensions) selection ciphertexts per queried index
+ * (he_pir_expand_device), take each index's first dimensions[0] of them to Eval, answer every chunk.
  *   query_ciphertexts   [query_ciphertext_count][2][L][N] Coeff (Query.ciphertexts)
  *   indices_count       Query.indicesCount
  *   galois_elements / galois_keys / galois_key_count   the evaluation key's Galois keys, as for he_pir_expand_device
  *   relinearization_key device key (NULL for one-dimensional databases)
- *   database            [chunk_count][prod(dimensions)][L][N] Eval, present_device as above
+ *   databases           HOST array of database_count device pointers, each [chunk_count][prod(dimensions)][L][N] Eval;
+ *                       database_count == 1: every index queries that database (four indices at a time then share one
+ *                       pass over it); database_count >= indices_count: index i queries databases[i].  Anything else is
+ *                       the reference's PirError.invalidBatchSize: HE_ERR_INVALID_ARGUMENT.
+ *   present_masks       HOST array of as many DEVICE masks [chunk_count][prod(dimensions)] (entries or the array NULL:
+ *                       all present)
  *   out                 [indices_count][chunk_count][2][1][N]  (Response.ciphertexts)
  * Enqueue-only once the context has seen the query's shape (he_pir_expand_device). */
 int he_pir_compute_response_to_query_device(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                                             const uint64_t* query_ciphertexts, size_t query_ciphertext_count,
                                             size_t indices_count, const uint64_t* galois_elements,
                                             const uint64_t* const* galois_keys, size_t galois_key_count,
-                                            const uint64_t* relinearization_key, const uint64_t* database,
-                                            const uint8_t* present_device, size_t chunk_count, uint64_t* out, he_stream s);
+                                            const uint64_t* relinearization_key, const uint64_t* const* databases,
+                                            const uint8_t* const* present_masks, size_t database_count, size_t chunk_count,
+                                            uint64_t* out, he_stream s);
 
 /* PirUtil.expand(ciphertexts:outputCount:using:) (PrivateInformationRetrieval/IndexPir/PirUtil.swift:196-355):
  * oblivious expansion of `ciphertext_count` query ciphertexts [..][2][L][N] (Coeff, top level) into `output_count`

@@ -557,7 +557,8 @@ extern "C" int he_pir_compute_response_to_query_device(
     const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count, const uint64_t* query_ciphertexts,
     size_t query_ciphertext_count, size_t indices_count, const uint64_t* galois_elements,
     const uint64_t* const* galois_keys, size_t galois_key_count, const uint64_t* relinearization_key,
-    const uint64_t* database, const uint8_t* present_device, size_t chunk_count, uint64_t* out, he_stream s) {
+    const uint64_t* const* databases, const uint8_t* const* present_masks, size_t database_count, size_t chunk_count,
+    uint64_t* out, he_stream s) {
     if (ctx == nullptr) return invalid_argument("null context");
     if (dimensions == nullptr || dimension_count == 0) return invalid_argument("empty dimensions");
     size_t expanded_count = 0;
@@ -567,8 +568,14 @@ extern "C" int he_pir_compute_response_to_query_device(
     // the remaining query is checked against the shape below; a placeholder stands in for it here
     HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_count ? query_ciphertexts : nullptr,
                                  remaining_count, shape));
+    // PirError.invalidBatchSize (PirUtil.swift:498-500): one database for every index, or one per index
+    if (databases == nullptr || !(database_count == 1 || database_count >= indices_count))
+        return invalid_argument("database count matches neither one nor the number of indices");
     if (indices_count == 0 || chunk_count == 0) return HE_OK;
-    if (query_ciphertexts == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    if (query_ciphertexts == nullptr || out == nullptr) return invalid_argument("null operand");
+    for (size_t d = 0; d < (database_count == 1 ? size_t(1) : indices_count); ++d)
+        if (databases[d] == nullptr) return invalid_argument("null database");
+    const bool shared = database_count == 1;
     hipStream_t stream = as_stream(s);
     const size_t ct_words = 2 * size_t(shape.L) * shape.n, ct_bytes = ct_words * sizeof(uint64_t);
     const size_t total = expanded_count * indices_count, out_words = 2 * shape.n;
@@ -577,19 +584,24 @@ extern "C" int he_pir_compute_response_to_query_device(
     uint64_t* expanded = static_cast<uint64_t*>(expanded_mem.get());  // [index][sum(dimensions)][2][L][N] Coeff
     HEAMD_TRY_STATUS(he_pir_expand_device(ctx, query_ciphertexts, query_ciphertext_count, total, galois_elements,
                                           galois_keys, galois_key_count, expanded, s));
-    constexpr size_t kTogether = 4;
+    // indices with a database of their own (PirUtil.swift:518) are answered one by one; those that share one go four at
+    // a time
+    constexpr size_t kGroup = 4;
+    const size_t kTogether = shared ? kGroup : 1;
     const size_t widest = indices_count < kTogether ? indices_count : kTogether;
     uint64_t* side = nullptr;  // [dimensions[0]][indices of a group][2][L][N]
     if (widest > 1) {
         HEAMD_HIP_TRY(side_mem.allocate(shape.d0 * widest * ct_bytes));
         side = static_cast<uint64_t*>(side_mem.get());
     }
-    const uint64_t* keys[kTogether] = {relinearization_key, relinearization_key, relinearization_key, relinearization_key};
+    const uint64_t* keys[kGroup] = {relinearization_key, relinearization_key, relinearization_key, relinearization_key};
     for (size_t first = 0; first < indices_count; first += kTogether) {
         const size_t now = indices_count - first < kTogether ? indices_count - first : kTogether;
         uint64_t* mine = expanded + first * expanded_count * ct_words;  // this group's selection ciphertexts
         const uint64_t* rest = remaining_count ? mine + shape.d0 * ct_words : nullptr;
         uint64_t* group_out = out + first * chunk_count * out_words;
+        const uint64_t* database = databases[shared ? 0 : first];
+        const uint8_t* present_device = present_masks ? present_masks[shared ? 0 : first] : nullptr;
         if (now == 1) {
             // convertToEvalFormat (PirUtil.swift:520-533) where the expansion left the dim-0 ciphertexts
             HEAMD_TRY_STATUS(he_ntt_forward_device(shape.q_ctx, mine, shape.d0 * 2, s));

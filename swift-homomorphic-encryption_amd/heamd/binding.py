@@ -121,7 +121,8 @@ SIGNATURES = [
     ("he_bfv_inner_product_plain_packed_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_pir_dim0_columns_packed_device", ctypes.c_int, [vp, vp, c_size, vp, vp, c_size, vp, vp]),
     ("he_pir_compute_response_to_query_device", ctypes.c_int,
-     [vp, ctypes.POINTER(c_u32), c_u32, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, vp, vp, c_size, vp, vp]),
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, ctypes.POINTER(vp),
+      ctypes.POINTER(vp), c_size, c_size, vp, vp]),
     ("he_pir_compute_response_packed_device", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
     # Bfv<UInt32> on packed 4-byte slabs
@@ -757,9 +758,10 @@ class BfvContext:
         return out
 
     def pir_compute_response_to_query(self, dimensions, query_ciphertexts, indices_count, galois_keys, relinearization_key,
-                                      database, chunk_count, present_device=None, stream=None):
-        """PirUtil.computeResponse for one database: Query.ciphertexts [count][2][L][N] Coeff + the evaluation key
-        ({element: Galois key tensor}, relinearization key tensor or None) -> [indices][chunks][2][1][N]."""
+                                      databases, chunk_count, present_devices=None, stream=None):
+        """PirUtil.computeResponse: Query.ciphertexts [count][2][L][N] Coeff + the evaluation key ({element: Galois key
+        tensor}, relinearization key tensor or None) + one database tensor (shared by all indices) or a list of one per
+        index (present_devices likewise: None, one mask or a list) -> [indices][chunks][2][1][N]."""
         dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
         count = query_ciphertexts.numel() // (2 * self.L * self.degree)
         out = self._empty((indices_count, chunk_count, 2, 1, self.degree), query_ciphertexts)
@@ -767,11 +769,16 @@ class BfvContext:
         element_array = _u64(elements)
         key_array = (vp * max(len(elements), 1))(*[vp(galois_keys[e].data_ptr()) for e in elements])
         relin = vp() if relinearization_key is None else _ptr(relinearization_key)
-        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        database_list = list(databases) if isinstance(databases, (list, tuple)) else [databases]
+        database_array = (vp * len(database_list))(*[vp(d.data_ptr()) for d in database_list])
+        mask_array = None
+        if present_devices is not None:
+            mask_list = list(present_devices) if isinstance(present_devices, (list, tuple)) else [present_devices]
+            mask_array = (vp * len(mask_list))(*[vp() if m is None else vp(m.data_ptr()) for m in mask_list])
         _check(load_library().he_pir_compute_response_to_query_device(
             self.h, dims, len(dimensions), _ptr(query_ciphertexts), count, indices_count,
-            element_array.ctypes.data_as(U64P), key_array, len(elements), relin, _ptr(database), mask, chunk_count,
-            _ptr(out), _stream(stream)))
+            element_array.ctypes.data_as(U64P), key_array, len(elements), relin, database_array, mask_array,
+            len(database_list), chunk_count, _ptr(out), _stream(stream)))
         return out
 
     def pir_compute_response_queries(self, dimensions, dim0_queries_eval, remaining_queries, database, chunk_count,

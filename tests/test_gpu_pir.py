@@ -343,7 +343,7 @@ def test_whole_query_response(oracle, small, indices):
     relin = client.relinearization_key()
     got = heamd.to_host(ours.pir_compute_response_to_query(
         dims, heamd.to_device(query), indices, {e: heamd.to_device(k) for e, k in galois.items()}, heamd.to_device(relin),
-        heamd.to_device(database), chunks, present_device=torch.from_numpy(present).cuda()))
+        heamd.to_device(database), chunks, present_devices=torch.from_numpy(present).cuda()))
     expanded = oracle.pir.expand(ref, query, total, galois)
     qctx = ref.ciphertext_context()
     zero = [0] * n
@@ -357,6 +357,37 @@ def test_whole_query_response(oracle, small, indices):
             assert np.array_equal(got[i, chunk], expected), (i, chunk)
             want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
             assert client.decrypt(got[i, chunk], moduli_count=1) == want
+
+
+def test_whole_query_with_a_database_per_index(oracle, small):
+    """databases.count >= query.indicesCount (PirUtil.swift:498-500, :518): index i is answered from databases[i]; two
+    databases for three indices is the reference's invalidBatchSize."""
+    import torch
+
+    ours, ref, client = small
+    n = ref.degree
+    rng = random.Random(500)
+    dims, chunks, per_chunk, indices = [3, 2], 1, 6, 3
+    expanded_count = sum(dims)
+    total = expanded_count * indices
+    tables = [[[rng.randrange(ref.t) for _ in range(n)] for _ in range(per_chunk)] for _ in range(indices)]
+    databases = [ref.plaintext_to_eval(np.array(t, dtype=np.uint64)).reshape(chunks, per_chunk, ref.L, n) for t in tables]
+    selections = [(rng.randrange(dims[0]), rng.randrange(dims[1])) for _ in range(indices)]
+    ones = []
+    for i, (a, b) in enumerate(selections):
+        ones += [i * expanded_count + a, i * expanded_count + dims[0] + b]
+    query = client.encrypt(_compressed_query(ref, total, ones))[None]
+    galois = {(n >> k) + 1: heamd.to_device(client.galois_key((n >> k) + 1)) for k in range((total - 1).bit_length())}
+    relin = heamd.to_device(client.relinearization_key())
+    device_dbs = [heamd.to_device(d) for d in databases]
+    got = heamd.to_host(ours.pir_compute_response_to_query(dims, heamd.to_device(query), indices, galois, relin, device_dbs,
+                                                           chunks))
+    for i, (a, b) in enumerate(selections):
+        assert client.decrypt(got[i, 0], moduli_count=1) == tables[i][a + dims[0] * b], i
+    with pytest.raises(heamd.HeError) as err:
+        ours.pir_compute_response_to_query(dims, heamd.to_device(query), indices, galois, relin, device_dbs[:2], chunks)
+    assert err.value.name == "invalidArgument"
+    assert torch.cuda.is_available()
 
 
 def test_queries_share_one_pass_config_shape(oracle):
