@@ -241,6 +241,10 @@ int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, 
 /* Bfv.modSwitchDown (Bfv/Bfv.swift:163-171): [batch][polys][L][N] -> [batch][polys][L-1][N]. */
 int he_bfv_mod_switch_down_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
                                   const uint64_t* in, uint64_t* out, size_t batch, he_stream s);
+/* Ciphertext.modSwitchDownToSingle (Bfv/Bfv.swift:163-171): in [batch][polys][moduli_count][N] -> out [batch][polys][1][N],
+ * the moduli_count - 1 divideAndRoundQLast steps in one kernel (word for word the chain of he_bfv_mod_switch_down_device). */
+int he_bfv_mod_switch_down_to_single_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                            const uint64_t* in, uint64_t* out, size_t batch, he_stream s);
 /* Bfv.mulAssign(_: inout EvalCiphertext, _: EvalPlaintext) (Bfv/Bfv.swift:120-129):
  * ct [batch][polys][L][N] *= pt [batch][L][N]. */
 int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,

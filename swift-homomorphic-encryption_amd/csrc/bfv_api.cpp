@@ -668,6 +668,42 @@ int he_bfv_mod_switch_down_device(const he_bfv_context* ctx, uint32_t moduli_cou
     return HE_OK;
 }
 
+// Ciphertext.modSwitchDownToSingle (Bfv.swift:163-171): moduli_count -> 1 moduli, one kernel for 2..8 moduli
+int he_bfv_mod_switch_down_to_single_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
+                                            const uint64_t* in, uint64_t* out, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (batch == 0 || poly_count == 0) return HE_OK;
+    if (in == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    hipStream_t stream = as_stream(s);
+    const size_t polys = batch * poly_count, n = ctx->impl->degree();
+    if (moduli_count == 1) {  // already there
+        if (in != out) HEAMD_HIP_TRY(hipMemcpyAsync(out, in, polys * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+        return HE_OK;
+    }
+    const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
+    hipError_t e = heamd::launch_mod_switch_down_to_single(in, out, pc->device_context(), moduli_count, polys, stream);
+    if (e != hipErrorNotSupported) {
+        HEAMD_HIP_TRY(e);
+        return HE_OK;
+    }
+    (void)hipGetLastError();
+    // more than 8 moduli (or degree 1): step by step through two scratch slabs
+    Scratch level_mem(stream);
+    HEAMD_HIP_TRY(level_mem.allocate(2 * polys * size_t(moduli_count - 1) * n * sizeof(uint64_t)));
+    uint64_t* ping = static_cast<uint64_t*>(level_mem.get());
+    uint64_t* pong = ping + polys * size_t(moduli_count - 1) * n;
+    const uint64_t* current = in;
+    for (uint32_t level = moduli_count; level > 1; --level) {
+        uint64_t* target = level == 2 ? out : (current == ping ? pong : ping);
+        HEAMD_HIP_TRY(heamd::launch_divide_and_round_q_last(current, target, ctx->impl->ciphertext(level)->device_context(),
+                                                            level, polys, stream));
+        current = target;
+    }
+    return HE_OK;
+}
+
 int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
                             const uint64_t* pt, size_t batch, he_stream s) {
     const RnsToolLevel* tool = nullptr;

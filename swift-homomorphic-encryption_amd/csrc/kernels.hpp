@@ -55,6 +55,10 @@ hipError_t launch_mul_plain(uint64_t* ct, const uint64_t* pt, const DeviceContex
 // divideAndRoundQLast with the first `moduli_count` moduli of ctx: in [polys][L][N] -> out [polys][L-1][N]
 hipError_t launch_divide_and_round_q_last(const uint64_t* in, uint64_t* out, const DeviceContext& ctx,
                                           uint32_t moduli_count, size_t polys, hipStream_t stream);
+// Ciphertext.modSwitchDownToSingle: in [polys][moduli_count][N] -> out [polys][1][N], the moduli_count - 1 steps of
+// divideAndRoundQLast in one kernel (2..8 moduli; hipErrorNotSupported otherwise: chain the kernel above).
+hipError_t launch_mod_switch_down_to_single(const uint64_t* in, uint64_t* out, const DeviceContext& ctx,
+                                            uint32_t moduli_count, size_t polys, hipStream_t stream);
 hipError_t launch_adding_lazy_product(const uint64_t* lhs, const uint64_t* rhs, uint64_t* acc_lo_hi,
                                       const DeviceContext& ctx, hipStream_t stream);
 hipError_t launch_reduce_accumulator(const uint64_t* acc_lo_hi, uint64_t* out, const DeviceContext& ctx,

@@ -98,43 +98,33 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
     hipStream_t stream = as_stream(s);
     const uint32_t L = shape.L;
     const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
-    Scratch next_mem(stream), products_mem(stream), level_mem(stream);
+    Scratch next_mem(stream), products_mem(stream);
     size_t count = shape.columns, cursor = 0;  // ciphertexts per chunk
     if (dimension_count > 1) {
         const size_t max_items = chunks * (shape.columns / dimensions[1]);
         HEAMD_HIP_TRY(next_mem.allocate((max_items ? max_items : 1) * ct2 * sizeof(uint64_t)));
         HEAMD_HIP_TRY(products_mem.allocate((max_items ? max_items : 1) * ct3 * sizeof(uint64_t)));
     }
-    uint64_t* next = static_cast<uint64_t*>(next_mem.get());
+    // the relinearized products of a dimension become the next one's operands: the two slabs swap roles
+    uint64_t* current = results;
+    uint64_t* other = static_cast<uint64_t*>(next_mem.get());
     uint64_t* products = static_cast<uint64_t*>(products_mem.get());
     for (uint32_t i = 1; i < dimension_count; ++i) {
         const size_t d = dimensions[i];
         if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
         const size_t items = chunks * (count / d);  // groups of d consecutive results, chunk after chunk
         const uint64_t* query = remaining_query + cursor * ct2;
-        HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device(ctx, L, query, results, d, items, products, s));
-        HEAMD_TRY_STATUS(he_bfv_relinearize_device(ctx, L, products, relinearization_key, next, items, nullptr, 0, s));
-        // the relinearized products become the next dimension's operands
-        HEAMD_HIP_TRY(hipMemcpyAsync(results, next, items * ct2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+        HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device(ctx, L, query, current, d, items, products, s));
+        HEAMD_TRY_STATUS(he_bfv_relinearize_device(ctx, L, products, relinearization_key, other, items, nullptr, 0, s));
+        uint64_t* swap = current;
+        current = other;
+        other = swap;
         count /= d;
         cursor += d;
     }
     if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
-    // modSwitchDownToSingle (:483): L - 1 divideAndRoundQLast steps on the chunks' 2-poly ciphertexts
-    if (L == 1) {
-        HEAMD_HIP_TRY(hipMemcpyAsync(out, results, chunks * 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
-        return HE_OK;
-    }
-    HEAMD_HIP_TRY(level_mem.allocate(2 * chunks * ct2 * sizeof(uint64_t)));
-    uint64_t* ping = static_cast<uint64_t*>(level_mem.get());
-    uint64_t* pong = ping + chunks * ct2;
-    const uint64_t* current = results;
-    for (uint32_t level = L; level > 1; --level) {
-        uint64_t* target = level == 2 ? out : (current == ping ? pong : ping);
-        HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device(ctx, level, 2, current, target, chunks, s));
-        current = target;
-    }
-    return HE_OK;
+    // modSwitchDownToSingle (:483) on the chunks' 2-polynomial ciphertexts
+    return he_bfv_mod_switch_down_to_single_device(ctx, L, 2, current, out, chunks, s);
 }
 
 // `chunks` chunks with a device-resident mask, enqueue-only: one dim-0 launch over the columns of all chunks, then the

@@ -161,6 +161,47 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// Ciphertext.modSwitchDownToSingle (Bfv.swift:163-171): divideAndRoundQLast from L moduli down to one, the L - 1 steps
+// in registers -- in [polys][L][N] -> out [polys][1][N], each step the same words as the kernel above.
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+    mod_switch_down_to_single_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
+                                     size_t polys) {
+    const uint32_t pairs_per_row = ctx.degree >> 1;
+    const size_t total = polys * pairs_per_row;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t poly = i / pairs_per_row;
+        const uint32_t k = static_cast<uint32_t>(i - poly * pairs_per_row);
+        const U64x2* src = reinterpret_cast<const U64x2*>(in) + poly * L * pairs_per_row + k;
+        U64x2 x[L];
+#pragma unroll
+        for (int row = 0; row < L; ++row) x[row] = stream_load(src + static_cast<size_t>(row) * pairs_per_row);
+#pragma unroll
+        for (int last = L - 1; last >= 1; --last) {
+            const uint64_t q_last = ctx.moduli[last].p, q_last_div2 = q_last >> 1;
+            const U64x2* __restrict__ inverse_q_last = ctx.inverse_q_last + static_cast<size_t>(last) * ctx.moduli_stride;
+            const uint64_t r0 = add_mod_uniform(x[last].x, q_last_div2, q_last);
+            const uint64_t r1 = add_mod_uniform(x[last].y, q_last_div2, q_last);
+            const bool negative0 = r0 < q_last_div2, negative1 = r1 < q_last_div2;
+            const uint64_t magnitude0 = negative0 ? q_last_div2 - r0 : r0 - q_last_div2;
+            const uint64_t magnitude1 = negative1 ? q_last_div2 - r1 : r1 - q_last_div2;
+#pragma unroll
+            for (int row = 0; row < last; ++row) {
+                const DeviceModulus m = ctx.moduli[row];
+                const U64x2 inv = inverse_q_last[row];
+                const uint64_t t0 = barrett_reduce64_uniform(magnitude0, m.p, m.barrett64);
+                const uint64_t t1 = barrett_reduce64_uniform(magnitude1, m.p, m.barrett64);
+                x[row].x = shoup_mul_uniform(negative0 ? add_mod_uniform(x[row].x, t0, m.p) : sub_mod_uniform(x[row].x, t0, m.p),
+                                             inv.x, inv.y, m.p);
+                x[row].y = shoup_mul_uniform(negative1 ? add_mod_uniform(x[row].y, t1, m.p) : sub_mod_uniform(x[row].y, t1, m.p),
+                                             inv.x, inv.y, m.p);
+            }
+        }
+        stream_store(reinterpret_cast<U64x2*>(out) + poly * pairs_per_row + k, x[0]);
+    }
+}
+
 __global__ void __launch_bounds__(kThreads)
     adding_lazy_product_kernel(const uint64_t* __restrict__ lhs, const uint64_t* __restrict__ rhs,
                                uint64_t* __restrict__ acc, size_t words) {
@@ -576,6 +617,29 @@ hipError_t launch_divide_and_round_q_last(const uint64_t* in, uint64_t* out, con
     hipLaunchKernelGGL(divide_and_round_q_last_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, ctx,
                        moduli_count, polys);
     return hipGetLastError();
+}
+
+hipError_t launch_mod_switch_down_to_single(const uint64_t* in, uint64_t* out, const DeviceContext& ctx,
+                                            uint32_t moduli_count, size_t polys, hipStream_t stream) {
+    const size_t total = polys * (ctx.degree >> 1);
+    if (total == 0) return hipSuccess;
+    if (ctx.degree < 2) return hipErrorNotSupported;
+#define HEAMD_TO_SINGLE_CASE(L)                                                                                      \
+    case L:                                                                                                          \
+        hipLaunchKernelGGL(mod_switch_down_to_single_kernel<L>, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, \
+                           out, ctx, polys);                                                                         \
+        return hipGetLastError()
+    switch (moduli_count) {
+        HEAMD_TO_SINGLE_CASE(2);
+        HEAMD_TO_SINGLE_CASE(3);
+        HEAMD_TO_SINGLE_CASE(4);
+        HEAMD_TO_SINGLE_CASE(5);
+        HEAMD_TO_SINGLE_CASE(6);
+        HEAMD_TO_SINGLE_CASE(7);
+        HEAMD_TO_SINGLE_CASE(8);
+        default: return hipErrorNotSupported;  // the caller chains launch_divide_and_round_q_last
+    }
+#undef HEAMD_TO_SINGLE_CASE
 }
 
 hipError_t launch_adding_lazy_product(const uint64_t* lhs, const uint64_t* rhs, uint64_t* acc_lo_hi,

@@ -109,6 +109,7 @@ SIGNATURES = [
     ("he_bfv_mul_device", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
     ("he_bfv_relinearize_device", ctypes.c_int, [vp, c_u32, vp, vp, vp, c_size, vp, c_size, vp]),
     ("he_bfv_mod_switch_down_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_mod_switch_down_to_single_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_mul_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_inner_product_plain_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, ctypes.POINTER(ctypes.c_uint8), c_size, c_size, vp, vp]),
@@ -806,6 +807,15 @@ class BfvContext:
         out = self._empty((batch, poly_count, L - 1, self.degree), ct)
         _check(load_library().he_bfv_mod_switch_down_device(self.h, L, poly_count, _ptr(ct), _ptr(out), batch,
                                                             _stream(stream)))
+        return out
+
+    def mod_switch_down_to_single(self, ct, poly_count, moduli_count=None, stream=None):
+        """Ciphertext.modSwitchDownToSingle: [batch][polys][L][N] -> [batch][polys][1][N]."""
+        L = self._L(moduli_count)
+        batch = ct.numel() // (poly_count * L * self.degree)
+        out = self._empty((batch, poly_count, 1, self.degree), ct)
+        _check(load_library().he_bfv_mod_switch_down_to_single_device(self.h, L, poly_count, _ptr(ct), _ptr(out), batch,
+                                                                      _stream(stream)))
         return out
 
     def mul_plain_(self, ct, pt, poly_count, moduli_count=None, stream=None):

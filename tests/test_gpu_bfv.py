@@ -233,6 +233,28 @@ def test_inner_product_plain_queries_side_by_side(oracle, small, config3, querie
         assert np.array_equal(got[:, q], single.reshape(columns, 2, big.L, big.degree)), q
 
 
+@pytest.mark.parametrize("bits", [[50, 55], [55, 40, 62, 48], [45] * 6, [60, 61, 62, 55, 50, 45, 40, 58, 59]])
+def test_mod_switch_down_to_single(oracle, bits):
+    """Ciphertext.modSwitchDownToSingle (Bfv.swift:163-171) in one kernel: word for word the chain of modSwitchDown steps
+    (the oracle's and the step entry point's), from every level of contexts with 1 to 8 ciphertext moduli; words at 0
+    and q - 1 included."""
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    rng = np.random.default_rng(len(bits))
+    for level in range(ours.L, 0, -1):
+        moduli = q[:level]
+        ct = _uniform(rng, (3, 2), moduli, degree)
+        ct[0, :, :, 0] = 0
+        ct[0, :, :, 1] = (np.array(moduli, dtype=np.uint64) - np.uint64(1))[None, :]
+        expected = ct
+        for step in range(level, 1, -1):
+            expected = ref.mod_switch_down(expected, poly_count=2, moduli_count=step)
+        got = heamd.to_host(ours.mod_switch_down_to_single(heamd.to_device(ct), 2, moduli_count=level))
+        assert np.array_equal(got, expected.reshape(got.shape)), level
+
+
 def test_single_modulus_context(oracle):
     """One coefficient modulus: no key-switching modulus (Context.swift:102-107); ct x ct still works."""
     degree = 32
