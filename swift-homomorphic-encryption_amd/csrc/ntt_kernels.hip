@@ -753,8 +753,11 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
                             hipStream_t stream) {
     const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
     const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    // a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way:
+    // one launch in the mode that serves every modulus costs one kernel latency instead of two
+    constexpr size_t kOneGeneration = 512;
     if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr ||
-        records * record_rows > (size_t(1) << 30))
+        records * record_rows > (size_t(1) << 30) || records * record_rows <= kOneGeneration)
         return launch_ntt(inverse, slab, ctx, 0, record_rows, records * record_rows, stream);
     hipError_t e = launch_ntt_band(inverse, slab, ctx, 0, prefix, record_rows, 0, records, kModeSplit, stream);
     if (e != hipSuccess) return e;
