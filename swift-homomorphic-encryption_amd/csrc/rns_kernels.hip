@@ -42,6 +42,65 @@ __device__ __forceinline__ uint64_t shoup_mul_pair(uint64_t x, U64x2 c, uint64_t
     return shoup_mul_uniform(x, c.x, c.y, p);
 }
 
+// ---- arithmetic by slab word type ----------------------------------------------------------------------------------
+// The kernels below are one body for Bfv<UInt64> and Bfv<UInt32>; what differs is how a sum of products and a product
+// by a table constant are carried out.  8-byte words: 62-bit moduli, exact 128-bit sums on the carry-counting
+// accumulator, 64-bit Shoup products.  4-byte words: every modulus (Bsk primes, gamma, t, mTilde included) is below 2^30
+// (MA/Scalar.swift:498-511), so a product is below 2^60, sixteen of them fit a 64-bit word (the kernels sum at most
+// nine), a sum is ONE multiply-add per term, its reduction a single-word Barrett, and a product by a constant a 32-bit
+// Shoup product (the table's floor(w 2^64 / p) holds floor(w 2^32 / p) in its high word) -- a fifth of the instructions.
+template <typename W>
+struct WordArith {  // uint64_t
+    using Sum = ProductSum;
+    static constexpr uint64_t kSlack = 5;  // a lazily reduced sum lies in [0, kSlack p)
+    static __device__ __forceinline__ Sum first(uint64_t a, uint64_t b) { return product_sum_first_uniform(a, b); }
+    static __device__ __forceinline__ void add(Sum& s, uint64_t a, uint64_t b) { product_sum_add_uniform(s, a, b); }
+    static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { product_sum_add(s, a, b); }
+    static __device__ __forceinline__ Sum zero() { return product_sum_zero(); }
+    static __device__ __forceinline__ uint64_t low_word(const Sum& s) { return product_sum_value(s).lo; }
+    template <typename Modulus>
+    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const Modulus& m) { return reduce_product_sum(s, m); }
+    template <typename Modulus>
+    static __device__ __forceinline__ uint64_t reduce_lazy(const Sum& s, const Modulus& m) {
+        return reduce_product_sum_lazy(s, m);
+    }
+    static __device__ __forceinline__ uint64_t shoup(uint64_t x, U64x2 c, uint64_t p) {
+        return shoup_mul_uniform(x, c.x, c.y, p);
+    }
+    static __device__ __forceinline__ uint64_t shoup_lazy(uint64_t x, U64x2 c, uint64_t p) {
+        return shoup_mul_uniform_lazy(x, c.x, c.y, p);
+    }
+    static __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b, const DeviceModulus& m) {
+        return barrett_mul(a, b, m.p, m.product_factor, static_cast<int>(m.product_shift));
+    }
+};
+template <>
+struct WordArith<uint32_t> {
+    using Sum = uint64_t;
+    static constexpr uint64_t kSlack = 1;  // sums are reduced to [0, p) at once
+    static __device__ __forceinline__ Sum first(uint64_t a, uint64_t b) { return mul32(lo32(a), lo32(b)); }
+    static __device__ __forceinline__ void add(Sum& s, uint64_t a, uint64_t b) { s = mad32(lo32(a), lo32(b), s); }
+    static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { s = mad32(lo32(a), lo32(b), s); }
+    static __device__ __forceinline__ Sum zero() { return 0; }
+    static __device__ __forceinline__ uint64_t low_word(const Sum& s) { return s; }
+    template <typename Modulus>
+    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const Modulus& m) {
+        return barrett_reduce64_uniform(s, m.p, m.barrett64);
+    }
+    template <typename Modulus>
+    static __device__ __forceinline__ uint64_t reduce_lazy(const Sum& s, const Modulus& m) { return reduce(s, m); }
+    // x < 2^32, constant w < p < 2^31 (or p = 2^16 for mTilde): x w - floor(x floor(w 2^32 / p) / 2^32) p in [0, 2p)
+    static __device__ __forceinline__ uint64_t shoup(uint64_t x, U64x2 c, uint64_t p) {
+        const uint32_t xs = lo32(x), q = mulhi32(xs, hi32(c.y));
+        const uint32_t r = xs * lo32(c.x) - q * lo32(p);
+        return r >= lo32(p) ? r - lo32(p) : r;
+    }
+    static __device__ __forceinline__ uint64_t shoup_lazy(uint64_t x, U64x2 c, uint64_t p) { return shoup(x, c, p); }
+    static __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b, const DeviceModulus& m) {
+        return barrett_reduce64_uniform(mul32(lo32(a), lo32(b)), m.p, m.barrett64);
+    }
+};
+
 // ---- liftQToQBsk: in [polys][L][N] -> out [polys][2L+1][N] -------------------------------------------------------
 // Polynomial p = item * polys_per_item + c is read at in + item * in_item_stride + c * L * N and written at
 // out + item * out_item_stride + c * (2L+1) * N (strides in words), so one launch can fill a slot range of a larger
@@ -59,6 +118,7 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
+    using A = WordArith<W>;
     const uint64_t kMTildeValue = tool.mtilde;  // 2^32 (UInt64 contexts) or 2^16 (UInt32 contexts)
     // one coefficient per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
     // spills SGPRs into VGPR lanes
@@ -72,31 +132,29 @@ __global__ void __launch_bounds__(kThreads)
         for (int i = 0; i < L; ++i) {
             const uint64_t x = stream_load(src + i * n);
             stream_store(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
-            y[i] = shoup_mul_pair(x, tool.lift_scale[i], tool.q_moduli[i].p);
+            y[i] = A::shoup(x, tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
-        ProductSum acc = product_sum_first_uniform(y[0], tool.q_to_ext[(L + 1) * L + 0]);
+        typename A::Sum acc = A::first(y[0], tool.q_to_ext[(L + 1) * L + 0]);
 #pragma unroll
-        for (int i = 1; i < L; ++i) product_sum_add_uniform(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
+        for (int i = 1; i < L; ++i) A::add(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
         // the (L+2)'th extended modulus is mTilde = 2^32 at the top level; a lower-level tool takes a prefix of
         // [Bsk..., mTilde] and finds a Bsk prime there (the reference's own behaviour, reproduced as is)
         const DeviceModulus last = tool.ext_moduli[L + 1];
-        uint64_t r = last.p == kMTildeValue ? (product_sum_value(acc).lo & (kMTildeValue - 1))
-                                            : reduce_product_sum(acc, last);
-        r = shoup_mul_pair(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
+        uint64_t r = last.p == kMTildeValue ? (A::low_word(acc) & (kMTildeValue - 1)) : A::reduce(acc, last);
+        r = A::shoup(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
         const bool below = r < (kMTildeValue >> 1);
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_bsk_scaled[j * L + 0]);
+            typename A::Sum sum = A::first(y[0], tool.q_to_bsk_scaled[j * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
+            for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
             // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
             // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
             const U64x2 scaled = tool.q_mod_bsk_scaled[j];
-            const uint64_t unfolded =
-                reduce_product_sum_lazy(sum, m) + shoup_mul_uniform_lazy(centered, scaled.x, scaled.y, m.p);
+            const uint64_t unfolded = A::reduce_lazy(sum, m) + A::shoup_lazy(centered, scaled, m.p);
             stream_store(dst + (L + j) * n, csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p));
         }
     }
@@ -106,6 +164,7 @@ __global__ void __launch_bounds__(kThreads)
 template <int L, typename W>
 __global__ void __launch_bounds__(kThreads)
     floor_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys) {
+    using A = WordArith<W>;
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
@@ -117,53 +176,53 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t y[L];
 #pragma unroll
         for (int i = 0; i < L; ++i)
-            y[i] = shoup_mul_pair(stream_load(src + i * n), tool.inv_punctured_q[i], tool.q_moduli[i].p);
+            y[i] = A::shoup(stream_load(src + i * n), tool.inv_punctured_q[i], tool.q_moduli[i].p);
         // (x_Bsk_j - conv_j) Q^-1 mod Bsk_j, and for j < L straight on to the Bsk -> Q converter's first product
         // z_j = f_j (B/Bsk_j)^-1 mod Bsk_j: two exact products mod Bsk_j = one by the product of the constants
         uint64_t z[L], f_msk = 0;
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_ext[j * L + 0]);
+            typename A::Sum sum = A::first(y[0], tool.q_to_ext[j * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_ext[j * L + i]);
+            for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_ext[j * L + i]);
             // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
             // checked when the tool is built), which is all the next exact product needs
-            const uint64_t difference = stream_load(src + (L + j) * n) + 5 * m.p - reduce_product_sum_lazy(sum, m);
+            const uint64_t difference = stream_load(src + (L + j) * n) + A::kSlack * m.p - A::reduce_lazy(sum, m);
             if (j < L) {
-                z[j] = shoup_mul_pair(difference, tool.floor_scale_b[j], m.p);
+                z[j] = A::shoup(difference, tool.floor_scale_b[j], m.p);
             } else {
-                f_msk = shoup_mul_pair(difference, tool.inv_q_mod_bsk[j], m.p);
+                f_msk = A::shoup(difference, tool.inv_q_mod_bsk[j], m.p);
             }
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
         const DeviceModulus msk = tool.ext_moduli[L];
-        ProductSum alpha_sum = product_sum_first_uniform(z[0], tool.b_to_msk[0]);
+        typename A::Sum alpha_sum = A::first(z[0], tool.b_to_msk[0]);
 #pragma unroll
-        for (int i = 1; i < L; ++i) product_sum_add_uniform(alpha_sum, z[i], tool.b_to_msk[i]);
+        for (int i = 1; i < L; ++i) A::add(alpha_sum, z[i], tool.b_to_msk[i]);
         // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
         // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
-        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? reduce_product_sum_lazy(alpha_sum, msk)  // < 5 m_sk
-                                                        : reduce_product_sum(alpha_sum, tool.alpha_modulus[0]);
-        alpha = shoup_mul_pair(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
+        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? A::reduce_lazy(alpha_sum, msk)  // < 5 m_sk
+                                                        : A::reduce(alpha_sum, tool.alpha_modulus[0]);
+        alpha = A::shoup(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
         for (int row = 0; row < L; ++row) {
             const DeviceModulus m = tool.q_moduli[row];
-            ProductSum sum = product_sum_first_uniform(z[0], tool.b_to_q[row * L + 0]);
+            typename A::Sum sum = A::first(z[0], tool.b_to_q[row * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, z[i], tool.b_to_q[row * L + i]);
+            for (int i = 1; i < L; ++i) A::add(sum, z[i], tool.b_to_q[row * L + i]);
             // RnsTool.swift:436-446: + (m_sk - alpha) (B mod q) when alpha > m_sk/2, else + alpha (-B mod q)
             if (tool.floor_merge_ok != 0) {
                 // the correction is one more product of the same exact sum: one reduction instead of a Shoup product,
                 // a negation and a modular add (uniform branch; the sum stays below 2^127)
                 const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
-                product_sum_add(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
-                stream_store(dst + row * n, reduce_product_sum(sum, m));
+                A::add_vector(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
+                stream_store(dst + row * n, A::reduce(sum, m));
             } else {
-                const uint64_t converted = reduce_product_sum(sum, m);
+                const uint64_t converted = A::reduce(sum, m);
                 // the second form is the negation of alpha (B mod q), so one product serves both
-                const uint64_t magnitude = shoup_mul_pair(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
+                const uint64_t magnitude = A::shoup(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
                 const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
                 stream_store(dst + row * n, add_mod_uniform(converted, adjust, m.p));
             }
@@ -176,6 +235,7 @@ template <int L, typename W>
 __global__ void __launch_bounds__(kThreads)
     scale_and_round_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool,
                            const U64x2 final_scale, size_t polys) {
+    using A = WordArith<W>;
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
@@ -185,15 +245,15 @@ __global__ void __launch_bounds__(kThreads)
         uint64_t y[L];
 #pragma unroll
         for (int i = 0; i < L; ++i)
-            y[i] = shoup_mul_pair(stream_load(src + i * n), tool.scale_round_scale[i], tool.q_moduli[i].p);
+            y[i] = A::shoup(stream_load(src + i * n), tool.scale_round_scale[i], tool.q_moduli[i].p);
         uint64_t converted[2];  // (gamma t x) converted to base [t, gamma], times -(Q^-1)          :279-282
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const DeviceModulus m = tool.t_gamma[j];
-            ProductSum sum = product_sum_first_uniform(y[0], tool.q_to_t_gamma[j * L + 0]);
+            typename A::Sum sum = A::first(y[0], tool.q_to_t_gamma[j * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) product_sum_add_uniform(sum, y[i], tool.q_to_t_gamma[j * L + i]);
-            converted[j] = shoup_mul_pair(reduce_product_sum(sum, m), tool.neg_inv_q_mod_t_gamma[j], m.p);
+            for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_t_gamma[j * L + i]);
+            converted[j] = A::shoup(A::reduce(sum, m), tool.neg_inv_q_mod_t_gamma[j], m.p);
         }
         const DeviceModulus t = tool.t_gamma[0];
         const uint64_t gamma = tool.t_gamma[1].p;
@@ -202,7 +262,7 @@ __global__ void __launch_bounds__(kThreads)
         const bool above = mod_gamma > (gamma >> 1);
         const uint64_t reduced = barrett_reduce64_uniform(above ? gamma - mod_gamma : mod_gamma, t.p, t.barrett64);
         const uint64_t s_gamma = above ? neg_mod_uniform(reduced, t.p) : reduced;
-        stream_store(out + idx, shoup_mul_pair(sub_mod_uniform(converted[0], s_gamma, t.p), final_scale, t.p));  // :298-301
+        stream_store(out + idx, A::shoup(sub_mod_uniform(converted[0], s_gamma, t.p), final_scale, t.p));  // :298-301
     }
 }
 
@@ -222,12 +282,17 @@ __global__ void __launch_bounds__(kThreads)
     const DeviceModulus m = ctx.moduli[row];
     const W* src = in + item * 4 * poly_words + (size_t(row) << logn) + k;
     const uint64_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
-    const int shift = static_cast<int>(m.product_shift);
+    using A = WordArith<W>;
     W* dst = out + item * 3 * poly_words + (size_t(row) << logn) + k;
-    dst[0] = static_cast<W>(barrett_mul(a0, b0, m.p, m.product_factor, shift));
-    dst[poly_words] = static_cast<W>(add_mod_uniform(barrett_mul(a0, b1, m.p, m.product_factor, shift),
-                                                     barrett_mul(a1, b0, m.p, m.product_factor, shift), m.p));
-    dst[2 * poly_words] = static_cast<W>(barrett_mul(a1, b1, m.p, m.product_factor, shift));
+    dst[0] = static_cast<W>(A::mul(a0, b0, m));
+    if constexpr (sizeof(W) == 4) {  // two products below 2^60: one sum, one reduction (the same canonical word)
+        typename A::Sum cross = A::first(a0, b1);
+        A::add_vector(cross, a1, b0);
+        dst[poly_words] = static_cast<W>(A::reduce(cross, m));
+    } else {
+        dst[poly_words] = static_cast<W>(add_mod_uniform(A::mul(a0, b1, m), A::mul(a1, b0, m), m.p));
+    }
+    dst[2 * poly_words] = static_cast<W>(A::mul(a1, b1, m));
 }
 
 // ---- lazy tensor accumulation for Bfv.innerProduct(ct, ct) (Bfv.swift:315-361) -----------------------------------
@@ -343,16 +408,17 @@ __global__ void __launch_bounds__(kThreads)
     const DeviceModulus m = ks.moduli[r];
     const W* __restrict__ x_row = spread + ((poly * L) * (L + 1) + r) * n + k;
     const W* __restrict__ key_row0 = key + size_t(key_row) * n + k;
-    ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+    using A = WordArith<W>;
+    typename A::Sum acc0 = A::zero(), acc1 = A::zero();
     for (uint32_t j = 0; j < L; ++j) {
         const uint64_t x = x_row[size_t(j) * (L + 1) * n];
         const W* key_j = key_row0 + size_t(j) * 2 * top_rows * n;
-        product_sum_add(acc0, x, key_j[0]);
-        product_sum_add(acc1, x, key_j[size_t(top_rows) * n]);
+        A::add_vector(acc0, x, key_j[0]);
+        A::add_vector(acc1, x, key_j[size_t(top_rows) * n]);
     }
     W* dst = out + (poly * 2 * (L + 1) + r) * n + k;
-    dst[0] = static_cast<W>(reduce_product_sum(acc0, m));
-    dst[size_t(L + 1) * n] = static_cast<W>(reduce_product_sum(acc1, m));
+    dst[0] = static_cast<W>(A::reduce(acc0, m));
+    dst[size_t(L + 1) * n] = static_cast<W>(A::reduce(acc1, m));
 }
 
 // ---- key switching, step 4: drop the special modulus and add into the ciphertext (Bfv.swift:216-217) --------------
@@ -425,8 +491,7 @@ __global__ void __launch_bounds__(kThreads)
             const U64x2 inv = inverse_q_last[row];
             const uint64_t t = barrett_reduce64_uniform(magnitude, m.p, m.barrett64);
             const uint64_t x = stream_load(src + row * n);
-            const uint64_t v = shoup_mul_uniform(negative ? add_mod_uniform(x, t, m.p) : sub_mod_uniform(x, t, m.p),
-                                                 inv.x, inv.y, m.p);
+            const uint64_t v = WordArith<W>::shoup(negative ? add_mod_uniform(x, t, m.p) : sub_mod_uniform(x, t, m.p), inv, m.p);
             if constexpr (MODE == kFinishPlain) {
                 // relinearize adds the update to (c0, c1) (Bfv.swift:216-217); applyGalois adds it to c0 only and
                 // replaces c1 (Bfv.swift:194-195)
