@@ -49,6 +49,8 @@ __device__ __forceinline__ uint64_t shoup_mul_pair(uint64_t x, U64x2 c, uint64_t
 // (MA/Scalar.swift:498-511), so a product is below 2^60, sixteen of them fit a 64-bit word (the kernels sum at most
 // nine), a sum is ONE multiply-add per term, its reduction a single-word Barrett, and a product by a constant a 32-bit
 // Shoup product (the table's floor(w 2^64 / p) holds floor(w 2^32 / p) in its high word) -- a fifth of the instructions.
+// 4-byte words: items between folds of a 64-bit sum that takes two products below 2^60 per item (2 x 7 + 1 < 16)
+constexpr uint64_t kNarrowTerms = 7;
 template <typename W>
 struct WordArith {  // uint64_t
     using Sum = ProductSum;
@@ -305,6 +307,27 @@ __global__ void __launch_bounds__(kThreads)
     const size_t poly_words = size_t(ctx.moduli_count) << logn;
     for (size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x; w < poly_words; w += size_t(gridDim.x) * kThreads) {
         const DeviceModulus m = ctx.moduli[w >> logn];
+        if constexpr (sizeof(W) == 4) {
+            // products below 2^60: 64-bit sums, folded every kNarrowTerms items (the middle sum takes two per item)
+            uint64_t s0 = 0, s1 = 0, s2 = 0, since32 = 0;
+            for (size_t item = 0; item < count; ++item) {
+                const W* src = in + item * 4 * poly_words + w;
+                const uint32_t a0 = src[0], a1 = src[poly_words], b0 = src[2 * poly_words], b1 = src[3 * poly_words];
+                s0 = mad32(a0, b0, s0);
+                s1 = mad32(a0, b1, mad32(a1, b0, s1));
+                s2 = mad32(a1, b1, s2);
+                if (++since32 >= kNarrowTerms) {
+                    since32 = 0;
+                    s0 = barrett_reduce64_uniform(s0, m.p, m.barrett64);
+                    s1 = barrett_reduce64_uniform(s1, m.p, m.barrett64);
+                    s2 = barrett_reduce64_uniform(s2, m.p, m.barrett64);
+                }
+            }
+            out[w] = static_cast<W>(barrett_reduce64_uniform(s0, m.p, m.barrett64));
+            out[poly_words + w] = static_cast<W>(barrett_reduce64_uniform(s1, m.p, m.barrett64));
+            out[2 * poly_words + w] = static_cast<W>(barrett_reduce64_uniform(s2, m.p, m.barrett64));
+            continue;
+        }
         U128 d0{0, 0}, d1{0, 0}, d2{0, 0};
         uint64_t since = 0;
         for (size_t item = 0; item < count; ++item) {
@@ -341,6 +364,27 @@ __global__ void __launch_bounds__(kThreads)
     W* __restrict__ sum = out + item * 3 * poly_words;
     for (size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x; w < poly_words; w += size_t(gridDim.x) * kThreads) {
         const DeviceModulus m = ctx.moduli[w >> logn];
+        if constexpr (sizeof(W) == 4) {
+            uint64_t s0 = 0, s1 = 0, s2 = 0, since32 = 0;
+            for (size_t k = 0; k < count; ++k) {
+                const W* a = lhs + k * 2 * poly_words + w;
+                const W* b = right + k * 2 * poly_words + w;
+                const uint32_t a0 = a[0], a1 = a[poly_words], b0 = b[0], b1 = b[poly_words];
+                s0 = mad32(a0, b0, s0);
+                s1 = mad32(a0, b1, mad32(a1, b0, s1));
+                s2 = mad32(a1, b1, s2);
+                if (++since32 >= kNarrowTerms) {
+                    since32 = 0;
+                    s0 = barrett_reduce64_uniform(s0, m.p, m.barrett64);
+                    s1 = barrett_reduce64_uniform(s1, m.p, m.barrett64);
+                    s2 = barrett_reduce64_uniform(s2, m.p, m.barrett64);
+                }
+            }
+            sum[w] = static_cast<W>(barrett_reduce64_uniform(s0, m.p, m.barrett64));
+            sum[poly_words + w] = static_cast<W>(barrett_reduce64_uniform(s1, m.p, m.barrett64));
+            sum[2 * poly_words + w] = static_cast<W>(barrett_reduce64_uniform(s2, m.p, m.barrett64));
+            continue;
+        }
         U128 d0{0, 0}, d1{0, 0}, d2{0, 0};
         uint64_t since = 0;
         for (size_t k = 0; k < count; ++k) {

@@ -572,6 +572,38 @@ def test_mul_and_relinearize_full_batch_properties(oracle, config3):
     assert torch.equal(again, relin[sub])
 
 
+@pytest.mark.parametrize("count", [7, 8, 23])
+def test_uint32_extremes_and_inner_product_cadence(oracle, count):
+    """Bfv<UInt32> in 4-byte arithmetic (rns_kernels.hip WordArith<uint32_t>): 64-bit sums of products below 2^60 and
+    32-bit Shoup products.  Words at q - 1 and 0 -- the largest sums the base conversions, the tensor product and the
+    ct . ct inner product (folded every 7 items: 7, 8 and 23 pairs sit on, just past and three times past the fold) can
+    see -- word for word against the 32-bit oracle, with moduli right under 2^30."""
+    degree = 64
+    t = oracle.generate_primes([10], True, degree, word_bits=32)[0]
+    q = oracle.generate_primes([30, 30, 30, 30], False, degree, word_bits=32)
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    moduli = q[:-1]
+    dev, host = heamd.to_device32, heamd.to_host32
+    rng = np.random.default_rng(count)
+    top = np.array(moduli, dtype=np.uint64)[:, None] - np.uint64(1)
+    lhs, rhs = _uniform(rng, (count, 2), moduli, degree), _uniform(rng, (count, 2), moduli, degree)
+    lhs[:, :, :, : degree // 2] = top[None, None, :, :]
+    rhs[:, :, :, : degree // 4] = top[None, None, :, :]
+    rhs[:, :, :, -4:] = 0
+    assert np.array_equal(host(ours.inner_product(dev(lhs), dev(rhs))), ref.inner_product(lhs, rhs))
+    product = host(ours.mul(dev(lhs[:3]), dev(rhs[:3])))
+    assert np.array_equal(product, ref.mul(lhs[:3], rhs[:3]))
+    key = _uniform(rng, (ours.L, 2), q, degree)
+    key[:, :, :, : degree // 2] = (np.array(q, dtype=np.uint64)[:, None] - np.uint64(1))[None, None, :, :]
+    assert np.array_equal(host(ours.relinearize(dev(product), dev(key))), ref.relinearize(product, key))
+    tool = ref.rns_tool(ours.L)
+    x = np.broadcast_to(top, (2, len(moduli), degree)).copy()
+    assert np.array_equal(host(ours.lift_q_to_qbsk(dev(x), ours.L)), np.stack([tool.lift_q_to_qbsk(p) for p in x]))
+    ext = ref.qbsk_context(ours.L).moduli
+    y = np.broadcast_to(np.array(ext, dtype=np.uint64)[:, None] - np.uint64(1), (2, len(ext), degree)).copy()
+    assert np.array_equal(host(ours.floor_qbsk_to_q(dev(y), ours.L)), np.stack([tool.floor_qbsk_to_q(p) for p in y]))
+
+
 def test_bfv_uint32_packed_slabs_match_oracle(oracle):
     """Bfv<UInt32> on packed [UInt32] slabs (he_*_device_u32): no word is widened in memory.  Every scheme operation
     word for word against the 32-bit oracle -- lift / floor / scaleAndRound at two levels, ct x ct, relinearize,
