@@ -390,6 +390,43 @@ def test_whole_query_with_a_database_per_index(oracle, small):
     assert torch.cuda.is_available()
 
 
+def test_pir_on_a_uint32_parameter_set(oracle):
+    """The reference's PIR parameter sets with 27/28-bit moduli are Bfv<UInt32> (EncryptionParameters.swift:313-345):
+    the PIR entry points take such a context on 8-byte slabs (zero-extended words; the constants -- 29-bit Bsk primes,
+    gamma, mTilde = 2^16 -- are the UInt32 ones).  N=4096: expansion and a two-chunk response word for word against
+    the 32-bit oracle, for one query and for three sharing the database pass."""
+    degree = 4096
+    q = [(1 << 27) - 40959, (1 << 28) - 65535, (1 << 28) - 73727]  # n_4096_logq_27_28_28
+    t = (1 << 16) + 1
+    ours = heamd.BfvContext(degree, t, q, word_bits=32)
+    ref = oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(99)
+    moduli = q[:-1]
+    total = 6
+    query = _uniform(rng, (1, 2), moduli, degree)
+    keys = {(degree >> k) + 1: _uniform(rng, (ours.L, 2), q, degree) for k in range(3)}
+    expanded = heamd.to_host(ours.pir_expand(heamd.to_device(query), total, {e: heamd.to_device(k) for e, k in keys.items()}))
+    assert np.array_equal(expanded, oracle.pir.expand(ref, query, total, keys))
+    dims, chunks, queries = [4, 3], 2, 3
+    database = _uniform(rng, (chunks, 12), moduli, degree)
+    dim0 = _uniform(rng, (dims[0], queries, 2), moduli, degree)
+    rest = _uniform(rng, (queries, dims[1], 2), moduli, degree)
+    relin = [_uniform(rng, (ours.L, 2), q, degree) for _ in range(queries)]
+    got = heamd.to_host(ours.pir_compute_response_queries(dims, heamd.to_device(dim0), heamd.to_device(rest),
+                                                          heamd.to_device(database), chunks,
+                                                          [heamd.to_device(k) for k in relin]))
+    for query_index in range(queries):
+        own = np.ascontiguousarray(dim0[:, query_index])
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, own, rest[query_index], database[chunk], None,
+                                                                 relin[query_index])
+            assert np.array_equal(got[query_index, chunk], expected), (query_index, chunk)
+    single = heamd.to_host(ours.pir_compute_response(dims, heamd.to_device(np.ascontiguousarray(dim0[:, 0])),
+                                                     heamd.to_device(rest[0]), heamd.to_device(database), chunks,
+                                                     relinearization_key=heamd.to_device(relin[0])))
+    assert np.array_equal(single, got[0])
+
+
 def test_queries_share_one_pass_config_shape(oracle):
     """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
     8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
