@@ -468,7 +468,7 @@ def _unpack_rows(packed, moduli, degree, count):
     return out
 
 
-@pytest.mark.parametrize("bits", [[55, 55, 55], [40, 56, 33, 55], [62, 61, 62]])
+@pytest.mark.parametrize("bits", [[55, 55, 55], [40, 56, 33, 55], [62, 61, 62], [27, 28, 29]])
 def test_packed_database_matches_plain(oracle, bits):
     """The packed plaintext layout (bits(q) bits per word, he_bfv_pack_plaintexts_device): the packed words unpack to the
     plaintexts on the host, and the inner products and the whole chunk loop over the packed database equal the ones over
