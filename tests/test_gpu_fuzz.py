@@ -179,3 +179,50 @@ def test_random_wire_formats(oracle, seed):
     seeds = np.random.default_rng(seed).integers(0, 256, size=(rnd.randint(1, 20), 32), dtype=np.uint8)
     got = heamd.to_host(ours.random_from_seeds(torch.from_numpy(seeds).cuda()))
     assert np.array_equal(got, ref.random_from_seeds(seeds)), (degree, len(seeds))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_uint32_shapes(oracle, seed):
+    """Bfv<UInt32> on packed 4-byte slabs over random parameter shapes (17..30-bit moduli, 1..4 ciphertext moduli, degrees
+    with and without tiled 4-byte transforms): base conversions, ct x ct, relinearize, the Galois key switch, mod-switch,
+    both inner products -- word for word against the 32-bit oracle."""
+    import torch
+
+    rnd = random.Random(seed)
+    dev, host = heamd.to_device32, heamd.to_host32
+    for trial in range(4):
+        degree = rnd.choice([64, 1024, 4096])
+        L = rnd.randint(1, 4)
+        log_2n = degree.bit_length()  # NTT-friendly primes are 1 mod 2N: leave room for a few of each size
+        bits = [rnd.randint(max(17, log_2n + 7), 30) for _ in range(L + 1)]
+        q = oracle.generate_primes(bits, False, degree, word_bits=32)
+        t = oracle.generate_primes([log_2n + 4], True, degree, word_bits=32)[0]
+        ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+        rng = np.random.default_rng(seed * 100 + trial)
+        moduli = q[:-1]
+        label = (degree, bits)
+        tool = ref.rns_tool(L)
+        x = _uniform(rng, (2,), moduli, degree)
+        assert np.array_equal(host(ours.lift_q_to_qbsk(dev(x), L)), np.stack([tool.lift_q_to_qbsk(p) for p in x])), label
+        y = _uniform(rng, (2,), ref.qbsk_context(L).moduli, degree)
+        assert np.array_equal(host(ours.floor_qbsk_to_q(dev(y), L)), np.stack([tool.floor_qbsk_to_q(p) for p in y])), label
+        assert np.array_equal(host(ours.scale_and_round(dev(x), 1)), np.stack([tool.scale_and_round(p, 1) for p in x])), label
+        lhs, rhs = _uniform(rng, (2, 2), moduli, degree), _uniform(rng, (2, 2), moduli, degree)
+        product = host(ours.mul(dev(lhs), dev(rhs)))
+        assert np.array_equal(product, ref.mul(lhs, rhs)), label
+        key = _uniform(rng, (L, 2), q, degree)
+        relin = host(ours.relinearize(dev(product), dev(key)))
+        assert np.array_equal(relin, ref.relinearize(product, key)), label
+        element = 2 * rnd.randrange(1, degree) + 1
+        assert np.array_equal(host(ours.apply_galois(dev(lhs), element, dev(key))), ref.apply_galois(lhs, element, key)), label
+        if L >= 2:
+            assert np.array_equal(host(ours.mod_switch_down(dev(lhs), 2)), ref.mod_switch_down(lhs, poly_count=2)), label
+        count, columns = rnd.randint(1, 30), rnd.randint(1, 6)
+        vector, other = _uniform(rng, (count, 2), moduli, degree), _uniform(rng, (count, 2), moduli, degree)
+        assert np.array_equal(host(ours.inner_product(dev(vector), dev(other))), ref.inner_product(vector, other)), label
+        plaintexts = _uniform(rng, (columns, count), moduli, degree)
+        present = rng.integers(0, 4, size=(columns, count), dtype=np.uint8).clip(0, 1)
+        got = host(ours.inner_product_plain_resident(dev(vector), dev(plaintexts), torch.from_numpy(present).cuda(), 2,
+                                                     columns))
+        column = rnd.randrange(columns)
+        assert np.array_equal(got[column], ref.inner_product_plain(vector, plaintexts[column], present[column])), label
