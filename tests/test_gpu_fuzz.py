@@ -222,7 +222,10 @@ def test_random_uint32_shapes(oracle, seed):
         assert np.array_equal(host(ours.inner_product(dev(vector), dev(other))), ref.inner_product(vector, other)), label
         plaintexts = _uniform(rng, (columns, count), moduli, degree)
         present = rng.integers(0, 4, size=(columns, count), dtype=np.uint8).clip(0, 1)
-        got = host(ours.inner_product_plain_resident(dev(vector), dev(plaintexts), torch.from_numpy(present).cuda(), 2,
-                                                     columns))
-        column = rnd.randrange(columns)
-        assert np.array_equal(got[column], ref.inner_product_plain(vector, plaintexts[column], present[column])), label
+        queries = rnd.choice([1, 2, 3, 4])  # several queries' vectors side by side share the plaintext stream
+        side_by_side = _uniform(rng, (count, queries, 2), moduli, degree)
+        got = host(ours.inner_product_plain_resident(dev(side_by_side), dev(plaintexts), torch.from_numpy(present).cuda(),
+                                                     2 * queries, columns)).reshape(columns, queries, 2, L, degree)
+        column, query = rnd.randrange(columns), rnd.randrange(queries)
+        own = np.ascontiguousarray(side_by_side[:, query])
+        assert np.array_equal(got[column, query], ref.inner_product_plain(own, plaintexts[column], present[column])), label
