@@ -330,6 +330,16 @@ int he_bfv_inner_product_plain_resident_device_u32(const he_bfv_context* ctx, ui
 int he_bfv_inner_product_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs,
                                     const uint32_t* rhs, size_t count, uint32_t* out, void* workspace,
                                     size_t workspace_bytes, he_stream s);
+int he_bfv_inner_product_shared_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs,
+                                           const uint32_t* rhs, size_t count, size_t items, uint32_t* out, he_stream s);
+/* he_pir_compute_response_device on packed 4-byte slabs (query, database, key and responses in UInt32 words): the PIR
+ * parameter sets with 27/28-bit moduli (EncryptionParameters.swift:313-345) stream half the database bytes of the
+ * 8-byte route.  Same shapes, same words as the reference's Bfv<UInt32>.  Enqueue-only. */
+int he_pir_compute_response_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                                       const uint32_t* dim0_query_eval, const uint32_t* remaining_query,
+                                       size_t remaining_query_count, const uint32_t* database,
+                                       const uint8_t* present_device, size_t chunk_count,
+                                       const uint32_t* relinearization_key, uint32_t* out, he_stream s);
 int he_bfv_plaintext_to_eval_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext,
                                         uint32_t* out, size_t batch, he_stream s);
 int he_bfv_plaintext_to_coeff_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext_eval,

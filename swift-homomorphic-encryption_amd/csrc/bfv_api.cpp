@@ -1067,4 +1067,15 @@ int he_bfv_inner_product_device_u32(const he_bfv_context* ctx, uint32_t moduli_c
     return inner_product_pipeline(ctx, tool, moduli_count, lhs, rhs, count, out, workspace, workspace_bytes, as_stream(s));
 }
 
+int he_bfv_inner_product_shared_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* lhs,
+                                           const uint32_t* rhs, size_t count, size_t items, uint32_t* out, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    if (count == 0) return invalid_argument("empty ciphertext vector");
+    if (items == 0) return HE_OK;
+    if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    return inner_product_shared_pipeline(ctx, tool, moduli_count, lhs, rhs, count, items, out, as_stream(s));
+}
+
 }  // extern "C"

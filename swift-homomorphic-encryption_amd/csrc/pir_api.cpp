@@ -229,6 +229,75 @@ extern "C" int he_pir_compute_response_packed_device(const he_bfv_context* ctx, 
                             packed_database, true, present_device, chunk_count, relinearization_key, out, s);
 }
 
+// ---- the same chunk loop for Bfv<UInt32> on packed 4-byte slabs (the reference's 27/28-bit PIR parameter sets,
+// EncryptionParameters.swift:313-345): half the database bytes of the 8-byte route --------------------------------
+extern "C" int he_pir_compute_response_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                  uint32_t dimension_count, const uint32_t* dim0_query_eval,
+                                                  const uint32_t* remaining_query, size_t remaining_query_count,
+                                                  const uint32_t* database, const uint8_t* present_device,
+                                                  size_t chunk_count, const uint32_t* relinearization_key, uint32_t* out,
+                                                  he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, reinterpret_cast<const uint64_t*>(remaining_query),
+                                 remaining_query_count, shape));
+    if (chunk_count == 0) return HE_OK;
+    if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = shape.L;
+    const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
+    const size_t chunk_words = shape.per_chunk * poly, out_words = 2 * n;
+    size_t group = (size_t(1) << 30) / (shape.columns * ct2 * sizeof(uint32_t));
+    group = group == 0 ? 1 : (group < chunk_count ? group : chunk_count);
+    const size_t widest = group * shape.columns;
+    Scratch results_mem(stream), next_mem(stream), products_mem(stream), level_mem(stream);
+    HEAMD_HIP_TRY(results_mem.allocate(widest * ct2 * sizeof(uint32_t)));
+    HEAMD_HIP_TRY(next_mem.allocate(widest * ct2 * sizeof(uint32_t)));
+    HEAMD_HIP_TRY(products_mem.allocate(widest * ct3 * sizeof(uint32_t)));
+    HEAMD_HIP_TRY(level_mem.allocate(2 * group * ct2 * sizeof(uint32_t)));
+    uint32_t* products = static_cast<uint32_t*>(products_mem.get());
+    for (size_t first = 0; first < chunk_count; first += group) {
+        const size_t chunks = chunk_count - first < group ? chunk_count - first : group;
+        uint32_t* current = static_cast<uint32_t*>(results_mem.get());
+        uint32_t* other = static_cast<uint32_t*>(next_mem.get());
+        // PirUtil.swift:428-438: every column of every chunk of the group in one launch, then back to Coeff
+        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device_u32(
+            ctx, L, 2, dim0_query_eval, database + first * chunk_words,
+            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, chunks * shape.columns, current, s));
+        HEAMD_TRY_STATUS(he_ntt_inverse_device_u32(shape.q_ctx, current, chunks * shape.columns * 2, s));
+        // PirUtil.swift:448-479, every stage one batch over the result groups of all chunks
+        size_t count = shape.columns, cursor = 0;
+        for (uint32_t i = 1; i < dimension_count; ++i) {
+            const size_t d = dimensions[i];
+            if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
+            const size_t items = chunks * (count / d);
+            HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device_u32(ctx, L, remaining_query + cursor * ct2, current, d, items,
+                                                                    products, s));
+            HEAMD_TRY_STATUS(he_bfv_relinearize_device_u32(ctx, L, products, relinearization_key, other, items, nullptr, 0, s));
+            uint32_t* swap = current;
+            current = other;
+            other = swap;
+            count /= d;
+            cursor += d;
+        }
+        if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
+        // modSwitchDownToSingle (:483)
+        uint32_t* target = out + first * out_words;
+        if (L == 1) {
+            HEAMD_HIP_TRY(hipMemcpyAsync(target, current, chunks * out_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            continue;
+        }
+        uint32_t* ping = static_cast<uint32_t*>(level_mem.get());
+        uint32_t* pong = ping + group * ct2;
+        const uint32_t* source = current;
+        for (uint32_t level = L; level > 1; --level) {
+            uint32_t* step = level == 2 ? target : (source == ping ? pong : ping);
+            HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device_u32(ctx, level, 2, source, step, chunks, s));
+            source = step;
+        }
+    }
+    return HE_OK;
+}
+
 // Several queries over the same database in one call: the dim-0 inner products of all of them stream the database once
 // (their ciphertext vectors side by side, he_amd.h he_bfv_inner_product_plain_device with polys = 2 x queries); the
 // remaining dimensions, which involve only query ciphertexts and intermediate results, then run query by query.

@@ -138,6 +138,9 @@ SIGNATURES = [
     ("he_bfv_inner_product_plain_resident_device_u32", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
+    ("he_bfv_inner_product_shared_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, c_size, vp, vp]),
+    ("he_pir_compute_response_device_u32", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
     ("he_bfv_plaintext_to_eval_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_coeff_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_galois_element_swapping_rows", ctypes.c_int, [c_u64, U64P]),
@@ -1005,6 +1008,20 @@ class BfvContext32(BfvContext):
         out = self._empty32((3, L, self.degree), lhs)
         _check(load_library().he_bfv_inner_product_device_u32(self.h, L, _ptr32(lhs), _ptr32(rhs), count, _ptr32(out), vp(),
                                                               0, _stream(stream)))
+        return out
+
+    def pir_compute_response(self, dimensions, dim0_query_eval, remaining_query, database, chunk_count,
+                             present_device=None, relinearization_key=None, stream=None):
+        """he_pir_compute_response_device_u32: everything in packed UInt32 words -> [chunks][2][1][N] (int32)."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = self._empty32((chunk_count, 2, 1, self.degree), dim0_query_eval)
+        rest = vp() if remaining_query is None else _ptr32(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr32(relinearization_key)
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_device_u32(self.h, dims, len(dimensions), _ptr32(dim0_query_eval),
+                                                                 rest, rest_count, _ptr32(database), mask, chunk_count,
+                                                                 key, _ptr32(out), _stream(stream)))
         return out
 
     def plaintext_to_eval(self, plaintext, moduli_count=None, stream=None):

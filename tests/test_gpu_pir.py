@@ -427,6 +427,36 @@ def test_pir_on_a_uint32_parameter_set(oracle):
     assert np.array_equal(single, got[0])
 
 
+@pytest.mark.parametrize("dims", [[5], [4, 3], [3, 2, 2]])
+def test_pir_response_on_packed_uint32_slabs(oracle, dims):
+    """he_pir_compute_response_device_u32: query, database, key and responses in UInt32 words (Bfv<UInt32>, the
+    n_4096_logq_27_28_28 parameter set; 1-, 2- and 3-dimensional databases, three chunks, nil plaintexts): every chunk
+    response word for word the 32-bit oracle's."""
+    import torch
+
+    degree = 4096
+    q = [(1 << 27) - 40959, (1 << 28) - 65535, (1 << 28) - 73727]
+    t = (1 << 16) + 1
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(len(dims))
+    moduli = q[:-1]
+    per_chunk, chunks, rest_count = int(np.prod(dims)), 3, sum(dims[1:])
+    database = _uniform(rng, (chunks, per_chunk), moduli, degree)
+    present = np.ones((chunks, per_chunk), dtype=np.uint8)
+    present[1, [0, per_chunk - 1]] = 0
+    dim0 = _uniform(rng, (dims[0], 2), moduli, degree)
+    rest = _uniform(rng, (max(rest_count, 1), 2), moduli, degree)[:rest_count]
+    key = _uniform(rng, (ours.L, 2), q, degree)
+    dev = heamd.to_device32
+    got = heamd.to_host32(ours.pir_compute_response(dims, dev(dim0), dev(rest) if rest_count else None, dev(database), chunks,
+                                                    present_device=torch.from_numpy(present).cuda(),
+                                                    relinearization_key=dev(key) if rest_count else None))
+    for chunk in range(chunks):
+        expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database[chunk], present[chunk],
+                                                             key if rest_count else None)
+        assert np.array_equal(got[chunk], expected), chunk
+
+
 def test_queries_share_one_pass_config_shape(oracle):
     """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
     8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
