@@ -340,6 +340,17 @@ int he_pir_compute_response_device_u32(const he_bfv_context* ctx, const uint32_t
                                        size_t remaining_query_count, const uint32_t* database,
                                        const uint8_t* present_device, size_t chunk_count,
                                        const uint32_t* relinearization_key, uint32_t* out, he_stream s);
+/* he_pir_compute_response_to_query_device for Bfv<UInt32> on packed 4-byte slabs (query, relinearization key, databases,
+ * responses in UInt32 words).  The expansion, which is bound by its key switches and not by bytes, runs on widened words:
+ * galois_keys_wide are the Galois keys as 8-byte slabs (he_words_widen_u32_device), as he_pir_expand_device takes them for
+ * a UInt32 context.  Indices are answered one at a time. */
+int he_pir_compute_response_to_query_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                uint32_t dimension_count, const uint32_t* query_ciphertexts,
+                                                size_t query_ciphertext_count, size_t indices_count,
+                                                const uint64_t* galois_elements, const uint64_t* const* galois_keys_wide,
+                                                size_t galois_key_count, const uint32_t* relinearization_key,
+                                                const uint32_t* const* databases, const uint8_t* const* present_masks,
+                                                size_t database_count, size_t chunk_count, uint32_t* out, he_stream s);
 int he_bfv_plaintext_to_eval_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext,
                                         uint32_t* out, size_t batch, he_stream s);
 int he_bfv_plaintext_to_coeff_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, const uint32_t* plaintext_eval,

@@ -680,3 +680,52 @@ extern "C" int he_pir_compute_response_to_query_device(
     }
     return HE_OK;
 }
+
+// The whole-query call for Bfv<UInt32> on packed 4-byte slabs: the expansion (bound by its key switches, not by bytes)
+// runs on widened words with the 8-byte kernels -- the Galois keys are therefore taken as 8-byte slabs, as
+// he_pir_expand_device takes them for a UInt32 context -- everything that touches the database is 4-byte.
+extern "C" int he_pir_compute_response_to_query_device_u32(
+    const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count, const uint32_t* query_ciphertexts,
+    size_t query_ciphertext_count, size_t indices_count, const uint64_t* galois_elements,
+    const uint64_t* const* galois_keys_wide, size_t galois_key_count, const uint32_t* relinearization_key,
+    const uint32_t* const* databases, const uint8_t* const* present_masks, size_t database_count, size_t chunk_count,
+    uint32_t* out, he_stream s) {
+    if (ctx == nullptr) return invalid_argument("null context");
+    if (dimensions == nullptr || dimension_count == 0) return invalid_argument("empty dimensions");
+    size_t expanded_count = 0;
+    for (uint32_t i = 0; i < dimension_count; ++i) expanded_count += dimensions[i];
+    const size_t remaining_count = expanded_count - dimensions[0];
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count,
+                                 remaining_count ? reinterpret_cast<const uint64_t*>(query_ciphertexts) : nullptr,
+                                 remaining_count, shape));
+    if (databases == nullptr || !(database_count == 1 || database_count >= indices_count))
+        return invalid_argument("database count matches neither one nor the number of indices");
+    if (indices_count == 0 || chunk_count == 0) return HE_OK;
+    if (query_ciphertexts == nullptr || out == nullptr) return invalid_argument("null operand");
+    hipStream_t stream = as_stream(s);
+    const size_t ct_words = 2 * size_t(shape.L) * shape.n;
+    const size_t total = expanded_count * indices_count, out_words = 2 * shape.n;
+    Scratch query_mem(stream), wide_mem(stream), expanded_mem(stream);
+    HEAMD_HIP_TRY(query_mem.allocate(query_ciphertext_count * ct_words * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(wide_mem.allocate(total * ct_words * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(expanded_mem.allocate(total * ct_words * sizeof(uint32_t)));
+    uint64_t* query_wide = static_cast<uint64_t*>(query_mem.get());
+    uint64_t* expanded_wide = static_cast<uint64_t*>(wide_mem.get());
+    uint32_t* expanded = static_cast<uint32_t*>(expanded_mem.get());  // [index][sum(dimensions)][2][L][N] Coeff
+    HEAMD_TRY_STATUS(he_words_widen_u32_device(query_ciphertexts, query_wide, query_ciphertext_count * ct_words, s));
+    HEAMD_TRY_STATUS(he_pir_expand_device(ctx, query_wide, query_ciphertext_count, total, galois_elements, galois_keys_wide,
+                                          galois_key_count, expanded_wide, s));
+    HEAMD_TRY_STATUS(he_words_narrow_u64_device(expanded_wide, expanded, total * ct_words, s));
+    for (size_t index = 0; index < indices_count; ++index) {
+        uint32_t* mine = expanded + index * expanded_count * ct_words;
+        const uint32_t* database = databases[database_count == 1 ? 0 : index];
+        if (database == nullptr) return invalid_argument("null database");
+        const uint8_t* present_device = present_masks ? present_masks[database_count == 1 ? 0 : index] : nullptr;
+        HEAMD_TRY_STATUS(he_ntt_forward_device_u32(shape.q_ctx, mine, shape.d0 * 2, s));
+        HEAMD_TRY_STATUS(he_pir_compute_response_device_u32(
+            ctx, dimensions, dimension_count, mine, remaining_count ? mine + shape.d0 * ct_words : nullptr, remaining_count,
+            database, present_device, chunk_count, relinearization_key, out + index * chunk_count * out_words, s));
+    }
+    return HE_OK;
+}

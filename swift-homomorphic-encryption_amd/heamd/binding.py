@@ -141,6 +141,9 @@ SIGNATURES = [
     ("he_bfv_inner_product_shared_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, c_size, vp, vp]),
     ("he_pir_compute_response_device_u32", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
+    ("he_pir_compute_response_to_query_device_u32", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, ctypes.POINTER(vp),
+      ctypes.POINTER(vp), c_size, c_size, vp, vp]),
     ("he_bfv_plaintext_to_eval_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_plaintext_to_coeff_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp]),
     ("he_galois_element_swapping_rows", ctypes.c_int, [c_u64, U64P]),
@@ -1022,6 +1025,29 @@ class BfvContext32(BfvContext):
         _check(load_library().he_pir_compute_response_device_u32(self.h, dims, len(dimensions), _ptr32(dim0_query_eval),
                                                                  rest, rest_count, _ptr32(database), mask, chunk_count,
                                                                  key, _ptr32(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_to_query(self, dimensions, query_ciphertexts, indices_count, galois_keys_wide,
+                                      relinearization_key, databases, chunk_count, present_devices=None, stream=None):
+        """he_pir_compute_response_to_query_device_u32: int32 query / relinearization key / databases, Galois keys as
+        int64 (widened) tensors -> [indices][chunks][2][1][N] (int32)."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        count = query_ciphertexts.numel() // (2 * self.L * self.degree)
+        out = self._empty32((indices_count, chunk_count, 2, 1, self.degree), query_ciphertexts)
+        elements = sorted(galois_keys_wide)
+        element_array = _u64(elements)
+        key_array = (vp * max(len(elements), 1))(*[vp(galois_keys_wide[e].data_ptr()) for e in elements])
+        relin = vp() if relinearization_key is None else _ptr32(relinearization_key)
+        database_list = list(databases) if isinstance(databases, (list, tuple)) else [databases]
+        database_array = (vp * len(database_list))(*[vp(d.data_ptr()) for d in database_list])
+        mask_array = None
+        if present_devices is not None:
+            mask_list = list(present_devices) if isinstance(present_devices, (list, tuple)) else [present_devices]
+            mask_array = (vp * len(mask_list))(*[vp() if m is None else vp(m.data_ptr()) for m in mask_list])
+        _check(load_library().he_pir_compute_response_to_query_device_u32(
+            self.h, dims, len(dimensions), _ptr32(query_ciphertexts), count, indices_count,
+            element_array.ctypes.data_as(U64P), key_array, len(elements), relin, database_array, mask_array,
+            len(database_list), chunk_count, _ptr32(out), _stream(stream)))
         return out
 
     def plaintext_to_eval(self, plaintext, moduli_count=None, stream=None):

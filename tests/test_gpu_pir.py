@@ -457,6 +457,35 @@ def test_pir_response_on_packed_uint32_slabs(oracle, dims):
         assert np.array_equal(got[chunk], expected), chunk
 
 
+def test_whole_query_on_packed_uint32_slabs(oracle):
+    """he_pir_compute_response_to_query_device_u32 (n_4096_logq_27_28_28, two indices, 4 x 3 database, two chunks): the
+    composition of the 32-bit oracle's expand and chunk responses, word for word."""
+    degree = 4096
+    q = [(1 << 27) - 40959, (1 << 28) - 65535, (1 << 28) - 73727]
+    t = (1 << 16) + 1
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(1234)
+    moduli = q[:-1]
+    dims, chunks, indices = [4, 3], 2, 2
+    expanded_count = sum(dims)
+    total = expanded_count * indices
+    query = _uniform(rng, (1, 2), moduli, degree)
+    galois = {(degree >> k) + 1: _uniform(rng, (ours.L, 2), q, degree) for k in range((total - 1).bit_length())}
+    relin = _uniform(rng, (ours.L, 2), q, degree)
+    database = _uniform(rng, (chunks, 12), moduli, degree)
+    dev = heamd.to_device32
+    got = heamd.to_host32(ours.pir_compute_response_to_query(
+        dims, dev(query), indices, {e: heamd.to_device(k) for e, k in galois.items()}, dev(relin), dev(database), chunks))
+    expanded = oracle.pir.expand(ref, query, total, galois)
+    qctx = ref.ciphertext_context()
+    for i in range(indices):
+        mine = expanded[i * expanded_count: (i + 1) * expanded_count]
+        dim0 = np.stack([qctx.forward_ntt(ct) for ct in mine[: dims[0]]])
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, mine[dims[0]:], database[chunk], None, relin)
+            assert np.array_equal(got[i, chunk], expected), (i, chunk)
+
+
 def test_queries_share_one_pass_config_shape(oracle):
     """The same on BASELINE config 5's ring (N=8192, L=4; the LDS-tiled kernel), 3 queries with their own keys over two
     8 x 4 chunks of uniform words: each query's responses equal the single-query entry point's word for word."""
