@@ -229,3 +229,17 @@ def test_random_uint32_shapes(oracle, seed):
         column, query = rnd.randrange(columns), rnd.randrange(queries)
         own = np.ascontiguousarray(side_by_side[:, query])
         assert np.array_equal(got[column, query], ref.inner_product_plain(own, plaintexts[column], present[column])), label
+        # the PIR chunk loop on the same packed slabs
+        dims = [rnd.randint(1, 4)] + rnd.choice([[], [rnd.randint(1, 3)], [2, 2]])
+        per_chunk, chunks, rest_count = int(np.prod(dims)), rnd.randint(1, 2), sum(dims[1:])
+        database = _uniform(rng, (chunks, per_chunk), moduli, degree)
+        mask = rng.integers(0, 5, size=(chunks, per_chunk), dtype=np.uint8).clip(0, 1)
+        dim0 = _uniform(rng, (dims[0], 2), moduli, degree)
+        rest = _uniform(rng, (max(rest_count, 1), 2), moduli, degree)[:rest_count]
+        response = host(ours.pir_compute_response(dims, dev(dim0), dev(rest) if rest_count else None, dev(database), chunks,
+                                                  present_device=torch.from_numpy(mask).cuda(),
+                                                  relinearization_key=dev(key) if rest_count else None))
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest, database[chunk], mask[chunk],
+                                                                 key if rest_count else None)
+            assert np.array_equal(response[chunk], expected), (label, dims, chunk)
