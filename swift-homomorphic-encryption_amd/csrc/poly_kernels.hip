@@ -303,6 +303,39 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// The lazy sums of the inner-product kernels by slab word type.  8-byte words: the carry-counting accumulator
+// (device_math.hpp ProductSum), folded by reduce_product_sum.  4-byte words (Bfv<UInt32>: every modulus below 2^30): a
+// product is below 2^60, so a sum is one multiply-add per term in a 64-bit word, folded at least every
+// kWord32Cadence terms (15 x 2^60 + a folded residue stays below 2^64) by a single-word Barrett.
+constexpr uint64_t kWord32Cadence = 15;
+template <typename W, int POLYS, bool NARROW>
+struct PlainSums {
+    using Sum = ProductSum;
+    static __device__ __forceinline__ Sum zero() { return product_sum_zero(); }
+    static __device__ __forceinline__ void add_all(Sum (&s)[POLYS], const uint64_t (&x)[POLYS], uint64_t y) {
+        product_sum_add_all<POLYS, NARROW>(s, x, y);
+    }
+    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const DeviceModulus& m) { return reduce_product_sum(s, m); }
+    static __device__ __forceinline__ Sum from_residue(uint64_t r) {
+        Sum s = product_sum_zero();
+        s.t = r;
+        return s;
+    }
+};
+template <int POLYS, bool NARROW>
+struct PlainSums<uint32_t, POLYS, NARROW> {
+    using Sum = uint64_t;
+    static __device__ __forceinline__ Sum zero() { return 0; }
+    static __device__ __forceinline__ void add_all(Sum (&s)[POLYS], const uint64_t (&x)[POLYS], uint64_t y) {
+#pragma unroll
+        for (int q = 0; q < POLYS; ++q) s[q] = mad32(lo32(x[q]), lo32(y), s[q]);
+    }
+    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const DeviceModulus& m) {
+        return barrett_reduce64_uniform(s, m.p, m.barrett64);
+    }
+    static __device__ __forceinline__ Sum from_residue(uint64_t r) { return r; }
+};
+
 // The same inner product on the carry-counting accumulator (device_math.hpp ProductSum: 4 multiply-adds and 3 carry
 // counts per product against ~18 instructions for a 128-bit multiply-add) with the residue row -- hence the modulus
 // -- wave-uniform: blockIdx.y covers kThreads words of ONE row (degree >= kThreads).  `cadence` products at most are
@@ -332,11 +365,12 @@ __global__ void __launch_bounds__(kThreads)
     const size_t word = block_word + threadIdx.x;
     const size_t col0 = static_cast<size_t>(column_group) * COLS;
     const DeviceModulus m = ctx.moduli[block_word >> logn];
-    ProductSum acc[COLS][POLYS];
+    using Sums = PlainSums<W, POLYS, NARROW>;
+    typename Sums::Sum acc[COLS][POLYS];
 #pragma unroll
     for (int c = 0; c < COLS; ++c)
 #pragma unroll
-        for (int q = 0; q < POLYS; ++q) acc[c][q] = product_sum_zero();
+        for (int q = 0; q < POLYS; ++q) acc[c][q] = Sums::zero();
     uint64_t since_reduce[COLS];
     bool live[COLS];
 #pragma unroll
@@ -424,14 +458,12 @@ __global__ void __launch_bounds__(kThreads)
             bool active = live[c];
             if constexpr (MASKED) active = active && mask[c] != 0;  // nil plaintext, Bfv.swift:486-489
             if (!active) continue;
-            product_sum_add_all<POLYS, NARROW>(acc[c], x, y[c]);
+            Sums::add_all(acc[c], x, y[c]);
             if (++since_reduce[c] >= cadence) {
                 since_reduce[c] = 0;
 #pragma unroll
                 for (int q = 0; q < POLYS; ++q) {
-                    const uint64_t folded = reduce_product_sum(acc[c][q], m);
-                    acc[c][q] = product_sum_zero();
-                    acc[c][q].t = folded;
+                    acc[c][q] = Sums::from_residue(Sums::reduce(acc[c][q], m));
                 }
             }
         }
@@ -441,7 +473,7 @@ __global__ void __launch_bounds__(kThreads)
         if (!live[c]) continue;
 #pragma unroll
         for (int q = 0; q < POLYS; ++q)
-            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(reduce_product_sum(acc[c][q], m));
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(Sums::reduce(acc[c][q], m));
     }
 }
 
@@ -475,11 +507,12 @@ __global__ void __launch_bounds__(kTileWords * kTileWavefronts)
     const size_t word = block_word + lane;
     const size_t col0 = (static_cast<size_t>(column_group) * kTileWavefronts + wave) * COLS;
     const DeviceModulus m = ctx.moduli[block_word >> logn];
-    ProductSum acc[COLS][POLYS];
+    using Sums = PlainSums<W, POLYS, NARROW>;
+    typename Sums::Sum acc[COLS][POLYS];
 #pragma unroll
     for (int c = 0; c < COLS; ++c)
 #pragma unroll
-        for (int q = 0; q < POLYS; ++q) acc[c][q] = product_sum_zero();
+        for (int q = 0; q < POLYS; ++q) acc[c][q] = Sums::zero();
     uint64_t since_reduce[COLS];
     bool live[COLS];
     size_t pt_column[COLS], mask_column[COLS];
@@ -560,14 +593,12 @@ __global__ void __launch_bounds__(kTileWords * kTileWavefronts)
                 bool active = live[c] && j < count;
                 if constexpr (MASKED) active = active && mask[c] != 0;  // nil plaintext, Bfv.swift:486-489
                 if (!active) continue;
-                product_sum_add_all<POLYS, NARROW>(acc[c], x, y[c]);
+                Sums::add_all(acc[c], x, y[c]);
                 if (++since_reduce[c] >= cadence) {
                     since_reduce[c] = 0;
 #pragma unroll
                     for (int q = 0; q < POLYS; ++q) {
-                        const uint64_t folded = reduce_product_sum(acc[c][q], m);
-                        acc[c][q] = product_sum_zero();
-                        acc[c][q].t = folded;
+                        acc[c][q] = Sums::from_residue(Sums::reduce(acc[c][q], m));
                     }
                 }
             }
@@ -580,7 +611,7 @@ __global__ void __launch_bounds__(kTileWords * kTileWavefronts)
         if (!live[c]) continue;
 #pragma unroll
         for (int q = 0; q < POLYS; ++q)
-            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(reduce_product_sum(acc[c][q], m));
+            out[((col0 + c) * POLYS + q) * words_per_poly + word] = static_cast<W>(Sums::reduce(acc[c][q], m));
     }
 }
 
@@ -709,6 +740,7 @@ hipError_t launch_inner_product_plain(const W* cts, const W* pts, const uint8_t*
     if (columns == 0) return hipSuccess;
     const bool narrow = narrow_moduli && cadence != 0;
     if (narrow && cadence > kNarrowProductSumCadence) cadence = kNarrowProductSumCadence;
+    if (sizeof(W) == 4 && cadence > kWord32Cadence) cadence = kWord32Cadence;  // 64-bit sums of products below 2^60
 #define HEAMD_INNER_PRODUCT_CASE(POLYS, COLS)                                                                              \
     case POLYS:                                                                                                            \
         return narrow ? launch_inner_product_plain_polys<POLYS, COLS, true>(cts, pts, present_device, out, ctx, count,     \
