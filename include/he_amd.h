@@ -249,6 +249,15 @@ int he_bfv_mod_switch_down_to_single_device(const he_bfv_context* ctx, uint32_t 
  * ct [batch][polys][L][N] *= pt [batch][L][N]. */
 int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
                             const uint64_t* pt, size_t batch, he_stream s);
+/* Bfv.addAssignCoeff / subAssignCoeff(_: inout CoeffCiphertext, _: CoeffPlaintext) (Bfv/Bfv.swift:110-117), i.e.
+ * plaintextTranslate (Bfv/Bfv+Encrypt.swift:75-140): c0 +-= floor(Q/t) m + floor(((Q mod t) m + (t + 1)/2) / t) per
+ * residue row.  ct [batch][polys][L][N] Coeff in place (only c0 is touched), plaintexts [batch][N] Coeff plaintexts
+ * with values < t (batch b's plaintext goes to batch b's ciphertext).  `plaintext - ciphertext`
+ * (HeScheme.swift:1540-1548) is he_poly_neg_device over the ciphertext's polynomials, then this add. */
+int he_bfv_add_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* plaintexts, size_t batch, he_stream s);
+int he_bfv_sub_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* plaintexts, size_t batch, he_stream s);
 /* Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv/Bfv.swift:476-505), batched over `columns` independent outputs
  * that share the ciphertext vector (the PIR dim-0 shape, PrivateInformationRetrieval/IndexPir/PirUtil.swift:427-445):
  *   cts      [count][polys][L][N]           Eval
@@ -323,6 +332,10 @@ int he_bfv_mod_switch_down_device_u32(const he_bfv_context* ctx, uint32_t moduli
                                       const uint32_t* in, uint32_t* out, size_t batch, he_stream s);
 int he_bfv_mul_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
                                 const uint32_t* pt, size_t batch, he_stream s);
+int he_bfv_add_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* plaintexts, size_t batch, he_stream s);
+int he_bfv_sub_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* plaintexts, size_t batch, he_stream s);
 int he_bfv_inner_product_plain_resident_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,
                                                    const uint32_t* cts, const uint32_t* pts,
                                                    const uint8_t* present_device, size_t count, size_t columns,

@@ -125,6 +125,7 @@ def _declare(L):
     L.orc_bfv_key_switching_update.argtypes = [vp, c_size, U64P, U64P, U64P]
     L.orc_bfv_mod_switch_down.argtypes = [vp, c_size, c_size, U64P, U64P, c_size]
     L.orc_bfv_mul_plain.argtypes = [vp, c_size, c_size, U64P, U64P, c_size]
+    L.orc_bfv_plaintext_translate.argtypes = [vp, c_size, c_size, U64P, U64P, ctypes.c_int, c_size]
     L.orc_bfv_inner_product_plain.argtypes = [vp, c_size, c_size, U64P, U64P, ctypes.POINTER(ctypes.c_uint8), c_size,
                                               U64P]
     L.orc_bfv_inner_product.argtypes = [vp, c_size, U64P, U64P, c_size, U64P]
@@ -620,6 +621,16 @@ class BfvContext:
         pt = _u64(pt)
         batch = pt.size // (L * self.degree)
         _check(lib().orc_bfv_mul_plain(self.h, L, poly_count, _p(out), _p(pt), batch))
+        return out
+
+    def plaintext_translate(self, ct, plaintexts, poly_count=2, subtract=False, moduli_count=None):
+        """Bfv.addAssignCoeff / subAssignCoeff(ciphertext, plaintext) (Bfv.swift:110-117, Bfv+Encrypt.swift:75-140):
+        ct [batch][polys][L][N] Coeff, plaintexts [batch][N] mod t."""
+        L = self._L(moduli_count)
+        out = _u64(ct).copy()
+        pt = _u64(plaintexts)
+        batch = pt.size // self.degree
+        _check(lib().orc_bfv_plaintext_translate(self.h, L, poly_count, _p(out), _p(pt), 1 if subtract else 0, batch))
         return out
 
     def inner_product_plain(self, cts, pts, present=None, poly_count=2, moduli_count=None):

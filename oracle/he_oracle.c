@@ -1605,6 +1605,57 @@ int orc_bfv_mul_plain(const orc_bfv_context* ctx, size_t L, size_t poly_count, u
     return ORC_OK;
 }
 
+/* floor(Q / t) mod p for Q = q_0 ... q_{L-1}: the composed Q in 64-bit limbs, long division by the single word t,
+ * the quotient's residue by Horner (RnsTool.swift:170-182 composes Q and t with Width32 integers). */
+static uint64_t q_div_t_mod(const uint64_t* q, size_t L, uint64_t t, uint64_t p) {
+    uint64_t limbs[16] = {1};
+    size_t used = 1;
+    for (size_t i = 0; i < L; ++i) {
+        uint64_t carry = 0;
+        for (size_t w = 0; w < used; ++w) {
+            u128 v = (u128)limbs[w] * q[i] + carry;
+            limbs[w] = (uint64_t)v;
+            carry = (uint64_t)(v >> 64);
+        }
+        if (carry) limbs[used++] = carry;
+    }
+    uint64_t remainder = 0, residue = 0;
+    for (size_t w = used; w-- > 0;) {
+        u128 v = ((u128)remainder << 64) | limbs[w];
+        uint64_t digit = (uint64_t)(v / t);
+        remainder = (uint64_t)(v % t);
+        residue = (uint64_t)((((u128)residue << 64) | digit) % p);
+    }
+    return residue;
+}
+
+/* Bfv+Encrypt.swift:75-140 plaintextTranslate (Bfv.addAssignCoeff / subAssignCoeff of a Coeff ciphertext and a Coeff
+ * plaintext, Bfv.swift:110-117): c0 +- (floor(Q/t) m + floor((Q mod t) m + (t + 1)/2) / t)) per residue row.
+ * ct [batch][poly_count][L][N] in place, plaintexts [batch][N] with values < t. */
+int orc_bfv_plaintext_translate(const orc_bfv_context* ctx, size_t L, size_t poly_count, uint64_t* ct,
+                                const uint64_t* plaintexts, int subtract, size_t batch) {
+    if (L < 1 || L > ctx->L || poly_count < 1) return ORC_ERR_INVALID_ARGUMENT;
+    const orc_poly_context* qctx = ctx->ciphertext[L];
+    const size_t n = (size_t)ctx->degree, poly = L * n;
+    const uint64_t t = ctx->t, t_threshold = (t + 1) / 2; /* RnsTool.swift:123-125 */
+    uint64_t q_mod_t = 1 % t;                             /* RnsTool.swift:167 */
+    for (size_t i = 0; i < L; ++i) q_mod_t = mul_mod_slow(q_mod_t, qctx->moduli[i] % t, t);
+    for (size_t i = 0; i < L; ++i) {
+        const uint64_t p = qctx->moduli[i];
+        const orc_shoup delta = shoup_init(q_div_t_mod(qctx->moduli, L, t, p), p); /* qDivT, RnsTool.swift:176-182 */
+        for (size_t b = 0; b < batch; ++b) {
+            uint64_t* c0 = ct + b * poly_count * poly + i * n;
+            for (size_t k = 0; k < n; ++k) {
+                const uint64_t m = plaintexts[b * n + k];
+                const uint64_t adjust = (uint64_t)(((u128)q_mod_t * m + t_threshold) / t); /* :92-107 */
+                const uint64_t round_q_times_mt = add_mod(shoup_mul(&delta, m), adjust, p);
+                c0[k] = subtract ? sub_mod(c0[k], round_q_times_mt, p) : add_mod(c0[k], round_q_times_mt, p);
+            }
+        }
+    }
+    return ORC_OK;
+}
+
 /* Bfv.swift:476-505 innerProduct(ciphertexts:plaintexts:) with the lazy accumulator and the
  * maxLazyProductAccumulationCount reduce cadence (Bfv.swift:365-376,496-500). */
 int orc_bfv_inner_product_plain(const orc_bfv_context* ctx, size_t L, size_t poly_count, const uint64_t* cts,

@@ -161,6 +161,9 @@ int orc_bfv_mod_switch_down(const orc_bfv_context* ctx, size_t moduli_count, siz
 /* Bfv.mulAssign(EvalCiphertext, EvalPlaintext) (Bfv.swift:120-129): ct [batch][polys][L][N] *= pt [batch][L][N] */
 int orc_bfv_mul_plain(const orc_bfv_context* ctx, size_t moduli_count, size_t poly_count, uint64_t* ct,
                       const uint64_t* pt, size_t batch);
+/* Bfv+Encrypt.swift:75-140 plaintextTranslate: ct [batch][poly_count][L][N] (Coeff) +-= plaintexts [batch][N] (< t) */
+int orc_bfv_plaintext_translate(const orc_bfv_context* ctx, size_t moduli_count, size_t poly_count, uint64_t* ct,
+                                const uint64_t* plaintexts, int subtract, size_t batch);
 /* Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv.swift:476-505): cts [count][polys][L][N], pts [count][L][N],
  * present[count] (0 = nil plaintext) -> out [polys][L][N] */
 int orc_bfv_inner_product_plain(const orc_bfv_context* ctx, size_t moduli_count, size_t poly_count,

@@ -718,6 +718,38 @@ int he_bfv_mul_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, ui
 
 extern "C++" {
 namespace {
+// Bfv.addAssignCoeff / subAssignCoeff(_: inout CoeffCiphertext, _: CoeffPlaintext) (Bfv/Bfv.swift:110-117) =
+// plaintextTranslate (Bfv/Bfv+Encrypt.swift:75-140)
+template <typename W>
+int plaintext_translate(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t poly_count, W* ct, const W* plaintexts,
+                        bool subtract, size_t batch, he_stream s) {
+    if (poly_count == 0) return invalid_argument("a ciphertext has at least one polynomial");
+    if (batch == 0) return HE_OK;
+    if (ct == nullptr || plaintexts == nullptr) return invalid_argument("null operand");
+    (void)ctx;
+    HEAMD_HIP_TRY(heamd::launch_plaintext_translate(ct, plaintexts, tool->device, poly_count, subtract, batch, as_stream(s)));
+    return HE_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int he_bfv_add_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* plaintexts, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    const int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    return plaintext_translate(ctx, tool, poly_count, ct, plaintexts, false, batch, s);
+}
+int he_bfv_sub_plain_device(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint64_t* ct,
+                            const uint64_t* plaintexts, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    const int status = check_level(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    return plaintext_translate(ctx, tool, poly_count, ct, plaintexts, true, batch, s);
+}
+
+extern "C++" {
+namespace {
 // Bfv.innerProduct(ciphertexts:plaintexts:) (Bfv/Bfv.swift:476-505) with the nil-plaintext mask resident on the device
 template <typename W>
 int inner_product_plain(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, const W* cts, const W* pts,
@@ -1043,6 +1075,21 @@ int he_bfv_mul_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count
     const PolyContext* pc = ctx->impl->ciphertext(moduli_count);
     HEAMD_HIP_TRY(heamd::launch_mul_plain32(ct, pt, pc->device_context(), poly_count, batch, as_stream(s)));
     return HE_OK;
+}
+
+int he_bfv_add_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* plaintexts, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    const int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    return plaintext_translate(ctx, tool, poly_count, ct, plaintexts, false, batch, s);
+}
+int he_bfv_sub_plain_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count, uint32_t* ct,
+                                const uint32_t* plaintexts, size_t batch, he_stream s) {
+    const RnsToolLevel* tool = nullptr;
+    const int status = check_level_u32(ctx, moduli_count, &tool);
+    if (status != HE_OK) return status;
+    return plaintext_translate(ctx, tool, poly_count, ct, plaintexts, true, batch, s);
 }
 
 int he_bfv_inner_product_plain_resident_device_u32(const he_bfv_context* ctx, uint32_t moduli_count, uint32_t poly_count,

@@ -208,6 +208,7 @@ int BfvContext::build_tool(uint32_t k) {
     const size_t o_tg_moduli = arena.reserve<DeviceModulus>(2);
     const size_t o_neg_inv_q_tg = arena.reserve<U64x2>(2);
     const size_t o_alpha_modulus = arena.reserve<DeviceModulus>(1);
+    const size_t o_q_div_t = arena.reserve<U64x2>(L);
 
     for (size_t i = 0; i < L; ++i) arena.at<DeviceModulus>(o_q_moduli)[i] = barrett_constants(q[i]);
     for (size_t j = 0; j < L + 2; ++j) arena.at<DeviceModulus>(o_ext_moduli)[j] = barrett_constants(ext[j]);
@@ -290,8 +291,18 @@ int BfvContext::build_tool(uint32_t k) {
         arena.at<U64x2>(o_sr_scale)[i] = shoup_pair(mul_mod(gamma_t, arena.at<U64x2>(o_inv_punct_q)[i].x, q[i]), q[i]);
     }
 
+    // plaintextTranslate (RnsTool.swift:167-182): Q = t floor(Q/t) + (Q mod t) and Q = 0 mod q_i, hence
+    // floor(Q/t) = -(Q mod t) t^-1 (mod q_i) -- no composed Q needed (the oracle divides the composed integer instead)
+    const u64 q_mod_t = product_mod(q, L, t_);
+    for (size_t i = 0; i < L; ++i) {
+        u64 inverse = 0;
+        if (!inverse_mod(t_ % q[i], q[i], inverse)) return HE_ERR_NOT_INVERTIBLE;
+        arena.at<U64x2>(o_q_div_t)[i] = shoup_pair(neg_mod(mul_mod(q_mod_t % q[i], inverse, q[i]), q[i]), q[i]);
+    }
+
     RnsToolDevice& d = level.device;
     d.L = static_cast<uint32_t>(L);
+    d.q_mod_t = q_mod_t;
     d.inv_gamma_mod_t = inv_gamma_mod_t;
     d.mtilde = mtilde_;
     {
@@ -334,6 +345,7 @@ int BfvContext::build_tool(uint32_t k) {
     d.t_gamma = reinterpret_cast<const DeviceModulus*>(base + o_tg_moduli);
     d.neg_inv_q_mod_t_gamma = reinterpret_cast<const U64x2*>(base + o_neg_inv_q_tg);
     d.alpha_modulus = reinterpret_cast<const DeviceModulus*>(base + o_alpha_modulus);
+    d.q_div_t = reinterpret_cast<const U64x2*>(base + o_q_div_t);
     return HE_OK;
 }
 

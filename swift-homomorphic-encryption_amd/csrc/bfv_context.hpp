@@ -43,6 +43,9 @@ struct RnsToolDevice {
     const DeviceModulus* t_gamma;      // [2]     Barrett constants of t and gamma
     const U64x2* neg_inv_q_mod_t_gamma;// [2]     -(Q^-1) mod t, mod gamma                          RnsTool.swift:157-160
     uint64_t inv_gamma_mod_t;          //         gamma^-1 mod t                                    RnsTool.swift:150-153
+    // plaintextTranslate (Bfv+Encrypt.swift:75-140)
+    const U64x2* q_div_t;              // [L]     floor(Q / t) mod q_i                              RnsTool.swift:170-182
+    uint64_t q_mod_t;                  //         Q mod t                                           RnsTool.swift:167
     uint64_t mtilde;                   //         T.mTilde: 2^32 (UInt64) or 2^16 (UInt32)          MA/Scalar.swift:508-525
     uint32_t floor_merge_ok;           //         (L + 1) (Bsk_max - 1) (q_max - 1) < 2^127: the alpha correction of the Bsk -> Q
                                        //         conversion may join that row's product sum (one reduction for both)

@@ -268,6 +268,42 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// ---- plaintextTranslate: c0 +-= floor(Q/t) m + floor(((Q mod t) m + (t+1)/2) / t)      Bfv+Encrypt.swift:75-140 ----
+// ct [batch][polys][L][N] Coeff (only c0 is touched), plaintexts [batch][N] with values < t.  The rounding term is the
+// same for every residue row: its 128-bit dividend is divided by t with the double-word Barrett estimate (one below
+// the quotient at worst) and one fix-up.
+template <int L, typename W, bool SUBTRACT>
+__global__ void __launch_bounds__(kThreads)
+    plaintext_translate_kernel(W* __restrict__ ct, const W* __restrict__ plaintexts, const RnsToolDevice tool,
+                               size_t ct_words, size_t batch) {
+    using A = WordArith<W>;
+    const uint32_t logn = tool.log_degree;
+    const size_t n = size_t(1) << logn;
+    const size_t total = batch << logn;
+    const size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x;
+    if (idx >= total) return;
+    const size_t item = idx >> logn, k = idx & (n - 1);
+    const uint64_t m = stream_load(plaintexts + idx);
+    const DeviceModulus t = tool.t_gamma[0];
+    U128 x = mul_wide(tool.q_mod_t, m);  // < t^2                                                   :92-107
+    const uint64_t threshold = (t.p + 1) >> 1;  // RnsTool.swift:123-125
+    x.lo += threshold;
+    x.hi += x.lo < threshold ? 1 : 0;
+    const uint64_t ll_hi = mulhi64(x.lo, t.barrett128_lo);
+    const U128 lh = mul_wide(x.lo, t.barrett128_hi), hl = mul_wide(x.hi, t.barrett128_lo);
+    const uint64_t mid = ll_hi + lh.lo, mid2 = mid + hl.lo;
+    const uint64_t estimate = lh.hi + hl.hi + (mid < ll_hi ? 1 : 0) + (mid2 < mid ? 1 : 0) + x.hi * t.barrett128_hi;
+    const uint64_t adjust = estimate + ((x.lo - estimate * t.p) >= t.p ? 1 : 0);  // the quotient is below t: one word
+    W* c0 = ct + item * ct_words + k;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint64_t p = tool.q_moduli[i].p;
+        const uint64_t round_q_times_mt = add_mod_uniform(A::shoup(m, tool.q_div_t[i], p), adjust, p);   // :117-120
+        const uint64_t c = stream_load(c0 + i * n);
+        stream_store(c0 + i * n, SUBTRACT ? sub_mod_uniform(c, round_q_times_mt, p) : add_mod_uniform(c, round_q_times_mt, p));
+    }
+}
+
 // ---- tensor product: (a0, a1) x (b0, b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1), word-wise in Eval form ----------------
 // in: [items][4][rows][N] (a0, a1, b0, b1); out: [items][3][rows][N]
 // blockIdx.y = item * rows + row: the modulus constants are wave-uniform
@@ -601,6 +637,23 @@ struct FloorLauncher {
 };
 
 template <int L>
+struct PlaintextTranslateLauncher {
+    template <typename W>
+    static hipError_t run(W* ct, const W* plaintexts, const RnsToolDevice& tool, size_t ct_words, bool subtract, size_t batch,
+                          hipStream_t s) {
+        if (((batch << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
+        const dim3 grid(exact_grid(batch << tool.log_degree));
+        if (subtract)
+            hipLaunchKernelGGL((plaintext_translate_kernel<L, W, true>), grid, dim3(kThreads), 0, s, ct, plaintexts, tool,
+                               ct_words, batch);
+        else
+            hipLaunchKernelGGL((plaintext_translate_kernel<L, W, false>), grid, dim3(kThreads), 0, s, ct, plaintexts, tool,
+                               ct_words, batch);
+        return hipGetLastError();
+    }
+};
+
+template <int L>
 struct ScaleAndRoundLauncher {
     template <typename W>
     static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
@@ -621,6 +674,14 @@ hipError_t launch_scale_and_round(const W* in, W* out, const RnsToolDevice& tool
                                   hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     return dispatch_L<ScaleAndRoundLauncher>(tool.L, in, out, tool, final_scale, polys, stream);
+}
+
+template <typename W>
+hipError_t launch_plaintext_translate(W* ct, const W* plaintexts, const RnsToolDevice& tool, uint32_t poly_count,
+                                      bool subtract, size_t batch, hipStream_t stream) {
+    if (batch == 0) return hipSuccess;
+    const size_t ct_words = (size_t(poly_count) * tool.L) << tool.log_degree;
+    return dispatch_L<PlaintextTranslateLauncher>(tool.L, ct, plaintexts, tool, ct_words, subtract, batch, stream);
 }
 
 template <typename W>
@@ -745,6 +806,8 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
 // the two slab word types of the library: Bfv<UInt64> and Bfv<UInt32>
 #define HEAMD_INSTANTIATE_RNS(W)                                                                                          \
     template hipError_t launch_scale_and_round<W>(const W*, W*, const RnsToolDevice&, U64x2, size_t, hipStream_t);        \
+    template hipError_t launch_plaintext_translate<W>(W*, const W*, const RnsToolDevice&, uint32_t, bool, size_t,         \
+                                                      hipStream_t);                                                       \
     template hipError_t launch_lift_q_to_qbsk<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);                \
     template hipError_t launch_lift_q_to_qbsk_strided<W>(const W*, W*, const RnsToolDevice&, size_t, size_t, size_t,      \
                                                          size_t, size_t, hipStream_t);                                    \

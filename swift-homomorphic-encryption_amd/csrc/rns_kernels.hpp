@@ -46,6 +46,10 @@ hipError_t launch_key_switch_mac(const W* spread, const W* key, W* out, const De
 template <typename W>
 hipError_t launch_scale_and_round(const W* in, W* out, const RnsToolDevice& tool, U64x2 final_scale, size_t polys,
                                   hipStream_t stream);
+// Bfv+Encrypt.swift:75-140 plaintextTranslate: ct [batch][poly_count][L][N] (c0 only) +-= plaintexts [batch][N] (< t)
+template <typename W>
+hipError_t launch_plaintext_translate(W* ct, const W* plaintexts, const RnsToolDevice& tool, uint32_t poly_count,
+                                      bool subtract, size_t batch, hipStream_t stream);
 // out[poly][c] = (c < added_polys ? ct[poly][c] : 0) + divideAndRoundQLast(prod[poly][c])
 template <typename W>
 hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,

@@ -111,6 +111,8 @@ SIGNATURES = [
     ("he_bfv_mod_switch_down_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_mod_switch_down_to_single_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_mul_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_add_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_sub_plain_device", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_inner_product_plain_device", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, ctypes.POINTER(ctypes.c_uint8), c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_plain_resident_device", ctypes.c_int,
@@ -135,6 +137,8 @@ SIGNATURES = [
     ("he_bfv_apply_galois_device_u32", ctypes.c_int, [vp, c_u32, vp, c_u64, vp, vp, c_size, vp, c_size, vp]),
     ("he_bfv_mod_switch_down_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_mul_plain_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_add_plain_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
+    ("he_bfv_sub_plain_device_u32", ctypes.c_int, [vp, c_u32, c_u32, vp, vp, c_size, vp]),
     ("he_bfv_inner_product_plain_resident_device_u32", ctypes.c_int,
      [vp, c_u32, c_u32, vp, vp, vp, c_size, c_size, vp, vp]),
     ("he_bfv_inner_product_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, vp, vp, c_size, vp]),
@@ -831,6 +835,15 @@ class BfvContext:
                                                       _stream(stream)))
         return ct
 
+    def add_plain_(self, ct, plaintexts, poly_count=2, subtract=False, moduli_count=None, stream=None):
+        """Bfv.addAssignCoeff / subAssignCoeff(ciphertext, plaintext): ct [batch][polys][L][N] Coeff in place,
+        plaintexts [batch][N] mod t."""
+        L = self._L(moduli_count)
+        batch = plaintexts.numel() // self.degree
+        fn = load_library().he_bfv_sub_plain_device if subtract else load_library().he_bfv_add_plain_device
+        _check(fn(self.h, L, poly_count, _ptr(ct), _ptr(plaintexts), batch, _stream(stream)))
+        return ct
+
     def inner_product_plain(self, cts, pts, present=None, poly_count=2, columns=1, moduli_count=None, stream=None):
         """cts [count][polys][L][N]; pts [columns][count][L][N]; present: host bytes [columns][count] or None."""
         L = self._L(moduli_count)
@@ -992,6 +1005,13 @@ class BfvContext32(BfvContext):
         batch = pt.numel() // (L * self.degree)
         _check(load_library().he_bfv_mul_plain_device_u32(self.h, L, poly_count, _ptr32(ct), _ptr32(pt), batch,
                                                           _stream(stream)))
+        return ct
+
+    def add_plain_(self, ct, plaintexts, poly_count=2, subtract=False, moduli_count=None, stream=None):
+        L = self._L(moduli_count)
+        batch = plaintexts.numel() // self.degree
+        fn = load_library().he_bfv_sub_plain_device_u32 if subtract else load_library().he_bfv_add_plain_device_u32
+        _check(fn(self.h, L, poly_count, _ptr32(ct), _ptr32(plaintexts), batch, _stream(stream)))
         return ct
 
     def inner_product_plain_resident(self, cts, pts, present_device=None, poly_count=2, columns=1, moduli_count=None,

@@ -5,6 +5,7 @@
 //   relinearize              Bfv/Bfv.swift:201-219, Bfv/Bfv+Keys.swift:123-208
 //   modSwitchDown            Bfv/Bfv.swift:163-171
 //   innerProduct(cts, pts)   Bfv/Bfv.swift:476-505
+//   addAssignCoeff / subAssignCoeff(ct, pt)   Bfv/Bfv.swift:110-117, Bfv/Bfv+Encrypt.swift:75-140
 import CHeAmd
 import HomomorphicEncryption
 
@@ -84,6 +85,18 @@ extension Bfv where T == UInt64 {
     {
         try heAmdCheck(he_bfv_mod_switch_down_device(context.gpu, UInt32(moduliCount), UInt32(polyCount), input.pointer,
                                                      output.pointer, batch, stream.raw))
+    }
+
+    /// `Bfv.addAssignCoeff` / `subAssignCoeff(_: inout CoeffCiphertext, _: CoeffPlaintext)` (Bfv.swift:110-117) on
+    /// resident ciphertexts: ciphertexts [batch][polyCount][L][N] Coeff in place, plaintexts [batch][N] (values < t).
+    /// The caller checks `correctionFactor == 1` and the contexts (Bfv+Encrypt.swift:80-83) before the call.
+    public static func gpuTranslate(context: Context<Bfv<UInt64>>, moduliCount: Int, polyCount: Int,
+                                    ciphertexts: DeviceBuffer, plaintexts: DeviceBuffer, subtract: Bool, batch: Int,
+                                    on stream: HeAmdStream) throws
+    {
+        let translate = subtract ? he_bfv_sub_plain_device : he_bfv_add_plain_device
+        try heAmdCheck(translate(context.gpu, UInt32(moduliCount), UInt32(polyCount), ciphertexts.pointer,
+                                 plaintexts.pointer, batch, stream.raw))
     }
 
     /// `Bfv.innerProduct(ciphertexts:plaintexts:)` (Bfv.swift:476-505) for `columns` outputs that share the ciphertext

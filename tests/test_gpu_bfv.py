@@ -172,6 +172,42 @@ def test_mul_plain_and_inner_product_plain(oracle, small):
     assert np.array_equal(heamd.to_host(ct), ref.mul_plain(cts[:3], pts[0, :3], 2))
 
 
+@pytest.mark.parametrize("t_bits", [17, 41, 60])  # t^2 below 2^64, above it, and t next to the 62-bit moduli
+def test_add_and_sub_plain_match_oracle(oracle, t_bits):
+    """Bfv.addAssignCoeff / subAssignCoeff(ciphertext, plaintext) (Bfv.swift:110-117, Bfv+Encrypt.swift:75-140): words
+    against the oracle at every level, two- and three-polynomial ciphertexts, extreme messages; decrypts to the sum."""
+    degree = 256
+    t = oracle.generate_primes([t_bits], True, degree)[0]
+    q = oracle.generate_primes([62, 61, 62, 62], False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    client = BfvClient(oracle, ref, seed=t_bits)
+    rng = np.random.default_rng(400 + t_bits)
+    for level in (None, 2, 1):
+        moduli = ref.ciphertext_context(level).moduli
+        for polys in (2, 3):
+            ct = _uniform(rng, (5, polys), moduli, degree)
+            messages = rng.integers(0, t, size=(5, degree), dtype=np.uint64)
+            messages[0, :] = t - 1
+            messages[1, :] = 0
+            messages[2, ::2] = 1
+            for subtract in (False, True):
+                got = heamd.to_host(ours.add_plain_(heamd.to_device(ct), heamd.to_device(messages), polys, subtract,
+                                                    moduli_count=level))
+                assert np.array_equal(got, ref.plaintext_translate(ct, messages, polys, subtract, moduli_count=level)), (
+                    level, polys, subtract)
+    if t_bits < 60:  # (a 60-bit t leaves no room for noise under these moduli's product at level 1)
+        m1 = [int(v) for v in rng.integers(0, t, size=degree)]
+        m2 = [int(v) for v in rng.integers(0, t, size=degree)]
+        fresh = heamd.to_device(client.encrypt(m1)[None])
+        ours.add_plain_(fresh, heamd.to_device(np.array([m2], dtype=np.uint64)), 2)
+        assert client.decrypt(heamd.to_host(fresh)[0]) == [(a + b) % t for a, b in zip(m1, m2)]
+        ours.add_plain_(fresh, heamd.to_device(np.array([m1], dtype=np.uint64)), 2, subtract=True)
+        assert client.decrypt(heamd.to_host(fresh)[0]) == m2
+    with pytest.raises(heamd.HeError):
+        ours.add_plain_(heamd.to_device(_uniform(rng, (1, 2), q[:1], degree)), heamd.to_device(np.zeros((1, degree), dtype=np.uint64)),
+                        2, moduli_count=ours.L + 1)
+
+
 def test_inner_product_ct_ct(oracle, small):
     ours, ref, client = small
     rng = random.Random(90)
@@ -657,6 +693,13 @@ def test_bfv_uint32_packed_slabs_match_oracle(oracle):
     assert client.decrypt(host(lower)[0], moduli_count=ours.L - 1) == negacyclic_multiply(m1, m2, t)
     assert np.array_equal(host(ours.mul(lower, lower, moduli_count=ours.L - 1)),
                           ref.mul(expected_lower, expected_lower, moduli_count=ours.L - 1))
+    # ciphertext +- plaintext (Bfv.swift:110-117)
+    messages = np.array([m2, [t - 1] * degree], dtype=np.uint64)
+    for subtract in (False, True):
+        assert np.array_equal(host(ours.add_plain_(dev(ct1), dev(messages), 2, subtract)),
+                              ref.plaintext_translate(ct1, messages, 2, subtract))
+    summed = host(ours.add_plain_(dev(ct1), dev(messages[:1]), 2))
+    assert client.decrypt(summed[0]) == [(a + b) % t for a, b in zip(m1, m2)]
     # plaintexts and ct x pt
     pts = np.array([[r.randrange(t) for _ in range(degree)] for _ in range(3)], dtype=np.uint64)
     pt_eval = ours.plaintext_to_eval(dev(pts))

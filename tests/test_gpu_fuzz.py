@@ -56,6 +56,11 @@ def test_random_parameter_shapes(oracle, seed):
         cts = _uniform(rng, (2, 2), moduli, degree)
         rotated = heamd.to_host(ours.apply_galois(heamd.to_device(cts), element, heamd.to_device(key)))
         assert np.array_equal(rotated, ref.apply_galois(cts, element, key)), (label, element)
+        # Bfv.addAssignCoeff / subAssignCoeff(ciphertext, plaintext)
+        messages = rng.integers(0, t, size=(2, degree), dtype=np.uint64)
+        subtract = bool(rnd.getrandbits(1))
+        translated = heamd.to_host(ours.add_plain_(heamd.to_device(cts), heamd.to_device(messages), 2, subtract))
+        assert np.array_equal(translated, ref.plaintext_translate(cts, messages, 2, subtract)), (label, subtract)
         # Bfv.innerProduct(ciphertexts:plaintexts:) with nil plaintexts, for 1..4 queries side by side
         queries = rnd.choice([1, 2, 3, 4])
         count, columns = rnd.randint(1, 70), rnd.randint(1, 9)
@@ -215,6 +220,13 @@ def test_random_uint32_shapes(oracle, seed):
         assert np.array_equal(relin, ref.relinearize(product, key)), label
         element = 2 * rnd.randrange(1, degree) + 1
         assert np.array_equal(host(ours.apply_galois(dev(lhs), element, dev(key))), ref.apply_galois(lhs, element, key)), label
+        if L >= 2:
+            assert np.array_equal(host(ours.mod_switch_down(dev(lhs), 2)), ref.mod_switch_down(lhs, poly_count=2)), label
+        messages = rng.integers(0, t, size=(2, degree), dtype=np.uint64)
+        subtract = bool(rnd.getrandbits(1))
+        assert np.array_equal(host(ours.add_plain_(dev(lhs), dev(messages), 2, subtract)),
+                              ref.plaintext_translate(lhs, messages, 2, subtract)), (label, subtract)
+        count, columns = rnd.randint(1, 30), rnd.randint(1, 6)
         if L >= 2:
             assert np.array_equal(host(ours.mod_switch_down(dev(lhs), 2)), ref.mod_switch_down(lhs, poly_count=2)), label
         count, columns = rnd.randint(1, 30), rnd.randint(1, 6)

@@ -387,6 +387,40 @@ def test_pir_expand_produces_encrypted_selection_bits(oracle, small_bfv, total, 
         assert client.decrypt(expanded[index]) == want, index
 
 
+@pytest.mark.parametrize("t_bits", [17, 41])  # t^2 below / above 2^64: both division branches of Bfv+Encrypt.swift:92-107
+def test_plaintext_translate_is_the_rounded_scaling_and_decrypts_to_the_sum(oracle, t_bits):
+    """Bfv.addAssignCoeff / subAssignCoeff(ciphertext, plaintext) (Bfv.swift:110-117, Bfv+Encrypt.swift:75-140) against
+    arbitrary-precision integers: c0 +- (floor(Q/t) m + floor(((Q mod t) m + (t + 1) // 2) / t)) mod q_i."""
+    degree = 32
+    t = oracle.generate_primes([t_bits], True, degree)[0]
+    q = oracle.generate_primes([50, 50, 50, 51], False, degree)
+    ctx = oracle.BfvContext(degree, t, q)
+    client = BfvClient(oracle, ctx, seed=t_bits)
+    rng = random.Random(50 + t_bits)
+    for level in (None, 2, 1):
+        moduli = ctx.ciphertext_context(level).moduli
+        big_q = _prod(moduli)
+        m1 = [rng.randrange(t) for _ in range(degree)]
+        m2 = [rng.choice((0, 1, t - 1, rng.randrange(t))) for _ in range(degree)]
+        ct = np.stack([client.encrypt(m1, level), client.encrypt(m1, level)])
+        pts = np.array([m2, m1], dtype=np.uint64)
+        for subtract in (False, True):
+            got = ctx.plaintext_translate(ct, pts, 2, subtract, moduli_count=level)
+            for b in range(2):
+                for i, qi in enumerate(moduli):
+                    for k in range(degree):
+                        m = int(pts[b, k])
+                        term = ((big_q // t) * m + ((big_q % t) * m + (t + 1) // 2) // t) % qi
+                        expected = (int(ct[b, 0, i, k]) + (-term if subtract else term)) % qi
+                        assert int(got[b, 0, i, k]) == expected
+                assert np.array_equal(got[b, 1], ct[b, 1])  # c1 untouched
+            sign = -1 if subtract else 1
+            assert client.decrypt(got[0], level) == [(a + sign * b) % t for a, b in zip(m1, m2)]
+    # encrypt is a zero encryption translated by the message (Bfv+Encrypt.swift:66-73)
+    zero = client.encrypt([0] * degree)
+    assert client.decrypt(ctx.plaintext_translate(zero[None], np.array([m1], dtype=np.uint64))[0]) == m1
+
+
 @pytest.fixture(scope="module")
 def small_bfv32(oracle):
     """Context<Bfv<UInt32>>-shaped parameters: 27-28-bit moduli as in n_4096_logq_27_28_28
