@@ -141,11 +141,38 @@ int tensor_and_inverse(const RnsToolLevel& tool, uint32_t* lifted, uint32_t* ten
     return HE_OK;
 }
 
+// computeBehzPolys (Bfv+Multiply.swift:51-57) for `items` pairs of two-polynomial ciphertexts: lift each of the four
+// polynomials into lifted[item][0..3] (lhs -> slots 0, 1; rhs -> slots 2, 3), then forward NTT over [Q, Bsk].  Rows
+// [0, L) of a lifted polynomial are the input itself (RnsTool.swift:329-330): where the tiled transform can read them
+// from the ciphertexts, the lift does not write the copy.
+hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs,
+                              const uint64_t* rhs, uint64_t* lifted, size_t items, hipStream_t stream) {
+    const DeviceContext qbsk = tool.qbsk->device_context();
+    const uint32_t rows = 2 * L + 1;
+    const bool from_source = heamd::ntt_lifted_forward_supported(qbsk, rows, L, items * 4);
+    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream,
+                                                        !from_source);
+    if (e != hipSuccess) return e;
+    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream,
+                                             !from_source);
+    if (e != hipSuccess) return e;
+    if (from_source) return heamd::launch_ntt_lifted_forward(lifted, qbsk, rows, items * 4, lhs, rhs, 2 * L * n, L, stream);
+    return ntt_records(false, lifted, *tool.qbsk, qbsk, rows, items * 4, stream);
+}
+hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint32_t* lhs,
+                              const uint32_t* rhs, uint32_t* lifted, size_t items, hipStream_t stream) {
+    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream);
+    if (e != hipSuccess) return e;
+    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream);
+    if (e != hipSuccess) return e;
+    return ntt_records(false, lifted, *tool.qbsk, tool.qbsk->device_context(), 2 * L + 1, items * 4, stream);
+}
+
 // Bfv.mulAssign(ct, ct) (Bfv/Bfv+Multiply.swift:18-85) on slabs of W
 template <typename W>
 int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L, const W* lhs, const W* rhs, W* out,
                  size_t batch, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), rows = 2 * L + 1;
+    const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L);
     Scratch scratch(stream);
     uint64_t* raw = nullptr;
     int status = resolve_workspace(workspace, workspace_bytes, batch * 7 * ext * sizeof(W), scratch, &raw);
@@ -153,13 +180,7 @@ int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L
     W* ws = reinterpret_cast<W*>(raw);
     W* lifted = ws;                   // [batch][4][2L+1][N]  (a0, a1, b0, b1)
     W* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
-    // computeBehzPolys (Bfv+Multiply.swift:51-57): lift each of the four polynomials, then forward NTT.  Two strided
-    // launches (lhs polys -> slots 0,1; rhs polys -> slots 2,3) so that item b owns lifted[b][0..3].
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 0, stream));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, batch, 2, 2 * L * n, 4 * ext, 2 * ext,
-                                                       stream));
-    const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(ntt_records(false, lifted, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), batch * 4, stream));
+    HEAMD_HIP_TRY(lift_pairs_to_eval(*tool, L, n, ext, lhs, rhs, lifted, batch, stream));
     bool in_coeff_form = false;
     status = tensor_and_inverse(*tool, lifted, tensor, batch, stream, &in_coeff_form);
     if (status != HE_OK) return status;
@@ -910,11 +931,8 @@ int inner_product_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, 
     if (status != HE_OK) return status;
     W* lifted = reinterpret_cast<W*>(raw);   // [count][4][2L+1][N]
     W* sum = lifted + count * 4 * ext;       // [3][2L+1][N]
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 0, stream));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool->device, count, 2, 2 * L * n, 4 * ext, 2 * ext,
-                                                       stream));
+    HEAMD_HIP_TRY(lift_pairs_to_eval(*tool, L, n, ext, lhs, rhs, lifted, count, stream));
     const DeviceContext qbsk = tool->qbsk->device_context();
-    HEAMD_HIP_TRY(ntt_records(false, lifted, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), count * 4, stream));
     // maxProductCount = maxLazyProductAccumulationCount() / 2 because poly1 takes two products per pair (Bfv.swift:339)
     const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
     HEAMD_HIP_TRY(heamd::launch_tensor_accumulate(static_cast<const W*>(lifted), sum, qbsk, count, max_lazy ? max_lazy : 1,

@@ -38,6 +38,14 @@ hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulu
 // the fold-free butterflies and the rest on the [0, 8p) ones (the [Q, Bsk] slabs of BEHZ multiplication)
 hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
                             hipStream_t stream);
+// Forward NTT of lifted [Q, Bsk] records [records][record_rows][N] whose first source_moduli rows were left unwritten by
+// the lift: they are read from the source polynomials -- record = item * 4 + slot from polynomial slot & 1 of item
+// `item` of `base` (slots 0, 1) or `second` (slots 2, 3), items `stride` words apart; second == nullptr: record r from
+// base + r * stride.  hipErrorNotSupported (ntt_lifted_forward_supported false): lift with the copy, launch_ntt_mixed.
+bool ntt_lifted_forward_supported(const DeviceContext& ctx, uint32_t record_rows, uint32_t source_moduli, size_t records);
+hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
+                                     const uint64_t* base, const uint64_t* second, size_t stride, uint32_t source_moduli,
+                                     hipStream_t stream);
 hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, const DeviceContext& ctx, uint32_t record_rows,
                                      size_t items, hipStream_t stream);
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,

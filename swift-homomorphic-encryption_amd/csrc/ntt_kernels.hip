@@ -113,7 +113,13 @@ __device__ __forceinline__ void locate_rows(const RowMap& map, uint32_t block, s
 //   kSourceLift    Plaintext.convertToEvalFormat (Plaintext.swift:149-170): output row (poly, r) of a [polys][L][N]
 //                  slab is the transform mod q_r of the centred lift of plaintext `poly` ([N] values < t):
 //                  x < (t + 1) / 2 ? x : x + (q_r - t).
-constexpr int kSourceSlab = 0, kSourceSpread = 1, kSourceLift = 2;
+//   kSourceRows    the Q band of BEHZ's [Q, Bsk] records (Bfv+Multiply.swift:51-57): liftQToQBsk leaves rows [0, L) of
+//                  a lifted polynomial equal to the input (RnsTool.swift:329-330), so row (record, r) of the band is
+//                  the transform of row r of the record's source polynomial, read where the ciphertext lies instead
+//                  of from a copy the lift would write: record = item * 4 + slot takes polynomial slot & 1 of item
+//                  `item` of `base` (slots 0, 1) or `second` (slots 2, 3), items `stride` words apart; without a
+//                  second operand, record r takes the polynomial at base + r * stride.
+constexpr int kSourceSlab = 0, kSourceSpread = 1, kSourceLift = 2, kSourceRows = 3;
 struct SpreadSource {
     const uint64_t* base;  // row j of polynomial `poly` at base + poly * stride + j * N
     size_t stride;
@@ -122,6 +128,7 @@ struct SpreadSource {
     // kSourceSpread only: g^-1 mod 2N when the source polynomial is to be taken through f(x) -> f(x^g) first
     // (PolyRq/Galois.swift:115-143), 0 otherwise
     uint32_t galois_inverse;
+    const uint64_t* second;  // kSourceRows only: the operand of slots 2, 3 (nullptr: one operand, consecutive polynomials)
 };
 
 constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
@@ -234,7 +241,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
-    if constexpr (SPREAD != kSourceSlab) {
+    if constexpr (SPREAD != kSourceSlab && SPREAD != kSourceRows) {
         // the band_rows output rows of a record are transforms of one source row: one replica set per group of ROWS
         // consecutive records (a workgroup transforms the same band row of each of them)
         uint32_t group;
@@ -260,7 +267,21 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         constexpr int LO0 = LOGN - LOGE;
-        if constexpr (SPREAD != kSourceSlab) {
+        if constexpr (SPREAD == kSourceRows) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const size_t rec = record + k;
+                const uint64_t* source;
+                if (spread.second == nullptr) {
+                    source = spread.base + rec * spread.stride + (static_cast<size_t>(within) << LOGN);
+                } else {
+                    const size_t item = rec >> 2, slot = rec & 3;
+                    source = ((slot & 2) != 0 ? spread.second : spread.base) + item * spread.stride +
+                             (((slot & 1) * spread.L + within) << LOGN);
+                }
+                global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(source, 8u << LOGN));
+            }
+        } else if constexpr (SPREAD != kSourceSlab) {
             bool reduce[ROWS];  // uniform: the source row is canonical mod a larger modulus than this row's
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
@@ -746,6 +767,10 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
     }
 }
 
+// a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way: one
+// launch in the mode that serves every modulus costs one kernel latency instead of two
+constexpr size_t kOneGeneration = 512;
+
 // [Q, Bsk] records (BEHZ): the first `headroom_prefix` moduli (the ciphertext moduli, when they are the usual <= 55-bit
 // primes) take the fold-free split butterflies, the 61-bit Bsk primes the [0, 8p) ones -- two launches over row bands of
 // the same slab.  Falls back to one launch when the context has no such prefix or no tiled kernel.
@@ -753,9 +778,6 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
                             hipStream_t stream) {
     const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
     const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
-    // a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way:
-    // one launch in the mode that serves every modulus costs one kernel latency instead of two
-    constexpr size_t kOneGeneration = 512;
     if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr ||
         records * record_rows > (size_t(1) << 30) || records * record_rows <= kOneGeneration)
         return launch_ntt(inverse, slab, ctx, 0, record_rows, records * record_rows, stream);
@@ -763,6 +785,35 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
     if (e != hipSuccess) return e;
     return launch_ntt_band(inverse, slab, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox,
                            stream);
+}
+
+// Forward NTT of lifted [Q, Bsk] records whose Q rows are still where the ciphertexts lie (the lift was told not to copy
+// them, rns_kernels launch_lift_q_to_qbsk_strided): the Q band is read from the source polynomials (kSourceRows) and
+// written into the slab, the Bsk band is transformed in place.  hipErrorNotSupported when the context has no fold-free
+// prefix of exactly source_moduli rows or no tiled kernel -- the caller then lifts with the copy and runs
+// launch_ntt_mixed.
+bool ntt_lifted_forward_supported(const DeviceContext& ctx, uint32_t record_rows, uint32_t source_moduli, size_t records) {
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    return tiled && source_moduli != 0 && source_moduli < record_rows && ctx.headroom_prefix == source_moduli &&
+           ctx.approx_ok != 0 && ctx.forward_split_pairs != nullptr && records * record_rows > kOneGeneration &&
+           records * record_rows <= (size_t(1) << 30);
+}
+hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
+                                     const uint64_t* base, const uint64_t* second, size_t stride, uint32_t source_moduli,
+                                     hipStream_t stream) {
+    if (records == 0) return hipSuccess;
+    if (!ntt_lifted_forward_supported(ctx, record_rows, source_moduli, records)) return hipErrorNotSupported;
+    const SpreadSource src{base, stride, source_moduli, 0, 0, second};
+    const size_t rows = records * source_moduli;
+    hipError_t e;
+    switch (ctx.log_degree) {
+        case 12: e = launch_forward_tiled<12, 9, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
+        case 13: e = launch_forward_tiled<13, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
+        default: e = launch_forward_tiled<14, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
+    }
+    if (e != hipSuccess) return e;
+    return launch_ntt_band(false, slab, ctx, source_moduli, record_rows - source_moduli, record_rows, source_moduli, records,
+                           kModeApprox, stream);
 }
 
 // Tensor product + inverse NTT of BEHZ multiplication in one kernel per row band: lifted [items][4][record_rows][N]

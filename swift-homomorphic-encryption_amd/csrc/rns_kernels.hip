@@ -109,6 +109,7 @@ struct WordArith<uint32_t> {
 // per-item record.
 struct LiftLayout {
     size_t polys_per_item, in_item_stride, out_item_stride;
+    uint32_t store_input;  // 0: rows [0, L) of the output are left to the transform that follows (it reads the input itself)
 };
 
 // W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int i = 0; i < L; ++i) {
             const uint64_t x = stream_load(src + i * n);
-            stream_store(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
+            if (layout.store_input != 0) stream_store(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
             y[i] = A::shoup(x, tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
@@ -688,16 +689,16 @@ template <typename W>
 hipError_t launch_lift_q_to_qbsk(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const size_t n = size_t(1) << tool.log_degree;
-    const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n};
+    const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n, 1};
     return dispatch_L<LiftLauncher>(tool.L, in, out, tool, polys, layout, stream);
 }
 
 template <typename W>
 hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevice& tool, size_t items,
                                          size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
-                                         size_t out_offset, hipStream_t stream) {
+                                         size_t out_offset, hipStream_t stream, bool store_input) {
     if (items == 0 || polys_per_item == 0) return hipSuccess;
-    const LiftLayout layout{polys_per_item, in_item_stride, out_item_stride};
+    const LiftLayout layout{polys_per_item, in_item_stride, out_item_stride, store_input ? 1u : 0u};
     return dispatch_L<LiftLauncher>(tool.L, in, out + out_offset, tool, items * polys_per_item, layout, stream);
 }
 
@@ -810,7 +811,7 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
                                                       hipStream_t);                                                       \
     template hipError_t launch_lift_q_to_qbsk<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);                \
     template hipError_t launch_lift_q_to_qbsk_strided<W>(const W*, W*, const RnsToolDevice&, size_t, size_t, size_t,      \
-                                                         size_t, size_t, hipStream_t);                                    \
+                                                         size_t, size_t, hipStream_t, bool);                              \
     template hipError_t launch_floor_qbsk_to_q<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);               \
     template hipError_t launch_tensor<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);                        \
     template hipError_t launch_tensor_accumulate<W>(const W*, W*, const DeviceContext&, size_t, uint64_t, hipStream_t);   \
