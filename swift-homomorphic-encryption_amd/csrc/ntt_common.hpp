@@ -212,8 +212,11 @@ __device__ __forceinline__ uint64_t divide_by_degree(uint64_t x, uint64_t p) {
 struct LazyReducer {
     uint64_t neg_p;
     float scale;
+    // the modulus is wave-uniform: the quotient scale is computed once per wave and parked in an SGPR
     __device__ __forceinline__ explicit LazyReducer(uint64_t modulus)
-        : neg_p(0 - modulus), scale((4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus)) {}
+        : neg_p(0 - modulus),
+          scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+              int, (4294967296.0f * (1.0f - 1.0f / 262144.0f)) / static_cast<float>(modulus))))) {}
     // [0, 2p)
     __device__ __forceinline__ uint64_t lazy(uint64_t x) const {
         float high;  // asm: hipcc otherwise converts through its generic 64-bit path (7 instructions)
