@@ -547,6 +547,82 @@ __device__ __forceinline__ void global_store(const uint64_t (&v)[1 << LOGE], uin
     }
 }
 
+// Store of the last forward pass (bits [0, W), W >= 2) in full cache lines.  A lane ends the transform with runs of 2^W
+// contiguous words (32 or 64 B): stored as they lie, every 16-byte store instruction puts a quarter or a half of 64
+// different lines (N = 4096: 0.331 ms per launch against 0.289 ms with whole lines, N = 16384: 0.358 against 0.326,
+// profiles/r02zd_store_probe.txt).  The wave's block of 64 2^W words (one per run index) goes through the wave's own
+// slice of the LDS tile instead -- the transpose into this pass never left the wave, so the slice is free -- and comes
+// back as 16-byte chunks in lane order: instruction j stores chunks [64 j, 64 j + 64) of the block, 1 KiB of whole
+// lines.  Chunk j of lane l sits at chunk position l C + (j ^ s(l)), C = 2^(W-1) chunks per lane: the XOR spreads both
+// the writes (lane stride 16 C bytes) and the reads over all banks.
+template <int LOGN, int LOGE, int LO_PREVIOUS, int W>
+constexpr bool kStagedStore = W >= 2 && W <= 3 && kWaveOwnsTopBits<LOGN, LOGE, LO_PREVIOUS> && kWaveOwnsTopBits<LOGN, LOGE, 0>;
+
+template <int LOGN, int LOGE, int W>
+__device__ __forceinline__ void global_store_staged(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row, uint64_t* lds) {
+    constexpr int C = 1 << (W - 1);          // 16-byte chunks per lane and run
+    constexpr int RUNS = 1 << (LOGE - W);    // runs per lane (the extra register bits of a partial pass)
+    const uint32_t lane = tid & 63u;
+    const uint32_t swizzle = (lane >> (4 - (W - 1))) & (C - 1);
+#pragma unroll
+    for (int run = 0; run < RUNS; ++run) {
+        // first element of the wave's block for this run: the lane part of lane 0 of this wave, plus the run's register part
+        const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u) | register_part<LOGN, LOGE, 0, W>(run << W);
+        char* const block = reinterpret_cast<char*>(lds + lds_slot(first));
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+            *reinterpret_cast<U64x2*>(block + ((lane * C + (j ^ swizzle)) << 4)) = U64x2{v[(run << W) + 2 * j], v[(run << W) + 2 * j + 1]};
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+            const uint32_t owner_swizzle = (owner >> (4 - (W - 1))) & (C - 1);
+            const U64x2 pair = *reinterpret_cast<const U64x2*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4));
+            const Dwordx4 words = {lo32(pair.x), hi32(pair.x), lo32(pair.y), hi32(pair.y)};
+            __builtin_amdgcn_raw_buffer_store_b128(words, row, (first << 3) + (lane << 4), j << 10, row_policy<LOGN>());
+        }
+    }
+}
+
+// The mirror image for the first inverse pass: the wave's block is loaded as 16-byte chunks in lane order (whole
+// lines per instruction), parked in the wave's own slice of the tile (nothing else has touched the tile yet, and every
+// wave stores only into its own slice) and picked up as runs of 2^W contiguous words per lane.
+template <int LOGN, int LOGE, int W>
+constexpr bool kStagedLoad = W >= 2 && W <= 3 && kWaveOwnsTopBits<LOGN, LOGE, 0>;
+
+template <int LOGN, int LOGE, int W, int POLICY = row_load_policy<LOGN>()>
+__device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row, uint64_t* lds) {
+    constexpr int C = 1 << (W - 1);
+    constexpr int RUNS = 1 << (LOGE - W);
+    const uint32_t lane = tid & 63u;
+    const uint32_t swizzle = (lane >> (4 - (W - 1))) & (C - 1);
+    Dwordx4 words[RUNS][C];
+#pragma unroll
+    for (int run = 0; run < RUNS; ++run) {
+        const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u) | register_part<LOGN, LOGE, 0, W>(run << W);
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+            words[run][j] = __builtin_amdgcn_raw_buffer_load_b128(row, (first << 3) + (lane << 4), j << 10, POLICY);
+    }
+#pragma unroll
+    for (int run = 0; run < RUNS; ++run) {
+        const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u) | register_part<LOGN, LOGE, 0, W>(run << W);
+        char* const block = reinterpret_cast<char*>(lds + lds_slot(first));
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+            const uint32_t owner_swizzle = (owner >> (4 - (W - 1))) & (C - 1);
+            *reinterpret_cast<U64x2*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4)) =
+                U64x2{pack64(words[run][j].x, words[run][j].y), pack64(words[run][j].z, words[run][j].w)};
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const U64x2 pair = *reinterpret_cast<const U64x2*>(block + ((lane * C + (j ^ swizzle)) << 4));
+            v[(run << W) + 2 * j] = pair.x;
+            v[(run << W) + 2 * j + 1] = pair.y;
+        }
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
     static_assert(MODE == kModeExact || MODE == kModeApprox, "split outputs go through LazyReducer");

@@ -337,8 +337,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         }
         forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, p, lds);
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k)
-            HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
+        for (int k = 0; k < ROWS; ++k) {
+            const BufferResource out = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
+            if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
+                HEAMD_X_STORE((global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds)));
+            } else {
+                HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out)));
+            }
+        }
     }
 }
 
@@ -465,8 +471,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         } else {
             [[maybe_unused]] const uint64_t p = mod.p;
 #pragma unroll
-            for (int k = 0; k < ROWS; ++k)
-                HEAMD_X_LOAD((global_load<LOGN, LOGE, 0, S::R>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
+            for (int k = 0; k < ROWS; ++k) {
+                const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
+                if constexpr (kStagedLoad<LOGN, LOGE, S::R>) {
+                    HEAMD_X_LOAD((global_load_staged<LOGN, LOGE, S::R>(v[k], tid, in, lds)));
+                } else {
+                    HEAMD_X_LOAD((global_load<LOGN, LOGE, 0, S::R>(v[k], tid, in)));
+                }
+            }
         }
         inverse_row<LOGN, LOGE, MODE, ROWS, SCALED>(v, tid, tw, mod, lds);
         constexpr int LOL = LOGN - LOGE;

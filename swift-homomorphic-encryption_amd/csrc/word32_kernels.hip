@@ -33,6 +33,27 @@ __device__ __forceinline__ uint32_t csub32(uint32_t x, uint32_t m) { return x >=
 __device__ __forceinline__ uint32_t shoup32_lazy(uint32_t x, uint32_t w, uint32_t wf, uint32_t p) {
     return x * w - __umulhi(x, wf) * p;
 }
+// The same product on the full-width multiplier for the register passes: q = high word of x wf, then the low word of
+// x w + q (2^32 - p) -- three v_mad_u64_u32 (two issue slots each) against v_mul_hi_u32 (three to four), two
+// v_mul_lo_u32 (two each) and a subtract.  UNIFORM: the twiddle is wave-uniform and read from SGPRs (one scalar operand
+// per instruction); neg_p = 2^32 - p always is.
+template <bool UNIFORM>
+__device__ __forceinline__ uint32_t shoup32_lazy_mad(uint32_t x, uint32_t w, uint32_t wf, uint32_t neg_p) {
+    uint64_t q, t, carry;
+    if constexpr (UNIFORM) {
+        asm("v_mad_u64_u32 %0, %2, %3, %4, 0\n\t"
+            "v_mad_u64_u32 %1, %2, %3, %5, 0"
+            : "=&v"(q), "=&v"(t), "=&s"(carry)
+            : "v"(x), "s"(wf), "s"(w));
+    } else {
+        asm("v_mad_u64_u32 %0, %2, %3, %4, 0\n\t"
+            "v_mad_u64_u32 %1, %2, %3, %5, 0"
+            : "=&v"(q), "=&v"(t), "=&s"(carry)
+            : "v"(x), "v"(wf), "v"(w));
+    }
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(t), "=&s"(carry) : "v"(static_cast<uint32_t>(q >> 32)), "s"(neg_p));
+    return static_cast<uint32_t>(t);
+}
 
 // +1 word per 32: de-conflicts the power-of-two strides of the late forward / early inverse stages
 __device__ __forceinline__ uint32_t slot32(uint32_t idx) { return idx + (idx >> 5); }
@@ -111,7 +132,7 @@ template <int LOGN, int LOGE, int LO, int W>
 __device__ __forceinline__ void forward_pass32(uint32_t (&v)[1 << LOGE], uint32_t tid, const U32x2* __restrict__ tw,
                                                uint32_t p, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
-    const uint32_t two_p = 2 * p;
+    const uint32_t two_p = 2 * p, neg_p = 0u - p;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + W - 1 - j, s = LOGN - 1 - b, stride = 1 << (b - LO);
@@ -126,7 +147,8 @@ __device__ __forceinline__ void forward_pass32(uint32_t (&v)[1 << LOGE], uint32_
             for (int o = 0; o < stride; ++o) {
                 uint32_t x = v[base + o];
                 if (!(first_stage_canonical && j == 0)) x = csub32(x, two_p);
-                const uint32_t t = shoup32_lazy(v[base + o + stride], w.x, w.y, p);
+                const uint32_t t = uniform ? shoup32_lazy_mad<true>(v[base + o + stride], w.x, w.y, neg_p)
+                                           : shoup32_lazy_mad<false>(v[base + o + stride], w.x, w.y, neg_p);
                 v[base + o] = x + t;
                 v[base + o + stride] = x + two_p - t;
             }
@@ -139,7 +161,7 @@ __device__ __forceinline__ void inverse_pass32(uint32_t (&v)[1 << LOGE], uint32_
                                                const DeviceModulus& mod, bool first_stage_canonical) {
     constexpr int E = 1 << LOGE;
     constexpr uint32_t N = 1u << LOGN;
-    const uint32_t p = static_cast<uint32_t>(mod.p), two_p = 2 * p;
+    const uint32_t p = static_cast<uint32_t>(mod.p), two_p = 2 * p, neg_p = 0u - p;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int b = LO + j, stride = 1 << (b - LO);
@@ -159,13 +181,14 @@ __device__ __forceinline__ void inverse_pass32(uint32_t (&v)[1 << LOGE], uint32_
                 // inputs in [0, 2p) (canonical on the very first stage): sum < 4p, diff in (0, 4p)
                 const uint32_t sum = x + y, diff = x + two_p - y;
                 if (last_stage) {
-                    v[base + o] = csub32(shoup32_lazy(sum, static_cast<uint32_t>(mod.inv_degree),
-                                                      static_cast<uint32_t>(mod.inv_degree_shoup >> 32), p), p);
-                    v[base + o + stride] = csub32(shoup32_lazy(diff, static_cast<uint32_t>(mod.inv_degree_root),
-                                                               static_cast<uint32_t>(mod.inv_degree_root_shoup >> 32), p), p);
+                    v[base + o] = csub32(shoup32_lazy_mad<true>(sum, static_cast<uint32_t>(mod.inv_degree),
+                                                                static_cast<uint32_t>(mod.inv_degree_shoup >> 32), neg_p), p);
+                    v[base + o + stride] = csub32(shoup32_lazy_mad<true>(diff, static_cast<uint32_t>(mod.inv_degree_root),
+                                                                         static_cast<uint32_t>(mod.inv_degree_root_shoup >> 32), neg_p), p);
                 } else {
                     v[base + o] = (first_stage_canonical && j == 0) ? sum : csub32(sum, two_p);
-                    v[base + o + stride] = shoup32_lazy(diff, w.x, w.y, p);
+                    v[base + o + stride] = uniform ? shoup32_lazy_mad<true>(diff, w.x, w.y, neg_p)
+                                                   : shoup32_lazy_mad<false>(diff, w.x, w.y, neg_p);
                 }
             }
         }
