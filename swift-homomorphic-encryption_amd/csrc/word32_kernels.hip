@@ -223,6 +223,58 @@ __device__ __forceinline__ void row32_store(const uint32_t (&v)[1 << LOGE], uint
         x[register_part<LOGN, LOGE, LO, W>(r) + lane_part<LOGN, LOGE, LO, W>(tid)] = v[r];
 }
 
+// Rows of the partial pass (bits [0, W)) in whole cache lines, as ntt_common.hpp global_store_staged / global_load_staged
+// do for 8-byte words: a lane's run of 2^W words is 2^(W-2) 16-byte chunks; with more than one of them per lane a store
+// as the words lie fills half of 64 lines per instruction.  The wave's block goes through its own slice of the tile and
+// crosses the memory interface in lane order.
+template <int LOGN, int LOGE, int W>
+constexpr bool kStaged32 = W == 3 && W == LOGE && ntt::kWaveOwnsTopBits<LOGN, LOGE, 0>;
+
+template <int LOGN, int LOGE, int W>
+__device__ __forceinline__ void row32_store_staged(const uint32_t (&v)[1 << LOGE], uint32_t tid, uint32_t* __restrict__ x,
+                                                   uint32_t* tile) {
+    constexpr int C = 1 << (W - 2);
+    const uint32_t lane = tid & 63u, swizzle = (lane >> (4 - (W - 2))) & (C - 1);
+    const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u);
+    char* const block = reinterpret_cast<char*>(tile + tile32_slot(first));
+#pragma unroll
+    for (int j = 0; j < C; ++j)
+        *reinterpret_cast<ntt::Dwordx4*>(block + ((lane * C + (j ^ swizzle)) << 4)) =
+            ntt::Dwordx4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+        const uint32_t owner_swizzle = (owner >> (4 - (W - 2))) & (C - 1);
+        *reinterpret_cast<ntt::Dwordx4*>(x + first + 4 * chunk) =
+            *reinterpret_cast<const ntt::Dwordx4*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4));
+    }
+}
+template <int LOGN, int LOGE, int W>
+__device__ __forceinline__ void row32_load_staged(uint32_t (&v)[1 << LOGE], uint32_t tid, const uint32_t* __restrict__ x,
+                                                  uint32_t* tile) {
+    constexpr int C = 1 << (W - 2);
+    const uint32_t lane = tid & 63u, swizzle = (lane >> (4 - (W - 2))) & (C - 1);
+    const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u);
+    char* const block = reinterpret_cast<char*>(tile + tile32_slot(first));
+    ntt::Dwordx4 words[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) words[j] = *reinterpret_cast<const ntt::Dwordx4*>(x + first + 4 * (j * 64 + lane));
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+        const uint32_t owner_swizzle = (owner >> (4 - (W - 2))) & (C - 1);
+        *reinterpret_cast<ntt::Dwordx4*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4)) = words[j];
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const ntt::Dwordx4 mine = *reinterpret_cast<const ntt::Dwordx4*>(block + ((lane * C + (j ^ swizzle)) << 4));
+        v[4 * j] = mine.x;
+        v[4 * j + 1] = mine.y;
+        v[4 * j + 2] = mine.z;
+        v[4 * j + 3] = mine.w;
+    }
+}
+
 template <int LOGN, int LOGT, bool INVERSE>
 __global__ void __launch_bounds__(1 << LOGT)
     ntt32_tiled_kernel(uint32_t* __restrict__ slab, const DeviceContext32 ctx, uint32_t mod_base, uint32_t mod_period) {
@@ -230,7 +282,7 @@ __global__ void __launch_bounds__(1 << LOGT)
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 2 && S::P <= 5, "unsupported pass count");
-    extern __shared__ uint32_t tile[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const uint32_t tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
@@ -270,9 +322,18 @@ __global__ void __launch_bounds__(1 << LOGT)
         forward_pass32<LOGN, LOGE, 0, S::R>(v, tid, tw, p, false);
 #pragma unroll
         for (int r = 0; r < E; ++r) v[r] = csub32(csub32(v[r], 2 * p), p);
-        row32_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+        // (the transpose into the last pass stayed inside the wave for every schedule with three or more passes)
+        if constexpr (kStaged32<LOGN, LOGE, S::R> && S::P >= 3 && ntt::kWaveOwnsTopBits<LOGN, LOGE, LOGN - (S::P - 1) * LOGE>) {
+            row32_store_staged<LOGN, LOGE, S::R>(v, tid, x, tile);
+        } else {
+            row32_store<LOGN, LOGE, 0, S::R>(v, tid, x);
+        }
     } else {
-        row32_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+        if constexpr (kStaged32<LOGN, LOGE, S::R>) {
+            row32_load_staged<LOGN, LOGE, S::R>(v, tid, x, tile);
+        } else {
+            row32_load<LOGN, LOGE, 0, S::R>(v, tid, x);
+        }
         inverse_pass32<LOGN, LOGE, 0, S::R>(v, tid, tw, mod, true);
         tile32_store<LOGN, LOGE, 0, S::R>(v, tid, tile);
         if constexpr (S::P >= 3) {
