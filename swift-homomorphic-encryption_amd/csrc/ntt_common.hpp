@@ -19,6 +19,40 @@ namespace ntt {
 __host__ __device__ constexpr uint32_t lds_slot(uint32_t idx) { return idx + (idx >> 3) + ((idx >> 8) << 3); }
 constexpr uint32_t lds_words(uint32_t n) { return n + (n >> 3) + ((n >> 8) << 3) + 8; }
 
+// The padding above serves the two transposes next to the low passes; the layouts of the upper passes read and write
+// runs of consecutive words, which it puts two to a bank (bench_tools/lds_bank_model.py: 8 / 4 cycles per store / load
+// instruction against 4 / 2; SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE on the N = 8192 kernels).  A transpose
+// only has to suit ITS two layouts, so the headline kernel (N = 8192, 8 words per lane) pads per transpose:
+//   scheme 1  passes on bits 10.. <-> 7..   runs of consecutive words on both sides: no padding
+//   scheme 2  passes on bits 7..  <-> 4..   +16 words per 128: the lane bit that jumps 128 words lands 16 banks away
+//   scheme 3  passes on bits 4..  <-> 1..   +2 words per 16
+//   scheme 0  everything else (the rule above)
+// -- every load and store of schemes 1-3 at its ideal cycle count.  All schemes keep a wave's 512-word block in the
+// same 592 slots (the padding acts inside the block only): between two wave-private transposes nothing orders one
+// wave's stores against its neighbours' loads, so the blocks must not move.  Each scheme is still a sum of per-bit
+// weights: lds_slot(a | b) == lds_slot(a) + lds_slot(b) for disjoint a, b.
+template <int SCHEME>
+__host__ __device__ constexpr uint32_t lds_slot_scheme(uint32_t idx) {
+    if constexpr (SCHEME == 0) {
+        return lds_slot(idx);
+    } else {
+        const uint32_t block = (idx >> 9) * 592u, within = idx & 511u;
+        if constexpr (SCHEME == 1) return block + within;
+        if constexpr (SCHEME == 2) return block + within + ((within >> 7) << 4);
+        return block + within + ((within >> 4) << 1);
+    }
+}
+static_assert(lds_slot(512) == 592 && lds_slot_scheme<3>(511) < 592, "all schemes share the 592-slot wave blocks");
+// the scheme of the transpose between the passes on bits [LO_A, ..) and [LO_B, ..)
+template <int LOGN, int LOGE, int LO_A, int LO_B>
+constexpr int transpose_scheme() {
+    constexpr int low = LO_A < LO_B ? LO_A : LO_B;
+#ifndef HEAMD_X_ONE_LDS_SCHEME  // (A/B hook: the single padding rule everywhere)
+    if constexpr (LOGN == 13 && LOGE == 3) return low == 7 ? 1 : low == 4 ? 2 : low == 1 ? 3 : 0;
+#endif
+    return 0;
+}
+
 // element index held in register r of lane tid during a pass over element bits [LO, LO + W)
 template <int LOGN, int LOGE, int LO, int W>
 __host__ __device__ constexpr uint32_t element_index(uint32_t r, uint32_t tid) {
@@ -468,18 +502,18 @@ __device__ __forceinline__ TwiddleWords inverse_first_twiddle(const Twiddles<MOD
     return inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid), 0);
 }
 
-template <int LOGN, int LOGE, int LO, int W>
+template <int LOGN, int LOGE, int LO, int W, int SCHEME = 0>
 __device__ __forceinline__ void lds_store(const uint64_t (&v)[1 << LOGE], uint32_t tid, uint64_t* lds) {
-    uint64_t* const base = lds + lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+    uint64_t* const base = lds + lds_slot_scheme<SCHEME>(lane_part<LOGN, LOGE, LO, W>(tid));
 #pragma unroll
-    for (int r = 0; r < (1 << LOGE); ++r) base[lds_slot(register_part<LOGN, LOGE, LO, W>(r))] = v[r];
+    for (int r = 0; r < (1 << LOGE); ++r) base[lds_slot_scheme<SCHEME>(register_part<LOGN, LOGE, LO, W>(r))] = v[r];
 }
-template <int LOGN, int LOGE, int LO, int W>
+template <int LOGN, int LOGE, int LO, int W, int SCHEME = 0>
 __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid, const uint64_t* lds) {
     // (tried: volatile reads to keep single ds_read_b64 instead of merged ds_read2_b64 -- 1.5 % slower, r01d notes)
-    const uint64_t* const base = lds + lds_slot(lane_part<LOGN, LOGE, LO, W>(tid));
+    const uint64_t* const base = lds + lds_slot_scheme<SCHEME>(lane_part<LOGN, LOGE, LO, W>(tid));
 #pragma unroll
-    for (int r = 0; r < (1 << LOGE); ++r) v[r] = base[lds_slot(register_part<LOGN, LOGE, LO, W>(r))];
+    for (int r = 0; r < (1 << LOGE); ++r) v[r] = base[lds_slot_scheme<SCHEME>(register_part<LOGN, LOGE, LO, W>(r))];
 }
 
 // Global <-> registers through the row's buffer descriptor: one 32-bit lane offset per pass, the register part is a

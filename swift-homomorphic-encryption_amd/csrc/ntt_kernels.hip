@@ -139,15 +139,21 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // ROWS rows of one modulus through ONE LDS tile, one after the other: a row's words leave in the layout of pass FROM
 // and come back in the layout of pass TO.  Between two rows every reader of the first must be done before the
 // second is written (the same fence the exchange itself needs: wave-private once a wave owns its slice of the row).
-template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS>
+// PER_TRANSPOSE: the padding rule that suits this transpose's two layouts (ntt_common.hpp transpose_scheme) instead of
+// the common one.  Every rule costs its own lane-base address words; the split-mode inverse kernel, which already
+// spills three words, spills six with them and loses more (0.572 -> 0.585 ms) than the conflict-free transposes give,
+// so it keeps the common rule; the forward kernels (0.510 -> 0.505 ms) and the [0, 8p) inverse (0.668 -> 0.659 ms) take
+// the per-transpose rules (profiles/r02ze_lds_schemes.txt).
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS, bool PER_TRANSPOSE = true>
 __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
 #ifndef HEAMD_X_NO_LDS
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
+        constexpr int SCHEME = PER_TRANSPOSE ? transpose_scheme<LOGN, LOGE, LO_FROM, LO_TO>() : 0;
         if (row > 0) lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
-        lds_store<LOGN, LOGE, LO_FROM, W_FROM>(v[row], tid, lds);
+        lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[row], tid, lds);
         lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
-        lds_load<LOGN, LOGE, LO_TO, W_TO>(v[row], tid, lds);
+        lds_load<LOGN, LOGE, LO_TO, W_TO, SCHEME>(v[row], tid, lds);
     }
 #endif
 }
@@ -206,7 +212,7 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
                                              const DeviceModulus& mod, uint64_t* lds) {
     TwiddleWords first{0, 0, 0};
     if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
-    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS>(v, tid, lds);
+    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, MODE != kModeSplit>(v, tid, lds);
     if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
     HEAMD_X_PASS((inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first)));
 }
