@@ -452,6 +452,8 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
+        // (without the request one twiddle ahead the kernel fits its 64 registers with nothing spilled -- and runs 4 %
+        // slower; without it but with the per-transpose LDS rules, still 1 % slower: profiles/r02ze_lds_schemes.txt)
         const TwiddleWords w = pending;
         if (k + 1 < COUNT) {
             pending = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
