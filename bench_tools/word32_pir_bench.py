@@ -32,4 +32,13 @@ out["packed_4_byte"] = {"ms_per_chunk": t32 / chunks * 1e3, "ct_pt_mac_per_s": m
                         "database_GBps": macs * len(moduli) * DEGREE * 4 / t32 / 1e9}
 out["on_8_byte_slabs"] = {"ms_per_chunk": t64 / chunks * 1e3, "ct_pt_mac_per_s": macs / t64,
                           "database_GBps": macs * len(moduli) * DEGREE * 8 / t64 / 1e9}
+# several queries in one call share the pass over the 4-byte database (he_pir_compute_response_queries_device_u32)
+for queries in (2, 4):
+    side = uniform32(moduli, (d0, queries, 2), 10 + queries)
+    rests = uniform32(moduli, (queries, d1, 2), 20 + queries)
+    keys = [key] * queries
+    tq = _timed(torch, lambda: narrow.pir_compute_response_queries([d0, d1], side, rests, database, chunks, keys), 3)
+    out[f"packed_4_byte_{queries}_queries"] = {"ms_per_chunk_per_query": tq / chunks / queries * 1e3,
+                                               "chunk_responses_per_s": chunks * queries / tq,
+                                               "ct_pt_mac_per_s": macs * queries / tq}
 print(json.dumps(out, indent=1))

@@ -353,10 +353,17 @@ int he_pir_compute_response_device_u32(const he_bfv_context* ctx, const uint32_t
                                        size_t remaining_query_count, const uint32_t* database,
                                        const uint8_t* present_device, size_t chunk_count,
                                        const uint32_t* relinearization_key, uint32_t* out, he_stream s);
+/* he_pir_compute_response_queries_device on packed 4-byte slabs (a Bfv<UInt32> context): 1..4 queries share one pass
+ * over the 4-byte database; layouts as there, 4-byte words. */
+int he_pir_compute_response_queries_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                               uint32_t dimension_count, size_t queries, const uint32_t* dim0_queries_eval,
+                                               const uint32_t* remaining_queries, size_t remaining_query_count,
+                                               const uint32_t* database, const uint8_t* present_device, size_t chunk_count,
+                                               const uint32_t* const* relinearization_keys, uint32_t* out, he_stream s);
 /* he_pir_compute_response_to_query_device for Bfv<UInt32> on packed 4-byte slabs (query, relinearization key, databases,
  * responses in UInt32 words).  The expansion, which is bound by its key switches and not by bytes, runs on widened words:
  * galois_keys_wide are the Galois keys as 8-byte slabs (he_words_widen_u32_device), as he_pir_expand_device takes them for
- * a UInt32 context.  Indices are answered one at a time. */
+ * a UInt32 context.  Indices that share the database share its pass four at a time. */
 int he_pir_compute_response_to_query_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
                                                 uint32_t dimension_count, const uint32_t* query_ciphertexts,
                                                 size_t query_ciphertext_count, size_t indices_count,

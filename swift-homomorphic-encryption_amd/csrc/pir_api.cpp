@@ -231,6 +231,66 @@ extern "C" int he_pir_compute_response_packed_device(const he_bfv_context* ctx, 
 
 // ---- the same chunk loop for Bfv<UInt32> on packed 4-byte slabs (the reference's 27/28-bit PIR parameter sets,
 // EncryptionParameters.swift:313-345): half the database bytes of the 8-byte route --------------------------------
+namespace {
+// scratch of the 4-byte remaining-dimension stages for up to `group` chunks at a time
+struct Word32Stages {
+    Scratch next_mem, products_mem, level_mem;
+    uint32_t *next = nullptr, *products = nullptr, *ping = nullptr, *pong = nullptr;
+    explicit Word32Stages(hipStream_t stream) : next_mem(stream), products_mem(stream), level_mem(stream) {}
+    hipError_t allocate(const ChunkShape& shape, size_t group) {
+        const size_t ct2 = 2 * size_t(shape.L) * shape.n, ct3 = 3 * size_t(shape.L) * shape.n, widest = group * shape.columns;
+        if (hipError_t e = next_mem.allocate(widest * ct2 * sizeof(uint32_t)); e != hipSuccess) return e;
+        if (hipError_t e = products_mem.allocate(widest * ct3 * sizeof(uint32_t)); e != hipSuccess) return e;
+        if (hipError_t e = level_mem.allocate(2 * group * ct2 * sizeof(uint32_t)); e != hipSuccess) return e;
+        next = static_cast<uint32_t*>(next_mem.get());
+        products = static_cast<uint32_t*>(products_mem.get());
+        ping = static_cast<uint32_t*>(level_mem.get());
+        pong = ping + group * ct2;
+        return hipSuccess;
+    }
+};
+
+// PirUtil.swift:448-485 for `chunks` chunks on 4-byte slabs: results [chunks][columns][2][L][N] Coeff (consumed) ->
+// target [chunks][2][1][N]; every stage one batch over the result groups of all chunks
+int remaining_dimensions_u32(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                             const ChunkShape& shape, size_t chunks, uint32_t* results, Word32Stages& stages,
+                             const uint32_t* remaining_query, const uint32_t* relinearization_key, uint32_t* target,
+                             he_stream s) {
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = shape.L;
+    const size_t ct2 = 2 * size_t(L) * shape.n, out_words = 2 * shape.n;
+    uint32_t* current = results;
+    uint32_t* other = stages.next;
+    size_t count = shape.columns, cursor = 0;
+    for (uint32_t i = 1; i < dimension_count; ++i) {
+        const size_t d = dimensions[i];
+        if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
+        const size_t items = chunks * (count / d);
+        HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device_u32(ctx, L, remaining_query + cursor * ct2, current, d, items,
+                                                                stages.products, s));
+        HEAMD_TRY_STATUS(he_bfv_relinearize_device_u32(ctx, L, stages.products, relinearization_key, other, items, nullptr, 0, s));
+        uint32_t* swap = current;
+        current = other;
+        other = swap;
+        count /= d;
+        cursor += d;
+    }
+    if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
+    // modSwitchDownToSingle (:483)
+    if (L == 1) {
+        HEAMD_HIP_TRY(hipMemcpyAsync(target, current, chunks * out_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        return HE_OK;
+    }
+    const uint32_t* source = current;
+    for (uint32_t level = L; level > 1; --level) {
+        uint32_t* step = level == 2 ? target : (source == stages.ping ? stages.pong : stages.ping);
+        HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device_u32(ctx, level, 2, source, step, chunks, s));
+        source = step;
+    }
+    return HE_OK;
+}
+}  // namespace
+
 extern "C" int he_pir_compute_response_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
                                                   uint32_t dimension_count, const uint32_t* dim0_query_eval,
                                                   const uint32_t* remaining_query, size_t remaining_query_count,
@@ -244,58 +304,86 @@ extern "C" int he_pir_compute_response_device_u32(const he_bfv_context* ctx, con
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
     hipStream_t stream = as_stream(s);
     const uint32_t L = shape.L;
-    const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
-    const size_t chunk_words = shape.per_chunk * poly, out_words = 2 * n;
+    const size_t poly = size_t(L) * shape.n, ct2 = 2 * poly;
+    const size_t chunk_words = shape.per_chunk * poly, out_words = 2 * shape.n;
     size_t group = (size_t(1) << 30) / (shape.columns * ct2 * sizeof(uint32_t));
     group = group == 0 ? 1 : (group < chunk_count ? group : chunk_count);
-    const size_t widest = group * shape.columns;
-    Scratch results_mem(stream), next_mem(stream), products_mem(stream), level_mem(stream);
-    HEAMD_HIP_TRY(results_mem.allocate(widest * ct2 * sizeof(uint32_t)));
-    HEAMD_HIP_TRY(next_mem.allocate(widest * ct2 * sizeof(uint32_t)));
-    HEAMD_HIP_TRY(products_mem.allocate(widest * ct3 * sizeof(uint32_t)));
-    HEAMD_HIP_TRY(level_mem.allocate(2 * group * ct2 * sizeof(uint32_t)));
-    uint32_t* products = static_cast<uint32_t*>(products_mem.get());
+    Scratch results_mem(stream);
+    Word32Stages stages(stream);
+    HEAMD_HIP_TRY(results_mem.allocate(group * shape.columns * ct2 * sizeof(uint32_t)));
+    HEAMD_HIP_TRY(stages.allocate(shape, group));
+    uint32_t* results = static_cast<uint32_t*>(results_mem.get());
     for (size_t first = 0; first < chunk_count; first += group) {
         const size_t chunks = chunk_count - first < group ? chunk_count - first : group;
-        uint32_t* current = static_cast<uint32_t*>(results_mem.get());
-        uint32_t* other = static_cast<uint32_t*>(next_mem.get());
         // PirUtil.swift:428-438: every column of every chunk of the group in one launch, then back to Coeff
         HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device_u32(
             ctx, L, 2, dim0_query_eval, database + first * chunk_words,
-            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, chunks * shape.columns, current, s));
-        HEAMD_TRY_STATUS(he_ntt_inverse_device_u32(shape.q_ctx, current, chunks * shape.columns * 2, s));
-        // PirUtil.swift:448-479, every stage one batch over the result groups of all chunks
-        size_t count = shape.columns, cursor = 0;
-        for (uint32_t i = 1; i < dimension_count; ++i) {
-            const size_t d = dimensions[i];
-            if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
-            const size_t items = chunks * (count / d);
-            HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device_u32(ctx, L, remaining_query + cursor * ct2, current, d, items,
-                                                                    products, s));
-            HEAMD_TRY_STATUS(he_bfv_relinearize_device_u32(ctx, L, products, relinearization_key, other, items, nullptr, 0, s));
-            uint32_t* swap = current;
-            current = other;
-            other = swap;
-            count /= d;
-            cursor += d;
-        }
-        if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
-        // modSwitchDownToSingle (:483)
-        uint32_t* target = out + first * out_words;
-        if (L == 1) {
-            HEAMD_HIP_TRY(hipMemcpyAsync(target, current, chunks * out_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-            continue;
-        }
-        uint32_t* ping = static_cast<uint32_t*>(level_mem.get());
-        uint32_t* pong = ping + group * ct2;
-        const uint32_t* source = current;
-        for (uint32_t level = L; level > 1; --level) {
-            uint32_t* step = level == 2 ? target : (source == ping ? pong : ping);
-            HEAMD_TRY_STATUS(he_bfv_mod_switch_down_device_u32(ctx, level, 2, source, step, chunks, s));
-            source = step;
+            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, chunks * shape.columns, results, s));
+        HEAMD_TRY_STATUS(he_ntt_inverse_device_u32(shape.q_ctx, results, chunks * shape.columns * 2, s));
+        HEAMD_TRY_STATUS(remaining_dimensions_u32(ctx, dimensions, dimension_count, shape, chunks, results, stages,
+                                                  remaining_query, relinearization_key, out + first * out_words, s));
+    }
+    return HE_OK;
+}
+
+// Several queries (1..4) over one packed 4-byte database in one call: as he_pir_compute_response_queries_device, the
+// dim-0 inner products of all of them share one pass over the database.
+namespace {
+int compute_response_queries_u32(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                                 size_t queries, const uint32_t* dim0_queries_eval, const uint32_t* remaining_queries,
+                                 size_t remaining_query_count, size_t remaining_stride, const uint32_t* database,
+                                 const uint8_t* present_device, size_t chunk_count,
+                                 const uint32_t* const* relinearization_keys, uint32_t* out, he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, reinterpret_cast<const uint64_t*>(remaining_queries),
+                                 remaining_query_count, shape));
+    if (queries == 0 || chunk_count == 0) return HE_OK;
+    if (queries > 4) return invalid_argument("at most 4 queries share one pass over the database");
+    if (dim0_queries_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
+    if (dimension_count > 1 && relinearization_keys == nullptr) return invalid_argument("null relinearization keys");
+    hipStream_t stream = as_stream(s);
+    const uint32_t L = shape.L;
+    const size_t ct_words = 2 * size_t(L) * shape.n, ct_bytes = ct_words * sizeof(uint32_t);
+    const size_t chunk_words = shape.per_chunk * size_t(L) * shape.n, out_words = 2 * shape.n;
+    size_t group = (size_t(1) << 30) / (shape.columns * queries * ct_bytes);
+    group = group == 0 ? 1 : (group < chunk_count ? group : chunk_count);
+    Scratch all_mem(stream), one_mem(stream);
+    Word32Stages stages(stream);
+    HEAMD_HIP_TRY(all_mem.allocate(group * shape.columns * queries * ct_bytes));
+    HEAMD_HIP_TRY(one_mem.allocate(group * shape.columns * ct_bytes));
+    HEAMD_HIP_TRY(stages.allocate(shape, group));
+    uint32_t* all = static_cast<uint32_t*>(all_mem.get());  // [chunk][column][query][2][L][N]
+    uint32_t* one = static_cast<uint32_t*>(one_mem.get());  // [chunk][column][2][L][N] of one query
+    for (size_t first = 0; first < chunk_count; first += group) {
+        const size_t now = chunk_count - first < group ? chunk_count - first : group;
+        const size_t columns = now * shape.columns;
+        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device_u32(
+            ctx, L, static_cast<uint32_t>(2 * queries), dim0_queries_eval, database + first * chunk_words,
+            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, columns, all, s));
+        HEAMD_TRY_STATUS(he_ntt_inverse_device_u32(shape.q_ctx, all, columns * 2 * queries, s));
+        for (size_t q = 0; q < queries; ++q) {
+            HEAMD_HIP_TRY(hipMemcpy2DAsync(one, ct_bytes, all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
+                                           hipMemcpyDeviceToDevice, stream));
+            HEAMD_TRY_STATUS(remaining_dimensions_u32(
+                ctx, dimensions, dimension_count, shape, now, one, stages,
+                remaining_queries ? remaining_queries + q * remaining_stride * ct_words : nullptr,
+                relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words, s));
         }
     }
     return HE_OK;
+}
+}  // namespace
+
+extern "C" int he_pir_compute_response_queries_device_u32(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                          uint32_t dimension_count, size_t queries,
+                                                          const uint32_t* dim0_queries_eval,
+                                                          const uint32_t* remaining_queries, size_t remaining_query_count,
+                                                          const uint32_t* database, const uint8_t* present_device,
+                                                          size_t chunk_count, const uint32_t* const* relinearization_keys,
+                                                          uint32_t* out, he_stream s) {
+    return compute_response_queries_u32(ctx, dimensions, dimension_count, queries, dim0_queries_eval, remaining_queries,
+                                        remaining_query_count, remaining_query_count, database, present_device, chunk_count,
+                                        relinearization_keys, out, s);
 }
 
 // Several queries over the same database in one call: the dim-0 inner products of all of them stream the database once
@@ -683,7 +771,8 @@ extern "C" int he_pir_compute_response_to_query_device(
 
 // The whole-query call for Bfv<UInt32> on packed 4-byte slabs: the expansion (bound by its key switches, not by bytes)
 // runs on widened words with the 8-byte kernels -- the Galois keys are therefore taken as 8-byte slabs, as
-// he_pir_expand_device takes them for a UInt32 context -- everything that touches the database is 4-byte.
+// he_pir_expand_device takes them for a UInt32 context -- everything that touches the database is 4-byte; indices that
+// share the database share its pass four at a time.
 extern "C" int he_pir_compute_response_to_query_device_u32(
     const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count, const uint32_t* query_ciphertexts,
     size_t query_ciphertext_count, size_t indices_count, const uint64_t* galois_elements,
@@ -717,15 +806,42 @@ extern "C" int he_pir_compute_response_to_query_device_u32(
     HEAMD_TRY_STATUS(he_pir_expand_device(ctx, query_wide, query_ciphertext_count, total, galois_elements, galois_keys_wide,
                                           galois_key_count, expanded_wide, s));
     HEAMD_TRY_STATUS(he_words_narrow_u64_device(expanded_wide, expanded, total * ct_words, s));
-    for (size_t index = 0; index < indices_count; ++index) {
-        uint32_t* mine = expanded + index * expanded_count * ct_words;
-        const uint32_t* database = databases[database_count == 1 ? 0 : index];
-        if (database == nullptr) return invalid_argument("null database");
-        const uint8_t* present_device = present_masks ? present_masks[database_count == 1 ? 0 : index] : nullptr;
-        HEAMD_TRY_STATUS(he_ntt_forward_device_u32(shape.q_ctx, mine, shape.d0 * 2, s));
-        HEAMD_TRY_STATUS(he_pir_compute_response_device_u32(
-            ctx, dimensions, dimension_count, mine, remaining_count ? mine + shape.d0 * ct_words : nullptr, remaining_count,
-            database, present_device, chunk_count, relinearization_key, out + index * chunk_count * out_words, s));
+    // indices with a database of their own are answered one by one; those that share one go four at a time
+    const bool shared = database_count == 1;
+    constexpr size_t kGroup = 4;
+    const size_t together = shared ? kGroup : 1;
+    const size_t widest = indices_count < together ? indices_count : together;
+    for (size_t d = 0; d < (shared ? size_t(1) : indices_count); ++d)
+        if (databases[d] == nullptr) return invalid_argument("null database");
+    Scratch side_mem(stream);
+    uint32_t* side = nullptr;  // [dimensions[0]][indices of a group][2][L][N]
+    if (widest > 1) {
+        HEAMD_HIP_TRY(side_mem.allocate(shape.d0 * widest * ct_words * sizeof(uint32_t)));
+        side = static_cast<uint32_t*>(side_mem.get());
+    }
+    const uint32_t* keys[kGroup] = {relinearization_key, relinearization_key, relinearization_key, relinearization_key};
+    const size_t ct_bytes = ct_words * sizeof(uint32_t);
+    for (size_t first = 0; first < indices_count; first += together) {
+        const size_t now = indices_count - first < together ? indices_count - first : together;
+        uint32_t* mine = expanded + first * expanded_count * ct_words;
+        const uint32_t* rest = remaining_count ? mine + shape.d0 * ct_words : nullptr;
+        uint32_t* group_out = out + first * chunk_count * out_words;
+        const uint32_t* database = databases[shared ? 0 : first];
+        const uint8_t* present_device = present_masks ? present_masks[shared ? 0 : first] : nullptr;
+        if (now == 1) {
+            HEAMD_TRY_STATUS(he_ntt_forward_device_u32(shape.q_ctx, mine, shape.d0 * 2, s));
+            HEAMD_TRY_STATUS(he_pir_compute_response_device_u32(ctx, dimensions, dimension_count, mine, rest, remaining_count,
+                                                                database, present_device, chunk_count, relinearization_key,
+                                                                group_out, s));
+            continue;
+        }
+        for (size_t q = 0; q < now; ++q)
+            HEAMD_HIP_TRY(hipMemcpy2DAsync(side + q * ct_words, now * ct_bytes, mine + q * expanded_count * ct_words, ct_bytes,
+                                           ct_bytes, shape.d0, hipMemcpyDeviceToDevice, stream));
+        HEAMD_TRY_STATUS(he_ntt_forward_device_u32(shape.q_ctx, side, shape.d0 * now * 2, s));
+        HEAMD_TRY_STATUS(compute_response_queries_u32(ctx, dimensions, dimension_count, now, side, rest, remaining_count,
+                                                      expanded_count, database, present_device, chunk_count,
+                                                      dimension_count > 1 ? keys : nullptr, group_out, s));
     }
     return HE_OK;
 }

@@ -145,6 +145,8 @@ SIGNATURES = [
     ("he_bfv_inner_product_shared_device_u32", ctypes.c_int, [vp, c_u32, vp, vp, c_size, c_size, vp, vp]),
     ("he_pir_compute_response_device_u32", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, vp, vp, c_size, vp, vp, vp]),
+    ("he_pir_compute_response_queries_device_u32", ctypes.c_int,
+     [vp, ctypes.POINTER(c_u32), c_u32, c_size, vp, vp, c_size, vp, vp, c_size, ctypes.POINTER(vp), vp, vp]),
     ("he_pir_compute_response_to_query_device_u32", ctypes.c_int,
      [vp, ctypes.POINTER(c_u32), c_u32, vp, c_size, c_size, U64P, ctypes.POINTER(vp), c_size, vp, ctypes.POINTER(vp),
       ctypes.POINTER(vp), c_size, c_size, vp, vp]),
@@ -1045,6 +1047,24 @@ class BfvContext32(BfvContext):
         _check(load_library().he_pir_compute_response_device_u32(self.h, dims, len(dimensions), _ptr32(dim0_query_eval),
                                                                  rest, rest_count, _ptr32(database), mask, chunk_count,
                                                                  key, _ptr32(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_queries(self, dimensions, dim0_queries_eval, remaining_queries, database, chunk_count,
+                                     relinearization_keys, present_device=None, stream=None):
+        """he_pir_compute_response_queries_device_u32: dim0_queries_eval [d0][queries][2][L][N] Eval, remaining_queries
+        [queries][rest][2][L][N] (or None), one relinearization key per query (or None) -> [queries][chunks][2][1][N]."""
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        queries = dim0_queries_eval.numel() // (int(dimensions[0]) * 2 * self.L * self.degree)
+        out = self._empty32((queries, chunk_count, 2, 1, self.degree), dim0_queries_eval)
+        rest = vp() if remaining_queries is None else _ptr32(remaining_queries)
+        rest_count = 0 if remaining_queries is None else remaining_queries.numel() // (queries * 2 * self.L * self.degree)
+        keys = None
+        if relinearization_keys is not None:
+            keys = (vp * queries)(*[vp(k.data_ptr()) for k in relinearization_keys])
+        mask = vp() if present_device is None else vp(present_device.data_ptr())
+        _check(load_library().he_pir_compute_response_queries_device_u32(
+            self.h, dims, len(dimensions), queries, _ptr32(dim0_queries_eval), rest, rest_count, _ptr32(database), mask,
+            chunk_count, keys, _ptr32(out), _stream(stream)))
         return out
 
     def pir_compute_response_to_query(self, dimensions, query_ciphertexts, indices_count, galois_keys_wide,

@@ -457,16 +457,52 @@ def test_pir_response_on_packed_uint32_slabs(oracle, dims):
         assert np.array_equal(got[chunk], expected), chunk
 
 
+@pytest.mark.parametrize("dims,queries", [([4, 3], 2), ([3, 2, 2], 4), ([5], 3)])
+def test_queries_share_one_pass_on_packed_uint32_slabs(oracle, dims, queries):
+    """he_pir_compute_response_queries_device_u32: several queries over one 4-byte database in one call, each with its own
+    relinearization key and a nil-plaintext mask: every response word for word the 32-bit oracle's single-query one."""
+    import torch
+
+    degree = 4096
+    q = [(1 << 27) - 40959, (1 << 28) - 65535, (1 << 28) - 73727]
+    t = (1 << 16) + 1
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(10 * len(dims) + queries)
+    moduli = q[:-1]
+    per_chunk, chunks, rest_count = int(np.prod(dims)), 2, sum(dims[1:])
+    database = _uniform(rng, (chunks, per_chunk), moduli, degree)
+    present = np.ones((chunks, per_chunk), dtype=np.uint8)
+    present[0, 1] = 0
+    dim0 = _uniform(rng, (dims[0], queries, 2), moduli, degree)
+    rest = _uniform(rng, (queries, max(rest_count, 1), 2), moduli, degree)[:, :rest_count]
+    keys = [_uniform(rng, (ours.L, 2), q, degree) for _ in range(queries)]
+    dev = heamd.to_device32
+    got = heamd.to_host32(ours.pir_compute_response_queries(
+        dims, dev(dim0), dev(np.ascontiguousarray(rest)) if rest_count else None, dev(database), chunks,
+        [dev(k) for k in keys] if rest_count else None, present_device=torch.from_numpy(present).cuda()))
+    for query in range(queries):
+        own = np.ascontiguousarray(dim0[:, query])
+        for chunk in range(chunks):
+            expected = oracle.pir.compute_response_for_one_chunk(ref, dims, own, rest[query], database[chunk], present[chunk],
+                                                                 keys[query] if rest_count else None)
+            assert np.array_equal(got[query, chunk], expected), (query, chunk)
+    with pytest.raises(heamd.HeError):
+        five = dev(_uniform(rng, (dims[0], 5, 2), moduli, degree))
+        ours.pir_compute_response_queries(dims, five, None if not rest_count else dev(np.zeros((5, rest_count, 2, ours.L, degree), dtype=np.uint64)),
+                                          dev(database), chunks, [dev(keys[0])] * 5 if rest_count else None)
+
+
 def test_whole_query_on_packed_uint32_slabs(oracle):
-    """he_pir_compute_response_to_query_device_u32 (n_4096_logq_27_28_28, two indices, 4 x 3 database, two chunks): the
-    composition of the 32-bit oracle's expand and chunk responses, word for word."""
+    """he_pir_compute_response_to_query_device_u32 (n_4096_logq_27_28_28, five indices -- a group of four that shares the
+    pass over the database and one on its own --, 4 x 3 database, two chunks): the composition of the 32-bit oracle's
+    expand and chunk responses, word for word."""
     degree = 4096
     q = [(1 << 27) - 40959, (1 << 28) - 65535, (1 << 28) - 73727]
     t = (1 << 16) + 1
     ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
     rng = np.random.default_rng(1234)
     moduli = q[:-1]
-    dims, chunks, indices = [4, 3], 2, 2
+    dims, chunks, indices = [4, 3], 2, 5
     expanded_count = sum(dims)
     total = expanded_count * indices
     query = _uniform(rng, (1, 2), moduli, degree)
