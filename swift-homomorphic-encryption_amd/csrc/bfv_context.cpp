@@ -30,6 +30,10 @@ DeviceModulus barrett_constants(u64 p) {
     m.product_shift = static_cast<uint32_t>(bits >= 2 ? bits - 2 : 0);
     m.two64_mod_p = static_cast<u64>((static_cast<u128>(1) << 64) % p);
     m.two64_mod_p_shoup = shoup_factor(m.two64_mod_p, p);
+    if (bits >= 34 && bits <= 61 && !is_power_of_two(p)) {
+        m.wide_shift = static_cast<uint32_t>(bits - 1);
+        m.wide_factor = static_cast<u64>((static_cast<u128>(1) << (64 + bits - 1)) / p);
+    }
     return m;
 }
 
@@ -313,6 +317,24 @@ int BfvContext::build_tool(uint32_t k) {
         for (size_t i = 0; i < L; ++i) q_max = q[i] > q_max ? q[i] : q_max;
         const unsigned __int128 worst = static_cast<unsigned __int128>(bsk_max - 1) * (q_max - 1);
         d.floor_merge_ok = (worst == 0 || (static_cast<unsigned __int128>(1) << 127) / worst > L + 1) ? 1u : 0u;
+    }
+    {
+        // worst exact sums of the two kernels against the bound 2^(64 + wide_shift) of the modulus they are reduced by:
+        // lift and approximateFloor: sum_i (q_i - 1) (ext_j - 1); the alpha sum: sum_j (Bsk_j - 1) (alpha modulus - 1);
+        // the Q rows: sum_j (Bsk_j - 1) (q - 1) + (m_sk - 1) (q - 1)
+        auto fits = [](unsigned __int128 worst, const DeviceModulus& m) {
+            return m.wide_shift != 0 && (worst >> (64 + m.wide_shift)) == 0;
+        };
+        bool ok = true;
+        unsigned __int128 q_sum = 0, bsk_sum = 0;
+        for (size_t i = 0; i < L; ++i) q_sum += q[i] - 1;
+        for (size_t j = 0; j < L; ++j) bsk_sum += bsk[j] - 1;
+        for (size_t j = 0; j <= L; ++j) ok = ok && fits(q_sum * (bsk[j] - 1), arena.at<DeviceModulus>(o_ext_moduli)[j]);
+        ok = ok && fits(bsk_sum * (top_m_sk - 1), arena.at<DeviceModulus>(o_alpha_modulus)[0]);
+        ok = ok && fits(bsk_sum * (m_sk - 1), arena.at<DeviceModulus>(o_ext_moduli)[L]);
+        for (size_t i = 0; i < L; ++i)
+            ok = ok && fits((bsk_sum + (m_sk - 1)) * (q[i] - 1), arena.at<DeviceModulus>(o_q_moduli)[i]);
+        d.wide_reduce_ok = ok ? 1u : 0u;
     }
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));
     d.neg_inv_q_mod_mtilde = neg_inv_q_mod_mtilde;

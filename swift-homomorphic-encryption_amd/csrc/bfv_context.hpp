@@ -47,6 +47,9 @@ struct RnsToolDevice {
     const U64x2* q_div_t;              // [L]     floor(Q / t) mod q_i                              RnsTool.swift:170-182
     uint64_t q_mod_t;                  //         Q mod t                                           RnsTool.swift:167
     uint64_t mtilde;                   //         T.mTilde: 2^32 (UInt64) or 2^16 (UInt32)          MA/Scalar.swift:508-525
+    uint32_t wide_reduce_ok;           //         every dot product of lift / floor stays below 2^(64 + wide_shift) of its
+                                       //         modulus (DeviceModulus::wide_shift != 0 for all of them): the kernels take
+                                       //         the one-word-quotient Barrett (device_math.hpp reduce_product_sum_bounded)
     uint32_t floor_merge_ok;           //         (L + 1) (Bsk_max - 1) (q_max - 1) < 2^127: the alpha correction of the Bsk -> Q
                                        //         conversion may join that row's product sum (one reduction for both)
     U64x2 neg_inv_q_mod_mtilde;        //         -(Q^-1) mod mTilde                      RnsTool.swift:163-169

@@ -33,6 +33,12 @@ struct DeviceModulus {
     uint64_t inv_degree_factors;
     uint64_t inv_degree_root_split;
     uint64_t inv_degree_root_factors;
+    // one-word-quotient Barrett for exact sums below 2^(64 + wide_shift) (device_math.hpp reduce_product_sum_bounded):
+    // wide_shift = bits(p) - 1, wide_factor = floor(2^(64 + wide_shift) / p); wide_shift = 0 where it does not apply
+    // (p below 2^33, above 2^61, or a power of two)
+    uint64_t wide_factor;
+    uint32_t wide_shift;
+    uint32_t reserved;
 };
 
 struct DeviceContext {

@@ -665,6 +665,33 @@ __device__ __forceinline__ uint64_t reduce_product_sum_lazy(const ProductSum& s,
            barrett_reduce64_uniform_lazy(v.lo, m.p, m.barrett64);
 }
 
+// The same residues for a sum KNOWN to be below 2^(64 + sh), sh = m.wide_shift = bits(p) - 1 (2^33 < p < 2^61, hence
+// 32 <= sh <= 60) -- the dot products of the base conversions, whose terms are residues times table constants.  Barrett
+// with a one-word quotient: x = T >> sh fits a word, mu = floor(2^(64+sh) / p) < 2^64, floor(x mu / 2^64) is at most 2
+// below floor(T / p); the high word of x mu is taken from three of its four partial products (at most 2 lower), so
+// T - q p lies in [0, 5p) -- two alignbits, three multiply-adds for q, three for the low word of T + q (2^64 - p):
+// 24 issue slots against 45 for the split at 2^64 above (_lazy) and 39 against 64 for the canonical residue.
+template <typename Modulus>
+__device__ __forceinline__ uint64_t reduce_product_sum_bounded_lazy(const ProductSum& s, const Modulus& m) {
+    const U128 v = product_sum_value(s);
+    const uint32_t shift = m.wide_shift - 32u;  // wave-uniform, 0..28
+    const uint32_t x0 = __builtin_amdgcn_alignbit(lo32(v.hi), hi32(v.lo), shift);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(hi32(v.hi), lo32(v.hi), shift);
+    const uint64_t q = shoup_quotient<true, true>(pack64(x0, x1), m.wide_factor);
+    const uint64_t neg_p = 0 - m.p;
+    uint64_t c0, c1, carry;
+    asm("v_mad_u64_u32 %0, %2, %3, %5, %7\n\t"
+        "v_mad_u64_u32 %1, %2, %3, %6, 0\n\t"
+        "v_mad_u64_u32 %1, %2, %4, %5, %1"
+        : "=&v"(c0), "=&v"(c1), "=&s"(carry)
+        : "v"(lo32(q)), "v"(hi32(q)), "s"(lo32(neg_p)), "s"(hi32(neg_p)), "v"(v.lo));
+    return pack64(lo32(c0), opaque32(hi32(c0) + lo32(c1)));
+}
+template <typename Modulus>
+__device__ __forceinline__ uint64_t reduce_product_sum_bounded(const ProductSum& s, const Modulus& m) {
+    return csub_uniform(csub_uniform(csub_uniform(reduce_product_sum_bounded_lazy(s, m), 4 * m.p), 2 * m.p), m.p);
+}
+
 // Barrett on a product x*y < p^2 (Modulus.swift:349-360): factor = floor(2^(bits(p)+62)/p), shift = bits(p)-2.
 __device__ __forceinline__ uint64_t barrett_mul(uint64_t x, uint64_t y, uint64_t p, uint64_t factor, int shift) {
     const U128 prod = mul_wide(x, y);

@@ -437,12 +437,18 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                         const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
                         const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
                         const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
-                        // a0 b1 + a1 b0 as one exact 128-bit sum and one reduction (two products < 2^125)
+                        // a0 b1 + a1 b0 as one exact 128-bit sum and one reduction (two products < 2^125); below 2^61 the
+                        // sum 2 p^2 is inside the one-word-quotient Barrett's bound 2^(64 + wide_shift)
                         ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
                         product_sum_add(cross0, a1.x, b0.x);
                         product_sum_add(cross1, a1.y, b0.y);
-                        v[k][r] = reduce_product_sum(cross0, mod);
-                        v[k][r + 1] = reduce_product_sum(cross1, mod);
+                        if (mod.wide_shift != 0) {  // wave-uniform
+                            v[k][r] = reduce_product_sum_bounded(cross0, mod);
+                            v[k][r + 1] = reduce_product_sum_bounded(cross1, mod);
+                        } else {
+                            v[k][r] = reduce_product_sum(cross0, mod);
+                            v[k][r + 1] = reduce_product_sum(cross1, mod);
+                        }
                     }
                 }
             }
@@ -470,6 +476,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                         product_sum_add(acc0, xs.x, ks.x);
                         product_sum_add(acc1, xs.y, ks.y);
                     }
+                    // (the one-word-quotient Barrett saves a quarter of this load's instructions and nothing of its time:
+                    // the key MAC streams eight rows per output row, profiles/r02zg_bounded_reduce.txt)
                     v[k][q] = reduce_product_sum(acc0, mod);
                     v[k][q + 1] = reduce_product_sum(acc1, mod);
                 }

@@ -63,6 +63,10 @@ static DeviceModulus make_constants(u64 p) {
     m.product_shift = static_cast<uint32_t>(bits >= 2 ? bits - 2 : 0);
     m.two64_mod_p = static_cast<u64>((static_cast<u128>(1) << 64) % p);
     m.two64_mod_p_shoup = shoup_factor(m.two64_mod_p, p);
+    if (bits >= 34 && bits <= 61 && !is_power_of_two(p)) {
+        m.wide_shift = static_cast<uint32_t>(bits - 1);
+        m.wide_factor = static_cast<u64>((static_cast<u128>(1) << (64 + bits - 1)) / p);
+    }
     return m;
 }
 

@@ -60,11 +60,17 @@ struct WordArith {  // uint64_t
     static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { product_sum_add(s, a, b); }
     static __device__ __forceinline__ Sum zero() { return product_sum_zero(); }
     static __device__ __forceinline__ uint64_t low_word(const Sum& s) { return product_sum_value(s).lo; }
-    template <typename Modulus>
-    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const Modulus& m) { return reduce_product_sum(s, m); }
-    template <typename Modulus>
+    // BOUNDED: the sum is known to lie below 2^(64 + m.wide_shift) (RnsToolDevice::wide_reduce_ok): the one-word-quotient
+    // Barrett of device_math.hpp, 21 / 25 issue slots less per residue
+    template <bool BOUNDED = false, typename Modulus>
+    static __device__ __forceinline__ uint64_t reduce(const Sum& s, const Modulus& m) {
+        if constexpr (BOUNDED) return reduce_product_sum_bounded(s, m);
+        else return reduce_product_sum(s, m);
+    }
+    template <bool BOUNDED = false, typename Modulus>
     static __device__ __forceinline__ uint64_t reduce_lazy(const Sum& s, const Modulus& m) {
-        return reduce_product_sum_lazy(s, m);
+        if constexpr (BOUNDED) return reduce_product_sum_bounded_lazy(s, m);
+        else return reduce_product_sum_lazy(s, m);
     }
     static __device__ __forceinline__ uint64_t shoup(uint64_t x, U64x2 c, uint64_t p) {
         return shoup_mul_uniform(x, c.x, c.y, p);
@@ -85,11 +91,11 @@ struct WordArith<uint32_t> {
     static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { s = mad32(lo32(a), lo32(b), s); }
     static __device__ __forceinline__ Sum zero() { return 0; }
     static __device__ __forceinline__ uint64_t low_word(const Sum& s) { return s; }
-    template <typename Modulus>
+    template <bool BOUNDED = false, typename Modulus>
     static __device__ __forceinline__ uint64_t reduce(const Sum& s, const Modulus& m) {
         return barrett_reduce64_uniform(s, m.p, m.barrett64);
     }
-    template <typename Modulus>
+    template <bool BOUNDED = false, typename Modulus>
     static __device__ __forceinline__ uint64_t reduce_lazy(const Sum& s, const Modulus& m) { return reduce(s, m); }
     // x < 2^32, constant w < p < 2^31 (or p = 2^16 for mTilde): x w - floor(x floor(w 2^32 / p) / 2^32) p in [0, 2p)
     static __device__ __forceinline__ uint64_t shoup(uint64_t x, U64x2 c, uint64_t p) {
@@ -114,7 +120,7 @@ struct LiftLayout {
 
 // W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
 // widened when loaded and narrowed when stored; the arithmetic is the same code for both.
-template <int L, typename W>
+template <int L, typename W, bool BOUNDED>
 __global__ void __launch_bounds__(kThreads)
     lift_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys,
                 const LiftLayout layout) {
@@ -157,14 +163,14 @@ __global__ void __launch_bounds__(kThreads)
             // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
             // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
             const U64x2 scaled = tool.q_mod_bsk_scaled[j];
-            const uint64_t unfolded = A::reduce_lazy(sum, m) + A::shoup_lazy(centered, scaled, m.p);
+            const uint64_t unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
             stream_store(dst + (L + j) * n, csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p));
         }
     }
 }
 
 // ---- floorQBskToQ: in [polys][2L+1][N] -> out [polys][L][N] ------------------------------------------------------
-template <int L, typename W>
+template <int L, typename W, bool BOUNDED>
 __global__ void __launch_bounds__(kThreads)
     floor_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys) {
     using A = WordArith<W>;
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(kThreads)
             for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_ext[j * L + i]);
             // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
             // checked when the tool is built), which is all the next exact product needs
-            const uint64_t difference = stream_load(src + (L + j) * n) + A::kSlack * m.p - A::reduce_lazy(sum, m);
+            const uint64_t difference = stream_load(src + (L + j) * n) + A::kSlack * m.p - A::template reduce_lazy<BOUNDED>(sum, m);
             if (j < L) {
                 z[j] = A::shoup(difference, tool.floor_scale_b[j], m.p);
             } else {
@@ -205,8 +211,8 @@ __global__ void __launch_bounds__(kThreads)
         for (int i = 1; i < L; ++i) A::add(alpha_sum, z[i], tool.b_to_msk[i]);
         // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
         // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
-        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? A::reduce_lazy(alpha_sum, msk)  // < 5 m_sk
-                                                        : A::reduce(alpha_sum, tool.alpha_modulus[0]);
+        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? A::template reduce_lazy<BOUNDED>(alpha_sum, msk)  // < 5 m_sk
+                                                        : A::template reduce<BOUNDED>(alpha_sum, tool.alpha_modulus[0]);
         alpha = A::shoup(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
         const bool exceeds = alpha > (msk.p >> 1);
 #pragma unroll
@@ -221,9 +227,9 @@ __global__ void __launch_bounds__(kThreads)
                 // a negation and a modular add (uniform branch; the sum stays below 2^127)
                 const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
                 A::add_vector(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
-                stream_store(dst + row * n, A::reduce(sum, m));
+                stream_store(dst + row * n, A::template reduce<BOUNDED>(sum, m));
             } else {
-                const uint64_t converted = A::reduce(sum, m);
+                const uint64_t converted = A::template reduce<BOUNDED>(sum, m);
                 // the second form is the negation of alpha (B mod q), so one product serves both
                 const uint64_t magnitude = A::shoup(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
                 const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
@@ -621,8 +627,17 @@ struct LiftLauncher {
     static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, const LiftLayout& layout,
                           hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((lift_kernel<L, W>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
-                           tool, polys, layout);
+        bool bounded = false;
+        if constexpr (sizeof(W) == 8) {
+            if (tool.wide_reduce_ok != 0) {
+                bounded = true;
+                hipLaunchKernelGGL((lift_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
+                                   in, out, tool, polys, layout);
+            }
+        }
+        if (!bounded)
+            hipLaunchKernelGGL((lift_kernel<L, W, false>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in,
+                               out, tool, polys, layout);
         return hipGetLastError();
     }
 };
@@ -631,8 +646,17 @@ struct FloorLauncher {
     template <typename W>
     static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((floor_kernel<L, W>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in, out,
-                           tool, polys);
+        bool bounded = false;
+        if constexpr (sizeof(W) == 8) {
+            if (tool.wide_reduce_ok != 0) {
+                bounded = true;
+                hipLaunchKernelGGL((floor_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
+                                   in, out, tool, polys);
+            }
+        }
+        if (!bounded)
+            hipLaunchKernelGGL((floor_kernel<L, W, false>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in,
+                               out, tool, polys);
         return hipGetLastError();
     }
 };

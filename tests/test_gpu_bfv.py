@@ -387,6 +387,45 @@ def test_bfv_uint32_packed_words_round_trip(oracle):
     assert lib.he_words_widen_u32_device(misaligned.data_ptr() + 4, wide.data_ptr(), 4, None) != 0
 
 
+@pytest.mark.parametrize("degree,bits", [(64, [61] * 9), (8192, [55] * 5), (4096, [34, 60, 47, 61, 40]), (64, [61, 61, 62, 61]),
+                                         (64, [34, 33, 40])])
+def test_one_word_quotient_reductions_at_their_limits(oracle, degree, bits):
+    """The base conversions' dot products on the one-word-quotient Barrett (device_math.hpp reduce_product_sum_bounded,
+    taken when every sum of the level stays below 2^(64 + bits(p) - 1) for moduli between 2^33 and 2^61): eight 61-bit
+    ciphertext moduli (the largest sums that still qualify), BASELINE config 3's moduli, mixed widths from 34 bits up --
+    and two sets that must fall back to the general reduction (a 62-bit and a 33-bit modulus) -- on the words that
+    maximise every sum (all residues p - 1), on zeros and on uniform words, word for word against the oracle; then a
+    product through the whole pipeline."""
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    L = ours.L
+    moduli = q[:-1]
+    rng = np.random.default_rng(sum(bits))
+    for level in sorted({L, max(1, L - 1), 1}):
+        tool = ref.rns_tool(level)
+        x = _uniform(rng, (4,), moduli[:level], degree)
+        x[0] = 0
+        x[1] = np.array(moduli[:level], dtype=np.uint64)[:, None] - np.uint64(1)
+        x[2, :, ::2] = x[1, :, ::2]
+        assert np.array_equal(heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x), level)),
+                              np.stack([tool.lift_q_to_qbsk(p) for p in x])), level
+        qbsk = ref.qbsk_context(level).moduli
+        y = _uniform(rng, (5,), qbsk, degree)
+        y[0] = 0
+        y[1] = np.array(qbsk, dtype=np.uint64)[:, None] - np.uint64(1)
+        y[2, :level] = 0                      # x_Bsk maximal, the Q part zero and the other way round
+        y[2, level:] = y[1, level:]
+        y[3, :level] = y[1, :level]
+        y[3, level:] = 0
+        assert np.array_equal(heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y), level)),
+                              np.stack([tool.floor_qbsk_to_q(p) for p in y])), level
+    lhs, rhs = _uniform(rng, (2, 2), moduli, degree), _uniform(rng, (2, 2), moduli, degree)
+    lhs[0] = np.array(moduli, dtype=np.uint64)[None, :, None] - np.uint64(1)
+    rhs[0] = lhs[0]
+    assert np.array_equal(heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs))), ref.mul(lhs, rhs))
+
+
 @pytest.mark.parametrize("bits", [[62, 62, 61, 62], [62] * 9, [61, 33, 62, 45, 62]])
 def test_widest_moduli_match_oracle(oracle, bits):
     """The largest moduli the reference admits (2^62 - 1, MA/Modulus.swift:177-180) and the most rows the kernels are
