@@ -334,6 +334,14 @@ int BfvContext::build_tool(uint32_t k) {
         ok = ok && fits(bsk_sum * (m_sk - 1), arena.at<DeviceModulus>(o_ext_moduli)[L]);
         for (size_t i = 0; i < L; ++i)
             ok = ok && fits((bsk_sum + (m_sk - 1)) * (q[i] - 1), arena.at<DeviceModulus>(o_q_moduli)[i]);
+        // ... and their cross columns cannot wrap (device_math.hpp product_sum_add_uniform_short): terms x (high word of
+        // the largest residue + high word of the largest constant + 2) <= 2^32; the Q rows take one more term (alpha)
+        // through the general multiply-add, which counts its carries
+        auto high = [](u64 v) { return static_cast<unsigned __int128>(v >> 32) + 1; };
+        u64 q_max = 0, ext_max = top_m_sk;
+        for (size_t i = 0; i < L; ++i) q_max = q[i] > q_max ? q[i] : q_max;
+        for (size_t j = 0; j <= L; ++j) ext_max = bsk[j] > ext_max ? bsk[j] : ext_max;
+        ok = ok && (L + 1) * (high(q_max) + high(ext_max)) <= (static_cast<unsigned __int128>(1) << 32);
         d.wide_reduce_ok = ok ? 1u : 0u;
     }
     d.log_degree = static_cast<uint32_t>(floor_log2(degree_));

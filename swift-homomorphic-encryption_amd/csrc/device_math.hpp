@@ -588,6 +588,33 @@ __device__ __forceinline__ ProductSum product_sum_first_uniform(uint64_t a, uint
     return s;
 }
 
+// Short sums whose cross column cannot wrap -- terms (hi32(a_max) + hi32(b_max) + 2) <= 2^32, e.g. four residues of
+// 55-bit moduli times 61-bit table constants -- skip its carry counts: five instructions per product instead of seven,
+// four for the first one (the callers check the bound on the host: RnsToolDevice::wide_reduce_ok).
+__device__ __forceinline__ void product_sum_add_uniform_short(ProductSum& s, uint64_t a, uint64_t b) {
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+        "v_addc_co_u32 %3, %4, 0, %3, %4\n\t"
+        "v_mad_u64_u32 %1, %4, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %1, %4, %6, %7, %1\n\t"
+        "v_mad_u64_u32 %2, %4, %6, %8, %2"
+        : "+v"(s.t), "+v"(s.c), "+v"(s.h), "+v"(s.t_carry), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "s"(lo32(b)), "s"(hi32(b)));
+}
+__device__ __forceinline__ ProductSum product_sum_first_uniform_short(uint64_t a, uint64_t b) {
+    ProductSum s;
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %3, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1\n\t"
+        "v_mad_u64_u32 %2, %3, %5, %7, 0"
+        : "=&v"(s.t), "=&v"(s.c), "=&v"(s.h), "=&s"(carry)
+        : "v"(lo32(a)), "v"(hi32(a)), "s"(lo32(b)), "s"(hi32(b)));
+    s.t_carry = 0;
+    s.c_carry = 0;
+    return s;
+}
+
 // the same with b in VGPRs
 __device__ __forceinline__ ProductSum product_sum_first(uint64_t a, uint64_t b) {
     ProductSum s;

@@ -55,8 +55,17 @@ template <typename W>
 struct WordArith {  // uint64_t
     using Sum = ProductSum;
     static constexpr uint64_t kSlack = 5;  // a lazily reduced sum lies in [0, kSlack p)
-    static __device__ __forceinline__ Sum first(uint64_t a, uint64_t b) { return product_sum_first_uniform(a, b); }
-    static __device__ __forceinline__ void add(Sum& s, uint64_t a, uint64_t b) { product_sum_add_uniform(s, a, b); }
+    // BOUNDED (below): the cross column of the sum cannot wrap either -- its carry counts are skipped
+    template <bool BOUNDED = false>
+    static __device__ __forceinline__ Sum first(uint64_t a, uint64_t b) {
+        if constexpr (BOUNDED) return product_sum_first_uniform_short(a, b);
+        else return product_sum_first_uniform(a, b);
+    }
+    template <bool BOUNDED = false>
+    static __device__ __forceinline__ void add(Sum& s, uint64_t a, uint64_t b) {
+        if constexpr (BOUNDED) product_sum_add_uniform_short(s, a, b);
+        else product_sum_add_uniform(s, a, b);
+    }
     static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { product_sum_add(s, a, b); }
     static __device__ __forceinline__ Sum zero() { return product_sum_zero(); }
     static __device__ __forceinline__ uint64_t low_word(const Sum& s) { return product_sum_value(s).lo; }
@@ -86,7 +95,9 @@ template <>
 struct WordArith<uint32_t> {
     using Sum = uint64_t;
     static constexpr uint64_t kSlack = 1;  // sums are reduced to [0, p) at once
+    template <bool BOUNDED = false>
     static __device__ __forceinline__ Sum first(uint64_t a, uint64_t b) { return mul32(lo32(a), lo32(b)); }
+    template <bool BOUNDED = false>
     static __device__ __forceinline__ void add(Sum& s, uint64_t a, uint64_t b) { s = mad32(lo32(a), lo32(b), s); }
     static __device__ __forceinline__ void add_vector(Sum& s, uint64_t a, uint64_t b) { s = mad32(lo32(a), lo32(b), s); }
     static __device__ __forceinline__ Sum zero() { return 0; }
@@ -156,9 +167,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            typename A::Sum sum = A::first(y[0], tool.q_to_bsk_scaled[j * L + 0]);
+            typename A::Sum sum = A::template first<BOUNDED>(y[0], tool.q_to_bsk_scaled[j * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
+            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
             const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
             // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
             // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
@@ -192,9 +203,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            typename A::Sum sum = A::first(y[0], tool.q_to_ext[j * L + 0]);
+            typename A::Sum sum = A::template first<BOUNDED>(y[0], tool.q_to_ext[j * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::add(sum, y[i], tool.q_to_ext[j * L + i]);
+            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[i], tool.q_to_ext[j * L + i]);
             // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
             // checked when the tool is built), which is all the next exact product needs
             const uint64_t difference = stream_load(src + (L + j) * n) + A::kSlack * m.p - A::template reduce_lazy<BOUNDED>(sum, m);
@@ -206,9 +217,9 @@ __global__ void __launch_bounds__(kThreads)
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
         const DeviceModulus msk = tool.ext_moduli[L];
-        typename A::Sum alpha_sum = A::first(z[0], tool.b_to_msk[0]);
+        typename A::Sum alpha_sum = A::template first<BOUNDED>(z[0], tool.b_to_msk[0]);
 #pragma unroll
-        for (int i = 1; i < L; ++i) A::add(alpha_sum, z[i], tool.b_to_msk[i]);
+        for (int i = 1; i < L; ++i) A::template add<BOUNDED>(alpha_sum, z[i], tool.b_to_msk[i]);
         // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
         // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
         uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? A::template reduce_lazy<BOUNDED>(alpha_sum, msk)  // < 5 m_sk
@@ -218,9 +229,9 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
         for (int row = 0; row < L; ++row) {
             const DeviceModulus m = tool.q_moduli[row];
-            typename A::Sum sum = A::first(z[0], tool.b_to_q[row * L + 0]);
+            typename A::Sum sum = A::template first<BOUNDED>(z[0], tool.b_to_q[row * L + 0]);
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::add(sum, z[i], tool.b_to_q[row * L + i]);
+            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, z[i], tool.b_to_q[row * L + i]);
             // RnsTool.swift:436-446: + (m_sk - alpha) (B mod q) when alpha > m_sk/2, else + alpha (-B mod q)
             if (tool.floor_merge_ok != 0) {
                 // the correction is one more product of the same exact sum: one reduction instead of a Shoup product,
