@@ -24,7 +24,7 @@ constexpr int kChains = 8;     // independent dependency chains per lane
 constexpr int kUnroll = 16;    // instructions per chain per loop iteration
 constexpr int kIters = 2000;
 
-enum Probe { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, LSHL_ADD_U64, ADD_U32, ADDCO_PAIR, CNDMASK, MAD_U32_U24, MUL_HI_U32_U24, NOT_B32, FMA_F64 };
+enum Probe { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, LSHL_ADD_U64, ADD_U32, ADDCO_PAIR, CNDMASK, MAD_U32_U24, MUL_HI_U32_U24, NOT_B32, FMA_F64, CMP_GT_I64, CMP_GT_I32 };
 
 template <int PROBE>
 __global__ void __launch_bounds__(256) probe_kernel(uint64_t* out, uint32_t seed, long long* cycles) {
@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(256) probe_kernel(uint64_t* out, uint32_t seed
                     uint32_t d;
                     asm volatile("v_not_b32 %0, %1" : "=v"(d) : "v"(uint32_t(acc[c])));
                     acc[c] = d;
+                } else if constexpr (PROBE == CMP_GT_I64) {
+                    asm volatile("v_cmp_gt_i64 vcc, 0, %0" : : "v"(acc[c]) : "vcc");
+                } else if constexpr (PROBE == CMP_GT_I32) {
+                    asm volatile("v_cmp_gt_i32 vcc, 0, %0" : : "v"(uint32_t(acc[c] >> 32)) : "vcc");
                 } else if constexpr (PROBE == FMA_F64) {
                     double d;
                     asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(__longlong_as_double(acc[c])), "v"(1.0000001), "v"(0.5));
@@ -339,6 +343,8 @@ int main() {
     run_probe<MAD_U32_U24>("v_mad_u32_u24", 1);
     run_probe<MUL_HI_U32_U24>("v_mul_hi_u32_u24", 1);
     run_probe<FMA_F64>("v_fma_f64", 1);
+    run_probe<CMP_GT_I64>("v_cmp_gt_i64", 1);
+    run_probe<CMP_GT_I32>("v_cmp_gt_i32", 1);
     run_bfly<FWD_APPROX_SELECT>("fwd_approx_select", 80);
     run_bfly<FWD_APPROX_MASK>("fwd_approx_mask", 80);
     run_bfly<FWD_APPROX_MIN>("fwd_approx_min", 80);
