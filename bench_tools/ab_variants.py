@@ -1,90 +1,156 @@
-"""A/B timing of compile-time kernel experiments.
+"""A/B timing of kernel experiments kept OUT of the product sources.
 
-  python bench_tools/ab_variants.py build NAME=[FILE.hip:]-DFLAG=1 [NAME2=...]   (no GPU needed)
-      recompiles csrc/FILE.hip (default ntt_kernels.hip) with the extra flag, links it with the other objects of the
-      current build into lib/variants/libhe_amd_NAME.so
-  python bench_tools/ab_variants.py run [NAME ...]                              (on the GPU box)
-      times forward / inverse NTT (N=8192, L=4, 4096 polynomials) for the production library and every variant, each in
-      its own process (HEAMD_LIBRARY), interleaved over three rounds so that clock drift shows up as spread
+An experiment is a module bench_tools/variants/NAME.py with
+    DESCRIPTION = "..."
+    COMPILE = ["ntt_kernels.hip", ...]            # translation units to rebuild (default: the files the edits touch)
+    EDITS = [("file under csrc/", "exact old text", "new text"), ...]
+The builder copies csrc/ to a scratch directory, applies the edits (an edit whose old text is not found exactly once is
+an error: the experiment has drifted from the source and must be updated), recompiles the affected translation units
+and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
+
+  python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|c3] [--rounds N] [NAME ...]     (on the GPU box)
+      times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
+      so that clock drift shows up as spread
 """
+import concurrent.futures
 import glob
+import importlib.util
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "swift-homomorphic-encryption_amd")
+CSRC = os.path.join(PKG, "csrc")
 VARIANTS = os.path.join(PKG, "lib", "variants")
+SPECS = os.path.join(ROOT, "bench_tools", "variants")
 
-TIMER = r'''
-import os, sys
+NTT_TIMER = r'''
+import sys
 sys.path.insert(0, %r)
 import torch, heamd
-degree, batch = 8192, 4096
-moduli = heamd.generate_primes([55] * 4, False, degree)
-ctx = heamd.PolyContext(degree, moduli)
-bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, -1, 1)
-x = torch.randint(0, 1 << 62, (batch, 4, degree), dtype=torch.int64, device="cuda") %% bound
+heamd.set_scratch_cache()
 out = []
-for variant in (0, 10):  # production schedule (split butterflies for these moduli), then pinned to the [0, 8p) schedule
+for degree, count, batch in %%s:
+    moduli = heamd.generate_primes([55] * count, False, degree)
+    ctx = heamd.PolyContext(degree, moduli)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, -1, 1)
+    x = torch.randint(0, 1 << 62, (batch, count, degree), dtype=torch.int64, device="cuda") %%%% bound
     for inverse in (False, True):
+        f = ctx.inverse_ntt_ if inverse else ctx.forward_ntt_
         for _ in range(20):
-            ctx.ntt_variant_(x, inverse, variant)
+            f(x)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); a.record()
         for _ in range(50):
-            ctx.ntt_variant_(x, inverse, variant)
+            f(x)
         b.record(); b.synchronize()
-        out.append(a.elapsed_time(b) / 50)
-print("production %%.4f %%.4f   approx %%.4f %%.4f" %% tuple(out))
+        out.append("N=%%%%d %%%%s %%%%.4f" %%%% (degree, "inv" if inverse else "fwd", a.elapsed_time(b) / 50))
+print("  ".join(out))
 ''' % PKG
+SHAPES = {"ntt": [(8192, 4, 4096)], "degrees": [(4096, 2, 8192), (8192, 4, 4096), (16384, 4, 1024)]}
+C3_TIMER = ("import sys; sys.path[:0] = [%r, %r, %r]; import torch, heamd, path_bench, json; heamd.set_scratch_cache(); "
+            "r = path_bench.config3_ct_mul(torch, heamd, batch=1024, reps=5); "
+            "print('ct x ct %%.1f k/s  relinearize %%.1f k/s  both %%.1f k/s' %% (r['ct_mul_per_s'] / 1e3, "
+            "r['relinearize_per_s'] / 1e3, r['ct_mul_relinearize_per_s'] / 1e3))" % (
+                ROOT, PKG, os.path.join(ROOT, "bench_tools")))
 
 
-def build(specs):
+def load_spec(name):
+    path = os.path.join(SPECS, name + ".py")
+    spec = importlib.util.spec_from_file_location("variant_" + name, path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module
+
+
+def apply_edits(name, scratch):
+    module = load_spec(name)
+    touched = []
+    for file, old, new in module.EDITS:
+        path = os.path.join(scratch, file)
+        text = open(path).read()
+        if text.count(old) != 1:
+            raise SystemExit(f"variant {name}: expected exactly one occurrence in {file} of:\n{old}\n(found {text.count(old)})")
+        open(path, "w").write(text.replace(old, new))
+        touched.append(file)
+    units = list(dict.fromkeys(getattr(module, "COMPILE", None) or [f for f in touched if f.endswith((".hip", ".cpp"))]))
+    if not units:
+        raise SystemExit(f"variant {name}: edits touch only headers; name the translation units in COMPILE")
+    return units
+
+
+def build_one(name, product_build):
+    top = tempfile.mkdtemp(prefix=f"heamd_{name}_")
+    scratch = os.path.join(top, "package", "csrc")  # the sources include "../../include/he_amd.h"
+    try:
+        os.makedirs(scratch)
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(top, "include"))
+        for f in os.listdir(CSRC):
+            if f.endswith((".hip", ".cpp", ".hpp", ".map")):
+                shutil.copy(os.path.join(CSRC, f), scratch)
+        units = apply_edits(name, scratch)
+        stems = {os.path.splitext(u)[0] for u in units}
+        objects = [o for o in glob.glob(os.path.join(CSRC, "build", "*.o"))
+                   if os.path.splitext(os.path.basename(o))[0] not in stems]
+        for unit in units:
+            obj = os.path.join(scratch, os.path.splitext(unit)[0] + ".o")
+            cmd = [product_build._hipcc(), *product_build.FLAGS, "-c", os.path.join(scratch, unit), "-o", obj]
+            if unit.endswith(".cpp"):
+                cmd[1:1] = ["-x", "hip"]
+            subprocess.run(cmd, check=True)
+            objects.append(obj)
+        subprocess.run([product_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={product_build.ARCH}",
+                        f"-Wl,--version-script={product_build.EXPORTS}", "-o",
+                        os.path.join(VARIANTS, f"libhe_amd_{name}.so"), *objects], check=True)
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+    print("built", name, flush=True)
+
+
+def build(names):
     sys.path.insert(0, PKG)
     import build as product_build
     product_build.build()
     os.makedirs(VARIANTS, exist_ok=True)
-    def one(spec):
-        name, flag = spec.split("=", 1)
-        source = "ntt_kernels.hip"
-        if ".hip:" in flag:
-            source, flag = flag.split(":", 1)
-        stem = os.path.splitext(source)[0]
-        objects = [o for o in glob.glob(os.path.join(PKG, "csrc", "build", "*.o")) if not o.endswith(stem + ".o")]
-        obj = os.path.join(VARIANTS, f"{stem}_{name}.o")
-        subprocess.run([product_build._hipcc(), *product_build.FLAGS, *flag.split(), "-c",
-                        os.path.join(PKG, "csrc", source), "-o", obj], check=True)
-        subprocess.run([product_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={product_build.ARCH}",
-                        f"-Wl,--version-script={product_build.EXPORTS}", "-o",
-                        os.path.join(VARIANTS, f"libhe_amd_{name}.so"), obj, *objects], check=True)
-        os.unlink(obj)
-        print("built", name, flush=True)
-
-    import concurrent.futures
+    if names == ["all"]:
+        names = sorted(os.path.splitext(f)[0] for f in os.listdir(SPECS) if f.endswith(".py") and not f.startswith("_"))
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
-        list(pool.map(one, specs))
+        list(pool.map(lambda n: build_one(n, product_build), names))
 
 
-def run(names):
+def run(args):
+    what, rounds, names = "ntt", 3, []
+    while args:
+        a = args.pop(0)
+        if a == "--what":
+            what = args.pop(0)
+        elif a == "--rounds":
+            rounds = int(args.pop(0))
+        else:
+            names.append(a)
+    timer = C3_TIMER if what == "c3" else NTT_TIMER % repr(SHAPES[what])
     libs = {"production": None}
     for path in sorted(glob.glob(os.path.join(VARIANTS, "libhe_amd_*.so"))):
         name = os.path.basename(path)[len("libhe_amd_"):-3]
         if not names or name in names:
             libs[name] = path
-    for round_index in range(3):
+    for round_index in range(rounds):
         for name, path in libs.items():
             env = dict(os.environ)
             if path:
                 env["HEAMD_LIBRARY"] = path
-            result = subprocess.run([sys.executable, "-c", TIMER], env=env, capture_output=True, text=True)
+            result = subprocess.run([sys.executable, "-c", timer], env=env, capture_output=True, text=True)
             line = result.stdout.strip().splitlines()[-1] if result.returncode == 0 and result.stdout.strip() else (
                 "FAILED " + result.stderr[-300:])
-            print(f"round {round_index}  {name:24s} fwd/inv ms: {line}", flush=True)
+            print(f"round {round_index}  {name:24s} {line}", flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) >= 2 and sys.argv[1] == "build":
         build(sys.argv[2:])
     else:
-        run(sys.argv[2:])
+        run(sys.argv[2:] if len(sys.argv) >= 2 and sys.argv[1] == "run" else sys.argv[1:])

@@ -70,6 +70,9 @@ const char* he_version(void);
 
 /* ---- device plumbing (so a Swift host never has to link HIP) ---- */
 int he_device_count(int* out_count);
+int he_get_device(int* out_device); /* the calling thread's current HIP device: contexts and buffers belong to the device
+                                     * that was current when they were created (HE_ERR_DEVICE on any other) */
+int he_set_device(int device);
 int he_device_malloc(void** out_ptr, size_t bytes);
 int he_device_free(void* ptr);
 int he_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, he_stream stream);
@@ -77,6 +80,13 @@ int he_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, he_strea
 int he_stream_synchronize(he_stream stream);
 int he_stream_create(he_stream* out);   /* a non-blocking HIP stream */
 int he_stream_destroy(he_stream stream);
+/* Scratch of the `_device` calls that take no workspace comes stream-ordered from a memory pool the library owns (one per
+ * device, never the process's default pool).  By default nothing is retained: freed scratch returns to the driver at the
+ * next synchronisation.  he_set_scratch_cache(bytes) lets the current device's pool keep up to `bytes` of freed scratch
+ * (UINT64_MAX: everything) -- what a server that expands queries sets once, because mapping tens of gigabytes per call
+ * costs seconds; he_device_trim_scratch(keep_bytes) hands everything above `keep_bytes` back. */
+int he_set_scratch_cache(uint64_t bytes);
+int he_device_trim_scratch(uint64_t keep_bytes);
 
 /* ---- completion primitives: what the reference's `...Async` twins (HomomorphicEncryption/HeSchemeAsync.swift:16-141)
  * await.  A Swift `async` wrapper enqueues the `_device` call and then either suspends in a continuation resumed by

@@ -32,25 +32,12 @@ inline int invalid_argument(const char* what) {
     return HE_ERR_INVALID_ARGUMENT;
 }
 
-// Stream-ordered scratch comes from the current device's default memory pool.  With the pool's default release
-// threshold (0) every freed block goes back to the driver at the next synchronisation and the next call pays for mapping
-// it again -- seconds for the tens of gigabytes a batched query expansion takes.  The first scratch allocation on a
-// device therefore raises the threshold so that freed scratch stays cached in the pool (what a caller of
-// hipMallocAsync is expected to configure; callers that want fixed memory pass workspaces instead).
-inline void keep_scratch_cached() {
-    static std::atomic<uint64_t> configured{0};  // bit per device ordinal < 64
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return;
-    const uint64_t bit = uint64_t(1) << device;
-    if (configured.load(std::memory_order_relaxed) & bit) return;
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr) {
-        uint64_t threshold = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
-    }
-    (void)hipGetLastError();
-    configured.fetch_or(bit, std::memory_order_relaxed);
-}
+// Stream-ordered scratch comes from a memory pool the LIBRARY owns (one per device, created on first use; c_api.cpp) --
+// never from the device's default pool, which belongs to the host process and its other HIP users.  The pool's release
+// threshold is 0 unless the host opts in with he_set_scratch_cache(bytes): freed scratch then goes back to the driver at
+// the next synchronisation.  A server that expands queries (tens of gigabytes of scratch per call) sets the threshold
+// once and gives memory back with he_device_trim_scratch.
+hipError_t scratch_allocate(void** out, size_t bytes, hipStream_t stream);
 
 // The recursion tree of PirUtil.expand for one (ciphertext count, output count) on one ring: the data movement of every
 // level (pir_api.cpp).  Planned on the first use, kept by the context with its table on the device, so that later
@@ -98,7 +85,7 @@ int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t*
                           const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
 
-// Stream-ordered scratch buffer (hipMallocAsync / hipFreeAsync on the same stream).
+// Stream-ordered scratch buffer (scratch_allocate / hipFreeAsync on the same stream).
 class Scratch {
   public:
     explicit Scratch(hipStream_t stream) : stream_(stream) {}
@@ -107,10 +94,7 @@ class Scratch {
     }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
-    hipError_t allocate(size_t bytes) {
-        keep_scratch_cached();
-        return hipMallocAsync(&ptr_, bytes ? bytes : 1, stream_);
-    }
+    hipError_t allocate(size_t bytes) { return scratch_allocate(&ptr_, bytes ? bytes : 1, stream_); }
     void* get() const { return ptr_; }
 
   private:

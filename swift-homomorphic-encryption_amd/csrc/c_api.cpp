@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,51 @@ int elementwise(const he_poly_context* ctx, heamd::ElementwiseOp op, uint64_t* l
 
 }  // namespace
 
+// ---- the library's own scratch pools (api_internal.hpp scratch_allocate) ----
+namespace {
+constexpr int kMaxDevices = 64;
+struct ScratchPools {
+    std::mutex mutex;
+    hipMemPool_t pool[kMaxDevices] = {};
+    bool failed[kMaxDevices] = {};  // pool creation refused: fall back to the default pool, untouched
+    uint64_t threshold[kMaxDevices] = {};
+};
+ScratchPools& scratch_pools() {
+    static ScratchPools* pools = new ScratchPools();  // never destroyed: HIP may already be gone at exit
+    return *pools;
+}
+// the current device's pool, or nullptr
+hipMemPool_t scratch_pool(int* device_out = nullptr) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
+    if (device_out != nullptr) *device_out = device;
+    ScratchPools& pools = scratch_pools();
+    std::lock_guard<std::mutex> lock(pools.mutex);
+    if (pools.pool[device] == nullptr && !pools.failed[device]) {
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = device;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool != nullptr) {
+            uint64_t threshold = pools.threshold[device];
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+            pools.pool[device] = pool;
+        } else {
+            pools.failed[device] = true;
+        }
+        (void)hipGetLastError();
+    }
+    return pools.pool[device];
+}
+}  // namespace
+
+hipError_t heamd::scratch_allocate(void** out, size_t bytes, hipStream_t stream) {
+    if (hipMemPool_t pool = scratch_pool(); pool != nullptr) return hipMallocFromPoolAsync(out, bytes, pool, stream);
+    return hipMallocAsync(out, bytes, stream);
+}
+
 extern "C" {
 
 const char* he_status_string(int status) {
@@ -129,6 +175,37 @@ int he_device_count(int* out_count) {
     HEAMD_HIP_TRY(hipGetDeviceCount(out_count));
     return HE_OK;
 }
+int he_get_device(int* out_device) {
+    if (out_device == nullptr) return invalid_argument("null out_device");
+    HEAMD_HIP_TRY(hipGetDevice(out_device));
+    return HE_OK;
+}
+int he_set_device(int device) {
+    HEAMD_HIP_TRY(hipSetDevice(device));
+    return HE_OK;
+}
+
+int he_set_scratch_cache(uint64_t bytes) {
+    int device = 0;
+    hipMemPool_t pool = scratch_pool(&device);
+    if (pool == nullptr) {
+        heamd::set_last_error("no library scratch pool on this device");
+        return HE_ERR_DEVICE;
+    }
+    ScratchPools& pools = scratch_pools();
+    std::lock_guard<std::mutex> lock(pools.mutex);
+    uint64_t threshold = bytes;
+    HEAMD_HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
+    pools.threshold[device] = bytes;
+    return HE_OK;
+}
+int he_device_trim_scratch(uint64_t keep_bytes) {
+    hipMemPool_t pool = scratch_pool();
+    if (pool == nullptr) return HE_OK;  // nothing cached
+    HEAMD_HIP_TRY(hipMemPoolTrimTo(pool, static_cast<size_t>(keep_bytes)));
+    return HE_OK;
+}
+
 int he_device_malloc(void** out_ptr, size_t bytes) {
     if (out_ptr == nullptr) return invalid_argument("null out_ptr");
     *out_ptr = nullptr;

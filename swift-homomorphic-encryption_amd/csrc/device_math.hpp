@@ -24,54 +24,30 @@ struct alignas(16) U64x2 {
 
 // 16-byte loads / stores of words that are touched once per launch (polynomial slabs streamed through a kernel):
 // non-temporal, so that they pass the caches without displacing what other workgroups re-read (constant tables,
-// shared operand tiles).  HEAMD_X_CACHED_STREAMS (experiment) restores the default policy.
+// shared operand tiles).
 typedef unsigned long long StreamWords __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ U64x2 stream_load(const U64x2* p) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    return *p;
-#else
     const StreamWords v = __builtin_nontemporal_load(reinterpret_cast<const StreamWords*>(p));
     return U64x2{v.x, v.y};
-#endif
 }
 __device__ __forceinline__ void stream_store(U64x2* p, U64x2 value) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    *p = value;
-#else
     const StreamWords v = {value.x, value.y};
     __builtin_nontemporal_store(v, reinterpret_cast<StreamWords*>(p));
-#endif
 }
 
 // the 8-byte forms (one word per lane: the per-coefficient BEHZ kernels)
 __device__ __forceinline__ uint64_t stream_load(const uint64_t* p) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 __device__ __forceinline__ void stream_store(uint64_t* p, uint64_t value) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    *p = value;
-#else
     __builtin_nontemporal_store(value, p);
-#endif
 }
 // 4-byte slabs (PolyRq<UInt32> / Bfv<UInt32>): the word is widened in the register, never in memory
 __device__ __forceinline__ uint64_t stream_load(const uint32_t* p) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 __device__ __forceinline__ void stream_store(uint32_t* p, uint64_t value) {
-#ifdef HEAMD_X_CACHED_STREAMS
-    *p = static_cast<uint32_t>(value);
-#else
     __builtin_nontemporal_store(static_cast<uint32_t>(value), p);
-#endif
 }
 
 __device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
@@ -82,20 +58,13 @@ __device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) {
     return static_cast<uint64_t>(a) * b + c;
 }
 __device__ __forceinline__ uint64_t mul32(uint32_t a, uint32_t b) { return static_cast<uint64_t>(a) * b; }
-#ifndef HEAMD_MULHI_VIA_MAD
-#define HEAMD_MULHI_VIA_MAD 1
-#endif
 // High half of a 32x32 product.  v_mul_hi_u32 issues at about half the rate of v_mad_u64_u32 on gfx950
 // (profiles/r01_microbench_instruction_rates.txt: 20.4 vs 36.3 T lane-ops/s), so take the high register of a full
 // multiply-add instead; asm because hipcc would narrow `(uint64_t(a) * b) >> 32` back to v_mul_hi_u32.
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if HEAMD_MULHI_VIA_MAD
     uint64_t d, carry;
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
     return static_cast<uint32_t>(d >> 32);
-#else
-    return __umulhi(a, b);
-#endif
 }
 // asm on purpose: with a plain `a * b` hipcc recognises the schoolbook pattern below, rebuilds a 64/128-bit multiply
 // and re-expands it with redundant (even multiply-by-zero) v_mad_u64_u32.

@@ -47,9 +47,7 @@ static_assert(lds_slot(512) == 592 && lds_slot_scheme<3>(511) < 592, "all scheme
 template <int LOGN, int LOGE, int LO_A, int LO_B>
 constexpr int transpose_scheme() {
     constexpr int low = LO_A < LO_B ? LO_A : LO_B;
-#ifndef HEAMD_X_ONE_LDS_SCHEME  // (A/B hook: the single padding rule everywhere)
     if constexpr (LOGN == 13 && LOGE == 3) return low == 7 ? 1 : low == 4 ? 2 : low == 1 ? 3 : 0;
-#endif
     return 0;
 }
 
@@ -309,13 +307,9 @@ constexpr int pass_index_in_stage(int k) { return PassWalk<LOGE, W, INVERSE>::kT
 
 template <int LOGN, int LOGE, int LO, int W, bool UNIFORM_TWIDDLES>
 constexpr bool stage_is_uniform(int b) {
-#ifdef HEAMD_X_UNIFORM_TW  // experiment (wrong results): every twiddle fetch is a scalar load, no gathers
-    return true;
-#else
     // When the six in-wave lane bits all sit at or below b the twiddle index is the same for the whole wave: read it
     // through the scalar cache into SGPRs.
     return UNIFORM_TWIDDLES || (element_index<LOGN, LOGE, LO, W>(0, 63u) >> (b + 1)) == 0;
-#endif
 }
 
 // k-th twiddle of a forward pass (stages from the top bit of the pass down)
@@ -528,20 +522,12 @@ __device__ __forceinline__ void lds_load(uint64_t (&v)[1 << LOGE], uint32_t tid,
 // default policy (profiles/r02j_ntt_policy_by_degree.txt).  aux bit 1 = nt on gfx940+.
 template <int LOGN>
 constexpr int row_policy() {
-#ifdef HEAMD_X_CACHED_ROWS  // experiment: the default cache policy everywhere
-    return 0;
-#else
     return LOGN >= 13 ? 2 : 0;
-#endif
 }
-// loads may take another policy than stores (experiment hook; production: the same)
+// loads may take another policy than stores (production: the same; profiles/r02k_row_load_policy.txt)
 template <int LOGN>
 constexpr int row_load_policy() {
-#ifdef HEAMD_X_ROW_LOAD_POLICY
-    return HEAMD_X_ROW_LOAD_POLICY;
-#else
     return row_policy<LOGN>();
-#endif
 }
 // POLICY: row_policy<LOGN>() for rows nobody else reads; 0 (cached) for source rows that several workgroups of a replica set
 // read (ntt_kernels.hip locate_replica: the others are meant to hit in L2)

@@ -26,35 +26,6 @@
 #include "ntt_common.hpp"
 #include "placement.hpp"
 
-// Experiment hooks of the forward kernel (bench_tools/ab_variants.py builds variant libraries with -DHEAMD_X_...; the
-// production build defines none of them and every hook is the plain statement).  Variants that drop work compute
-// WRONG results and exist only in lib/variants/ for timing.
-#ifdef HEAMD_X_NO_LOAD
-#define HEAMD_X_LOAD(statement)                                                     \
-    _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) v[k][r_] = (tid * 2654435761u + r_ + k) % p
-#else
-#define HEAMD_X_LOAD(statement) statement
-#endif
-#ifdef HEAMD_X_NO_STORE
-#define HEAMD_X_STORE(statement)                                                    \
-    do {                                                                            \
-        uint64_t sum_ = 0;                                                          \
-        _Pragma("unroll") for (int r_ = 0; r_ < E; ++r_) sum_ ^= v[k][r_];          \
-        if (sum_ == 0x123456789ull) statement;                                      \
-    } while (0)
-#else
-#define HEAMD_X_STORE(statement) statement
-#endif
-#ifdef HEAMD_X_NO_LDS
-#define HEAMD_X_LDS(statement) (void)0
-#else
-#define HEAMD_X_LDS(statement) statement
-#endif
-#ifdef HEAMD_X_NO_PASS
-#define HEAMD_X_PASS(statement) (void)0
-#else
-#define HEAMD_X_PASS(statement) statement
-#endif
 namespace heamd {
 
 namespace {
@@ -146,7 +117,6 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // the per-transpose rules (profiles/r02ze_lds_schemes.txt).
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS, bool PER_TRANSPOSE = true>
 __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
-#ifndef HEAMD_X_NO_LDS
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
         constexpr int SCHEME = PER_TRANSPOSE ? transpose_scheme<LOGN, LOGE, LO_FROM, LO_TO>() : 0;
@@ -155,7 +125,6 @@ __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_
         lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
         lds_load<LOGN, LOGE, LO_TO, W_TO, SCHEME>(v[row], tid, lds);
     }
-#endif
 }
 
 // ROWS residue rows of one modulus, registers to registers: in -- the words of the top pass
@@ -167,46 +136,40 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
                                             uint64_t p, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int LO0 = LOGN - LOGE;
-#ifndef HEAMD_X_NO_PASS
     forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS>(
         v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
-#endif
     if constexpr (S::P >= 3) {
         constexpr int LO1 = LOGN - 2 * LOGE;
         const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, tid);
         exchange<LOGN, LOGE, LO0, LOGE, LO1, LOGE, ROWS>(v, tid, lds);
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+        forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
     }
     if constexpr (S::P >= 4) {
         constexpr int LO1 = LOGN - 2 * LOGE, LO2 = LOGN - 3 * LOGE;
         const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, tid);
         exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, tid, lds);
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+        forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
     }
     if constexpr (S::P >= 5) {
         constexpr int LO2 = LOGN - 3 * LOGE, LO3 = LOGN - 4 * LOGE;
         const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, tid);
         exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, tid, lds);
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+        forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
     }
     {
         constexpr int LO_PREVIOUS = LOGN - (S::P - 1) * LOGE;
         const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, tid);
         exchange<LOGN, LOGE, LO_PREVIOUS, LOGE, 0, S::R, ROWS>(v, tid, lds);
-        HEAMD_X_PASS((forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, tid, tw, p, false, first)));
+        forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, tid, tw, p, false, first);
     }
-    HEAMD_X_PASS((canonicalize_all<MODE>(v, p)));
+    canonicalize_all<MODE>(v, p);
 }
 
 // One inverse pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout of pass
 // (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
 // transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
-#ifdef HEAMD_X_INVERSE_EARLY_FIRST
-constexpr bool kInverseFirstTwiddleEarly = true;
-#else
 constexpr bool kInverseFirstTwiddleEarly = false;
-#endif
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
@@ -214,7 +177,7 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
     if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, MODE != kModeSplit>(v, tid, lds);
     if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
-    HEAMD_X_PASS((inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first)));
+    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first);
 }
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
@@ -224,8 +187,8 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
                                             const DeviceModulus& mod, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
-    HEAMD_X_PASS((inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS>(
-        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid))));
+    inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS>(
+        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid));
     if constexpr (S::P >= 3) inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 4) inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 5)
@@ -339,16 +302,16 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         } else {
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
-                HEAMD_X_LOAD((global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
+                global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         }
         forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, p, lds);
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             const BufferResource out = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
             if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
-                HEAMD_X_STORE((global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds)));
+                global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds);
             } else {
-                HEAMD_X_STORE((global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out)));
+                global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out);
             }
         }
     }
@@ -488,9 +451,9 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             for (int k = 0; k < ROWS; ++k) {
                 const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
                 if constexpr (kStagedLoad<LOGN, LOGE, S::R>) {
-                    HEAMD_X_LOAD((global_load_staged<LOGN, LOGE, S::R>(v[k], tid, in, lds)));
+                    global_load_staged<LOGN, LOGE, S::R>(v[k], tid, in, lds);
                 } else {
-                    HEAMD_X_LOAD((global_load<LOGN, LOGE, 0, S::R>(v[k], tid, in)));
+                    global_load<LOGN, LOGE, 0, S::R>(v[k], tid, in);
                 }
             }
         }
@@ -498,7 +461,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         constexpr int LOL = LOGN - LOGE;
 #pragma unroll
         for (int k = 0; k < ROWS; ++k)
-            HEAMD_X_STORE((global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN))));
+            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
     }
 }
 
@@ -593,27 +556,20 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
-#ifndef HEAMD_X_ROWS
-#define HEAMD_X_ROWS 2
-#endif
+constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
-constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? HEAMD_X_ROWS : 1;
+constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? kRowGroup : 1;
 
 // Rows per workgroup of the fused-load inverse kernels.  Their loads hold far more registers than a plain row load (the
 // key MAC's carry-counting sums, the tensor's four operand streams), so a second row spills: measured on ct x ct +
 // relinearize (profiles/r02i_c3_fused_row_groups.txt), two rows lose 6 % on the key MAC (104 bytes of scratch per lane)
 // and gain nothing on the tensor load -- one row each.  (The fused FORWARD loads -- spread, lift -- are plain row loads
 // and do run two rows per workgroup: relinearize +7 %, convertToEvalFormat +21 %.)
-#ifndef HEAMD_X_TENSOR_ROWS
-#define HEAMD_X_TENSOR_ROWS 1
-#endif
-#ifndef HEAMD_X_KEYMAC_ROWS
-#define HEAMD_X_KEYMAC_ROWS 1
-#endif
+constexpr int kTensorRowGroup = 1, kKeyMacRowGroup = 1;
 template <int LOGN, int LOGT>
-constexpr int kTensorRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? HEAMD_X_TENSOR_ROWS : 1;
+constexpr int kTensorRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kTensorRowGroup : 1;
 template <int LOGN, int LOGT>
-constexpr int kKeyMacRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? HEAMD_X_KEYMAC_ROWS : 1;
+constexpr int kKeyMacRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kKeyMacRowGroup : 1;
 
 template <int LOGN, int LOGT, int SPREAD, int ROWS>
 hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,

@@ -13,10 +13,6 @@ namespace heamd {
 // the last multiple of 8 keep the plain order.  Performance only: any placement computes the same thing.
 __device__ __forceinline__ void locate_replica(uint32_t block, uint32_t sets, uint32_t replicas, uint32_t& set,
                                                uint32_t& replica) {
-#ifdef HEAMD_X_NO_XCD_SETS
-    set = block / replicas;
-    replica = block - set * replicas;
-#else
     constexpr uint32_t kXcds = 8;
     const uint32_t full = sets & ~(kXcds - 1);
     if (block < full * replicas) {
@@ -28,7 +24,6 @@ __device__ __forceinline__ void locate_replica(uint32_t block, uint32_t sets, ui
         set = full + q;
         replica = rest - q * replicas;
     }
-#endif
     // the divisions by a run-time count go through the vector ALU: hand the (wave-uniform) results back to scalar
     // registers explicitly, so that everything derived from them (moduli, table bases, row offsets) stays scalar
     set = __builtin_amdgcn_readfirstlane(set);

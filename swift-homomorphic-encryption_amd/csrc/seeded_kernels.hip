@@ -252,11 +252,7 @@ __global__ void __launch_bounds__(64)
     }
 }
 
-#ifdef HEAMD_X_AES_TABLE_COPIES  // experiment hook (bench_tools/ab_variants.py)
-constexpr int kTableCopies = HEAMD_X_AES_TABLE_COPIES;
-#else
-constexpr int kTableCopies = 16;
-#endif
+constexpr int kTableCopies = 16;  // interleaved copies of the AES T-table in LDS (profiles/r02n_wire_format_table_copies.txt)
 constexpr int kStreamWaves = 4;
 
 // the 256 counter blocks of one (seed, chunk) per wavefront, 4 per lane

@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     BfvContext32,
     HeError,
     PolyContext,
+    current_device,
     device_count,
     galois_element_rotating_columns,
     galois_element_swapping_rows,
@@ -19,10 +20,13 @@ from .binding import (  # noqa: F401
     library_path,
     load_library,
     narrow_u64,
+    set_device,
+    set_scratch_cache,
     to_device,
     to_device32,
     to_host,
     to_host32,
+    trim_scratch,
     version,
     widen_u32,
 )

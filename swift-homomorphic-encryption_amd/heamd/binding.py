@@ -41,6 +41,10 @@ SIGNATURES = [
     ("he_last_error_message", ctypes.c_char_p, []),
     ("he_version", ctypes.c_char_p, []),
     ("he_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("he_get_device", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("he_set_device", ctypes.c_int, [ctypes.c_int]),
+    ("he_set_scratch_cache", ctypes.c_int, [c_u64]),
+    ("he_device_trim_scratch", ctypes.c_int, [c_u64]),
     ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
     ("he_device_free", ctypes.c_int, [vp]),
     ("he_memcpy_h2d", ctypes.c_int, [vp, vp, c_size, vp]),
@@ -227,6 +231,25 @@ def device_count():
     n = ctypes.c_int(0)
     _check(load_library().he_device_count(ctypes.byref(n)))
     return n.value
+
+
+def current_device():
+    n = ctypes.c_int(0)
+    _check(load_library().he_get_device(ctypes.byref(n)))
+    return n.value
+
+
+def set_device(device):
+    _check(load_library().he_set_device(device))
+
+
+def set_scratch_cache(nbytes=2**64 - 1):
+    """Let the library's scratch pool of the current device keep up to `nbytes` of freed scratch (default: all)."""
+    _check(load_library().he_set_scratch_cache(nbytes))
+
+
+def trim_scratch(keep_bytes=0):
+    _check(load_library().he_device_trim_scratch(keep_bytes))
 
 
 def widen_u32(slab32, stream=None):
