@@ -611,20 +611,32 @@ __device__ __forceinline__ void global_store_staged(uint64_t (&v)[1 << LOGE], ui
 template <int LOGN, int LOGE, int W>
 constexpr bool kStagedLoad = W >= 2 && W <= 3 && kWaveOwnsTopBits<LOGN, LOGE, 0>;
 
+// in two halves, so that a workgroup that walks over rows can have the next row's chunks in flight while it transforms
+// the current one: the request (registers only) and the pick-up through the wave's slice of the tile
+template <int LOGN, int LOGE, int W>
+struct StagedChunks {
+    Dwordx4 words[1 << (LOGE - W)][1 << (W - 1)];
+};
 template <int LOGN, int LOGE, int W, int POLICY = row_load_policy<LOGN>()>
-__device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row, uint64_t* lds) {
+__device__ __forceinline__ void global_load_staged_request(StagedChunks<LOGN, LOGE, W>& chunks, uint32_t tid, BufferResource row) {
     constexpr int C = 1 << (W - 1);
     constexpr int RUNS = 1 << (LOGE - W);
     const uint32_t lane = tid & 63u;
-    const uint32_t swizzle = (lane >> (4 - (W - 1))) & (C - 1);
-    Dwordx4 words[RUNS][C];
 #pragma unroll
     for (int run = 0; run < RUNS; ++run) {
         const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u) | register_part<LOGN, LOGE, 0, W>(run << W);
 #pragma unroll
         for (int j = 0; j < C; ++j)
-            words[run][j] = __builtin_amdgcn_raw_buffer_load_b128(row, (first << 3) + (lane << 4), j << 10, POLICY);
+            chunks.words[run][j] = __builtin_amdgcn_raw_buffer_load_b128(row, (first << 3) + (lane << 4), j << 10, POLICY);
     }
+}
+template <int LOGN, int LOGE, int W>
+__device__ __forceinline__ void global_load_staged_unpack(uint64_t (&v)[1 << LOGE], const StagedChunks<LOGN, LOGE, W>& chunks,
+                                                          uint32_t tid, uint64_t* lds) {
+    constexpr int C = 1 << (W - 1);
+    constexpr int RUNS = 1 << (LOGE - W);
+    const uint32_t lane = tid & 63u;
+    const uint32_t swizzle = (lane >> (4 - (W - 1))) & (C - 1);
 #pragma unroll
     for (int run = 0; run < RUNS; ++run) {
         const uint32_t first = lane_part<LOGN, LOGE, 0, W>(tid & ~63u) | register_part<LOGN, LOGE, 0, W>(run << W);
@@ -633,8 +645,9 @@ __device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uin
         for (int j = 0; j < C; ++j) {
             const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
             const uint32_t owner_swizzle = (owner >> (4 - (W - 1))) & (C - 1);
+            const Dwordx4 w = chunks.words[run][j];
             *reinterpret_cast<U64x2*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4)) =
-                U64x2{pack64(words[run][j].x, words[run][j].y), pack64(words[run][j].z, words[run][j].w)};
+                U64x2{pack64(w.x, w.y), pack64(w.z, w.w)};
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -643,6 +656,12 @@ __device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uin
             v[(run << W) + 2 * j + 1] = pair.y;
         }
     }
+}
+template <int LOGN, int LOGE, int W, int POLICY = row_load_policy<LOGN>()>
+__device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uint32_t tid, BufferResource row, uint64_t* lds) {
+    StagedChunks<LOGN, LOGE, W> chunks;
+    global_load_staged_request<LOGN, LOGE, W, POLICY>(chunks, tid, row);
+    global_load_staged_unpack<LOGN, LOGE, W>(v, chunks, tid, lds);
 }
 
 template <int MODE>

@@ -182,9 +182,15 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED>
+// `before_top_pass` runs once, ahead of the last exchange: from there on the transform gathers nothing (the top pass's
+// twiddles are scalar loads), which is where a streamed workgroup requests its next row.
+struct Nothing {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, typename BeforeTopPass = Nothing>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                            const DeviceModulus& mod, uint64_t* lds) {
+                                            const DeviceModulus& mod, uint64_t* lds,
+                                            BeforeTopPass before_top_pass = BeforeTopPass{}) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
     inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS>(
@@ -194,6 +200,7 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
     if constexpr (S::P >= 5)
         inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
     // into the top pass (uniform twiddles; its last stage folds in N^-1)
+    before_top_pass();
     if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
     else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
 }
@@ -465,6 +472,102 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     }
 }
 
+// The constants of a modulus, read through the constant address space: inside a loop that also stores to global memory
+// the compiler no longer proves the table unclobbered and would fetch it with vector loads (whose in-order return would
+// then wait for everything in flight).  The tables never change while a context lives.
+__device__ __forceinline__ DeviceModulus load_modulus(const DeviceContext& ctx, uint32_t modulus_index) {
+    using ConstWord = const __attribute__((address_space(4))) uint64_t;
+    static_assert(sizeof(DeviceModulus) % sizeof(uint64_t) == 0, "copied word by word");
+    constexpr int kWords = sizeof(DeviceModulus) / sizeof(uint64_t);
+    ConstWord* const source = (ConstWord*)(ctx.moduli + modulus_index);
+    union {
+        DeviceModulus modulus;
+        uint64_t words[kWords];
+    } copy;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) copy.words[i] = source[i];  // (the unused ones fold away)
+    return copy.modulus;
+}
+
+// ---- streamed transforms: where a row fills the CU's LDS (N = 16384: one workgroup of 4 waves per SIMD per CU whatever
+// the kernel does), a workgroup per CU walks over rows g, g + G, g + 2G, ... and keeps the NEXT row's words in flight while
+// it transforms the current one -- the register budget of 4 waves per SIMD (128) has room for both.  Vector-memory data
+// returns in order, so the request is placed where the transform does not gather for a while (the first forward passes
+// and the last inverse pass take their twiddles through the scalar cache): a gather issued right behind it would wait
+// for the whole row to arrive from HBM.  The tile is handed from row to row with one workgroup barrier.
+template <int LOGN, int LOGT, int MODE>
+__global__ void __launch_bounds__(1 << LOGT, 4)
+    ntt_forward_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
+    constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LO0 = LOGN - LOGE;
+    using S = Schedule<LOGN, LOGE>;
+    static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    uint64_t v[1][E], next[E];
+    uint32_t unit = blockIdx.x, record, within;
+    size_t rows[1];
+    locate_rows<1>(map, unit, rows, record, within);
+    global_load<LOGN, LOGE, LO0, LOGE>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[0][r] = next[r];
+        const size_t row = rows[0];
+        const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);  // (scalar loads of its constants)
+        // the row after this one (the last row again once there is none: a load behind a branch would drain the queue)
+        const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
+        locate_rows<1>(map, following, rows, record, within);
+        global_load<LOGN, LOGE, LO0, LOGE>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
+        __builtin_amdgcn_sched_barrier(0);
+        const DeviceModulus mod = load_modulus(ctx, mi);
+        const Twiddles<MODE> tw(ctx, false, mi, LOGN);
+        forward_row<LOGN, LOGE, MODE, 1>(v, tid, tw, mod.p, lds);
+        const BufferResource out = make_resource(slab + (row << LOGN), 8u << LOGN);
+        if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
+            global_store_staged<LOGN, LOGE, S::R>(v[0], tid, out, lds);
+        } else {
+            global_store<LOGN, LOGE, 0, S::R>(v[0], tid, out);
+        }
+        if (following == unit) break;
+        unit = following;
+        __syncthreads();  // every wave is done with the tile before the next row's first exchange writes into it
+    }
+}
+
+template <int LOGN, int LOGT, int MODE, bool SCALED>
+__global__ void __launch_bounds__(1 << LOGT, 4)
+    ntt_inverse_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
+    constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LOL = LOGN - LOGE;
+    using S = Schedule<LOGN, LOGE>;
+    static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
+    static_assert(kStagedLoad<LOGN, LOGE, S::R>, "the next row waits as the 16-byte chunks of the staged load");
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    uint64_t v[1][E];
+    StagedChunks<LOGN, LOGE, S::R> next;
+    uint32_t unit = blockIdx.x, record, within;
+    size_t rows[1];
+    locate_rows<1>(map, unit, rows, record, within);
+    global_load_staged_request<LOGN, LOGE, S::R>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
+    for (;;) {
+        global_load_staged_unpack<LOGN, LOGE, S::R>(v[0], next, tid, lds);
+        const size_t row = rows[0];
+        const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);
+        const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
+        locate_rows<1>(map, following, rows, record, within);
+        const BufferResource next_row = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
+        const DeviceModulus mod = load_modulus(ctx, mi);
+        const Twiddles<MODE> tw(ctx, true, mi, LOGN);
+        inverse_row<LOGN, LOGE, MODE, 1, SCALED>(v, tid, tw, mod, lds, [&]() {
+            global_load_staged_request<LOGN, LOGE, S::R>(next, tid, next_row);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        global_store<LOGN, LOGE, LOL, LOGE>(v[0], tid, make_resource(slab + (row << LOGN), 8u << LOGN));
+        if (following == unit) break;
+        unit = following;
+        __syncthreads();  // the staged pick-up of the next row writes into the tile
+    }
+}
+
 // ---- any power-of-two degree: one workgroup per row, radix-2 stage loop over an LDS (or, for rows that do not
 // fit, global-memory) buffer.  Exact Harvey butterflies in [0, 4p): valid for every modulus <= 2^62 - 1. ---------
 template <bool USE_LDS>
@@ -621,11 +724,62 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     return hipGetLastError();
 }
 
+// Streamed launches (ntt_forward_streamed / ntt_inverse_streamed): for the shapes whose tile leaves room for one workgroup
+// per CU, one workgroup per CU and rows dealt round-robin.
+template <int LOGN, int LOGT>
+constexpr bool kStreamedRows = kRowsPerWorkgroup<LOGN, LOGT> == 1 && Schedule<LOGN, LOGN - LOGT>::P >= 2 &&
+                               lds_words(1u << LOGN) * sizeof(uint64_t) > 80 * 1024 &&
+                               kStagedLoad<LOGN, LOGN - LOGT, Schedule<LOGN, LOGN - LOGT>::R>;
+inline unsigned compute_units() {
+    static int cached[64] = {};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 256;
+    if (cached[device] == 0) {
+        int count = 0;
+        if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) count = 256;
+        cached[device] = count;
+    }
+    return static_cast<unsigned>(cached[device]);
+}
+template <int LOGN, int LOGT>
+hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+                           hipStream_t stream) {
+    constexpr size_t lds_bytes = lds_words(1u << LOGN) * sizeof(uint64_t);
+    const unsigned workgroups = rows < compute_units() ? static_cast<unsigned>(rows) : compute_units();
+    const uint32_t total = static_cast<uint32_t>(rows);
+    if (!inverse) {
+        auto kernel = mode == kModeSplit    ? ntt_forward_streamed<LOGN, LOGT, kModeSplit>
+                      : mode == kModeApprox ? ntt_forward_streamed<LOGN, LOGT, kModeApprox>
+                                            : ntt_forward_streamed<LOGN, LOGT, kModeExact>;
+        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
+    } else if (ctx.scaled_inverse_degree != 0) {
+        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, true>
+                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, true>
+                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, true>;
+        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
+    } else {
+        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, false>
+                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, false>
+                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, false>;
+        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
+    }
+    return hipGetLastError();
+}
+
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
                         uint32_t row_offset = 0, int source = kInverseFromSlab,
                         const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
+    if constexpr (kStreamedRows<LOGN, LOGT>) {
+        // plain slabs with more rows than one per CU
+        if ((source == kInverseFromSlab || !inverse) && rows > compute_units())
+            return launch_streamed<LOGN, LOGT>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                                               rows, stream);
+    }
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
                                                              SpreadSource{nullptr, 0, 0, 0, 0}, stream, row_period,
