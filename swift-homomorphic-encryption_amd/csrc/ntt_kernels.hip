@@ -169,6 +169,7 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
 // transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
+// (The streamed kernels have the registers to request it before; it gains them nothing: profiles/r03e_ntt_streamed_pairs.txt.)
 constexpr bool kInverseFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
@@ -495,7 +496,7 @@ __device__ __forceinline__ DeviceModulus load_modulus(const DeviceContext& ctx, 
 // returns in order, so the request is placed where the transform does not gather for a while (the first forward passes
 // and the last inverse pass take their twiddles through the scalar cache): a gather issued right behind it would wait
 // for the whole row to arrive from HBM.  The tile is handed from row to row with one workgroup barrier.
-template <int LOGN, int LOGT, int MODE>
+template <int LOGN, int LOGT, int MODE, int ROWS>
 __global__ void __launch_bounds__(1 << LOGT, 4)
     ntt_forward_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
     constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LO0 = LOGN - LOGE;
@@ -503,68 +504,98 @@ __global__ void __launch_bounds__(1 << LOGT, 4)
     static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    uint64_t v[1][E], next[E];
-    uint32_t unit = blockIdx.x, record, within;
-    size_t rows[1];
-    locate_rows<1>(map, unit, rows, record, within);
-    global_load<LOGN, LOGE, LO0, LOGE>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
-    for (;;) {
+    uint64_t v[ROWS][E], next[ROWS][E];
+    uint32_t unit = blockIdx.x, record, within;  // a unit = ROWS rows of one modulus (locate_rows)
+    size_t rows[ROWS];
+    locate_rows<ROWS>(map, unit, rows, record, within);
 #pragma unroll
-        for (int r = 0; r < E; ++r) v[0][r] = next[r];
-        const size_t row = rows[0];
+    for (int k = 0; k < ROWS; ++k)
+        global_load<LOGN, LOGE, LO0, LOGE>(next[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+    for (;;) {
+        size_t current[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            current[k] = rows[k];
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[k][r] = next[k][r];
+        }
         const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);  // (scalar loads of its constants)
-        // the row after this one (the last row again once there is none: a load behind a branch would drain the queue)
+        // the unit after this one (the last one again once there is none: a load behind a branch would drain the queue)
         const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
-        locate_rows<1>(map, following, rows, record, within);
-        global_load<LOGN, LOGE, LO0, LOGE>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
+        locate_rows<ROWS>(map, following, rows, record, within);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            global_load<LOGN, LOGE, LO0, LOGE>(next[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         __builtin_amdgcn_sched_barrier(0);
         const DeviceModulus mod = load_modulus(ctx, mi);
         const Twiddles<MODE> tw(ctx, false, mi, LOGN);
-        forward_row<LOGN, LOGE, MODE, 1>(v, tid, tw, mod.p, lds);
-        const BufferResource out = make_resource(slab + (row << LOGN), 8u << LOGN);
-        if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
-            global_store_staged<LOGN, LOGE, S::R>(v[0], tid, out, lds);
-        } else {
-            global_store<LOGN, LOGE, 0, S::R>(v[0], tid, out);
+        forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, mod.p, lds);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const BufferResource out = make_resource(slab + (current[k] << LOGN), 8u << LOGN);
+            if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
+                global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds);
+            } else {
+                global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out);
+            }
         }
         if (following == unit) break;
         unit = following;
-        __syncthreads();  // every wave is done with the tile before the next row's first exchange writes into it
+        __syncthreads();  // every wave is done with the tile before the next unit's first exchange writes into it
     }
 }
 
-template <int LOGN, int LOGT, int MODE, bool SCALED>
+template <int LOGN, int LOGT, int MODE, bool SCALED, int ROWS>
 __global__ void __launch_bounds__(1 << LOGT, 4)
     ntt_inverse_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
     constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LOL = LOGN - LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
-    static_assert(kStagedLoad<LOGN, LOGE, S::R>, "the next row waits as the 16-byte chunks of the staged load");
+    constexpr bool STAGED = kStagedLoad<LOGN, LOGE, S::R>;  // the next rows wait as the 16-byte chunks of the staged load
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
-    uint64_t v[1][E];
-    StagedChunks<LOGN, LOGE, S::R> next;
+    uint64_t v[ROWS][E];
+    StagedChunks<LOGN, LOGE, STAGED ? S::R : LOGE> chunks[STAGED ? ROWS : 1];
+    uint64_t next[STAGED ? 1 : ROWS][E];
     uint32_t unit = blockIdx.x, record, within;
-    size_t rows[1];
-    locate_rows<1>(map, unit, rows, record, within);
-    global_load_staged_request<LOGN, LOGE, S::R>(next, tid, make_resource(slab + (rows[0] << LOGN), 8u << LOGN));
+    size_t rows[ROWS];
+    locate_rows<ROWS>(map, unit, rows, record, within);
+    auto request = [&]() {
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
+            if constexpr (STAGED) global_load_staged_request<LOGN, LOGE, S::R>(chunks[k], tid, in);
+            else global_load<LOGN, LOGE, 0, S::R>(next[k], tid, in);
+        }
+    };
+    request();
     for (;;) {
-        global_load_staged_unpack<LOGN, LOGE, S::R>(v[0], next, tid, lds);
-        const size_t row = rows[0];
+        size_t current[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            current[k] = rows[k];
+            if constexpr (STAGED) {
+                global_load_staged_unpack<LOGN, LOGE, S::R>(v[k], chunks[k], tid, lds);
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[k][r] = next[k][r];
+            }
+        }
         const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);
         const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
-        locate_rows<1>(map, following, rows, record, within);
-        const BufferResource next_row = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
+        locate_rows<ROWS>(map, following, rows, record, within);
         const DeviceModulus mod = load_modulus(ctx, mi);
         const Twiddles<MODE> tw(ctx, true, mi, LOGN);
-        inverse_row<LOGN, LOGE, MODE, 1, SCALED>(v, tid, tw, mod, lds, [&]() {
-            global_load_staged_request<LOGN, LOGE, S::R>(next, tid, next_row);
+        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED>(v, tid, tw, mod, lds, [&]() {
+            request();
             __builtin_amdgcn_sched_barrier(0);
         });
-        global_store<LOGN, LOGE, LOL, LOGE>(v[0], tid, make_resource(slab + (row << LOGN), 8u << LOGN));
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (current[k] << LOGN), 8u << LOGN));
         if (following == unit) break;
         unit = following;
-        __syncthreads();  // the staged pick-up of the next row writes into the tile
+        __syncthreads();  // the staged pick-up of the next rows writes into the tile
     }
 }
 
@@ -728,8 +759,7 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
 // per CU, one workgroup per CU and rows dealt round-robin.
 template <int LOGN, int LOGT>
 constexpr bool kStreamedRows = kRowsPerWorkgroup<LOGN, LOGT> == 1 && Schedule<LOGN, LOGN - LOGT>::P >= 2 &&
-                               lds_words(1u << LOGN) * sizeof(uint64_t) > 80 * 1024 &&
-                               kStagedLoad<LOGN, LOGN - LOGT, Schedule<LOGN, LOGN - LOGT>::R>;
+                               lds_words(1u << LOGN) * sizeof(uint64_t) > 80 * 1024;
 inline unsigned compute_units() {
     static int cached[64] = {};
     int device = 0;
@@ -741,28 +771,29 @@ inline unsigned compute_units() {
     }
     return static_cast<unsigned>(cached[device]);
 }
-template <int LOGN, int LOGT>
-hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+// `units` groups of ROWS rows (locate_rows) over one workgroup per CU
+template <int LOGN, int LOGT, int ROWS>
+hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t units,
                            hipStream_t stream) {
     constexpr size_t lds_bytes = lds_words(1u << LOGN) * sizeof(uint64_t);
-    const unsigned workgroups = rows < compute_units() ? static_cast<unsigned>(rows) : compute_units();
-    const uint32_t total = static_cast<uint32_t>(rows);
+    const unsigned workgroups = units < compute_units() ? static_cast<unsigned>(units) : compute_units();
+    const uint32_t total = static_cast<uint32_t>(units);
     if (!inverse) {
-        auto kernel = mode == kModeSplit    ? ntt_forward_streamed<LOGN, LOGT, kModeSplit>
-                      : mode == kModeApprox ? ntt_forward_streamed<LOGN, LOGT, kModeApprox>
-                                            : ntt_forward_streamed<LOGN, LOGT, kModeExact>;
+        auto kernel = mode == kModeSplit    ? ntt_forward_streamed<LOGN, LOGT, kModeSplit, ROWS>
+                      : mode == kModeApprox ? ntt_forward_streamed<LOGN, LOGT, kModeApprox, ROWS>
+                                            : ntt_forward_streamed<LOGN, LOGT, kModeExact, ROWS>;
         if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
     } else if (ctx.scaled_inverse_degree != 0) {
-        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, true>
-                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, true>
-                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, true>;
+        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, true, ROWS>
+                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, true, ROWS>
+                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, true, ROWS>;
         if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
     } else {
-        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, false>
-                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, false>
-                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, false>;
+        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, false, ROWS>
+                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, false, ROWS>
+                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, false, ROWS>;
         if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
     }
@@ -777,8 +808,8 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     if constexpr (kStreamedRows<LOGN, LOGT>) {
         // plain slabs with more rows than one per CU
         if ((source == kInverseFromSlab || !inverse) && rows > compute_units())
-            return launch_streamed<LOGN, LOGT>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
-                                               rows, stream);
+            return launch_streamed<LOGN, LOGT, 1>(inverse, mode, slab, ctx,
+                                                  make_row_map(mod_base, mod_period, row_period, row_offset), rows, stream);
     }
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
