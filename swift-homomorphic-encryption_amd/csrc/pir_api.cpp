@@ -597,19 +597,21 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
     const heamd::DeviceContext q_device = q_ctx->impl->device_context();
     Scratch cur_mem(stream), next_mem(stream), parent_mem(stream), rotated_mem(stream), tmp_mem(stream),
         workspace_mem(stream);
-    // every level runs over all queries at once: buffers hold [query][node of the level]
-    const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, queries * ((widest + 1) / 2));
+    // every level runs over all queries at once: buffers hold [query][node of the level].  The gathered parents, the key
+    // switch's workspace and the fallback's two rotation buffers only ever hold the parents of a level (at most half of the
+    // widest level: every parent has two children in the next one); the rotation buffers are allocated when the fallback
+    // is first taken.
+    size_t most_parents = 1;
+    for (const heamd::ExpandPlan::Level& level : moves) most_parents = std::max(most_parents, level.parent_count);
+    const size_t workspace_bytes = he_bfv_apply_galois_workspace_bytes(ctx, L, queries * most_parents);
     HEAMD_HIP_TRY(cur_mem.allocate(queries * widest * ct_bytes));
     HEAMD_HIP_TRY(next_mem.allocate(queries * widest * ct_bytes));
-    HEAMD_HIP_TRY(parent_mem.allocate(queries * widest * ct_bytes));
-    HEAMD_HIP_TRY(rotated_mem.allocate(queries * widest * ct_bytes));
-    HEAMD_HIP_TRY(tmp_mem.allocate(queries * widest * ct_bytes));
+    HEAMD_HIP_TRY(parent_mem.allocate(queries * most_parents * ct_bytes));
     HEAMD_HIP_TRY(workspace_mem.allocate(workspace_bytes));
     const uint64_t* cur = ciphertexts;  // level 0 reads the caller's ciphertexts in place
     uint64_t* buffers[2] = {static_cast<uint64_t*>(cur_mem.get()), static_cast<uint64_t*>(next_mem.get())};
     uint64_t* gathered = static_cast<uint64_t*>(parent_mem.get());
-    uint64_t* rotated = static_cast<uint64_t*>(rotated_mem.get());
-    uint64_t* tmp = static_cast<uint64_t*>(tmp_mem.get());
+    uint64_t *rotated = nullptr, *tmp = nullptr;
 
     // ---- execute: every stage of a level is one launch over all nodes of all trees of all queries at that depth
     // (the inner product with the Galois key alone runs per run of queries that share a key)
@@ -651,7 +653,23 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
             break;
         }
         const uint64_t element = galois_elements[best];
+        // the reference applies the element 2^(log2(target - 1) - log2(element - 1)) times and then traps unless the
+        // composition IS the target element (precondition(currElement == targetElement), PirUtil.swift:222-231): with an
+        // evaluation key outside the 2^k + 1 ladder this call fails instead of returning another expansion
+        if (element < 3 || (element & 1) == 0) {
+            heamd::set_last_error("Galois element " + std::to_string(element) + " cannot reach " + std::to_string(target));
+            status = HE_ERR_MISSING_GALOIS_KEY;
+            break;
+        }
         const int applications = 1 << (floor_log2_size(target - 1) - floor_log2_size(element - 1));
+        uint64_t composed = 1;
+        for (int a = 0; a < applications; ++a) composed = (composed * element) % (2 * n);
+        if (composed != target) {
+            heamd::set_last_error("Galois element " + std::to_string(element) + " applied " + std::to_string(applications) +
+                                  " times is not " + std::to_string(target) + " (mod 2N)");
+            status = HE_ERR_MISSING_GALOIS_KEY;
+            break;
+        }
         // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
         const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
         uint64_t* next = buffers[depth % 2];
@@ -670,6 +688,12 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
             }
             if (status != heamd::kExpandStepUnavailable) break;
             status = HE_OK;
+        }
+        if (rotated == nullptr) {
+            HEAMD_HIP_TRY(rotated_mem.allocate(queries * most_parents * ct_bytes));
+            HEAMD_HIP_TRY(tmp_mem.allocate(queries * most_parents * ct_bytes));
+            rotated = static_cast<uint64_t*>(rotated_mem.get());
+            tmp = static_cast<uint64_t*>(tmp_mem.get());
         }
         const uint64_t* c1 = parents;
         for (int a = 0; a < applications && status == HE_OK; ++a) {  // applyGalois(element) until x -> x^target

@@ -162,6 +162,17 @@ def test_pir_expand_errors(small):
     with pytest.raises(heamd.HeError) as err:
         ours.pir_expand(ct, ours.degree + 1, {})
     assert err.value.name == "invalidArgument"
+    # an evaluation key outside the 2^k + 1 ladder: the reference's expandCiphertextForOneStep traps on
+    # precondition(currElement == targetElement) (PirUtil.swift:222-231); here the call fails, it does not return another
+    # expansion.  N = 64: the first level targets 65; 7 <= 65 applied 2^(6 - 2) = 16 times is 7^16 mod 128 = 1, not 65.
+    key = heamd.to_device(np.zeros((ours.L, 2, ours.L + 1, ours.degree), dtype=np.uint64))
+    assert pow(7, 16, 2 * ours.degree) != ours.degree + 1
+    with pytest.raises(heamd.HeError) as err:
+        ours.pir_expand(ct, 4, {7: key})
+    assert err.value.name == "missingGaloisKey"
+    with pytest.raises(heamd.HeError) as err:  # element 1 (the identity) can reach nothing
+        ours.pir_expand(ct, 4, {1: key})
+    assert err.value.name == "missingGaloisKey"
 
 
 def test_pir_one_dimension_single_modulus(oracle):
