@@ -1,6 +1,8 @@
-// Level B3 of include/he_amd.h behind Bfv<UInt64>: the scheme operations on the hot path as batched, device-resident
-// pipelines.  Each function is the batched form of one HeScheme requirement and performs the reference's own metadata
-// checks on the Swift side (they never cross the boundary):
+// Level B3 of include/he_amd.h next to Bfv<UInt64>: the scheme operations on the hot path as BATCHED, device-resident
+// pipelines for callers that hold batches (a server loop).  The per-ciphertext HeScheme surface is GpuBfv.swift; these
+// are the forms that amortise the PCIe round trip over a batch or skip it altogether (resident buffers).  Each function
+// is the batched form of one HeScheme requirement and performs the reference's own metadata checks on the Swift side
+// (they never cross the boundary):
 //   mulAssign(ct, ct)        Sources/HomomorphicEncryption/Bfv/Bfv+Multiply.swift:18-85
 //   relinearize              Bfv/Bfv.swift:201-219, Bfv/Bfv+Keys.swift:123-208
 //   modSwitchDown            Bfv/Bfv.swift:163-171
@@ -8,24 +10,6 @@
 //   addAssignCoeff / subAssignCoeff(ct, pt)   Bfv/Bfv.swift:110-117, Bfv/Bfv+Encrypt.swift:75-140
 import CHeAmd
 import HomomorphicEncryption
-
-/// An evaluation key's key-switching key resident on the device in the layout he_bfv_relinearize_device /
-/// he_bfv_apply_galois_device take: [L][2][L+1][N] Eval -- the ciphertexts of `_KeySwitchKey` (Keys.swift:66-91) back
-/// to back, each two polynomials over the key-switching context.
-public final class DeviceKeySwitchKey: @unchecked Sendable {
-    public let buffer: DeviceBuffer
-
-    public init(_ key: _KeySwitchKey<Bfv<UInt64>>, on stream: HeAmdStream) throws {
-        let ciphertexts = key._ciphertexts
-        let words = ciphertexts.reduce(0) { sum, ct in sum + ct.polys.reduce(0) { $0 + $1.data.count } }
-        buffer = try DeviceBuffer(count: words)
-        var cursor = 0
-        for ciphertext in ciphertexts {
-            try buffer.upload(ciphertext, at: cursor, on: stream)
-            cursor += ciphertext.polys.reduce(0) { $0 + $1.data.count }
-        }
-    }
-}
 
 extension Bfv where T == UInt64 {
     /// `lhs[i] *= rhs[i]` followed by `relinearize(using:)` for a whole batch: one upload, ten kernel launches, one

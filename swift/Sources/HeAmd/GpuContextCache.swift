@@ -1,12 +1,16 @@
 // Device twins of the reference's immutable contexts.  PolyContext and Context are final classes of another module, so
 // the handles cannot be stored on them; they are cached here, keyed by what defines the context (degree, moduli,
-// plaintext modulus), created once and kept for the life of the process -- contexts are immutable and Sendable
-// (PolyRq/PolyContext.swift:19, Context.swift:19), and every entry point of the C ABI is re-entrant on a shared handle.
+// plaintext modulus) AND by the HIP device that was current when the twin was built -- a handle belongs to its device
+// (every C entry point answers HE_ERR_DEVICE on another one), so a process that drives several GPUs, one thread or task
+// per device after `he_set_device`, gets one twin per device.  Twins live for the life of the process: contexts are
+// immutable and Sendable (PolyRq/PolyContext.swift:19, Context.swift:19) and every entry point of the C ABI is
+// re-entrant on a shared handle.
 import CHeAmd
 import Foundation
 import HomomorphicEncryption
 
 struct ContextKey: Hashable {
+    let device: Int32
     let degree: Int
     let moduli: [UInt64]
     let plaintextModulus: UInt64
@@ -17,11 +21,28 @@ final class GpuContextCache: @unchecked Sendable {
     private let lock = NSLock()
     private var polyContexts: [ContextKey: OpaquePointer] = [:]
     private var bfvContexts: [ContextKey: OpaquePointer] = [:]
+    private var retainsScratch: Set<Int32> = []
+
+    /// The calling thread's current HIP device.
+    static func currentDevice() throws -> Int32 {
+        var device: Int32 = 0
+        try heAmdCheck(he_get_device(&device))
+        return device
+    }
+
+    /// A server keeps the library's scratch pool warm (query expansion takes tens of gigabytes per call; mapping them
+    /// anew costs seconds): opted into once per device, on first use.  `he_device_trim_scratch` gives it back.
+    private func retainScratch(on device: Int32) {
+        guard !retainsScratch.contains(device) else { return }
+        retainsScratch.insert(device)
+        _ = he_set_scratch_cache(UInt64.max)
+    }
 
     /// `he_poly_context` of a PolyContext<UInt64> (PolyContext.init's validation already passed on the Swift side; the
     /// C side repeats it in the same order and builds the device tables).
     func handle(for context: PolyContext<UInt64>) throws -> OpaquePointer {
-        let key = ContextKey(degree: context.degree, moduli: context.moduli, plaintextModulus: 0)
+        let device = try Self.currentDevice()
+        let key = ContextKey(device: device, degree: context.degree, moduli: context.moduli, plaintextModulus: 0)
         lock.lock()
         defer { lock.unlock() }
         if let cached = polyContexts[key] { return cached }
@@ -34,17 +55,18 @@ final class GpuContextCache: @unchecked Sendable {
         return out
     }
 
-    /// `he_bfv_context` of a Context<Bfv<UInt64>> (Context.swift:94-143): all coefficient moduli, the last one being
-    /// the key-switching modulus when there are several.
-    func handle(for context: Context<Bfv<UInt64>>) throws -> OpaquePointer {
-        let key = ContextKey(degree: context.degree, moduli: context.coefficientModuli,
-                             plaintextModulus: context.plaintextModulus)
+    /// `he_bfv_context` of any scheme's context over UInt64 (Context.swift:94-143): all coefficient moduli, the last
+    /// one being the key-switching modulus when there are several.
+    func handle(degree: Int, coefficientModuli: [UInt64], plaintextModulus: UInt64) throws -> OpaquePointer {
+        let device = try Self.currentDevice()
+        let key = ContextKey(device: device, degree: degree, moduli: coefficientModuli, plaintextModulus: plaintextModulus)
         lock.lock()
         defer { lock.unlock() }
         if let cached = bfvContexts[key] { return cached }
+        retainScratch(on: device)
         var out: OpaquePointer?
-        try context.coefficientModuli.withUnsafeBufferPointer { moduli in
-            try heAmdCheck(he_bfv_context_create(UInt32(context.degree), context.plaintextModulus, moduli.baseAddress,
+        try coefficientModuli.withUnsafeBufferPointer { moduli in
+            try heAmdCheck(he_bfv_context_create(UInt32(degree), plaintextModulus, moduli.baseAddress,
                                                  UInt32(moduli.count), &out))
         }
         guard let out else { throw HeError.unsupportedHeOperation(description: "he_bfv_context_create returned nil") }
@@ -54,15 +76,19 @@ final class GpuContextCache: @unchecked Sendable {
 }
 
 extension PolyContext where T == UInt64 {
-    /// The device twin of this context (created on first use, on the HIP device current at that time).
+    /// The device twin of this context on the current HIP device (created on first use).
     public var gpu: OpaquePointer {
         get throws { try GpuContextCache.shared.handle(for: self) }
     }
 }
 
-extension Context where Scheme == Bfv<UInt64> {
-    /// The device twin of this context.
+extension HeContext where Scalar == UInt64 {
+    /// The device twin of this context on the current HIP device -- for `Context<Bfv<UInt64>>` and `Context<GpuBfv>`
+    /// alike (HeScheme.swift:88-101: what defines a context is its encryption parameters).
     public var gpu: OpaquePointer {
-        get throws { try GpuContextCache.shared.handle(for: self) }
+        get throws {
+            try GpuContextCache.shared.handle(degree: degree, coefficientModuli: coefficientModuli,
+                                              plaintextModulus: plaintextModulus)
+        }
     }
 }
