@@ -41,7 +41,8 @@ DEGREE = 8192
 MODULI_BITS = [55, 55, 55, 55]
 BATCH = 4096
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+HBM_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md: measured float4 streaming copy (79 % of peak)
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def parse_args():
@@ -69,14 +70,21 @@ def synthetic_slab(torch, moduli, prefix, degree, seed):
     return x % bound
 
 
-def profiled_traffic(key):
+def profiled_traffic(key, algorithmic_bytes_per_unit=None):
     """HBM bytes per unit (and per launch of the dominant kernel) counted by the rocprofv3 --pmc passes committed under
-    profiles/ (bench.py cannot run rocprofv3 around itself); None when there is no entry."""
+    profiles/ (bench.py cannot run rocprofv3 around itself); None when there is no entry -- or when the entry claims
+    FEWER bytes than the algorithm must move (a stale or miscalibrated profile: counters cannot undercut the compulsory
+    traffic of a kernel whose working set exceeds every cache)."""
     try:
         with open(TRAFFIC_PROFILE) as f:
-            return json.load(f).get(key)
+            entry = json.load(f).get(key)
     except OSError:
         return None
+    if entry and algorithmic_bytes_per_unit is not None and entry.get("hbm_bytes_per_unit", 0) < 0.98 * algorithmic_bytes_per_unit:
+        print(f"bench.py: ignoring {TRAFFIC_PROFILE}[{key}]: {entry.get('hbm_bytes_per_unit')} B/unit is below the "
+              f"algorithmic {algorithmic_bytes_per_unit} B/unit", file=sys.stderr)
+        return None
+    return entry
 
 
 def time_kernel(torch, fn, reps):
@@ -92,7 +100,7 @@ def time_kernel(torch, fn, reps):
     return start.elapsed_time(stop) * 1e-3 / reps
 
 
-def clocks_under_load(torch, fn, seconds=1.5):
+def clocks_under_load(torch, fn, seconds=6.0):
     """Shader clock (MHz) and socket power (W) reported by rocm-smi while fn() runs back to back; None without rocm-smi.
     The NTT kernel runs at the socket power cap, so the clock it gets is part of the measurement."""
     import re
@@ -171,6 +179,7 @@ def cpu_baseline(moduli, sample_polys):
     t0 = time.perf_counter()
     small_ctx.forward_ntt_inplace(small, threads=1)
     config0 = small.shape[0] / (time.perf_counter() - t0)
+    ct_mul = cpu_ct_mul_baseline(oracle, np, threads)
     return {
         "value": 2 * sample_polys / elapsed,
         "unit": "poly-NTT/s",
@@ -182,6 +191,47 @@ def cpu_baseline(moduli, sample_polys):
         "single_thread_forward_poly_ntt_per_s": single,
         "config0_forward_ntt_n4096_l2_single_thread_per_s": config0,
         "config0_sample": "BASELINE configs[0]: forwardNtt N=4096, 2 x 55-bit moduli, 512 polynomials on one thread (port)",
+        **ct_mul,
+    }
+
+
+def cpu_ct_mul_baseline(oracle, np, threads):
+    """BASELINE.json's second metric on the host: Bfv ct x ct + relinearize at N=8192, L=4 (the reference's
+    Benchmarks/RlweBenchmark/RlweBenchmark.swift:387-399,414-428 time `ciphertext * ciphertext` and `relinearize` one
+    ciphertext at a time on one thread), with the CPU oracle -- one thread, and one product per thread on all host
+    threads -- on a sample sized for a few seconds each."""
+    q = oracle.generate_primes([55] * 5, False, DEGREE)
+    ctx = oracle.BfvContext(DEGREE, 557057, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(0xC3)
+
+    def uniform(prefix, row_moduli):
+        return np.ascontiguousarray(np.stack(
+            [rng.integers(0, m, size=tuple(prefix) + (DEGREE,), dtype=np.uint64) for m in row_moduli], axis=len(prefix)))
+
+    key = uniform((ctx.L, 2), q)
+    lhs, rhs = uniform((2, 2), moduli), uniform((2, 2), moduli)
+    t0 = time.perf_counter()
+    product = ctx.mul(lhs, rhs, threads=1)
+    ctx.relinearize(product, key, threads=1)
+    per_product = (time.perf_counter() - t0) / 2
+    single = 1.0 / per_product
+    count = int(max(threads, min(1024, 6.0 / per_product * threads * 0.7)))
+    lhs, rhs = uniform((count, 2), moduli), uniform((count, 2), moduli)
+    t0 = time.perf_counter()
+    product = ctx.mul(lhs, rhs, threads=threads)
+    t_mul = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx.relinearize(product, key, threads=threads)
+    t_relin = time.perf_counter() - t0
+    return {
+        "ct_mul_relinearize_per_s": count / (t_mul + t_relin),
+        "ct_mul_per_s": count / t_mul,
+        "relinearize_per_s": count / t_relin,
+        "ct_mul_relinearize_single_thread_per_s": single,
+        "ct_mul_sample": f"Bfv ct x ct + relinearize of {count} ciphertext pairs (N={DEGREE}, L=4, t=557057), {threads} host "
+                         f"threads, one product per thread, and 2 pairs on one thread; C port (oracle/he_oracle.c "
+                         f"orc_bfv_mul_mt / orc_bfv_relinearize_mt), not the Swift binary",
     }
 
 
@@ -236,13 +286,14 @@ class NttWorkload:
         inverse_s = time_kernel(torch, lambda: ctx.inverse_ntt_(slab), max(5, steps))
         polys = slab.shape[0]
         achieved = self.bytes_per_transform * polys / forward_s / 1e9
-        # the attainable figure next to the nominal peak: a device-to-device copy of the same slab
+        # the attainable figure next to the nominal peak: the library's own streaming copy of the same
+        # slab -- 8 bytes per lane, non-temporal, the transforms' access width (he_words_copy_device)
         scratch = torch.empty_like(slab)
-        copy_s = time_kernel(torch, lambda: scratch.copy_(slab), max(5, steps))
+        copy_s = time_kernel(torch, lambda: self.heamd.stream_copy(slab, scratch), max(5, steps))
         copy_gbps = 2 * slab.numel() * 8 / copy_s / 1e9
         del scratch
         load_state = clocks_under_load(torch, lambda: ctx.forward_ntt_(slab)) if rank == 0 else None
-        profile = profiled_traffic("c2_forward_ntt")
+        profile = profiled_traffic("c2_forward_ntt", self.bytes_per_transform)
         traffic = None
         if profile and profile.get("units_per_launch") == polys:
             traffic = profile["hbm_bytes_per_launch"] / forward_s / 1e9
@@ -258,8 +309,9 @@ class NttWorkload:
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.bytes_per_transform * polys,
             "avg_launch_ms": forward_s * 1e3,
-            "copy_rate": copy_gbps,  # measured read + write rate of a plain copy of the same 1 GiB slab
+            "copy_rate": copy_gbps,  # read + write rate of the library's streaming copy of the same 1 GiB slab
             "frac_of_copy_rate": achieved / copy_gbps,
+            "frac_of_6.29TBps": achieved / HBM_COPY_GBPS,  # against the guide's measured streaming-copy rate
             "under_load": load_state,  # rocm-smi while the kernel runs back to back: it sits at the power cap
         }
         extras = {
@@ -335,7 +387,7 @@ class CtMulWorkload:
         t_relin = time_kernel(torch, relin, reps)
         t_both = t_mul + t_relin
         achieved = self.COMPULSORY * self.units / t_both / 1e9
-        profile = profiled_traffic("c3_ct_mul_relinearize")
+        profile = profiled_traffic("c3_ct_mul_relinearize", self.COMPULSORY)
         traffic = profile["hbm_bytes_per_unit"] * self.units / t_both / 1e9 if profile else None
         roofline = {
             "bound": "hbm",
@@ -396,7 +448,7 @@ class ModSwitchWorkload:
     def roofline(self, steps, rank):
         t = time_kernel(self.torch, self.step, max(5, steps))
         achieved = self.bytes_per_poly * self.units / t / 1e9
-        profile = profiled_traffic("c4_mod_switch")
+        profile = profiled_traffic("c4_mod_switch", self.bytes_per_poly)
         traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
         return {
             "bound": "hbm",
@@ -434,12 +486,25 @@ class PirDim0Workload:
         self.units = self.columns * self.D0
         self.db_bytes = self.units * len(moduli) * DEGREE * 8
         self.out = None
+        # the second half of configs[4], run on the gathered set (PirUtil.swift:448-485): the second dimension's query
+        # ciphertexts (one per column of the whole database) and the relinearization key, replicated like the dim-0 query
+        self.remaining = self.key_ = self.response = None
+        if world > 1:
+            self.remaining = synthetic_slab(torch, moduli, (self.total_columns, 2), DEGREE, 7)
+            self.key_ = synthetic_slab(torch, q, (self.ctx.L, 2), DEGREE, 3)
 
     def step(self):
-        self.out = self.ctx.inner_product_plain(self.query, self.database, None, 2, self.columns)
+        # this rank's columns: the ct x pt inner products and their inverse NTT (he_pir_dim0_columns_device)
+        self.out = self.ctx.pir_dim0_columns(self.query, self.database)
 
     def result(self):
         return self.out, self.total_columns
+
+    def consume(self, gathered):
+        """What follows the all-gather in a column-sharded deployment: the remaining dimension over ALL columns'
+        intermediate ciphertexts (he_pir_remaining_dimensions_device; it overwrites its input)."""
+        self.response = self.ctx.pir_remaining_dimensions([self.D0, self.total_columns], gathered, self.remaining,
+                                                          self.key_)
 
     def describe(self, world):
         return {
@@ -463,7 +528,7 @@ class PirDim0Workload:
     def roofline(self, steps, rank):
         t = time_kernel(self.torch, self.step, max(3, steps // 4))
         achieved = self.db_bytes / t / 1e9
-        profile = profiled_traffic("c5_inner_product_plain")
+        profile = profiled_traffic("c5_inner_product_plain", self.db_bytes / self.units)
         traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
         return {
             "bound": "hbm",
@@ -527,8 +592,9 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
     # ---- separately timed kernels: the workload's dominant kernel for the roofline figure
     roofline, extras = job.roofline(args.steps, rank)
 
-    gather_ms = with_gather_elapsed = None
+    gather_ms = with_gather_elapsed = gather_bytes = None
     if distributed and not args.skip_gather:
+        gather_bytes = job.result()[0].numel() * job.result()[0].element_size()  # what this rank contributes
         # the only collective on the path: gather the per-GPU result shards (RCCL all-gather over xGMI); also the same
         # K steps with the gather after every step, max over ranks
         local, total = job.result()
@@ -547,6 +613,8 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
             job.step()
             local, total = job.result()
             out = sharding.gather_shards(local, total)
+            if hasattr(job, "consume"):  # c5: dim-0 -> all-gather -> remaining dimensions, the whole configs[4] flow
+                job.consume(out)
         synchronize()
         with_gather_elapsed = sharding.max_over_ranks(time.perf_counter() - t1, device=device)
         del out
@@ -569,7 +637,7 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
         "data": "synthetic",
         "config": description["config"],
         "roofline": roofline,
-        "extras": dict(extras, all_gather_ms=gather_ms,
+        "extras": dict(extras, all_gather_ms=gather_ms, all_gather_bytes_per_gpu=gather_bytes,
                        value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed
                                               if with_gather_elapsed else None)),
     }
@@ -595,6 +663,8 @@ def main():
     if args.gpus != world and rank == 0 and distributed:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
+    # the library retains no scratch unless the host opts in (he_set_scratch_cache); a server does, and so does this job
+    heamd.set_scratch_cache()
     result = run_benchmark(args, lambda: WORKLOADS[args.workload](torch, heamd, sharding, args, rank, world), rank, world,
                            "cuda", dist)
     if rank == 0:

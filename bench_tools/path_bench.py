@@ -48,26 +48,32 @@ def _uniform(torch, moduli, prefix, degree, seed):
 
 
 def _profiled(key):
-    """HBM bytes per unit from the committed rocprofv3 counter passes (profiles/r02_pmc_traffic.json), or None."""
+    """HBM bytes per unit from the committed rocprofv3 counter passes (profiles/r03_pmc_traffic.json), or None -- also
+    when the entry claims fewer bytes than the algorithm must move (bench.py profiled_traffic: a stale or miscalibrated
+    profile)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f).get(key)
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            entry = json.load(f).get(key)
     except OSError:
         return None
+    if entry and entry.get("hbm_bytes_per_unit", 0) < 0.98 * entry.get("algorithmic_bytes_per_unit", 0):
+        return None
+    return entry
 
 
-def config1_ntt(torch, heamd, batch=8192, reps=10):
-    """Forward / inverse NTT at BASELINE configs[0]'s shape on the GPU: N=4096, 2 moduli (55-bit), `batch` polynomials."""
-    degree = 4096
-    moduli = heamd.generate_primes([55, 55], False, degree)
+def config1_ntt(torch, heamd, batch=8192, reps=10, degree=4096, moduli_count=2):
+    """Forward / inverse NTT at BASELINE configs[0]'s shape on the GPU: N=4096, 2 moduli (55-bit), `batch` polynomials
+    (and, with other arguments, at the other ring sizes)."""
+    moduli = heamd.generate_primes([55] * moduli_count, False, degree)
     ctx = heamd.PolyContext(degree, moduli)
     x = _uniform(torch, moduli, (batch,), degree, 11)
     forward = _timed(torch, lambda: ctx.forward_ntt_(x), reps)
     inverse = _timed(torch, lambda: ctx.inverse_ntt_(x), reps)
-    bytes_per_poly = 2 * 2 * degree * 8
+    bytes_per_poly = 2 * moduli_count * degree * 8
     return {"batch": batch, "forward_poly_ntt_per_s": batch / forward, "inverse_poly_ntt_per_s": batch / inverse,
             "forward_GBps": bytes_per_poly * batch / forward / 1e9, "inverse_GBps": bytes_per_poly * batch / inverse / 1e9,
-            "forward_frac_of_8TBps": bytes_per_poly * batch / forward / 8e12}
+            "forward_frac_of_8TBps": bytes_per_poly * batch / forward / 8e12,
+            "inverse_frac_of_8TBps": bytes_per_poly * batch / inverse / 8e12}
 
 
 def config3_ct_mul(torch, heamd, batch=1024, reps=5):
@@ -230,6 +236,7 @@ def run_all(quick=False):
 
     out = {}
     out["config1_ntt_n4096_l2"] = config1_ntt(torch, heamd, batch=1024 if quick else 8192)
+    out["ntt_n16384_l4"] = config1_ntt(torch, heamd, batch=256 if quick else 1024, degree=16384, moduli_count=4)
     out["config3_ct_mul"] = config3_ct_mul(torch, heamd, batch=256 if quick else 1024)
     out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
     # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round-2 closing pass: parity, the driver's bench command (+ rocprofv3 kernel stats of the same command), HBM counters
-# of the four workloads, the other workload lines, next-row and UInt32 benches.
+# Round-3 closing pass: parity, the driver's bench command (+ rocprofv3 kernel stats of the same command), HBM counters
+# of the four workloads (-> profiles/r03_pmc_traffic.json, what bench.py reports as `traffic`), the other workload lines,
+# next-row and UInt32 benches.   bash bench_tools/r03_final.sh TAG
 cd "$GRAFT_REPO_ROOT"
-T=${1:-r02z}
+T=${1:-r03z}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
 O=gpurun_out/$T
@@ -20,8 +21,8 @@ pmc c3 bench_tools/c3_profile_target.py
 pmc c4 bench_tools/c4_profile_target.py
 pmc c5 bench_tools/c5_profile_target.py
 (for d in c2 c3 c4 c5; do echo "== $d"; python bench_tools/pmc_traffic.py $O/pmc_$d | grep -v "at::\|rocclr"; done) > $O/pmc_traffic_per_kernel.txt
-python bench_tools/traffic_json.py $O/pmc_c2 $O/pmc_c3 $O/pmc_c4 $O/pmc_c5 $O/r02_pmc_traffic.json > /dev/null
-cp $O/r02_pmc_traffic.json profiles/r02_pmc_traffic.json
+python bench_tools/traffic_json.py $O/pmc_c2 $O/pmc_c3 $O/pmc_c4 $O/pmc_c5 $O/r03_pmc_traffic.json > /dev/null
+cp $O/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
 cut -c1-400 $O/bench.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --skip-other-configs --no-cpu-baseline > $O/bench_ntt_only.json 2> $O/bench_stats.err

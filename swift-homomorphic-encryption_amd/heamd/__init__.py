@@ -22,6 +22,7 @@ from .binding import (  # noqa: F401
     narrow_u64,
     set_device,
     set_scratch_cache,
+    stream_copy,
     to_device,
     to_device32,
     to_host,

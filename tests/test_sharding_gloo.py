@@ -198,6 +198,96 @@ def test_bench_contract_with_two_ranks():
     assert line0["higher_is_better"] is True and line0["config"]["world"] == 2
 
 
+def _c5_flow_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import argparse
+    import importlib.util
+
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    import oracle.pir
+    from heamd import sharding
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        degree, dims = 64, [4, 5]
+        t = oracle.generate_primes([17], True, degree)[0]
+        q = oracle.generate_primes([40, 40, 41], False, degree)
+        bfv = oracle.BfvContext(degree, t, q)
+        moduli = bfv.ciphertext_context().moduli
+        rng = np.random.default_rng(77)  # the same stream on both ranks: query, key and database are replicated inputs
+
+        def uniform(prefix, row_moduli):
+            return np.ascontiguousarray(np.stack(
+                [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in row_moduli], axis=len(prefix)))
+
+        dim0 = uniform((dims[0], 2), moduli)
+        rest = uniform((dims[1], 2), moduli)
+        database = uniform((dims[1], dims[0]), moduli)
+        key = uniform((bfv.L, 2), q)
+        begin, end = sharding.shard_bounds(dims[1], world, rank)
+
+        class PirJob:  # PirDim0Workload's interface on CPU tensors, the oracle standing in for the kernels
+            def __init__(self):
+                self.units = (end - begin) * dims[0]
+                self.response = None
+                self.consumed = 0
+
+            def step(self):
+                self.out = oracle.pir.dim0_columns(bfv, dim0, database[begin:end])
+
+            def result(self):
+                return torch.from_numpy(self.out.view(np.int64)), dims[1]
+
+            def consume(self, gathered):
+                self.consumed += 1
+                self.response = oracle.pir.remaining_dimensions(bfv, dims, gathered.numpy().view(np.uint64), rest, key)
+
+            def describe(self, w):
+                return {"metric": "m", "unit": "ct-pt-mac/s", "dtype": "u64", "config": {"workload": "c5 dry run"}}
+
+            def roofline(self, steps, r):
+                return {"bound": "hbm", "frac": 0.0}, {}
+
+        jobs = []
+
+        def make_job():
+            jobs.append(PirJob())
+            return jobs[-1]
+
+        args = argparse.Namespace(steps=2, warmup=1, skip_gather=False)
+        line = bench.run_benchmark(args, make_job, rank, world, device="cpu", dist=dist)
+        whole = oracle.pir.compute_response_for_one_chunk(bfv, dims, dim0, rest, database.reshape(-1, bfv.L, degree), None, key)
+        results[rank] = (line, jobs[0].consumed, bool(np.array_equal(jobs[0].response, whole)), jobs[0].units)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_c5_flow_with_two_ranks():
+    """The whole of BASELINE configs[4] under bench.py's contract with two gloo ranks: each step computes the rank's
+    columns (dim 0), the gather phase all-gathers them (ragged 3 + 2) and hands the set to the job's `consume`, which runs
+    the remaining dimension -- and the response equals the unsharded chunk response word for word on both ranks.  The JSON
+    line records what each GPU contributes to the all-gather."""
+    import torch.multiprocessing as mp
+
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_c5_flow_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    line0, consumed0, equal0, units0 = results[0]
+    line1, consumed1, equal1, units1 = results[1]
+    assert line1 is None and line0 is not None
+    assert consumed0 == consumed1 == 2 and equal0 and equal1
+    assert (units0, units1) == (12, 8)
+    assert line0["extras"]["all_gather_bytes_per_gpu"] == 3 * 2 * 2 * 64 * 8  # rank 0: 3 columns x [2][L=2][N=64] words
+    assert line0["extras"]["value_with_all_gather"] > 0
+
+
 def test_shard_bounds_partition():
     from heamd import sharding
 
