@@ -559,9 +559,10 @@ int he_poly_context_copy_ntt_tables(const he_poly_context* ctx, uint32_t rns_ind
                                     uint64_t* root_factors, uint64_t* inverse_root_powers,
                                     uint64_t* inverse_root_factors, uint64_t* inverse_degree,
                                     uint64_t* inverse_degree_root);
-/* A streaming copy of `words` 8-byte words, 8 bytes per lane and non-temporal -- the access pattern of the transforms'
- * row loads and stores.  What bench.py reports as the attainable rate next to the nominal 8 TB/s (`roofline.copy_rate`). */
-int he_words_copy_device(const uint64_t* device_in, uint64_t* device_out, size_t words, he_stream s);
+/* A streaming copy of `words` 8-byte words, 8 bytes per lane -- the access width of the transforms' row loads and stores;
+ * non_temporal != 0 also takes their cache policy.  What bench.py reports as the attainable rate next to the nominal
+ * 8 TB/s (`roofline.copy_rate`: the faster of the two policies). */
+int he_words_copy_device(const uint64_t* device_in, uint64_t* device_out, size_t words, int non_temporal, he_stream s);
 /* NTT with a named kernel schedule -- every accepted variant computes the same canonical transform (parity tests
  * pin each schedule against the oracle): 0 = auto (production), 1 = exact-quotient butterflies, 2 = generic radix-2
  * kernel, 3 = 16 words per lane, 8 = 32 words per lane, 10 = [0, 8p) butterflies.  Anything else:

@@ -605,10 +605,10 @@ int he_words_widen_u32_device(const uint32_t* in, uint64_t* out, size_t words, h
     HEAMD_HIP_TRY(heamd::launch_widen_words(in, out, words, as_stream(s)));
     return HE_OK;
 }
-int he_words_copy_device(const uint64_t* in, uint64_t* out, size_t words, he_stream s) {
+int he_words_copy_device(const uint64_t* in, uint64_t* out, size_t words, int non_temporal, he_stream s) {
     if (words == 0) return HE_OK;
     if (in == nullptr || out == nullptr) return invalid_argument("null slab");
-    HEAMD_HIP_TRY(heamd::launch_stream_copy(in, out, words, as_stream(s)));
+    HEAMD_HIP_TRY(heamd::launch_stream_copy(in, out, words, non_temporal != 0, as_stream(s)));
     return HE_OK;
 }
 int he_words_narrow_u64_device(const uint64_t* in, uint32_t* out, size_t words, he_stream s) {

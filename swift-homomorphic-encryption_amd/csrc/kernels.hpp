@@ -115,7 +115,7 @@ hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t*
                                 const DeviceContext32& ctx, size_t rows, hipStream_t stream);
 // packed [UInt32] words <-> the zero-extended 8-byte words of the Bfv<UInt32> scheme layer (16-byte aligned slabs)
 hipError_t launch_widen_words(const uint32_t* in, uint64_t* out, size_t words, hipStream_t stream);
-hipError_t launch_stream_copy(const uint64_t* in, uint64_t* out, size_t words, hipStream_t stream);
+hipError_t launch_stream_copy(const uint64_t* in, uint64_t* out, size_t words, bool non_temporal, hipStream_t stream);
 hipError_t launch_narrow_words(const uint64_t* in, uint32_t* out, size_t words, hipStream_t stream);
 hipError_t launch_divide_and_round_q_last32(const uint32_t* in, uint32_t* out, const DeviceContext32& ctx,
                                             uint32_t moduli_count, size_t polys, hipStream_t stream);

@@ -527,18 +527,24 @@ __global__ void __launch_bounds__(kThreads)
         out[(quads << 2) + threadIdx.x] = static_cast<uint32_t>(in[(quads << 2) + threadIdx.x]);
 }
 // the reference point of the transforms' roofline figures: every word read once and written once, 8 bytes per lane (the
-// NTT's access width), non-temporal like the transforms' row loads and stores
+// NTT's access width).  NT = non-temporal like the transforms' row loads and stores, or the default cache policy.
+template <bool NT>
 __global__ void __launch_bounds__(kThreads)
     stream_copy_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t words) {
     for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < words;
-         i += static_cast<size_t>(gridDim.x) * kThreads)
-        stream_store(out + i, stream_load(in + i));
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        if constexpr (NT) stream_store(out + i, stream_load(in + i));
+        else out[i] = in[i];
+    }
 }
 }  // namespace
 
-hipError_t launch_stream_copy(const uint64_t* in, uint64_t* out, size_t words, hipStream_t stream) {
+hipError_t launch_stream_copy(const uint64_t* in, uint64_t* out, size_t words, bool non_temporal, hipStream_t stream) {
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, words);
+    if (non_temporal)
+        hipLaunchKernelGGL(stream_copy_kernel<true>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, words);
+    else
+        hipLaunchKernelGGL(stream_copy_kernel<false>, dim3(grid_for(words)), dim3(kThreads), 0, stream, in, out, words);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ SIGNATURES = [
     ("he_last_error_message", ctypes.c_char_p, []),
     ("he_version", ctypes.c_char_p, []),
     ("he_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
-    ("he_words_copy_device", ctypes.c_int, [vp, vp, c_size, vp]),
+    ("he_words_copy_device", ctypes.c_int, [vp, vp, c_size, ctypes.c_int, vp]),
     ("he_get_device", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("he_set_device", ctypes.c_int, [ctypes.c_int]),
     ("he_set_scratch_cache", ctypes.c_int, [c_u64]),
@@ -253,9 +253,10 @@ def trim_scratch(keep_bytes=0):
     _check(load_library().he_device_trim_scratch(keep_bytes))
 
 
-def stream_copy(src, dst, stream=None):
-    """dst <- src with the library's streaming copy (8 bytes per lane, non-temporal): the roofline's reference rate."""
-    _check(load_library().he_words_copy_device(vp(src.data_ptr()), vp(dst.data_ptr()), src.numel(), _stream(stream)))
+def stream_copy(src, dst, non_temporal=False, stream=None):
+    """dst <- src with the library's streaming copy (8 bytes per lane): the roofline's reference rate."""
+    _check(load_library().he_words_copy_device(vp(src.data_ptr()), vp(dst.data_ptr()), src.numel(),
+                                               1 if non_temporal else 0, _stream(stream)))
 
 
 def widen_u32(slab32, stream=None):
