@@ -68,7 +68,7 @@ int check_level(const he_bfv_context* ctx, uint32_t moduli_count, const RnsToolL
     if (status != HE_OK) return status;
     *tool = ctx->impl->tool(moduli_count);
     if ((*tool)->device.L > heamd::rns_max_supported_moduli()) {
-        heamd::set_last_error("more than 8 ciphertext moduli are not supported by the BEHZ kernels yet");
+        heamd::set_last_error("more than 16 ciphertext moduli are not supported by the BEHZ kernels");
         return HE_ERR_UNSUPPORTED;
     }
     return HE_OK;

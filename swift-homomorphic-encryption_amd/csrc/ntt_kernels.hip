@@ -1010,7 +1010,7 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
     const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;
     const size_t records = polys * 2;
-    if (!tiled || L > 8 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
+    if (!tiled || L > 64 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
     return launch_ntt_band(true, out, ks, 0, L + 1, L + 1, 0, records, production_mode(ks), stream, kInverseFromKeyMac,
                            InverseSource{spread, key, L, top_rows});

@@ -20,7 +20,7 @@ namespace heamd {
 namespace {
 
 constexpr unsigned kThreads = 256;
-constexpr int kMaxL = 8;  // compile-time specialisations for L = 1..kMaxL
+constexpr int kMaxL = 16;  // compile-time specialisations for L = 1..kMaxL (16 x 55 bits = the N = 32768 security cap)
 
 inline unsigned grid_for(size_t work_items) {
     const size_t blocks = (work_items + kThreads - 1) / kThreads;
@@ -627,10 +627,18 @@ hipError_t dispatch_L(uint32_t L, Args&&... args) {
         case 6: return Launcher<6>::run(args...);
         case 7: return Launcher<7>::run(args...);
         case 8: return Launcher<8>::run(args...);
+        case 9: return Launcher<9>::run(args...);
+        case 10: return Launcher<10>::run(args...);
+        case 11: return Launcher<11>::run(args...);
+        case 12: return Launcher<12>::run(args...);
+        case 13: return Launcher<13>::run(args...);
+        case 14: return Launcher<14>::run(args...);
+        case 15: return Launcher<15>::run(args...);
+        case 16: return Launcher<16>::run(args...);
         default: return hipErrorNotSupported;
     }
 }
-static_assert(kMaxL == 8, "dispatch_L covers 1..8");
+static_assert(kMaxL == 16, "dispatch_L covers 1..16");
 
 template <int L>
 struct LiftLauncher {
@@ -799,7 +807,7 @@ hipError_t launch_key_switch_mac(const W* spread, const W* key, W* out, const De
                                  uint32_t top_rows, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const size_t n = size_t(1) << ks.log_degree;
-    if (L > 8) return hipErrorInvalidValue;  // ProductSum headroom
+    if (L > kMaxL) return hipErrorInvalidValue;  // (ProductSum itself has headroom for 65 536 products)
     // grid.y carries (polynomial, modulus); it is limited to 65535, so long batches go out in slices
     const size_t rows_per_poly = L + 1, max_polys = 65535 / rows_per_poly;
     for (size_t done = 0; done < polys; done += max_polys) {

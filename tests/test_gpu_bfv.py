@@ -1,5 +1,6 @@
 """GPU parity tests of the BEHZ kernels and the Bfv<UInt64> scheme operations against the CPU oracle, plus the
 reference's semantic (decrypt) checks (Sources/_TestUtilities/HeApiTestUtils.swift:494-720,1223-1285).  Bit-exact."""
+import os
 import random
 
 import numpy as np
@@ -125,16 +126,65 @@ def test_mul_and_relinearize_config3(oracle, config3):
     key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, ours.degree)
     product = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs))
     relin = ours.relinearize(product, heamd.to_device(key))
-    sample = [0, 15]
-    expected_product = ref.mul(lhs[sample], rhs[sample])
-    assert np.array_equal(heamd.to_host(product)[sample], expected_product)
-    assert np.array_equal(heamd.to_host(relin)[sample], ref.relinearize(expected_product, key))
+    # every item word for word (the oracle spreads the 16 products over the host's threads)
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    expected_product = ref.mul(lhs, rhs, threads=threads)
+    assert np.array_equal(heamd.to_host(product), expected_product)
+    assert np.array_equal(heamd.to_host(relin), ref.relinearize(expected_product, key, threads=threads))
     # caller-provided workspace gives the same words
     import torch
 
     ws = torch.empty(ours.mul_workspace_bytes(16) // 8, dtype=torch.int64, device="cuda")
     again = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), workspace=ws)
     assert torch.equal(again, product)
+
+
+@pytest.mark.parametrize("level", [3, 2, 1])
+def test_mul_and_relinearize_below_the_top_level_config3(oracle, config3, level):
+    """ct x ct + relinearize on the real ring (N=8192) BELOW the top level, where no reference test pins the words
+    (SURVEY.md 4.3): the tiled fused loads (lifted-forward source rows, tensor + inverse, spread, key MAC) with L' < L
+    rows per polynomial, the shared-m_sk constants of a lower-level tool -- every word against the oracle."""
+    ours, ref = config3
+    moduli = ref.ciphertext_context(level).moduli
+    rng = np.random.default_rng(160 + level)
+    lhs, rhs = _uniform(rng, (5, 2), moduli, ours.degree), _uniform(rng, (5, 2), moduli, ours.degree)
+    key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, ours.degree)
+    product = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), level)
+    expected_product = ref.mul(lhs, rhs, level, threads=5)
+    assert np.array_equal(heamd.to_host(product), expected_product)
+    relin = ours.relinearize(product, heamd.to_device(key), level)
+    assert np.array_equal(heamd.to_host(relin), ref.relinearize(expected_product, key, level, threads=5))
+
+
+@pytest.mark.parametrize("count", [9, 12, 16])
+def test_more_than_eight_ciphertext_moduli(oracle, count):
+    """Context.init puts no bound on the number of coefficient moduli (Context.swift:94-143); the BEHZ kernels are
+    specialised for 1..16 ciphertext moduli (16 x 55 bits is the N = 32768 security cap).  Lift, floor, ct x ct,
+    relinearize and modSwitchDownToSingle word for word against the oracle with 9, 12 and 16 of them."""
+    degree = 64
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes([36 + (i % 5) for i in range(count + 1)], False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    assert ours.L == ref.L == count
+    moduli = ref.ciphertext_context().moduli
+    rng = np.random.default_rng(900 + count)
+    x = _uniform(rng, (3,), moduli, degree)
+    assert np.array_equal(heamd.to_host(ours.lift_q_to_qbsk(heamd.to_device(x))),
+                          np.stack([ref.rns_tool().lift_q_to_qbsk(p) for p in x]))
+    y = _uniform(rng, (3,), ref.qbsk_context().moduli, degree)
+    assert np.array_equal(heamd.to_host(ours.floor_qbsk_to_q(heamd.to_device(y))),
+                          np.stack([ref.rns_tool().floor_qbsk_to_q(p) for p in y]))
+    lhs, rhs = _uniform(rng, (2, 2), moduli, degree), _uniform(rng, (2, 2), moduli, degree)
+    key = _uniform(rng, (count, 2), ref.key_switching_context().moduli, degree)
+    product = ours.mul(heamd.to_device(lhs), heamd.to_device(rhs))
+    expected = ref.mul(lhs, rhs)
+    assert np.array_equal(heamd.to_host(product), expected)
+    relin = heamd.to_host(ours.relinearize(product, heamd.to_device(key)))
+    assert np.array_equal(relin, ref.relinearize(expected, key))
+    single = relin
+    for level in range(count, 1, -1):
+        single = ref.mod_switch_down(single, 2, level)
+    assert np.array_equal(heamd.to_host(ours.mod_switch_down_to_single(heamd.to_device(relin), 2)), single)
 
 
 def test_mod_switch_down_matches_oracle(oracle, small):
