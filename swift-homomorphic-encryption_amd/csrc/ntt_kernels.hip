@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 // sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] mod ks_modulus[r], accumulated in the carry-counting form.
 // kInverseFromSlabScaled: a plain slab whose context carries t N^-1 (dropExtendedBase without the fused tensor load)
 constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2, kInverseFromSlabScaled = 3;
+constexpr bool kKeyMacBoundedReduce = true;
 struct InverseSource {
     const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
     const uint64_t* second;  // key MAC: the key
@@ -438,19 +439,31 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 #pragma unroll
                 for (int q = 0; q < E; q += 2) {
                     const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
-                    const U64x2 x0 = *reinterpret_cast<const U64x2*>(spread_row + at);
-                    const U64x2 k0 = *reinterpret_cast<const U64x2*>(key_rows + at);
-                    ProductSum acc0 = product_sum_first(x0.x, k0.x), acc1 = product_sum_first(x0.y, k0.y);
-                    for (uint32_t j = 1; j < L; ++j) {
-                        const U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(j) * (L + 1)) << LOGN) + at);
-                        const U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(j) * 2 * top_rows) << LOGN) + at);
+                    // the words of term j + 1 are requested before term j is accumulated (the count L is a run-time
+                    // value: the loop is not unrolled, and without the request ahead every term would wait out its own
+                    // L2 round trip); past the last term the request repeats it -- a load behind a branch would drain
+                    // the queue
+                    U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + at);
+                    U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + at);
+                    ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+                    for (uint32_t j = 0; j < L; ++j) {
+                        const uint32_t ahead = j + 1 < L ? j + 1 : j;
+                        const U64x2 xn = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(ahead) * (L + 1)) << LOGN) + at);
+                        const U64x2 kn = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(ahead) * 2 * top_rows) << LOGN) + at);
                         product_sum_add(acc0, xs.x, ks.x);
                         product_sum_add(acc1, xs.y, ks.y);
+                        xs = xn;
+                        ks = kn;
                     }
-                    // (the one-word-quotient Barrett saves a quarter of this load's instructions and nothing of its time:
-                    // the key MAC streams eight rows per output row, profiles/r02zg_bounded_reduce.txt)
-                    v[k][q] = reduce_product_sum(acc0, mod);
-                    v[k][q + 1] = reduce_product_sum(acc1, mod);
+                    // (the one-word-quotient Barrett where the sum allows it: L products of canonical words stay below
+                    // L p^2 < 2^(64 + wide_shift) = 2^(63 + bits(p)) whenever L p < 2^63)
+                    if (kKeyMacBoundedReduce && mod.wide_shift != 0 && L <= 8 && uint64_t(L) * mod.p < (uint64_t(1) << 63)) {  // wave-uniform
+                        v[k][q] = reduce_product_sum_bounded(acc0, mod);
+                        v[k][q + 1] = reduce_product_sum_bounded(acc1, mod);
+                    } else {
+                        v[k][q] = reduce_product_sum(acc0, mod);
+                        v[k][q + 1] = reduce_product_sum(acc1, mod);
+                    }
                 }
             }
         } else {
@@ -694,12 +707,13 @@ constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
 constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? kRowGroup : 1;
 
-// Rows per workgroup of the fused-load inverse kernels.  Their loads hold far more registers than a plain row load (the
-// key MAC's carry-counting sums, the tensor's four operand streams), so a second row spills: measured on ct x ct +
-// relinearize (profiles/r02i_c3_fused_row_groups.txt), two rows lose 6 % on the key MAC (104 bytes of scratch per lane)
-// and gain nothing on the tensor load -- one row each.  (The fused FORWARD loads -- spread, lift -- are plain row loads
-// and do run two rows per workgroup: relinearize +7 %, convertToEvalFormat +21 %.)
-constexpr int kTensorRowGroup = 1, kKeyMacRowGroup = 1;
+// Rows per workgroup of the fused-load inverse kernels.  The tensor load gains nothing from a second row (the three
+// workgroups of a replica set already gather the same twiddles side by side; profiles/r02i_c3_fused_row_groups.txt,
+// r03j_c3_fused_row_groups.txt).  The key MAC does since its load is a rolled loop over the terms with the next term
+// requested ahead -- two rows then cost 20 bytes of scratch per lane instead of the 104 of the unrolled
+// carry-counting form that lost 6 % in round 2: relinearize 638 -> 659 k/s.  (The fused FORWARD loads -- spread, lift --
+// are plain row loads and run two rows per workgroup: relinearize +7 %, convertToEvalFormat +21 %.)
+constexpr int kTensorRowGroup = 1, kKeyMacRowGroup = 2;
 template <int LOGN, int LOGT>
 constexpr int kTensorRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kTensorRowGroup : 1;
 template <int LOGN, int LOGT>
