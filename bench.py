@@ -80,10 +80,15 @@ def profiled_traffic(key, algorithmic_bytes_per_unit=None):
             entry = json.load(f).get(key)
     except OSError:
         return None
-    if entry and algorithmic_bytes_per_unit is not None and entry.get("hbm_bytes_per_unit", 0) < 0.98 * algorithmic_bytes_per_unit:
-        print(f"bench.py: ignoring {TRAFFIC_PROFILE}[{key}]: {entry.get('hbm_bytes_per_unit')} B/unit is below the "
-              f"algorithmic {algorithmic_bytes_per_unit} B/unit", file=sys.stderr)
-        return None
+    if entry and algorithmic_bytes_per_unit is not None:
+        per_unit = entry.get("hbm_bytes_per_unit")
+        if per_unit is None and entry.get("units_per_launch"):
+            per_unit = entry["hbm_bytes_per_launch"] / entry["units_per_launch"]
+        if per_unit is None or per_unit < algorithmic_bytes_per_unit:
+            print(f"bench.py: ignoring {TRAFFIC_PROFILE}[{key}]: {per_unit} B/unit is below the algorithmic "
+                  f"{algorithmic_bytes_per_unit} B/unit (FETCH_SIZE / WRITE_SIZE are calibrated for 16-byte streaming "
+                  f"accesses only; MI355X_MICROARCH.md)", file=sys.stderr)
+            return None
     return entry
 
 

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 import path_bench  # noqa: E402
 
 print(path_bench.config3_ct_mul(torch, heamd, batch=1024, reps=3))

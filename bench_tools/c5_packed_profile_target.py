@@ -7,6 +7,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "swift-homomorphic-encryption_amd"), os
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 from path_bench import _uniform  # noqa: E402
 
 packed = len(sys.argv) > 1 and sys.argv[1] == "packed"

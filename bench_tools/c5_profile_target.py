@@ -7,6 +7,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "swift-homomorphic-encryption_amd"), os
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 import path_bench  # noqa: E402
 
 print(path_bench.config5_inner_product(torch, heamd, count=1024, columns=128, reps=2))

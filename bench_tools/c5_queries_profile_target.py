@@ -7,6 +7,9 @@ sys.path[:0] = [os.path.join(ROOT, "swift-homomorphic-encryption_amd"), os.path.
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 from path_bench import _uniform  # noqa: E402
 
 queries = int(sys.argv[1]) if len(sys.argv) > 1 else 4

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 import path_bench  # noqa: E402
 
 shapes = [(256, 64), (1024, 32), (1024, 128)] if len(sys.argv) < 2 else [tuple(map(int, a.split("x"))) for a in sys.argv[1:]]

@@ -9,6 +9,9 @@ import torch  # noqa: E402
 
 import heamd  # noqa: E402
 
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
+
 degree, bits, batch = 8192, [55] * 4, 4096
 moduli = heamd.generate_primes(bits, False, degree)
 ctx = heamd.PolyContext(degree, moduli)

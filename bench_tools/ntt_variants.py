@@ -9,6 +9,9 @@ import torch  # noqa: E402
 
 import heamd  # noqa: E402
 
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
+
 NAMES = {0: "auto", 1: "auto-exact", 2: "generic", 3: "16 words/lane", 8: "32 words/lane", 10: "auto-approx"}
 
 

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 import path_bench  # noqa: E402
 
 print(path_bench.config5_pir_chunk(torch, heamd, d0=256, d1=64, reps=5))

@@ -10,6 +10,9 @@ import torch  # noqa: E402
 import heamd  # noqa: E402
 
 
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
+
+
 def run(degree, bits, batch, reps=20):
     moduli = heamd.generate_primes(bits, False, degree)
     ctx = heamd.PolyContext(degree, moduli)

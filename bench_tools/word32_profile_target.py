@@ -7,6 +7,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "swift-homomorphic-encryption_amd"), os
 import torch  # noqa: E402
 
 import heamd  # noqa: E402
+
+
+heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 from word32_scheme_bench import DEGREE, Q, T, uniform32  # noqa: E402
 
 ctx = heamd.BfvContext32(DEGREE, T, Q)
