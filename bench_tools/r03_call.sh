@@ -10,6 +10,7 @@ for step in "$@"; do
     tests) timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log ;;
     ab_ntt) timeout 900 python bench_tools/ab_variants.py run --what degrees --rounds 2 > $O/ab_degrees.txt 2>&1; cat $O/ab_degrees.txt ;;
     ab_c3) timeout 900 python bench_tools/ab_variants.py run --what c3 --rounds 2 > $O/ab_c3.txt 2>&1; cat $O/ab_c3.txt ;;
+    variant_parity) for lib in swift-homomorphic-encryption_amd/lib/variants/libhe_amd_*.so; do echo "== $lib"; HEAMD_LIBRARY=$PWD/$lib timeout 600 python -m pytest tests/test_gpu_ntt.py -m gpu -q -k "${PARITY_K:-4096-bits5 or 8192-bits6 or variants_agree or row_pairs or full_size}" 2>&1 | tail -4; done > $O/variant_parity.txt 2>&1; cat $O/variant_parity.txt ;;
     bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err; cut -c1-600 $O/bench.json ;;
     *) echo "unknown step $step" ;;
   esac

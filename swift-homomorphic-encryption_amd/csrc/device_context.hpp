@@ -38,7 +38,11 @@ struct DeviceModulus {
     // (p below 2^33, above 2^61, or a power of two)
     uint64_t wide_factor;
     uint32_t wide_shift;
-    uint32_t reserved;
+    // The limb-wise quotient factors of a constant c -- floor(c 2^32 / 2p) -- read off c itself: for a modulus just below a
+    // power of two, p = 2^b - delta with delta < 2^(b - 33) (what generatePrimes(preferringSmall: false) returns, i.e.
+    // every parameter set of the reference), floor(c 2^32 / 2p) is c >> split_shift or one more, split_shift = b - 31.
+    // 0 where the modulus is not of that form (ntt_common.hpp kModeSplitShift).
+    uint32_t split_shift;
 };
 
 struct DeviceContext {
@@ -59,6 +63,7 @@ struct DeviceContext {
     uint32_t approx_ok;            // 1 when every modulus is < 2^61 (lazy range [0, 8p) fits 64 bits)
     uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): the NTT runs the fold-free split butterflies
     uint32_t headroom_prefix;      // how many leading moduli are in that range (the Q part of a [Q, Bsk] context)
+    uint32_t shift_prefix;         // how many leading moduli also have DeviceModulus::split_shift != 0
     uint32_t scaled_inverse_degree;  // 1 when `moduli` is a table whose N^-1 constants carry another factor
                                      // (kNttScaledInverseDegree): the inverse transform must not divide by N exactly
 };

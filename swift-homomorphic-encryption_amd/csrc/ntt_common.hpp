@@ -122,7 +122,15 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                                    gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62), the inverse
 //                                    brings its sums back under 2p once their bound reaches 2^9 p (one round for
 //                                    N <= 8192); one float-estimated quotient makes outputs canonical.
-constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3;
+//   kModeSplitShift  the same for moduli just below a power of two (DeviceModulus::split_shift != 0): a gathered twiddle
+//                    is its 16 bytes (w, w 2^32 mod p) alone and the two 31-bit quotient factors are read off those
+//                    words by a shift instead of fetched -- one gather instruction per twiddle instead of two.  A shifted
+//                    factor is at most one below the tabulated one, which lowers the quotient by at most 2 more:
+//                    products in [0, 12p), one more fold in the inverse.  Used where it measures faster (forward
+//                    transforms at N = 4096 -5 %, inverse at N = 16384 -4 %; N = 8192 is indifferent to its gathers'
+//                    bytes: profiles/r03k_ntt_shift_factors.txt).
+constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4;
+constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift; }
 
 using BufferResource = __amdgpu_buffer_rsrc_t;
 typedef unsigned int Dwordx2 __attribute__((ext_vector_type(2)));
@@ -142,13 +150,19 @@ struct Twiddles {
     const U64x2* pairs;
     const uint64_t* factors;
     BufferResource pair_resource, factor_resource;  // split mode gathers
+    uint32_t shift;                                 // kModeSplitShift: the modulus's split_shift (wave-uniform)
     __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree) {
         const size_t at = static_cast<size_t>(modulus_index) << log_degree;
-        if constexpr (MODE == kModeSplit) {
+        shift = 0;
+        if constexpr (is_split(MODE)) {
             pairs = (inverse ? ctx.inverse_split_pairs : ctx.forward_split_pairs) + at;
             factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
             pair_resource = make_resource(pairs, 16u << log_degree);
             factor_resource = make_resource(factors, 8u << log_degree);
+            if constexpr (MODE == kModeSplitShift) {
+                using ConstWord = const __attribute__((address_space(4))) uint32_t;
+                shift = *(ConstWord*)(&ctx.moduli[modulus_index].split_shift);
+            }
         } else {
             pairs = (inverse ? ctx.inverse_twiddles : ctx.forward_twiddles) + at;
             factors = nullptr;
@@ -168,13 +182,19 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
         t.w = pair.x;
         t.second = pair.y;
         t.factors = 0;
-        if constexpr (MODE == kModeSplit) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
+        if constexpr (is_split(MODE)) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
     } else if constexpr (MODE == kModeSplit) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         const Dwordx2 factors = __builtin_amdgcn_raw_buffer_load_b64(tw.factor_resource, lane_index << 3, fixed_index << 3, 0);
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
         t.factors = pack64(factors.x, factors.y);
+    } else if constexpr (MODE == kModeSplitShift) {
+        const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
+        t.w = pack64(pair.x, pair.y);
+        t.second = pack64(pair.z, pair.w);
+        // the low word of each constant >> shift (shift = bits(p) - 31 in [10, 24]; the constants are below 2^55)
+        t.factors = pack64(__builtin_amdgcn_alignbit(pair.y, pair.x, tw.shift), __builtin_amdgcn_alignbit(pair.w, pair.z, tw.shift));
     } else {
         const U64x2 pair = load_twiddle(tw.pairs + fixed_index + lane_index);
         t.w = pair.x;
@@ -186,8 +206,9 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 
 template <int MODE>
 struct Lazy {
-    static constexpr bool kSplit = MODE == kModeSplit;
-    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;  // products < p << this
+    static constexpr bool kSplit = is_split(MODE);
+    // products < p << this (split: [0, 8p); with shifted factors [0, 12p))
+    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : MODE == kModeSplit ? 3 : 4;
     // cap on stage inputs of the inverse transform, as a shift of p (split: sums of two stay below 2^9 p < 2^64)
     static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 8;
     // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
@@ -333,7 +354,9 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     constexpr int COUNT = pass_twiddle_count<LOGE, W, false>();
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
-    static_assert(MODE != kModeSplit || 1 + 8 * LOGN <= 127, "split mode: growth must stay below 2^7 p");
+    // split modes never fold: a word gains at most p << kProductLog per stage; the final reducer takes x < 2^10 p and
+    // p < 2^55 keeps 2^9 p inside 64 bits
+    static_assert(!is_split(MODE) || 1 + (LOGN << Lazy<MODE>::kProductLog) <= 511, "split mode: growth must stay below 2^9 p");
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
     TwiddleWords pending = first;
 #pragma unroll
@@ -354,11 +377,11 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
             for (int o = 0; o < stride; ++o) {
                 uint64_t x = v[row][base + o];
                 const uint64_t y = v[row][base + o + stride];
-                if (MODE != kModeSplit && !(first_stage_canonical && j == 0)) x = csub_uniform(x, half_bound);
-                if constexpr (MODE == kModeSplit || MODE == kModeApprox) {
+                if (!is_split(MODE) && !(first_stage_canonical && j == 0)) x = csub_uniform(x, half_bound);
+                if constexpr (is_split(MODE) || MODE == kModeApprox) {
                     // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
                     uint64_t sum;
-                    if constexpr (MODE == kModeSplit) {
+                    if constexpr (is_split(MODE)) {
                         sum = uniform ? split_mul_add<true, true>(x, y, w.w, w.second, w.factors, neg_p)
                                       : split_mul_add<false, true>(x, y, w.w, w.second, w.factors, neg_p);
                     } else {
@@ -389,7 +412,7 @@ __device__ __forceinline__ TwiddleWords forward_first_twiddle(const Twiddles<MOD
 template <int MODE>
 constexpr int inverse_in_shift(int b) {
     constexpr int H = Lazy<MODE>::kInverseCapLog, K = Lazy<MODE>::kProductLog;
-    if constexpr (MODE != kModeSplit) {
+    if constexpr (!is_split(MODE)) {
         return b == 0 ? 0 : (b + K - 1 < H ? b + K - 1 : H);
     } else {
         int shift = 0;
@@ -462,7 +485,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
                 uint64_t sum = x + y;
                 const uint64_t diff = x + bound - y;
                 if (last_stage) {
-                    if constexpr (MODE == kModeSplit) {
+                    if constexpr (is_split(MODE)) {
                         const LazyReducer reduce(p);
                         if constexpr (SCALED)
                             v[row][base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
@@ -478,7 +501,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
                     }
                 } else {
                     if (fold) {
-                        if constexpr (MODE == kModeSplit) {
+                        if constexpr (is_split(MODE)) {
                             sum = LazyReducer(p).lazy(sum);
                         } else {
                             sum = csub_uniform(sum, bound);
@@ -676,7 +699,7 @@ template <int MODE, int ROWS, int N>
 __device__ __forceinline__ void canonicalize_all(uint64_t (&v)[ROWS][N], uint64_t p) {
 #pragma unroll
     for (int row = 0; row < ROWS; ++row) {
-        if constexpr (MODE == kModeSplit) {
+        if constexpr (is_split(MODE)) {
             const LazyReducer reduce(p);
 #pragma unroll
             for (int r = 0; r < N; ++r) v[row][r] = reduce(v[row][r]);

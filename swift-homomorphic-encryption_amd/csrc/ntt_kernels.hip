@@ -176,7 +176,7 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
                                              const DeviceModulus& mod, uint64_t* lds) {
     TwiddleWords first{0, 0, 0};
     if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
-    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, MODE != kModeSplit>(v, tid, lds);
+    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
     if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
     inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first);
 }
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     v[k], tid, make_resource(spread.base + poly * spread.stride + (j << LOGN), 8u << LOGN));
                 // the split butterflies take any 64-bit multiplicand and have room for an addend below 2p, so they
                 // transform a residue below 2p as it is
-                reduce[k] = SPREAD == kSourceSpread && ctx.moduli[j].p > p && !(MODE == kModeSplit && ctx.moduli[j].p < 2 * p);
+                reduce[k] = SPREAD == kSourceSpread && ctx.moduli[j].p > p && !(is_split(MODE) && ctx.moduli[j].p < 2 * p);
                 if constexpr (SPREAD == kSourceSpread) {
                     if (spread.galois_inverse != 0) {
                         // output coefficient e takes source coefficient i = e g^-1 mod 2N, negated mod q_j when i >= N.
@@ -703,6 +703,11 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
+// Where the shifted-factor butterflies (ntt_common.hpp kModeSplitShift) replace the tabulated ones for the contexts that
+// allow them: the plain-slab launches they measured faster on (profiles/r03k_ntt_shift_factors.txt).
+template <int LOGN, bool INVERSE>
+constexpr bool kShiftFactors = INVERSE ? LOGN == 14 : LOGN == 12;
+
 constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
 constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? kRowGroup : 1;
@@ -727,6 +732,11 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD, ROWS>
                   : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD, ROWS>
                                         : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD, ROWS>;
+    if constexpr (kShiftFactors<LOGN, false> && SPREAD == kSourceSlab) {
+        // every modulus of the launch is just below a power of two: the gathered twiddles' factors come by a shift
+        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
+            kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
                        spread);
@@ -808,6 +818,10 @@ hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceC
         auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, false, ROWS>
                       : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, false, ROWS>
                                             : ntt_inverse_streamed<LOGN, LOGT, kModeExact, false, ROWS>;
+        if constexpr (kShiftFactors<LOGN, true>) {
+            if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
+                kernel = ntt_inverse_streamed<LOGN, LOGT, kModeSplitShift, false, ROWS>;
+        }
         if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
     }

@@ -67,6 +67,10 @@ static DeviceModulus make_constants(u64 p) {
         m.wide_shift = static_cast<uint32_t>(bits - 1);
         m.wide_factor = static_cast<u64>((static_cast<u128>(1) << (64 + bits - 1)) / p);
     }
+    // p = 2^bits - delta, delta < 2^(bits - 33): for every c < p, c 2^32 / 2p - c / 2^(bits - 31) = (c / 2^(bits - 31))
+    // (delta / p) < 2^31 2^(bits - 33) / 2^(bits - 1) = 1/2, so floor(c 2^32 / 2p) is c >> (bits - 31) or one more
+    if (bits >= 41 && bits <= 55 && ((static_cast<u64>(1) << bits) - p) < (static_cast<u64>(1) << (bits - 33)))
+        m.split_shift = static_cast<uint32_t>(bits - 31);
     return m;
 }
 
@@ -285,15 +289,18 @@ u64 PolyContext::max_lazy_product_accumulation_count(uint32_t count) const {
 DeviceContext PolyContext::device_context(uint32_t count) const {
     DeviceContext d = dev_;
     d.moduli_count = count;
-    uint32_t approx = 1, headroom = 1, prefix = 0;
+    uint32_t approx = 1, headroom = 1, prefix = 0, shift = 1, shift_prefix = 0;
     for (uint32_t i = 0; i < count; ++i) {
         if (moduli_[i] >= (static_cast<u64>(1) << 61)) approx = 0;
         if (moduli_[i] >= (static_cast<u64>(1) << 55) || moduli_[i] < (static_cast<u64>(1) << 40)) headroom = 0;
         if (headroom != 0) prefix = i + 1;
+        if (headroom == 0 || host_moduli_[i].split_shift == 0) shift = 0;
+        if (shift != 0) shift_prefix = i + 1;
     }
     d.approx_ok = approx;
     d.headroom_ok = headroom;
     d.headroom_prefix = prefix;
+    d.shift_prefix = shift_prefix;
     return d;
 }
 

@@ -167,6 +167,46 @@ def test_ntt_split_limb_edges(oracle, degree):
     assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab))), ref.inverse_ntt(slab))
 
 
+@pytest.mark.parametrize("bits,batch", [([55, 55, 55], 100), ([55, 50, 61], 90), ([62, 45], 140), ([47], 300)])
+def test_ntt_streamed_rows(oracle, bits, batch):
+    """N = 16384 with more rows than compute units: one workgroup per CU walks over the rows with the next row's words in
+    flight (ntt_forward_streamed / ntt_inverse_streamed) -- every butterfly schedule, row counts that do not divide by
+    the CU count, and (the all-55-bit set) the shifted-factor inverse.  Word for word against the oracle."""
+    degree = 16384
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(len(bits) * 1000 + batch)
+    slab = _rand_slab(rng, batch, moduli, degree)
+    slab[0, :, :] = 0
+    slab[-1, -1, :] = moduli[-1] - 1
+    assert batch * len(moduli) > 256
+    forward = ref.forward_ntt(slab)
+    assert np.array_equal(heamd.to_host(ours.forward_ntt_(heamd.to_device(slab))), forward)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(forward))), slab)
+
+
+@pytest.mark.parametrize("degree", [4096, 16384])
+@pytest.mark.parametrize("bits", [[55, 54], [50, 48, 44], [42, 55], [41, 41]])
+def test_ntt_shifted_factor_moduli(oracle, degree, bits):
+    """Moduli just below a power of two (generatePrimes(preferringSmall: false)) take their gathered twiddles' quotient
+    factors by a shift where that measures faster (forward N = 4096, streamed inverse N = 16384; DeviceModulus::split_shift);
+    42-bit and smaller primes of an NTT-friendly form sit too far below their power of two and keep the table, as does
+    a context that mixes the two.  Limb-edge words included; the oracle decides."""
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    batch = 300 // len(moduli) + 1
+    rng = np.random.default_rng(degree + sum(bits))
+    slab = _rand_slab(rng, batch, moduli, degree)
+    q = np.array(moduli, dtype=np.uint64)[:, None]
+    low_ones = np.uint64(0xFFFFFFFF)
+    slab[0] = (slab[0] | low_ones) % q
+    slab[1] = np.minimum(q - np.uint64(1), (q & ~low_ones) | (slab[1] & low_ones))
+    slab[2] = q - np.uint64(1)
+    forward = ref.forward_ntt(slab)
+    assert np.array_equal(heamd.to_host(ours.forward_ntt_(heamd.to_device(slab))), forward)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(forward))), slab)
+
+
 @pytest.mark.parametrize("moduli_count", [1, 2, 3, 5, 6, 7])
 def test_ntt_row_map_periods(oracle, moduli_count):
     """A workgroup finds its row's modulus with one scalar multiply-high (ntt_kernels.hip locate): every period, with
