@@ -42,3 +42,4 @@ if __name__ == "__main__":
     run(8192, [55] * 4, 4096, variants=(0, 3, 0, 3, 10, 1, 8))
     run(4096, [55] * 2, 8192, variants=(0, 3, 10, 1))
     run(16384, [55] * 4, 1024, variants=(0, 10, 1))
+    run(32768, [55] * 4, 512, variants=(0, 10, 1, 2))

@@ -151,14 +151,17 @@ struct Twiddles {
     const uint64_t* factors;
     BufferResource pair_resource, factor_resource;  // split mode gathers
     uint32_t shift;                                 // kModeSplitShift: the modulus's split_shift (wave-uniform)
-    __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree) {
-        const size_t at = static_cast<size_t>(modulus_index) << log_degree;
+    // `skip`: the table as seen from entry `skip` on (the sub-transforms of an interleaved row index the tail of the
+    // inverse table, ntt_kernels.hip ntt_inverse_interleaved)
+    __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree,
+                                        uint32_t skip = 0) {
+        const size_t at = (static_cast<size_t>(modulus_index) << log_degree) + skip;
         shift = 0;
         if constexpr (is_split(MODE)) {
             pairs = (inverse ? ctx.inverse_split_pairs : ctx.forward_split_pairs) + at;
             factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
-            pair_resource = make_resource(pairs, 16u << log_degree);
-            factor_resource = make_resource(factors, 8u << log_degree);
+            pair_resource = make_resource(pairs, (16u << log_degree) - 16u * skip);
+            factor_resource = make_resource(factors, (8u << log_degree) - 8u * skip);
             if constexpr (MODE == kModeSplitShift) {
                 using ConstWord = const __attribute__((address_space(4))) uint32_t;
                 shift = *(ConstWord*)(&ctx.moduli[modulus_index].split_shift);
@@ -203,6 +206,11 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
     }
     return t;
 }
+
+// How many twiddles of a pass are in flight ahead of the butterflies (forward_pass / inverse_pass): every one held costs
+// its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels.
+template <int MODE>
+constexpr int kTwiddlesAhead = 1;
 
 template <int MODE>
 struct Lazy {
@@ -348,6 +356,33 @@ __device__ __forceinline__ TwiddleWords forward_twiddle(const Twiddles<MODE>& tw
     return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
 }
 
+// One forward butterfly (x, y) -> (x + w y, x - w y + B) in the lazy ranges of MODE (forward_pass).  `fold`: exact /
+// approx bring x under half_bound first (not needed on canonical input); the split modes never fold.
+template <int MODE>
+__device__ __forceinline__ void forward_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
+                                                  uint64_t neg_p, uint64_t half_bound, bool fold) {
+    uint64_t x = first;
+    const uint64_t y = second;
+    if (!is_split(MODE) && fold) x = csub_uniform(x, half_bound);
+    if constexpr (is_split(MODE) || MODE == kModeApprox) {
+        // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
+        uint64_t sum;
+        if constexpr (is_split(MODE)) {
+            sum = uniform ? split_mul_add<true, true>(x, y, w.w, w.second, w.factors, neg_p)
+                          : split_mul_add<false, true>(x, y, w.w, w.second, w.factors, neg_p);
+        } else {
+            sum = uniform ? shoup_lazy4_fma<true>(x, y, w.w, w.second, neg_p)
+                          : shoup_lazy4_fma<false>(x, y, w.w, w.second, neg_p);
+        }
+        first = sum;
+        second = ((x << 1) + half_bound) - sum;
+    } else {
+        const uint64_t t = uniform ? Lazy<MODE>::template mul<true>(y, w, neg_p) : Lazy<MODE>::template mul<false>(y, w, neg_p);
+        first = x + t;
+        second = x + half_bound - t;
+    }
+}
+
 template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS>
 __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              uint64_t p, bool first_stage_canonical, TwiddleWords first) {
@@ -358,7 +393,12 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // p < 2^55 keeps 2^9 p inside 64 bits
     static_assert(!is_split(MODE) || 1 + (LOGN << Lazy<MODE>::kProductLog) <= 511, "split mode: growth must stay below 2^9 p");
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
-    TwiddleWords pending = first;
+    constexpr int AHEAD = kTwiddlesAhead<MODE>;
+    TwiddleWords pending[AHEAD];
+    pending[0] = first;
+#pragma unroll
+    for (int a = 1; a < AHEAD; ++a)
+        if (a < COUNT) pending[a] = forward_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, a);
 #pragma unroll
     for (int k = 0; k < COUNT; ++k) {
         const int j = pass_stage_of<LOGE, W, false>(k), idx = pass_index_in_stage<LOGE, W, false>(k);
@@ -366,37 +406,18 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const int stride = 1 << (b - LO);
         const int base = idx * 2 * stride;
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
-        const TwiddleWords w = pending;
-        if (k + 1 < COUNT) {
-            pending = forward_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
-            __builtin_amdgcn_sched_barrier(0);  // the request stays ahead of the butterflies below
-        }
+        const TwiddleWords w = pending[0];
+#pragma unroll
+        for (int a = 1; a < AHEAD; ++a) pending[a - 1] = pending[a];
+        if (k + AHEAD < COUNT)
+            pending[AHEAD - 1] = forward_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + AHEAD);
+        if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);  // the request stays ahead of the butterflies below
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
-            for (int o = 0; o < stride; ++o) {
-                uint64_t x = v[row][base + o];
-                const uint64_t y = v[row][base + o + stride];
-                if (!is_split(MODE) && !(first_stage_canonical && j == 0)) x = csub_uniform(x, half_bound);
-                if constexpr (is_split(MODE) || MODE == kModeApprox) {
-                    // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
-                    uint64_t sum;
-                    if constexpr (is_split(MODE)) {
-                        sum = uniform ? split_mul_add<true, true>(x, y, w.w, w.second, w.factors, neg_p)
-                                      : split_mul_add<false, true>(x, y, w.w, w.second, w.factors, neg_p);
-                    } else {
-                        sum = uniform ? shoup_lazy4_fma<true>(x, y, w.w, w.second, neg_p)
-                                      : shoup_lazy4_fma<false>(x, y, w.w, w.second, neg_p);
-                    }
-                    v[row][base + o] = sum;
-                    v[row][base + o + stride] = ((x << 1) + half_bound) - sum;
-                    continue;
-                }
-                const uint64_t t = uniform ? Lazy<MODE>::template mul<true>(y, w, neg_p)
-                                           : Lazy<MODE>::template mul<false>(y, w, neg_p);
-                v[row][base + o] = x + t;
-                v[row][base + o + stride] = x + half_bound - t;
-            }
+            for (int o = 0; o < stride; ++o)
+                forward_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, neg_p, half_bound,
+                                        !(first_stage_canonical && j == 0));
         }
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
     }
@@ -445,7 +466,29 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
 // SCALED: mod.inv_degree carries a factor besides N^-1 (DeviceModulus::has_ntt == kNttScaledInverseDegree): the last
 // stage's sums take the Shoup product; otherwise they are divided by N exactly (divide_by_degree).
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, bool SCALED = false>
+// One inverse butterfly below the last stage: (x, y) -> (x + y, (x - y + bound) w) with inputs below `bound` = p <<
+// in_shift; `fold` brings the sum back under the cap (inverse_in_shift).
+template <int MODE>
+__device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
+                                                  uint64_t p, uint64_t neg_p, uint64_t bound, bool fold) {
+    const uint64_t x = first, y = second;
+    uint64_t sum = x + y;
+    const uint64_t diff = x + bound - y;
+    if (fold) {
+        if constexpr (is_split(MODE)) {
+            sum = LazyReducer(p).lazy(sum);
+        } else {
+            sum = csub_uniform(sum, bound);
+        }
+    }
+    first = sum;
+    second = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p) : Lazy<MODE>::template mul<false>(diff, w, neg_p);
+}
+
+// PRIOR: stages of the same transform that ran before the ones on bits [0, LOGN) (the cross stages of an interleaved
+// row, ntt_kernels.hip): they only move the lazy bounds.  LOGD: log2 of the transform's degree (N^-1 = 2^-LOGD).
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, bool SCALED = false, int PRIOR = 0,
+          int LOGD = LOGN>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, bool first_stage_canonical, TwiddleWords first) {
     constexpr int COUNT = pass_twiddle_count<LOGE, W, true>();
@@ -456,7 +499,12 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
     constexpr int H = Lazy<MODE>::kInverseCapLog;
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
-    TwiddleWords pending = first;
+    constexpr int AHEAD = kTwiddlesAhead<MODE>;
+    TwiddleWords pending[AHEAD];
+    pending[0] = first;
+#pragma unroll
+    for (int a = 1; a < AHEAD; ++a)
+        if (a < COUNT) pending[a] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, a);
 #pragma unroll
     for (int k = 0; k < COUNT; ++k) {
         const int j = pass_stage_of<LOGE, W, true>(k), idx = pass_index_in_stage<LOGE, W, true>(k);
@@ -465,51 +513,45 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const int base = idx * 2 * stride;
         const bool last_stage = (b == LOGN - 1);
         const bool canonical_in = first_stage_canonical && j == 0;
-        const int in_shift = canonical_in ? 0 : inverse_in_shift<MODE>(b);
+        const int in_shift = canonical_in ? 0 : inverse_in_shift<MODE>(b + PRIOR);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
         // (without the request one twiddle ahead the kernel fits its 64 registers with nothing spilled -- and runs 4 %
         // slower; without it but with the per-transpose LDS rules, still 1 % slower: profiles/r02ze_lds_schemes.txt)
-        const TwiddleWords w = pending;
-        if (k + 1 < COUNT) {
-            pending = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const TwiddleWords w = pending[0];
+#pragma unroll
+        for (int a = 1; a < AHEAD; ++a) pending[a - 1] = pending[a];
+        if (k + AHEAD < COUNT)
+            pending[AHEAD - 1] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + AHEAD);
+        if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
+                if (!last_stage) {
+                    inverse_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, p, neg_p, bound, fold);
+                    continue;
+                }
                 const uint64_t x = v[row][base + o];
                 const uint64_t y = v[row][base + o + stride];
-                uint64_t sum = x + y;
+                const uint64_t sum = x + y;
                 const uint64_t diff = x + bound - y;
-                if (last_stage) {
+                {
                     if constexpr (is_split(MODE)) {
                         const LazyReducer reduce(p);
                         if constexpr (SCALED)
                             v[row][base + o] = reduce(split_mul_add<true, false>(0, sum, mod.inv_degree, mod.inv_degree_split,
                                                                                  mod.inv_degree_factors, neg_p));
                         else
-                            v[row][base + o] = divide_by_degree<LOGN>(sum, p);  // sum < 2^9 p (inverse_in_shift)
+                            v[row][base + o] = divide_by_degree<LOGD>(sum, p);  // sum < 2^9 p (inverse_in_shift)
                         v[row][base + o + stride] = reduce(split_mul_add<true, false>(
                             0, diff, mod.inv_degree_root, mod.inv_degree_root_split, mod.inv_degree_root_factors, neg_p));
                     } else {
                         v[row][base + o] = SCALED ? shoup_mul(sum, mod.inv_degree, mod.inv_degree_shoup, p)
-                                                  : divide_by_degree<LOGN>(sum, p);  // sum < 8p
+                                                  : divide_by_degree<LOGD>(sum, p);  // sum < 8p
                         v[row][base + o + stride] = shoup_mul(diff, mod.inv_degree_root, mod.inv_degree_root_shoup, p);
                     }
-                } else {
-                    if (fold) {
-                        if constexpr (is_split(MODE)) {
-                            sum = LazyReducer(p).lazy(sum);
-                        } else {
-                            sum = csub_uniform(sum, bound);
-                        }
-                    }
-                    v[row][base + o] = sum;
-                    v[row][base + o + stride] = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p)
-                                                        : Lazy<MODE>::template mul<false>(diff, w, neg_p);
                 }
             }
         }

@@ -131,7 +131,8 @@ __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_
 // (element_index<LOGN, LOGE, LOGN - LOGE, LOGE>), out -- the canonical transforms in the layout of the last pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>).  The first twiddle of a pass is requested before the exchange that
 // feeds the pass.
-template <int LOGN, int LOGE, int MODE, int ROWS>
+// CANONICAL = false: the words stay in the lazy range of MODE (more stages follow: ntt_forward_interleaved).
+template <int LOGN, int LOGE, int MODE, int ROWS, bool CANONICAL = true>
 __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             uint64_t p, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
         exchange<LOGN, LOGE, LO_PREVIOUS, LOGE, 0, S::R, ROWS>(v, tid, lds);
         forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, tid, tw, p, false, first);
     }
-    canonicalize_all<MODE>(v, p);
+    if constexpr (CANONICAL) canonicalize_all<MODE>(v, p);
 }
 
 // One inverse pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout of pass
@@ -171,14 +172,15 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
 // (The streamed kernels have the registers to request it before; it gains them nothing: profiles/r03e_ntt_streamed_pairs.txt.)
 constexpr bool kInverseFirstTwiddleEarly = false;
-template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED>
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
+          int LOGD = LOGN>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
     TwiddleWords first{0, 0, 0};
     if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
     if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
-    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED>(v, tid, tw, mod, false, first);
+    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, false, first);
 }
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
@@ -188,22 +190,27 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
 struct Nothing {
     __device__ __forceinline__ void operator()() const {}
 };
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, typename BeforeTopPass = Nothing>
+// PRIOR / LOGD: the rows are the sub-rows of an interleaved row of degree 2^LOGD whose first PRIOR stages already ran
+// (ntt_inverse_interleaved); `tw` then indexes the tail of the degree's table.
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, typename BeforeTopPass = Nothing, int PRIOR = 0,
+          int LOGD = LOGN>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             const DeviceModulus& mod, uint64_t* lds,
                                             BeforeTopPass before_top_pass = BeforeTopPass{}) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
-    inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS>(
-        v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid));
-    if constexpr (S::P >= 3) inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
-    if constexpr (S::P >= 4) inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
+    inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD>(
+        v, tid, tw, mod, PRIOR == 0, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid));
+    if constexpr (S::P >= 3)
+        inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+    if constexpr (S::P >= 4)
+        inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 5)
-        inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     // into the top pass (uniform twiddles; its last stage folds in N^-1)
     before_top_pass();
-    if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
-    else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED>(v, tid, tw, mod, lds);
+    if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+    else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
 }
 
 template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab, int ROWS = 1>
@@ -612,6 +619,244 @@ __global__ void __launch_bounds__(1 << LOGT, 4)
     }
 }
 
+// ---- interleaved rows: N = 2^(13 + LOGS) as 2^LOGS sub-rows of 8192 words --------------------------------------------
+// A row of 16384 (32768) words fills the CU's LDS as one tile.  Taken as its 2 (4) sub-rows "element index mod 2^LOGS"
+// it is the row group of the N = 8192 kernel: sub-row h holds the words idx = i 2^LOGS + h, and every stage on an element
+// bit b >= LOGS pairs words of ONE sub-row (i and i + 2^(b - LOGS)) under a twiddle that only depends on idx >> (b + 1)
+// = i >> (b - LOGS + 1) -- the same for all sub-rows, and the very index the 8192-point transform of sub-row words uses
+// in its own stage: W[2^s + group] of the degree's table, s < 13, is read exactly as the smaller transform would read
+// its own table.  So the first 13 forward stages are forward_row<13> over the sub-rows (one 76 KB tile in turn, every
+// twiddle fetched once for all sub-rows, two workgroups per CU at N = 16384), and the remaining LOGS stages pair words
+// of different sub-rows held in the same register of the same lane (cross stages, gathered twiddles).  The inverse
+// mirrors it: cross stages first, then inverse_row<13> against the tail of the inverse table (which lists its stages
+// from the low bit up, ntt_common.hpp inverse_twiddle: block m at N - 2m + 1, so the sub-transform's index plus
+// N - 8192).  In the top-pass layout a lane's words i = r 1024 + tid of all sub-rows are 16 (32) contiguous bytes of
+// the row: the forward load and the inverse store move whole lines with 16-byte accesses.
+constexpr int kSubLogN = 13, kSubLogT = 10, kSubLogE = kSubLogN - kSubLogT;
+
+// forward cross stage c (global stage 13 + c) pairs sub-row bit LOGS - 1 - c; twiddle 2^(13+c) + (idx >> (LOGS - c))
+template <int LOGS, int MODE>
+__device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
+                                                     const Twiddles<MODE>& tw, uint64_t p) {
+    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R;
+    static_assert(!is_split(MODE) || 1 + ((kSubLogN + LOGS) << Lazy<MODE>::kProductLog) <= 511, "growth stays below 2^9 p");
+    const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
+    const uint64_t half_bound = p << Lazy<MODE>::kProductLog;
+    const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
+#pragma unroll
+    for (int c = 0; c < LOGS; ++c) {
+        const int count = E << c;  // twiddles of the stage per lane: one per (word, upper sub-row bits)
+        auto request = [&](int k) {
+            const int r = k >> c, upper = k & ((1 << c) - 1);
+            const uint32_t fixed = (1u << (kSubLogN + c)) + (register_part<kSubLogN, kSubLogE, 0, R>(r) << c) + upper;
+            return fetch_twiddle<MODE, false>(tw, lane_words << c, fixed);
+        };
+        TwiddleWords pending = request(0);
+#pragma unroll
+        for (int k = 0; k < count; ++k) {
+            const TwiddleWords w = pending;
+            if (k + 1 < count) {
+                pending = request(k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int r = k >> c, upper = k & ((1 << c) - 1);
+            const int span = 1 << (LOGS - 1 - c);  // sub-row distance of a pair
+#pragma unroll
+            for (int low = 0; low < span; ++low) {
+                const int h = (upper << (LOGS - c)) | low;
+                forward_butterfly<MODE>(v[h][r], v[h + span][r], w, false, neg_p, half_bound, true);
+            }
+            if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// inverse cross stage c pairs sub-row bit c (element bit c): m = N >> (c + 1) groups, twiddle (N - 2m + 1) + (idx >> (c + 1))
+template <int LOGS, int MODE>
+__device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
+                                                     const Twiddles<MODE>& tw, uint64_t p) {
+    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog;
+    constexpr uint32_t N = 1u << (kSubLogN + LOGS);
+    const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
+    const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
+#pragma unroll
+    for (int c = 0; c < LOGS; ++c) {
+        const int in_shift = inverse_in_shift<MODE>(c);
+        const uint64_t bound = p << in_shift;
+        const bool fold = in_shift + 1 > H;
+        const uint32_t m = N >> (c + 1);
+        const int upper_bits = LOGS - 1 - c;  // sub-row bits above the paired one
+        const int count = E << upper_bits;
+        auto request = [&](int k) {
+            const int r = k >> upper_bits, upper = k & ((1 << upper_bits) - 1);
+            const uint32_t fixed = (N - 2 * m + 1) + (register_part<kSubLogN, kSubLogE, 0, R>(r) << upper_bits) + upper;
+            return fetch_twiddle<MODE, false>(tw, lane_words << upper_bits, fixed);
+        };
+        TwiddleWords pending = request(0);
+#pragma unroll
+        for (int k = 0; k < count; ++k) {
+            const TwiddleWords w = pending;
+            if (k + 1 < count) {
+                pending = request(k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int r = k >> upper_bits, upper = k & ((1 << upper_bits) - 1);
+            const int span = 1 << c;
+#pragma unroll
+            for (int low = 0; low < span; ++low) {
+                const int h = (upper << (c + 1)) | low;
+                inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold);
+            }
+            if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Words i = r 1024 + tid (top-pass layout of the sub-rows) of all sub-rows: 8 2^LOGS contiguous bytes of the row per lane.
+template <int LOGS, bool STORE>
+__device__ __forceinline__ void interleaved_top_words(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid, BufferResource row) {
+    constexpr int ROWS = 1 << LOGS, POLICY = row_policy<kSubLogN + LOGS>();
+    const uint32_t lane_bytes = tid << (3 + LOGS);
+#pragma unroll
+    for (int r = 0; r < (1 << kSubLogE); ++r) {
+#pragma unroll
+        for (int h = 0; h < ROWS; h += 2) {
+            const uint32_t fixed = (static_cast<uint32_t>(r) << (kSubLogT + 3 + LOGS)) + h * 8;
+            if constexpr (STORE) {
+                const Dwordx4 words = {lo32(v[h][r]), hi32(v[h][r]), lo32(v[h + 1][r]), hi32(v[h + 1][r])};
+                __builtin_amdgcn_raw_buffer_store_b128(words, row, lane_bytes, fixed, POLICY);
+            } else {
+                const Dwordx4 words = __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, fixed, POLICY);
+                v[h][r] = pack64(words.x, words.y);
+                v[h + 1][r] = pack64(words.z, words.w);
+            }
+        }
+    }
+}
+// Words of the low-pass layout of the sub-rows (element_index<13, 3, 0, 1>: runs of 2 words of a sub-row per lane, i.e.
+// runs of 2^(LOGS + 1) words of the row) of all sub-rows: 16-byte accesses as the words lie.
+template <int LOGS, bool STORE>
+__device__ __forceinline__ void interleaved_low_words(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid, BufferResource row) {
+    constexpr int ROWS = 1 << LOGS, R = Schedule<kSubLogN, kSubLogE>::R, POLICY = row_policy<kSubLogN + LOGS>();
+    const uint32_t lane_bytes = lane_part<kSubLogN, kSubLogE, 0, R>(tid) << (3 + LOGS);
+#pragma unroll
+    for (int r = 0; r < (1 << kSubLogE); ++r) {
+#pragma unroll
+        for (int h = 0; h < ROWS; h += 2) {
+            const uint32_t fixed = (register_part<kSubLogN, kSubLogE, 0, R>(r) << (3 + LOGS)) + h * 8;
+            if constexpr (STORE) {
+                const Dwordx4 words = {lo32(v[h][r]), hi32(v[h][r]), lo32(v[h + 1][r]), hi32(v[h + 1][r])};
+                __builtin_amdgcn_raw_buffer_store_b128(words, row, lane_bytes, fixed, POLICY);
+            } else {
+                const Dwordx4 words = __builtin_amdgcn_raw_buffer_load_b128(row, lane_bytes, fixed, POLICY);
+                v[h][r] = pack64(words.x, words.y);
+                v[h + 1][r] = pack64(words.z, words.w);
+            }
+        }
+    }
+}
+
+// The same words in whole cache lines (ntt_common.hpp global_store_staged / global_load_staged): a lane's run is 2^(LOGS+1)
+// contiguous words of the row, i.e. C = 2^LOGS 16-byte chunks; the wave's block of 64 C chunks per run goes through the
+// wave's own 592-slot slice of the tile (free on both occasions: the exchange next to the low pass never leaves the
+// wave) and crosses the memory interface in lane order, 1 KiB per instruction.
+constexpr bool kInterleavedStaged = true;
+template <int LOGS, bool STORE>
+__device__ __forceinline__ void interleaved_low_words_staged(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
+                                                             BufferResource row, uint64_t* lds) {
+    constexpr int ROWS = 1 << LOGS, C = ROWS, R = Schedule<kSubLogN, kSubLogE>::R, POLICY = row_policy<kSubLogN + LOGS>();
+    static_assert(R == 1 && C * 64 * 16 <= 592 * 8, "runs of two sub-row words; the block fits the wave's slice");
+    const uint32_t lane = tid & 63u;
+    const uint32_t swizzle = (lane >> (4 - LOGS)) & (C - 1);
+    char* const block = reinterpret_cast<char*>(lds + (tid >> 6) * 592u);
+#pragma unroll
+    for (int run = 0; run < (1 << (kSubLogE - R)); ++run) {
+        const uint32_t first = (lane_part<kSubLogN, kSubLogE, 0, R>(tid & ~63u) | register_part<kSubLogN, kSubLogE, 0, R>(run << R))
+                               << LOGS;  // row word the wave's block starts at
+        if constexpr (STORE) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int b = j / (ROWS / 2), h = (j % (ROWS / 2)) * 2;
+                *reinterpret_cast<U64x2*>(block + ((lane * C + (j ^ swizzle)) << 4)) = U64x2{v[h][(run << R) + b], v[h + 1][(run << R) + b]};
+            }
+        }
+        U64x2 picked[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+            const uint32_t owner_swizzle = (owner >> (4 - LOGS)) & (C - 1);
+            char* const at = block + ((owner * C + (slot ^ owner_swizzle)) << 4);
+            if constexpr (STORE) {
+                const U64x2 pair = *reinterpret_cast<const U64x2*>(at);
+                const Dwordx4 words = {lo32(pair.x), hi32(pair.x), lo32(pair.y), hi32(pair.y)};
+                __builtin_amdgcn_raw_buffer_store_b128(words, row, (first << 3) + (lane << 4), j << 10, POLICY);
+            } else {
+                const Dwordx4 words = __builtin_amdgcn_raw_buffer_load_b128(row, (first << 3) + (lane << 4), j << 10, POLICY);
+                picked[j] = U64x2{pack64(words.x, words.y), pack64(words.z, words.w)};
+            }
+        }
+        if constexpr (!STORE) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const uint32_t chunk = j * 64 + lane, owner = chunk / C, slot = chunk % C;
+                const uint32_t owner_swizzle = (owner >> (4 - LOGS)) & (C - 1);
+                *reinterpret_cast<U64x2*>(block + ((owner * C + (slot ^ owner_swizzle)) << 4)) = picked[j];
+            }
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int b = j / (ROWS / 2), h = (j % (ROWS / 2)) * 2;
+                const U64x2 pair = *reinterpret_cast<const U64x2*>(block + ((lane * C + (j ^ swizzle)) << 4));
+                v[h][(run << R) + b] = pair.x;
+                v[h + 1][(run << R) + b] = pair.y;
+            }
+        }
+    }
+}
+
+template <int LOGS, int MODE>
+__global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 << LOGS))
+    ntt_forward_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map) {
+    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    uint32_t record, within;
+    size_t rows[1];
+    locate_rows<1>(map, blockIdx.x, rows, record, within);
+    const uint32_t mi = map.mod_base + within;
+    const uint64_t p = ctx.moduli[mi].p;
+    const Twiddles<MODE> tw(ctx, false, mi, LOGD);
+    const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
+    uint64_t v[ROWS][1 << kSubLogE];
+    interleaved_top_words<LOGS, false>(v, tid, row);
+    forward_row<kSubLogN, kSubLogE, MODE, ROWS, false>(v, tid, tw, p, lds);
+    forward_cross_stages<LOGS, MODE>(v, tid, tw, p);
+    canonicalize_all<MODE>(v, p);
+    if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, true>(v, tid, row, lds);
+    else interleaved_low_words<LOGS, true>(v, tid, row);
+}
+
+template <int LOGS, int MODE, bool SCALED>
+__global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 << LOGS))
+    ntt_inverse_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map) {
+    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    uint32_t record, within;
+    size_t rows[1];
+    locate_rows<1>(map, blockIdx.x, rows, record, within);
+    const uint32_t mi = map.mod_base + within;
+    const DeviceModulus mod = ctx.moduli[mi];
+    const Twiddles<MODE> cross(ctx, true, mi, LOGD);
+    const Twiddles<MODE> tail(ctx, true, mi, LOGD, (1u << LOGD) - (1u << kSubLogN));
+    const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
+    uint64_t v[ROWS][1 << kSubLogE];
+    if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
+    else interleaved_low_words<LOGS, false>(v, tid, row);
+    inverse_cross_stages<LOGS, MODE>(v, tid, cross, mod.p);
+    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, Nothing, LOGS, LOGD>(v, tid, tail, mod, lds);
+    interleaved_top_words<LOGS, true>(v, tid, row);
+}
+
 // ---- any power-of-two degree: one workgroup per row, radix-2 stage loop over an LDS (or, for rows that do not
 // fit, global-memory) buffer.  Exact Harvey butterflies in [0, 4p): valid for every modulus <= 2^62 - 1. ---------
 template <bool USE_LDS>
@@ -773,6 +1018,10 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
+    if constexpr (kShiftFactors<LOGN, true> && SOURCE == kInverseFromSlab) {
+        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
+            kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
                        source_spec);
@@ -828,11 +1077,53 @@ hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceC
     return hipGetLastError();
 }
 
+// Interleaved launches (ntt_forward_interleaved / ntt_inverse_interleaved): one workgroup per row of 2^(13 + LOGS) words.
+// N = 16384 takes them for plain slabs instead of the streamed rows (profiles/r03p_ntt_interleaved.txt); N = 32768 has no
+// other tiled kernel.
+constexpr bool kInterleaved16384 = true;
+constexpr bool kInterleavedShiftForward = true, kInterleavedShiftInverse = true;
+template <int LOGS>
+hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+                              hipStream_t stream) {
+    constexpr size_t lds_bytes = lds_words(1u << kSubLogN) * sizeof(uint64_t);
+    using Kernel = void (*)(uint64_t*, const DeviceContext, const RowMap);
+    Kernel kernel;
+    if (!inverse) {
+        kernel = mode == kModeSplit    ? ntt_forward_interleaved<LOGS, kModeSplit>
+                 : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox>
+                                       : ntt_forward_interleaved<LOGS, kModeExact>;
+    } else if (ctx.scaled_inverse_degree != 0) {
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, true>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, true>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, true>;
+    } else {
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, false>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, false>;
+    }
+    // every modulus of the launch just below a power of two: the gathered twiddles' factors come by a shift
+    if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix) {
+        if (!inverse) {
+            if constexpr (kInterleavedShiftForward) kernel = ntt_forward_interleaved<LOGS, kModeSplitShift>;
+        } else if (ctx.scaled_inverse_degree == 0) {
+            if constexpr (kInterleavedShiftInverse) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, false>;
+        }
+    }
+    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), lds_bytes, stream, slab, ctx, map);
+    return hipGetLastError();
+}
+
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
                         uint32_t row_offset = 0, int source = kInverseFromSlab,
                         const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
+    if constexpr (LOGN == 14 && LOGT == 10 && kInterleaved16384) {
+        if (source == kInverseFromSlab || !inverse)
+            return launch_interleaved<1>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                                         rows, stream);
+    }
     if constexpr (kStreamedRows<LOGN, LOGT>) {
         // plain slabs with more rows than one per CU
         if ((source == kInverseFromSlab || !inverse) && rows > compute_units())
@@ -958,6 +1249,9 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
         case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
         case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
         case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
+        case 15:
+            if (source != kInverseFromSlab && inverse) return hipErrorNotSupported;
+            return launch_interleaved<2>(inverse, mode, slab, ctx, make_row_map(mod_base, band_rows, record_rows, band_offset), rows, stream);
         default: return hipErrorNotSupported;
     }
 }
@@ -1077,6 +1371,7 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
+            case 15: return launch_interleaved<2>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, 0, 0), rows, stream);
             default: break;
         }
     }

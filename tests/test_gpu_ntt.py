@@ -185,6 +185,29 @@ def test_ntt_streamed_rows(oracle, bits, batch):
     assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(forward))), slab)
 
 
+@pytest.mark.parametrize("degree", [16384, 32768])
+@pytest.mark.parametrize("bits,batch", [([55, 55, 55], 3), ([55, 50, 61], 5), ([62, 45], 2), ([47], 9), ([61, 61], 4),
+                                        ([50, 48, 44, 41], 1)])
+def test_ntt_interleaved_rows(oracle, degree, bits, batch):
+    """N = 16384 / 32768 as 2 / 4 interleaved sub-rows of 8192 words (ntt_forward_interleaved / ntt_inverse_interleaved):
+    thirteen stages on the sub-rows with shared twiddles, the rest across them -- every butterfly schedule (limb-wise,
+    [0, 8p), exact), limb-edge and extreme words; the oracle decides, word for word."""
+    moduli = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    rng = np.random.default_rng(degree + len(bits) * 1000 + batch)
+    slab = _rand_slab(rng, batch + 3, moduli, degree)
+    q = np.array(moduli, dtype=np.uint64)[:, None]
+    low_ones = np.uint64(0xFFFFFFFF)
+    slab[0] = (slab[0] | low_ones) % q
+    slab[1] = q - np.uint64(1)
+    slab[2] = 0
+    slab[2, :, 1] = 1  # x: the transform is the table of odd powers of psi
+    forward = ref.forward_ntt(slab)
+    assert np.array_equal(heamd.to_host(ours.forward_ntt_(heamd.to_device(slab))), forward)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(forward))), slab)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab))), ref.inverse_ntt(slab))
+
+
 @pytest.mark.parametrize("degree", [4096, 16384])
 @pytest.mark.parametrize("bits", [[55, 54], [50, 48, 44], [42, 55], [41, 41]])
 def test_ntt_shifted_factor_moduli(oracle, degree, bits):
