@@ -127,8 +127,8 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    words by a shift instead of fetched -- one gather instruction per twiddle instead of two.  A shifted
 //                    factor is at most one below the tabulated one, which lowers the quotient by at most 2 more:
 //                    products in [0, 12p), one more fold in the inverse.  Used where it measures faster (forward
-//                    transforms at N = 4096 -5 %, inverse at N = 16384 -4 %; N = 8192 is indifferent to its gathers'
-//                    bytes: profiles/r03k_ntt_shift_factors.txt).
+//                    transforms at N = 4096 -5 %; N = 8192 and the interleaved rows are indifferent to their gathers'
+//                    bytes: profiles/r03k_ntt_shift_factors.txt, r03p_ntt_interleaved.txt).
 constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4;
 constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift; }
 
@@ -208,7 +208,8 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 }
 
 // How many twiddles of a pass are in flight ahead of the butterflies (forward_pass / inverse_pass): every one held costs
-// its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels.
+// its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels -- two ahead lose
+// 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt).
 template <int MODE>
 constexpr int kTwiddlesAhead = 1;
 

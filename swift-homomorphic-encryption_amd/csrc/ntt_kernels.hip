@@ -15,7 +15,9 @@
 //   * twiddles of the first two passes are wave-uniform (scalar loads); later passes gather them from the L2-resident
 //     per-modulus tables, shared by every workgroup of that modulus;
 //   * butterflies: limb-wise Shoup products for the usual <= 55-bit moduli (ntt_common.hpp kModeSplit), Harvey
-//     butterflies with a 3- or 4-multiply quotient for moduli up to 2^61 / 2^62.
+//     butterflies with a 3- or 4-multiply quotient for moduli up to 2^61 / 2^62;
+//   * N = 16384 / 32768: the row as 2 / 4 interleaved sub-rows of 8192 words through the same machinery
+//     (ntt_forward_interleaved / ntt_inverse_interleaved below).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -170,7 +172,6 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
 // transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
-// (The streamed kernels have the registers to request it before; it gains them nothing: profiles/r03e_ntt_streamed_pairs.txt.)
 constexpr bool kInverseFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
           int LOGD = LOGN>
@@ -185,18 +186,11 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
-// `before_top_pass` runs once, ahead of the last exchange: from there on the transform gathers nothing (the top pass's
-// twiddles are scalar loads), which is where a streamed workgroup requests its next row.
-struct Nothing {
-    __device__ __forceinline__ void operator()() const {}
-};
 // PRIOR / LOGD: the rows are the sub-rows of an interleaved row of degree 2^LOGD whose first PRIOR stages already ran
 // (ntt_inverse_interleaved); `tw` then indexes the tail of the degree's table.
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, typename BeforeTopPass = Nothing, int PRIOR = 0,
-          int LOGD = LOGN>
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                            const DeviceModulus& mod, uint64_t* lds,
-                                            BeforeTopPass before_top_pass = BeforeTopPass{}) {
+                                            const DeviceModulus& mod, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
     inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD>(
@@ -208,7 +202,6 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
     if constexpr (S::P >= 5)
         inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     // into the top pass (uniform twiddles; its last stage folds in N^-1)
-    before_top_pass();
     if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
 }
@@ -493,132 +486,6 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     }
 }
 
-// The constants of a modulus, read through the constant address space: inside a loop that also stores to global memory
-// the compiler no longer proves the table unclobbered and would fetch it with vector loads (whose in-order return would
-// then wait for everything in flight).  The tables never change while a context lives.
-__device__ __forceinline__ DeviceModulus load_modulus(const DeviceContext& ctx, uint32_t modulus_index) {
-    using ConstWord = const __attribute__((address_space(4))) uint64_t;
-    static_assert(sizeof(DeviceModulus) % sizeof(uint64_t) == 0, "copied word by word");
-    constexpr int kWords = sizeof(DeviceModulus) / sizeof(uint64_t);
-    ConstWord* const source = (ConstWord*)(ctx.moduli + modulus_index);
-    union {
-        DeviceModulus modulus;
-        uint64_t words[kWords];
-    } copy;
-#pragma unroll
-    for (int i = 0; i < kWords; ++i) copy.words[i] = source[i];  // (the unused ones fold away)
-    return copy.modulus;
-}
-
-// ---- streamed transforms: where a row fills the CU's LDS (N = 16384: one workgroup of 4 waves per SIMD per CU whatever
-// the kernel does), a workgroup per CU walks over rows g, g + G, g + 2G, ... and keeps the NEXT row's words in flight while
-// it transforms the current one -- the register budget of 4 waves per SIMD (128) has room for both.  Vector-memory data
-// returns in order, so the request is placed where the transform does not gather for a while (the first forward passes
-// and the last inverse pass take their twiddles through the scalar cache): a gather issued right behind it would wait
-// for the whole row to arrive from HBM.  The tile is handed from row to row with one workgroup barrier.
-template <int LOGN, int LOGT, int MODE, int ROWS>
-__global__ void __launch_bounds__(1 << LOGT, 4)
-    ntt_forward_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
-    constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LO0 = LOGN - LOGE;
-    using S = Schedule<LOGN, LOGE>;
-    static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-    const uint32_t tid = threadIdx.x;
-    uint64_t v[ROWS][E], next[ROWS][E];
-    uint32_t unit = blockIdx.x, record, within;  // a unit = ROWS rows of one modulus (locate_rows)
-    size_t rows[ROWS];
-    locate_rows<ROWS>(map, unit, rows, record, within);
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k)
-        global_load<LOGN, LOGE, LO0, LOGE>(next[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
-    for (;;) {
-        size_t current[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            current[k] = rows[k];
-#pragma unroll
-            for (int r = 0; r < E; ++r) v[k][r] = next[k][r];
-        }
-        const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);  // (scalar loads of its constants)
-        // the unit after this one (the last one again once there is none: a load behind a branch would drain the queue)
-        const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
-        locate_rows<ROWS>(map, following, rows, record, within);
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k)
-            global_load<LOGN, LOGE, LO0, LOGE>(next[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
-        __builtin_amdgcn_sched_barrier(0);
-        const DeviceModulus mod = load_modulus(ctx, mi);
-        const Twiddles<MODE> tw(ctx, false, mi, LOGN);
-        forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, mod.p, lds);
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const BufferResource out = make_resource(slab + (current[k] << LOGN), 8u << LOGN);
-            if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
-                global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds);
-            } else {
-                global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out);
-            }
-        }
-        if (following == unit) break;
-        unit = following;
-        __syncthreads();  // every wave is done with the tile before the next unit's first exchange writes into it
-    }
-}
-
-template <int LOGN, int LOGT, int MODE, bool SCALED, int ROWS>
-__global__ void __launch_bounds__(1 << LOGT, 4)
-    ntt_inverse_streamed(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const uint32_t total) {
-    constexpr int LOGE = LOGN - LOGT, E = 1 << LOGE, LOL = LOGN - LOGE;
-    using S = Schedule<LOGN, LOGE>;
-    static_assert(S::P >= 2 && S::P <= 5, "streamed rows go through the LDS tile");
-    constexpr bool STAGED = kStagedLoad<LOGN, LOGE, S::R>;  // the next rows wait as the 16-byte chunks of the staged load
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-    const uint32_t tid = threadIdx.x;
-    uint64_t v[ROWS][E];
-    StagedChunks<LOGN, LOGE, STAGED ? S::R : LOGE> chunks[STAGED ? ROWS : 1];
-    uint64_t next[STAGED ? 1 : ROWS][E];
-    uint32_t unit = blockIdx.x, record, within;
-    size_t rows[ROWS];
-    locate_rows<ROWS>(map, unit, rows, record, within);
-    auto request = [&]() {
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
-            if constexpr (STAGED) global_load_staged_request<LOGN, LOGE, S::R>(chunks[k], tid, in);
-            else global_load<LOGN, LOGE, 0, S::R>(next[k], tid, in);
-        }
-    };
-    request();
-    for (;;) {
-        size_t current[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            current[k] = rows[k];
-            if constexpr (STAGED) {
-                global_load_staged_unpack<LOGN, LOGE, S::R>(v[k], chunks[k], tid, lds);
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; ++r) v[k][r] = next[k][r];
-            }
-        }
-        const uint32_t mi = __builtin_amdgcn_readfirstlane(map.mod_base + within);
-        const uint32_t following = unit + gridDim.x < total ? unit + gridDim.x : unit;
-        locate_rows<ROWS>(map, following, rows, record, within);
-        const DeviceModulus mod = load_modulus(ctx, mi);
-        const Twiddles<MODE> tw(ctx, true, mi, LOGN);
-        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED>(v, tid, tw, mod, lds, [&]() {
-            request();
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k)
-            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (current[k] << LOGN), 8u << LOGN));
-        if (following == unit) break;
-        unit = following;
-        __syncthreads();  // the staged pick-up of the next rows writes into the tile
-    }
-}
-
 // ---- interleaved rows: N = 2^(13 + LOGS) as 2^LOGS sub-rows of 8192 words --------------------------------------------
 // A row of 16384 (32768) words fills the CU's LDS as one tile.  Taken as its 2 (4) sub-rows "element index mod 2^LOGS"
 // it is the row group of the N = 8192 kernel: sub-row h holds the words idx = i 2^LOGS + h, and every stage on an element
@@ -853,7 +720,7 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
     else interleaved_low_words<LOGS, false>(v, tid, row);
     inverse_cross_stages<LOGS, MODE>(v, tid, cross, mod.p);
-    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, Nothing, LOGS, LOGD>(v, tid, tail, mod, lds);
+    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS, LOGD>(v, tid, tail, mod, lds);
     interleaved_top_words<LOGS, true>(v, tid, row);
 }
 
@@ -949,9 +816,10 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
 // Where the shifted-factor butterflies (ntt_common.hpp kModeSplitShift) replace the tabulated ones for the contexts that
-// allow them: the plain-slab launches they measured faster on (profiles/r03k_ntt_shift_factors.txt).
+// allow them: the plain-slab launches they measured faster on -- the forward transform at N = 4096
+// (profiles/r03k_ntt_shift_factors.txt; the interleaved rows are indifferent: profiles/r03p_ntt_interleaved.txt).
 template <int LOGN, bool INVERSE>
-constexpr bool kShiftFactors = INVERSE ? LOGN == 14 : LOGN == 12;
+constexpr bool kShiftFactors = !INVERSE && LOGN == 12;
 
 constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
@@ -1018,62 +886,9 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
-    if constexpr (kShiftFactors<LOGN, true> && SOURCE == kInverseFromSlab) {
-        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
-            kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
-    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
                        source_spec);
-    return hipGetLastError();
-}
-
-// Streamed launches (ntt_forward_streamed / ntt_inverse_streamed): for the shapes whose tile leaves room for one workgroup
-// per CU, one workgroup per CU and rows dealt round-robin.
-template <int LOGN, int LOGT>
-constexpr bool kStreamedRows = kRowsPerWorkgroup<LOGN, LOGT> == 1 && Schedule<LOGN, LOGN - LOGT>::P >= 2 &&
-                               lds_words(1u << LOGN) * sizeof(uint64_t) > 80 * 1024;
-inline unsigned compute_units() {
-    static int cached[64] = {};
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 256;
-    if (cached[device] == 0) {
-        int count = 0;
-        if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || count <= 0) count = 256;
-        cached[device] = count;
-    }
-    return static_cast<unsigned>(cached[device]);
-}
-// `units` groups of ROWS rows (locate_rows) over one workgroup per CU
-template <int LOGN, int LOGT, int ROWS>
-hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t units,
-                           hipStream_t stream) {
-    constexpr size_t lds_bytes = lds_words(1u << LOGN) * sizeof(uint64_t);
-    const unsigned workgroups = units < compute_units() ? static_cast<unsigned>(units) : compute_units();
-    const uint32_t total = static_cast<uint32_t>(units);
-    if (!inverse) {
-        auto kernel = mode == kModeSplit    ? ntt_forward_streamed<LOGN, LOGT, kModeSplit, ROWS>
-                      : mode == kModeApprox ? ntt_forward_streamed<LOGN, LOGT, kModeApprox, ROWS>
-                                            : ntt_forward_streamed<LOGN, LOGT, kModeExact, ROWS>;
-        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
-    } else if (ctx.scaled_inverse_degree != 0) {
-        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, true, ROWS>
-                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, true, ROWS>
-                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, true, ROWS>;
-        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
-    } else {
-        auto kernel = mode == kModeSplit    ? ntt_inverse_streamed<LOGN, LOGT, kModeSplit, false, ROWS>
-                      : mode == kModeApprox ? ntt_inverse_streamed<LOGN, LOGT, kModeApprox, false, ROWS>
-                                            : ntt_inverse_streamed<LOGN, LOGT, kModeExact, false, ROWS>;
-        if constexpr (kShiftFactors<LOGN, true>) {
-            if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
-                kernel = ntt_inverse_streamed<LOGN, LOGT, kModeSplitShift, false, ROWS>;
-        }
-        if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map, total);
-    }
     return hipGetLastError();
 }
 
@@ -1081,7 +896,6 @@ hipError_t launch_streamed(bool inverse, int mode, uint64_t* slab, const DeviceC
 // N = 16384 takes them for plain slabs instead of the streamed rows (profiles/r03p_ntt_interleaved.txt); N = 32768 has no
 // other tiled kernel.
 constexpr bool kInterleaved16384 = true;
-constexpr bool kInterleavedShiftForward = true, kInterleavedShiftInverse = true;
 template <int LOGS>
 hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
                               hipStream_t stream) {
@@ -1101,14 +915,6 @@ hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const Devi
                  : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false>
                                        : ntt_inverse_interleaved<LOGS, kModeExact, false>;
     }
-    // every modulus of the launch just below a power of two: the gathered twiddles' factors come by a shift
-    if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix) {
-        if (!inverse) {
-            if constexpr (kInterleavedShiftForward) kernel = ntt_forward_interleaved<LOGS, kModeSplitShift>;
-        } else if (ctx.scaled_inverse_degree == 0) {
-            if constexpr (kInterleavedShiftInverse) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, false>;
-        }
-    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), lds_bytes, stream, slab, ctx, map);
     return hipGetLastError();
@@ -1123,12 +929,6 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
         if (source == kInverseFromSlab || !inverse)
             return launch_interleaved<1>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
                                          rows, stream);
-    }
-    if constexpr (kStreamedRows<LOGN, LOGT>) {
-        // plain slabs with more rows than one per CU
-        if ((source == kInverseFromSlab || !inverse) && rows > compute_units())
-            return launch_streamed<LOGN, LOGT, 1>(inverse, mode, slab, ctx,
-                                                  make_row_map(mod_base, mod_period, row_period, row_offset), rows, stream);
     }
     if (!inverse) {
         return launch_forward_tiled<LOGN, LOGT, kSourceSlab>(mode, slab, ctx, mod_base, mod_period, rows,
@@ -1233,7 +1033,8 @@ const char* ntt_variant_name(uint32_t log_degree) {
     switch (log_degree) {
         case 12: return "ntt_tiled<4096, 512 lanes x 8 words>";
         case 13: return "ntt_tiled<8192, 1024 lanes x 8 words>";
-        case 14: return "ntt_tiled<16384, 1024 lanes x 16 words>";
+        case 14: return "ntt_interleaved<16384 = 2 x 8192, 1024 lanes x 8 words x 2 sub-rows>";
+        case 15: return "ntt_interleaved<32768 = 4 x 8192, 1024 lanes x 8 words x 4 sub-rows>";
         default: return "generic radix-2";
     }
 }

@@ -168,10 +168,9 @@ def test_ntt_split_limb_edges(oracle, degree):
 
 
 @pytest.mark.parametrize("bits,batch", [([55, 55, 55], 100), ([55, 50, 61], 90), ([62, 45], 140), ([47], 300)])
-def test_ntt_streamed_rows(oracle, bits, batch):
-    """N = 16384 with more rows than compute units: one workgroup per CU walks over the rows with the next row's words in
-    flight (ntt_forward_streamed / ntt_inverse_streamed) -- every butterfly schedule, row counts that do not divide by
-    the CU count, and (the all-55-bit set) the shifted-factor inverse.  Word for word against the oracle."""
+def test_ntt_many_rows_16384(oracle, bits, batch):
+    """N = 16384 with more rows than the chip holds workgroups at a time -- every butterfly schedule, row counts that do
+    not divide by the CU count.  Word for word against the oracle."""
     degree = 16384
     moduli = oracle.generate_primes(bits, False, degree)
     ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
@@ -212,7 +211,7 @@ def test_ntt_interleaved_rows(oracle, degree, bits, batch):
 @pytest.mark.parametrize("bits", [[55, 54], [50, 48, 44], [42, 55], [41, 41]])
 def test_ntt_shifted_factor_moduli(oracle, degree, bits):
     """Moduli just below a power of two (generatePrimes(preferringSmall: false)) take their gathered twiddles' quotient
-    factors by a shift where that measures faster (forward N = 4096, streamed inverse N = 16384; DeviceModulus::split_shift);
+    factors by a shift where that measures faster (forward N = 4096; DeviceModulus::split_shift);
     42-bit and smaller primes of an NTT-friendly form sit too far below their power of two and keep the table, as does
     a context that mixes the two.  Limb-edge words included; the oracle decides."""
     moduli = oracle.generate_primes(bits, False, degree)
