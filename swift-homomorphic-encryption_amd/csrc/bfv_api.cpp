@@ -136,8 +136,19 @@ int tensor_and_inverse(const RnsToolLevel& tool, uint64_t* lifted, uint64_t* ten
 }
 int tensor_and_inverse(const RnsToolLevel& tool, uint32_t* lifted, uint32_t* tensor, size_t batch, hipStream_t stream,
                        bool* in_coeff_form) {
-    HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, tool.qbsk->device_context(), batch, stream));
-    *in_coeff_form = false;
+    const uint32_t rows = tool.qbsk->moduli_count();
+    heamd::DeviceContext32 scaled{};
+    if (tool.qbsk->device_context32(rows, scaled) != HE_OK) return invalid_argument("no 4-byte image of the [Q, Bsk] context");
+    scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds the multiplication by t into N^-1
+    hipError_t fused = heamd::launch_ntt32_tensor_inverse(lifted, tensor, scaled, rows, batch, stream);
+    if (fused == hipErrorNotSupported) {
+        (void)hipGetLastError();
+        HEAMD_HIP_TRY(heamd::launch_tensor(lifted, tensor, tool.qbsk->device_context(), batch, stream));
+        *in_coeff_form = false;
+        return HE_OK;
+    }
+    HEAMD_HIP_TRY(fused);
+    *in_coeff_form = true;
     return HE_OK;
 }
 
@@ -161,11 +172,18 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
 }
 hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint32_t* lhs,
                               const uint32_t* rhs, uint32_t* lifted, size_t items, hipStream_t stream) {
-    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream);
+    const uint32_t rows = 2 * L + 1;
+    heamd::DeviceContext32 qbsk32{};
+    if (tool.qbsk->device_context32(rows, qbsk32) != HE_OK) return hipErrorInvalidValue;
+    const bool from_source = heamd::ntt32_lifted_forward_supported(qbsk32) && items * 4 * rows <= (size_t(1) << 30);
+    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream,
+                                                        !from_source);
     if (e != hipSuccess) return e;
-    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream);
+    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream,
+                                             !from_source);
     if (e != hipSuccess) return e;
-    return ntt_records(false, lifted, *tool.qbsk, tool.qbsk->device_context(), 2 * L + 1, items * 4, stream);
+    if (from_source) return heamd::launch_ntt32_lifted_forward(lifted, qbsk32, rows, items, lhs, rhs, 2 * L * n, L, stream);
+    return ntt_records(false, lifted, *tool.qbsk, tool.qbsk->device_context(), rows, items * 4, stream);
 }
 
 // Bfv.mulAssign(ct, ct) (Bfv/Bfv+Multiply.swift:18-85) on slabs of W
@@ -204,7 +222,12 @@ hipError_t spread_to_eval(const uint64_t* target, size_t target_stride, uint64_t
 hipError_t spread_to_eval(const uint32_t* target, size_t target_stride, uint32_t* spread, const PolyContext& ks_ctx,
                           uint32_t L, size_t polys, hipStream_t stream) {
     const DeviceContext ks = ks_ctx.device_context();
-    hipError_t e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
+    heamd::DeviceContext32 ks32{};
+    if (ks_ctx.device_context32(L + 1, ks32) != HE_OK) return hipErrorInvalidValue;
+    hipError_t e = heamd::launch_ntt32_spread(target, target_stride, L, polys, spread, ks32, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_spread(target, target_stride, spread, ks, L, polys, stream);
     if (e != hipSuccess) return e;
     return ntt_records(false, spread, ks_ctx, ks, L + 1, polys * L, stream);
 }
@@ -223,7 +246,12 @@ hipError_t key_mac_to_coeff(const uint64_t* spread, const uint64_t* key, uint64_
 hipError_t key_mac_to_coeff(const uint32_t* spread, const uint32_t* key, uint32_t* prod, const PolyContext& ks_ctx,
                             uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
     const DeviceContext ks = ks_ctx.device_context();
-    hipError_t e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
+    heamd::DeviceContext32 ks32{};
+    if (ks_ctx.device_context32(L + 1, ks32) != HE_OK) return hipErrorInvalidValue;
+    hipError_t e = heamd::launch_ntt32_key_mac_inverse(spread, key, prod, ks32, L, top_rows, polys, stream);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = heamd::launch_key_switch_mac(spread, key, prod, ks, L, top_rows, polys, stream);
     if (e != hipSuccess) return e;
     return ntt_records(true, prod, ks_ctx, ks, L + 1, polys * 2, stream);
 }

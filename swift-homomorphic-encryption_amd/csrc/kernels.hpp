@@ -110,6 +110,20 @@ hipError_t launch_mul_plain32(uint32_t* ct, const uint32_t* pt, const DeviceCont
 // word32_kernels.hip: PolyRq<UInt32> (4-byte words; every modulus <= 2^30 - 1)
 hipError_t launch_ntt32(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base, uint32_t mod_period,
                         size_t rows, hipStream_t stream);
+// the same transforms with the step before them applied to the words as they are loaded (word32_kernels.hip Source32):
+// the key-switching decomposition, the BEHZ tensor product, the inner product with the key-switching key.
+// hipErrorNotSupported where the degree has no tiled 4-byte transform (the caller runs the unfused kernels).
+hipError_t launch_ntt32_spread(const uint32_t* target, size_t stride, uint32_t L, size_t polys, uint32_t* spread,
+                               const DeviceContext32& ks_ctx, hipStream_t stream);
+bool ntt32_lifted_forward_supported(const DeviceContext32& ctx);
+hipError_t launch_ntt32_lifted_forward(uint32_t* lifted, const DeviceContext32& ctx, uint32_t record_rows, size_t items,
+                                       const uint32_t* lhs, const uint32_t* rhs, size_t stride, uint32_t L,
+                                       hipStream_t stream);
+hipError_t launch_ntt32_tensor_inverse(const uint32_t* lifted, uint32_t* out, const DeviceContext32& ctx, uint32_t record_rows,
+                                       size_t items, hipStream_t stream);
+hipError_t launch_ntt32_key_mac_inverse(const uint32_t* spread, const uint32_t* key, uint32_t* out,
+                                        const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
+                                        hipStream_t stream);
 // scalars: device array of L (scalar, 64-bit Shoup factor) pairs, only for MulScalar
 hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t* rhs, const uint64_t* scalars,
                                 const DeviceContext32& ctx, size_t rows, hipStream_t stream);

@@ -15,6 +15,7 @@
 #include "device_math.hpp"
 #include "kernels.hpp"
 #include "ntt_common.hpp"
+#include "placement.hpp"
 
 namespace heamd {
 
@@ -275,17 +276,58 @@ __device__ __forceinline__ void row32_load_staged(uint32_t (&v)[1 << LOGE], uint
     }
 }
 
-template <int LOGN, int LOGT, bool INVERSE>
+// Row sources other than the slab itself, as in ntt_kernels.hip: the step that would otherwise write the slab for this
+// kernel to read back is applied to the words while they are loaded.  All of them take mod_period rows per record with
+// modulus mod_base + (row within the record); the workgroups that read the same source words form one replica set on one
+// XCD (placement.hpp).
+//   kSource32Spread  forward: row (poly, j, r) of a [polys][L][L+1][N] slab is the transform mod ks_modulus[r] of row j of
+//                    polynomial `poly` at first + poly * stride + j * N, reduced mod r first when q_j > modulus r
+//                    (Bfv+Keys.swift:165-179)
+//   kSource32Tensor  inverse: row r of record (item, c), c in {0, 1, 2}, is a0 b0 | a0 b1 + a1 b0 | a1 b1 of row r of the
+//                    four Eval polynomials of the item at first + (item * 4 + k) * mod_period * N
+//                    (Bfv+Multiply.swift:80-82)
+//   kSource32KeyMac  inverse: row r of record (poly, c), c in {0, 1}, is sum_j spread[poly][j][r] key[j][c][key_row(r)]
+//                    mod ks_modulus[r] (Bfv+Keys.swift:180-202): products below 2^60, at most 15 of them in a 64-bit word
+//   kSource32Rows    forward: rows [0, L) of record item * 4 + slot of a [records][mod_period][N] slab are rows of the
+//                    source ciphertexts (liftQToQBsk leaves them equal to its input, RnsTool.swift:329-330): polynomial
+//                    slot & 1 of item `item` of `first` (slots 0, 1) or `second` (slots 2, 3), items `stride` words
+//                    apart; the other rows are read from the slab
+constexpr int kSource32Slab = 0, kSource32Spread = 1, kSource32Tensor = 2, kSource32KeyMac = 3, kSource32Rows = 4;
+struct Source32 {
+    const uint32_t* first;
+    const uint32_t* second;  // key MAC: the key
+    size_t stride;           // spread: words between source polynomials
+    uint32_t L, top_rows;    // spread / key MAC: source moduli; key MAC: rows per key polynomial
+};
+
+template <int LOGN, int LOGT, bool INVERSE, int SOURCE = kSource32Slab>
 __global__ void __launch_bounds__(1 << LOGT)
-    ntt32_tiled_kernel(uint32_t* __restrict__ slab, const DeviceContext32 ctx, uint32_t mod_base, uint32_t mod_period) {
+    ntt32_tiled_kernel(uint32_t* __restrict__ slab, const DeviceContext32 ctx, uint32_t mod_base, uint32_t mod_period,
+                       const Source32 source) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
     static_assert(S::P >= 2 && S::P <= 5, "unsupported pass count");
+    static_assert(SOURCE == kSource32Slab || (SOURCE == kSource32Spread || SOURCE == kSource32Rows) == !INVERSE,
+                  "spread and source rows feed the forward transform");
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const uint32_t tid = threadIdx.x;
-    const size_t row = blockIdx.x;
-    const uint32_t mi = mod_base + static_cast<uint32_t>(row % mod_period);
+    size_t row = blockIdx.x;
+    uint32_t within = 0, set = 0, replica = 0;  // fused sources: row within the record, replica set, member
+    if constexpr (SOURCE == kSource32Slab || SOURCE == kSource32Rows) {
+        set = static_cast<uint32_t>(row / mod_period);  // the record
+        within = static_cast<uint32_t>(row - size_t(set) * mod_period);
+    } else if constexpr (SOURCE == kSource32Spread) {
+        locate_replica(blockIdx.x, gridDim.x / mod_period, mod_period, set, within);  // set = poly * L + j
+        row = size_t(set) * mod_period + within;
+    } else {
+        constexpr uint32_t REPLICAS = SOURCE == kSource32Tensor ? 3 : 2;
+        locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, replica);     // set = record group * rows + r
+        const uint32_t group = set / mod_period;
+        within = set - group * mod_period;
+        row = (size_t(group) * REPLICAS + replica) * mod_period + within;
+    }
+    const uint32_t mi = mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const uint32_t p = static_cast<uint32_t>(mod.p);
     const U32x2* __restrict__ tw = (INVERSE ? ctx.inverse_twiddles : ctx.forward_twiddles) + (static_cast<size_t>(mi) << LOGN);
@@ -293,7 +335,24 @@ __global__ void __launch_bounds__(1 << LOGT)
     uint32_t v[E];
     if constexpr (!INVERSE) {
         constexpr int LO0 = LOGN - LOGE;
-        row32_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
+        if constexpr (SOURCE == kSource32Spread) {
+            const uint32_t poly = set / source.L, j = set - poly * source.L;
+            row32_load<LOGN, LOGE, LO0, LOGE>(v, tid, source.first + size_t(poly) * source.stride + (size_t(j) << LOGN));
+            if (ctx.moduli[j].p > mod.p) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[r] = static_cast<uint32_t>(barrett_reduce64_uniform(v[r], mod.p, mod.barrett64));
+            }
+        } else if constexpr (SOURCE == kSource32Rows) {
+            const uint32_t* from = x;
+            if (within < source.L) {  // wave-uniform
+                const size_t item = set >> 2, slot = set & 3;
+                from = ((slot & 2) != 0 ? source.second : source.first) + item * source.stride +
+                       (((slot & 1) * source.L + within) << LOGN);
+            }
+            row32_load<LOGN, LOGE, LO0, LOGE>(v, tid, from);
+        } else {
+            row32_load<LOGN, LOGE, LO0, LOGE>(v, tid, x);
+        }
         forward_pass32<LOGN, LOGE, LO0, LOGE>(v, tid, tw, p, true);
         tile32_store<LOGN, LOGE, LO0, LOGE>(v, tid, tile);
         __syncthreads();
@@ -329,7 +388,55 @@ __global__ void __launch_bounds__(1 << LOGT)
             row32_store<LOGN, LOGE, 0, S::R>(v, tid, x);
         }
     } else {
-        if constexpr (kStaged32<LOGN, LOGE, S::R>) {
+        if constexpr (SOURCE == kSource32Tensor) {
+            const size_t poly_words = static_cast<size_t>(mod_period) << LOGN;
+            const uint32_t* const base = source.first + size_t(set / mod_period) * 4 * poly_words + (size_t(within) << LOGN);
+            uint32_t a[E], b[E];
+            if (replica != 1) {  // wave-uniform: a0 b0 or a1 b1
+                row32_load<LOGN, LOGE, 0, S::R>(a, tid, base + (replica == 0 ? 0 : 1) * poly_words);
+                row32_load<LOGN, LOGE, 0, S::R>(b, tid, base + (replica == 0 ? 2 : 3) * poly_words);
+#pragma unroll
+                for (int r = 0; r < E; ++r)
+                    v[r] = static_cast<uint32_t>(barrett_reduce64_uniform(mul32(a[r], b[r]), mod.p, mod.barrett64));
+            } else {           // a0 b1 + a1 b0: two products below 2^60 in one word, one reduction
+                uint32_t c[E], d[E];
+                row32_load<LOGN, LOGE, 0, S::R>(a, tid, base);
+                row32_load<LOGN, LOGE, 0, S::R>(b, tid, base + 3 * poly_words);
+                row32_load<LOGN, LOGE, 0, S::R>(c, tid, base + poly_words);
+                row32_load<LOGN, LOGE, 0, S::R>(d, tid, base + 2 * poly_words);
+#pragma unroll
+                for (int r = 0; r < E; ++r)
+                    v[r] = static_cast<uint32_t>(barrett_reduce64_uniform(mad32(c[r], d[r], mul32(a[r], b[r])), mod.p, mod.barrett64));
+            }
+        } else if constexpr (SOURCE == kSource32KeyMac) {
+            const uint32_t L = source.L, top_rows = source.top_rows;
+            const uint32_t key_row = within == L ? top_rows - 1 : within;  // Bfv+Keys.swift:153
+            const size_t poly = set / mod_period;
+            const uint32_t* spread_row = source.first + ((poly * L * mod_period + within) << LOGN);       // + j (L+1) N
+            const uint32_t* key_rows = source.second + ((size_t(replica) * top_rows + key_row) << LOGN);  // + j 2 top_rows N
+            uint64_t sum[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) sum[r] = 0;
+            uint32_t a[E], b[E];
+            row32_load<LOGN, LOGE, 0, S::R>(a, tid, spread_row);
+            row32_load<LOGN, LOGE, 0, S::R>(b, tid, key_rows);
+            for (uint32_t j = 0; j < L; ++j) {
+                // the words of term j + 1 are requested before term j is accumulated (past the last term the request
+                // repeats it: a load behind a branch would drain the queue)
+                const uint32_t ahead = j + 1 < L ? j + 1 : j;
+                uint32_t an[E], bn[E];
+                row32_load<LOGN, LOGE, 0, S::R>(an, tid, spread_row + ((size_t(ahead) * mod_period) << LOGN));
+                row32_load<LOGN, LOGE, 0, S::R>(bn, tid, key_rows + ((size_t(ahead) * 2 * top_rows) << LOGN));
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    sum[r] = mad32(a[r], b[r], sum[r]);
+                    a[r] = an[r];
+                    b[r] = bn[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = static_cast<uint32_t>(barrett_reduce64_uniform(sum[r], mod.p, mod.barrett64));
+        } else if constexpr (kStaged32<LOGN, LOGE, S::R>) {
             row32_load_staged<LOGN, LOGE, S::R>(v, tid, x, tile);
         } else {
             row32_load<LOGN, LOGE, 0, S::R>(v, tid, x);
@@ -365,20 +472,44 @@ __global__ void __launch_bounds__(1 << LOGT)
     }
 }
 
-template <int LOGN, int LOGT>
+template <int LOGN, int LOGT, int SOURCE = kSource32Slab>
 hipError_t launch_ntt32_tiled(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base,
-                              uint32_t mod_period, size_t rows, hipStream_t stream) {
+                              uint32_t mod_period, size_t rows, hipStream_t stream,
+                              const Source32& source = Source32{nullptr, nullptr, 0, 0, 0}) {
     constexpr size_t lds_bytes = tile32_words(1u << LOGN) * sizeof(uint32_t);
-    using Kernel = void (*)(uint32_t*, const DeviceContext32, uint32_t, uint32_t);
-    Kernel kernel = inverse ? ntt32_tiled_kernel<LOGN, LOGT, true> : ntt32_tiled_kernel<LOGN, LOGT, false>;
+    using Kernel = void (*)(uint32_t*, const DeviceContext32, uint32_t, uint32_t, const Source32);
+    Kernel kernel;
+    if constexpr (SOURCE == kSource32Slab) {
+        kernel = inverse ? ntt32_tiled_kernel<LOGN, LOGT, true> : ntt32_tiled_kernel<LOGN, LOGT, false>;
+    } else if constexpr (SOURCE == kSource32Spread || SOURCE == kSource32Rows) {
+        if (inverse) return hipErrorInvalidValue;
+        kernel = ntt32_tiled_kernel<LOGN, LOGT, false, SOURCE>;
+    } else {
+        if (!inverse) return hipErrorInvalidValue;
+        kernel = ntt32_tiled_kernel<LOGN, LOGT, true, SOURCE>;
+    }
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx,
-                       mod_base, mod_period);
+                       mod_base, mod_period, source);
     return hipGetLastError();
+}
+
+// the fused-source launches: every record's rows in one launch (rows <= 2^30), tiled degrees only
+template <int SOURCE>
+hipError_t launch_ntt32_fused(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t record_rows, size_t rows,
+                              const Source32& source, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    if (rows > (size_t(1) << 30) || ctx.degree < 2) return hipErrorNotSupported;
+    switch (ctx.log_degree) {
+        case 12: return launch_ntt32_tiled<12, 9, SOURCE>(inverse, slab, ctx, 0, record_rows, rows, stream, source);
+        case 13: return launch_ntt32_tiled<13, 10, SOURCE>(inverse, slab, ctx, 0, record_rows, rows, stream, source);
+        case 14: return launch_ntt32_tiled<14, 10, SOURCE>(inverse, slab, ctx, 0, record_rows, rows, stream, source);
+        default: return hipErrorNotSupported;
+    }
 }
 
 // ---- element-wise: one lane = one word -------------------------------------------------------------------------
@@ -433,6 +564,40 @@ __global__ void __launch_bounds__(kThreads)
 }
 
 }  // namespace
+
+// Bfv+Keys.swift:165-179 into the forward transform's load: target polynomials of L rows, `stride` words apart ->
+// spread [polys][L][L+1][N] (Eval).  hipErrorNotSupported where the degree has no tiled 4-byte transform.
+hipError_t launch_ntt32_spread(const uint32_t* target, size_t stride, uint32_t L, size_t polys, uint32_t* spread,
+                               const DeviceContext32& ks_ctx, hipStream_t stream) {
+    if (ks_ctx.moduli_count < L + 1) return hipErrorInvalidValue;
+    return launch_ntt32_fused<kSource32Spread>(false, spread, ks_ctx, L + 1, polys * L * (L + 1),
+                                               Source32{target, nullptr, stride, L, 0}, stream);
+}
+// Forward transform of lifted [items][4][rows][N] records whose rows [0, L) were left unwritten by the lift: they are read
+// from the ciphertext pairs (Bfv+Multiply.swift:51-57)
+bool ntt32_lifted_forward_supported(const DeviceContext32& ctx) { return ctx.log_degree >= 12 && ctx.log_degree <= 14; }
+hipError_t launch_ntt32_lifted_forward(uint32_t* lifted, const DeviceContext32& ctx, uint32_t record_rows, size_t items,
+                                       const uint32_t* lhs, const uint32_t* rhs, size_t stride, uint32_t L,
+                                       hipStream_t stream) {
+    return launch_ntt32_fused<kSource32Rows>(false, lifted, ctx, record_rows, items * 4 * record_rows,
+                                             Source32{lhs, rhs, stride, L, 0}, stream);
+}
+// Bfv+Multiply.swift:80-82 into the inverse transform's load: lifted [items][4][rows][N] (Eval) -> out [items][3][rows][N]
+// (Coeff; the context carries t N^-1)
+hipError_t launch_ntt32_tensor_inverse(const uint32_t* lifted, uint32_t* out, const DeviceContext32& ctx, uint32_t record_rows,
+                                       size_t items, hipStream_t stream) {
+    return launch_ntt32_fused<kSource32Tensor>(true, out, ctx, record_rows, items * 3 * record_rows,
+                                               Source32{lifted, nullptr, 0, 0, 0}, stream);
+}
+// Bfv+Keys.swift:180-207 into the inverse transform's load: spread [polys][L][L+1][N], key [L][2][top_rows][N] ->
+// out [polys][2][L+1][N] (Coeff)
+hipError_t launch_ntt32_key_mac_inverse(const uint32_t* spread, const uint32_t* key, uint32_t* out,
+                                        const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
+                                        hipStream_t stream) {
+    if (L > 15) return hipErrorNotSupported;  // the sum of L products below 2^60 stays in 64 bits
+    return launch_ntt32_fused<kSource32KeyMac>(true, out, ks_ctx, L + 1, polys * 2 * (L + 1),
+                                               Source32{spread, key, 0, L, top_rows}, stream);
+}
 
 hipError_t launch_ntt32(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base, uint32_t mod_period,
                         size_t rows, hipStream_t stream) {

@@ -186,6 +186,29 @@ def test_random_wire_formats(oracle, seed):
     assert np.array_equal(got, ref.random_from_seeds(seeds)), (degree, len(seeds))
 
 
+@pytest.mark.parametrize("degree,bits", [(8192, [30, 28, 29, 30]), (16384, [27, 30, 30]), (4096, [30, 20, 30, 24, 30])])
+def test_uint32_fused_transforms_at_every_tiled_degree(oracle, degree, bits):
+    """The 4-byte transforms with fused loads (word32_kernels.hip Source32: key-switching decomposition into the forward
+    transform, tensor product and key inner product into the inverse one) at each degree that has a tiled 4-byte kernel,
+    with moduli of mixed sizes (a decomposed row is reduced where its modulus is the larger one) and an odd batch: ct x ct,
+    relinearize and the Galois key switch word for word against the 32-bit oracle."""
+    dev, host = heamd.to_device32, heamd.to_host32
+    q = oracle.generate_primes(bits, False, degree, word_bits=32)
+    t = oracle.generate_primes([degree.bit_length() + 6], True, degree, word_bits=32)[0]
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(degree + len(bits))
+    moduli, L = q[:-1], len(q) - 1
+    lhs, rhs = _uniform(rng, (3, 2), moduli, degree), _uniform(rng, (3, 2), moduli, degree)
+    lhs[0] = np.array(moduli, dtype=np.uint64)[None, :, None] - np.uint64(1)
+    rhs[1] = 0
+    product = host(ours.mul(dev(lhs), dev(rhs)))
+    assert np.array_equal(product, ref.mul(lhs, rhs))
+    key = _uniform(rng, (L, 2), q, degree)
+    assert np.array_equal(host(ours.relinearize(dev(product), dev(key))), ref.relinearize(product, key))
+    element = 2 * 1234 + 1
+    assert np.array_equal(host(ours.apply_galois(dev(lhs), element, dev(key))), ref.apply_galois(lhs, element, key))
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_uint32_shapes(oracle, seed):
     """Bfv<UInt32> on packed 4-byte slabs over random parameter shapes (17..30-bit moduli, 1..4 ciphertext moduli, degrees
