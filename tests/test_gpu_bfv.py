@@ -581,11 +581,13 @@ def test_inner_product_plain_narrow_moduli(oracle, bits, polys):
 
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55]),
-                                         (8192, [55, 61, 50, 55])])
+                                         (8192, [55, 61, 50, 55]), (16384, [61, 45, 62, 55]), (32768, [55, 50, 55]),
+                                         (32768, [62, 55])])
 def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     """The transforms with a fused load stage (key-switching decomposition, plaintext lift, tensor product, key inner
     product) exist per tiled degree: N = 4096 and 16384 instantiations, headroom and mixed [Q, Bsk] bands, and moduli
-    that force the exact butterflies, word for word against the oracle."""
+    that force the exact butterflies; N = 32768 runs the same pipelines unfused over the interleaved transforms (row
+    bands of the [Q, Bsk] records, t N^-1 contexts).  Word for word against the oracle."""
     t = oracle.generate_primes([17], True, degree)[0]
     q = oracle.generate_primes(bits, False, degree)
     ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
