@@ -309,6 +309,13 @@ constexpr int pass_twiddle_count() {
     for (int j = 0; j < W; ++j) count += INVERSE ? (1 << (LOGE - 1 - j)) : (1 << (LOGE - W + j));
     return count;
 }
+// twiddles of the first `stages` stages of the walk
+template <int LOGE, int W, bool INVERSE>
+constexpr int pass_twiddle_prefix(int stages) {
+    int count = 0;
+    for (int j = 0; j < stages; ++j) count += INVERSE ? (1 << (LOGE - 1 - j)) : (1 << (LOGE - W + j));
+    return count;
+}
 template <int LOGE, int W, bool INVERSE>
 struct PassWalk {
     static constexpr int kCount = pass_twiddle_count<LOGE, W, INVERSE>();
@@ -384,10 +391,12 @@ __device__ __forceinline__ void forward_butterfly(uint64_t& first, uint64_t& sec
     }
 }
 
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS>
+// STAGES: only the first STAGES stages of the layout's W (the one-stage pass of a schedule whose partial pass sits on
+// the TOP bits runs in the layout of a full top pass); `first` is then still twiddle 0.
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, int STAGES = W>
 __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              uint64_t p, bool first_stage_canonical, TwiddleWords first) {
-    constexpr int COUNT = pass_twiddle_count<LOGE, W, false>();
+    constexpr int COUNT = pass_twiddle_prefix<LOGE, W, false>(STAGES);
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;  // Harvey: fold x into [0, half_bound) first
     // split modes never fold: a word gains at most p << kProductLog per stage; the final reducer takes x < 2^10 p and
@@ -488,11 +497,14 @@ __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& sec
 
 // PRIOR: stages of the same transform that ran before the ones on bits [0, LOGN) (the cross stages of an interleaved
 // row, ntt_kernels.hip): they only move the lazy bounds.  LOGD: log2 of the transform's degree (N^-1 = 2^-LOGD).
+// FIRST_STAGE: the pass skips the first FIRST_STAGE stages of the layout's W (the top pass of a schedule whose partial
+// pass sits on the top bits: the lower bits of its layout were paired by the pass before); `first` is the first twiddle
+// of the stages it does run (inverse_first_twiddle with the same FIRST_STAGE).
 template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, bool SCALED = false, int PRIOR = 0,
-          int LOGD = LOGN>
+          int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, bool first_stage_canonical, TwiddleWords first) {
-    constexpr int COUNT = pass_twiddle_count<LOGE, W, true>();
+    constexpr int COUNT = pass_twiddle_count<LOGE, W, true>(), BEGIN = pass_twiddle_prefix<LOGE, W, true>(FIRST_STAGE);
     const uint64_t p = mod.p;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     // Words entering the stage on element bit b live in [0, p << in_shift(b)): canonical input for b = 0; after
@@ -505,9 +517,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     pending[0] = first;
 #pragma unroll
     for (int a = 1; a < AHEAD; ++a)
-        if (a < COUNT) pending[a] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, a);
+        if (BEGIN + a < COUNT) pending[a] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, BEGIN + a);
 #pragma unroll
-    for (int k = 0; k < COUNT; ++k) {
+    for (int k = BEGIN; k < COUNT; ++k) {
         const int j = pass_stage_of<LOGE, W, true>(k), idx = pass_index_in_stage<LOGE, W, true>(k);
         const int b = LO + j;
         const int stride = 1 << (b - LO);
@@ -559,9 +571,10 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES>
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int FIRST_STAGE = 0>
 __device__ __forceinline__ TwiddleWords inverse_first_twiddle(const Twiddles<MODE>& tw, uint32_t tid) {
-    return inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid), 0);
+    return inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid),
+                                                                      pass_twiddle_prefix<LOGE, W, true>(FIRST_STAGE));
 }
 
 template <int LOGN, int LOGE, int LO, int W, int SCHEME = 0>
@@ -759,6 +772,20 @@ template <int LOGN, int LOGE>
 struct Schedule {
     static constexpr int P = (LOGN + LOGE - 1) / LOGE;
     static constexpr int R = LOGN - (P - 1) * LOGE;
+};
+// TOP = true: the partial pass sits on the TOP bits instead -- the FIRST forward pass and the LAST inverse pass, run in
+// the layout of a full top pass -- and the full passes cover bits [0, LOGE), [LOGE, 2 LOGE), ...  For N = 8192 with 8
+// words per lane the passes are then bit 12 | 11-9 | 8-6 | 5-3 | 2-0 instead of 12-10 | 9-7 | 6-4 | 3-1 | 0: the twiddles
+// of three passes instead of two are wave-uniform (scalar loads), a lane gathers 14 twiddles per transform instead of
+// 18, and the one-stage pass -- one butterfly per row and twiddle -- has a single uniform twiddle instead of four
+// gathered ones.  LOW: the width of the pass on the low bits (the layout rows are loaded / stored in).
+template <int LOGN, int LOGE, bool TOP>
+struct PassOrder {
+    using S = Schedule<LOGN, LOGE>;
+    static constexpr bool kTop = TOP && S::R < LOGE && S::P >= 3;
+    static constexpr int LOW = kTop ? LOGE : S::R;
+    // bit offset of full pass k (k = 1 .. P-1, counted from the top) and of the layout the rows leave the last one in
+    static constexpr int lo(int k) { return kTop ? LOGN - S::R - k * LOGE : LOGN - (k + 1) * LOGE; }
 };
 
 

@@ -129,16 +129,50 @@ __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_
     }
 }
 
+// Which tiled kernels run the pass order with the partial pass on the top bits (ntt_common.hpp PassOrder): the plain-slab
+// INVERSE transform at N = 8192 with 8 words per lane, -4.7 % (profiles/r03x_ntt_top_partial.txt).  The forward transform
+// loses 2 % with it (its rows then leave as runs of 8 words through the staged store, and the per-transpose LDS rules
+// were laid out for the other order); the fused inverse loads read their sources 16 bytes per lane in the low-pass
+// layout, and with runs of 8 words per lane instead of 2 every load instruction takes a quarter of 64 lines
+// (relinearize 675 -> 409 k/s) -- both keep the partial pass on the low bits.
+template <int LOGN, int LOGE, bool INVERSE, bool FROM_SLAB>
+constexpr bool kTopPartialOrder = LOGN == 13 && LOGE == 3 && INVERSE && FROM_SLAB;
+
 // ROWS residue rows of one modulus, registers to registers: in -- the words of the top pass
 // (element_index<LOGN, LOGE, LOGN - LOGE, LOGE>), out -- the canonical transforms in the layout of the last pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>).  The first twiddle of a pass is requested before the exchange that
 // feeds the pass.
 // CANONICAL = false: the words stay in the lazy range of MODE (more stages follow: ntt_forward_interleaved).
-template <int LOGN, int LOGE, int MODE, int ROWS, bool CANONICAL = true>
+// One forward pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout (LO_FROM, LOGE); its
+// first twiddle is requested before the exchange.
+template <int LOGN, int LOGE, int LO_FROM, int LO_TO, int MODE, int ROWS>
+__device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw, uint64_t p,
+                                             uint64_t* lds) {
+    const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, false>(tw, tid);
+    exchange<LOGN, LOGE, LO_FROM, LOGE, LO_TO, LOGE, ROWS>(v, tid, lds);
+    forward_pass<LOGN, LOGE, LO_TO, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
+}
+
+// TOP: the pass order with the partial pass on the top bits (ntt_common.hpp PassOrder); out -- the layout of the full pass
+// on bits [0, LOGE).
+template <int LOGN, int LOGE, int MODE, int ROWS, bool CANONICAL = true, bool TOP = false>
 __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             uint64_t p, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int LO0 = LOGN - LOGE;
+    if constexpr (PassOrder<LOGN, LOGE, TOP>::kTop) {
+        using O = PassOrder<LOGN, LOGE, TOP>;
+        // the partial pass in the layout of a full top pass: its stages pair the layout's top R bits
+        forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS, S::R>(
+            v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
+        forward_step<LOGN, LOGE, LO0, O::lo(1), MODE, ROWS>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 3) forward_step<LOGN, LOGE, O::lo(1), O::lo(2), MODE, ROWS>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 4) forward_step<LOGN, LOGE, O::lo(2), O::lo(3), MODE, ROWS>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 5) forward_step<LOGN, LOGE, O::lo(3), O::lo(4), MODE, ROWS>(v, tid, tw, p, lds);
+        static_assert(O::lo(S::P - 1) == 0, "the last full pass sits on bits [0, LOGE)");
+        if constexpr (CANONICAL) canonicalize_all<MODE>(v, p);
+        return;
+    }
     forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS>(
         v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
     if constexpr (S::P >= 3) {
@@ -174,25 +208,42 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
 constexpr bool kInverseFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
-          int LOGD = LOGN>
+          int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
     TwiddleWords first{0, 0, 0};
-    if constexpr (kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
+    if constexpr (kInverseFirstTwiddleEarly)
+        first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
-    if constexpr (!kInverseFirstTwiddleEarly) first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM>(tw, tid);
-    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, false, first);
+    if constexpr (!kInverseFirstTwiddleEarly)
+        first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
+    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE>(v, tid, tw, mod, false, first);
 }
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
 // PRIOR / LOGD: the rows are the sub-rows of an interleaved row of degree 2^LOGD whose first PRIOR stages already ran
 // (ntt_inverse_interleaved); `tw` then indexes the tail of the degree's table.
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN>
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             const DeviceModulus& mod, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
+    if constexpr (PassOrder<LOGN, LOGE, TOP>::kTop) {
+        // in -- the layout of the full pass on bits [0, LOGE); the full passes from the low bits up, then the partial
+        // pass (the transform's last R stages) in the layout of a full top pass
+        using O = PassOrder<LOGN, LOGE, TOP>;
+        inverse_pass<LOGN, LOGE, 0, LOGE, MODE, false, ROWS, false, PRIOR, LOGD>(
+            v, tid, tw, mod, PRIOR == 0, inverse_first_twiddle<LOGN, LOGE, 0, LOGE, MODE, false>(tw, tid));
+        if constexpr (S::P >= 5)
+            inverse_step<LOGN, LOGE, O::lo(4), LOGE, O::lo(3), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        if constexpr (S::P >= 4)
+            inverse_step<LOGN, LOGE, O::lo(3), LOGE, O::lo(2), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        if constexpr (S::P >= 3)
+            inverse_step<LOGN, LOGE, O::lo(2), LOGE, O::lo(1), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, O::lo(1), LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, LOGE - R>(v, tid, tw, mod, lds);
+        return;
+    }
     inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD>(
         v, tid, tw, mod, PRIOR == 0, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid));
     if constexpr (S::P >= 3)
@@ -312,14 +363,16 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             for (int k = 0; k < ROWS; ++k)
                 global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         }
-        forward_row<LOGN, LOGE, MODE, ROWS>(v, tid, tw, p, lds);
+        using O = PassOrder<LOGN, LOGE, kTopPartialOrder<LOGN, LOGE, false, SPREAD == kSourceSlab>>;
+        forward_row<LOGN, LOGE, MODE, ROWS, true, O::kTop>(v, tid, tw, p, lds);
+        constexpr int LO_BEFORE_LOW = O::kTop ? O::lo(S::P - 2) : LOGN - (S::P - 1) * LOGE;
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             const BufferResource out = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
-            if constexpr (kStagedStore<LOGN, LOGE, LOGN - (S::P - 1) * LOGE, S::R>) {
-                global_store_staged<LOGN, LOGE, S::R>(v[k], tid, out, lds);
+            if constexpr (kStagedStore<LOGN, LOGE, LO_BEFORE_LOW, O::LOW>) {
+                global_store_staged<LOGN, LOGE, O::LOW>(v[k], tid, out, lds);
             } else {
-                global_store<LOGN, LOGE, 0, S::R>(v[k], tid, out);
+                global_store<LOGN, LOGE, 0, O::LOW>(v[k], tid, out);
             }
         }
     }
@@ -353,6 +406,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr int LOGE = LOGN - LOGT;
     constexpr int E = 1 << LOGE;
     using S = Schedule<LOGN, LOGE>;
+    using O = PassOrder<LOGN, LOGE, kTopPartialOrder<LOGN, LOGE, true, FROM_SLAB>>;
+    constexpr int LOW = O::LOW;  // the width of the pass on the low bits: the layout the rows are loaded in
     static_assert(S::P >= 1 && S::P <= 5, "unsupported pass count");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -391,14 +446,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const size_t poly_words = static_cast<size_t>(map.record_rows) << LOGN;
             const uint64_t p = mod.p, factor = mod.product_factor;
             const int shift = static_cast<int>(mod.product_shift);
-            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
+            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, LOW>(tid);
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
                 const uint64_t* const source = tensor_source + (first_item + k) * 4 * poly_words +
                                                (static_cast<size_t>(map.band_offset + within) << LOGN);
 #pragma unroll
                 for (int r = 0; r < E; r += 2) {
-                    const size_t at = register_part<LOGN, LOGE, 0, S::R>(r) + lane_words;
+                    const size_t at = register_part<LOGN, LOGE, 0, LOW>(r) + lane_words;
                     if (c != 1) {
                         const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
                         const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
@@ -429,7 +484,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
             const uint32_t r = map.band_offset + within;
             const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
-            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, S::R>(tid);
+            const uint32_t lane_words = lane_part<LOGN, LOGE, 0, LOW>(tid);
             const uint64_t* const key_rows =
                 source_spec.second + ((c * top_rows + key_row) << LOGN) + lane_words;           // + j 2 top_rows N
 #pragma unroll
@@ -438,7 +493,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     source_spec.first + (((first_poly + k) * L * (L + 1) + r) << LOGN) + lane_words;  // + j (L+1) N
 #pragma unroll
                 for (int q = 0; q < E; q += 2) {
-                    const size_t at = register_part<LOGN, LOGE, 0, S::R>(q);
+                    const size_t at = register_part<LOGN, LOGE, 0, LOW>(q);
                     // the words of term j + 1 are requested before term j is accumulated (the count L is a run-time
                     // value: the loop is not unrolled, and without the request ahead every term would wait out its own
                     // L2 round trip); past the last term the request repeats it -- a load behind a branch would drain
@@ -471,14 +526,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
                 const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
-                if constexpr (kStagedLoad<LOGN, LOGE, S::R>) {
-                    global_load_staged<LOGN, LOGE, S::R>(v[k], tid, in, lds);
+                if constexpr (kStagedLoad<LOGN, LOGE, LOW>) {
+                    global_load_staged<LOGN, LOGE, LOW>(v[k], tid, in, lds);
                 } else {
-                    global_load<LOGN, LOGE, 0, S::R>(v[k], tid, in);
+                    global_load<LOGN, LOGE, 0, LOW>(v[k], tid, in);
                 }
             }
         }
-        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED>(v, tid, tw, mod, lds);
+        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop>(v, tid, tw, mod, lds);
         constexpr int LOL = LOGN - LOGE;
 #pragma unroll
         for (int k = 0; k < ROWS; ++k)
