@@ -11,7 +11,8 @@
 //     lane (T = 2^LOGT lanes), and is touched in HBM exactly once in and once out (buffer loads / stores: one 32-bit
 //     lane offset, scalar row offsets -- no 64-bit address arithmetic on the vector ALU);
 //   * log2(N) radix-2 stages are grouped into passes of LOGE stages executed on registers; between passes the row
-//     is transposed through a padded LDS tile (4 transposes for N = 8192 with 8 words per lane: 13 = 3+3+3+3+1);
+//     is transposed through a padded LDS tile (4 transposes for N = 8192 with 8 words per lane: 13 = 3+3+3+3+1, the
+//     one-stage pass on bit 0 or -- the plain-slab inverse -- on bit 12: kTopPartialOrder below);
 //   * twiddles of the first two passes are wave-uniform (scalar loads); later passes gather them from the L2-resident
 //     per-modulus tables, shared by every workgroup of that modulus;
 //   * butterflies: limb-wise Shoup products for the usual <= 55-bit moduli (ntt_common.hpp kModeSplit), Harvey
