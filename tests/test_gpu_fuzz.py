@@ -29,7 +29,7 @@ SEEDS = [int(v) for v in os.environ.get("HEAMD_FUZZ_SEEDS", "11,23,47").split(",
 def test_random_parameter_shapes(oracle, seed):
     rnd = random.Random(seed)
     for trial in range(6):
-        degree = rnd.choice([256, 4096, 8192])
+        degree = rnd.choice([256, 4096, 8192, 16384])
         L = rnd.randint(1, 5)
         bits = [rnd.choice(SIZES) for _ in range(L + 1)]
         q = oracle.generate_primes(bits, False, degree)
