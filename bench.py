@@ -661,7 +661,10 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
         "vs_baseline": None,
         "dtype": description["dtype"],
         "data": "synthetic",
-        "config": description["config"],
+        "config": dict(description["config"],
+                       pre_roll="the job runs untimed for pre_roll_s before the W warm-up steps so that the device leaves "
+                                "its idle power state (set-up; the W warm-up and K timed steps are unchanged); with W = 5 and "
+                                "~1 ms steps the same command reads ~8 % lower without it (DESIGN.md section 6)"),
         "roofline": roofline,
         "extras": dict(extras, all_gather_ms=gather_ms, all_gather_bytes_per_gpu=gather_bytes,
                        value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed
