@@ -43,3 +43,5 @@ if __name__ == "__main__":
     run(4096, [55] * 2, 8192, variants=(0, 3, 10, 1))
     run(16384, [55] * 4, 1024, variants=(0, 10, 1))
     run(32768, [55] * 4, 512, variants=(0, 10, 1, 2))
+    run(8192, [60] * 3, 4096, variants=(0,))
+    run(4096, [60] * 2, 8192, variants=(0,))

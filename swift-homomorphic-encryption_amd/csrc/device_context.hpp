@@ -64,6 +64,9 @@ struct DeviceContext {
     uint32_t headroom_ok;          // 1 when every modulus is in [2^40, 2^55): the NTT runs the fold-free split butterflies
     uint32_t headroom_prefix;      // how many leading moduli are in that range (the Q part of a [Q, Bsk] context)
     uint32_t shift_prefix;         // how many leading moduli also have DeviceModulus::split_shift != 0
+    // bit i: modulus i takes the fold butterflies (ntt_common.hpp kModeFoldMinus / kModeFoldPlus): 2^b - d with
+    // 56 <= b <= 60 and d < 2^(b-33), or 2^60 + e with e < 2^24
+    uint64_t fold_minus_mask, fold_plus_mask;
     uint32_t scaled_inverse_degree;  // 1 when `moduli` is a table whose N^-1 constants carry another factor
                                      // (kNttScaledInverseDegree): the inverse transform must not divide by N exactly
 };

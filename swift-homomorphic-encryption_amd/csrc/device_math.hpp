@@ -308,6 +308,95 @@ __device__ __forceinline__ uint64_t split_mul_add(uint64_t addend, uint64_t y, u
     return pack64(lo32(c0), opaque32(hi32(c0) + lo32(c1)));
 }
 
+// ---- product by a constant for moduli next to a power of two ("fold" butterflies): 5 multiply-adds -------------------
+// For p = 2^b - d (the largest b-bit primes, what generatePrimes(preferringSmall: false) returns) or p = 2^60 + e (the
+// BEHZ auxiliary primes, RnsTool.swift:28-66) the high part of a product folds back by a SHIFT: with y = b0 + b1 2^32 and
+// the constant's (w, wt = w 2^32 mod p),  V = b0 w + b1 wt = w y (mod p)  is below 2^(b+33); cut at F = 2^(b+2):
+//     minus form:  F = 4d (mod p):   r = (V mod F) + (V >> (b+2)) 4d
+//     plus form:   F = -4e (mod p):  r = ((V + e) mod F) + 2^60 - ((V + e) >> 62) 4e      (e + 2^60 = p)
+// r = w y (mod p), 0 <= r < F + 2^31 |4d| < 6p for ANY 64-bit y, no quotient estimate and no table of factors.  V is
+// formed exactly: its low column b0 w0 + b1 t0 may carry (the carry-out of the second multiply-add, one add-with-carry to
+// put it in place), its 2^32 column cannot.  5 multiply-adds, one shift, one mask, three simple operations (five in the
+// plus form) against 9 multiply-adds and two 64-bit shifts for the Shoup product with its estimated quotient: 2.21 against
+// 1.87 T butterflies/s with one conditional subtract each (bench_tools/butterfly_probe.hip).  The constants are scalar
+// work on p (FoldConstants); eligibility is decided on the host (poly_context.cpp).
+struct FoldConstants {
+    uint32_t multiplier;  // 4d, or 2^32 - 4e
+    uint32_t shift, mask; // V >> (b + 2) = U >> shift for U = V >> 32; mask = 2^shift - 1
+    uint32_t high_bias;   // plus form: the high word of 2^60
+    uint64_t addend;      // plus form: e
+};
+template <bool PLUS>
+__device__ __forceinline__ FoldConstants fold_constants(uint64_t p) {
+    FoldConstants c{};
+    if constexpr (PLUS) {
+        const uint64_t e = p - (uint64_t(1) << 60);
+        c.multiplier = 0u - static_cast<uint32_t>(4 * e);
+        c.shift = 30;
+        c.high_bias = 1u << 28;
+        c.addend = e;
+    } else {
+        const int bits = 64 - __builtin_clzll(p);
+        c.multiplier = static_cast<uint32_t>(4 * ((uint64_t(1) << bits) - p));
+        c.shift = static_cast<uint32_t>(bits - 30);
+        c.high_bias = 0;
+        c.addend = 0;
+    }
+    c.mask = (1u << c.shift) - 1u;
+    return c;
+}
+// UNIFORM: the constant's words are wave-uniform (SGPRs); the addend then travels in a VGPR pair (one scalar operand per
+// instruction).
+template <bool UNIFORM, bool PLUS>
+__device__ __forceinline__ uint64_t fold_mul(uint64_t y, uint64_t w, uint64_t wt, const FoldConstants& fc) {
+    const uint32_t b0 = lo32(y), b1 = hi32(y), w0 = lo32(w), w1 = hi32(w), t0 = lo32(wt), t1 = hi32(wt);
+    uint64_t a, t, carry0, carry;
+    if constexpr (UNIFORM) {
+        if constexpr (PLUS) {
+            const uint64_t addend = opaque(fc.addend);
+            asm("v_mad_u64_u32 %0, %2, %4, %6, %8\n\t"
+                "v_mad_u64_u32 %1, %3, %5, %7, %0"
+                : "=&v"(a), "=&v"(t), "=&s"(carry0), "=&s"(carry)
+                : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "v"(addend));
+        } else {
+            asm("v_mad_u64_u32 %0, %2, %4, %6, 0\n\t"
+                "v_mad_u64_u32 %1, %3, %5, %7, %0"
+                : "=&v"(a), "=&v"(t), "=&s"(carry0), "=&s"(carry)
+                : "v"(b0), "v"(b1), "s"(w0), "s"(t0));
+        }
+    } else if constexpr (PLUS) {
+        asm("v_mad_u64_u32 %0, %2, %4, %6, %8\n\t"
+            "v_mad_u64_u32 %1, %3, %5, %7, %0"
+            : "=&v"(a), "=&v"(t), "=&s"(carry0), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "s"(fc.addend));
+    } else {
+        asm("v_mad_u64_u32 %0, %2, %4, %6, 0\n\t"
+            "v_mad_u64_u32 %1, %3, %5, %7, %0"
+            : "=&v"(a), "=&v"(t), "=&s"(carry0), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0));
+    }
+    uint32_t carry_bit;
+    asm("v_addc_co_u32 %0, %1, 0, 0, %1" : "=v"(carry_bit), "+s"(carry));
+    uint64_t u = pack64(hi32(t), carry_bit), carry2;
+    if constexpr (UNIFORM) {
+        asm("v_mad_u64_u32 %0, %1, %2, %4, %0\n\t"
+            "v_mad_u64_u32 %0, %1, %3, %5, %0"
+            : "+v"(u), "=&s"(carry2)
+            : "v"(b0), "v"(b1), "s"(w1), "s"(t1));
+    } else {
+        asm("v_mad_u64_u32 %0, %1, %2, %4, %0\n\t"
+            "v_mad_u64_u32 %0, %1, %3, %5, %0"
+            : "+v"(u), "=&s"(carry2)
+            : "v"(b0), "v"(b1), "v"(w1), "v"(t1));
+    }
+    const uint32_t high = __builtin_amdgcn_alignbit(hi32(u), lo32(u), fc.shift);
+    uint32_t kept = lo32(u) & fc.mask;
+    if constexpr (PLUS) kept = kept + fc.high_bias - high;
+    uint64_t r = pack64(lo32(t), kept), carry3;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(r), "=&s"(carry3) : "v"(high), "s"(fc.multiplier));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t shoup_mul(uint64_t x, uint64_t w, uint64_t wf, uint64_t p) {
     return csub63(shoup_lazy(x, w, wf, 0 - p), 0 - p);  // lazy < 2p < 2^63
 }

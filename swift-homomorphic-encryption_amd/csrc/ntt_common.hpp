@@ -129,8 +129,19 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    products in [0, 12p), one more fold in the inverse.  Used where it measures faster (forward
 //                    transforms at N = 4096 -5 %; N = 8192 and the interleaved rows are indifferent to their gathers'
 //                    bytes: profiles/r03k_ntt_shift_factors.txt, r03p_ntt_interleaved.txt).
-constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4;
+//   kModeFoldMinus / kModeFoldPlus   2^55 < p < 2^60.2 next to a power of two -- p = 2^b - d, 56 <= b <= 60 (the largest
+//                    b-bit primes: the reference's 60-bit parameter sets) or p = 2^60 + e (the BEHZ auxiliary primes): the
+//                    product folds back by a shift (device_math.hpp fold_mul: 5 multiply-adds, products in [0, 6p), no
+//                    factor table), values in [0, 14p) with one conditional subtract per butterfly like the [0, 8p)
+//                    schedule it replaces where the moduli allow it (DeviceContext::fold_minus_mask / fold_plus_mask).
+constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4, kModeFoldMinus = 5, kModeFoldPlus = 6;
 constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift; }
+constexpr bool is_fold(int mode) { return mode == kModeFoldMinus || mode == kModeFoldPlus; }
+template <int MODE>
+__device__ __forceinline__ FoldConstants mode_fold_constants(uint64_t p) {
+    if constexpr (is_fold(MODE)) return fold_constants<MODE == kModeFoldPlus>(p);
+    else return FoldConstants{};
+}
 
 using BufferResource = __amdgpu_buffer_rsrc_t;
 typedef unsigned int Dwordx2 __attribute__((ext_vector_type(2)));
@@ -157,7 +168,7 @@ struct Twiddles {
                                         uint32_t skip = 0) {
         const size_t at = (static_cast<size_t>(modulus_index) << log_degree) + skip;
         shift = 0;
-        if constexpr (is_split(MODE)) {
+        if constexpr (is_split(MODE) || is_fold(MODE)) {  // (w, w 2^32 mod p); the fold butterflies use no factors
             pairs = (inverse ? ctx.inverse_split_pairs : ctx.forward_split_pairs) + at;
             factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
             pair_resource = make_resource(pairs, (16u << log_degree) - 16u * skip);
@@ -192,6 +203,11 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
         t.factors = pack64(factors.x, factors.y);
+    } else if constexpr (is_fold(MODE)) {
+        const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
+        t.w = pack64(pair.x, pair.y);
+        t.second = pack64(pair.z, pair.w);
+        t.factors = 0;
     } else if constexpr (MODE == kModeSplitShift) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         t.w = pack64(pair.x, pair.y);
@@ -217,9 +233,11 @@ template <int MODE>
 struct Lazy {
     static constexpr bool kSplit = is_split(MODE);
     // products < p << this (split: [0, 8p); with shifted factors [0, 12p))
-    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : MODE == kModeSplit ? 3 : 4;
+    // (the fold modes keep their own fixed ranges -- products below 6p, forward words below 14p, inverse words below 6p --
+    // in forward_butterfly / inverse_butterfly; the two constants below are not used for them)
+    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : MODE == kModeSplit ? 3 : is_fold(MODE) ? 3 : 4;
     // cap on stage inputs of the inverse transform, as a shift of p (split: sums of two stay below 2^9 p < 2^64)
-    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 8;
+    static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : is_fold(MODE) ? 3 : 8;
     // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
     template <bool UNIFORM = false>
     __device__ static __forceinline__ uint64_t mul(uint64_t x, const TwiddleWords& w, uint64_t reduction) {
@@ -236,7 +254,7 @@ struct Lazy {
     __device__ static __forceinline__ uint64_t reduction_constant(uint64_t p) {
         if constexpr (kSplit) {
             return 0 - 2 * p;
-        } else if constexpr (MODE == kModeApprox) {
+        } else if constexpr (MODE == kModeApprox || is_fold(MODE)) {
             return 0 - p;  // asm multiply: the uniform constant is read from SGPRs (or copied once when needed in VGPRs)
         } else {
             return opaque(0 - p);  // keep in VGPRs: a uniform multiplicand triggers a poor 64-bit expansion
@@ -368,9 +386,20 @@ __device__ __forceinline__ TwiddleWords forward_twiddle(const Twiddles<MODE>& tw
 // approx bring x under half_bound first (not needed on canonical input); the split modes never fold.
 template <int MODE>
 __device__ __forceinline__ void forward_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
-                                                  uint64_t neg_p, uint64_t half_bound, bool fold) {
+                                                  uint64_t neg_p, uint64_t half_bound, bool fold,
+                                                  const FoldConstants& fc = FoldConstants{}) {
     uint64_t x = first;
     const uint64_t y = second;
+    if constexpr (is_fold(MODE)) {
+        // words below 14p: x under 8p first, the product below 6p; x + r < 14p and x + 6p - r in (0, 14p); p = 0 - neg_p
+        constexpr bool PLUS = MODE == kModeFoldPlus;
+        const uint64_t p = 0 - neg_p;
+        if (fold) x = csub_uniform(x, 8 * p);
+        const uint64_t r = uniform ? fold_mul<true, PLUS>(y, w.w, w.second, fc) : fold_mul<false, PLUS>(y, w.w, w.second, fc);
+        first = x + r;
+        second = x + 6 * p - r;
+        return;
+    }
     if (!is_split(MODE) && fold) x = csub_uniform(x, half_bound);
     if constexpr (is_split(MODE) || MODE == kModeApprox) {
         // x + w y leaves the multiplier's addend port; x - w y + B = (2x + B) - (x + w y)
@@ -403,6 +432,7 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // p < 2^55 keeps 2^9 p inside 64 bits
     static_assert(!is_split(MODE) || 1 + (LOGN << Lazy<MODE>::kProductLog) <= 511, "split mode: growth must stay below 2^9 p");
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
+    const FoldConstants fc = mode_fold_constants<MODE>(p);
     constexpr int AHEAD = kTwiddlesAhead<MODE>;
     TwiddleWords pending[AHEAD];
     pending[0] = first;
@@ -427,7 +457,7 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
 #pragma unroll
             for (int o = 0; o < stride; ++o)
                 forward_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, neg_p, half_bound,
-                                        !(first_stage_canonical && j == 0));
+                                        !(first_stage_canonical && j == 0), fc);
         }
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
     }
@@ -480,8 +510,18 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
 // in_shift; `fold` brings the sum back under the cap (inverse_in_shift).
 template <int MODE>
 __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
-                                                  uint64_t p, uint64_t neg_p, uint64_t bound, bool fold) {
+                                                  uint64_t p, uint64_t neg_p, uint64_t bound, bool fold,
+                                                  const FoldConstants& fc = FoldConstants{}) {
     const uint64_t x = first, y = second;
+    if constexpr (is_fold(MODE)) {
+        // words below 6p (`fold`: not on canonical input): the sum back under 6p, x + 6p - y in (0, 12p), the product below 6p
+        constexpr bool PLUS = MODE == kModeFoldPlus;
+        const uint64_t sum = x + y;
+        first = fold ? csub_uniform(sum, 6 * p) : sum;
+        const uint64_t diff = x + 6 * p - y;
+        second = uniform ? fold_mul<true, PLUS>(diff, w.w, w.second, fc) : fold_mul<false, PLUS>(diff, w.w, w.second, fc);
+        return;
+    }
     uint64_t sum = x + y;
     const uint64_t diff = x + bound - y;
     if (fold) {
@@ -512,6 +552,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     // reaches the cap H every sum is folded back under p << H; split: see inverse_in_shift.
     constexpr int H = Lazy<MODE>::kInverseCapLog;
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
+    const FoldConstants fc = mode_fold_constants<MODE>(p);
     constexpr int AHEAD = kTwiddlesAhead<MODE>;
     TwiddleWords pending[AHEAD];
     pending[0] = first;
@@ -527,8 +568,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         const bool last_stage = (b == LOGN - 1);
         const bool canonical_in = first_stage_canonical && j == 0;
         const int in_shift = canonical_in ? 0 : inverse_in_shift<MODE>(b + PRIOR);
-        const uint64_t bound = p << in_shift;
-        const bool fold = in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
+        // (fold modes: every stage but one on canonical input folds its sums, and the last stage's difference is x + 6p - y)
+        const uint64_t bound = is_fold(MODE) ? (canonical_in ? p : 6 * p) : p << in_shift;
+        const bool fold = is_fold(MODE) ? !canonical_in : in_shift + 1 > H;  // x + y may reach 2 * bound: allowed while that stays under the cap
         const bool uniform = stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b);
         // (without the request one twiddle ahead the kernel fits its 64 registers with nothing spilled -- and runs 4 %
         // slower; without it but with the per-transpose LDS rules, still 1 % slower: profiles/r02ze_lds_schemes.txt)
@@ -543,7 +585,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 if (!last_stage) {
-                    inverse_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, p, neg_p, bound, fold);
+                    inverse_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, p, neg_p, bound, fold, fc);
                     continue;
                 }
                 const uint64_t x = v[row][base + o];
@@ -745,8 +787,9 @@ __device__ __forceinline__ void global_load_staged(uint64_t (&v)[1 << LOGE], uin
 
 template <int MODE>
 __device__ __forceinline__ uint64_t canonicalize(uint64_t x, uint64_t p) {
-    static_assert(MODE == kModeExact || MODE == kModeApprox, "split outputs go through LazyReducer");
-    if constexpr (MODE == kModeApprox) x = csub_uniform(x, 4 * p);
+    static_assert(MODE == kModeExact || MODE == kModeApprox || is_fold(MODE), "split outputs go through LazyReducer");
+    if constexpr (is_fold(MODE)) x = csub_uniform(x, 8 * p);  // below 14p
+    if constexpr (MODE == kModeApprox || is_fold(MODE)) x = csub_uniform(x, 4 * p);
     x = csub_uniform(x, 2 * p);
     return csub_uniform(x, p);
 }

@@ -877,6 +877,21 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 template <int LOGN, bool INVERSE>
 constexpr bool kShiftFactors = !INVERSE && LOGN == 12;
 
+// The fold butterflies (ntt_common.hpp kModeFoldMinus / kModeFoldPlus) in place of the [0, 8p) ones where every modulus of
+// the launch allows them -- the 60-bit moduli of the reference's parameter sets, the 61-bit BEHZ auxiliary primes: the
+// plain-slab transforms and the tensor-fused inverse of the production shapes at N = 4096 / 8192
+// (profiles/r03w_ntt_fold_butterflies.txt).  0: not all of one form.
+constexpr bool kFoldButterflies = true;
+template <int LOGN, int LOGT>
+constexpr bool kFoldShape = kFoldButterflies && ((LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10));
+inline int fold_mode(const DeviceContext& ctx, uint32_t mod_base, uint32_t band_rows) {
+    if (band_rows == 0 || mod_base + band_rows > 64) return 0;
+    const uint64_t band = (band_rows == 64 ? ~uint64_t(0) : ((uint64_t(1) << band_rows) - 1)) << mod_base;
+    if ((ctx.fold_minus_mask & band) == band) return kModeFoldMinus;
+    if ((ctx.fold_plus_mask & band) == band) return kModeFoldPlus;
+    return 0;
+}
+
 constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
 constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? kRowGroup : 1;
@@ -905,6 +920,13 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
         // every modulus of the launch is just below a power of two: the gathered twiddles' factors come by a shift
         if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
             kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
+    }
+    if constexpr (kFoldShape<LOGN, LOGT> && SPREAD == kSourceSlab) {
+        if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
+            const int fold = fold_mode(ctx, map.mod_base, map.band_rows);
+            if (fold == kModeFoldMinus) kernel = ntt_forward_tiled<LOGN, LOGT, kModeFoldMinus, SPREAD, ROWS>;
+            if (fold == kModeFoldPlus) kernel = ntt_forward_tiled<LOGN, LOGT, kModeFoldPlus, SPREAD, ROWS>;
+        }
     }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
@@ -942,6 +964,13 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
+    if constexpr (kFoldShape<LOGN, LOGT> && SOURCE != kInverseFromKeyMac) {
+        if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
+            const int fold = fold_mode(ctx, map.mod_base, map.band_rows);
+            if (fold == kModeFoldMinus) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeFoldMinus, SOURCE, ROWS>;
+            if (fold == kModeFoldPlus) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeFoldPlus, SOURCE, ROWS>;
+        }
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, slab, ctx, map,
                        source_spec);

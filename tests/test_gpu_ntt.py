@@ -207,6 +207,33 @@ def test_ntt_interleaved_rows(oracle, degree, bits, batch):
     assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab))), ref.inverse_ntt(slab))
 
 
+@pytest.mark.parametrize("degree", [4096, 8192])
+@pytest.mark.parametrize("bits,small", [([60, 60, 60], False), ([56, 57, 58, 59], False), ([60], False), ([61, 61, 61, 61, 61], True),
+                                        ([61], True), ([60, 55, 60], False), ([61, 60], True), ([58, 61], False)])
+def test_ntt_fold_butterfly_moduli(oracle, degree, bits, small):
+    """Moduli next to a power of two above 2^55 take the fold butterflies (ntt_common.hpp kModeFoldMinus / kModeFoldPlus):
+    the largest 56..60-bit primes (what the reference's 60-bit parameter sets hold) fold by 2^(b+2) = 4d, the smallest 61-bit
+    primes (the BEHZ auxiliary base, RnsTool.swift:28-66) by 2^62 = -4e; sets that mix the forms, or hold a smaller or a
+    far-off prime, keep the [0, 8p) butterflies.  Limb-edge and extreme words; row counts that leave an odd row; the
+    oracle decides."""
+    moduli = oracle.generate_primes(bits, small, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    batch = 5
+    rng = np.random.default_rng(degree + sum(bits) + int(small))
+    slab = _rand_slab(rng, batch, moduli, degree)
+    q = np.array(moduli, dtype=np.uint64)[:, None]
+    low_ones = np.uint64(0xFFFFFFFF)
+    slab[0] = (slab[0] | low_ones) % q
+    slab[1] = np.minimum(q - np.uint64(1), (q & ~low_ones) | (slab[1] & low_ones))
+    slab[2] = q - np.uint64(1)
+    slab[3] = 0
+    slab[3, :, 1] = 1
+    forward = ref.forward_ntt(slab)
+    assert np.array_equal(heamd.to_host(ours.forward_ntt_(heamd.to_device(slab))), forward)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(forward))), slab)
+    assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab))), ref.inverse_ntt(slab))
+
+
 @pytest.mark.parametrize("degree", [4096, 16384])
 @pytest.mark.parametrize("bits", [[55, 54], [50, 48, 44], [42, 55], [41, 41]])
 def test_ntt_shifted_factor_moduli(oracle, degree, bits):
