@@ -1142,6 +1142,37 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
     }
 }
 
+// The rows of a record (row r uses modulus r) as runs of moduli of one butterfly class -- the fold-free limb-wise
+// butterflies (the leading moduli in [2^40, 2^55)), the fold butterflies of either form, the [0, 8p) ones: one launch per
+// run over that row band of every record.  BEHZ's [Q, Bsk] records with the usual 55-bit ciphertext moduli are two runs
+// (Q | Bsk); with the reference's 60-bit parameter sets, e.g. 29 | 60, 60 | Bsk.  0 runs: the context takes one mode as a
+// whole (a modulus above 2^61: exact butterflies) or has no tables for a split.
+struct BandRun {
+    uint32_t base, rows;
+    int mode;  // what launch_ntt_band is given: kModeSplit or kModeApprox (a fold form is resolved from the band's moduli)
+};
+constexpr int kMaxBandRuns = 8;
+inline int band_runs(const DeviceContext& ctx, uint32_t record_rows, BandRun (&runs)[kMaxBandRuns]) {
+    if (ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr || record_rows == 0 || record_rows > 64) return 0;
+    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
+    auto row_class = [&](uint32_t r) {
+        if (r < prefix) return 0;
+        if (((ctx.fold_minus_mask >> r) & 1) != 0) return 1;
+        if (((ctx.fold_plus_mask >> r) & 1) != 0) return 2;
+        return 3;
+    };
+    int count = 0;
+    for (uint32_t r = 0; r < record_rows;) {
+        const int cls = row_class(r);
+        uint32_t end = r + 1;
+        while (end < record_rows && row_class(end) == cls) ++end;
+        if (count == kMaxBandRuns) return 0;  // a context this fragmented takes one launch in the common mode
+        runs[count++] = BandRun{r, end - r, cls == 0 ? kModeSplit : kModeApprox};
+        r = end;
+    }
+    return count;
+}
+
 // a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way: one
 // launch in the mode that serves every modulus costs one kernel latency instead of two
 constexpr size_t kOneGeneration = 512;
@@ -1151,15 +1182,17 @@ constexpr size_t kOneGeneration = 512;
 // the same slab.  Falls back to one launch when the context has no such prefix or no tiled kernel.
 hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
                             hipStream_t stream) {
-    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
     const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
-    if (!tiled || prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr ||
-        records * record_rows > (size_t(1) << 30) || records * record_rows <= kOneGeneration)
+    BandRun runs[kMaxBandRuns];
+    const int count = tiled ? band_runs(ctx, record_rows, runs) : 0;
+    if (count <= 1 || records * record_rows > (size_t(1) << 30) || records * record_rows <= kOneGeneration)
         return launch_ntt(inverse, slab, ctx, 0, record_rows, records * record_rows, stream);
-    hipError_t e = launch_ntt_band(inverse, slab, ctx, 0, prefix, record_rows, 0, records, kModeSplit, stream);
-    if (e != hipSuccess) return e;
-    return launch_ntt_band(inverse, slab, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox,
-                           stream);
+    for (int k = 0; k < count; ++k) {
+        hipError_t e = launch_ntt_band(inverse, slab, ctx, runs[k].base, runs[k].rows, record_rows, runs[k].base, records,
+                                       runs[k].mode, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // Forward NTT of lifted [Q, Bsk] records whose Q rows are still where the ciphertexts lie (the lift was told not to copy
@@ -1200,16 +1233,18 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
     const size_t records = items * 3;
     if (!tiled || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
-    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
-    if (prefix == 0 || prefix == record_rows || ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr)
-        return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records, production_mode(ctx), stream,
-                               kInverseFromTensor, InverseSource{lifted, nullptr, 0, 0});
     const InverseSource spec{lifted, nullptr, 0, 0};
-    hipError_t e = launch_ntt_band(true, out, ctx, 0, prefix, record_rows, 0, records, kModeSplit, stream,
-                                   kInverseFromTensor, spec);
-    if (e != hipSuccess) return e;
-    return launch_ntt_band(true, out, ctx, prefix, record_rows - prefix, record_rows, prefix, records, kModeApprox, stream,
-                           kInverseFromTensor, spec);
+    BandRun runs[kMaxBandRuns];
+    const int count = band_runs(ctx, record_rows, runs);
+    if (count <= 1)
+        return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records, production_mode(ctx), stream,
+                               kInverseFromTensor, spec);
+    for (int k = 0; k < count; ++k) {
+        hipError_t e = launch_ntt_band(true, out, ctx, runs[k].base, runs[k].rows, record_rows, runs[k].base, records,
+                                       runs[k].mode, stream, kInverseFromTensor, spec);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // Key-switching inner product + inverse NTT in one kernel (Bfv+Keys.swift:180-207): spread [polys][L][L+1][N] (Eval),

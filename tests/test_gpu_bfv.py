@@ -582,12 +582,16 @@ def test_inner_product_plain_narrow_moduli(oracle, bits, polys):
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55, 55]), (16384, [55, 50, 55]), (4096, [61, 45, 62, 55]),
                                          (8192, [55, 61, 50, 55]), (16384, [61, 45, 62, 55]), (32768, [55, 50, 55]),
-                                         (32768, [62, 55])])
+                                         (32768, [62, 55]), (8192, [29, 60, 60]), (8192, [40, 60, 60]), (4096, [60, 60, 60]),
+                                         (8192, [28, 60, 60])])
 def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     """The transforms with a fused load stage (key-switching decomposition, plaintext lift, tensor product, key inner
     product) exist per tiled degree: N = 4096 and 16384 instantiations, headroom and mixed [Q, Bsk] bands, and moduli
     that force the exact butterflies; N = 32768 runs the same pipelines unfused over the interleaved transforms (row
-    bands of the [Q, Bsk] records, t N^-1 contexts).  Word for word against the oracle."""
+    bands of the [Q, Bsk] records, t N^-1 contexts); the reference's 60-bit parameter sets (n_8192_logq_29_60_60 and its
+    siblings, EncryptionParameters.swift:257-263) split their [Q, Bsk] records into runs of one butterfly class each -- the
+    small modulus, the 60-bit ones on the fold butterflies, the auxiliary primes on the other fold form.  Word for word
+    against the oracle."""
     t = oracle.generate_primes([17], True, degree)[0]
     q = oracle.generate_primes(bits, False, degree)
     ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
