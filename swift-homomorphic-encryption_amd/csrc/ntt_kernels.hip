@@ -15,8 +15,9 @@
 //     one-stage pass on bit 0 or -- the plain-slab inverse -- on bit 12: kTopPartialOrder below);
 //   * twiddles of the first two passes are wave-uniform (scalar loads); later passes gather them from the L2-resident
 //     per-modulus tables, shared by every workgroup of that modulus;
-//   * butterflies: limb-wise Shoup products for the usual <= 55-bit moduli (ntt_common.hpp kModeSplit), Harvey
-//     butterflies with a 3- or 4-multiply quotient for moduli up to 2^61 / 2^62;
+//   * butterflies: limb-wise Shoup products for the usual <= 55-bit moduli (ntt_common.hpp kModeSplit), products folded
+//     by a shift for larger moduli next to a power of two (kModeFoldMinus / kModeFoldPlus: the 60-bit parameter sets, the
+//     BEHZ auxiliary primes), Harvey butterflies with a 3- or 4-multiply quotient for the other moduli up to 2^61 / 2^62;
 //   * N = 16384 / 32768: the row as 2 / 4 interleaved sub-rows of 8192 words through the same machinery
 //     (ntt_forward_interleaved / ntt_inverse_interleaved below).
 #include <hip/hip_runtime.h>
