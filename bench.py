@@ -15,10 +15,12 @@ by rank with heamd.sharding, no data-path collective; the RCCL all-gather of the
                     plaintexts per GPU); 8 GPUs = the 2^20 products of configs[4], the database sharded by column as
                     PirUtil.computeResponseForOneChunk groups columns (IndexPir/PirUtil.swift:427-445)
 
-Before the W warm-up steps the job runs untimed for `pre_roll_s` (0.25 s) as part of set-up: the device idles while the
-host builds contexts and inputs, and at ~1 ms per step W = 5 warm-up steps end before its clocks have settled under the
-power cap (20 steps then read 8 % slower than after 100 warm-up steps).  The W warm-up steps and the K timed steps are
-unchanged; `value` is the steady state a server sees and the roofline leg measures.
+The contract's measurement (W warm-up steps, K timed steps) runs twice in the process.  The first pass, straight after
+set-up, is reported as `value_without_pre_roll` / `ms_per_step_without_pre_roll`: the device idles while the host builds
+contexts and inputs, and at ~1 ms per step W = 5 warm-up steps end before its clocks have settled under the power cap
+(20 steps then read 5-8 % slower than after 100 warm-up steps).  Then the job runs untimed for `pre_roll_s` (0.25 s) and
+the same W + K steps are measured again: `value` / `ms_per_step`, the steady state a server sees and the roofline leg
+measures.
 
 The JSON line carries
   * roofline     -- achieved algorithmic HBM bytes/s of the workload's dominant kernel, timed live with HIP events on
@@ -35,6 +37,8 @@ Launch: `python bench.py --gpus 1` or, for N > 1,
 import argparse
 import json
 import os
+import re
+import statistics
 import sys
 import time
 
@@ -48,7 +52,8 @@ BATCH = 4096
 PRE_ROLL_S = 0.25  # untimed set-up run of the job before the W warm-up steps (run_benchmark)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 HBM_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md: measured float4 streaming copy (79 % of peak)
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+ROOFLINE_WARMUPS, ROOFLINE_LAUNCHES = 10, 30  # >= 10 warm-ups, median of >= 30 launches
 
 
 def parse_args():
@@ -76,16 +81,60 @@ def synthetic_slab(torch, moduli, prefix, degree, seed):
     return x % bound
 
 
+def _mangled_kernel(name):
+    """Itanium-mangled fragment of a kernel name as pmc_traffic.py prints it ('ntt_forward_tiled<13, 10, 3, 0, 2>',
+    'floor_kernel<4, unsigned long, true>') -- what the library's symbol table holds for the instantiation."""
+    base, _, args = name.partition("<")
+    if not args:
+        return base.encode()
+    out = []
+    for a in args.rstrip(">").split(","):
+        a = a.strip()
+        if a in ("true", "false"):
+            out.append("Lb%dE" % (a == "true"))
+        elif a == "unsigned long":
+            out.append("m")
+        elif a == "unsigned int":
+            out.append("j")
+        elif re.fullmatch(r"-?\d+", a):
+            out.append("Li%sE" % a.replace("-", "n"))
+        else:
+            return base.encode()  # a type this table does not know: fall back to the bare name
+    return ("%sI%sE" % (base, "".join(out))).encode()
+
+
+_LIBRARY_IMAGE = None
+
+
+def kernels_in_library(names):
+    """True when every kernel the entry was counted on is an instantiation the CURRENT libhe_amd.so still carries (its
+    symbol table lists the kernel stubs): an entry collected on kernels that no longer exist is stale."""
+    global _LIBRARY_IMAGE
+    if _LIBRARY_IMAGE is None:
+        import heamd
+
+        with open(heamd.library_path(), "rb") as f:
+            _LIBRARY_IMAGE = f.read()
+    return [n for n in names if _mangled_kernel(n) not in _LIBRARY_IMAGE]
+
+
 def profiled_traffic(key, algorithmic_bytes_per_unit=None):
     """HBM bytes per unit (and per launch of the dominant kernel) counted by the rocprofv3 --pmc passes committed under
     profiles/ (bench.py cannot run rocprofv3 around itself); None when there is no entry -- or when the entry claims
     FEWER bytes than the algorithm must move (a stale or miscalibrated profile: counters cannot undercut the compulsory
-    traffic of a kernel whose working set exceeds every cache)."""
+    traffic of a kernel whose working set exceeds every cache), or names a kernel the current library does not contain."""
     try:
         with open(TRAFFIC_PROFILE) as f:
             entry = json.load(f).get(key)
     except OSError:
         return None
+    if entry:
+        names = list(entry.get("kernel") or []) + list((entry.get("per_kernel_bytes_per_unit") or {}).keys())
+        missing = kernels_in_library(names)
+        if missing:
+            print(f"bench.py: ignoring {TRAFFIC_PROFILE}[{key}]: counted on kernels the library no longer has: {missing}",
+                  file=sys.stderr)
+            return None
     if entry and algorithmic_bytes_per_unit is not None:
         per_unit = entry.get("hbm_bytes_per_unit")
         if per_unit is None and entry.get("units_per_launch"):
@@ -98,8 +147,10 @@ def profiled_traffic(key, algorithmic_bytes_per_unit=None):
     return entry
 
 
-def time_kernel(torch, fn, reps):
-    """Average duration (s) of fn() over reps launches, HIP events on the current (launch) stream."""
+def time_kernel(torch, fn, reps, warmups=0):
+    """Average duration (s) of fn() over reps back-to-back launches, HIP events on the current (launch) stream."""
+    for _ in range(warmups):
+        fn()
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -109,6 +160,24 @@ def time_kernel(torch, fn, reps):
     stop.record()
     stop.synchronize()
     return start.elapsed_time(stop) * 1e-3 / reps
+
+
+def time_launches(torch, fn, warmups=ROOFLINE_WARMUPS, launches=ROOFLINE_LAUNCHES):
+    """SURVEY.md 8(d)'s protocol for the roofline leg: `warmups` untimed launches, then `launches` launches in one
+    back-to-back stream with a HIP event between consecutive ones (on the launch stream).  Returns (average, median, min)
+    in seconds: the average is the whole region / launches (what rocprofv3's kernel trace averages), the median and the
+    minimum are over the per-launch intervals."""
+    for _ in range(warmups):
+        fn()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    torch.cuda.synchronize()
+    marks[0].record()
+    for k in range(launches):
+        fn()
+        marks[k + 1].record()
+    marks[-1].synchronize()
+    each = [marks[k].elapsed_time(marks[k + 1]) * 1e-3 for k in range(launches)]
+    return marks[0].elapsed_time(marks[-1]) * 1e-3 / launches, statistics.median(each), min(each)
 
 
 def clocks_under_load(torch, fn, seconds=6.0):
@@ -293,8 +362,9 @@ class NttWorkload:
 
     def roofline(self, steps, rank):
         torch, ctx, slab = self.torch, self.ctx, self.slab
-        forward_s = time_kernel(torch, lambda: ctx.forward_ntt_(slab), max(5, steps))
-        inverse_s = time_kernel(torch, lambda: ctx.inverse_ntt_(slab), max(5, steps))
+        launches = max(ROOFLINE_LAUNCHES, steps)
+        forward_s, forward_median_s, forward_min_s = time_launches(torch, lambda: ctx.forward_ntt_(slab), launches=launches)
+        inverse_s, inverse_median_s, _ = time_launches(torch, lambda: ctx.inverse_ntt_(slab), launches=launches)
         polys = slab.shape[0]
         achieved = self.bytes_per_transform * polys / forward_s / 1e9
         # the attainable figure next to the nominal peak: the library's own streaming copy of the same
@@ -324,6 +394,11 @@ class NttWorkload:
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.bytes_per_transform * polys,
             "avg_launch_ms": forward_s * 1e3,
+            "median_launch_ms": forward_median_s * 1e3,
+            "min_launch_ms": forward_min_s * 1e3,
+            "frac_at_median": self.bytes_per_transform * polys / forward_median_s / 1e9 / HBM_PEAK_GBPS,
+            "launches": launches,
+            "warmup_launches": ROOFLINE_WARMUPS,
             "copy_rate": copy_gbps,  # read + write rate of the library's streaming copy of the same 1 GiB slab
             "frac_of_copy_rate": achieved / copy_gbps,
             "frac_of_6.29TBps": achieved / HBM_COPY_GBPS,  # against the guide's measured streaming-copy rate
@@ -334,10 +409,33 @@ class NttWorkload:
             "inverse_poly_ntt_per_s": polys / inverse_s,
             "forward_residue_ntt_per_s": polys * len(self.moduli) / forward_s,
             "inverse_avg_launch_ms": inverse_s * 1e3,
+            "inverse_median_launch_ms": inverse_median_s * 1e3,
             "inverse_achieved_GBps": self.bytes_per_transform * polys / inverse_s / 1e9,
             "inverse_frac_of_8TBps": self.bytes_per_transform * polys / inverse_s / 1e9 / HBM_PEAK_GBPS,
         }
+        if rank == 0:
+            extras.update(self.host_pointer_rate())
         return roofline, extras
+
+    def host_pointer_rate(self, polys=256, reps=3):
+        """SURVEY.md 8(d)'s end-to-end figure: he_ntt_forward on HOST pointers (the B1 seam as the reference's benchmark
+        loop times a call, PolyBenchmark.swift:148-158) -- upload, transform, download, synchronise, per call."""
+        import numpy as np
+
+        rng = np.random.default_rng(0xE2E)
+        host = np.ascontiguousarray(np.stack([rng.integers(0, q, size=(polys, DEGREE), dtype=np.uint64) for q in self.moduli],
+                                             axis=1))
+        self.ctx.forward_ntt_host(host)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.ctx.forward_ntt_host(host)
+        per_call = (time.perf_counter() - t0) / reps
+        return {
+            "pcie_inclusive_forward_poly_ntt_per_s": polys / per_call,
+            "pcie_inclusive_GBps": 2 * host.nbytes / per_call / 1e9,
+            "pcie_inclusive_sample": f"he_ntt_forward on a pageable host slab of {polys} polynomials ({host.nbytes >> 20} MiB): "
+                                     f"H2D + forward NTT + D2H + synchronise per call, {reps} calls",
+        }
 
 
 class CtMulWorkload:
@@ -396,10 +494,10 @@ class CtMulWorkload:
         def relin():
             ctx.relinearize(state["p"], self.key_, workspace=self.ws_relin)
 
-        reps = max(3, steps // 4)
+        reps = max(ROOFLINE_LAUNCHES, steps)
         mul()
-        t_mul = time_kernel(torch, mul, reps)
-        t_relin = time_kernel(torch, relin, reps)
+        t_mul = time_kernel(torch, mul, reps, warmups=ROOFLINE_WARMUPS)
+        t_relin = time_kernel(torch, relin, reps, warmups=ROOFLINE_WARMUPS)
         t_both = t_mul + t_relin
         achieved = self.COMPULSORY * self.units / t_both / 1e9
         profile = profiled_traffic("c3_ct_mul_relinearize", self.COMPULSORY)
@@ -461,7 +559,7 @@ class ModSwitchWorkload:
         }
 
     def roofline(self, steps, rank):
-        t = time_kernel(self.torch, self.step, max(5, steps))
+        t, t_median, _ = time_launches(self.torch, self.step, launches=max(ROOFLINE_LAUNCHES, steps))
         achieved = self.bytes_per_poly * self.units / t / 1e9
         profile = profiled_traffic("c4_mod_switch", self.bytes_per_poly)
         traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
@@ -476,6 +574,7 @@ class ModSwitchWorkload:
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.bytes_per_poly * self.units,
             "avg_launch_ms": t * 1e3,
+            "median_launch_ms": t_median * 1e3,
         }, {}
 
 
@@ -541,7 +640,7 @@ class PirDim0Workload:
         }
 
     def roofline(self, steps, rank):
-        t = time_kernel(self.torch, self.step, max(3, steps // 4))
+        t = time_kernel(self.torch, self.step, max(ROOFLINE_LAUNCHES, steps), warmups=ROOFLINE_WARMUPS)
         achieved = self.db_bytes / t / 1e9
         profile = profiled_traffic("c5_inner_product_plain", self.db_bytes / self.units)
         traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
@@ -587,27 +686,34 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
         synchronize()
 
     job = make_job()
-    # Pre-roll (untimed, part of set-up): the device sat idle while the host built contexts and inputs and is in its idle
-    # power state; at 1 ms per step the contract's W warm-up steps end before the clocks have settled under the power cap
-    # (20 steps after 5 warm-ups read 8 % slower than after 100).  Steady state is what a server sees and what the
-    # roofline leg measures, so the job runs for PRE_ROLL_S first; the W warm-up steps and the K timed steps follow
-    # unchanged.  Reported as `pre_roll_s`.
+    # Pre-roll: the device sat idle while the host built contexts and inputs and is in its idle power state; at 1 ms per
+    # step the contract's W warm-up steps end before the clocks have settled under the power cap (20 steps after 5
+    # warm-ups read 5-8 % slower than after 100).  Both readings are reported (see timed_steps below).
+    def timed_steps():
+        """The contract's measurement: W warm-up steps, a barrier, exactly K steps bracketed by synchronisation, the
+        maximum over ranks."""
+        for _ in range(args.warmup):
+            job.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            job.step()
+        synchronize()
+        seconds = time.perf_counter() - t0
+        if distributed:
+            dist.barrier()
+            seconds = sharding.max_over_ranks(seconds, device=device)
+        return seconds
+
+    # the same measurement twice in one process: first as the bare contract reads it (W warm-ups straight after set-up:
+    # `value_without_pre_roll`), then again after the pre-roll (`value`)
     synchronize()
+    elapsed_cold = timed_steps()
     pre_roll_start = time.perf_counter()
     while on_gpu and time.perf_counter() - pre_roll_start < PRE_ROLL_S:
         job.step()
         synchronize()
-    for _ in range(args.warmup):
-        job.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step()
-    synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        dist.barrier()
-        elapsed = sharding.max_over_ranks(elapsed, device=device)
+    elapsed = timed_steps()
     units_all_ranks = job.units
     if distributed:
         counter = torch.tensor([job.units], dtype=torch.int64, device=device)
@@ -656,15 +762,18 @@ def run_benchmark(args, make_job, rank, world, device="cuda", dist=None):
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "pre_roll_s": PRE_ROLL_S if on_gpu else 0.0,
+        "value_without_pre_roll": units_all_ranks * args.steps / elapsed_cold,
+        "ms_per_step_without_pre_roll": elapsed_cold / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": description["dtype"],
         "data": "synthetic",
         "config": dict(description["config"],
-                       pre_roll="the job runs untimed for pre_roll_s before the W warm-up steps so that the device leaves "
-                                "its idle power state (set-up; the W warm-up and K timed steps are unchanged); with W = 5 and "
-                                "~1 ms steps the same command reads ~8 % lower without it (DESIGN.md section 6)"),
+                       pre_roll="W warm-ups + K timed steps are run twice in this process: straight after set-up "
+                                "(value_without_pre_roll: the device is still leaving its idle power state) and again "
+                                "after the job has run untimed for pre_roll_s (value: the steady state the roofline leg "
+                                "measures); DESIGN.md section 6"),
         "roofline": roofline,
         "extras": dict(extras, all_gather_ms=gather_ms, all_gather_bytes_per_gpu=gather_bytes,
                        value_with_all_gather=(units_all_ranks * args.steps / with_gather_elapsed

@@ -48,14 +48,12 @@ def _uniform(torch, moduli, prefix, degree, seed):
 
 
 def _profiled(key):
-    """HBM bytes per unit from the committed rocprofv3 counter passes (profiles/r03_pmc_traffic.json), or None -- also
-    when the entry claims fewer bytes than the algorithm must move (bench.py profiled_traffic: a stale or miscalibrated
-    profile)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-            entry = json.load(f).get(key)
-    except OSError:
-        return None
+    """HBM bytes per unit from the committed rocprofv3 counter passes (bench.py TRAFFIC_PROFILE), or None -- bench.py
+    profiled_traffic's rules: not when the entry claims fewer bytes than the algorithm must move, nor when it was counted
+    on kernels the current library no longer contains."""
+    import bench
+
+    entry = bench.profiled_traffic(key)
     if entry and entry.get("hbm_bytes_per_unit", 0) < entry.get("algorithmic_bytes_per_unit", 0):
         return None
     return entry

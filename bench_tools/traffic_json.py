@@ -1,4 +1,4 @@
-"""Builds profiles/r03_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
+"""Builds profiles/r04_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
 bench_tools/pmc_traffic.py leaves in the PMC pass directories of the four workloads.
 
   python bench_tools/traffic_json.py <ntt-dir> <c3-dir> <c4-dir> <c5-dir> <out.json>

@@ -713,3 +713,34 @@ def test_new_pir_entry_points_edge_cases(small):
     got = ours.pir_compute_response([2, 3], dim0, rest, database, 2, relinearization_key=key)
     torch.cuda.synchronize()
     assert got.shape == (2, 2, 1, n) and int(got.abs().sum()) == 0
+
+
+def test_column_shard_at_the_benchmark_size(oracle):
+    """The per-GPU shard of BASELINE configs[4] at the size bench.py --workload c5 times it: 1024 query ciphertexts x 128
+    database columns (34 GB of Eval plaintexts, device-generated) through he_pir_dim0_columns_device -- the lazy inner
+    products (Bfv.swift:476-505) and their inverse transforms (PirUtil.swift:428-446).  Eight columns spread over the
+    shard -- the first, the last, and ones whose plaintexts start beyond 4 GiB (268 MB per column: from column 16 on) and
+    beyond 32 GiB (column 120 on) -- equal the oracle's dim-0 step word for word; every output word is canonical."""
+    import torch
+
+    degree, d0, columns = 8192, 1024, 128
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(640)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, 1, len(moduli), 1)
+    query = torch.randint(0, 1 << 62, (d0, 2, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    database = torch.empty((columns, d0, len(moduli), degree), dtype=torch.int64, device="cuda")
+    for c in range(columns):  # column by column: randint's 268 MB temporaries instead of 34 GB ones
+        database[c] = torch.randint(0, 1 << 62, (d0, len(moduli), degree), dtype=torch.int64, device="cuda",
+                                    generator=gen) % bound.view(1, len(moduli), 1)
+    assert database.numel() * 8 == columns * d0 * len(moduli) * degree * 8 > 34 * 10**9
+    out = ours.pir_dim0_columns(query, database)
+    assert out.shape == (columns, 2, len(moduli), degree)
+    assert bool((out < bound).all()) and bool((out >= 0).all())
+    sample = [0, 1, 15, 16, 17, 64, 120, 127]
+    host_query = heamd.to_host(query)
+    for c in sample:
+        want = oracle.pir.dim0_columns(ref, host_query, heamd.to_host(database[c:c + 1]))
+        assert np.array_equal(heamd.to_host(out[c]), want[0]), c

@@ -128,3 +128,30 @@ def test_lazy_product_accumulation(oracle):
     # a full-range 128-bit accumulator (wrapping arithmetic + double-word Barrett on arbitrary input)
     wild = rng.integers(0, 1 << 63, size=(2, degree, 2), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     assert np.array_equal(heamd.to_host(ours.reduce_accumulator(heamd.to_device(wild))), ref.reduce_accumulator(wild))
+
+
+def test_mod_switch_at_the_benchmark_size(oracle):
+    """BASELINE configs[3] at the size bench.py times it: N=16384, 6 -> 5 moduli, 8192 polynomials (6 GiB in, 5 GiB out,
+    device-generated).  Polynomials sampled over the whole slab -- the first, the last, and several whose input AND
+    output byte offsets lie beyond 4 GiB (786 432 B per input polynomial: from index 5462 on; 655 360 B per output
+    polynomial: from index 6554 on) -- equal the oracle's divideAndRoundQLast (PolyRq.swift:365-393) word for word, and
+    every output word is canonical."""
+    import torch
+
+    degree, batch = 16384, 8192
+    moduli = oracle.generate_primes([55] * 6, False, degree)
+    ours = heamd.PolyContext(degree, moduli)
+    ref = oracle.PolyContext(degree, moduli)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(404)
+    bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)
+    x = torch.randint(0, 1 << 62, (batch, len(moduli), degree), dtype=torch.int64, device="cuda", generator=gen) % bound
+    assert x.numel() * 8 == 6 << 30
+    out = ours.divide_and_round_q_last(x)
+    assert out.shape == (batch, len(moduli) - 1, degree)
+    for part in range(0, batch, 1024):  # canonical everywhere (in slices: the comparison's temporaries stay small)
+        piece = out[part:part + 1024]
+        assert int((piece >= bound[:, :-1]).sum()) == 0 and int((piece < 0).sum()) == 0
+    sample = [0, 1, 2047, 4096, 5461, 5462, 6553, 6554, 7000, 8190, 8191]
+    assert sample[5] * len(moduli) * degree * 8 > 1 << 32 and sample[7] * (len(moduli) - 1) * degree * 8 > 1 << 32
+    assert np.array_equal(heamd.to_host(out[sample]), ref.divide_and_round_q_last(heamd.to_host(x[sample])))

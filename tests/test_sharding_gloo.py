@@ -191,7 +191,10 @@ def test_bench_contract_with_two_ranks():
     line1, steps1, units1 = results[1]
     assert line1 is None and line0 is not None
     assert (units0, units1) == (8, 6)
-    assert steps0 == steps1 == 2 + 3 + 3  # warm-up, timed steps, the steps repeated with the gather
+    # (warm-up + timed steps) twice -- straight after set-up and again after the pre-roll (none on CPU) -- then the steps
+    # repeated with the gather
+    assert steps0 == steps1 == 2 * (2 + 3) + 3
+    assert line0["value_without_pre_roll"] > 0 and line0["ms_per_step_without_pre_roll"] > 0
     assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
     assert abs(line0["value"] * line0["ms_per_step"] * 1e-3 - (units0 + units1)) < 1e-6  # (8 + 6) units per step
     assert line0["extras"]["all_gather_ms"] > 0 and line0["extras"]["value_with_all_gather"] > 0
