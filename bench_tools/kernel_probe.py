@@ -1,0 +1,53 @@
+"""Compile a FEW instantiations of the NTT kernel templates on their own (seconds instead of the minutes the whole
+translation unit takes) and print their register / scratch figures -- the inner loop of register-pressure work.
+
+  python bench_tools/kernel_probe.py [--asm OUT.s] 'ntt_inverse_tiled<13, 10, kModeSplit, kInverseFromKeyMacFinish, 2>' ...
+
+The kernel definitions of csrc/ntt_kernels.hip (everything above the launchers) are copied to a scratch file followed by
+explicit instantiations of the named kernels; nothing is linked into the library.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "swift-homomorphic-encryption_amd", "csrc")
+SIGNATURES = {
+    "ntt_forward_tiled": "(uint64_t*, const DeviceContext, const RowMap, const SpreadSource)",
+    "ntt_inverse_tiled": "(uint64_t*, const DeviceContext, const RowMap, const InverseSource)",
+    "ntt_forward_interleaved": "(uint64_t*, const DeviceContext, const RowMap)",
+    "ntt_inverse_interleaved": "(uint64_t*, const DeviceContext, const RowMap)",
+}
+
+
+def main():
+    args = sys.argv[1:]
+    asm_out = None
+    if args and args[0] == "--asm":
+        asm_out, args = args[1], args[2:]
+    source = open(os.path.join(CSRC, "ntt_kernels.hip")).read()
+    head = source[:source.index("template <typename Kernel>\nhipError_t allow_dynamic_lds")]
+    body = head + "\n".join(f"template __global__ void {k}{SIGNATURES[k.split('<')[0].strip()]};" for k in args)
+    body += "\n}  // namespace\n}  // namespace heamd\n"
+    with tempfile.TemporaryDirectory() as work:
+        path = os.path.join(work, "probe.hip")
+        open(path, "w").write(body)
+        out = os.path.join(work, "probe.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-I" + CSRC, "-o", out, path], check=True)
+        text = open(out).read()
+        if asm_out:
+            open(asm_out, "w").write(text)
+    for block in re.findall(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", text, re.S):
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))  # noqa: E731
+        demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+        short = re.sub(r"\(anonymous namespace\)::|heamd::|^void ", "", demangled).split("(")[0]
+        print(f"{short:70s} vgpr {get('vgpr_count'):3d}  sgpr {get('sgpr_count'):3d}  scratch {get('private_segment_fixed_size'):4d} B"
+              f"  spilled {get('vgpr_spill_count'):2d}")
+
+
+if __name__ == "__main__":
+    main()

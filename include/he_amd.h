@@ -75,6 +75,11 @@ int he_get_device(int* out_device); /* the calling thread's current HIP device: 
 int he_set_device(int device);
 int he_device_malloc(void** out_ptr, size_t bytes);
 int he_device_free(void* ptr);
+/* Page-locked host memory: a copy between it and the device is truly asynchronous (from pageable memory the runtime
+ * stages the bytes before he_memcpy_h2d returns, and a borrowed pageable pointer has to be waited for).  What the Swift
+ * host stages ciphertexts, keys and databases in: one copy and no wait per object instead of one per polynomial. */
+int he_host_malloc(void** out_ptr, size_t bytes);
+int he_host_free(void* ptr);
 int he_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, he_stream stream);
 int he_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, he_stream stream);
 int he_stream_synchronize(he_stream stream);

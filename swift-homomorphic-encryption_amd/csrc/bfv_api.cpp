@@ -256,6 +256,20 @@ hipError_t key_mac_to_coeff(const uint32_t* spread, const uint32_t* key, uint32_
     return ntt_records(true, prod, ks_ctx, ks, L + 1, polys * 2, stream);
 }
 
+// The inner product with the key, the inverse transforms and the key switch's last step (relinearize: added_polys = 2) in
+// two launches of one kernel where the degree has it (ntt_kernels.hip kInverseFromKeyMacFinish); hipErrorNotSupported
+// otherwise (nothing launched).
+hipError_t key_mac_and_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod, const uint64_t* ct_base,
+                              size_t ct_stride, uint64_t* out, const PolyContext& ks_ctx, uint32_t L, uint32_t top_rows,
+                              size_t polys, uint32_t added_polys, hipStream_t stream) {
+    return heamd::launch_ntt_key_mac_inverse_finish(spread, key, prod, ct_base, ct_stride, out, ks_ctx.device_context(), L,
+                                                    top_rows, polys, added_polys, stream);
+}
+hipError_t key_mac_and_finish(const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*, size_t, uint32_t*,
+                              const PolyContext&, uint32_t, uint32_t, size_t, uint32_t, hipStream_t) {
+    return hipErrorNotSupported;  // packed 4-byte slabs keep the separate finish kernel
+}
+
 // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on polynomial `target` of every item, then
 // out[item][c] = (c < added_polys ? ct[item][c] : 0) + update[item][c]  (relinearize: added 2; applyGalois: added 1)
 template <typename W>
@@ -264,6 +278,12 @@ int key_switch_pipeline(const he_bfv_context* ctx, uint32_t L, const W* target, 
                         hipStream_t stream) {
     const PolyContext* ks_ctx = ctx->impl->key_switching(L);
     HEAMD_HIP_TRY(spread_to_eval(target, target_stride, spread, *ks_ctx, L, batch, stream));
+    const hipError_t fused = key_mac_and_finish(spread, key, prod, ct_base, ct_stride, out, *ks_ctx, L,
+                                                ctx->impl->top_level() + 1, batch, added_polys, stream);
+    if (fused != hipErrorNotSupported) {
+        HEAMD_HIP_TRY(fused);
+        return HE_OK;
+    }
     HEAMD_HIP_TRY(key_mac_to_coeff(spread, key, prod, *ks_ctx, L, ctx->impl->top_level() + 1, batch, stream));
     HEAMD_HIP_TRY(heamd::launch_key_switch_finish(prod, ct_base, ct_stride, out, ks_ctx->device_context(), L, batch,
                                                   added_polys, stream));

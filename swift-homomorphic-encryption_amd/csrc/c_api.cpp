@@ -217,6 +217,17 @@ int he_device_free(void* ptr) {
     HEAMD_HIP_TRY(hipFree(ptr));
     return HE_OK;
 }
+int he_host_malloc(void** out_ptr, size_t bytes) {
+    if (out_ptr == nullptr) return invalid_argument("null out_ptr");
+    *out_ptr = nullptr;
+    HEAMD_HIP_TRY(hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return HE_OK;
+}
+int he_host_free(void* ptr) {
+    if (ptr == nullptr) return HE_OK;
+    HEAMD_HIP_TRY(hipHostFree(ptr));
+    return HE_OK;
+}
 int he_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes, he_stream stream) {
     HEAMD_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     return HE_OK;

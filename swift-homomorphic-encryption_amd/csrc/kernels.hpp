@@ -50,6 +50,15 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
                                      size_t items, hipStream_t stream);
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
+// launch_ntt_key_mac_inverse with the key switch's last step (drop the special modulus, add the update to the first
+// `added_polys` polynomials of the ciphertext at ct_base + polynomial * ct_stride) applied as the rows are stored:
+// out [polys][2][L][N]; of `prod` ([polys][2][L+1][N]) only the q_ks rows are written.  hipErrorNotSupported (nothing
+// launched, ntt_key_mac_finish_supported false): launch_ntt_key_mac_inverse + launch_key_switch_finish.
+bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys);
+hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,
+                                             const uint64_t* ct_base, size_t ct_stride, uint64_t* out, const DeviceContext& ks,
+                                             uint32_t L, uint32_t top_rows, size_t polys, uint32_t added_polys,
+                                             hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
 
 enum class ElementwiseOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, MulScalar = 4 };

@@ -540,10 +540,13 @@ __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& sec
 // FIRST_STAGE: the pass skips the first FIRST_STAGE stages of the layout's W (the top pass of a schedule whose partial
 // pass sits on the top bits: the lower bits of its layout were paired by the pass before); `first` is the first twiddle
 // of the stages it does run (inverse_first_twiddle with the same FIRST_STAGE).
+// AHEAD / `head`: the pass keeps AHEAD twiddles in flight ahead of its butterflies; the caller hands it the first AHEAD of
+// them (requested wherever it suits the caller: the transform's first pass asks for them before the rows are unpacked).
 template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int ROWS, bool SCALED = false, int PRIOR = 0,
-          int LOGD = LOGN, int FIRST_STAGE = 0>
+          int LOGD = LOGN, int FIRST_STAGE = 0, int AHEAD = kTwiddlesAhead<MODE>>
 __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                             const DeviceModulus& mod, bool first_stage_canonical, TwiddleWords first) {
+                                             const DeviceModulus& mod, bool first_stage_canonical,
+                                             const TwiddleWords (&head)[AHEAD]) {
     constexpr int COUNT = pass_twiddle_count<LOGE, W, true>(), BEGIN = pass_twiddle_prefix<LOGE, W, true>(FIRST_STAGE);
     const uint64_t p = mod.p;
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
@@ -553,12 +556,9 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     constexpr int H = Lazy<MODE>::kInverseCapLog;
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
     const FoldConstants fc = mode_fold_constants<MODE>(p);
-    constexpr int AHEAD = kTwiddlesAhead<MODE>;
     TwiddleWords pending[AHEAD];
-    pending[0] = first;
 #pragma unroll
-    for (int a = 1; a < AHEAD; ++a)
-        if (BEGIN + a < COUNT) pending[a] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, BEGIN + a);
+    for (int a = 0; a < AHEAD; ++a) pending[a] = head[a];
 #pragma unroll
     for (int k = BEGIN; k < COUNT; ++k) {
         const int j = pass_stage_of<LOGE, W, true>(k), idx = pass_index_in_stage<LOGE, W, true>(k);
@@ -617,6 +617,16 @@ template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, in
 __device__ __forceinline__ TwiddleWords inverse_first_twiddle(const Twiddles<MODE>& tw, uint32_t tid) {
     return inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_part<LOGN, LOGE, LO, W>(tid),
                                                                       pass_twiddle_prefix<LOGE, W, true>(FIRST_STAGE));
+}
+// the first AHEAD twiddles of an inverse pass
+template <int LOGN, int LOGE, int LO, int W, int MODE, bool UNIFORM_TWIDDLES, int AHEAD, int FIRST_STAGE = 0>
+__device__ __forceinline__ void inverse_first_twiddles(TwiddleWords (&head)[AHEAD], const Twiddles<MODE>& tw, uint32_t tid) {
+    constexpr int COUNT = pass_twiddle_count<LOGE, W, true>(), BEGIN = pass_twiddle_prefix<LOGE, W, true>(FIRST_STAGE);
+    const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        head[a] = BEGIN + a < COUNT ? inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, BEGIN + a)
+                                    : TwiddleWords{0, 0, 0};
 }
 
 template <int LOGN, int LOGE, int LO, int W, int SCHEME = 0>

@@ -208,35 +208,44 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // (LO_FROM, W_FROM).  Its first twiddle is requested after the exchange: requesting it before (as the forward
 // transform does, the gather then overlaps the LDS round trip) keeps six more registers live across the exchange and
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
+template <int MODE>
 constexpr bool kInverseFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
           int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
     TwiddleWords first{0, 0, 0};
-    if constexpr (kInverseFirstTwiddleEarly)
+    if constexpr (kInverseFirstTwiddleEarly<MODE>)
         first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
-    if constexpr (!kInverseFirstTwiddleEarly)
+    if constexpr (!kInverseFirstTwiddleEarly<MODE>)
         first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
-    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE>(v, tid, tw, mod, false, first);
+    const TwiddleWords head[1] = {first};
+    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE, 1>(v, tid, tw, mod, false, head);
 }
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass
 // (element_index<LOGN, LOGE, 0, Schedule::R>), out -- canonical words in the layout of the top pass.
 // PRIOR / LOGD: the rows are the sub-rows of an interleaved row of degree 2^LOGD whose first PRIOR stages already ran
 // (ntt_inverse_interleaved); `tw` then indexes the tail of the degree's table.
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false>
+// HEAD / `head`: the first HEAD twiddles of the first pass (inverse_row_head), which then keeps HEAD of them in flight:
+// the caller requests them BEFORE the rows are loaded -- they travel with the row loads instead of starting a chain of L2
+// round trips (one per twiddle of the gather-heavy first pass) behind them.
+template <int LOGN, int LOGE, int MODE, bool TOP, int HEAD>
+__device__ __forceinline__ void inverse_row_head(TwiddleWords (&head)[HEAD], const Twiddles<MODE>& tw, uint32_t tid) {
+    constexpr int LOW = PassOrder<LOGN, LOGE, TOP>::LOW;
+    inverse_first_twiddles<LOGN, LOGE, 0, LOW, MODE, false, HEAD>(head, tw, tid);
+}
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false, int HEAD = 1>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                            const DeviceModulus& mod, uint64_t* lds) {
+                                            const DeviceModulus& mod, uint64_t* lds, const TwiddleWords (&head)[HEAD]) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
     if constexpr (PassOrder<LOGN, LOGE, TOP>::kTop) {
         // in -- the layout of the full pass on bits [0, LOGE); the full passes from the low bits up, then the partial
         // pass (the transform's last R stages) in the layout of a full top pass
         using O = PassOrder<LOGN, LOGE, TOP>;
-        inverse_pass<LOGN, LOGE, 0, LOGE, MODE, false, ROWS, false, PRIOR, LOGD>(
-            v, tid, tw, mod, PRIOR == 0, inverse_first_twiddle<LOGN, LOGE, 0, LOGE, MODE, false>(tw, tid));
+        inverse_pass<LOGN, LOGE, 0, LOGE, MODE, false, ROWS, false, PRIOR, LOGD, 0, HEAD>(v, tid, tw, mod, PRIOR == 0, head);
         if constexpr (S::P >= 5)
             inverse_step<LOGN, LOGE, O::lo(4), LOGE, O::lo(3), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
         if constexpr (S::P >= 4)
@@ -246,8 +255,7 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
         inverse_step<LOGN, LOGE, O::lo(1), LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, LOGE - R>(v, tid, tw, mod, lds);
         return;
     }
-    inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD>(
-        v, tid, tw, mod, PRIOR == 0, inverse_first_twiddle<LOGN, LOGE, 0, R, MODE, false>(tw, tid));
+    inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD, 0, HEAD>(v, tid, tw, mod, PRIOR == 0, head);
     if constexpr (S::P >= 3)
         inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 4)
@@ -388,13 +396,38 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 // are (polynomial, c), c in {0, 1}, of record_rows = L + 1 rows; word k of row r is
 // sum_j spread[poly][j][r][k] * key[j][c][key_row(r)][k] mod ks_modulus[r], accumulated in the carry-counting form.
 // kInverseFromSlabScaled: a plain slab whose context carries t N^-1 (dropExtendedBase without the fused tensor load)
-constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2, kInverseFromSlabScaled = 3;
+// kInverseFromKeyMacFinish: the same load, restricted to the band rows r < L, with the last step of the key switch --
+// drop the special modulus (divideAndRoundQLast by the centred representative of the q_ks word, Bfv+Keys.swift:203-207)
+// and add the update to the ciphertext (Bfv.swift:216-217) -- applied to the transform's canonical words before they are
+// stored: the q_ks row of every (polynomial, c) comes from an earlier launch of the plain kInverseFromKeyMac kernel over
+// that one band row, the rows r < L of the product are never written, and the separate finish kernel (26 row moves per
+// ciphertext) is gone.
+constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac = 2, kInverseFromSlabScaled = 3,
+              kInverseFromKeyMacFinish = 4;
+constexpr bool is_key_mac(int source) { return source == kInverseFromKeyMac || source == kInverseFromKeyMacFinish; }
 constexpr bool kKeyMacBoundedReduce = true;
+// Two rows per workgroup of the key MAC = the two key columns (c = 0, 1) of ONE polynomial: every spread word is
+// fetched once (from HBM) and meets both key words (the key is a few MB and stays in L2).  The earlier pairing -- the same
+// column of two consecutive polynomials, the other column in a sibling workgroup of the same XCD -- fetched the 1 280 MiB
+// spread slab of 1024 products 1.7 times (2 214 MiB by the counters, profiles/r03z_pmc_traffic_per_kernel.txt).
+constexpr bool kKeyMacColumnPairs = true;
 struct InverseSource {
     const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
     const uint64_t* second;  // key MAC: the key
     uint32_t L, top_rows;    // key MAC: source moduli, rows per key polynomial
+    // kInverseFromKeyMacFinish: the ciphertexts the update is added to ([item] ct_stride words apart, polynomial c at
+    // c L N; the first `added_polys` polynomials are added, the others replaced), and where the result goes
+    // ([item][2][L][N]); the slab argument of the kernel is the product slab whose q_ks rows are read
+    const uint64_t* ct_base;
+    size_t ct_stride;
+    uint64_t* out;
+    uint32_t added_polys;
 };
+
+// How many twiddles of the first (gather-heavy) pass are requested before the rows are loaded and then kept in flight
+// through that pass (inverse_row_head).  1: the first one only, requested once the rows are in (the schedule of rounds 2-3).
+template <int LOGN, int LOGE, int MODE, int SOURCE, int ROWS>
+constexpr int kInverseHeadTwiddles = 1;
 
 template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab, int ROWS = 1>
 __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROWS))
@@ -403,6 +436,8 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr bool TENSOR = SOURCE == kInverseFromTensor;
     constexpr bool SCALED = SOURCE == kInverseFromTensor || SOURCE == kInverseFromSlabScaled;
     constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
+    constexpr bool KEYMAC = is_key_mac(SOURCE), FINISH = SOURCE == kInverseFromKeyMacFinish;
+    constexpr bool COLUMNS = KEYMAC && ROWS == 2 && kKeyMacColumnPairs;  // the rows are (polynomial, c = 0) and (polynomial, c = 1)
     static_assert(ROWS == 1 || SOURCE != kInverseFromSlabScaled, "scaled plain slabs go one row per workgroup");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -415,7 +450,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
-    if constexpr (!FROM_SLAB) {
+    if constexpr (COLUMNS) {
+        // one workgroup per (polynomial, band row): records (polynomial, 0) and (polynomial, 1); record_base counts items
+        uint32_t group;
+        locate(map, blockIdx.x, group, within);
+        record = (map.record_base + group) * 2;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) rows[k] = size_t(record + k) * map.record_rows + map.band_offset + within;
+    } else if constexpr (!FROM_SLAB) {
         // records (item, c) of one item read the same source rows: one replica set per (group of ROWS consecutive
         // items, band row); the workgroup transforms record (item + k, c) for k < ROWS
         constexpr uint32_t REPLICAS = TENSOR ? 3 : 2;
@@ -437,11 +479,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     if constexpr (S::P == 1) {
         const BufferResource x = make_resource(slab + (rows[0] << LOGN), 8u << LOGN);
         global_load<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
-        inverse_pass<LOGN, LOGE, 0, LOGN, MODE, false, 1, SCALED>(
-            v, tid, tw, mod, true, inverse_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, false>(tw, tid));
+        const TwiddleWords head[1] = {inverse_first_twiddle<LOGN, LOGE, 0, LOGN, MODE, false>(tw, tid)};
+        inverse_pass<LOGN, LOGE, 0, LOGN, MODE, false, 1, SCALED, 0, LOGN, 0, 1>(v, tid, tw, mod, true, head);
         global_store<LOGN, LOGE, 0, LOGN>(v[0], tid, x);
     } else {
         // every transpose but the last one (into the top pass) stays inside a wave
+        constexpr int HEAD = kInverseHeadTwiddles<LOGN, LOGE, MODE, SOURCE, ROWS>;
+        TwiddleWords head[HEAD];
+        if constexpr (HEAD > 1) inverse_row_head<LOGN, LOGE, MODE, O::kTop, HEAD>(head, tw, tid);
         if constexpr (TENSOR) {
             const size_t first_item = record / 3;
             const uint32_t c = static_cast<uint32_t>(record - first_item * 3);  // wave-uniform
@@ -481,7 +526,53 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     }
                 }
             }
-        } else if constexpr (SOURCE == kInverseFromKeyMac) {
+        } else if constexpr (COLUMNS) {
+            // word e of the two rows: sum_j spread[poly][j][r][e] * key[j][c][key_row(r)][e], c = 0, 1, one word at a time
+            // (two sums of 7-8 registers each: a 16-byte pair per lane would need four), every word through a buffer
+            // descriptor with a scalar term offset -- no 64-bit address arithmetic on the vector ALU.  The words of
+            // term j + 1 are requested before term j is accumulated; past the last term the request repeats it (a load
+            // behind a branch would drain the queue).
+            const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
+            const uint32_t r = map.band_offset + within;
+            const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
+            const size_t poly = record >> 1;
+            const uint32_t lane_bytes = lane_part<LOGN, LOGE, 0, LOW>(tid) << 3;
+            const uint32_t spread_step = (L + 1) << (LOGN + 3), key_step = (2 * top_rows) << (LOGN + 3),
+                           column_step = top_rows << (LOGN + 3);
+            const BufferResource spread_rows = make_resource(source_spec.first + ((poly * L * (L + 1) + r) << LOGN),
+                                                             (L - 1) * spread_step + (8u << LOGN));
+            const BufferResource key_rows = make_resource(source_spec.second + (static_cast<size_t>(key_row) << LOGN),
+                                                          (L - 1) * key_step + column_step + (8u << LOGN));
+            constexpr bool NARROW = is_split(MODE);  // both operands canonical mod a modulus below 2^55
+            const bool bounded = kKeyMacBoundedReduce && mod.wide_shift != 0 && L <= 8 && uint64_t(L) * mod.p < (uint64_t(1) << 63);
+            auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t at = register_part<LOGN, LOGE, 0, LOW>(e) << 3;
+                uint64_t x = word(__builtin_amdgcn_raw_buffer_load_b64(spread_rows, lane_bytes, at, 0));
+                uint64_t k0 = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, at, 0));
+                uint64_t k1 = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, at + column_step, 0));
+                ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+                for (uint32_t j = 0; j < L; ++j) {
+                    const uint32_t ahead = j + 1 < L ? j + 1 : j;
+                    const uint64_t xn = word(__builtin_amdgcn_raw_buffer_load_b64(spread_rows, lane_bytes, ahead * spread_step + at, 0));
+                    const uint64_t k0n = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, ahead * key_step + at, 0));
+                    const uint64_t k1n =
+                        word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, ahead * key_step + column_step + at, 0));
+                    product_sum_add_pair<NARROW>(acc0, acc1, k0, k1, x);
+                    x = xn;
+                    k0 = k0n;
+                    k1 = k1n;
+                }
+                if (bounded) {  // wave-uniform (the one-word-quotient Barrett: L p^2 < 2^(63 + bits(p)) whenever L p < 2^63)
+                    v[0][e] = reduce_product_sum_bounded(acc0, mod);
+                    v[1][e] = reduce_product_sum_bounded(acc1, mod);
+                } else {
+                    v[0][e] = reduce_product_sum(acc0, mod);
+                    v[1][e] = reduce_product_sum(acc1, mod);
+                }
+            }
+        } else if constexpr (KEYMAC) {
             const size_t first_poly = record >> 1, c = record & 1;  // record = poly * 2 + c
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
             const uint32_t r = map.band_offset + within;
@@ -535,11 +626,62 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 }
             }
         }
-        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop>(v, tid, tw, mod, lds);
+        if constexpr (HEAD == 1) inverse_row_head<LOGN, LOGE, MODE, O::kTop, HEAD>(head, tw, tid);
+        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
         constexpr int LOL = LOGN - LOGE;
+        if constexpr (FINISH) {
+            // key_switch_finish_kernel's arithmetic (rns_kernels.hip) on the words this lane holds: with x_ks the q_ks word
+            // of the coefficient and c its centred representative, out = (x - c) q_ks^-1 mod q_r (+ the ciphertext word)
+            const uint32_t L = source_spec.L, r = map.band_offset + within;
+            const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
+            // (the launcher only takes this path when q_ks / 2 is below every q_r: |c| needs no reduction mod q_r)
+            const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
+            const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(tid) << 3;
+            constexpr int CHUNK = 4;  // words in flight per row: the q_ks and ciphertext words of a chunk are requested together
+            auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k)
-            global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+            for (int k = 0; k < ROWS; ++k) {
+                const size_t pc = record + (COLUMNS ? k : 2 * k);  // polynomial * 2 + c
+                const size_t poly = pc >> 1;
+                const uint32_t c = static_cast<uint32_t>(pc & 1);
+                const BufferResource last_row = make_resource(slab + ((pc * (L + 1) + L) << LOGN), 8u << LOGN);
+                const BufferResource out_row = make_resource(source_spec.out + ((pc * L + r) << LOGN), 8u << LOGN);
+                const bool add = c < source_spec.added_polys;  // wave-uniform; without an addend the q_ks row is read twice
+                const BufferResource added_row =
+                    add ? make_resource(source_spec.ct_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN)
+                        : last_row;
+#pragma unroll
+                for (int base = 0; base < E; base += CHUNK) {
+                    uint64_t last[CHUNK], added[CHUNK];
+                    __builtin_amdgcn_sched_barrier(0);  // the requests stay behind the transform's last pass
+#pragma unroll
+                    for (int e = 0; e < CHUNK; ++e) {
+                        const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
+                        last[e] = word(__builtin_amdgcn_raw_buffer_load_b64(last_row, lane_bytes, at, row_load_policy<LOGN>()));
+                        added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < CHUNK; ++e) {
+                        const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
+                        // straight-line: x - c = x + (c < 0 ? |c| : p - |c|) mod p, an absent addend is zero
+                        const uint64_t shifted = add_mod_uniform(last[e], half, q_last);
+                        const bool negative = shifted < half;
+                        const uint64_t t = negative ? half - shifted : shifted - half;
+                        const uint64_t difference = csub_uniform(v[k][base + e] + (negative ? t : p - t), p);
+                        const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, p);
+                        const uint64_t result = csub_uniform((add ? added[e] : 0) + update, p);
+                        const Dwordx2 words = {lo32(result), hi32(result)};
+                        __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+        }
     }
 }
 
@@ -777,7 +919,9 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
     else interleaved_low_words<LOGS, false>(v, tid, row);
     inverse_cross_stages<LOGS, MODE>(v, tid, cross, mod.p);
-    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS, LOGD>(v, tid, tail, mod, lds);
+    TwiddleWords head[1];
+    inverse_row_head<kSubLogN, kSubLogE, MODE, false, 1>(head, tail, tid);
+    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS, LOGD>(v, tid, tail, mod, lds, head);
     interleaved_top_words<LOGS, true>(v, tid, row);
 }
 
@@ -965,7 +1109,11 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
-    if constexpr (kFoldShape<LOGN, LOGT> && SOURCE != kInverseFromKeyMac) {
+    if constexpr (kShiftFactors<LOGN, true> && SOURCE == kInverseFromSlab) {
+        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
+            kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
+    }
+    if constexpr (kFoldShape<LOGN, LOGT> && !is_key_mac(SOURCE)) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
             const int fold = fold_mode(ctx, map.mod_base, map.band_rows);
             if (fold == kModeFoldMinus) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeFoldMinus, SOURCE, ROWS>;
@@ -1010,7 +1158,7 @@ template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
                         uint32_t row_offset = 0, int source = kInverseFromSlab,
-                        const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
+                        const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0}) {
     if constexpr (LOGN == 14 && LOGT == 10 && kInterleaved16384) {
         if (source == kInverseFromSlab || !inverse)
             return launch_interleaved<1>(inverse, mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
@@ -1025,13 +1173,21 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
     const RowMap map = make_row_map(mod_base, mod_period, row_period, row_offset);
     if (ctx.scaled_inverse_degree != 0) {
-        if (source == kInverseFromKeyMac) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
+        if (is_key_mac(source)) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
         if (source == kInverseFromSlab)
             return launch_inverse_kernel<LOGN, LOGT, kInverseFromSlabScaled, 1>(mode, slab, ctx, map, rows, source_spec, stream);
     } else if (source == kInverseFromTensor) {
         return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
     }
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+    if (is_key_mac(source) && kKeyMacColumnPairs && kKeyMacRows<LOGN, LOGT> == 2) {
+        // one workgroup per (polynomial, band row) takes both key columns
+        const size_t workgroups = rows / 2;
+        return source == kInverseFromKeyMacFinish
+                   ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, 2>(mode, slab, ctx, map, workgroups, source_spec, stream)
+                   : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 2>(mode, slab, ctx, map, workgroups, source_spec, stream);
+    }
+    if (source == kInverseFromKeyMacFinish) return hipErrorNotSupported;  // callers run the separate finish kernel
     if (source == kInverseFromTensor || source == kInverseFromKeyMac) {
         // records are (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the odd items at
         // the end go one per workgroup.  record_base counts items for these kernels.
@@ -1128,7 +1284,7 @@ const char* ntt_variant_name(uint32_t log_degree) {
 hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t band_rows,
                            uint32_t record_rows, uint32_t band_offset, size_t records, int mode, hipStream_t stream,
                            int source = kInverseFromSlab,
-                           const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0}) {
+                           const InverseSource& source_spec = InverseSource{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0}) {
     const size_t rows = records * band_rows;
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30)) return hipErrorInvalidValue;
@@ -1234,7 +1390,7 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
     const size_t records = items * 3;
     if (!tiled || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
-    const InverseSource spec{lifted, nullptr, 0, 0};
+    const InverseSource spec{lifted, nullptr, 0, 0, nullptr, 0, nullptr, 0};
     BandRun runs[kMaxBandRuns];
     const int count = band_runs(ctx, record_rows, runs);
     if (count <= 1)
@@ -1257,7 +1413,32 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
     if (!tiled || L > 64 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
     return launch_ntt_band(true, out, ks, 0, L + 1, L + 1, 0, records, production_mode(ks), stream, kInverseFromKeyMac,
-                           InverseSource{spread, key, L, top_rows});
+                           InverseSource{spread, key, L, top_rows, nullptr, 0, nullptr, 0});
+}
+
+// The same with the key switch's last step applied as the rows r < L are stored (kInverseFromKeyMacFinish): first the q_ks
+// row of every (polynomial, c) into `prod` (the only rows of it that are written), then the rows r < L, which read that
+// row, drop the special modulus and add the update to the first `added_polys` polynomials of the ciphertext at
+// ct_base + polynomial * ct_stride: out [polys][2][L][N].  hipErrorNotSupported (nothing launched) where the degree has
+// no kernel that pairs the key columns; the caller then runs launch_ntt_key_mac_inverse + launch_key_switch_finish.
+bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys) {
+    const bool paired = kKeyMacColumnPairs && (ks.log_degree == 12 || ks.log_degree == 13);  // kKeyMacRows == 2
+    // bit r of narrow_special_mask: q_ks / 2 < q_r, i.e. the centred q_ks word needs no reduction mod q_r
+    const uint64_t band = L >= 64 ? ~uint64_t(0) : (uint64_t(1) << L) - 1;
+    return paired && L >= 1 && L < 64 && ks.moduli_count == L + 1 && (ks.narrow_special_mask & band) == band &&
+           polys * 2 * (L + 1) <= (size_t(1) << 30);
+}
+hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,
+                                             const uint64_t* ct_base, size_t ct_stride, uint64_t* out, const DeviceContext& ks,
+                                             uint32_t L, uint32_t top_rows, size_t polys, uint32_t added_polys,
+                                             hipStream_t stream) {
+    if (!ntt_key_mac_finish_supported(ks, L, polys)) return hipErrorNotSupported;
+    if (polys == 0) return hipSuccess;
+    const InverseSource spec{spread, key, L, top_rows, ct_base, ct_stride, out, added_polys};
+    const int mode = production_mode(ks);
+    hipError_t e = launch_ntt_band(true, prod, ks, L, 1, L + 1, L, polys * 2, mode, stream, kInverseFromKeyMac, spec);
+    if (e != hipSuccess) return e;
+    return launch_ntt_band(true, prod, ks, 0, L, L + 1, 0, polys * 2, mode, stream, kInverseFromKeyMacFinish, spec);
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,

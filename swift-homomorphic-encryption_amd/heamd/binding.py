@@ -48,6 +48,8 @@ SIGNATURES = [
     ("he_device_trim_scratch", ctypes.c_int, [c_u64]),
     ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
     ("he_device_free", ctypes.c_int, [vp]),
+    ("he_host_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
+    ("he_host_free", ctypes.c_int, [vp]),
     ("he_memcpy_h2d", ctypes.c_int, [vp, vp, c_size, vp]),
     ("he_memcpy_d2h", ctypes.c_int, [vp, vp, c_size, vp]),
     ("he_stream_synchronize", ctypes.c_int, [vp]),

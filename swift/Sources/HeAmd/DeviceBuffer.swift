@@ -5,10 +5,68 @@
 import CHeAmd
 import HomomorphicEncryption
 
+/// `capacity` UInt64 words of page-locked host memory (`he_host_malloc`): where the polynomials of a ciphertext, a key or a
+/// block of a database are laid back to back before they go up in ONE asynchronous copy.  A copy out of pinned memory
+/// needs no wait before the next call is enqueued behind it on the same stream; the staging only has to outlive the copy,
+/// so the `DeviceBuffer` it was uploaded to keeps it (see `DeviceBuffer.upload(staged:at:on:)`).
+public final class HostStaging: @unchecked Sendable {
+    public let pointer: UnsafeMutablePointer<UInt64>
+    public let capacity: Int
+    /// Words appended so far.
+    public private(set) var count = 0
+
+    public init(capacity: Int) throws {
+        var raw: UnsafeMutableRawPointer?
+        try heAmdCheck(he_host_malloc(&raw, max(capacity, 1) * MemoryLayout<UInt64>.stride))
+        guard let raw else { throw HeError.unsupportedHeOperation(description: "he_host_malloc returned nil") }
+        pointer = raw.bindMemory(to: UInt64.self, capacity: max(capacity, 1))
+        self.capacity = capacity
+    }
+
+    deinit {
+        _ = he_host_free(pointer)
+    }
+
+    /// Appends `words`; returns the word offset they were put at.
+    @discardableResult
+    public func append(words: UnsafeBufferPointer<UInt64>) -> Int {
+        precondition(count + words.count <= capacity)
+        let offset = count
+        if let source = words.baseAddress {
+            (pointer + offset).update(from: source, count: words.count)
+        }
+        count += words.count
+        return offset
+    }
+
+    /// Appends the row-major words of `poly` (Array2d.swift:95, :117-119).
+    @discardableResult
+    public func append<F: PolyFormat>(_ poly: PolyRq<UInt64, F>) -> Int {
+        poly.data.withDataSpan { span in
+            span.withUnsafeBufferPointer { words in append(words: words) }
+        }
+    }
+
+    /// Appends all polynomials of `ciphertext`, back to back (Ciphertext.swift:23).
+    @discardableResult
+    public func append<S: HeScheme, F: PolyFormat>(_ ciphertext: Ciphertext<S, F>) -> Int where S.Scalar == UInt64 {
+        let offset = count
+        for poly in ciphertext.polys { append(poly) }
+        return offset
+    }
+
+    /// Forgets the appended words (after the copy that read them has been waited for).
+    public func reset() {
+        count = 0
+    }
+}
+
 /// `count` UInt64 words of HBM (`he_device_malloc`), freed on deinit.
 public final class DeviceBuffer: @unchecked Sendable {
     public let pointer: UnsafeMutablePointer<UInt64>
     public let count: Int
+    /// Pinned sources of copies that may still be in flight; released with the buffer or by `releaseStaging()`.
+    private var staged: [HostStaging] = []
 
     public init(count: Int) throws {
         var raw: UnsafeMutableRawPointer?
@@ -22,9 +80,24 @@ public final class DeviceBuffer: @unchecked Sendable {
         _ = he_device_free(pointer)
     }
 
-    /// Copies `words` to word offset `offset`.  The source is a pointer borrowed for the duration of a closure and
-    /// `he_memcpy_h2d` is an asynchronous copy from pageable memory, so the copy is waited for before the pointer goes
-    /// out of scope (the C side does the same for its borrowed host masks, csrc/pir_api.cpp).
+    /// ONE asynchronous copy of everything appended to `staging` to word offset `offset`; no wait.  The buffer keeps the
+    /// staging alive (a `DeviceWork` holds its buffers until the result has been read back, i.e. past the copy).
+    public func upload(staged staging: HostStaging, at offset: Int, on stream: HeAmdStream) throws {
+        precondition(offset + staging.count <= count)
+        try heAmdCheck(he_memcpy_h2d(pointer + offset, staging.pointer, staging.count * MemoryLayout<UInt64>.stride,
+                                     stream.raw))
+        staged.append(staging)
+    }
+
+    /// Drops the pinned sources once the stream they were copied on has been waited for.
+    public func releaseStaging() {
+        staged.removeAll()
+    }
+
+    /// Copies `words` to word offset `offset` from a pointer borrowed for the duration of a closure: `he_memcpy_h2d` is an
+    /// asynchronous copy from pageable memory here, so the copy is waited for before the pointer goes out of scope (the C
+    /// side does the same for its borrowed host masks, csrc/pir_api.cpp).  For single small objects; anything made of
+    /// several polynomials goes through a `HostStaging`.
     public func upload(words: UnsafeBufferPointer<UInt64>, at offset: Int, on stream: HeAmdStream) throws {
         precondition(offset + words.count <= count)
         try heAmdCheck(he_memcpy_h2d(pointer + offset, words.baseAddress, words.count * MemoryLayout<UInt64>.stride,
@@ -40,24 +113,30 @@ public final class DeviceBuffer: @unchecked Sendable {
         try heAmdCheck(he_stream_synchronize(stream.raw))
     }
 
-    /// Copies the words of `poly` to word offset `offset`.
+    /// Copies the words of `poly` to word offset `offset` (one staged copy, no wait).
     public func upload<F: PolyFormat>(_ poly: PolyRq<UInt64, F>, at offset: Int, on stream: HeAmdStream) throws {
-        try poly.data.withDataSpan { span in // Array2d.swift:95: the storage, row-major
-            try span.withUnsafeBufferPointer { words in
-                try upload(words: words, at: offset, on: stream)
-            }
-        }
+        let staging = try HostStaging(capacity: poly.data.count)
+        staging.append(poly)
+        try upload(staged: staging, at: offset, on: stream)
     }
 
-    /// All polynomials of `ciphertext`, back to back, starting at word offset `offset`.
+    /// All polynomials of `ciphertext`, back to back, starting at word offset `offset`: one staged copy, no wait.
     public func upload<S: HeScheme, F: PolyFormat>(_ ciphertext: Ciphertext<S, F>, at offset: Int,
                                                    on stream: HeAmdStream) throws where S.Scalar == UInt64
     {
-        var cursor = offset
-        for poly in ciphertext.polys { // Ciphertext.swift:23
-            try upload(poly, at: cursor, on: stream)
-            cursor += poly.data.count
-        }
+        let staging = try HostStaging(capacity: ciphertext.polys.reduce(0) { $0 + $1.data.count })
+        staging.append(ciphertext)
+        try upload(staged: staging, at: offset, on: stream)
+    }
+
+    /// `ciphertexts` back to back from word offset `offset` (a query, the operands of an inner product): ONE copy.
+    public func upload<S: HeScheme, F: PolyFormat>(contentsOf ciphertexts: [Ciphertext<S, F>], at offset: Int,
+                                                   on stream: HeAmdStream) throws where S.Scalar == UInt64
+    {
+        let words = ciphertexts.reduce(0) { sum, ciphertext in sum + ciphertext.polys.reduce(0) { $0 + $1.data.count } }
+        let staging = try HostStaging(capacity: words)
+        for ciphertext in ciphertexts { staging.append(ciphertext) }
+        try upload(staged: staging, at: offset, on: stream)
     }
 
     /// Reads `rowCount * degree` words back as one polynomial over `context`.  Waits for the copy before the destination
@@ -77,14 +156,23 @@ public final class DeviceBuffer: @unchecked Sendable {
     }
 
     /// Reads `polyCount` polynomials back as a ciphertext with no seed, as every evaluation result of the reference
-    /// carries (Ciphertext.swift:64-84, `clearSeed()` at the end of each operation).
+    /// carries (Ciphertext.swift:64-84, `clearSeed()` at the end of each operation): ONE copy and one wait for all of them.
     public func downloadCiphertext<S: HeScheme, F: PolyFormat>(
         context: S.Context, polyContext: PolyContext<UInt64>, polyCount: Int, at offset: Int,
         correctionFactor: UInt64 = 1, on stream: HeAmdStream) throws -> Ciphertext<S, F> where S.Scalar == UInt64
     {
         let stride = polyContext.moduli.count * polyContext.degree
-        let polys: [PolyRq<UInt64, F>] = try (0..<polyCount).map { index in
-            try downloadPoly(context: polyContext, at: offset + index * stride, on: stream)
+        var words = [UInt64](repeating: 0, count: polyCount * stride)
+        try words.withUnsafeMutableBufferPointer { destination in
+            try heAmdCheck(he_memcpy_d2h(destination.baseAddress, pointer + offset,
+                                         polyCount * stride * MemoryLayout<UInt64>.stride, stream.raw))
+            try heAmdCheck(he_stream_synchronize(stream.raw))
+        }
+        releaseStaging() // the stream has been waited for: every copy into this buffer is done
+        let polys: [PolyRq<UInt64, F>] = (0..<polyCount).map { index in
+            let data = Array2d(data: Array(words[index * stride..<(index + 1) * stride]),
+                               rowCount: polyContext.moduli.count, columnCount: polyContext.degree)
+            return PolyRq(context: polyContext, data: data) // PolyRq.swift:31
         }
         return try Ciphertext(_context: context, _polys: polys, _correctionFactor: correctionFactor,
                               _auxiliaryData: nil)
@@ -101,10 +189,11 @@ public final class DeviceKeySwitchKey: @unchecked Sendable {
         let ciphertexts = key._ciphertexts
         let words = ciphertexts.reduce(0) { sum, ct in sum + ct.polys.reduce(0) { $0 + $1.data.count } }
         buffer = try DeviceBuffer(count: words)
-        var cursor = 0
-        for ciphertext in ciphertexts {
-            try buffer.upload(ciphertext, at: cursor, on: stream)
-            cursor += ciphertext.polys.reduce(0) { $0 + $1.data.count }
-        }
+        try buffer.upload(contentsOf: ciphertexts, at: 0, on: stream) // the whole key: one staged copy
+    }
+
+    /// Bytes of HBM the key occupies.
+    public var byteCount: Int {
+        buffer.count * MemoryLayout<UInt64>.stride
     }
 }

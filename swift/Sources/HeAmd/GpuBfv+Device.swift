@@ -247,10 +247,8 @@ extension GpuBfv {
         let count = lhs.count
         let stream = try HeAmdStream()
         let left = try DeviceBuffer(count: count * 2 * polyWords), right = try DeviceBuffer(count: count * 2 * polyWords)
-        for index in 0..<count {
-            try left.upload(lhs[index], at: index * 2 * polyWords, on: stream)
-            try right.upload(rhs[index], at: index * 2 * polyWords, on: stream)
-        }
+        try left.upload(contentsOf: lhs, at: 0, on: stream) // each operand vector: one staged copy
+        try right.upload(contentsOf: rhs, at: 0, on: stream)
         let out = try DeviceBuffer(count: 3 * polyWords)
         try heAmdCheck(he_bfv_inner_product_device(context.gpu, level, left.pointer, right.pointer, count, out.pointer, nil,
                                                    0, stream.raw))

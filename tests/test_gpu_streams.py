@@ -174,3 +174,34 @@ def test_events_and_stream_callbacks(oracle):
     assert np.array_equal(heamd.to_host(ours.forward_ntt_(slab)), ref.forward_ntt(x))
     assert lib.he_event_destroy(event) == 0
     assert lib.he_stream_destroy(producer) == 0 and lib.he_stream_destroy(consumer) == 0
+
+
+def test_pinned_host_staging_round_trip(oracle):
+    """he_host_malloc / he_host_free: a ciphertext's polynomials staged back to back in page-locked memory go up with ONE
+    asynchronous copy and no wait before the transform is enqueued behind it on the same stream -- what the Swift host's
+    DeviceBuffer does for a ciphertext, a key or a database block -- and the result read back into the same staging
+    equals the oracle's transform."""
+    import ctypes
+
+    from heamd import binding
+
+    lib = binding.load_library()
+    degree = 4096
+    moduli = oracle.generate_primes([55, 55], False, degree)
+    ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+    x = _slab(np.random.default_rng(94), 3, moduli, degree)
+    nbytes = x.nbytes
+    staging, device, stream = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.he_host_malloc(ctypes.byref(staging), nbytes) == 0 and staging.value
+    assert lib.he_device_malloc(ctypes.byref(device), nbytes) == 0
+    assert lib.he_stream_create(ctypes.byref(stream)) == 0
+    ctypes.memmove(staging, x.ctypes.data, nbytes)
+    assert lib.he_memcpy_h2d(device, staging, nbytes, stream) == 0
+    assert lib.he_ntt_forward_device(ours.h, device, 3, stream) == 0
+    assert lib.he_memcpy_d2h(staging, device, nbytes, stream) == 0
+    assert lib.he_stream_synchronize(stream) == 0
+    got = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(staging.value), dtype=np.uint64).reshape(x.shape).copy()
+    assert np.array_equal(got, ref.forward_ntt(x))
+    assert lib.he_host_free(staging) == 0 and lib.he_host_free(None) == 0
+    assert lib.he_device_free(device) == 0 and lib.he_stream_destroy(stream) == 0
+    assert lib.he_host_malloc(None, 8) == 16  # invalidArgument
