@@ -7,8 +7,13 @@ O=gpurun_out/$T
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
-timeout 900 python bench_tools/ab_variants.py run --what c3 --rounds 2 keymac_item_pairs keymac_columns_separate_finish > $O/ab_c3.txt 2>&1; cat $O/ab_c3.txt
-timeout 900 python bench_tools/ab_variants.py run --what ntt --rounds 2 inv_shift inv_shift_early inv_shift_early_head2 > $O/ab_ntt.txt 2>&1; cat $O/ab_ntt.txt
+# every variant library under lib/variants/ is timed (C3_VARIANTS / NTT_VARIANTS restrict the lists; "none" skips a leg)
+if [ "${C3_VARIANTS:-}" != "none" ]; then
+  timeout 900 python bench_tools/ab_variants.py run --what c3 --rounds ${ROUNDS:-3} ${C3_VARIANTS:-} > $O/ab_c3.txt 2>&1; cat $O/ab_c3.txt
+fi
+if [ "${NTT_VARIANTS:-}" != "none" ]; then
+  timeout 900 python bench_tools/ab_variants.py run --what ${NTT_WHAT:-ntt} --rounds ${ROUNDS:-3} ${NTT_VARIANTS:-} > $O/ab_ntt.txt 2>&1; cat $O/ab_ntt.txt
+fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -- python bench_tools/c3_profile_target.py > $O/c3_stats.log 2>&1
 f=$(find $O/c3_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/c3_kernel_stats.csv; python bench_tools/kernel_stats_summary.py $O/c3_kernel_stats.csv | head -16
 rm -rf $O/c3_stats

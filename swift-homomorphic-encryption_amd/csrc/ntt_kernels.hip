@@ -236,11 +236,51 @@ __device__ __forceinline__ void inverse_row_head(TwiddleWords (&head)[HEAD], con
     constexpr int LOW = PassOrder<LOGN, LOGE, TOP>::LOW;
     inverse_first_twiddles<LOGN, LOGE, 0, LOW, MODE, false, HEAD>(head, tw, tid);
 }
-template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false, int HEAD = 1>
+// The transform's last step (the exchange into the top pass and that pass) ROW BY ROW, each row handed to `finish` as soon
+// as its canonical words exist: row 0 is brought into the top layout, row 1 is parked in the tile behind it -- its
+// registers are free while row 0 runs its last pass and whatever `finish` does with it (loads of other operands, the
+// store) -- and is picked up afterwards.  Same barriers as the exchange of both rows; the pass's wave-uniform twiddles are
+// scalar loads and are simply read again for the second row.
+struct NoFinish {};
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int MODE, int ROWS, bool SCALED, int PRIOR, int LOGD, typename Finish>
+__device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+                                                         const DeviceModulus& mod, uint64_t* lds, Finish& finish) {
+    static_assert(ROWS <= 2, "one row in registers, one parked in the tile");
+    constexpr int E = 1 << LOGE, LOL = LOGN - LOGE;
+    constexpr int SCHEME = !is_split(MODE) ? transpose_scheme<LOGN, LOGE, LO_FROM, LOL>() : 0;  // as exchange<> in inverse_step
+    lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[0], tid, lds);
+    lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
+    lds_load<LOGN, LOGE, LOL, LOGE, SCHEME>(v[0], tid, lds);
+    if constexpr (ROWS == 2) {
+        lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
+        lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[ROWS - 1], tid, lds);
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        if constexpr (ROWS == 2) {
+            if (k == 1) {
+                lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
+                lds_load<LOGN, LOGE, LOL, LOGE, SCHEME>(v[ROWS - 1], tid, lds);
+            }
+        }
+        uint64_t (&row)[1][E] = *reinterpret_cast<uint64_t (*)[1][E]>(&v[k]);
+        const TwiddleWords head[1] = {inverse_first_twiddle<LOGN, LOGE, LOL, LOGE, MODE, true>(tw, tid)};
+        inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true, 1, SCALED, PRIOR, LOGD, 0, 1>(row, tid, tw, mod, false, head);
+        finish(k, row[0]);
+    }
+}
+
+// Finish: NoFinish, or a callable (row index, the row's canonical words in the top layout) that takes over each row as it
+// is completed (inverse_last_step_by_row; only with the partial pass on the low bits).
+template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false, int HEAD = 1,
+          typename Finish = NoFinish>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
-                                            const DeviceModulus& mod, uint64_t* lds, const TwiddleWords (&head)[HEAD]) {
+                                            const DeviceModulus& mod, uint64_t* lds, const TwiddleWords (&head)[HEAD],
+                                            Finish finish = Finish{}) {
     using S = Schedule<LOGN, LOGE>;
     constexpr int R = S::R, LOL = LOGN - LOGE;
+    constexpr bool BY_ROW = !std::is_same<Finish, NoFinish>::value;
+    static_assert(!BY_ROW || !PassOrder<LOGN, LOGE, TOP>::kTop, "rows are finished one by one in the low-partial order only");
     if constexpr (PassOrder<LOGN, LOGE, TOP>::kTop) {
         // in -- the layout of the full pass on bits [0, LOGE); the full passes from the low bits up, then the partial
         // pass (the transform's last R stages) in the layout of a full top pass
@@ -263,8 +303,14 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
     if constexpr (S::P >= 5)
         inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
     // into the top pass (uniform twiddles; its last stage folds in N^-1)
-    if constexpr (S::P == 2) inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
-    else inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+    if constexpr (BY_ROW) {
+        if constexpr (S::P == 2) inverse_last_step_by_row<LOGN, LOGE, 0, R, MODE, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds, finish);
+        else inverse_last_step_by_row<LOGN, LOGE, LOL - LOGE, LOGE, MODE, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds, finish);
+    } else if constexpr (S::P == 2) {
+        inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+    } else {
+        inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+    }
 }
 
 template <int LOGN, int LOGT, int MODE, int SPREAD = kSourceSlab, int ROWS = 1>
@@ -406,11 +452,10 @@ constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac =
               kInverseFromKeyMacFinish = 4;
 constexpr bool is_key_mac(int source) { return source == kInverseFromKeyMac || source == kInverseFromKeyMacFinish; }
 constexpr bool kKeyMacBoundedReduce = true;
-// Two rows per workgroup of the key MAC = the two key columns (c = 0, 1) of ONE polynomial: every spread word is
-// fetched once (from HBM) and meets both key words (the key is a few MB and stays in L2).  The earlier pairing -- the same
-// column of two consecutive polynomials, the other column in a sibling workgroup of the same XCD -- fetched the 1 280 MiB
-// spread slab of 1024 products 1.7 times (2 214 MiB by the counters, profiles/r03z_pmc_traffic_per_kernel.txt).
-constexpr bool kKeyMacColumnPairs = true;
+// (Measured and dropped, profiles/r04a_keymac_pairing_ab.txt: a workgroup that takes the two key COLUMNS of one polynomial
+// instead of the same column of two consecutive polynomials reads every spread word once -- but its sums are per word,
+// i.e. 8-byte loads at a 16-byte lane stride, twice the load instructions for the same bytes: relinearize 684 -> 614 k/s.
+// The spread slab's re-reads were never what bound the kernel.)
 struct InverseSource {
     const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
     const uint64_t* second;  // key MAC: the key
@@ -437,7 +482,6 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr bool SCALED = SOURCE == kInverseFromTensor || SOURCE == kInverseFromSlabScaled;
     constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
     constexpr bool KEYMAC = is_key_mac(SOURCE), FINISH = SOURCE == kInverseFromKeyMacFinish;
-    constexpr bool COLUMNS = KEYMAC && ROWS == 2 && kKeyMacColumnPairs;  // the rows are (polynomial, c = 0) and (polynomial, c = 1)
     static_assert(ROWS == 1 || SOURCE != kInverseFromSlabScaled, "scaled plain slabs go one row per workgroup");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -450,14 +494,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[ROWS];
-    if constexpr (COLUMNS) {
-        // one workgroup per (polynomial, band row): records (polynomial, 0) and (polynomial, 1); record_base counts items
-        uint32_t group;
-        locate(map, blockIdx.x, group, within);
-        record = (map.record_base + group) * 2;
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) rows[k] = size_t(record + k) * map.record_rows + map.band_offset + within;
-    } else if constexpr (!FROM_SLAB) {
+    if constexpr (!FROM_SLAB) {
         // records (item, c) of one item read the same source rows: one replica set per (group of ROWS consecutive
         // items, band row); the workgroup transforms record (item + k, c) for k < ROWS
         constexpr uint32_t REPLICAS = TENSOR ? 3 : 2;
@@ -526,52 +563,6 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     }
                 }
             }
-        } else if constexpr (COLUMNS) {
-            // word e of the two rows: sum_j spread[poly][j][r][e] * key[j][c][key_row(r)][e], c = 0, 1, one word at a time
-            // (two sums of 7-8 registers each: a 16-byte pair per lane would need four), every word through a buffer
-            // descriptor with a scalar term offset -- no 64-bit address arithmetic on the vector ALU.  The words of
-            // term j + 1 are requested before term j is accumulated; past the last term the request repeats it (a load
-            // behind a branch would drain the queue).
-            const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
-            const uint32_t r = map.band_offset + within;
-            const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
-            const size_t poly = record >> 1;
-            const uint32_t lane_bytes = lane_part<LOGN, LOGE, 0, LOW>(tid) << 3;
-            const uint32_t spread_step = (L + 1) << (LOGN + 3), key_step = (2 * top_rows) << (LOGN + 3),
-                           column_step = top_rows << (LOGN + 3);
-            const BufferResource spread_rows = make_resource(source_spec.first + ((poly * L * (L + 1) + r) << LOGN),
-                                                             (L - 1) * spread_step + (8u << LOGN));
-            const BufferResource key_rows = make_resource(source_spec.second + (static_cast<size_t>(key_row) << LOGN),
-                                                          (L - 1) * key_step + column_step + (8u << LOGN));
-            constexpr bool NARROW = is_split(MODE);  // both operands canonical mod a modulus below 2^55
-            const bool bounded = kKeyMacBoundedReduce && mod.wide_shift != 0 && L <= 8 && uint64_t(L) * mod.p < (uint64_t(1) << 63);
-            auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const uint32_t at = register_part<LOGN, LOGE, 0, LOW>(e) << 3;
-                uint64_t x = word(__builtin_amdgcn_raw_buffer_load_b64(spread_rows, lane_bytes, at, 0));
-                uint64_t k0 = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, at, 0));
-                uint64_t k1 = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, at + column_step, 0));
-                ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
-                for (uint32_t j = 0; j < L; ++j) {
-                    const uint32_t ahead = j + 1 < L ? j + 1 : j;
-                    const uint64_t xn = word(__builtin_amdgcn_raw_buffer_load_b64(spread_rows, lane_bytes, ahead * spread_step + at, 0));
-                    const uint64_t k0n = word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, ahead * key_step + at, 0));
-                    const uint64_t k1n =
-                        word(__builtin_amdgcn_raw_buffer_load_b64(key_rows, lane_bytes, ahead * key_step + column_step + at, 0));
-                    product_sum_add_pair<NARROW>(acc0, acc1, k0, k1, x);
-                    x = xn;
-                    k0 = k0n;
-                    k1 = k1n;
-                }
-                if (bounded) {  // wave-uniform (the one-word-quotient Barrett: L p^2 < 2^(63 + bits(p)) whenever L p < 2^63)
-                    v[0][e] = reduce_product_sum_bounded(acc0, mod);
-                    v[1][e] = reduce_product_sum_bounded(acc1, mod);
-                } else {
-                    v[0][e] = reduce_product_sum(acc0, mod);
-                    v[1][e] = reduce_product_sum(acc1, mod);
-                }
-            }
         } else if constexpr (KEYMAC) {
             const size_t first_poly = record >> 1, c = record & 1;  // record = poly * 2 + c
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
@@ -627,21 +618,19 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             }
         }
         if constexpr (HEAD == 1) inverse_row_head<LOGN, LOGE, MODE, O::kTop, HEAD>(head, tw, tid);
-        inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
         constexpr int LOL = LOGN - LOGE;
         if constexpr (FINISH) {
-            // key_switch_finish_kernel's arithmetic (rns_kernels.hip) on the words this lane holds: with x_ks the q_ks word
-            // of the coefficient and c its centred representative, out = (x - c) q_ks^-1 mod q_r (+ the ciphertext word)
+            // key_switch_finish_kernel's arithmetic (rns_kernels.hip) on each row as its last pass completes: with x_ks the
+            // q_ks word of the coefficient and c its centred representative, out = (x - c) q_ks^-1 mod q_r (+ the ciphertext
+            // word).  (The launcher only takes this path when q_ks / 2 is below every q_r: |c| needs no reduction mod q_r.)
             const uint32_t L = source_spec.L, r = map.band_offset + within;
             const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
-            // (the launcher only takes this path when q_ks / 2 is below every q_r: |c| needs no reduction mod q_r)
             const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
             const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(tid) << 3;
-            constexpr int CHUNK = 4;  // words in flight per row: the q_ks and ciphertext words of a chunk are requested together
-            auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
-#pragma unroll
-            for (int k = 0; k < ROWS; ++k) {
-                const size_t pc = record + (COLUMNS ? k : 2 * k);  // polynomial * 2 + c
+            auto finish = [&](int k, uint64_t (&row)[E]) {
+                constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
+                auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
+                const size_t pc = record + 2 * k;  // polynomial * 2 + c (the rows are the same column of consecutive polynomials)
                 const size_t poly = pc >> 1;
                 const uint32_t c = static_cast<uint32_t>(pc & 1);
                 const BufferResource last_row = make_resource(slab + ((pc * (L + 1) + L) << LOGN), 8u << LOGN);
@@ -653,14 +642,12 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 #pragma unroll
                 for (int base = 0; base < E; base += CHUNK) {
                     uint64_t last[CHUNK], added[CHUNK];
-                    __builtin_amdgcn_sched_barrier(0);  // the requests stay behind the transform's last pass
 #pragma unroll
                     for (int e = 0; e < CHUNK; ++e) {
                         const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
                         last[e] = word(__builtin_amdgcn_raw_buffer_load_b64(last_row, lane_bytes, at, row_load_policy<LOGN>()));
                         added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
                     }
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < CHUNK; ++e) {
                         const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
@@ -668,16 +655,17 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                         const uint64_t shifted = add_mod_uniform(last[e], half, q_last);
                         const bool negative = shifted < half;
                         const uint64_t t = negative ? half - shifted : shifted - half;
-                        const uint64_t difference = csub_uniform(v[k][base + e] + (negative ? t : p - t), p);
+                        const uint64_t difference = csub_uniform(row[base + e] + (negative ? t : p - t), p);
                         const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, p);
                         const uint64_t result = csub_uniform((add ? added[e] : 0) + update, p);
                         const Dwordx2 words = {lo32(result), hi32(result)};
                         __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
                 global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
@@ -1180,18 +1168,10 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
         return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
     }
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
-    if (is_key_mac(source) && kKeyMacColumnPairs && kKeyMacRows<LOGN, LOGT> == 2) {
-        // one workgroup per (polynomial, band row) takes both key columns
-        const size_t workgroups = rows / 2;
-        return source == kInverseFromKeyMacFinish
-                   ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, 2>(mode, slab, ctx, map, workgroups, source_spec, stream)
-                   : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 2>(mode, slab, ctx, map, workgroups, source_spec, stream);
-    }
-    if (source == kInverseFromKeyMacFinish) return hipErrorNotSupported;  // callers run the separate finish kernel
-    if (source == kInverseFromTensor || source == kInverseFromKeyMac) {
+    if (source == kInverseFromTensor || is_key_mac(source)) {
         // records are (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the odd items at
         // the end go one per workgroup.  record_base counts items for these kernels.
-        const bool tensor = source == kInverseFromTensor;
+        const bool tensor = source == kInverseFromTensor, finish = source == kInverseFromKeyMacFinish;
         const size_t replicas = tensor ? 3 : 2;
         const size_t items = rows / mod_period / replicas;
         const size_t group = tensor ? kTensorRows<LOGN, LOGT> : kKeyMacRows<LOGN, LOGT>;
@@ -1203,16 +1183,20 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
             const size_t workgroups = grouped / group * replicas * mod_period;
             hipError_t e = tensor ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, kTensorRows<LOGN, LOGT>>(
                                         mode, slab, ctx, map_from(0), workgroups, source_spec, stream)
-                                  : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, kKeyMacRows<LOGN, LOGT>>(
-                                        mode, slab, ctx, map_from(0), workgroups, source_spec, stream);
+                           : finish ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, kKeyMacRows<LOGN, LOGT>>(
+                                          mode, slab, ctx, map_from(0), workgroups, source_spec, stream)
+                                    : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, kKeyMacRows<LOGN, LOGT>>(
+                                          mode, slab, ctx, map_from(0), workgroups, source_spec, stream);
             if (e != hipSuccess) return e;
         }
         if (items == grouped) return hipSuccess;
         const size_t workgroups = (items - grouped) * replicas * mod_period;
-        return tensor ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map_from(grouped),
-                                                                                workgroups, source_spec, stream)
-                      : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map_from(grouped),
-                                                                                workgroups, source_spec, stream);
+        return tensor   ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map_from(grouped),
+                                                                                  workgroups, source_spec, stream)
+               : finish ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, 1>(mode, slab, ctx, map_from(grouped),
+                                                                                        workgroups, source_spec, stream)
+                        : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map_from(grouped),
+                                                                                  workgroups, source_spec, stream);
     }
     size_t paired_records = 0;
     if constexpr (GROUP > 1) {
@@ -1422,10 +1406,10 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
 // ct_base + polynomial * ct_stride: out [polys][2][L][N].  hipErrorNotSupported (nothing launched) where the degree has
 // no kernel that pairs the key columns; the caller then runs launch_ntt_key_mac_inverse + launch_key_switch_finish.
 bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys) {
-    const bool paired = kKeyMacColumnPairs && (ks.log_degree == 12 || ks.log_degree == 13);  // kKeyMacRows == 2
+    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;  // the degrees with a fused key-MAC transform
     // bit r of narrow_special_mask: q_ks / 2 < q_r, i.e. the centred q_ks word needs no reduction mod q_r
     const uint64_t band = L >= 64 ? ~uint64_t(0) : (uint64_t(1) << L) - 1;
-    return paired && L >= 1 && L < 64 && ks.moduli_count == L + 1 && (ks.narrow_special_mask & band) == band &&
+    return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && (ks.narrow_special_mask & band) == band &&
            polys * 2 * (L + 1) <= (size_t(1) << 30);
 }
 hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,

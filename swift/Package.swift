@@ -49,6 +49,10 @@ let package = Package(
             dependencies: [
                 "HeAmd",
                 .product(name: "HomomorphicEncryption", package: "swift-homomorphic-encryption"),
+                .product(name: "PrivateInformationRetrieval", package: "swift-homomorphic-encryption"),
+                // the reference's generic scheme / index-PIR suites (reference Package.swift:74,157), instantiated with
+                // GpuBfv and GpuPirUtil in Tests/HeAmdTests/ReferenceSuites.swift
+                .product(name: "_TestUtilities", package: "swift-homomorphic-encryption"),
             ],
             path: "Tests/HeAmdTests"),
     ])

@@ -46,10 +46,8 @@ extension Bfv where T == UInt64 {
         let stream = try HeAmdStream()
         let left = try DeviceBuffer(count: batch * 2 * polyWords), right = try DeviceBuffer(count: batch * 2 * polyWords)
         let product = try DeviceBuffer(count: batch * 3 * polyWords), out = try DeviceBuffer(count: batch * 2 * polyWords)
-        for index in 0..<batch {
-            try left.upload(lhs[index], at: index * 2 * polyWords, on: stream)
-            try right.upload(rhs[index], at: index * 2 * polyWords, on: stream)
-        }
+        try left.upload(contentsOf: lhs, at: 0, on: stream) // each operand batch: one staged copy, no wait
+        try right.upload(contentsOf: rhs, at: 0, on: stream)
         let key = try DeviceKeySwitchKey(relinearizationKey._keySwitchKey, on: stream)
         try heAmdCheck(he_bfv_mul_device(handle, level, left.pointer, right.pointer, product.pointer, batch, nil, 0,
                                          stream.raw))

@@ -12,8 +12,9 @@ import HomomorphicEncryption
 public final class HostStaging: @unchecked Sendable {
     public let pointer: UnsafeMutablePointer<UInt64>
     public let capacity: Int
+    private var used = 0
     /// Words appended so far.
-    public private(set) var count = 0
+    public var count: Int { used }
 
     public init(capacity: Int) throws {
         var raw: UnsafeMutableRawPointer?
@@ -30,12 +31,12 @@ public final class HostStaging: @unchecked Sendable {
     /// Appends `words`; returns the word offset they were put at.
     @discardableResult
     public func append(words: UnsafeBufferPointer<UInt64>) -> Int {
-        precondition(count + words.count <= capacity)
-        let offset = count
+        precondition(used + words.count <= capacity)
+        let offset = used
         if let source = words.baseAddress {
             (pointer + offset).update(from: source, count: words.count)
         }
-        count += words.count
+        used += words.count
         return offset
     }
 
@@ -57,7 +58,7 @@ public final class HostStaging: @unchecked Sendable {
 
     /// Forgets the appended words (after the copy that read them has been waited for).
     public func reset() {
-        count = 0
+        used = 0
     }
 }
 
@@ -137,6 +138,42 @@ public final class DeviceBuffer: @unchecked Sendable {
         let staging = try HostStaging(capacity: words)
         for ciphertext in ciphertexts { staging.append(ciphertext) }
         try upload(staged: staging, at: offset, on: stream)
+    }
+
+    /// A run of optional Eval plaintexts (a database, a chunk of one: IndexPirProtocol.swift:249-290) to word offset 0,
+    /// plaintext k at k * polyWords, through ONE reusable pinned block of at most `blockBytes`: one copy and one wait per
+    /// block instead of one per plaintext.  Returns the presence mask (0 = nil, Bfv.swift:486-489); the words of a nil
+    /// plaintext are never used by the kernels (its mask byte travels with them) and are left as they are.
+    public func upload<S: HeScheme>(plaintexts: some Collection<Plaintext<S, Eval>?>, polyWords: Int, on stream: HeAmdStream,
+                                    blockBytes: Int = 256 << 20) throws -> [UInt8] where S.Scalar == UInt64
+    {
+        precondition(plaintexts.count * polyWords <= count)
+        let perBlock = max(1, blockBytes / (polyWords * MemoryLayout<UInt64>.stride))
+        let staging = try HostStaging(capacity: min(perBlock, max(plaintexts.count, 1)) * polyWords)
+        var present = [UInt8](repeating: 0, count: plaintexts.count)
+        var blockStart = 0, inBlock = 0
+        func flush() throws {
+            guard inBlock > 0 else { return }
+            try heAmdCheck(he_memcpy_h2d(pointer + blockStart * polyWords, staging.pointer,
+                                         inBlock * polyWords * MemoryLayout<UInt64>.stride, stream.raw))
+            try heAmdCheck(he_stream_synchronize(stream.raw)) // the block is reused
+            blockStart += inBlock
+            inBlock = 0
+        }
+        for (index, plaintext) in plaintexts.enumerated() {
+            if let plaintext {
+                present[index] = 1
+                plaintext._poly.data.withDataSpan { span in // Plaintext.swift:28, Array2d.swift:95
+                    span.withUnsafeBufferPointer { words in
+                        (staging.pointer + inBlock * polyWords).update(from: words.baseAddress!, count: polyWords)
+                    }
+                }
+            }
+            inBlock += 1
+            if inBlock == perBlock { try flush() }
+        }
+        try flush()
+        return present
     }
 
     /// Reads `rowCount * degree` words back as one polynomial over `context`.  Waits for the copy before the destination

@@ -241,6 +241,10 @@ extension GpuBfv {
             guard right.polys.count == freshCiphertextPolyCount, right.correctionFactor == 1 else {
                 throw HeError.invalidCiphertext("rhs: \(right.polys.count) polynomials, correction factor \(right.correctionFactor)")
             }
+            // the operands are laid out in `first`'s shape: one level for all (Bfv+Multiply.swift:73-75)
+            guard left.polys[0].context == first.polys[0].context, right.polys[0].context == first.polys[0].context else {
+                throw HeError.incompatibleCiphertexts("the ciphertexts are at different levels")
+            }
         }
         let context = first.context
         let (level, polyContext, polyWords) = shape(first)
@@ -270,19 +274,28 @@ extension GpuBfv {
                      "All ciphertexts must have the same polynomial count")
         let context = first.context
         let (level, polyContext, polyWords) = shape(first)
+        // every operand is written at index * polyWords in `first`'s shape: all of them must be at its level.  The
+        // reference checks each term as it multiplies it (lazyMultiply, Bfv.swift:365-394: validateEquality, then
+        // ciphertext.moduli.count == plaintext.moduli.count -> incompatibleCiphertextAndPlaintext); ciphertexts of
+        // different levels cannot be added (Bfv.swift:80-93 -> incompatibleCiphertexts).
+        for (ciphertext, plaintext) in zip(ciphertexts, plaintexts) {
+            try validateEquality(of: context, and: ciphertext.context)
+            guard ciphertext.polys[0].context == polyContext else {
+                throw HeError.incompatibleCiphertexts("the ciphertexts are at different levels")
+            }
+            guard let plaintext else { continue }
+            try validateEquality(of: context, and: plaintext.context)
+            guard plaintext._poly.context.moduli.count == polyContext.moduli.count else {
+                throw HeError.incompatibleCiphertextAndPlaintext("ciphertext and plaintext levels differ")
+            }
+        }
         let polyCount = first.polys.count, count = ciphertexts.count
         let correctionFactor = first.correctionFactor
         let stream = try HeAmdStream()
         let vector = try DeviceBuffer(count: count * polyCount * polyWords)
         let factors = try DeviceBuffer(count: count * polyWords)
-        var present = [UInt8](repeating: 0, count: count)
-        for index in 0..<count {
-            try vector.upload(ciphertexts[index], at: index * polyCount * polyWords, on: stream)
-            guard let plaintext = plaintexts[index] else { continue }
-            try validateEquality(of: context, and: plaintext.context)
-            present[index] = 1
-            try factors.upload(plaintext._poly, at: index * polyWords, on: stream)
-        }
+        try vector.upload(contentsOf: ciphertexts, at: 0, on: stream) // the ciphertext vector: one staged copy
+        let present = try factors.upload(plaintexts: plaintexts, polyWords: polyWords, on: stream)
         let out = try DeviceBuffer(count: polyCount * polyWords)
         try present.withUnsafeBufferPointer { mask in // (the host-mask form waits for the mask's upload itself)
             try heAmdCheck(he_bfv_inner_product_plain_device(context.gpu, level, UInt32(polyCount), vector.pointer,

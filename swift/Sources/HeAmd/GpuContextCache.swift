@@ -21,21 +21,12 @@ final class GpuContextCache: @unchecked Sendable {
     private let lock = NSLock()
     private var polyContexts: [ContextKey: OpaquePointer] = [:]
     private var bfvContexts: [ContextKey: OpaquePointer] = [:]
-    private var retainsScratch: Set<Int32> = []
 
     /// The calling thread's current HIP device.
     static func currentDevice() throws -> Int32 {
         var device: Int32 = 0
         try heAmdCheck(he_get_device(&device))
         return device
-    }
-
-    /// A server keeps the library's scratch pool warm (query expansion takes tens of gigabytes per call; mapping them
-    /// anew costs seconds): opted into once per device, on first use.  `he_device_trim_scratch` gives it back.
-    private func retainScratch(on device: Int32) {
-        guard !retainsScratch.contains(device) else { return }
-        retainsScratch.insert(device)
-        _ = he_set_scratch_cache(UInt64.max)
     }
 
     /// `he_poly_context` of a PolyContext<UInt64> (PolyContext.init's validation already passed on the Swift side; the
@@ -63,7 +54,6 @@ final class GpuContextCache: @unchecked Sendable {
         lock.lock()
         defer { lock.unlock() }
         if let cached = bfvContexts[key] { return cached }
-        retainScratch(on: device)
         var out: OpaquePointer?
         try coefficientModuli.withUnsafeBufferPointer { moduli in
             try heAmdCheck(he_bfv_context_create(UInt32(degree), plaintextModulus, moduli.baseAddress,
@@ -72,6 +62,23 @@ final class GpuContextCache: @unchecked Sendable {
         guard let out else { throw HeError.unsupportedHeOperation(description: "he_bfv_context_create returned nil") }
         bfvContexts[key] = out
         return out
+    }
+}
+
+/// The library's scratch pool on the current HIP device (include/he_amd.h `he_set_scratch_cache`).  By default nothing is
+/// retained: scratch of the multi-kernel calls returns to the driver at the next synchronisation.  A server that expands
+/// queries opts in ONCE with a bound it chooses -- a batched expansion takes tens of gigabytes, and mapping them anew costs
+/// a second per call -- and hands the memory back with `trimScratch` when it goes idle.  The package never opts in on the
+/// host's behalf.
+public enum HeAmdScratch {
+    /// Lets the current device's pool keep up to `bytes` of freed scratch (`UInt64.max`: everything).
+    public static func setScratchCache(bytes: UInt64) throws {
+        try heAmdCheck(he_set_scratch_cache(bytes))
+    }
+
+    /// Returns everything above `keepBytes` to the driver.
+    public static func trimScratch(keepBytes: UInt64 = 0) throws {
+        try heAmdCheck(he_device_trim_scratch(keepBytes))
     }
 }
 

@@ -56,9 +56,7 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
 
         let stream = try HeAmdStream()
         let ciphertexts = try DeviceBuffer(count: query.ciphertexts.count * 2 * polyWords)
-        for (index, ciphertext) in query.ciphertexts.enumerated() {
-            try ciphertexts.upload(ciphertext, at: index * 2 * polyWords, on: stream)
-        }
+        try ciphertexts.upload(contentsOf: query.ciphertexts, at: 0, on: stream) // the whole query: one staged copy
         let responses = try DeviceBuffer(count: query.indicesCount * chunkCount * 2 * degree) // [index][chunk][2][1][N]
         let dimensions = parameter.dimensions.map { UInt32($0) }
         let databasePointers: [UnsafePointer<UInt64>?] = resident.map { UnsafePointer($0.plaintexts.pointer) }
@@ -110,9 +108,7 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
         let keys = try GpuResidentCache.shared.resident(evaluationKey)
         let stream = try HeAmdStream()
         let input = try DeviceBuffer(count: ciphertexts.count * 2 * polyWords)
-        for (index, ciphertext) in ciphertexts.enumerated() {
-            try input.upload(ciphertext, at: index * 2 * polyWords, on: stream)
-        }
+        try input.upload(contentsOf: ciphertexts, at: 0, on: stream)
         let output = try DeviceBuffer(count: outputCount * 2 * polyWords)
         let galoisPointers = keys.galoisPointers
         let handle = try context.gpu
@@ -160,23 +156,14 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
         let stream = try HeAmdStream()
 
         let dim0 = try DeviceBuffer(count: expandedDim0Query.count * 2 * polyWords)
-        for (index, ciphertext) in expandedDim0Query.enumerated() {
-            try dim0.upload(ciphertext, at: index * 2 * polyWords, on: stream)
-        }
+        try dim0.upload(contentsOf: expandedDim0Query, at: 0, on: stream)
         let rest = try DeviceBuffer(count: expandedRemainingQuery.count * 2 * polyWords)
-        for (index, ciphertext) in expandedRemainingQuery.enumerated() {
-            try rest.upload(ciphertext, at: index * 2 * polyWords, on: stream)
-        }
+        try rest.upload(contentsOf: expandedRemainingQuery, at: 0, on: stream)
         // The chunk: plaintext k of column c at index c * d0 + k (MulPir.swift:547-555); nil plaintexts are masked out.
         // This requirement hands over a slice by value, so the slice is uploaded; computeResponse(to:...) above is the
         // path that never moves the database.
         let database = try DeviceBuffer(count: perChunk * polyWords)
-        var present = [UInt8](repeating: 0, count: perChunk)
-        for (index, plaintext) in dataChunk.enumerated() where index < perChunk {
-            guard let plaintext else { continue }
-            present[index] = 1
-            try database.upload(plaintext._poly, at: index * polyWords, on: stream) // Plaintext.swift:28
-        }
+        let present = try database.upload(plaintexts: dataChunk.prefix(perChunk), polyWords: polyWords, on: stream)
         let keys = try GpuResidentCache.shared.resident(evaluationKey) // resident after the first chunk
         if parameter.dimensions.count > 1, keys.relinearizationKey == nil {
             throw HeError.missingRelinearizationKey

@@ -1,5 +1,5 @@
 """Writes tests/golden/reference_swift_api.json: for every function / initialiser / enum-case NAME that the Swift package
-under swift/Sources/HeAmd calls, every argument-label list under which the REFERENCE declares that name (anywhere under
+under swift/Sources/HeAmd (and its tests under swift/Tests/HeAmdTests) calls, every argument-label list under which the REFERENCE declares that name (anywhere under
 its Sources/), plus the reference's property and type names the package mentions.  tests/test_swift_reference_api.py
 resolves the package's calls against this list where the reference checkout is absent (the GPU box) and re-derives it
 where it is present.
@@ -39,7 +39,8 @@ def reference_declarations():
 
 def package_call_names():
     names = set()
-    for path in sorted(glob.glob(os.path.join(ROOT, "swift", "Sources", "HeAmd", "*.swift"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "swift", "Sources", "HeAmd", "*.swift")) +
+                       glob.glob(os.path.join(ROOT, "swift", "Tests", "HeAmdTests", "*.swift"))):
         for name, signature, is_init in call_signatures(open(path).read()):
             names.add("init" if is_init else name)
     return names
@@ -48,7 +49,8 @@ def package_call_names():
 if __name__ == "__main__":
     by_name, bare = reference_declarations()
     names = package_call_names()
-    text = "\n".join(open(p).read() for p in glob.glob(os.path.join(ROOT, "swift", "Sources", "HeAmd", "*.swift")))
+    text = "\n".join(open(p).read() for p in glob.glob(os.path.join(ROOT, "swift", "Sources", "HeAmd", "*.swift")) +
+                     glob.glob(os.path.join(ROOT, "swift", "Tests", "HeAmdTests", "*.swift")))
     mentioned = sorted(b for b in bare if re.search(r"\b%s\b" % re.escape(b), text))
     out = {"source": "declarations under /root/reference/Sources (the checkout of this build)",
            "label_lists": {n: sorted(list(l) for l in by_name[n]) for n in sorted(names) if n in by_name},

@@ -24,7 +24,7 @@ REFERENCE = "/root/reference/Sources"
 STANDARD = {
     "assumingMemoryBound": [["to"]], "bindMemory": [["to", "capacity"]], "compactMap": [["_"]], "map": [["_"]],
     "enumerated": [[]], "fromOpaque": [["_"]], "toOpaque": [[]], "passRetained": [["_"]], "takeRetainedValue": [[]],
-    "lock": [[]], "unlock": [[]], "max": [["_", "_"]], "min": [["_", "_"]], "zip": [["_", "_"]],
+    "lock": [[]], "unlock": [[]], "max": [["_", "_"]], "min": [["_", "_"], ["by"]], "zip": [["_", "_"]],
     "reduce": [["_", "_"]], "resume": [[], ["throwing"], ["returning"]], "withExtendedLifetime": [["_", "_"]],
     "withUnsafeBufferPointer": [["_"]], "withUnsafeMutableBufferPointer": [["_"]], "withUnsafeBytes": [["_"]],
     "withCheckedThrowingContinuation": [["_"]], "allSatisfy": [["_"]], "contains": [["_"], ["where"]],
@@ -132,3 +132,56 @@ def test_a_wrong_label_is_caught():
     assert not any(is_ordered_subset(["config", "with"], d) for d in reference_by_name["generateEvaluationKey"])
     assert not any(is_ordered_subset(["using", "config"], d) for d in reference_by_name["generateEvaluationKey"])
     assert not any(is_ordered_subset(["databaseCount", "queryCount"], d) for d in reference_by_name["invalidBatchSize"])
+
+
+# ---- the reference's generic suites over the drop-in types (swift/Tests/HeAmdTests/ReferenceSuites.swift) ----------------
+TEST_SOURCES = sorted(glob.glob(os.path.join(ROOT, "swift", "Tests", "HeAmdTests", "*.swift")))
+TEST_STANDARD = {"expect": [["_"], ["throws"], ["_", "_"]], "require": [["_"]], "shuffle": [[]], "random": [["in"]]}
+
+
+def test_every_call_of_the_swift_tests_resolves():
+    """The calls swift/Tests/HeAmdTests makes -- above all the reference's generic suites instantiated with GpuBfv /
+    GpuPirUtil -- resolve label for label to declarations of the reference (its _TestUtilities product included), of the
+    package, or of the tests themselves."""
+    reference_by_name, reference_bare = _reference_from_golden()
+    own_by_name, own_bare = _collect(PACKAGE + TEST_SOURCES)
+    unresolved = []
+    for path in TEST_SOURCES:
+        for name, signature, is_init in call_signatures(open(path).read()):
+            labels = signature_parts(signature)[1]
+            key = "init" if is_init or name == "init" else name
+            if is_init and name in STANDARD_TYPES:
+                continue
+            candidates = (reference_by_name.get(key, []) + own_by_name.get(key, []) + STANDARD.get(name, []) +
+                          TEST_STANDARD.get(name, []))
+            if any(is_ordered_subset(labels, declared) for declared in candidates):
+                continue
+            if not is_init and (name in own_bare or name in reference_bare) and "_" * len(labels) == "".join(labels):
+                continue
+            unresolved.append((os.path.basename(path), name, labels))
+    assert not unresolved, unresolved
+
+
+def test_reference_suites_cover_what_the_reference_runs_for_bfv():
+    """ReferenceSuites.swift calls every HeAPITestHelpers.* the reference's runBfvTests calls for Bfv<T>
+    (Tests/HomomorphicEncryptionTests/HeAPITests.swift:176-221) -- with GpuBfv.self -- plus the index-PIR suite with the
+    GpuPirUtil server and the public indexPir(scheme:) entry point."""
+    import re
+
+    text = open(os.path.join(ROOT, "swift", "Tests", "HeAmdTests", "ReferenceSuites.swift")).read()
+    ours = set(re.findall(r"HeAPITestHelpers\.(\w+)\(", text))
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_bfv_suite_calls.json")))
+    assert set(golden["helpers"]) <= ours, sorted(set(golden["helpers"]) - ours)
+    for helper in golden["helpers"]:
+        if helper != "schemeEvaluationKeyTest":  # (context:) only
+            assert re.search(r"HeAPITestHelpers\.%s\(context: context, scheme: GpuBfv\.self\)" % helper, text), helper
+    assert "indexPirTest(\n            server: MulPirServer<GpuPirUtil<GpuBfv>>.self" in text
+    assert "IndexPirTests.indexPir(scheme: GpuBfv.self)" in text
+    assert "@testable import _TestUtilities" in text
+    package = open(os.path.join(ROOT, "swift", "Package.swift")).read()
+    assert '.product(name: "_TestUtilities", package: "swift-homomorphic-encryption")' in package
+    reference_tests = "/root/reference/Tests/HomomorphicEncryptionTests/HeAPITests.swift"
+    if os.path.exists(reference_tests):
+        body = open(reference_tests).read()
+        body = body[body.index("private func runBfvTests"):body.index("func bfvUInt32")]
+        assert sorted(set(re.findall(r"HeAPITestHelpers\.(\w+)\(", body))) == sorted(golden["helpers"])
