@@ -14,6 +14,12 @@ fi
 if [ "${NTT_VARIANTS:-}" != "none" ]; then
   timeout 900 python bench_tools/ab_variants.py run --what ${NTT_WHAT:-ntt} --rounds ${ROUNDS:-3} ${NTT_VARIANTS:-} > $O/ab_ntt.txt 2>&1; cat $O/ab_ntt.txt
 fi
+if [ -n "${PARAM_SETS:-}" ]; then  # the 60-bit parameter sets, production and every variant library
+  (echo "production: $(timeout 300 python bench_tools/param_sets_bench.py 2>&1 | tail -1)"
+   for lib in swift-homomorphic-encryption_amd/lib/variants/libhe_amd_*.so; do
+     [ -e "$lib" ] && echo "$(basename $lib .so | sed s/libhe_amd_//): $(HEAMD_LIBRARY=$PWD/$lib timeout 300 python bench_tools/param_sets_bench.py 2>&1 | tail -1)"
+   done) > $O/param_sets.txt; cat $O/param_sets.txt
+fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -- python bench_tools/c3_profile_target.py > $O/c3_stats.log 2>&1
 f=$(find $O/c3_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/c3_kernel_stats.csv; python bench_tools/kernel_stats_summary.py $O/c3_kernel_stats.csv | head -16
 rm -rf $O/c3_stats

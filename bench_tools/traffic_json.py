@@ -29,7 +29,7 @@ def bytes_per_dispatch(report, needle, exclude=()):
 
 def main():
     ntt_dir, c3_dir, c4_dir, c5_dir, out = sys.argv[1:6]
-    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r03_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
+    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r04_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
     result = {}
     ntt = load(ntt_dir)
     forward, names = bytes_per_dispatch(ntt, "ntt_forward_tiled")

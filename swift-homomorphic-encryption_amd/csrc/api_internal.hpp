@@ -80,10 +80,12 @@ ExpandPlanCache& expand_plans(const he_bfv_context* ctx);
 
 // bfv_api.cpp: one PirUtil.expand level through the fused Galois key switch (not exported)
 constexpr int kExpandStepUnavailable = -1;
+// `rotated`: what the key switch rotates when it is not the parents themselves -- the parents already taken through the
+// level's element all but one time (a level whose element is reached by repeated application); nullptr: the parents.
 int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* parents, uint64_t element,
                           const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* next, uint32_t shift,
                           const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
-                          hipStream_t stream);
+                          hipStream_t stream, const uint64_t* rotated = nullptr);
 
 // Stream-ordered scratch buffer (scratch_allocate / hipFreeAsync on the same stream).
 class Scratch {

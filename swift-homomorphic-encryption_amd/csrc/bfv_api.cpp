@@ -325,10 +325,11 @@ uint32_t inverse_mod_power_of_two(uint64_t g, uint64_t modulus) {
 // decomposition's transform loads its rows, that of c0 as the last kernel adds it to the update; expand_shift != 0
 // turns that last kernel into one step of PirUtil.expand (rns_kernels.hpp, launch_galois_finish).  One key per group of
 // `group_size` consecutive ciphertexts.  hipErrorNotSupported (nothing launched): the degree has no tiled transform.
+// `own` (expand steps): the ciphertexts the children are formed with when they are not `ct` (launch_galois_finish).
 hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* ct, uint32_t galois_inverse,
                                const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* out,
                                uint32_t expand_shift, const heamd::ExpandTargets& targets, uint64_t* spread, uint64_t* prod,
-                               hipStream_t stream) {
+                               hipStream_t stream, const uint64_t* own = nullptr) {
     const PolyContext* ks_ctx = ctx->impl->key_switching(L);
     const DeviceContext ks = ks_ctx->device_context();
     const size_t n = ctx->impl->degree(), batch = groups * group_size, ct_stride = 2 * size_t(L) * n;
@@ -344,7 +345,7 @@ hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint
         g += run;
     }
     return heamd::launch_galois_finish(static_cast<const uint64_t*>(prod), ct, ct_stride, out, ks, L, batch,
-                                       galois_inverse, expand_shift, targets, stream);
+                                       galois_inverse, expand_shift, targets, stream, own);
 }
 
 template <typename W>
@@ -375,15 +376,16 @@ namespace heamd {
 int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t* parents, uint64_t element,
                           const uint64_t* const* keys, size_t groups, size_t group_size, uint64_t* next, uint32_t shift,
                           const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
-                          hipStream_t stream) {
+                          hipStream_t stream, const uint64_t* rotated) {
     const size_t n = ctx->impl->degree(), batch = groups * group_size;
     if (batch == 0) return HE_OK;
     if (workspace_bytes < he_bfv_apply_galois_workspace_bytes(ctx, L, batch)) return invalid_argument("workspace too small");
     uint64_t* spread = static_cast<uint64_t*>(workspace);    // [batch][L][L+1][N]
     uint64_t* prod = spread + batch * L * (L + 1) * n;       // [batch][2][L+1][N]
-    const hipError_t e = galois_switch_fused(ctx, L, parents, inverse_mod_power_of_two(element, 2 * n), keys, groups,
-                                             group_size, next, shift, heamd::ExpandTargets{leaf_table, group_size, leaf_stride},
-                                             spread, prod, stream);
+    const hipError_t e = galois_switch_fused(ctx, L, rotated != nullptr ? rotated : parents,
+                                             inverse_mod_power_of_two(element, 2 * n), keys, groups, group_size, next, shift,
+                                             heamd::ExpandTargets{leaf_table, group_size, leaf_stride}, spread, prod, stream,
+                                             rotated != nullptr ? parents : nullptr);
     if (e == hipErrorNotSupported) {
         (void)hipGetLastError();
         return kExpandStepUnavailable;

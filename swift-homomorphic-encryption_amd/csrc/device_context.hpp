@@ -67,9 +67,6 @@ struct DeviceContext {
     // bit i: modulus i takes the fold butterflies (ntt_common.hpp kModeFoldMinus / kModeFoldPlus): 2^b - d with
     // 56 <= b <= 60 and d < 2^(b-33), or 2^60 + e with e < 2^24
     uint64_t fold_minus_mask, fold_plus_mask;
-    // bit i: floor(q_last / 2) < q_i for the LAST active modulus q_last -- the centred representative of a q_last word
-    // needs no reduction mod q_i (what the fused end of the key switch assumes, ntt_kernels.hip kInverseFromKeyMacFinish)
-    uint64_t narrow_special_mask;
     uint32_t scaled_inverse_degree;  // 1 when `moduli` is a table whose N^-1 constants carry another factor
                                      // (kNttScaledInverseDegree): the inverse transform must not divide by N exactly
 };

@@ -328,11 +328,13 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     if constexpr (SPREAD != kSourceSlab && SPREAD != kSourceRows) {
         // the band_rows output rows of a record are transforms of one source row: one replica set per group of ROWS
         // consecutive records (a workgroup transforms the same band row of each of them)
+        // (a launch may cover a band of the records' rows -- the moduli of one butterfly class, launch_ntt_spread)
         uint32_t group;
         locate_replica(blockIdx.x, gridDim.x / map.band_rows, map.band_rows, group, within);
         record = map.record_base + group * ROWS;
+        const size_t record_rows = map.record_rows == 0 ? map.band_rows : map.record_rows;
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) rows[k] = size_t(record + k) * map.band_rows + within;
+        for (int k = 0; k < ROWS; ++k) rows[k] = size_t(record + k) * record_rows + map.band_offset + within;
     } else {
         locate_rows<ROWS>(map, blockIdx.x, rows, record, within);
     }
@@ -452,10 +454,14 @@ constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac =
               kInverseFromKeyMacFinish = 4;
 constexpr bool is_key_mac(int source) { return source == kInverseFromKeyMac || source == kInverseFromKeyMacFinish; }
 constexpr bool kKeyMacBoundedReduce = true;
-// (Measured and dropped, profiles/r04a_keymac_pairing_ab.txt: a workgroup that takes the two key COLUMNS of one polynomial
-// instead of the same column of two consecutive polynomials reads every spread word once -- but its sums are per word,
-// i.e. 8-byte loads at a 16-byte lane stride, twice the load instructions for the same bytes: relinearize 684 -> 614 k/s.
-// The spread slab's re-reads were never what bound the kernel.)
+// Which two rows a key-MAC workgroup takes where the register file holds two: the same key column of two consecutive
+// polynomials, the other column in a sibling workgroup of the same XCD.  The counters read 1.7 x the spread slab for this
+// kernel (profiles/r03z_pmc_traffic_per_kernel.txt), which suggested pairing the two COLUMNS of one polynomial instead
+// (every spread word fetched once).  Measured both ways and dropped: with per-word sums (8-byte loads at a 16-byte lane
+// stride, twice the load instructions) relinearize 684 -> 614 k/s (profiles/r04a_keymac_pairing_ab.txt); with the two
+// columns summed one after the other through the same 16-byte loads 723 -> 708 k/s
+// (profiles/r04c_keymac_columns_in_turn_ab.txt).  The slab's re-reads come out of L2 / the memory-side cache; they are not
+// what binds the kernel.
 struct InverseSource {
     const uint64_t* first;   // tensor: the lifted polynomials; key MAC: the spread slab
     const uint64_t* second;  // key MAC: the key
@@ -622,11 +628,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
         if constexpr (FINISH) {
             // key_switch_finish_kernel's arithmetic (rns_kernels.hip) on each row as its last pass completes: with x_ks the
             // q_ks word of the coefficient and c its centred representative, out = (x - c) q_ks^-1 mod q_r (+ the ciphertext
-            // word).  (The launcher only takes this path when q_ks / 2 is below every q_r: |c| needs no reduction mod q_r.)
+            // word).  |c| <= q_ks / 2 needs a reduction mod q_r only where q_r is the smaller one (`wide`, wave-uniform: the
+            // 29-bit modulus next to the 60-bit ones of the reference's n_8192_logq_29_60_60); the word loop exists in both
+            // forms.
             const uint32_t L = source_spec.L, r = map.band_offset + within;
             const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
             const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
             const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(tid) << 3;
+            const bool wide = half >= p;
             auto finish = [&](int k, uint64_t (&row)[E]) {
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
@@ -639,29 +648,34 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 const BufferResource added_row =
                     add ? make_resource(source_spec.ct_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN)
                         : last_row;
+                auto words_of_row = [&](auto reduce_magnitude) {
 #pragma unroll
-                for (int base = 0; base < E; base += CHUNK) {
-                    uint64_t last[CHUNK], added[CHUNK];
+                    for (int base = 0; base < E; base += CHUNK) {
+                        uint64_t last[CHUNK], added[CHUNK];
 #pragma unroll
-                    for (int e = 0; e < CHUNK; ++e) {
-                        const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
-                        last[e] = word(__builtin_amdgcn_raw_buffer_load_b64(last_row, lane_bytes, at, row_load_policy<LOGN>()));
-                        added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
+                        for (int e = 0; e < CHUNK; ++e) {
+                            const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
+                            last[e] = word(__builtin_amdgcn_raw_buffer_load_b64(last_row, lane_bytes, at, row_load_policy<LOGN>()));
+                            added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
+                        }
+#pragma unroll
+                        for (int e = 0; e < CHUNK; ++e) {
+                            const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
+                            // straight-line: x - c = x + (c < 0 ? |c| : p - |c|) mod p, an absent addend is zero
+                            const uint64_t shifted = add_mod_uniform(last[e], half, q_last);
+                            const bool negative = shifted < half;
+                            uint64_t t = negative ? half - shifted : shifted - half;
+                            if constexpr (decltype(reduce_magnitude)::value) t = barrett_reduce64_uniform(t, p, mod.barrett64);
+                            const uint64_t difference = csub_uniform(row[base + e] + (negative ? t : p - t), p);
+                            const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, p);
+                            const uint64_t result = csub_uniform((add ? added[e] : 0) + update, p);
+                            const Dwordx2 words = {lo32(result), hi32(result)};
+                            __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
+                        }
                     }
-#pragma unroll
-                    for (int e = 0; e < CHUNK; ++e) {
-                        const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
-                        // straight-line: x - c = x + (c < 0 ? |c| : p - |c|) mod p, an absent addend is zero
-                        const uint64_t shifted = add_mod_uniform(last[e], half, q_last);
-                        const bool negative = shifted < half;
-                        const uint64_t t = negative ? half - shifted : shifted - half;
-                        const uint64_t difference = csub_uniform(row[base + e] + (negative ? t : p - t), p);
-                        const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, p);
-                        const uint64_t result = csub_uniform((add ? added[e] : 0) + update, p);
-                        const Dwordx2 words = {lo32(result), hi32(result)};
-                        __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
-                    }
-                }
+                };
+                if (wide) words_of_row(std::true_type{});
+                else words_of_row(std::false_type{});
             };
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
@@ -1054,7 +1068,7 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
         if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
             kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
     }
-    if constexpr (kFoldShape<LOGN, LOGT> && SPREAD == kSourceSlab) {
+    if constexpr (kFoldShape<LOGN, LOGT> && (SPREAD == kSourceSlab || SPREAD == kSourceSpread)) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
             const int fold = fold_mode(ctx, map.mod_base, map.band_rows);
             if (fold == kModeFoldMinus) kernel = ntt_forward_tiled<LOGN, LOGT, kModeFoldMinus, SPREAD, ROWS>;
@@ -1101,7 +1115,7 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
         if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
             kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
     }
-    if constexpr (kFoldShape<LOGN, LOGT> && !is_key_mac(SOURCE)) {
+    if constexpr (kFoldShape<LOGN, LOGT>) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
             const int fold = fold_mode(ctx, map.mod_base, map.band_rows);
             if (fold == kModeFoldMinus) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeFoldMinus, SOURCE, ROWS>;
@@ -1223,6 +1237,41 @@ int production_mode(const DeviceContext& ctx) {
 
 }  // namespace
 
+// The rows of a record (row r uses modulus r) as runs of moduli of one butterfly class -- the fold-free limb-wise
+// butterflies (the leading moduli in [2^40, 2^55)), the fold butterflies of either form, the [0, 8p) ones: one launch per
+// run over that row band of every record.  BEHZ's [Q, Bsk] records with the usual 55-bit ciphertext moduli are two runs
+// (Q | Bsk); with the reference's 60-bit parameter sets, e.g. 29 | 60, 60 | Bsk.  0 runs: the context takes one mode as a
+// whole (a modulus above 2^61: exact butterflies) or has no tables for a split.
+struct BandRun {
+    uint32_t base, rows;
+    int mode;  // what launch_ntt_band is given: kModeSplit or kModeApprox (a fold form is resolved from the band's moduli)
+};
+constexpr int kMaxBandRuns = 8;
+inline int band_runs(const DeviceContext& ctx, uint32_t record_rows, BandRun (&runs)[kMaxBandRuns]) {
+    if (ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr || record_rows == 0 || record_rows > 64) return 0;
+    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
+    auto row_class = [&](uint32_t r) {
+        if (r < prefix) return 0;
+        if (((ctx.fold_minus_mask >> r) & 1) != 0) return 1;
+        if (((ctx.fold_plus_mask >> r) & 1) != 0) return 2;
+        return 3;
+    };
+    int count = 0;
+    for (uint32_t r = 0; r < record_rows;) {
+        const int cls = row_class(r);
+        uint32_t end = r + 1;
+        while (end < record_rows && row_class(end) == cls) ++end;
+        if (count == kMaxBandRuns) return 0;  // a context this fragmented takes one launch in the common mode
+        runs[count++] = BandRun{r, end - r, cls == 0 ? kModeSplit : kModeApprox};
+        r = end;
+    }
+    return count;
+}
+
+// a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way: one
+// launch in the mode that serves every modulus costs one kernel latency instead of two
+constexpr size_t kOneGeneration = 512;
+
 hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_t source_moduli, size_t polys,
                              uint64_t* spread, const DeviceContext& ks_ctx, uint32_t galois_inverse, hipStream_t stream) {
     const uint32_t period = source_moduli + 1;
@@ -1230,13 +1279,25 @@ hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_
     if (rows == 0) return hipSuccess;
     if (rows > (size_t(1) << 30) || ks_ctx.moduli_count < period) return hipErrorInvalidValue;
     const SpreadSource src{source, poly_stride, source_moduli, 0, galois_inverse};
-    const int mode = production_mode(ks_ctx);
-    switch (ks_ctx.log_degree) {
-        case 12: return launch_forward_tiled<12, 9, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
-        case 13: return launch_forward_tiled<13, 10, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
-        case 14: return launch_forward_tiled<14, 10, kSourceSpread>(mode, spread, ks_ctx, 0, period, rows, src, stream);
-        default: return hipErrorNotSupported;  // caller falls back to spread kernel + launch_ntt
-    }
+    // One launch per run of key-switching moduli of one butterfly class (band_runs: e.g. 29 | 60, 60 for the reference's
+    // n_8192_logq_29_60_60, whose 60-bit rows then take the fold butterflies); the usual contexts -- every modulus in
+    // [2^40, 2^55) -- are one run, and a batch of one workgroup generation takes one launch either way.
+    auto launch = [&](int mode, uint32_t base, uint32_t band) {
+        const size_t band_total = polys * source_moduli * band;
+        const uint32_t row_period = band == period ? 0 : period;
+        switch (ks_ctx.log_degree) {
+            case 12: return launch_forward_tiled<12, 9, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
+            case 13: return launch_forward_tiled<13, 10, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
+            case 14: return launch_forward_tiled<14, 10, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
+            default: return hipErrorNotSupported;  // caller falls back to spread kernel + launch_ntt
+        }
+    };
+    BandRun runs[kMaxBandRuns];
+    const int count = (ks_ctx.log_degree == 12 || ks_ctx.log_degree == 13) && rows > kOneGeneration ? band_runs(ks_ctx, period, runs) : 0;
+    if (count <= 1) return launch(production_mode(ks_ctx), 0, period);
+    for (int k = 0; k < count; ++k)
+        if (hipError_t e = launch(runs[k].mode, runs[k].base, runs[k].rows); e != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulus, size_t polys, uint64_t* out,
@@ -1282,41 +1343,6 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
         default: return hipErrorNotSupported;
     }
 }
-
-// The rows of a record (row r uses modulus r) as runs of moduli of one butterfly class -- the fold-free limb-wise
-// butterflies (the leading moduli in [2^40, 2^55)), the fold butterflies of either form, the [0, 8p) ones: one launch per
-// run over that row band of every record.  BEHZ's [Q, Bsk] records with the usual 55-bit ciphertext moduli are two runs
-// (Q | Bsk); with the reference's 60-bit parameter sets, e.g. 29 | 60, 60 | Bsk.  0 runs: the context takes one mode as a
-// whole (a modulus above 2^61: exact butterflies) or has no tables for a split.
-struct BandRun {
-    uint32_t base, rows;
-    int mode;  // what launch_ntt_band is given: kModeSplit or kModeApprox (a fold form is resolved from the band's moduli)
-};
-constexpr int kMaxBandRuns = 8;
-inline int band_runs(const DeviceContext& ctx, uint32_t record_rows, BandRun (&runs)[kMaxBandRuns]) {
-    if (ctx.approx_ok == 0 || ctx.forward_split_pairs == nullptr || record_rows == 0 || record_rows > 64) return 0;
-    const uint32_t prefix = ctx.headroom_prefix < record_rows ? ctx.headroom_prefix : record_rows;
-    auto row_class = [&](uint32_t r) {
-        if (r < prefix) return 0;
-        if (((ctx.fold_minus_mask >> r) & 1) != 0) return 1;
-        if (((ctx.fold_plus_mask >> r) & 1) != 0) return 2;
-        return 3;
-    };
-    int count = 0;
-    for (uint32_t r = 0; r < record_rows;) {
-        const int cls = row_class(r);
-        uint32_t end = r + 1;
-        while (end < record_rows && row_class(end) == cls) ++end;
-        if (count == kMaxBandRuns) return 0;  // a context this fragmented takes one launch in the common mode
-        runs[count++] = BandRun{r, end - r, cls == 0 ? kModeSplit : kModeApprox};
-        r = end;
-    }
-    return count;
-}
-
-// a handful of rows (one ciphertext's worth: the tail of a PIR response) is one workgroup generation either way: one
-// launch in the mode that serves every modulus costs one kernel latency instead of two
-constexpr size_t kOneGeneration = 512;
 
 // [Q, Bsk] records (BEHZ): the first `headroom_prefix` moduli (the ciphertext moduli, when they are the usual <= 55-bit
 // primes) take the fold-free split butterflies, the 61-bit Bsk primes the [0, 8p) ones -- two launches over row bands of
@@ -1390,14 +1416,33 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
 
 // Key-switching inner product + inverse NTT in one kernel (Bfv+Keys.swift:180-207): spread [polys][L][L+1][N] (Eval),
 // key [top][2][top_rows][N] -> out [polys][2][L+1][N] (Coeff).  hipErrorNotSupported where no tiled kernel exists.
+// The rows [first, first + count) of every (polynomial, c) record of the key-switching product, one launch per run of
+// moduli of one butterfly class inside that range (band_runs over the whole key-switching context, clipped).
+hipError_t launch_key_mac_runs(uint64_t* prod, const DeviceContext& ks, uint32_t first, uint32_t count, uint32_t L,
+                               size_t records, int source, const InverseSource& spec, hipStream_t stream) {
+    BandRun runs[kMaxBandRuns];
+    const bool fold_shape = ks.log_degree == 12 || ks.log_degree == 13;
+    const int run_count = fold_shape && records * count > kOneGeneration ? band_runs(ks, L + 1, runs) : 0;
+    if (run_count <= 1)
+        return launch_ntt_band(true, prod, ks, first, count, L + 1, first, records, production_mode(ks), stream, source, spec);
+    for (int k = 0; k < run_count; ++k) {
+        const uint32_t begin = runs[k].base > first ? runs[k].base : first;
+        const uint32_t end = runs[k].base + runs[k].rows < first + count ? runs[k].base + runs[k].rows : first + count;
+        if (begin >= end) continue;
+        hipError_t e = launch_ntt_band(true, prod, ks, begin, end - begin, L + 1, begin, records, runs[k].mode, stream, source, spec);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
     const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;
     const size_t records = polys * 2;
     if (!tiled || L > 64 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
-    return launch_ntt_band(true, out, ks, 0, L + 1, L + 1, 0, records, production_mode(ks), stream, kInverseFromKeyMac,
-                           InverseSource{spread, key, L, top_rows, nullptr, 0, nullptr, 0});
+    return launch_key_mac_runs(out, ks, 0, L + 1, L, records, kInverseFromKeyMac,
+                               InverseSource{spread, key, L, top_rows, nullptr, 0, nullptr, 0}, stream);
 }
 
 // The same with the key switch's last step applied as the rows r < L are stored (kInverseFromKeyMacFinish): first the q_ks
@@ -1407,10 +1452,7 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
 // no kernel that pairs the key columns; the caller then runs launch_ntt_key_mac_inverse + launch_key_switch_finish.
 bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys) {
     const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;  // the degrees with a fused key-MAC transform
-    // bit r of narrow_special_mask: q_ks / 2 < q_r, i.e. the centred q_ks word needs no reduction mod q_r
-    const uint64_t band = L >= 64 ? ~uint64_t(0) : (uint64_t(1) << L) - 1;
-    return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && (ks.narrow_special_mask & band) == band &&
-           polys * 2 * (L + 1) <= (size_t(1) << 30);
+    return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && polys * 2 * (L + 1) <= (size_t(1) << 30);
 }
 hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,
                                              const uint64_t* ct_base, size_t ct_stride, uint64_t* out, const DeviceContext& ks,
@@ -1419,10 +1461,9 @@ hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint6
     if (!ntt_key_mac_finish_supported(ks, L, polys)) return hipErrorNotSupported;
     if (polys == 0) return hipSuccess;
     const InverseSource spec{spread, key, L, top_rows, ct_base, ct_stride, out, added_polys};
-    const int mode = production_mode(ks);
-    hipError_t e = launch_ntt_band(true, prod, ks, L, 1, L + 1, L, polys * 2, mode, stream, kInverseFromKeyMac, spec);
+    hipError_t e = launch_key_mac_runs(prod, ks, L, 1, L, polys * 2, kInverseFromKeyMac, spec, stream);
     if (e != hipSuccess) return e;
-    return launch_ntt_band(true, prod, ks, 0, L, L + 1, 0, polys * 2, mode, stream, kInverseFromKeyMacFinish, spec);
+    return launch_key_mac_runs(prod, ks, 0, L, L, polys * 2, kInverseFromKeyMacFinish, spec, stream);
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,

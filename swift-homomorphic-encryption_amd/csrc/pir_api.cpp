@@ -673,37 +673,49 @@ extern "C" int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint6
         // children: c1 + ciphertext and (ciphertext - c1) x^(-2^(logStep-1)), interleaved as the plan numbered them
         const uint32_t shift = static_cast<uint32_t>(2 * n - (size_t(1) << (log_step - 1)));
         uint64_t* next = buffers[depth % 2];
-        if (applications == 1) {  // the element has its own key: the children leave the key switch directly
-            // ... and when all of them are leaves, for their output slots (the next level's leaf table is in node order)
-            const bool to_outputs = depth + 1 < moves.size() && moves[depth + 1].parent_count == 0 &&
-                                    moves[depth + 1].leaf_count == 2 * batch;
-            status = heamd::bfv_expand_step_fused(
-                ctx, L, parents, element, level_keys.data(), queries, batch, to_outputs ? out : next, shift,
-                to_outputs ? table_device + moves[depth + 1].leaf_offset : nullptr, output_count, workspace_mem.get(),
-                workspace_bytes, stream);
-            if (status == HE_OK) {
-                if (to_outputs) break;  // nothing below this level
-                cur = next;
-                continue;
-            }
-            if (status != heamd::kExpandStepUnavailable) break;
-            status = HE_OK;
-        }
-        if (rotated == nullptr) {
+        // The children leave the LAST application's key switch directly (the element has its own key: the only one) -- and
+        // when all of them are leaves, for their output slots (the next level's leaf table is in node order).  With
+        // repeated application (keyCompression configurations, PirUtil.swift:221-231) the applications before the last
+        // one are plain Galois key switches of the parents; the last one rotates their result and forms the children
+        // with the parents themselves.
+        const bool to_outputs = depth + 1 < moves.size() && moves[depth + 1].parent_count == 0 &&
+                                moves[depth + 1].leaf_count == 2 * batch;
+        if (applications > 1 && rotated == nullptr) {
             HEAMD_HIP_TRY(rotated_mem.allocate(queries * most_parents * ct_bytes));
             HEAMD_HIP_TRY(tmp_mem.allocate(queries * most_parents * ct_bytes));
             rotated = static_cast<uint64_t*>(rotated_mem.get());
             tmp = static_cast<uint64_t*>(tmp_mem.get());
         }
         const uint64_t* c1 = parents;
-        for (int a = 0; a < applications && status == HE_OK; ++a) {  // applyGalois(element) until x -> x^target
+        for (int a = 0; a + 1 < applications && status == HE_OK; ++a) {  // applyGalois(element), all but the last time
             uint64_t* dst = (a % 2 == 0) ? rotated : tmp;
             status = he_bfv_apply_galois_grouped_device(ctx, L, c1, element, level_keys.data(), queries, batch, dst,
                                                         workspace_mem.get(), workspace_bytes, s);
             c1 = dst;
         }
         if (status != HE_OK) break;
-        HEAMD_HIP_TRY(heamd::launch_expand_step(parents, c1, next, q_device, shift, queries * batch, stream));
+        status = heamd::bfv_expand_step_fused(
+            ctx, L, parents, element, level_keys.data(), queries, batch, to_outputs ? out : next, shift,
+            to_outputs ? table_device + moves[depth + 1].leaf_offset : nullptr, output_count, workspace_mem.get(),
+            workspace_bytes, stream, c1 == parents ? nullptr : c1);
+        if (status == HE_OK) {
+            if (to_outputs) break;  // nothing below this level
+            cur = next;
+            continue;
+        }
+        if (status != heamd::kExpandStepUnavailable) break;
+        // no fused key switch for this degree: the last application on its own, then the step kernel
+        if (rotated == nullptr) {
+            HEAMD_HIP_TRY(rotated_mem.allocate(queries * most_parents * ct_bytes));
+            HEAMD_HIP_TRY(tmp_mem.allocate(queries * most_parents * ct_bytes));
+            rotated = static_cast<uint64_t*>(rotated_mem.get());
+            tmp = static_cast<uint64_t*>(tmp_mem.get());
+        }
+        uint64_t* last = (c1 == rotated) ? tmp : rotated;
+        status = he_bfv_apply_galois_grouped_device(ctx, L, c1, element, level_keys.data(), queries, batch, last,
+                                                    workspace_mem.get(), workspace_bytes, s);
+        if (status != HE_OK) break;
+        HEAMD_HIP_TRY(heamd::launch_expand_step(parents, last, next, q_device, shift, queries * batch, stream));
         cur = next;
     }
     if (status != HE_OK) return status;

@@ -301,10 +301,9 @@ DeviceContext PolyContext::device_context(uint32_t count) const {
     d.headroom_ok = headroom;
     d.headroom_prefix = prefix;
     d.shift_prefix = shift_prefix;
-    d.fold_minus_mask = d.fold_plus_mask = d.narrow_special_mask = 0;
+    d.fold_minus_mask = d.fold_plus_mask = 0;
     for (uint32_t i = 0; i < count && i < 64; ++i) {
         const u64 p = moduli_[i];
-        if ((moduli_[count - 1] >> 1) < p) d.narrow_special_mask |= static_cast<u64>(1) << i;
         const int bits = 64 - __builtin_clzll(p);
         if (bits >= 56 && bits <= 60 && (static_cast<u64>(1) << bits) - p < (static_cast<u64>(1) << (bits - 33)))
             d.fold_minus_mask |= static_cast<u64>(1) << i;

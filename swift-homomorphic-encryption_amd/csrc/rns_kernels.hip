@@ -529,13 +529,16 @@ __global__ void __launch_bounds__(kThreads)
 // out [2 polys][2][L][N] holds the children ct + c' and (ct - c') x^shift, interleaved; the second one is written
 // where its coefficient lands (k + shift mod 2N, negated past N) instead of being gathered by another kernel.  With
 // `targets` the children are leaves of the expansion and go straight to their output slots (ExpandTargets).
+// `own_base` (kFinishExpand): the ciphertext the children are formed WITH -- ct_base itself when the level's element has
+// its own key; when the element is reached by applying a smaller one several times (PirUtil.swift:221-231), ct_base is
+// the result of the applications before the last one (what this key switch rotates) and own_base the level's parent.
 constexpr int kFinishPlain = 0, kFinishGalois = 1, kFinishExpand = 2;
 template <typename W, int MODE>
 __global__ void __launch_bounds__(kThreads)
     key_switch_finish_kernel(const W* __restrict__ prod, const W* __restrict__ ct_base, size_t ct_stride,
                              W* __restrict__ out, const DeviceContext ks, uint32_t L, size_t polys,
                              uint32_t added_polys, uint32_t galois_inverse, uint32_t expand_shift,
-                             const ExpandTargets targets) {
+                             const ExpandTargets targets, const W* __restrict__ own_base) {
     const uint32_t logn = ks.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = (polys * 2) << logn;
@@ -603,7 +606,7 @@ __global__ void __launch_bounds__(kThreads)
                 if constexpr (MODE == kFinishGalois) {
                     stream_store(dst + row * n, rotated);
                 } else {
-                    const uint64_t own = ct[row * n];
+                    const uint64_t own = own_base[poly * ct_stride + c * L * n + row * n + k];
                     const uint64_t sum = add_mod_uniform(own, rotated, m.p);
                     stream_store(dst + row * n, first_doubled ? add_mod_uniform(sum, sum, m.p) : sum);
                     uint64_t difference = sub_mod_uniform(own, rotated, m.p);
@@ -828,22 +831,23 @@ hipError_t launch_key_switch_finish(const W* prod, const W* ct_base, size_t ct_s
     if (polys == 0) return hipSuccess;
     hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishPlain>), dim3(grid_for((polys * 2) << ks.log_degree)),
                        dim3(kThreads), 0, stream, prod, ct_base, ct_stride, out, ks, L, polys, added_polys, 0u, 0u,
-                       ExpandTargets{nullptr, 1, 0});
+                       ExpandTargets{nullptr, 1, 0}, ct_base);
     return hipGetLastError();
 }
 
 template <typename W>
 hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                 uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
-                                const ExpandTargets& targets, hipStream_t stream) {
+                                const ExpandTargets& targets, hipStream_t stream, const W* own_base) {
     if (polys == 0) return hipSuccess;
     const dim3 grid(grid_for((polys * 2) << ks.log_degree));
     if (expand_shift != 0)
         hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishExpand>), grid, dim3(kThreads), 0, stream, prod, ct_base,
-                           ct_stride, out, ks, L, polys, 1u, galois_inverse, expand_shift, targets);
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, expand_shift, targets,
+                           own_base != nullptr ? own_base : ct_base);
     else
         hipLaunchKernelGGL((key_switch_finish_kernel<W, kFinishGalois>), grid, dim3(kThreads), 0, stream, prod, ct_base,
-                           ct_stride, out, ks, L, polys, 1u, galois_inverse, 0u, ExpandTargets{nullptr, 1, 0});
+                           ct_stride, out, ks, L, polys, 1u, galois_inverse, 0u, ExpandTargets{nullptr, 1, 0}, ct_base);
     return hipGetLastError();
 }
 
@@ -867,7 +871,7 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
     template hipError_t launch_key_switch_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t,       \
                                                     size_t, uint32_t, hipStream_t);                                       \
     template hipError_t launch_galois_finish<W>(const W*, const W*, size_t, W*, const DeviceContext&, uint32_t, size_t,   \
-                                                uint32_t, uint32_t, const ExpandTargets&, hipStream_t);
+                                                uint32_t, uint32_t, const ExpandTargets&, hipStream_t, const W*);
 HEAMD_INSTANTIATE_RNS(uint64_t)
 HEAMD_INSTANTIATE_RNS(uint32_t)
 #undef HEAMD_INSTANTIATE_RNS

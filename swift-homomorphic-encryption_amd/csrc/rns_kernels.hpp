@@ -67,10 +67,12 @@ struct ExpandTargets {
 // The same for Bfv.applyGalois with `ct` the ciphertext BEFORE the automorphism (Bfv.swift:190-196):
 // c' = (galois(ct.c0) + update0, update1), galois_inverse = g^-1 mod 2N.  expand_shift = 0: out [polys][2][L][N] = c';
 // otherwise one PirUtil.expand step (PirUtil.swift:204-236): out [2 polys][2][L][N] = the children
-// ct + c' and (ct - c') x^expand_shift, interleaved.  out must not alias ct.
+// ct + c' and (ct - c') x^expand_shift, interleaved.  out must not alias ct.  own_base (expand steps only; nullptr =
+// ct_base): the ciphertexts the children are formed with when they differ from the ones the key switch rotates -- a level
+// whose element is reached by repeated application (PirUtil.swift:221-231): children own + c' and (own - c') x^shift.
 template <typename W>
 hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_stride, W* out, const DeviceContext& ks,
                                 uint32_t L, size_t polys, uint32_t galois_inverse, uint32_t expand_shift,
-                                const ExpandTargets& targets, hipStream_t stream);
+                                const ExpandTargets& targets, hipStream_t stream, const W* own_base = nullptr);
 
 }  // namespace heamd

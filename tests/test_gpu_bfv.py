@@ -820,3 +820,27 @@ def test_bfv_uint32_packed_slabs_match_oracle(oracle):
     status = heamd.load_library().he_rns_lift_q_to_qbsk_device_u32(wide_ctx.h, wide_ctx.L, zeros.data_ptr(),
                                                                     zeros.data_ptr(), 1, None)
     assert status == 16  # HE_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("degree,bits,batch", [(4096, [29, 60, 60], 96), (4096, [60, 60, 60], 96), (8192, [55, 55, 60], 48),
+                                               (4096, [50, 60, 50], 96), (4096, [55, 55, 55], 97)])
+def test_key_switch_on_runs_of_butterfly_classes(oracle, degree, bits, batch):
+    """relinearize and applyGalois on batches wide enough (more than one workgroup generation of rows) for the
+    key-switching moduli to be launched as runs of one butterfly class each -- the reference's 60-bit parameter sets
+    (29 | 60, 60: the 60-bit rows on the fold butterflies; the centred q_ks word exceeds the 29-bit modulus and is reduced
+    as the key switch ends in the key-MAC transform's store), all-60-bit moduli (one fold run), 55, 55 | 60 (q_ks above
+    both ciphertext moduli) and 50 | 60 | 50 (three classes) -- and an odd batch of the usual 55-bit moduli (the last
+    polynomial goes one row per workgroup).  Word for word against the oracle (Bfv+Keys.swift:123-208, Bfv.swift:174-219)."""
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli, L = q[:-1], len(q) - 1
+    rng = np.random.default_rng(degree + sum(bits))
+    ct3 = _uniform(rng, (batch, 3), moduli, degree)
+    key = _uniform(rng, (L, 2), q, degree)
+    relin = heamd.to_host(ours.relinearize(heamd.to_device(ct3), heamd.to_device(key)))
+    assert np.array_equal(relin, ref.relinearize(ct3, key, threads=16))
+    element = 2 * degree - 1
+    ct = _uniform(rng, (batch, 2), moduli, degree)
+    rotated = heamd.to_host(ours.apply_galois(heamd.to_device(ct), element, heamd.to_device(key)))
+    assert np.array_equal(rotated, ref.apply_galois(ct, element, key))

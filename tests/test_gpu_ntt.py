@@ -50,11 +50,11 @@ def test_ntt_delta_and_zero(kats):
         (256, [60, 62], 4),             # NttTests.swift:193-206
         (1024, [27, 28, 28], 3),
         (2048, [61, 61, 33], 2),
-        (4096, [55, 55], 6),            # BASELINE config 1 shape (tiled kernel, 16 words per lane)
-        (8192, [55, 55, 55, 55], 5),    # BASELINE config 2 shape (tiled kernel, 32 words per lane, approx quotient)
+        (4096, [55, 55], 6),            # BASELINE config 1 shape (tiled kernel: 512 lanes x 8 words, row pairs + an odd row)
+        (8192, [55, 55, 55, 55], 5),    # BASELINE config 2 shape (tiled kernel: 1024 lanes x 8 words, limb-wise butterflies)
         (8192, [62, 61, 60, 33], 3),    # a 62-bit modulus forces the exact-quotient butterflies
-        (16384, [55, 61, 45], 2),       # tiled kernel, 512 lanes
-        (32768, [55, 40], 1),           # generic global-memory kernel
+        (16384, [55, 61, 45], 2),       # two interleaved sub-rows of the 8192-point kernel
+        (32768, [55, 40], 1),           # four interleaved sub-rows of the 8192-point kernel
     ],
 )
 def test_ntt_matches_oracle(oracle, degree, bits, batch):

@@ -116,12 +116,14 @@ def test_pir_expand_matches_oracle_and_decrypts(oracle, small, total, ones, key_
             assert client.decrypt(got[index]) == [1 if index in ones else 0] + [0] * (n - 1), index
 
 
-@pytest.mark.parametrize("total,key_shifts", [(6, None), (13, None), (8, [2])])
+@pytest.mark.parametrize("total,key_shifts", [(6, None), (13, None), (8, [2]), (4, [2]), (5, [2]), (16, [1, 3])])
 def test_pir_expand_fused_levels(oracle, total, key_shifts):
-    """PirUtil.expand on a ring with a tiled transform (N=4096): levels whose Galois element has its own key leave the
-    key switch as children directly (no rotated copy, no separate step kernel); with key_shifts=[2] the first levels
-    reach their element by repeated application and take the composed path.  Uniform words, word-exact against the
-    oracle's recursion; the same for two queries with different keys in one call."""
+    """PirUtil.expand on a ring with a tiled transform (N=4096): the children of a level leave its (last) key switch
+    directly (no rotated copy, no separate step kernel).  With key_shifts=[2] only the element N/4 + 1 has a key: the
+    first levels reach their element by applying it 4 and 2 times (PirUtil.swift:221-231) -- all but the last application
+    are plain Galois key switches, the last one forms the children with the level's parents (and, for total = 4, writes
+    them to their output slots); key_shifts=[1, 3] mixes levels with and without a key of their own.  Uniform words,
+    word-exact against the oracle's recursion; the same for two queries with different keys in one call."""
     degree = 4096
     q = oracle.generate_primes([50, 45, 55], False, degree)
     ours, ref = heamd.BfvContext(degree, 65537, q), oracle.BfvContext(degree, 65537, q)
