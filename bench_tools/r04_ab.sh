@@ -23,3 +23,9 @@ fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -- python bench_tools/c3_profile_target.py > $O/c3_stats.log 2>&1
 f=$(find $O/c3_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/c3_kernel_stats.csv; python bench_tools/kernel_stats_summary.py $O/c3_kernel_stats.csv | head -16
 rm -rf $O/c3_stats
+if [ -n "${TRACE_C5:-}" ]; then  # the timeline of one PIR chunk response: kernels against the gaps between them
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/c5_trace -- python bench_tools/pir_profile_target.py > $O/c5_trace.log 2>&1
+  f=$(find $O/c5_trace -name "*kernel_trace.csv" | head -1)
+  python bench_tools/kernel_gaps.py "$f" inner_product_plain 80 > $O/c5_chunk_timeline.txt 2>&1; tail -45 $O/c5_chunk_timeline.txt
+  rm -rf $O/c5_trace
+fi
