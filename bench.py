@@ -504,8 +504,9 @@ class CtMulWorkload:
         traffic = profile["hbm_bytes_per_unit"] * self.units / t_both / 1e9 if profile else None
         roofline = {
             "bound": "hbm",
-            "kernel": "pipeline of 10 kernels (lift x2, [Q,Bsk] forward NTT x2 bands, tensor + inverse NTT x2 bands, "
-                      "floor, spread + forward NTT, key MAC + inverse NTT, finish); achieved = compulsory bytes / time",
+            "kernel": "pipeline of 10 launches (lift x2, [Q,Bsk] forward NTT x2 bands, tensor + inverse NTT x2 bands, "
+                      "floor, spread + forward NTT, key MAC + inverse NTT of the q_ks row, key MAC + inverse NTT of the "
+                      "other rows with the key switch's end in its store); achieved = compulsory bytes / time",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
