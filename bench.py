@@ -403,6 +403,10 @@ class NttWorkload:
             "frac_of_copy_rate": achieved / copy_gbps,
             "frac_of_6.29TBps": achieved / HBM_COPY_GBPS,  # against the guide's measured streaming-copy rate
             "under_load": load_state,  # rocm-smi while the kernel runs back to back: it sits at the power cap
+            # what the cap means for this kernel, measured once with bench_tools/power_probe.py: its butterflies alone
+            # (registers only) and its slab's copy alone spend 0.360 J + 0.343 J per launch at 1 225 W / 875 W; the
+            # transform spends 0.683 J at the 1 400 W cap -- time follows energy, not the slower of the two halves
+            "power_bound": "profiles/r04f_power_probe.txt",
         }
         extras = {
             "forward_poly_ntt_per_s": polys / forward_s,
