@@ -516,6 +516,7 @@ class CtMulWorkload:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_frac": traffic / HBM_PEAK_GBPS if traffic else None,  # what the pipeline really moves, against the peak
             "traffic_bytes_per_unit": (profile or {}).get("hbm_bytes_per_unit"),
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_unit": self.COMPULSORY,
