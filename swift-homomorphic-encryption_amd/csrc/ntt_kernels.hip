@@ -147,9 +147,14 @@ constexpr bool kTopPartialOrder = LOGN == 13 && LOGE == 3 && INVERSE && FROM_SLA
 // CANONICAL = false: the words stay in the lazy range of MODE (more stages follow: ntt_forward_interleaved).
 // One forward pass over element bits [LO_TO, LO_TO + LOGE) fed by the exchange out of the layout (LO_FROM, LOGE); its
 // first twiddle is requested before the exchange.
+// kLateLaneAddresses: every step derives its lane addresses (LDS slots, twiddle offsets) from an opaque copy of the lane
+// index, i.e. next to where it uses them -- the compiler otherwise computes all of them at the top of the kernel and
+// carries them through the passes, in scratch where the register file is full.
+constexpr bool kLateLaneAddresses = true;
 template <int LOGN, int LOGE, int LO_FROM, int LO_TO, int MODE, int ROWS>
-__device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw, uint64_t p,
+__device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw, uint64_t p,
                                              uint64_t* lds) {
+    const uint32_t tid = kLateLaneAddresses ? opaque32(lane) : lane;
     const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, false>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, LOGE, LO_TO, LOGE, ROWS>(v, tid, lds);
     forward_pass<LOGN, LOGE, LO_TO, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
@@ -212,8 +217,9 @@ template <int MODE>
 constexpr bool kInverseFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
           int LOGD = LOGN, int FIRST_STAGE = 0>
-__device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+__device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
+    const uint32_t tid = kLateLaneAddresses ? opaque32(lane) : lane;
     TwiddleWords first{0, 0, 0};
     if constexpr (kInverseFirstTwiddleEarly<MODE>)
         first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
@@ -634,9 +640,9 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const uint32_t L = source_spec.L, r = map.band_offset + within;
             const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
             const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
-            const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(tid) << 3;
             const bool wide = half >= p;
             auto finish = [&](int k, uint64_t (&row)[E]) {
+                const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(kLateLaneAddresses ? opaque32(tid) : tid) << 3;
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
                 const size_t pc = record + 2 * k;  // polynomial * 2 + c (the rows are the same column of consecutive polynomials)
@@ -680,9 +686,10 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
+            const uint32_t store_lane = kLateLaneAddresses ? opaque32(tid) : tid;
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
-                global_store<LOGN, LOGE, LOL, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
+                global_store<LOGN, LOGE, LOL, LOGE>(v[k], store_lane, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         }
     }
 }
@@ -899,7 +906,9 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     forward_row<kSubLogN, kSubLogE, MODE, ROWS, false>(v, tid, tw, p, lds);
     forward_cross_stages<LOGS, MODE>(v, tid, tw, p);
     canonicalize_all<MODE>(v, p);
-    if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, true>(v, tid, row, lds);
+    // (the store's lane addresses are derived from an opaque copy of the lane index: the compiler otherwise computes them
+    // at the top of the kernel and carries them through every pass in scratch)
+    if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, true>(v, opaque32(tid), row, lds);
     else interleaved_low_words<LOGS, true>(v, tid, row);
 }
 
