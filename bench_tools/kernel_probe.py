@@ -1,7 +1,9 @@
 """Compile a FEW instantiations of the NTT kernel templates on their own (seconds instead of the minutes the whole
 translation unit takes) and print their register / scratch figures -- the inner loop of register-pressure work.
 
-  python bench_tools/kernel_probe.py [--asm OUT.s] 'ntt_inverse_tiled<13, 10, kModeSplit, kInverseFromKeyMacFinish, 2>' ...
+  python bench_tools/kernel_probe.py [--asm OUT.s] [--mix] 'ntt_inverse_tiled<13, 10, kModeSplit, kInverseFromKeyMacFinish, 2>' ...
+
+--mix also prints each kernel's static instruction mix (opcode counts of its body).
 
 The kernel definitions of csrc/ntt_kernels.hip (everything above the launchers) are copied to a scratch file followed by
 explicit instantiations of the named kernels; nothing is linked into the library.
@@ -24,9 +26,14 @@ SIGNATURES = {
 
 def main():
     args = sys.argv[1:]
-    asm_out = None
-    if args and args[0] == "--asm":
-        asm_out, args = args[1], args[2:]
+    asm_out, mix = None, False
+    while args and args[0].startswith("--"):
+        if args[0] == "--asm":
+            asm_out, args = args[1], args[2:]
+        elif args[0] == "--mix":
+            mix, args = True, args[1:]
+        else:
+            raise SystemExit("unknown option " + args[0])
     source = open(os.path.join(CSRC, "ntt_kernels.hip")).read()
     head = source[:source.index("template <typename Kernel>\nhipError_t allow_dynamic_lds")]
     body = head + "\n".join(f"template __global__ void {k}{SIGNATURES[k.split('<')[0].strip()]};" for k in args)
@@ -47,6 +54,12 @@ def main():
         short = re.sub(r"\(anonymous namespace\)::|heamd::|^void ", "", demangled).split("(")[0]
         print(f"{short:70s} vgpr {get('vgpr_count'):3d}  sgpr {get('sgpr_count'):3d}  scratch {get('private_segment_fixed_size'):4d} B"
               f"  spilled {get('vgpr_spill_count'):2d}")
+        if mix:
+            import collections
+
+            body = re.search(r"^%s:[^\n]*\n(.*?)^\.Lfunc_end\d+:" % re.escape(name), text, re.S | re.M).group(1)
+            ops = collections.Counter(m.group(1) for m in re.finditer(r"^\s+([vs]_\w+|ds_\w+|buffer_\w+|scratch_\w+|global_\w+)", body, re.M))
+            print("   " + "  ".join(f"{o}:{c}" for o, c in ops.most_common(40)))
 
 
 if __name__ == "__main__":
