@@ -154,6 +154,15 @@ __device__ __forceinline__ BufferResource make_resource(const void* base, uint32
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
 }
 
+// The same for an address and a size the compiler cannot PROVE wave-uniform (run-time term counts and row indices that went
+// through vector registers on their way): both are pinned to scalar registers explicitly -- a descriptor in vector
+// registers makes every load a "waterfall" loop over its distinct values.
+__device__ __forceinline__ BufferResource make_uniform_resource(const void* base, uint32_t bytes) {
+    const uint64_t address = reinterpret_cast<uint64_t>(base);
+    const uint64_t pinned = pack64(__builtin_amdgcn_readfirstlane(lo32(address)), __builtin_amdgcn_readfirstlane(hi32(address)));
+    return make_resource(reinterpret_cast<const void*>(pinned), __builtin_amdgcn_readfirstlane(bytes));
+}
+
 // The tables one residue row's butterflies read.  Exact / approx: `pairs` = (w, floor(w 2^64 / p)).
 // Split: `pairs` = (w, w 2^32 mod p), `factors` = floor(w 2^32 / 2p) | floor((w 2^32 mod p) 2^32 / 2p) << 32.
 template <int MODE>

@@ -464,8 +464,9 @@ constexpr bool kKeyMacBoundedReduce = true;
 // polynomials, the other column in a sibling workgroup of the same XCD.  The counters read 1.7 x the spread slab for this
 // kernel (profiles/r03z_pmc_traffic_per_kernel.txt), which suggested pairing the two COLUMNS of one polynomial instead
 // (every spread word fetched once).  Measured both ways and dropped: with per-word sums (8-byte loads at a 16-byte lane
-// stride, twice the load instructions) relinearize 684 -> 614 k/s (profiles/r04a_keymac_pairing_ab.txt); with the two
-// columns summed one after the other through the same 16-byte loads 723 -> 708 k/s
+// stride, twice the load instructions) relinearize 727 -> 671 k/s (profiles/r04j_keymac_loads_and_column_words_ab.txt,
+// bench_tools/variants/keymac_column_words.py); with the two columns summed one after the other through the same 16-byte
+// loads 723 -> 708 k/s
 // (profiles/r04c_keymac_columns_in_turn_ab.txt).  The slab's re-reads come out of L2 / the memory-side cache; they are not
 // what binds the kernel.
 struct InverseSource {
@@ -580,29 +581,34 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
             const uint32_t r = map.band_offset + within;
             const uint32_t key_row = (r == L) ? top_rows - 1 : r;  // Bfv+Keys.swift:153
+            // (flat 64-bit addresses: the same loads through scalar buffer descriptors with a scalar offset per term --
+            // no address arithmetic on the vector ALU -- measured 1.4 % slower, profiles/r04j_keymac_loads_and_column_words_ab.txt)
             const uint32_t lane_words = lane_part<LOGN, LOGE, 0, LOW>(tid);
-            const uint64_t* const key_rows =
-                source_spec.second + ((c * top_rows + key_row) << LOGN) + lane_words;           // + j 2 top_rows N
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
-                const uint64_t* const spread_row =
-                    source_spec.first + (((first_poly + k) * L * (L + 1) + r) << LOGN) + lane_words;  // + j (L+1) N
 #pragma unroll
                 for (int q = 0; q < E; q += 2) {
-                    const size_t at = register_part<LOGN, LOGE, 0, LOW>(q);
+                    const uint32_t at = register_part<LOGN, LOGE, 0, LOW>(q);
                     // the words of term j + 1 are requested before term j is accumulated (the count L is a run-time
                     // value: the loop is not unrolled, and without the request ahead every term would wait out its own
                     // L2 round trip); past the last term the request repeats it -- a load behind a branch would drain
                     // the queue
-                    U64x2 xs = *reinterpret_cast<const U64x2*>(spread_row + at);
-                    U64x2 ks = *reinterpret_cast<const U64x2*>(key_rows + at);
+                    const uint64_t* const flat_spread =
+                        source_spec.first + (((first_poly + k) * L * (L + 1) + r) << LOGN) + lane_words + at;  // + j (L+1) N
+                    const uint64_t* const flat_key =
+                        source_spec.second + ((c * top_rows + key_row) << LOGN) + lane_words + at;          // + j 2 top_rows N
+                    U64x2 xs = *reinterpret_cast<const U64x2*>(flat_spread);
+                    U64x2 ks = *reinterpret_cast<const U64x2*>(flat_key);
                     ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
                     for (uint32_t j = 0; j < L; ++j) {
                         const uint32_t ahead = j + 1 < L ? j + 1 : j;
-                        const U64x2 xn = *reinterpret_cast<const U64x2*>(spread_row + ((size_t(ahead) * (L + 1)) << LOGN) + at);
-                        const U64x2 kn = *reinterpret_cast<const U64x2*>(key_rows + ((size_t(ahead) * 2 * top_rows) << LOGN) + at);
-                        product_sum_add(acc0, xs.x, ks.x);
-                        product_sum_add(acc1, xs.y, ks.y);
+                        const U64x2 xn = *reinterpret_cast<const U64x2*>(flat_spread + ((size_t(ahead) * (L + 1)) << LOGN));
+                        const U64x2 kn = *reinterpret_cast<const U64x2*>(flat_key + ((size_t(ahead) * 2 * top_rows) << LOGN));
+                        // (limb-wise schedule = every modulus below 2^55: canonical operands keep the middle column of a
+                        // sum from wrapping for 127 products, so its carry counts are not kept -- 5 instructions per
+                        // product instead of 7; L <= 64 terms stay inside kNarrowProductSumCadence)
+                        product_sum_add_one<is_split(MODE)>(acc0, xs.x, ks.x);
+                        product_sum_add_one<is_split(MODE)>(acc1, xs.y, ks.y);
                         xs = xn;
                         ks = kn;
                     }
