@@ -130,15 +130,22 @@ public final class GpuResidentCache: @unchecked Sendable {
         where Scheme.Scalar == UInt64
     {
         let device = try GpuContextCache.currentDevice()
-        let stored = database.plaintexts.indices.filter { database.plaintexts[$0] != nil }
-        var fingerprint: [UInt64] = [UInt64(stored.count)]
-        for position in sampleIndices(count: stored.count) {
-            if let plaintext = database.plaintexts[stored[position]] {
-                fingerprint.append(UInt64(stored[position]))
-                sample(of: plaintext._poly, into: &fingerprint)
+        // a lookup happens on every query: sixteen positions spread over the list, each moved on to the next plaintext that
+        // is not nil (the last one back to the previous) -- never a pass over the whole database
+        let plaintexts = database.plaintexts
+        var fingerprint: [UInt64] = []
+        for position in sampleIndices(count: plaintexts.count) {
+            var index = position
+            while index < plaintexts.count, plaintexts[index] == nil { index += 1 }
+            if index == plaintexts.count {
+                index = position
+                while index > 0, plaintexts[index] == nil { index -= 1 }
             }
+            guard let plaintext = plaintexts[index] else { continue }
+            fingerprint.append(UInt64(index))
+            sample(of: plaintext._poly, into: &fingerprint)
         }
-        return StorageKey(device: device, count: database.plaintexts.count, fingerprint: fingerprint)
+        return StorageKey(device: device, count: plaintexts.count, fingerprint: fingerprint)
     }
 
     /// The resident copy of `database` on the current device, uploaded on first sight.
