@@ -180,7 +180,7 @@ def time_launches(torch, fn, warmups=ROOFLINE_WARMUPS, launches=ROOFLINE_LAUNCHE
     return marks[0].elapsed_time(marks[-1]) * 1e-3 / launches, statistics.median(each), min(each)
 
 
-def clocks_under_load(torch, fn, seconds=6.0):
+def clocks_under_load(torch, fn, seconds=6.0, launches_per_sync=100):
     """Shader clock (MHz) and socket power (W) reported by rocm-smi while fn() runs back to back; None without rocm-smi.
     The NTT kernel runs at the socket power cap, so the clock it gets is part of the measurement."""
     import re
@@ -209,7 +209,7 @@ def clocks_under_load(torch, fn, seconds=6.0):
     thread.start()
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for _ in range(100):
+        for _ in range(launches_per_sync):
             fn()
         torch.cuda.synchronize()
     stop.set()
@@ -522,6 +522,8 @@ class CtMulWorkload:
             "algorithmic_bytes_per_unit": self.COMPULSORY,
             "avg_launch_ms": t_both * 1e3,
         }
+        if rank == 0:  # is the pipeline at the socket's power cap too?  (rocm-smi while it runs back to back)
+            roofline["under_load"] = clocks_under_load(torch, lambda: (mul(), relin()), seconds=3.0, launches_per_sync=4)
         extras = {"ct_mul_per_s": self.units / t_mul, "relinearize_per_s": self.units / t_relin}
         return roofline, extras
 
@@ -581,6 +583,7 @@ class ModSwitchWorkload:
             "algorithmic_bytes_per_launch": self.bytes_per_poly * self.units,
             "avg_launch_ms": t * 1e3,
             "median_launch_ms": t_median * 1e3,
+            "under_load": clocks_under_load(self.torch, self.step, seconds=3.0, launches_per_sync=20) if rank == 0 else None,
         }, {}
 
 
@@ -663,6 +666,7 @@ class PirDim0Workload:
             "algorithmic_bytes_per_launch": self.db_bytes,
             "avg_launch_ms": t * 1e3,
             "database_GBps_per_gpu": achieved,
+            "under_load": clocks_under_load(self.torch, self.step, seconds=3.0, launches_per_sync=4) if rank == 0 else None,
         }, {}
 
 
