@@ -265,9 +265,13 @@ hipError_t key_mac_and_finish(const uint64_t* spread, const uint64_t* key, uint6
     return heamd::launch_ntt_key_mac_inverse_finish(spread, key, prod, ct_base, ct_stride, out, ks_ctx.device_context(), L,
                                                     top_rows, polys, added_polys, stream);
 }
-hipError_t key_mac_and_finish(const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*, size_t, uint32_t*,
-                              const PolyContext&, uint32_t, uint32_t, size_t, uint32_t, hipStream_t) {
-    return hipErrorNotSupported;  // packed 4-byte slabs keep the separate finish kernel
+hipError_t key_mac_and_finish(const uint32_t* spread, const uint32_t* key, uint32_t* prod, const uint32_t* ct_base,
+                              size_t ct_stride, uint32_t* out, const PolyContext& ks_ctx, uint32_t L, uint32_t top_rows,
+                              size_t polys, uint32_t added_polys, hipStream_t stream) {
+    heamd::DeviceContext32 ks32{};
+    if (ks_ctx.device_context32(L + 1, ks32) != HE_OK) return hipErrorNotSupported;
+    return heamd::launch_ntt32_key_mac_inverse_finish(spread, key, prod, ct_base, ct_stride, out, ks32, L, top_rows, polys,
+                                                      added_polys, stream);
 }
 
 // _computeKeySwitchingUpdate (Bfv+Keys.swift:123-208) on polynomial `target` of every item, then

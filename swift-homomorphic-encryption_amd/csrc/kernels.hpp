@@ -133,6 +133,11 @@ hipError_t launch_ntt32_tensor_inverse(const uint32_t* lifted, uint32_t* out, co
 hipError_t launch_ntt32_key_mac_inverse(const uint32_t* spread, const uint32_t* key, uint32_t* out,
                                         const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
                                         hipStream_t stream);
+// ... and the key switch's last step applied as the rows r < L are stored (launch_ntt_key_mac_inverse_finish's 4-byte twin)
+hipError_t launch_ntt32_key_mac_inverse_finish(const uint32_t* spread, const uint32_t* key, uint32_t* prod,
+                                               const uint32_t* ct_base, size_t ct_stride, uint32_t* out,
+                                               const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
+                                               uint32_t added_polys, hipStream_t stream);
 // scalars: device array of L (scalar, 64-bit Shoup factor) pairs, only for MulScalar
 hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t* rhs, const uint64_t* scalars,
                                 const DeviceContext32& ctx, size_t rows, hipStream_t stream);

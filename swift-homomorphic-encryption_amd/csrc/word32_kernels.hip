@@ -292,12 +292,27 @@ __device__ __forceinline__ void row32_load_staged(uint32_t (&v)[1 << LOGE], uint
 //                    source ciphertexts (liftQToQBsk leaves them equal to its input, RnsTool.swift:329-330): polynomial
 //                    slot & 1 of item `item` of `first` (slots 0, 1) or `second` (slots 2, 3), items `stride` words
 //                    apart; the other rows are read from the slab
-constexpr int kSource32Slab = 0, kSource32Spread = 1, kSource32Tensor = 2, kSource32KeyMac = 3, kSource32Rows = 4;
+//   kSource32KeyMacFinish  the same load over the band rows r < L, with the key switch's last step (drop the special
+//                    modulus, add the update to the ciphertext: key_switch_finish_kernel, rns_kernels.hip) applied to the
+//                    transform's canonical words before they are stored -- the 4-byte twin of ntt_kernels.hip
+//                    kInverseFromKeyMacFinish: the q_ks rows come from an earlier launch of kSource32KeyMac over that band
+constexpr int kSource32Slab = 0, kSource32Spread = 1, kSource32Tensor = 2, kSource32KeyMac = 3, kSource32Rows = 4,
+              kSource32KeyMacFinish = 5;
+constexpr bool is_key_mac32(int source) { return source == kSource32KeyMac || source == kSource32KeyMacFinish; }
 struct Source32 {
     const uint32_t* first;
     const uint32_t* second;  // key MAC: the key
     size_t stride;           // spread: words between source polynomials
     uint32_t L, top_rows;    // spread / key MAC: source moduli; key MAC: rows per key polynomial
+    // key MAC: the launch covers the band [band_offset, band_offset + band_rows) of every record's rows (band_rows = 0: all)
+    uint32_t band_offset, band_rows;
+    // kSource32KeyMacFinish: the ciphertexts the update is added to ([item] ct_stride words apart, polynomial c at c L N; the
+    // first `added_polys` polynomials are added, the others replaced) and where the result goes ([item][2][L][N]); the
+    // kernel's slab is the product slab whose q_ks rows are read
+    const uint32_t* ct_base;
+    size_t ct_stride;
+    uint32_t* out;
+    uint32_t added_polys;
 };
 
 template <int LOGN, int LOGT, bool INVERSE, int SOURCE = kSource32Slab>
@@ -313,7 +328,7 @@ __global__ void __launch_bounds__(1 << LOGT)
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const uint32_t tid = threadIdx.x;
     size_t row = blockIdx.x;
-    uint32_t within = 0, set = 0, replica = 0;  // fused sources: row within the record, replica set, member
+    uint32_t within = 0, set = 0, replica = 0, group = 0;  // fused sources: row within the record, replica set, member, record group
     if constexpr (SOURCE == kSource32Slab || SOURCE == kSource32Rows) {
         set = static_cast<uint32_t>(row / mod_period);  // the record
         within = static_cast<uint32_t>(row - size_t(set) * mod_period);
@@ -322,9 +337,10 @@ __global__ void __launch_bounds__(1 << LOGT)
         row = size_t(set) * mod_period + within;
     } else {
         constexpr uint32_t REPLICAS = SOURCE == kSource32Tensor ? 3 : 2;
-        locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, replica);     // set = record group * rows + r
-        const uint32_t group = set / mod_period;
-        within = set - group * mod_period;
+        locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, replica);     // set = record group * band + r
+        const uint32_t band = is_key_mac32(SOURCE) && source.band_rows != 0 ? source.band_rows : mod_period;
+        group = set / band;
+        within = (is_key_mac32(SOURCE) ? source.band_offset : 0u) + (set - group * band);
         row = (size_t(group) * REPLICAS + replica) * mod_period + within;
     }
     const uint32_t mi = mod_base + within;
@@ -390,7 +406,7 @@ __global__ void __launch_bounds__(1 << LOGT)
     } else {
         if constexpr (SOURCE == kSource32Tensor) {
             const size_t poly_words = static_cast<size_t>(mod_period) << LOGN;
-            const uint32_t* const base = source.first + size_t(set / mod_period) * 4 * poly_words + (size_t(within) << LOGN);
+            const uint32_t* const base = source.first + size_t(group) * 4 * poly_words + (size_t(within) << LOGN);
             uint32_t a[E], b[E];
             if (replica != 1) {  // wave-uniform: a0 b0 or a1 b1
                 row32_load<LOGN, LOGE, 0, S::R>(a, tid, base + (replica == 0 ? 0 : 1) * poly_words);
@@ -408,10 +424,10 @@ __global__ void __launch_bounds__(1 << LOGT)
                 for (int r = 0; r < E; ++r)
                     v[r] = static_cast<uint32_t>(barrett_reduce64_uniform(mad32(c[r], d[r], mul32(a[r], b[r])), mod.p, mod.barrett64));
             }
-        } else if constexpr (SOURCE == kSource32KeyMac) {
+        } else if constexpr (is_key_mac32(SOURCE)) {
             const uint32_t L = source.L, top_rows = source.top_rows;
             const uint32_t key_row = within == L ? top_rows - 1 : within;  // Bfv+Keys.swift:153
-            const size_t poly = set / mod_period;
+            const size_t poly = group;
             const uint32_t* spread_row = source.first + ((poly * L * mod_period + within) << LOGN);       // + j (L+1) N
             const uint32_t* key_rows = source.second + ((size_t(replica) * top_rows + key_row) << LOGN);  // + j 2 top_rows N
             uint64_t sum[E];
@@ -468,14 +484,38 @@ __global__ void __launch_bounds__(1 << LOGT)
         constexpr int LOL = LOGN - LOGE;
         tile32_load<LOGN, LOGE, LOL, LOGE>(v, tid, tile);
         inverse_pass32<LOGN, LOGE, LOL, LOGE>(v, tid, tw, mod, false);
-        row32_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
+        if constexpr (SOURCE == kSource32KeyMacFinish) {
+            // with x_ks the q_ks word of the coefficient and c its centred representative: out = (x - c) q_ks^-1 mod q_r
+            // (+ the ciphertext word); |c| is reduced mod q_r where q_ks / 2 is not below it (wave-uniform)
+            const uint32_t L = source.L, r = within;
+            const uint64_t q = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
+            const U64x2 inverse_q_last = ctx.inverse_q_last[size_t(L) * ctx.moduli_stride + r];
+            const size_t pc = size_t(group) * 2 + replica;  // polynomial * 2 + c
+            const bool add = replica < source.added_polys, wide = half >= q;
+            uint32_t last[E], added[E];
+            row32_load<LOGN, LOGE, LOL, LOGE>(last, tid, slab + ((pc * (L + 1) + L) << LOGN));
+            if (add) row32_load<LOGN, LOGE, LOL, LOGE>(added, tid, source.ct_base + size_t(group) * source.ct_stride + ((size_t(replica) * L + r) << LOGN));
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint64_t shifted = add_mod_uniform(last[e], half, q_last);
+                const bool negative = shifted < half;
+                uint64_t t = negative ? half - shifted : shifted - half;
+                if (wide) t = barrett_reduce64_uniform(t, q, mod.barrett64);
+                const uint64_t difference = csub_uniform(uint64_t(v[e]) + (negative ? t : q - t), q);
+                const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, q);
+                v[e] = static_cast<uint32_t>(csub_uniform((add ? uint64_t(added[e]) : 0) + update, q));
+            }
+            row32_store<LOGN, LOGE, LOL, LOGE>(v, tid, source.out + ((pc * L + r) << LOGN));
+        } else {
+            row32_store<LOGN, LOGE, LOL, LOGE>(v, tid, x);
+        }
     }
 }
 
 template <int LOGN, int LOGT, int SOURCE = kSource32Slab>
 hipError_t launch_ntt32_tiled(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base,
                               uint32_t mod_period, size_t rows, hipStream_t stream,
-                              const Source32& source = Source32{nullptr, nullptr, 0, 0, 0}) {
+                              const Source32& source = Source32{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0}) {
     constexpr size_t lds_bytes = tile32_words(1u << LOGN) * sizeof(uint32_t);
     using Kernel = void (*)(uint32_t*, const DeviceContext32, uint32_t, uint32_t, const Source32);
     Kernel kernel;
@@ -571,7 +611,7 @@ hipError_t launch_ntt32_spread(const uint32_t* target, size_t stride, uint32_t L
                                const DeviceContext32& ks_ctx, hipStream_t stream) {
     if (ks_ctx.moduli_count < L + 1) return hipErrorInvalidValue;
     return launch_ntt32_fused<kSource32Spread>(false, spread, ks_ctx, L + 1, polys * L * (L + 1),
-                                               Source32{target, nullptr, stride, L, 0}, stream);
+                                               Source32{target, nullptr, stride, L, 0, 0, 0, nullptr, 0, nullptr, 0}, stream);
 }
 // Forward transform of lifted [items][4][rows][N] records whose rows [0, L) were left unwritten by the lift: they are read
 // from the ciphertext pairs (Bfv+Multiply.swift:51-57)
@@ -580,14 +620,14 @@ hipError_t launch_ntt32_lifted_forward(uint32_t* lifted, const DeviceContext32& 
                                        const uint32_t* lhs, const uint32_t* rhs, size_t stride, uint32_t L,
                                        hipStream_t stream) {
     return launch_ntt32_fused<kSource32Rows>(false, lifted, ctx, record_rows, items * 4 * record_rows,
-                                             Source32{lhs, rhs, stride, L, 0}, stream);
+                                             Source32{lhs, rhs, stride, L, 0, 0, 0, nullptr, 0, nullptr, 0}, stream);
 }
 // Bfv+Multiply.swift:80-82 into the inverse transform's load: lifted [items][4][rows][N] (Eval) -> out [items][3][rows][N]
 // (Coeff; the context carries t N^-1)
 hipError_t launch_ntt32_tensor_inverse(const uint32_t* lifted, uint32_t* out, const DeviceContext32& ctx, uint32_t record_rows,
                                        size_t items, hipStream_t stream) {
     return launch_ntt32_fused<kSource32Tensor>(true, out, ctx, record_rows, items * 3 * record_rows,
-                                               Source32{lifted, nullptr, 0, 0, 0}, stream);
+                                               Source32{lifted, nullptr, 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0}, stream);
 }
 // Bfv+Keys.swift:180-207 into the inverse transform's load: spread [polys][L][L+1][N], key [L][2][top_rows][N] ->
 // out [polys][2][L+1][N] (Coeff)
@@ -596,7 +636,24 @@ hipError_t launch_ntt32_key_mac_inverse(const uint32_t* spread, const uint32_t* 
                                         hipStream_t stream) {
     if (L > 15) return hipErrorNotSupported;  // the sum of L products below 2^60 stays in 64 bits
     return launch_ntt32_fused<kSource32KeyMac>(true, out, ks_ctx, L + 1, polys * 2 * (L + 1),
-                                               Source32{spread, key, 0, L, top_rows}, stream);
+                                               Source32{spread, key, 0, L, top_rows, 0, 0, nullptr, 0, nullptr, 0}, stream);
+}
+// The same with the key switch's last step in the store of the rows r < L (kSource32KeyMacFinish): first the q_ks row of
+// every (polynomial, c) into `prod`, then the other rows, which read it: out [polys][2][L][N].  hipErrorNotSupported
+// (nothing launched) where the degree has no tiled 4-byte transform.
+hipError_t launch_ntt32_key_mac_inverse_finish(const uint32_t* spread, const uint32_t* key, uint32_t* prod,
+                                               const uint32_t* ct_base, size_t ct_stride, uint32_t* out,
+                                               const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
+                                               uint32_t added_polys, hipStream_t stream) {
+    if (L == 0 || L > 15 || ks_ctx.moduli_count != L + 1 || ks_ctx.log_degree < 12 || ks_ctx.log_degree > 14)
+        return hipErrorNotSupported;
+    if (polys == 0) return hipSuccess;
+    hipError_t e = launch_ntt32_fused<kSource32KeyMac>(
+        true, prod, ks_ctx, L + 1, polys * 2, Source32{spread, key, 0, L, top_rows, L, 1, nullptr, 0, nullptr, 0}, stream);
+    if (e != hipSuccess) return e;
+    return launch_ntt32_fused<kSource32KeyMacFinish>(
+        true, prod, ks_ctx, L + 1, polys * 2 * L, Source32{spread, key, 0, L, top_rows, 0, L, ct_base, ct_stride, out, added_polys},
+        stream);
 }
 
 hipError_t launch_ntt32(bool inverse, uint32_t* slab, const DeviceContext32& ctx, uint32_t mod_base, uint32_t mod_period,
