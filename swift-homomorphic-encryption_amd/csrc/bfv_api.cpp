@@ -262,8 +262,9 @@ hipError_t key_mac_to_coeff(const uint32_t* spread, const uint32_t* key, uint32_
 hipError_t key_mac_and_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod, const uint64_t* ct_base,
                               size_t ct_stride, uint64_t* out, const PolyContext& ks_ctx, uint32_t L, uint32_t top_rows,
                               size_t polys, uint32_t added_polys, hipStream_t stream) {
-    return heamd::launch_ntt_key_mac_inverse_finish(spread, key, prod, ct_base, ct_stride, out, ks_ctx.device_context(), L,
-                                                    top_rows, polys, added_polys, stream);
+    const heamd::KeySwitchEnd end{ct_base, ct_stride, out, added_polys};
+    return heamd::launch_ntt_key_mac_inverse_finish(spread, key, prod, end, ks_ctx.device_context(), L, top_rows, polys,
+                                                    stream);
 }
 hipError_t key_mac_and_finish(const uint32_t* spread, const uint32_t* key, uint32_t* prod, const uint32_t* ct_base,
                               size_t ct_stride, uint32_t* out, const PolyContext& ks_ctx, uint32_t L, uint32_t top_rows,
@@ -339,15 +340,42 @@ hipError_t galois_switch_fused(const he_bfv_context* ctx, uint32_t L, const uint
     const size_t n = ctx->impl->degree(), batch = groups * group_size, ct_stride = 2 * size_t(L) * n;
     hipError_t e = heamd::launch_ntt_spread(ct + size_t(L) * n, ct_stride, L, batch, spread, ks, galois_inverse, stream);
     if (e != hipSuccess) return e;
+    // the key switch's end (galois(c0) + update0 | update1, or the two children of an expand step) in the key-MAC
+    // transform's store where the degree has that kernel; the separate finish kernel otherwise
+    // -- decided on the smallest run of queries with one key: every run is two launches of its own there, against one
+    // key-MAC launch per run and ONE finish kernel over the whole batch (profiles/r04m_galois_fused_end_ab.txt)
+    size_t smallest_run = groups;
+    for (size_t g = 0; g < groups;) {
+        size_t run = 1;
+        while (g + run < groups && keys[g + run] == keys[g]) ++run;
+        smallest_run = run < smallest_run ? run : smallest_run;
+        g += run;
+    }
+    const bool fused_end = heamd::ntt_key_mac_finish_supported(ks, L, smallest_run * group_size);
     for (size_t g = 0; g < groups;) {
         size_t run = 1;
         while (g + run < groups && keys[g + run] == keys[g]) ++run;
         const size_t first = g * group_size, polys = run * group_size;
-        e = key_mac_to_coeff(static_cast<const uint64_t*>(spread) + first * L * (L + 1) * n, keys[g],
-                             prod + first * 2 * (L + 1) * n, *ks_ctx, L, ctx->impl->top_level() + 1, polys, stream);
+        const uint64_t* const run_spread = static_cast<const uint64_t*>(spread) + first * L * (L + 1) * n;
+        uint64_t* const run_prod = prod + first * 2 * (L + 1) * n;
+        if (fused_end) {
+            heamd::KeySwitchEnd end{ct, ct_stride, out, 1u};
+            end.galois_inverse = galois_inverse;
+            end.expand_shift = expand_shift;
+            end.own_base = own;
+            end.targets_table = targets.table;
+            end.targets_group_size = targets.group_size;
+            end.targets_group_stride = targets.group_stride;
+            end.poly_base = first;
+            e = heamd::launch_ntt_key_mac_inverse_finish(run_spread, keys[g], run_prod, end, ks, L, ctx->impl->top_level() + 1,
+                                                         polys, stream);
+        } else {
+            e = key_mac_to_coeff(run_spread, keys[g], run_prod, *ks_ctx, L, ctx->impl->top_level() + 1, polys, stream);
+        }
         if (e != hipSuccess) return e;
         g += run;
     }
+    if (fused_end) return hipSuccess;
     return heamd::launch_galois_finish(static_cast<const uint64_t*>(prod), ct, ct_stride, out, ks, L, batch,
                                        galois_inverse, expand_shift, targets, stream, own);
 }

@@ -54,11 +54,26 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
 // `added_polys` polynomials of the ciphertext at ct_base + polynomial * ct_stride) applied as the rows are stored:
 // out [polys][2][L][N]; of `prod` ([polys][2][L+1][N]) only the q_ks rows are written.  hipErrorNotSupported (nothing
 // launched, ntt_key_mac_finish_supported false): launch_ntt_key_mac_inverse + launch_key_switch_finish.
+// KeySwitchEnd says which end: relinearize (the update added to the first `added_polys` polynomials), the Galois key switch
+// (galois_inverse = g^-1 mod 2N: ct_base holds the ciphertexts BEFORE the automorphism, c0 is read through it), or one step
+// of PirUtil.expand on top of that (expand_shift != 0: out takes the two children of every polynomial; own_base: the
+// ciphertexts the children are formed with, nullptr = ct_base; targets_*: rns_kernels.hpp ExpandTargets).  poly_base: the
+// launch's first polynomial in ct_base / own_base / out (spread, key and prod are passed from a run's own start).
+struct KeySwitchEnd {
+    const uint64_t* ct_base;
+    size_t ct_stride;
+    uint64_t* out;
+    uint32_t added_polys;
+    uint32_t galois_inverse = 0, expand_shift = 0;
+    const uint64_t* own_base = nullptr;
+    const uint32_t* targets_table = nullptr;
+    size_t targets_group_size = 1, targets_group_stride = 0;
+    size_t poly_base = 0;
+};
 bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys);
 hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,
-                                             const uint64_t* ct_base, size_t ct_stride, uint64_t* out, const DeviceContext& ks,
-                                             uint32_t L, uint32_t top_rows, size_t polys, uint32_t added_polys,
-                                             hipStream_t stream);
+                                             const KeySwitchEnd& end, const DeviceContext& ks, uint32_t L, uint32_t top_rows,
+                                             size_t polys, hipStream_t stream);
 const char* ntt_variant_name(uint32_t log_degree);
 
 enum class ElementwiseOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, MulScalar = 4 };

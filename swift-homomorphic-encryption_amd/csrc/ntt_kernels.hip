@@ -480,6 +480,18 @@ struct InverseSource {
     size_t ct_stride;
     uint64_t* out;
     uint32_t added_polys;
+    // ... the Galois key switch's end (Bfv.swift:190-196): galois_inverse = g^-1 mod 2N != 0: `ct_base` holds the
+    // ciphertexts BEFORE the automorphism, polynomial 0 of the result is galois(c0) + update0 -- coefficient k takes source
+    // coefficient k g^-1 mod 2N, negated past N (PolyRq/Galois.swift:115-143) -- and polynomial 1 is update1;
+    // expand_shift != 0 on top of that: one step of PirUtil.expand (PirUtil.swift:204-236), out = the children
+    // own + c' and (own - c') x^expand_shift of every polynomial (rns_kernels.hpp ExpandTargets says where they go; own_base:
+    // the ciphertexts the children are formed with).  poly_base: the launch's first polynomial in ct_base / own_base / out
+    // (the spread and product slabs of a run of equal keys are passed from their own start).
+    uint32_t galois_inverse, expand_shift;
+    const uint64_t* own_base;
+    const uint32_t* targets_table;
+    size_t targets_group_size, targets_group_stride;
+    size_t poly_base;
 };
 
 // How many twiddles of the first (gather-heavy) pass are requested before the rows are loaded and then kept in flight
@@ -647,28 +659,67 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
             const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
             const bool wide = half >= p;
+            constexpr int kEndPlain = 0, kEndGalois = 1, kEndExpand = 2;
             auto finish = [&](int k, uint64_t (&row)[E]) {
-                const uint32_t lane_bytes = lane_part<LOGN, LOGE, LOL, LOGE>(kLateLaneAddresses ? opaque32(tid) : tid) << 3;
+                const uint32_t lane = kLateLaneAddresses ? opaque32(tid) : tid;
+                const uint32_t lane_words = lane_part<LOGN, LOGE, LOL, LOGE>(lane), lane_bytes = lane_words << 3;
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
                 const size_t pc = record + 2 * k;  // polynomial * 2 + c (the rows are the same column of consecutive polynomials)
-                const size_t poly = pc >> 1;
+                const size_t poly = source_spec.poly_base + (pc >> 1);  // in the ciphertext / output slabs
                 const uint32_t c = static_cast<uint32_t>(pc & 1);
                 const BufferResource last_row = make_resource(slab + ((pc * (L + 1) + L) << LOGN), 8u << LOGN);
-                const BufferResource out_row = make_resource(source_spec.out + ((pc * L + r) << LOGN), 8u << LOGN);
-                const bool add = c < source_spec.added_polys;  // wave-uniform; without an addend the q_ks row is read twice
+                const uint32_t galois_inverse = source_spec.galois_inverse, expand_shift = source_spec.expand_shift;
+                // polynomial c of the ciphertext: added as it lies (relinearize), or -- c0 under an automorphism -- gathered
+                const bool gathered = galois_inverse != 0 && c == 0;
+                const bool add = galois_inverse != 0 ? gathered : c < source_spec.added_polys;  // wave-uniform
                 const BufferResource added_row =
                     add ? make_resource(source_spec.ct_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN)
-                        : last_row;
-                auto words_of_row = [&](auto reduce_magnitude) {
+                        : last_row;  // (without an addend the q_ks row is read twice)
+                // where the row goes: polynomial c of ciphertext `poly`, or -- an expand step -- of its two children
+                size_t first_ct = poly, second_ct = 0;
+                bool first_doubled = false, second_doubled = false;
+                if (expand_shift != 0) {
+                    first_ct = 2 * poly;
+                    second_ct = 2 * poly + 1;
+                    if (source_spec.targets_table != nullptr) {
+                        using ConstWord = const __attribute__((address_space(4))) uint32_t;
+                        const size_t group = poly / source_spec.targets_group_size, parent = poly - group * source_spec.targets_group_size;
+                        const uint32_t first = *(ConstWord*)(source_spec.targets_table + 4 * parent + 1);
+                        const uint32_t second = *(ConstWord*)(source_spec.targets_table + 4 * parent + 3);
+                        first_ct = group * source_spec.targets_group_stride + (first >> 1);
+                        second_ct = group * source_spec.targets_group_stride + (second >> 1);
+                        first_doubled = (first & 1u) != 0;
+                        second_doubled = (second & 1u) != 0;
+                    }
+                }
+                const BufferResource out_row = make_uniform_resource(source_spec.out + (((first_ct * 2 + c) * L + r) << LOGN), 8u << LOGN);
+                const BufferResource moved_row = expand_shift != 0
+                    ? make_uniform_resource(source_spec.out + (((second_ct * 2 + c) * L + r) << LOGN), 8u << LOGN) : out_row;
+                const BufferResource own_row = expand_shift != 0
+                    ? make_resource(source_spec.own_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN) : last_row;
+                auto words_of_row = [&](auto reduce_magnitude, auto end_tag) {
+                    constexpr int END = decltype(end_tag)::value;
 #pragma unroll
                     for (int base = 0; base < E; base += CHUNK) {
                         uint64_t last[CHUNK], added[CHUNK];
+                        [[maybe_unused]] uint64_t own[CHUNK];
+                        [[maybe_unused]] bool negate[CHUNK];
 #pragma unroll
                         for (int e = 0; e < CHUNK; ++e) {
                             const uint32_t at = register_part<LOGN, LOGE, LOL, LOGE>(base + e) << 3;
                             last[e] = word(__builtin_amdgcn_raw_buffer_load_b64(last_row, lane_bytes, at, row_load_policy<LOGN>()));
-                            added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
+                            if constexpr (END == kEndPlain) {
+                                added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, lane_bytes, at, row_load_policy<LOGN>()));
+                            } else {
+                                // coefficient idx of galois(c0) = -+ coefficient idx g^-1 mod 2N of c0 (row c = 1: not used)
+                                const uint32_t idx = register_part<LOGN, LOGE, LOL, LOGE>(base + e) | lane_words;
+                                const uint32_t doubled = (idx * galois_inverse) & ((2u << LOGN) - 1u);
+                                negate[e] = (doubled >> LOGN) != 0;
+                                added[e] = word(__builtin_amdgcn_raw_buffer_load_b64(added_row, (doubled & ((1u << LOGN) - 1u)) << 3, 0, 0));
+                                if constexpr (END == kEndExpand)
+                                    own[e] = word(__builtin_amdgcn_raw_buffer_load_b64(own_row, lane_bytes, at, row_load_policy<LOGN>()));
+                            }
                         }
 #pragma unroll
                         for (int e = 0; e < CHUNK; ++e) {
@@ -680,14 +731,38 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                             if constexpr (decltype(reduce_magnitude)::value) t = barrett_reduce64_uniform(t, p, mod.barrett64);
                             const uint64_t difference = csub_uniform(row[base + e] + (negative ? t : p - t), p);
                             const uint64_t update = shoup_mul_uniform(difference, inverse_q_last.x, inverse_q_last.y, p);
-                            const uint64_t result = csub_uniform((add ? added[e] : 0) + update, p);
-                            const Dwordx2 words = {lo32(result), hi32(result)};
-                            __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
+                            uint64_t addend = add ? added[e] : 0;
+                            if constexpr (END != kEndPlain) addend = negate[e] && addend != 0 ? p - addend : addend;
+                            const uint64_t result = csub_uniform(addend + update, p);  // c' (or ct + update)
+                            if constexpr (END != kEndExpand) {
+                                const Dwordx2 words = {lo32(result), hi32(result)};
+                                __builtin_amdgcn_raw_buffer_store_b64(words, out_row, lane_bytes, at, row_policy<LOGN>());
+                            } else {
+                                // children own + c' and (own - c') x^shift: the second one lands at idx + shift mod 2N,
+                                // negated past N
+                                uint64_t sum = csub_uniform(own[e] + result, p);
+                                if (first_doubled) sum = csub_uniform(sum + sum, p);
+                                const Dwordx2 first_words = {lo32(sum), hi32(sum)};
+                                __builtin_amdgcn_raw_buffer_store_b64(first_words, out_row, lane_bytes, at, row_policy<LOGN>());
+                                const uint32_t idx = register_part<LOGN, LOGE, LOL, LOGE>(base + e) | lane_words;
+                                const uint32_t landed = (idx + expand_shift) & ((2u << LOGN) - 1u);
+                                uint64_t moved = csub_uniform(own[e] + (p - result), p);
+                                moved = (landed >> LOGN) != 0 && moved != 0 ? p - moved : moved;
+                                if (second_doubled) moved = csub_uniform(moved + moved, p);
+                                const Dwordx2 moved_words = {lo32(moved), hi32(moved)};
+                                __builtin_amdgcn_raw_buffer_store_b64(moved_words, moved_row, (landed & ((1u << LOGN) - 1u)) << 3, 0,
+                                                                      row_policy<LOGN>());
+                            }
                         }
                     }
                 };
-                if (wide) words_of_row(std::true_type{});
-                else words_of_row(std::false_type{});
+                auto with_end = [&](auto reduce_magnitude) {
+                    if (expand_shift != 0) words_of_row(reduce_magnitude, std::integral_constant<int, kEndExpand>{});
+                    else if (galois_inverse != 0) words_of_row(reduce_magnitude, std::integral_constant<int, kEndGalois>{});
+                    else words_of_row(reduce_magnitude, std::integral_constant<int, kEndPlain>{});
+                };
+                if (wide) with_end(std::true_type{});
+                else with_end(std::false_type{});
             };
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
@@ -1467,15 +1542,22 @@ hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* ke
 // no kernel that pairs the key columns; the caller then runs launch_ntt_key_mac_inverse + launch_key_switch_finish.
 bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t polys) {
     const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;  // the degrees with a fused key-MAC transform
-    return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && polys * 2 * (L + 1) <= (size_t(1) << 30);
+    // (a batch of up to two workgroup generations is latency-bound: there two transforms in a row cost more than one
+    // transform and the small element-wise kernel -- single-query expansions lost 11-29 % with the fused end at every
+    // level, and the Galois key switch crosses over between 96 and 128 ciphertexts at N = 8192, L = 4:
+    // profiles/r04m_galois_fused_end_ab.txt)
+    return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && polys * 2 * (L + 1) > 2 * kOneGeneration &&
+           polys * 2 * (L + 1) <= (size_t(1) << 30);
 }
 hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint64_t* key, uint64_t* prod,
-                                             const uint64_t* ct_base, size_t ct_stride, uint64_t* out, const DeviceContext& ks,
-                                             uint32_t L, uint32_t top_rows, size_t polys, uint32_t added_polys,
-                                             hipStream_t stream) {
+                                             const KeySwitchEnd& end, const DeviceContext& ks, uint32_t L, uint32_t top_rows,
+                                             size_t polys, hipStream_t stream) {
     if (!ntt_key_mac_finish_supported(ks, L, polys)) return hipErrorNotSupported;
     if (polys == 0) return hipSuccess;
-    const InverseSource spec{spread, key, L, top_rows, ct_base, ct_stride, out, added_polys};
+    const InverseSource spec{spread, key, L, top_rows, end.ct_base, end.ct_stride, end.out, end.added_polys,
+                             end.galois_inverse, end.expand_shift, end.own_base != nullptr ? end.own_base : end.ct_base,
+                             end.targets_table, end.targets_group_size == 0 ? 1 : end.targets_group_size,
+                             end.targets_group_stride, end.poly_base};
     hipError_t e = launch_key_mac_runs(prod, ks, L, 1, L, polys * 2, kInverseFromKeyMac, spec, stream);
     if (e != hipSuccess) return e;
     return launch_key_mac_runs(prod, ks, 0, L, L, polys * 2, kInverseFromKeyMacFinish, spec, stream);

@@ -645,7 +645,10 @@ hipError_t launch_ntt32_key_mac_inverse_finish(const uint32_t* spread, const uin
                                                const uint32_t* ct_base, size_t ct_stride, uint32_t* out,
                                                const DeviceContext32& ks_ctx, uint32_t L, uint32_t top_rows, size_t polys,
                                                uint32_t added_polys, hipStream_t stream) {
-    if (L == 0 || L > 15 || ks_ctx.moduli_count != L + 1 || ks_ctx.log_degree < 12 || ks_ctx.log_degree > 14)
+    // (beyond two workgroup generations only -- 4 x 256 workgroups at N = 4096: a smaller batch is latency-bound and two
+    // transforms in a row cost more than one transform and the small element-wise kernel)
+    if (L == 0 || L > 15 || ks_ctx.moduli_count != L + 1 || ks_ctx.log_degree < 12 || ks_ctx.log_degree > 14 ||
+        polys * 2 * (L + 1) <= 2048)
         return hipErrorNotSupported;
     if (polys == 0) return hipSuccess;
     hipError_t e = launch_ntt32_fused<kSource32KeyMac>(

@@ -822,10 +822,10 @@ def test_bfv_uint32_packed_slabs_match_oracle(oracle):
     assert status == 16  # HE_ERR_INVALID_ARGUMENT
 
 
-@pytest.mark.parametrize("degree,bits,batch", [(4096, [29, 60, 60], 96), (4096, [60, 60, 60], 96), (8192, [55, 55, 60], 48),
-                                               (4096, [50, 60, 50], 96), (4096, [55, 55, 55], 97)])
+@pytest.mark.parametrize("degree,bits,batch", [(4096, [29, 60, 60], 176), (4096, [60, 60, 60], 176), (8192, [55, 55, 60], 176),
+                                               (4096, [50, 60, 50], 176), (4096, [55, 55, 55], 177)])
 def test_key_switch_on_runs_of_butterfly_classes(oracle, degree, bits, batch):
-    """relinearize and applyGalois on batches wide enough (more than one workgroup generation of rows) for the
+    """relinearize and applyGalois on batches wide enough (more than two workgroup generations of rows) for the
     key-switching moduli to be launched as runs of one butterfly class each -- the reference's 60-bit parameter sets
     (29 | 60, 60: the 60-bit rows on the fold butterflies; the centred q_ks word exceeds the 29-bit modulus and is reduced
     as the key switch ends in the key-MAC transform's store), all-60-bit moduli (one fold run), 55, 55 | 60 (q_ks above

@@ -209,6 +209,26 @@ def test_uint32_fused_transforms_at_every_tiled_degree(oracle, degree, bits):
     assert np.array_equal(host(ours.apply_galois(dev(lhs), element, dev(key))), ref.apply_galois(lhs, element, key))
 
 
+@pytest.mark.parametrize("degree,bits,batch", [(4096, [27, 28, 28], 352), (8192, [30, 20, 30, 29], 264)])
+def test_uint32_key_switch_ends_in_the_transform_store(oracle, degree, bits, batch):
+    """Bfv<UInt32> relinearize and the (in-place) Galois key switch on batches beyond two workgroup generations of
+    key-switching rows: there the key switch ends in the 4-byte key-MAC transform's store (word32_kernels.hip
+    kSource32KeyMacFinish) -- the reference's n_4096_logq_27_28_28 moduli, and a set whose special modulus exceeds a 20-bit
+    ciphertext modulus (the centred q_ks word is reduced first).  Word for word against the 32-bit oracle."""
+    dev, host = heamd.to_device32, heamd.to_host32
+    q = oracle.generate_primes(bits, False, degree, word_bits=32)
+    t = oracle.generate_primes([degree.bit_length() + 4], True, degree, word_bits=32)[0]
+    ours, ref = heamd.BfvContext32(degree, t, q), oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(degree + batch)
+    moduli, L = q[:-1], len(q) - 1
+    ct3 = _uniform(rng, (batch, 3), moduli, degree)
+    key = _uniform(rng, (L, 2), q, degree)
+    assert np.array_equal(host(ours.relinearize(dev(ct3), dev(key))), ref.relinearize(ct3, key, threads=16))
+    ct = _uniform(rng, (batch, 2), moduli, degree)
+    element = 2 * degree - 1
+    assert np.array_equal(host(ours.apply_galois(dev(ct), element, dev(key))), ref.apply_galois(ct, element, key))
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_uint32_shapes(oracle, seed):
     """Bfv<UInt32> on packed 4-byte slabs over random parameter shapes (17..30-bit moduli, 1..4 ciphertext moduli, degrees

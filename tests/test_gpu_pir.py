@@ -139,6 +139,26 @@ def test_pir_expand_fused_levels(oracle, total, key_shifts):
     assert np.array_equal(both[0], expected[0]) and np.array_equal(both[1], expected[1])
 
 
+@pytest.mark.parametrize("total,key_shifts", [(400, None), (512, [0, 2, 4, 5, 6, 7, 8])])
+def test_pir_expand_wide_levels(oracle, total, key_shifts):
+    """Expansions wide enough for every run of equal keys in their last level to exceed two workgroup generations of
+    key-switching rows (N=4096, L=2, two queries under different keys in one call: 200 and 256 parents each): there the
+    children leave the key-MAC transform's store (ntt_kernels.hip kInverseFromKeyMacFinish with the expand end) -- per run
+    of equal keys, straight to their output slots, ragged totals (400) and levels reached by two applications (no keys for the
+    elements N/2 + 1 and N/8 + 1; below 2^7 + 1 an element does not compose to the next one, PirUtil.swift:222-231) included.  Word for word against the oracle's recursion."""
+    degree = 4096
+    q = oracle.generate_primes([50, 45, 55], False, degree)
+    ours, ref = heamd.BfvContext(degree, 65537, q), oracle.BfvContext(degree, 65537, q)
+    rng = np.random.default_rng(300 + total)
+    shifts = key_shifts if key_shifts is not None else list(range(0, (total - 1).bit_length()))
+    queries = _uniform(rng, (2, 1, 2), q[:-1], degree)
+    keys = [{(degree >> k) + 1: _uniform(rng, (ours.L, 2), q, degree) for k in shifts} for _ in range(2)]
+    device_keys = [{e: heamd.to_device(k) for e, k in keys[i].items()} for i in range(2)]
+    both = heamd.to_host(ours.pir_expand_batch(heamd.to_device(queries), total, device_keys))
+    for i in range(2):
+        assert np.array_equal(both[i], oracle.pir.expand(ref, queries[i], total, keys[i])), i
+
+
 def test_pir_expand_two_query_ciphertexts(oracle, small):
     """More outputs than one ciphertext can carry: the second ciphertext expands the remainder (PirUtil.swift:327-333)."""
     ours, ref, client = small
