@@ -120,6 +120,46 @@ struct WordArith<uint32_t> {
     }
 };
 
+// V consecutive coefficients of a row per lane.  The base-conversion kernels take one 8-byte word per lane on 8-byte slabs
+// (they are bound by their multiply-adds there: about 400 issue slots per coefficient at L = 4) and FOUR 4-byte words on
+// 4-byte slabs, whose arithmetic is a fifth of that: one 16-byte access per lane and row instead of four 4-byte ones,
+// lift 129.6 -> 102.9 us and floor 211.3 -> 187.7 us per 2048 products at n_4096_logq_27_28_28
+// (profiles/r04n_word32_base_conversions_ab.txt; two words per lane: 112.8 / 199.0).  Rows whose base is not 16-byte
+// aligned fall back to one word per lane.
+template <int V, typename W>
+__device__ __forceinline__ void load_words(const W* p, uint64_t (&x)[V]) {
+    if constexpr (V == 1) {
+        x[0] = stream_load(p);
+    } else if constexpr (V == 2) {
+        static_assert(sizeof(W) == 4, "two 4-byte words per lane");
+        const uint64_t pair = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
+        x[0] = lo32(pair);
+        x[1] = hi32(pair);
+    } else {
+        static_assert(V == 4 && sizeof(W) == 4, "four 4-byte words per lane");
+        const StreamWords quad = __builtin_nontemporal_load(reinterpret_cast<const StreamWords*>(p));
+        x[0] = lo32(quad.x);
+        x[1] = hi32(quad.x);
+        x[2] = lo32(quad.y);
+        x[3] = hi32(quad.y);
+    }
+}
+template <int V, typename W>
+__device__ __forceinline__ void store_words(W* p, const uint64_t (&x)[V]) {
+    if constexpr (V == 1) {
+        stream_store(p, x[0]);
+    } else if constexpr (V == 2) {
+        static_assert(sizeof(W) == 4, "two 4-byte words per lane");
+        __builtin_nontemporal_store(lo32(x[0]) | (x[1] << 32), reinterpret_cast<uint64_t*>(p));
+    } else {
+        static_assert(V == 4 && sizeof(W) == 4, "four 4-byte words per lane");
+        const StreamWords quad = {lo32(x[0]) | (x[1] << 32), lo32(x[2]) | (x[3] << 32)};
+        __builtin_nontemporal_store(quad, reinterpret_cast<StreamWords*>(p));
+    }
+}
+template <typename W>
+inline bool quad_aligned(const W* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // ---- liftQToQBsk: in [polys][L][N] -> out [polys][2L+1][N] -------------------------------------------------------
 // Polynomial p = item * polys_per_item + c is read at in + item * in_item_stride + c * L * N and written at
 // out + item * out_item_stride + c * (2L+1) * N (strides in words), so one launch can fill a slot range of a larger
@@ -131,7 +171,7 @@ struct LiftLayout {
 
 // W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
 // widened when loaded and narrowed when stored; the arithmetic is the same code for both.
-template <int L, typename W, bool BOUNDED>
+template <int L, typename W, bool BOUNDED, int V = 1>
 __global__ void __launch_bounds__(kThreads)
     lift_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys,
                 const LiftLayout layout) {
@@ -140,112 +180,143 @@ __global__ void __launch_bounds__(kThreads)
     const size_t total = polys << logn;
     using A = WordArith<W>;
     const uint64_t kMTildeValue = tool.mtilde;  // 2^32 (UInt64 contexts) or 2^16 (UInt32 contexts)
-    // one coefficient per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
+    // V coefficients per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
     // spills SGPRs into VGPR lanes
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
+    for (size_t idx = (blockIdx.x * size_t(kThreads) + threadIdx.x) * V; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
         const size_t item = poly / layout.polys_per_item, c = poly - item * layout.polys_per_item;
         const W* src = in + item * layout.in_item_stride + c * L * n + k;
         W* dst = out + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
-        uint64_t y[L];
+        uint64_t y[V][L];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const uint64_t x = stream_load(src + i * n);
-            if (layout.store_input != 0) stream_store(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
-            y[i] = A::shoup(x, tool.lift_scale[i], tool.q_moduli[i].p);
+            uint64_t x[V];
+            load_words<V>(src + i * n, x);
+            if (layout.store_input != 0) store_words<V>(dst + i * n, x);  // rows [0, L): the input itself (RnsTool.swift:329-330)
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[v][i] = A::shoup(x[v], tool.lift_scale[i], tool.q_moduli[i].p);
         }
         // mTilde row first: r = -(x' * Q^-1) mod mTilde  (smallMontgomeryReduce, RnsTool.swift:343-348)
-        typename A::Sum acc = A::first(y[0], tool.q_to_ext[(L + 1) * L + 0]);
-#pragma unroll
-        for (int i = 1; i < L; ++i) A::add(acc, y[i], tool.q_to_ext[(L + 1) * L + i]);
         // the (L+2)'th extended modulus is mTilde = 2^32 at the top level; a lower-level tool takes a prefix of
         // [Bsk..., mTilde] and finds a Bsk prime there (the reference's own behaviour, reproduced as is)
         const DeviceModulus last = tool.ext_moduli[L + 1];
-        uint64_t r = last.p == kMTildeValue ? (A::low_word(acc) & (kMTildeValue - 1)) : A::reduce(acc, last);
-        r = A::shoup(r, tool.neg_inv_q_mod_mtilde, kMTildeValue);
-        const bool below = r < (kMTildeValue >> 1);
+        uint64_t r[V];
+        bool below[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            typename A::Sum acc = A::first(y[v][0], tool.q_to_ext[(L + 1) * L + 0]);
+#pragma unroll
+            for (int i = 1; i < L; ++i) A::add(acc, y[v][i], tool.q_to_ext[(L + 1) * L + i]);
+            r[v] = last.p == kMTildeValue ? (A::low_word(acc) & (kMTildeValue - 1)) : A::reduce(acc, last);
+            r[v] = A::shoup(r[v], tool.neg_inv_q_mod_mtilde, kMTildeValue);
+            below[v] = r[v] < (kMTildeValue >> 1);
+        }
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            typename A::Sum sum = A::template first<BOUNDED>(y[0], tool.q_to_bsk_scaled[j * L + 0]);
+            uint64_t lifted[V];
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[i], tool.q_to_bsk_scaled[j * L + i]);
-            const uint64_t centered = below ? r : r + m.p - kMTildeValue;  // RnsTool.swift:357-361
-            // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
-            // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
-            const U64x2 scaled = tool.q_mod_bsk_scaled[j];
-            const uint64_t unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
-            stream_store(dst + (L + j) * n, csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p));
+            for (int v = 0; v < V; ++v) {
+                typename A::Sum sum = A::template first<BOUNDED>(y[v][0], tool.q_to_bsk_scaled[j * L + 0]);
+#pragma unroll
+                for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[v][i], tool.q_to_bsk_scaled[j * L + i]);
+                const uint64_t centered = below[v] ? r[v] : r[v] + m.p - kMTildeValue;  // RnsTool.swift:357-361
+                // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
+                // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
+                const U64x2 scaled = tool.q_mod_bsk_scaled[j];
+                const uint64_t unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
+                lifted[v] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
+            }
+            store_words<V>(dst + (L + j) * n, lifted);
         }
     }
 }
 
 // ---- floorQBskToQ: in [polys][2L+1][N] -> out [polys][L][N] ------------------------------------------------------
-template <int L, typename W, bool BOUNDED>
+template <int L, typename W, bool BOUNDED, int V = 1>
 __global__ void __launch_bounds__(kThreads)
     floor_kernel(const W* __restrict__ in, W* __restrict__ out, const RnsToolDevice tool, size_t polys) {
     using A = WordArith<W>;
     const uint32_t logn = tool.log_degree;
     const size_t n = size_t(1) << logn;
     const size_t total = polys << logn;
-    for (size_t idx = blockIdx.x * size_t(kThreads) + threadIdx.x; idx < total; idx = total) {
+    for (size_t idx = (blockIdx.x * size_t(kThreads) + threadIdx.x) * V; idx < total; idx = total) {
         const size_t poly = idx >> logn, k = idx & (n - 1);
         const W* src = in + poly * (2 * L + 1) * n + k;
         W* dst = out + poly * L * n + k;
         // approximateFloor (RnsTool.swift:378-398)
-        uint64_t y[L];
+        uint64_t y[V][L];
 #pragma unroll
-        for (int i = 0; i < L; ++i)
-            y[i] = A::shoup(stream_load(src + i * n), tool.inv_punctured_q[i], tool.q_moduli[i].p);
+        for (int i = 0; i < L; ++i) {
+            uint64_t x[V];
+            load_words<V>(src + i * n, x);
+#pragma unroll
+            for (int v = 0; v < V; ++v) y[v][i] = A::shoup(x[v], tool.inv_punctured_q[i], tool.q_moduli[i].p);
+        }
         // (x_Bsk_j - conv_j) Q^-1 mod Bsk_j, and for j < L straight on to the Bsk -> Q converter's first product
         // z_j = f_j (B/Bsk_j)^-1 mod Bsk_j: two exact products mod Bsk_j = one by the product of the constants
-        uint64_t z[L], f_msk = 0;
+        uint64_t z[V][L], f_msk[V];
 #pragma unroll
         for (int j = 0; j <= L; ++j) {
             const DeviceModulus m = tool.ext_moduli[j];
-            typename A::Sum sum = A::template first<BOUNDED>(y[0], tool.q_to_ext[j * L + 0]);
+            uint64_t x[V];
+            load_words<V>(src + (L + j) * n, x);
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[i], tool.q_to_ext[j * L + i]);
-            // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
-            // checked when the tool is built), which is all the next exact product needs
-            const uint64_t difference = stream_load(src + (L + j) * n) + A::kSlack * m.p - A::template reduce_lazy<BOUNDED>(sum, m);
-            if (j < L) {
-                z[j] = A::shoup(difference, tool.floor_scale_b[j], m.p);
-            } else {
-                f_msk = A::shoup(difference, tool.inv_q_mod_bsk[j], m.p);
+            for (int v = 0; v < V; ++v) {
+                typename A::Sum sum = A::template first<BOUNDED>(y[v][0], tool.q_to_ext[j * L + 0]);
+#pragma unroll
+                for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[v][i], tool.q_to_ext[j * L + i]);
+                // x - conv with conv unfolded in [0, 5p): the difference stays below 6p < 2^63 (extended moduli < 2^63 / 6,
+                // checked when the tool is built), which is all the next exact product needs
+                const uint64_t difference = x[v] + A::kSlack * m.p - A::template reduce_lazy<BOUNDED>(sum, m);
+                if (j < L) {
+                    z[v][j] = A::shoup(difference, tool.floor_scale_b[j], m.p);
+                } else {
+                    f_msk[v] = A::shoup(difference, tool.inv_q_mod_bsk[j], m.p);
+                }
             }
         }
         // convertApproximateBskToQ (RnsTool.swift:402-450)
         const DeviceModulus msk = tool.ext_moduli[L];
-        typename A::Sum alpha_sum = A::template first<BOUNDED>(z[0], tool.b_to_msk[0]);
+        uint64_t alpha[V];
+        bool exceeds[V];
 #pragma unroll
-        for (int i = 1; i < L; ++i) A::template add<BOUNDED>(alpha_sum, z[i], tool.b_to_msk[i]);
-        // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
-        // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
-        uint64_t alpha = tool.alpha_modulus_is_msk != 0 ? A::template reduce_lazy<BOUNDED>(alpha_sum, msk)  // < 5 m_sk
-                                                        : A::template reduce<BOUNDED>(alpha_sum, tool.alpha_modulus[0]);
-        alpha = A::shoup(alpha + msk.p - f_msk, tool.inv_b_mod_msk, msk.p);
-        const bool exceeds = alpha > (msk.p >> 1);
+        for (int v = 0; v < V; ++v) {
+            typename A::Sum alpha_sum = A::template first<BOUNDED>(z[v][0], tool.b_to_msk[0]);
+#pragma unroll
+            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(alpha_sum, z[v][i], tool.b_to_msk[i]);
+            // the converter's output modulus is the top level's m_sk (RnsTool.swift:44-62, 240-250); below the top level
+            // its canonical residue is then read as an integer mod THIS level's m_sk, as the reference does
+            alpha[v] = tool.alpha_modulus_is_msk != 0 ? A::template reduce_lazy<BOUNDED>(alpha_sum, msk)  // < 5 m_sk
+                                                      : A::template reduce<BOUNDED>(alpha_sum, tool.alpha_modulus[0]);
+            alpha[v] = A::shoup(alpha[v] + msk.p - f_msk[v], tool.inv_b_mod_msk, msk.p);
+            exceeds[v] = alpha[v] > (msk.p >> 1);
+        }
 #pragma unroll
         for (int row = 0; row < L; ++row) {
             const DeviceModulus m = tool.q_moduli[row];
-            typename A::Sum sum = A::template first<BOUNDED>(z[0], tool.b_to_q[row * L + 0]);
+            uint64_t floored[V];
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, z[i], tool.b_to_q[row * L + i]);
-            // RnsTool.swift:436-446: + (m_sk - alpha) (B mod q) when alpha > m_sk/2, else + alpha (-B mod q)
-            if (tool.floor_merge_ok != 0) {
-                // the correction is one more product of the same exact sum: one reduction instead of a Shoup product,
-                // a negation and a modular add (uniform branch; the sum stays below 2^127)
-                const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
-                A::add_vector(sum, exceeds ? msk.p - alpha : alpha, exceeds ? plus.x : minus.x);
-                stream_store(dst + row * n, A::template reduce<BOUNDED>(sum, m));
-            } else {
-                const uint64_t converted = A::template reduce<BOUNDED>(sum, m);
-                // the second form is the negation of alpha (B mod q), so one product serves both
-                const uint64_t magnitude = A::shoup(exceeds ? msk.p - alpha : alpha, tool.b_mod_q[row], m.p);
-                const uint64_t adjust = exceeds ? magnitude : neg_mod_uniform(magnitude, m.p);
-                stream_store(dst + row * n, add_mod_uniform(converted, adjust, m.p));
+            for (int v = 0; v < V; ++v) {
+                typename A::Sum sum = A::template first<BOUNDED>(z[v][0], tool.b_to_q[row * L + 0]);
+#pragma unroll
+                for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, z[v][i], tool.b_to_q[row * L + i]);
+                // RnsTool.swift:436-446: + (m_sk - alpha) (B mod q) when alpha > m_sk/2, else + alpha (-B mod q)
+                if (tool.floor_merge_ok != 0) {
+                    // the correction is one more product of the same exact sum: one reduction instead of a Shoup product,
+                    // a negation and a modular add (uniform branch; the sum stays below 2^127)
+                    const U64x2 plus = tool.b_mod_q[row], minus = tool.neg_b_mod_q[row];
+                    A::add_vector(sum, exceeds[v] ? msk.p - alpha[v] : alpha[v], exceeds[v] ? plus.x : minus.x);
+                    floored[v] = A::template reduce<BOUNDED>(sum, m);
+                } else {
+                    const uint64_t converted = A::template reduce<BOUNDED>(sum, m);
+                    // the second form is the negation of alpha (B mod q), so one product serves both
+                    const uint64_t magnitude = A::shoup(exceeds[v] ? msk.p - alpha[v] : alpha[v], tool.b_mod_q[row], m.p);
+                    const uint64_t adjust = exceeds[v] ? magnitude : neg_mod_uniform(magnitude, m.p);
+                    floored[v] = add_mod_uniform(converted, adjust, m.p);
+                }
             }
+            store_words<V>(dst + row * n, floored);
         }
     }
 }
@@ -649,15 +720,24 @@ struct LiftLauncher {
     static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, const LiftLayout& layout,
                           hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        bool bounded = false;
+        bool launched = false;
         if constexpr (sizeof(W) == 8) {
             if (tool.wide_reduce_ok != 0) {
-                bounded = true;
+                launched = true;
                 hipLaunchKernelGGL((lift_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
                                    in, out, tool, polys, layout);
             }
         }
-        if (!bounded)
+        if constexpr (sizeof(W) == 4) {
+            // four words per lane where every row starts on a 16-byte boundary (strides are multiples of N in practice)
+            if (quad_aligned(in) && quad_aligned(out) && layout.in_item_stride % 4 == 0 && layout.out_item_stride % 4 == 0 &&
+                tool.log_degree >= 2) {
+                launched = true;
+                hipLaunchKernelGGL((lift_kernel<L, W, false, 4>), dim3(exact_grid(polys << (tool.log_degree - 2))),
+                                   dim3(kThreads), 0, s, in, out, tool, polys, layout);
+            }
+        }
+        if (!launched)
             hipLaunchKernelGGL((lift_kernel<L, W, false>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in,
                                out, tool, polys, layout);
         return hipGetLastError();
@@ -668,15 +748,22 @@ struct FloorLauncher {
     template <typename W>
     static hipError_t run(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t s) {
         if (((polys << tool.log_degree) + kThreads - 1) / kThreads > 0x7fffffffull) return hipErrorInvalidValue;
-        bool bounded = false;
+        bool launched = false;
         if constexpr (sizeof(W) == 8) {
             if (tool.wide_reduce_ok != 0) {
-                bounded = true;
+                launched = true;
                 hipLaunchKernelGGL((floor_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
                                    in, out, tool, polys);
             }
         }
-        if (!bounded)
+        if constexpr (sizeof(W) == 4) {
+            if (quad_aligned(in) && quad_aligned(out) && tool.log_degree >= 2) {
+                launched = true;
+                hipLaunchKernelGGL((floor_kernel<L, W, false, 4>), dim3(exact_grid(polys << (tool.log_degree - 2))),
+                                   dim3(kThreads), 0, s, in, out, tool, polys);
+            }
+        }
+        if (!launched)
             hipLaunchKernelGGL((floor_kernel<L, W, false>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s, in,
                                out, tool, polys);
         return hipGetLastError();

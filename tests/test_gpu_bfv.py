@@ -735,6 +735,32 @@ def test_uint32_extremes_and_inner_product_cadence(oracle, count):
     assert np.array_equal(host(ours.floor_qbsk_to_q(dev(y), ours.L)), np.stack([tool.floor_qbsk_to_q(p) for p in y]))
 
 
+def test_uint32_base_conversions_four_words_per_lane(oracle):
+    """Bfv<UInt32> lift / floor at n_4096_logq_27_28_28: the kernels take four 4-byte words per lane (one 16-byte access)
+    when every row starts on a 16-byte boundary and one word per lane otherwise -- a slab that starts 4 bytes into its
+    allocation gives the same words as the aligned one, and both equal the 32-bit oracle's."""
+    import torch
+
+    degree = 4096
+    t = (1 << 16) + 1
+    q = oracle.generate_primes([27, 28, 28], False, degree, word_bits=32)
+    ours = heamd.BfvContext32(degree, t, q)
+    ref = oracle.BfvContext(degree, t, q, word_bits=32)
+    rng = np.random.default_rng(731)
+    tool = ref.rns_tool(ours.L)
+    x = _uniform(rng, (3,), q[:-1], degree)
+    y = _uniform(rng, (3,), ref.qbsk_context(ours.L).moduli, degree)
+    for words, run, expected in ((x, ours.lift_q_to_qbsk, np.stack([tool.lift_q_to_qbsk(p) for p in x])),
+                                 (y, ours.floor_qbsk_to_q, np.stack([tool.floor_qbsk_to_q(p) for p in y]))):
+        aligned = heamd.to_device32(words)
+        assert aligned.data_ptr() % 16 == 0
+        assert np.array_equal(heamd.to_host32(run(aligned)), expected)
+        shifted = torch.empty(aligned.numel() + 1, dtype=aligned.dtype, device=aligned.device)[1:]
+        shifted.copy_(aligned.reshape(-1))
+        assert shifted.data_ptr() % 16 == 4
+        assert np.array_equal(heamd.to_host32(run(shifted)), expected)
+
+
 def test_bfv_uint32_packed_slabs_match_oracle(oracle):
     """Bfv<UInt32> on packed [UInt32] slabs (he_*_device_u32): no word is widened in memory.  Every scheme operation
     word for word against the 32-bit oracle -- lift / floor / scaleAndRound at two levels, ct x ct, relinearize,
