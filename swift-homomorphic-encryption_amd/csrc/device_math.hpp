@@ -308,6 +308,53 @@ __device__ __forceinline__ uint64_t split_mul_add(uint64_t addend, uint64_t y, u
     return pack64(lo32(c0), opaque32(hi32(c0) + lo32(c1)));
 }
 
+// The same product for a SIGNED multiplicand d = b0 + b1 2^32 (b1 signed, any 64-bit d): the inverse butterfly's x - y
+// as it leaves the subtraction, without the bound that would keep it non-negative (one 64-bit addition per butterfly).
+// The constant's second word comes in signed-limb form, wt = t0s + t1' 2^32 with t0s = the low word read as signed and
+// t1' = hi32(wt) + (t0 >> 31) (the inverse tables of the split-mode moduli hold it that way, poly_context.cpp), so that
+// V = b0 w + b1 wt = d w (mod p) is formed by signed multiply-adds on b1 (v_mad_i64_i32) -- V in (-2^31 p, 3 2^31 p).
+// Its quotient by 2p, Q = floor((b0 f + b1 ft) / 2^32) in [-2^30, 2^31 + 2^30), fits no 32-bit word of either signedness;
+// Q' = Q + 2^30 does (the estimate's chain starts at 2^62 -- the inline constant 2.0 read as a 64-bit operand), and
+//     V - Q 2p = V + Q' (2^64 - 2p) + 2^31 p   (mod 2^64),
+// so the chains are the unsigned ones with the 2^0 column started at  bias = beta + 2^31 p (mod 2^64).  The estimate:
+// b0 w / 2p - b0 f / 2^32 in [0, 1), b1 (wt / 2p - ft / 2^32) in (-1/2, 1/2), Q at most one above E - 1: V - Q 2p lies in
+// (-p, 5p); beta = p brings it to (0, 6p), inside the [0, 8p) the unsigned form promises.  `bias` = p + 2^31 p (mod 2^64).
+// 8 multiply-adds and one add like split_mul_add.  UNIFORM: the constant's words are in SGPRs and take the one scalar
+// operand an instruction may read, so the bias comes in vector registers.
+template <bool UNIFORM>
+__device__ __forceinline__ uint64_t split_mul_signed(uint64_t d, uint64_t w, uint64_t wt_signed_limbs, uint64_t f_pair,
+                                                    uint64_t neg_2p, uint64_t bias) {
+    const uint32_t b0 = lo32(d), b1 = hi32(d);
+    const uint32_t w0 = lo32(w), w1 = hi32(w), t0 = lo32(wt_signed_limbs), t1 = hi32(wt_signed_limbs);
+    const uint32_t f = lo32(f_pair), ft = hi32(f_pair);
+    const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
+    uint64_t q, c0, c1, carry;
+#define HEAMD_SPLIT_SIGNED_BODY                       \
+    "v_mad_u64_u32 %0, %3, %4, %10, 2.0\n\t"          \
+    "v_mad_u64_u32 %1, %3, %4, %6, %12\n\t"           \
+    "v_mad_u64_u32 %2, %3, %4, %8, 0\n\t"             \
+    "v_mad_i64_i32 %0, %3, %5, %11, %0\n\t"           \
+    "v_mad_i64_i32 %1, %3, %5, %7, %1\n\t"            \
+    "v_mad_i64_i32 %2, %3, %5, %9, %2"
+    // operands: 0 q, 1 c0, 2 c1, 3 carry | 4 b0, 5 b1, 6 w0, 7 t0, 8 w1, 9 t1, 10 f, 11 ft, 12 bias
+    if constexpr (UNIFORM) {
+        asm(HEAMD_SPLIT_SIGNED_BODY
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "s"(w1), "s"(t1), "s"(f), "s"(ft), "v"(bias));
+    } else {
+        asm(HEAMD_SPLIT_SIGNED_BODY
+            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "v"(w1), "v"(t1), "v"(f), "v"(ft), "s"(bias));
+    }
+#undef HEAMD_SPLIT_SIGNED_BODY
+    uint64_t carry2;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\t"
+        "v_mad_u64_u32 %1, %2, %3, %5, %1"
+        : "+v"(c0), "+v"(c1), "=&s"(carry2)
+        : "v"(hi32(q)), "s"(n0), "s"(n1));
+    return pack64(lo32(c0), opaque32(hi32(c0) + lo32(c1)));
+}
+
 // ---- product by a constant for moduli next to a power of two ("fold" butterflies): 5 multiply-adds -------------------
 // For p = 2^b - d (the largest b-bit primes, what generatePrimes(preferringSmall: false) returns) or p = 2^60 + e (the
 // BEHZ auxiliary primes, RnsTool.swift:28-66) the high part of a product folds back by a SHIFT: with y = b0 + b1 2^32 and

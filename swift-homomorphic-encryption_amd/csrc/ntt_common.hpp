@@ -121,7 +121,9 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                                    conditional subtract per butterfly: the forward transform never folds (a word
 //                                    gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62), the inverse
 //                                    brings its sums back under 2p once their bound reaches 2^9 p (one round for
-//                                    N <= 8192); one float-estimated quotient makes outputs canonical.
+//                                    N <= 8192) and multiplies its differences x - y as SIGNED words (split_mul_signed:
+//                                    no bound added to keep them non-negative; the inverse tables hold w 2^32 mod p in
+//                                    signed limbs for that); one float-estimated quotient makes outputs canonical.
 //   kModeSplitShift  the same for moduli just below a power of two (DeviceModulus::split_shift != 0): a gathered twiddle
 //                    is its 16 bytes (w, w 2^32 mod p) alone and the two 31-bit quotient factors are read off those
 //                    words by a shift instead of fetched -- one gather instruction per twiddle instead of two.  A shifted
@@ -511,16 +513,26 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
     return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
 }
 
+// beta + 2^31 p (mod 2^64) with beta = p: what split_mul_signed starts its 2^0 column at
+__device__ __forceinline__ uint64_t split_signed_bias(uint64_t p) { return p + (p << 31); }
+// a wave-uniform 64-bit value in vector registers, made where it is written (not hoisted, not merged)
+__device__ __forceinline__ uint64_t vector_copy(uint64_t uniform_value) {
+    uint64_t out;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(out) : "s"(uniform_value));
+    return out;
+}
+
 // ---- inverse pass over element bits [LO, LO+W): stages run from the low bit up; the very last stage of the
 // transform (bit LOGN-1) folds in N^-1 and N^-1 psi^(-N/2) and produces canonical words --------------------------
 // SCALED: mod.inv_degree carries a factor besides N^-1 (DeviceModulus::has_ntt == kNttScaledInverseDegree): the last
 // stage's sums take the Shoup product; otherwise they are divided by N exactly (divide_by_degree).
 // One inverse butterfly below the last stage: (x, y) -> (x + y, (x - y + bound) w) with inputs below `bound` = p <<
-// in_shift; `fold` brings the sum back under the cap (inverse_in_shift).
+// in_shift; `fold` brings the sum back under the cap (inverse_in_shift).  Split mode: (x + y, (x - y) w) with the
+// difference multiplied as a signed word (`bias`: split_signed_bias(p), in vector registers beside a wave-uniform twiddle).
 template <int MODE>
 __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
                                                   uint64_t p, uint64_t neg_p, uint64_t bound, bool fold,
-                                                  const FoldConstants& fc = FoldConstants{}) {
+                                                  const FoldConstants& fc = FoldConstants{}, uint64_t bias = 0) {
     const uint64_t x = first, y = second;
     if constexpr (is_fold(MODE)) {
         // words below 6p (`fold`: not on canonical input): the sum back under 6p, x + 6p - y in (0, 12p), the product below 6p
@@ -532,14 +544,19 @@ __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& sec
         return;
     }
     uint64_t sum = x + y;
-    const uint64_t diff = x + bound - y;
-    if (fold) {
-        if constexpr (is_split(MODE)) {
-            sum = LazyReducer(p).lazy(sum);
-        } else {
-            sum = csub_uniform(sum, bound);
-        }
+    if constexpr (is_split(MODE)) {
+        // x - y goes to the product as a signed word (device_math.hpp split_mul_signed: the bound that would keep it
+        // non-negative is one 64-bit addition per butterfly; inputs are below 2^63, so the difference cannot wrap); the
+        // product comes back in (0, 6p)
+        static_assert(MODE == kModeSplit, "the inverse tables hold w 2^32 mod p in signed limbs: no factors read off its words");
+        if (fold) sum = LazyReducer(p).lazy(sum);
+        first = sum;
+        second = uniform ? split_mul_signed<true>(x - y, w.w, w.second, w.factors, neg_p, bias)
+                         : split_mul_signed<false>(x - y, w.w, w.second, w.factors, neg_p, bias);
+        return;
     }
+    const uint64_t diff = x + bound - y;
+    if (fold) sum = csub_uniform(sum, bound);
     first = sum;
     second = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p) : Lazy<MODE>::template mul<false>(diff, w, neg_p);
 }
@@ -589,12 +606,20 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         if (k + AHEAD < COUNT)
             pending[AHEAD - 1] = inverse_twiddle<LOGN, LOGE, LO, W, MODE, UNIFORM_TWIDDLES>(tw, lane_elements, k + AHEAD);
         if (k + 1 < COUNT) __builtin_amdgcn_sched_barrier(0);
+        // split mode: the signed product's bias (device_math.hpp split_mul_signed) -- a scalar operand beside gathered
+        // twiddles; beside wave-uniform ones (their words take the instruction's one scalar operand) a vector copy made
+        // here, once per twiddle, so that it is not carried through the gathered stages
+        uint64_t bias = split_signed_bias(p);
+        if constexpr (is_split(MODE)) {
+            if (uniform && !last_stage) bias = vector_copy(bias);
+        }
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
 #pragma unroll
             for (int o = 0; o < stride; ++o) {
                 if (!last_stage) {
-                    inverse_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, p, neg_p, bound, fold, fc);
+                    inverse_butterfly<MODE>(v[row][base + o], v[row][base + o + stride], w, uniform, p, neg_p, bound, fold, fc,
+                                            bias);
                     continue;
                 }
                 const uint64_t x = v[row][base + o];

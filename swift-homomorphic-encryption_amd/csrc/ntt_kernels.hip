@@ -861,7 +861,7 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
 #pragma unroll
             for (int low = 0; low < span; ++low) {
                 const int h = (upper << (c + 1)) | low;
-                inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold);
+                inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold, FoldConstants{}, split_signed_bias(p));
             }
             if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1110,9 +1110,12 @@ hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
 // consecutive records -- one modulus, every twiddle fetched once for both.
 // Where the shifted-factor butterflies (ntt_common.hpp kModeSplitShift) replace the tabulated ones for the contexts that
 // allow them: the plain-slab launches they measured faster on -- the forward transform at N = 4096
-// (profiles/r03k_ntt_shift_factors.txt; the interleaved rows are indifferent: profiles/r03p_ntt_interleaved.txt).
-template <int LOGN, bool INVERSE>
-constexpr bool kShiftFactors = !INVERSE && LOGN == 12;
+// (profiles/r03k_ntt_shift_factors.txt; the interleaved rows are indifferent: profiles/r03p_ntt_interleaved.txt).  Forward
+// transforms only: the inverse tables hold their second word in signed limbs (ntt_common.hpp inverse_butterfly), which no
+// factor can be read off; the inverse transform with shifted factors measured 3 % slower anyway
+// (profiles/r04a_inverse_variants_ab.txt).
+template <int LOGN>
+constexpr bool kShiftFactors = LOGN == 12;
 
 // The fold butterflies (ntt_common.hpp kModeFoldMinus / kModeFoldPlus) in place of the [0, 8p) ones where every modulus of
 // the launch allows them -- the 60-bit moduli of the reference's parameter sets, the 61-bit BEHZ auxiliary primes: the
@@ -1153,7 +1156,7 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD, ROWS>
                   : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD, ROWS>
                                         : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD, ROWS>;
-    if constexpr (kShiftFactors<LOGN, false> && SPREAD == kSourceSlab) {
+    if constexpr (kShiftFactors<LOGN> && SPREAD == kSourceSlab) {
         // every modulus of the launch is just below a power of two: the gathered twiddles' factors come by a shift
         if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
             kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
@@ -1201,10 +1204,6 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
-    if constexpr (kShiftFactors<LOGN, true> && SOURCE == kInverseFromSlab) {
-        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
-            kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
-    }
     if constexpr (kFoldShape<LOGN, LOGT>) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
             const int fold = fold_mode(ctx, map.mod_base, map.band_rows);

@@ -199,7 +199,14 @@ int PolyContext::upload() {
                 const u64 p = moduli_[i];
                 for (size_t k = 0; k < n; ++k) {
                     const u64 w = table[i * n + k].x;
-                    pairs[i * n + k] = U64x2{w, split_shifted(w, p)};
+                    u64 shifted = split_shifted(w, p);
+                    // inverse tables of the moduli that take the limb-wise butterflies (device_context(): 2^40 <= p < 2^55):
+                    // w 2^32 mod p in signed limbs, t0s + t1' 2^32 with t1' = t1 + (t0 >> 31) -- the inverse butterfly
+                    // multiplies a signed difference (device_math.hpp split_mul_signed); the fold butterflies (p > 2^55)
+                    // read the plain word
+                    if (direction == 1 && p >= (static_cast<u64>(1) << 40) && p < (static_cast<u64>(1) << 55))
+                        shifted += (shifted & 0x80000000ull) << 1;
+                    pairs[i * n + k] = U64x2{w, shifted};
                     factors[i * n + k] = split_factors(w, p);
                 }
             }
