@@ -120,18 +120,20 @@ struct WordArith<uint32_t> {
     }
 };
 
-// V consecutive coefficients of a row per lane.  The base-conversion kernels take one 8-byte word per lane on 8-byte slabs
-// (they are bound by their multiply-adds there: about 400 issue slots per coefficient at L = 4) and FOUR 4-byte words on
-// 4-byte slabs, whose arithmetic is a fifth of that: one 16-byte access per lane and row instead of four 4-byte ones,
-// lift 129.6 -> 102.9 us and floor 211.3 -> 187.7 us per 2048 products at n_4096_logq_27_28_28
-// (profiles/r04n_word32_base_conversions_ab.txt; two words per lane: 112.8 / 199.0).  Rows whose base is not 16-byte
-// aligned fall back to one word per lane.
+// V consecutive coefficients of a row per lane.  4-byte slabs: FOUR words per lane in lift and floor (one 16-byte access per
+// lane and row instead of four 4-byte ones: lift 129.6 -> 102.9 us and floor 211.3 -> 187.7 us per 2048 products at
+// n_4096_logq_27_28_28, profiles/r04n_word32_base_conversions_ab.txt; two words per lane: 112.8 / 199.0).  8-byte slabs: the
+// kernels are bound by their multiply-adds (about 400 issue slots per coefficient at L = 4); the lift takes two words per
+// lane (kLiftPairs below), the floor one.  Rows whose base is not 16-byte aligned fall back to one word per lane.
 template <int V, typename W>
 __device__ __forceinline__ void load_words(const W* p, uint64_t (&x)[V]) {
     if constexpr (V == 1) {
         x[0] = stream_load(p);
+    } else if constexpr (V == 2 && sizeof(W) == 8) {
+        const StreamWords pair = __builtin_nontemporal_load(reinterpret_cast<const StreamWords*>(p));
+        x[0] = pair.x;
+        x[1] = pair.y;
     } else if constexpr (V == 2) {
-        static_assert(sizeof(W) == 4, "two 4-byte words per lane");
         const uint64_t pair = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
         x[0] = lo32(pair);
         x[1] = hi32(pair);
@@ -148,8 +150,10 @@ template <int V, typename W>
 __device__ __forceinline__ void store_words(W* p, const uint64_t (&x)[V]) {
     if constexpr (V == 1) {
         stream_store(p, x[0]);
+    } else if constexpr (V == 2 && sizeof(W) == 8) {
+        const StreamWords pair = {x[0], x[1]};
+        __builtin_nontemporal_store(pair, reinterpret_cast<StreamWords*>(p));
     } else if constexpr (V == 2) {
-        static_assert(sizeof(W) == 4, "two 4-byte words per lane");
         __builtin_nontemporal_store(lo32(x[0]) | (x[1] << 32), reinterpret_cast<uint64_t*>(p));
     } else {
         static_assert(V == 4 && sizeof(W) == 4, "four 4-byte words per lane");
@@ -157,6 +161,10 @@ __device__ __forceinline__ void store_words(W* p, const uint64_t (&x)[V]) {
         __builtin_nontemporal_store(quad, reinterpret_cast<StreamWords*>(p));
     }
 }
+// 8-byte slabs: the bounded lift takes two coefficients per lane (one 16-byte access per lane and row; scalar constants
+// and addresses shared by both): 588.7 -> 560.7 us per 1024 products at N = 8192, L = 4; the floor gained under 1 % that way
+// and stays at one (profiles/r04p_behz_two_coefficients_per_lane.txt)
+constexpr bool kLiftPairs = true;
 template <typename W>
 inline bool quad_aligned(const W* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -724,8 +732,17 @@ struct LiftLauncher {
         if constexpr (sizeof(W) == 8) {
             if (tool.wide_reduce_ok != 0) {
                 launched = true;
-                hipLaunchKernelGGL((lift_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0, s,
-                                   in, out, tool, polys, layout);
+                bool pairs = false;
+                if constexpr (kLiftPairs && L <= 6) {  // two coefficients per lane stay within 64 registers up to L = 6
+                    pairs = quad_aligned(in) && quad_aligned(out) && layout.in_item_stride % 2 == 0 &&
+                            layout.out_item_stride % 2 == 0 && tool.log_degree >= 1;
+                    if (pairs)
+                        hipLaunchKernelGGL((lift_kernel<L, W, true, 2>), dim3(exact_grid(polys << (tool.log_degree - 1))),
+                                           dim3(kThreads), 0, s, in, out, tool, polys, layout);
+                }
+                if (!pairs)
+                    hipLaunchKernelGGL((lift_kernel<L, W, true>), dim3(exact_grid(polys << tool.log_degree)), dim3(kThreads), 0,
+                                       s, in, out, tool, polys, layout);
             }
         }
         if constexpr (sizeof(W) == 4) {

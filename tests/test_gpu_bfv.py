@@ -735,6 +735,27 @@ def test_uint32_extremes_and_inner_product_cadence(oracle, count):
     assert np.array_equal(host(ours.floor_qbsk_to_q(dev(y), ours.L)), np.stack([tool.floor_qbsk_to_q(p) for p in y]))
 
 
+def test_lift_two_coefficients_per_lane(oracle):
+    """liftQToQBsk on 8-byte slabs at the C3 ring (N=8192, five 55-bit moduli): the bounded kernel takes two coefficients
+    per lane (one 16-byte access per row) when every row starts on a 16-byte boundary and one otherwise -- a slab that
+    starts 8 bytes into its allocation gives the same words as the aligned one, and both equal the oracle's."""
+    import torch
+
+    degree = 8192
+    q = oracle.generate_primes([55] * 5, False, degree)
+    ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
+    rng = np.random.default_rng(733)
+    x = _uniform(rng, (3,), q[:-1], degree)
+    expected = np.stack([ref.rns_tool().lift_q_to_qbsk(p) for p in x])
+    aligned = heamd.to_device(x)
+    assert aligned.data_ptr() % 16 == 0
+    assert np.array_equal(heamd.to_host(ours.lift_q_to_qbsk(aligned)), expected)
+    shifted = torch.empty(aligned.numel() + 1, dtype=aligned.dtype, device=aligned.device)[1:]
+    shifted.copy_(aligned.reshape(-1))
+    assert shifted.data_ptr() % 16 == 8
+    assert np.array_equal(heamd.to_host(ours.lift_q_to_qbsk(shifted)), expected)
+
+
 def test_uint32_base_conversions_four_words_per_lane(oracle):
     """Bfv<UInt32> lift / floor at n_4096_logq_27_28_28: the kernels take four 4-byte words per lane (one 16-byte access)
     when every row starts on a 16-byte boundary and one word per lane otherwise -- a slab that starts 4 bytes into its
