@@ -329,7 +329,9 @@ int BfvContext::build_tool(uint32_t k) {
         unsigned __int128 q_sum = 0, bsk_sum = 0;
         for (size_t i = 0; i < L; ++i) q_sum += q[i] - 1;
         for (size_t j = 0; j < L; ++j) bsk_sum += bsk[j] - 1;
-        for (size_t j = 0; j <= L; ++j) ok = ok && fits(q_sum * (bsk[j] - 1), arena.at<DeviceModulus>(o_ext_moduli)[j]);
+        // (the lift adds the mTilde correction's product, two residues mod Bsk_j, to its sums)
+        for (size_t j = 0; j <= L; ++j)
+            ok = ok && fits((q_sum + (bsk[j] - 1)) * (bsk[j] - 1), arena.at<DeviceModulus>(o_ext_moduli)[j]);
         ok = ok && fits(bsk_sum * (top_m_sk - 1), arena.at<DeviceModulus>(o_alpha_modulus)[0]);
         ok = ok && fits(bsk_sum * (m_sk - 1), arena.at<DeviceModulus>(o_ext_moduli)[L]);
         for (size_t i = 0; i < L; ++i)

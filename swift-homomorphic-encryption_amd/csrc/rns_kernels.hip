@@ -212,10 +212,18 @@ __global__ void __launch_bounds__(kThreads)
         bool below[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            typename A::Sum acc = A::first(y[v][0], tool.q_to_ext[(L + 1) * L + 0]);
+            if (sizeof(W) == 8 && last.p == kMTildeValue) {
+                // mod mTilde = 2^32 only the low words of the terms count: one multiply-add each (uniform branch)
+                uint64_t low = mul32(lo32(y[v][0]), lo32(tool.q_to_ext[(L + 1) * L + 0]));
 #pragma unroll
-            for (int i = 1; i < L; ++i) A::add(acc, y[v][i], tool.q_to_ext[(L + 1) * L + i]);
-            r[v] = last.p == kMTildeValue ? (A::low_word(acc) & (kMTildeValue - 1)) : A::reduce(acc, last);
+                for (int i = 1; i < L; ++i) low = mad32(lo32(y[v][i]), lo32(tool.q_to_ext[(L + 1) * L + i]), low);
+                r[v] = low & (kMTildeValue - 1);
+            } else {
+                typename A::Sum acc = A::first(y[v][0], tool.q_to_ext[(L + 1) * L + 0]);
+#pragma unroll
+                for (int i = 1; i < L; ++i) A::add(acc, y[v][i], tool.q_to_ext[(L + 1) * L + i]);
+                r[v] = last.p == kMTildeValue ? (A::low_word(acc) & (kMTildeValue - 1)) : A::reduce(acc, last);
+            }
             r[v] = A::shoup(r[v], tool.neg_inv_q_mod_mtilde, kMTildeValue);
             below[v] = r[v] < (kMTildeValue >> 1);
         }
@@ -229,10 +237,19 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
                 for (int i = 1; i < L; ++i) A::template add<BOUNDED>(sum, y[v][i], tool.q_to_bsk_scaled[j * L + i]);
                 const uint64_t centered = below[v] ? r[v] : r[v] + m.p - kMTildeValue;  // RnsTool.swift:357-361
-                // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants;
-                // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
+                // (x'_j + (Q mod Bsk_j) r) mTilde^-1 (RnsTool.swift:363-364) with mTilde^-1 already inside both constants
                 const U64x2 scaled = tool.q_mod_bsk_scaled[j];
-                const uint64_t unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
+                uint64_t unfolded;
+                if constexpr (BOUNDED && sizeof(W) == 8) {
+                    // the r term is one more product of the same exact sum (through the multiply-add that counts its
+                    // carries: both factors are 61-bit words; RnsToolDevice::wide_reduce_ok covers the longer sum): one
+                    // reduction, below 5p, instead of a reduction and a Shoup product
+                    A::template add<false>(sum, centered, scaled.x);
+                    unfolded = A::template reduce_lazy<BOUNDED>(sum, m);
+                } else {
+                    // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
+                    unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
+                }
                 lifted[v] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
             }
             store_words<V>(dst + (L + j) * n, lifted);
