@@ -460,6 +460,13 @@ constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac =
               kInverseFromKeyMacFinish = 4;
 constexpr bool is_key_mac(int source) { return source == kInverseFromKeyMac || source == kInverseFromKeyMacFinish; }
 constexpr bool kKeyMacBoundedReduce = true;
+// The fused inverse loads (tensor product, key MAC) hand the transform the one-word-quotient Barrett's remainder as it
+// comes, in [0, 5p), where the butterflies take lazy input: the limb-wise ones (any word below 2^63; the stage bounds are
+// those of a row whose first kLazyInputStages stages already ran: inverse_in_shift(3) = 5 covers 5p) and the fold ones
+// (words below 6p).  Three conditional subtracts less per word; the [0, 8p) / exact butterflies keep canonical input.
+template <int MODE>
+constexpr bool kLazyTransformInput = MODE == kModeSplit || is_fold(MODE);
+constexpr int kLazyInputStages = 3;
 // Which two rows a key-MAC workgroup takes where the register file holds two: the same key column of two consecutive
 // polynomials, the other column in a sibling workgroup of the same XCD.  The counters read 1.7 x the spread slab for this
 // kernel (profiles/r03z_pmc_traffic_per_kernel.txt), which suggested pairing the two COLUMNS of one polynomial instead
@@ -507,6 +514,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr bool SCALED = SOURCE == kInverseFromTensor || SOURCE == kInverseFromSlabScaled;
     constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
     constexpr bool KEYMAC = is_key_mac(SOURCE), FINISH = SOURCE == kInverseFromKeyMacFinish;
+    constexpr int INPUT_STAGES = (TENSOR || KEYMAC) && kLazyTransformInput<MODE> ? kLazyInputStages : 0;
     static_assert(ROWS == 1 || SOURCE != kInverseFromSlabScaled, "scaled plain slabs go one row per workgroup");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -566,8 +574,14 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     if (c != 1) {
                         const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
                         const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
-                        v[k][r] = barrett_mul(a.x, b.x, p, factor, shift);
-                        v[k][r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
+                        if constexpr (kLazyTransformInput<MODE>) {
+                            // (these moduli are 41 .. 61 bits: wide_shift != 0, p^2 inside the bounded reduction's range)
+                            v[k][r] = reduce_product_sum_bounded_lazy(product_sum_first(a.x, b.x), mod);
+                            v[k][r + 1] = reduce_product_sum_bounded_lazy(product_sum_first(a.y, b.y), mod);
+                        } else {
+                            v[k][r] = barrett_mul(a.x, b.x, p, factor, shift);
+                            v[k][r + 1] = barrett_mul(a.y, b.y, p, factor, shift);
+                        }
                     } else {
                         const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
                         const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
@@ -578,7 +592,10 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                         ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
                         product_sum_add(cross0, a1.x, b0.x);
                         product_sum_add(cross1, a1.y, b0.y);
-                        if (mod.wide_shift != 0) {  // wave-uniform
+                        if constexpr (kLazyTransformInput<MODE>) {
+                            v[k][r] = reduce_product_sum_bounded_lazy(cross0, mod);
+                            v[k][r + 1] = reduce_product_sum_bounded_lazy(cross1, mod);
+                        } else if (mod.wide_shift != 0) {  // wave-uniform
                             v[k][r] = reduce_product_sum_bounded(cross0, mod);
                             v[k][r + 1] = reduce_product_sum_bounded(cross1, mod);
                         } else {
@@ -627,8 +644,13 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                     // (the one-word-quotient Barrett where the sum allows it: L products of canonical words stay below
                     // L p^2 < 2^(64 + wide_shift) = 2^(63 + bits(p)) whenever L p < 2^63)
                     if (kKeyMacBoundedReduce && mod.wide_shift != 0 && L <= 8 && uint64_t(L) * mod.p < (uint64_t(1) << 63)) {  // wave-uniform
-                        v[k][q] = reduce_product_sum_bounded(acc0, mod);
-                        v[k][q + 1] = reduce_product_sum_bounded(acc1, mod);
+                        if constexpr (kLazyTransformInput<MODE>) {
+                            v[k][q] = reduce_product_sum_bounded_lazy(acc0, mod);
+                            v[k][q + 1] = reduce_product_sum_bounded_lazy(acc1, mod);
+                        } else {
+                            v[k][q] = reduce_product_sum_bounded(acc0, mod);
+                            v[k][q + 1] = reduce_product_sum_bounded(acc1, mod);
+                        }
                     } else {
                         v[k][q] = reduce_product_sum(acc0, mod);
                         v[k][q + 1] = reduce_product_sum(acc1, mod);
@@ -764,9 +786,9 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 if (wide) with_end(std::true_type{});
                 else with_end(std::false_type{});
             };
-            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
-            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, 0, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
             const uint32_t store_lane = kLateLaneAddresses ? opaque32(tid) : tid;
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
