@@ -24,7 +24,7 @@ constexpr int kChains = 8;     // independent dependency chains per lane
 constexpr int kUnroll = 16;    // instructions per chain per loop iteration
 constexpr int kIters = 2000;
 
-enum Probe { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, LSHL_ADD_U64, ADD_U32, ADDCO_PAIR, CNDMASK, MAD_U32_U24, MUL_HI_U32_U24, NOT_B32, FMA_F64, CMP_GT_I64, CMP_GT_I32 };
+enum Probe { MAD_U64_U32, MAD_I64_I32, MUL_LO_U32, MUL_HI_U32, LSHL_ADD_U64, ADD_U32, ADDCO_PAIR, CNDMASK, MAD_U32_U24, MUL_HI_U32_U24, NOT_B32, FMA_F64, CMP_GT_I64, CMP_GT_I32 };
 
 template <int PROBE>
 __global__ void __launch_bounds__(256) probe_kernel(uint64_t* out, uint32_t seed, long long* cycles) {
@@ -42,6 +42,10 @@ __global__ void __launch_bounds__(256) probe_kernel(uint64_t* out, uint32_t seed
                 if constexpr (PROBE == MAD_U64_U32) {
                     uint64_t d, carry;
                     asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(acc[c]));
+                    acc[c] = d;
+                } else if constexpr (PROBE == MAD_I64_I32) {
+                    uint64_t d, carry;
+                    asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(acc[c]));
                     acc[c] = d;
                 } else if constexpr (PROBE == MUL_LO_U32) {
                     uint32_t d;
@@ -335,6 +339,7 @@ int main() {
     run_probe<ADD_U32>("v_add_u32", 1);
     run_probe<NOT_B32>("v_not_b32", 1);
     run_probe<MAD_U64_U32>("v_mad_u64_u32", 1);
+    run_probe<MAD_I64_I32>("v_mad_i64_i32", 1);
     run_probe<MUL_LO_U32>("v_mul_lo_u32", 1);
     run_probe<MUL_HI_U32>("v_mul_hi_u32", 1);
     run_probe<LSHL_ADD_U64>("v_lshl_add_u64", 1);

@@ -1,12 +1,11 @@
-COMPILE = ["ntt_kernels.hip", "poly_context.cpp"]
-DESCRIPTION = ("the inverse limb-wise butterfly multiplies x + bound - y as an unsigned word (rounds 2-4) instead of the signed "
-               "difference x - y: one more 64-bit addition per butterfly, plain inverse tables")
+COMPILE = ["ntt_kernels.hip"]
+DESCRIPTION = ("every limb-wise inverse transform multiplies x + bound - y as an unsigned word (rounds 2-4: kModeSplit) instead of the "
+               "signed difference x - y (kModeSplitSigned) where that is the committed form")
 EDITS = [
-    ("poly_context.cpp", "                    if (direction == 1 && p >= (static_cast<u64>(1) << 40) && p < (static_cast<u64>(1) << 55))",
-     "                    if (false && direction == 1 && p >= (static_cast<u64>(1) << 40) && p < (static_cast<u64>(1) << 55))"),
-    ("ntt_common.hpp", """        second = uniform ? split_mul_signed<true>(x - y, w.w, w.second, w.factors, neg_p, bias)
-                         : split_mul_signed<false>(x - y, w.w, w.second, w.factors, neg_p, bias);""",
-     """        (void)bias;
-        second = uniform ? split_mul_add<true, false>(0, x + bound - y, w.w, w.second, w.factors, neg_p)
-                         : split_mul_add<false, false>(0, x + bound - y, w.w, w.second, w.factors, neg_p);"""),
+    ("ntt_kernels.hip", "constexpr bool kSignedInverse = !(LOGN == 13 && (SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled));",
+     "constexpr bool kSignedInverse = false;"),
+    ("ntt_kernels.hip", "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, true>",
+     "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, true>"),
+    ("ntt_kernels.hip", "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, false>",
+     "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, false>"),
 ]

@@ -54,6 +54,7 @@ struct DeviceContext {
     // pairs (w, w 2^32 mod p), factors floor(w 2^32 / 2p) | floor((w 2^32 mod p) 2^32 / 2p) << 32
     const U64x2* forward_split_pairs;      // [L][N]
     const U64x2* inverse_split_pairs;      // [L][N]
+    const U64x2* inverse_split_pairs_signed;  // [L][N] the same with w 2^32 mod p in signed limbs (kModeSplitSigned)
     const uint64_t* forward_split_factors; // [L][N]
     const uint64_t* inverse_split_factors; // [L][N]
     uint32_t degree;

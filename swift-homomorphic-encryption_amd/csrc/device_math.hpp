@@ -329,24 +329,28 @@ __device__ __forceinline__ uint64_t split_mul_signed(uint64_t d, uint64_t w, uin
     const uint32_t f = lo32(f_pair), ft = hi32(f_pair);
     const uint32_t n0 = lo32(neg_2p), n1 = hi32(neg_2p);
     uint64_t q, c0, c1, carry;
-#define HEAMD_SPLIT_SIGNED_BODY                       \
-    "v_mad_u64_u32 %0, %3, %4, %10, 2.0\n\t"          \
-    "v_mad_u64_u32 %1, %3, %4, %6, %12\n\t"           \
-    "v_mad_u64_u32 %2, %3, %4, %8, 0\n\t"             \
-    "v_mad_i64_i32 %0, %3, %5, %11, %0\n\t"           \
-    "v_mad_i64_i32 %1, %3, %5, %7, %1\n\t"            \
-    "v_mad_i64_i32 %2, %3, %5, %9, %2"
-    // operands: 0 q, 1 c0, 2 c1, 3 carry | 4 b0, 5 b1, 6 w0, 7 t0, 8 w1, 9 t1, 10 f, 11 ft, 12 bias
+    // two blocks: the quotient's chain first (its words are free again once the high word is taken), then the columns
     if constexpr (UNIFORM) {
-        asm(HEAMD_SPLIT_SIGNED_BODY
-            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
-            : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "s"(w1), "s"(t1), "s"(f), "s"(ft), "v"(bias));
+        asm("v_mad_u64_u32 %0, %1, %2, %4, 2.0\n\t"
+            "v_mad_i64_i32 %0, %1, %3, %5, %0"
+            : "=&v"(q), "=&s"(carry) : "v"(b0), "v"(b1), "s"(f), "s"(ft));
+        asm("v_mad_u64_u32 %0, %2, %3, %5, %9\n\t"
+            "v_mad_u64_u32 %1, %2, %3, %7, 0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %4, %8, %1"
+            : "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "s"(w0), "s"(t0), "s"(w1), "s"(t1), "v"(bias));
     } else {
-        asm(HEAMD_SPLIT_SIGNED_BODY
-            : "=&v"(q), "=&v"(c0), "=&v"(c1), "=&s"(carry)
-            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "v"(w1), "v"(t1), "v"(f), "v"(ft), "s"(bias));
+        asm("v_mad_u64_u32 %0, %1, %2, %4, 2.0\n\t"
+            "v_mad_i64_i32 %0, %1, %3, %5, %0"
+            : "=&v"(q), "=&s"(carry) : "v"(b0), "v"(b1), "v"(f), "v"(ft));
+        asm("v_mad_u64_u32 %0, %2, %3, %5, %9\n\t"
+            "v_mad_u64_u32 %1, %2, %3, %7, 0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %4, %8, %1"
+            : "=&v"(c0), "=&v"(c1), "=&s"(carry)
+            : "v"(b0), "v"(b1), "v"(w0), "v"(t0), "v"(w1), "v"(t1), "s"(bias));
     }
-#undef HEAMD_SPLIT_SIGNED_BODY
     uint64_t carry2;
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\t"
         "v_mad_u64_u32 %1, %2, %3, %5, %1"

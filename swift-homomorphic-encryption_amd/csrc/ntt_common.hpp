@@ -121,9 +121,12 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                                    conditional subtract per butterfly: the forward transform never folds (a word
 //                                    gains at most 8p per stage: < (1 + 8 log2 N) p <= 113 p < 2^62), the inverse
 //                                    brings its sums back under 2p once their bound reaches 2^9 p (one round for
-//                                    N <= 8192) and multiplies its differences x - y as SIGNED words (split_mul_signed:
-//                                    no bound added to keep them non-negative; the inverse tables hold w 2^32 mod p in
-//                                    signed limbs for that); one float-estimated quotient makes outputs canonical.
+//                                    N <= 8192); one float-estimated quotient makes outputs canonical.
+//   kModeSplitSigned  inverse transforms only: the same schedule with the differences x - y multiplied as SIGNED words
+//                    (split_mul_signed: no bound added to keep them non-negative; a second inverse table holds
+//                    w 2^32 mod p in signed limbs for that) -- one 64-bit addition less per butterfly.  Used where it
+//                    measures faster: every limb-wise inverse kernel but the plain-slab one at N = 8192
+//                    (profiles/r04t_inverse_forms_ab.txt).
 //   kModeSplitShift  the same for moduli just below a power of two (DeviceModulus::split_shift != 0): a gathered twiddle
 //                    is its 16 bytes (w, w 2^32 mod p) alone and the two 31-bit quotient factors are read off those
 //                    words by a shift instead of fetched -- one gather instruction per twiddle instead of two.  A shifted
@@ -136,8 +139,9 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    product folds back by a shift (device_math.hpp fold_mul: 5 multiply-adds, products in [0, 6p), no
 //                    factor table), values in [0, 14p) with one conditional subtract per butterfly like the [0, 8p)
 //                    schedule it replaces where the moduli allow it (DeviceContext::fold_minus_mask / fold_plus_mask).
-constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4, kModeFoldMinus = 5, kModeFoldPlus = 6;
-constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift; }
+constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4, kModeFoldMinus = 5, kModeFoldPlus = 6,
+              kModeSplitSigned = 7;
+constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift || mode == kModeSplitSigned; }
 constexpr bool is_fold(int mode) { return mode == kModeFoldMinus || mode == kModeFoldPlus; }
 template <int MODE>
 __device__ __forceinline__ FoldConstants mode_fold_constants(uint64_t p) {
@@ -180,7 +184,8 @@ struct Twiddles {
         const size_t at = (static_cast<size_t>(modulus_index) << log_degree) + skip;
         shift = 0;
         if constexpr (is_split(MODE) || is_fold(MODE)) {  // (w, w 2^32 mod p); the fold butterflies use no factors
-            pairs = (inverse ? ctx.inverse_split_pairs : ctx.forward_split_pairs) + at;
+            pairs = (inverse ? (MODE == kModeSplitSigned ? ctx.inverse_split_pairs_signed : ctx.inverse_split_pairs)
+                             : ctx.forward_split_pairs) + at;
             factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
             pair_resource = make_resource(pairs, (16u << log_degree) - 16u * skip);
             factor_resource = make_resource(factors, (8u << log_degree) - 8u * skip);
@@ -208,7 +213,7 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
         t.second = pair.y;
         t.factors = 0;
         if constexpr (is_split(MODE)) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
-    } else if constexpr (MODE == kModeSplit) {
+    } else if constexpr (MODE == kModeSplit || MODE == kModeSplitSigned) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         const Dwordx2 factors = __builtin_amdgcn_raw_buffer_load_b64(tw.factor_resource, lane_index << 3, fixed_index << 3, 0);
         t.w = pack64(pair.x, pair.y);
@@ -246,7 +251,7 @@ struct Lazy {
     // products < p << this (split: [0, 8p); with shifted factors [0, 12p))
     // (the fold modes keep their own fixed ranges -- products below 6p, forward words below 14p, inverse words below 6p --
     // in forward_butterfly / inverse_butterfly; the two constants below are not used for them)
-    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : MODE == kModeSplit ? 3 : is_fold(MODE) ? 3 : 4;
+    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : (MODE == kModeSplit || MODE == kModeSplitSigned) ? 3 : is_fold(MODE) ? 3 : 4;
     // cap on stage inputs of the inverse transform, as a shift of p (split: sums of two stay below 2^9 p < 2^64)
     static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : is_fold(MODE) ? 3 : 8;
     // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
@@ -528,7 +533,8 @@ __device__ __forceinline__ uint64_t vector_copy(uint64_t uniform_value) {
 // stage's sums take the Shoup product; otherwise they are divided by N exactly (divide_by_degree).
 // One inverse butterfly below the last stage: (x, y) -> (x + y, (x - y + bound) w) with inputs below `bound` = p <<
 // in_shift; `fold` brings the sum back under the cap (inverse_in_shift).  Split mode: (x + y, (x - y) w) with the
-// difference multiplied as a signed word (`bias`: split_signed_bias(p), in vector registers beside a wave-uniform twiddle).
+// difference multiplied as a signed word in kModeSplitSigned (`bias`: split_signed_bias(p), in vector registers beside a
+// wave-uniform twiddle).
 template <int MODE>
 __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& second, const TwiddleWords& w, bool uniform,
                                                   uint64_t p, uint64_t neg_p, uint64_t bound, bool fold,
@@ -544,19 +550,25 @@ __device__ __forceinline__ void inverse_butterfly(uint64_t& first, uint64_t& sec
         return;
     }
     uint64_t sum = x + y;
-    if constexpr (is_split(MODE)) {
+    if constexpr (MODE == kModeSplitSigned) {
         // x - y goes to the product as a signed word (device_math.hpp split_mul_signed: the bound that would keep it
         // non-negative is one 64-bit addition per butterfly; inputs are below 2^63, so the difference cannot wrap); the
-        // product comes back in (0, 6p)
-        static_assert(MODE == kModeSplit, "the inverse tables hold w 2^32 mod p in signed limbs: no factors read off its words");
-        if (fold) sum = LazyReducer(p).lazy(sum);
-        first = sum;
+        // product comes back in (0, 6p).  The product first: its operands (x - y, the twiddle) die in it, and the sum can
+        // then take x's registers.
         second = uniform ? split_mul_signed<true>(x - y, w.w, w.second, w.factors, neg_p, bias)
                          : split_mul_signed<false>(x - y, w.w, w.second, w.factors, neg_p, bias);
+        if (fold) sum = LazyReducer(p).lazy(sum);
+        first = sum;
         return;
     }
     const uint64_t diff = x + bound - y;
-    if (fold) sum = csub_uniform(sum, bound);
+    if (fold) {
+        if constexpr (is_split(MODE)) {
+            sum = LazyReducer(p).lazy(sum);
+        } else {
+            sum = csub_uniform(sum, bound);
+        }
+    }
     first = sum;
     second = uniform ? Lazy<MODE>::template mul<true>(diff, w, neg_p) : Lazy<MODE>::template mul<false>(diff, w, neg_p);
 }
@@ -610,7 +622,7 @@ __device__ __forceinline__ void inverse_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
         // twiddles; beside wave-uniform ones (their words take the instruction's one scalar operand) a vector copy made
         // here, once per twiddle, so that it is not carried through the gathered stages
         uint64_t bias = split_signed_bias(p);
-        if constexpr (is_split(MODE)) {
+        if constexpr (MODE == kModeSplitSigned) {
             if (uniform && !last_stage) bias = vector_copy(bias);
         }
 #pragma unroll

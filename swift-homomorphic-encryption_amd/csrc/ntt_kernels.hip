@@ -151,10 +151,27 @@ constexpr bool kTopPartialOrder = LOGN == 13 && LOGE == 3 && INVERSE && FROM_SLA
 // index, i.e. next to where it uses them -- the compiler otherwise computes all of them at the top of the kernel and
 // carries them through the passes, in scratch where the register file is full.
 constexpr bool kLateLaneAddresses = true;
+// The lane index again, without a vector register between uses: wave base (the first lane's index -- one scalar register,
+// computed once) + the lane's position in its wave (two instructions where it is needed).
+__device__ __forceinline__ uint32_t late_lane(uint32_t lane) {
+    uint32_t within;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(within));
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lane))) + within;
+}
+// Which form a step takes: the kernels of kModeSplitSigned re-derive the index (they sit at the 64-register cap with
+// nothing to spare: no scratch in the plain-slab inverse at N = 4096 and in the key-MAC transform that way, N = 4096 inverse
+// -2 ... -4 %); the others carry an opaque copy (the plain-slab inverse at N = 8192 is 2 % faster with it, and the forward
+// kernels fit either way) -- profiles/r04t_inverse_forms_ab.txt.
+template <int MODE>
+__device__ __forceinline__ uint32_t step_lane(uint32_t lane) {
+    if constexpr (!kLateLaneAddresses) return lane;
+    else if constexpr (MODE == kModeSplitSigned) return late_lane(lane);
+    else return opaque32(lane);
+}
 template <int LOGN, int LOGE, int LO_FROM, int LO_TO, int MODE, int ROWS>
 __device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw, uint64_t p,
                                              uint64_t* lds) {
-    const uint32_t tid = kLateLaneAddresses ? opaque32(lane) : lane;
+    const uint32_t tid = step_lane<MODE>(lane);
     const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, false>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, LOGE, LO_TO, LOGE, ROWS>(v, tid, lds);
     forward_pass<LOGN, LOGE, LO_TO, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
@@ -219,7 +236,7 @@ template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool
           int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
-    const uint32_t tid = kLateLaneAddresses ? opaque32(lane) : lane;
+    const uint32_t tid = step_lane<MODE>(lane);
     TwiddleWords first{0, 0, 0};
     if constexpr (kInverseFirstTwiddleEarly<MODE>)
         first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
@@ -460,12 +477,17 @@ constexpr int kInverseFromSlab = 0, kInverseFromTensor = 1, kInverseFromKeyMac =
               kInverseFromKeyMacFinish = 4;
 constexpr bool is_key_mac(int source) { return source == kInverseFromKeyMac || source == kInverseFromKeyMacFinish; }
 constexpr bool kKeyMacBoundedReduce = true;
+// Where the limb-wise inverse transform multiplies its differences as signed words (ntt_common.hpp kModeSplitSigned): the
+// plain-slab transform at N = 8192 (partial pass on the top bits) is 2.5 % faster in the unsigned form, N = 4096 1.8 % and the
+// interleaved rows of N = 16384 3.3 % faster in the signed one, the key-MAC transforms 1.9 % (profiles/r04t_inverse_forms_ab.txt).
+template <int LOGN, int SOURCE>
+constexpr bool kSignedInverse = !(LOGN == 13 && (SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled));
 // The fused inverse loads (tensor product, key MAC) hand the transform the one-word-quotient Barrett's remainder as it
 // comes, in [0, 5p), where the butterflies take lazy input: the limb-wise ones (any word below 2^63; the stage bounds are
 // those of a row whose first kLazyInputStages stages already ran: inverse_in_shift(3) = 5 covers 5p) and the fold ones
 // (words below 6p).  Three conditional subtracts less per word; the [0, 8p) / exact butterflies keep canonical input.
 template <int MODE>
-constexpr bool kLazyTransformInput = MODE == kModeSplit || is_fold(MODE);
+constexpr bool kLazyTransformInput = MODE == kModeSplit || MODE == kModeSplitSigned || is_fold(MODE);
 constexpr int kLazyInputStages = 3;
 // Which two rows a key-MAC workgroup takes where the register file holds two: the same key column of two consecutive
 // polynomials, the other column in a sibling workgroup of the same XCD.  The counters read 1.7 x the spread slab for this
@@ -683,7 +705,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const bool wide = half >= p;
             constexpr int kEndPlain = 0, kEndGalois = 1, kEndExpand = 2;
             auto finish = [&](int k, uint64_t (&row)[E]) {
-                const uint32_t lane = kLateLaneAddresses ? opaque32(tid) : tid;
+                const uint32_t lane = step_lane<MODE>(tid);
                 const uint32_t lane_words = lane_part<LOGN, LOGE, LOL, LOGE>(lane), lane_bytes = lane_words << 3;
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
@@ -789,7 +811,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
         } else {
             inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
-            const uint32_t store_lane = kLateLaneAddresses ? opaque32(tid) : tid;
+            const uint32_t store_lane = step_lane<MODE>(tid);
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
                 global_store<LOGN, LOGE, LOL, LOGE>(v[k], store_lane, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
@@ -1223,7 +1245,9 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
                                  const InverseSource& source_spec, hipStream_t stream) {
     constexpr int LOGE = LOGN - LOGT;
     constexpr size_t lds_bytes = (Schedule<LOGN, LOGE>::P > 1) ? lds_words(1u << LOGN) * sizeof(uint64_t) : 0;
-    auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, kModeSplit, SOURCE, ROWS>
+    // (the limb-wise inverse in its signed form wherever that measured faster: ntt_common.hpp kModeSplitSigned)
+    constexpr int SPLIT = kSignedInverse<LOGN, SOURCE> ? kModeSplitSigned : kModeSplit;
+    auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, SPLIT, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
     if constexpr (kFoldShape<LOGN, LOGT>) {
@@ -1254,11 +1278,11 @@ hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const Devi
                  : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox>
                                        : ntt_forward_interleaved<LOGS, kModeExact>;
     } else if (ctx.scaled_inverse_degree != 0) {
-        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, true>
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, true>
                  : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, true>
                                        : ntt_inverse_interleaved<LOGS, kModeExact, true>;
     } else {
-        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, false>
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, false>
                  : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false>
                                        : ntt_inverse_interleaved<LOGS, kModeExact, false>;
     }

@@ -175,7 +175,7 @@ int PolyContext::upload() {
     const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
     // limb-wise Shoup form of both twiddle tables: pairs (16 B) and quotient factors (8 B) per entry
     const size_t bytes_factors = round_up(count * n * sizeof(u64));
-    const size_t total = bytes_moduli + 4 * bytes_twiddles + bytes_inverse_q_last + 2 * bytes_factors;
+    const size_t total = bytes_moduli + 5 * bytes_twiddles + bytes_inverse_q_last + 2 * bytes_factors;
     HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
     char* base = static_cast<char*>(device_block_);
     HEAMD_HIP_TRY(hipMemcpy(base, host_moduli_.data(), count * sizeof(DeviceModulus), hipMemcpyHostToDevice));
@@ -190,6 +190,7 @@ int PolyContext::upload() {
     char* inverse_pairs = forward_pairs + bytes_twiddles;
     char* forward_factors = inverse_pairs + bytes_twiddles;
     char* inverse_factors = forward_factors + bytes_factors;
+    char* inverse_pairs_signed = inverse_factors + bytes_factors;
     {
         std::vector<U64x2> pairs(count * n);
         std::vector<u64> factors(count * n);
@@ -199,14 +200,7 @@ int PolyContext::upload() {
                 const u64 p = moduli_[i];
                 for (size_t k = 0; k < n; ++k) {
                     const u64 w = table[i * n + k].x;
-                    u64 shifted = split_shifted(w, p);
-                    // inverse tables of the moduli that take the limb-wise butterflies (device_context(): 2^40 <= p < 2^55):
-                    // w 2^32 mod p in signed limbs, t0s + t1' 2^32 with t1' = t1 + (t0 >> 31) -- the inverse butterfly
-                    // multiplies a signed difference (device_math.hpp split_mul_signed); the fold butterflies (p > 2^55)
-                    // read the plain word
-                    if (direction == 1 && p >= (static_cast<u64>(1) << 40) && p < (static_cast<u64>(1) << 55))
-                        shifted += (shifted & 0x80000000ull) << 1;
-                    pairs[i * n + k] = U64x2{w, shifted};
+                    pairs[i * n + k] = U64x2{w, split_shifted(w, p)};
                     factors[i * n + k] = split_factors(w, p);
                 }
             }
@@ -215,9 +209,15 @@ int PolyContext::upload() {
             HEAMD_HIP_TRY(hipMemcpy(direction == 0 ? forward_factors : inverse_factors, factors.data(),
                                     count * n * sizeof(u64), hipMemcpyHostToDevice));
         }
+        // the inverse table once more with w 2^32 mod p in signed limbs, t0s + t1' 2^32 with t1' = t1 + (t0 >> 31): the
+        // butterflies of kModeSplitSigned multiply a signed difference (device_math.hpp split_mul_signed); `pairs` still
+        // holds the inverse direction
+        for (U64x2& pair : pairs) pair.y += (pair.y & 0x80000000ull) << 1;
+        HEAMD_HIP_TRY(hipMemcpy(inverse_pairs_signed, pairs.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
     }
     dev_.forward_split_pairs = reinterpret_cast<const U64x2*>(forward_pairs);
     dev_.inverse_split_pairs = reinterpret_cast<const U64x2*>(inverse_pairs);
+    dev_.inverse_split_pairs_signed = reinterpret_cast<const U64x2*>(inverse_pairs_signed);
     dev_.forward_split_factors = reinterpret_cast<const u64*>(forward_factors);
     dev_.inverse_split_factors = reinterpret_cast<const u64*>(inverse_factors);
     dev_.moduli = reinterpret_cast<const DeviceModulus*>(base);
