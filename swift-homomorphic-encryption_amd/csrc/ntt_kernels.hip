@@ -278,19 +278,21 @@ __device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 <
         lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
         lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[ROWS - 1], tid, lds);
     }
-#pragma unroll
-    for (int k = 0; k < ROWS; ++k) {
-        if constexpr (ROWS == 2) {
-            if (k == 1) {
-                lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
-                lds_load<LOGN, LOGE, LOL, LOGE, SCHEME>(v[ROWS - 1], tid, lds);
-            }
+    // (the rows one after the other as straight-line code, not as a loop to unroll: with the key switch's three ends in it the
+    // body is past the optimizer's unrolling budget, and a rolled loop indexes the rows at run time -- i.e. out of scratch)
+    auto one_row = [&](auto row_tag) {
+        constexpr int k = decltype(row_tag)::value;
+        if constexpr (k == 1) {
+            lds_transpose_fence<LOGN, LOGE, LO_FROM, LOL>();
+            lds_load<LOGN, LOGE, LOL, LOGE, SCHEME>(v[ROWS - 1], tid, lds);
         }
         uint64_t (&row)[1][E] = *reinterpret_cast<uint64_t (*)[1][E]>(&v[k]);
         const TwiddleWords head[1] = {inverse_first_twiddle<LOGN, LOGE, LOL, LOGE, MODE, true>(tw, tid)};
         inverse_pass<LOGN, LOGE, LOL, LOGE, MODE, true, 1, SCALED, PRIOR, LOGD, 0, 1>(row, tid, tw, mod, false, head);
         finish(k, row[0]);
-    }
+    };
+    one_row(std::integral_constant<int, 0>{});
+    if constexpr (ROWS == 2) one_row(std::integral_constant<int, 1>{});
 }
 
 // Finish: NoFinish, or a callable (row index, the row's canonical words in the top layout) that takes over each row as it

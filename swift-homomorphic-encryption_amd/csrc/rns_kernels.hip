@@ -762,7 +762,7 @@ struct LiftLauncher {
                                        s, in, out, tool, polys, layout);
             }
         }
-        if constexpr (sizeof(W) == 4) {
+        if constexpr (sizeof(W) == 4 && L <= 8) {  // (beyond L = 8 four coefficients per lane no longer fit the register file)
             // four words per lane where every row starts on a 16-byte boundary (strides are multiples of N in practice)
             if (quad_aligned(in) && quad_aligned(out) && layout.in_item_stride % 4 == 0 && layout.out_item_stride % 4 == 0 &&
                 tool.log_degree >= 2) {
@@ -790,7 +790,7 @@ struct FloorLauncher {
                                    in, out, tool, polys);
             }
         }
-        if constexpr (sizeof(W) == 4) {
+        if constexpr (sizeof(W) == 4 && L <= 8) {
             if (quad_aligned(in) && quad_aligned(out) && tool.log_degree >= 2) {
                 launched = true;
                 hipLaunchKernelGGL((floor_kernel<L, W, false, 4>), dim3(exact_grid(polys << (tool.log_degree - 2))),
