@@ -40,6 +40,7 @@ timeout 600 python bench_tools/wire_format_bench.py > $O/wire_format.json 2>&1
 # register / scratch figures of the built library's headline, key-MAC and interleaved kernels, and the static instruction
 # mix of the headline pair (the build's own code objects; no GPU involved)
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 3" > $O/isa_stats.txt 2>&1
+python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 7" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<12, 9, " >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "interleaved" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py --spills-only >> $O/isa_stats.txt 2>&1
