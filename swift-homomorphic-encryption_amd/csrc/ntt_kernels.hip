@@ -266,9 +266,10 @@ __device__ __forceinline__ void inverse_row_head(TwiddleWords (&head)[HEAD], con
 // scalar loads and are simply read again for the second row.
 struct NoFinish {};
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int MODE, int ROWS, bool SCALED, int PRIOR, int LOGD, typename Finish>
-__device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
+__device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                                          const DeviceModulus& mod, uint64_t* lds, Finish& finish) {
     static_assert(ROWS <= 2, "one row in registers, one parked in the tile");
+    const uint32_t tid = step_lane<MODE>(lane);
     constexpr int E = 1 << LOGE, LOL = LOGN - LOGE;
     constexpr int SCHEME = !is_split(MODE) ? transpose_scheme<LOGN, LOGE, LO_FROM, LOL>() : 0;  // as exchange<> in inverse_step
     lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[0], tid, lds);
@@ -701,6 +702,19 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             // word).  |c| <= q_ks / 2 needs a reduction mod q_r only where q_r is the smaller one (`wide`, wave-uniform: the
             // 29-bit modulus next to the 60-bit ones of the reference's n_8192_logq_29_60_60); the word loop exists in both
             // forms.
+            // The end's parameters are read from the kernel-argument segment WHERE THEY ARE USED (scalar loads off the segment's
+            // base), not as kernel arguments: those are all loaded in the entry block, and this kernel then parks them in
+            // vector-register lanes across the whole transform -- two of its 64 registers, paid for in scratch.
+            struct KernelArguments {
+                uint64_t* slab;
+                DeviceContext ctx;
+                RowMap map;
+                InverseSource source_spec;
+            };
+            using ConstSpec = const __attribute__((address_space(4))) InverseSource;
+            using ConstByte = const __attribute__((address_space(4))) char;
+            ConstSpec* const end_spec = (ConstSpec*)((ConstByte*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                     offsetof(KernelArguments, source_spec));
             const uint32_t L = source_spec.L, r = map.band_offset + within;
             const uint64_t p = mod.p, q_last = ctx.moduli[L].p, half = q_last >> 1;
             const U64x2 inverse_q_last = load_twiddle(ctx.inverse_q_last + size_t(L) * ctx.moduli_stride + r);
@@ -712,40 +726,43 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
                 const size_t pc = record + 2 * k;  // polynomial * 2 + c (the rows are the same column of consecutive polynomials)
-                const size_t poly = source_spec.poly_base + (pc >> 1);  // in the ciphertext / output slabs
+                const size_t poly = end_spec->poly_base + (pc >> 1);  // in the ciphertext / output slabs
                 const uint32_t c = static_cast<uint32_t>(pc & 1);
                 const BufferResource last_row = make_resource(slab + ((pc * (L + 1) + L) << LOGN), 8u << LOGN);
-                const uint32_t galois_inverse = source_spec.galois_inverse, expand_shift = source_spec.expand_shift;
+                const uint32_t galois_inverse = end_spec->galois_inverse, expand_shift = end_spec->expand_shift;
                 // polynomial c of the ciphertext: added as it lies (relinearize), or -- c0 under an automorphism -- gathered
                 const bool gathered = galois_inverse != 0 && c == 0;
-                const bool add = galois_inverse != 0 ? gathered : c < source_spec.added_polys;  // wave-uniform
+                const bool add = galois_inverse != 0 ? gathered : c < end_spec->added_polys;  // wave-uniform
                 const BufferResource added_row =
-                    add ? make_resource(source_spec.ct_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN)
+                    add ? make_resource(end_spec->ct_base + poly * end_spec->ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN)
                         : last_row;  // (without an addend the q_ks row is read twice)
-                // where the row goes: polynomial c of ciphertext `poly`, or -- an expand step -- of its two children
-                size_t first_ct = poly, second_ct = 0;
-                bool first_doubled = false, second_doubled = false;
-                if (expand_shift != 0) {
-                    first_ct = 2 * poly;
-                    second_ct = 2 * poly + 1;
-                    if (source_spec.targets_table != nullptr) {
-                        using ConstWord = const __attribute__((address_space(4))) uint32_t;
-                        const size_t group = poly / source_spec.targets_group_size, parent = poly - group * source_spec.targets_group_size;
-                        const uint32_t first = *(ConstWord*)(source_spec.targets_table + 4 * parent + 1);
-                        const uint32_t second = *(ConstWord*)(source_spec.targets_table + 4 * parent + 3);
-                        first_ct = group * source_spec.targets_group_stride + (first >> 1);
-                        second_ct = group * source_spec.targets_group_stride + (second >> 1);
-                        first_doubled = (first & 1u) != 0;
-                        second_doubled = (second & 1u) != 0;
-                    }
-                }
-                const BufferResource out_row = make_uniform_resource(source_spec.out + (((first_ct * 2 + c) * L + r) << LOGN), 8u << LOGN);
-                const BufferResource moved_row = expand_shift != 0
-                    ? make_uniform_resource(source_spec.out + (((second_ct * 2 + c) * L + r) << LOGN), 8u << LOGN) : out_row;
-                const BufferResource own_row = expand_shift != 0
-                    ? make_resource(source_spec.own_base + poly * source_spec.ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN) : last_row;
                 auto words_of_row = [&](auto reduce_magnitude, auto end_tag) {
                     constexpr int END = decltype(end_tag)::value;
+                    // where the row goes: polynomial c of ciphertext `poly`, or -- an expand step -- of its two children.  The
+                    // descriptors are built inside the end that uses them: held across all three they cost scalar registers
+                    // that this kernel parks in vector-register lanes
+                    size_t first_ct = poly, second_ct = 0;
+                    [[maybe_unused]] bool first_doubled = false, second_doubled = false;
+                    if constexpr (END == kEndExpand) {
+                        first_ct = 2 * poly;
+                        second_ct = 2 * poly + 1;
+                        if (end_spec->targets_table != nullptr) {
+                            using ConstWord = const __attribute__((address_space(4))) uint32_t;
+                            const size_t group = poly / end_spec->targets_group_size, parent = poly - group * end_spec->targets_group_size;
+                            const uint32_t first = *(ConstWord*)(end_spec->targets_table + 4 * parent + 1);
+                            const uint32_t second = *(ConstWord*)(end_spec->targets_table + 4 * parent + 3);
+                            first_ct = group * end_spec->targets_group_stride + (first >> 1);
+                            second_ct = group * end_spec->targets_group_stride + (second >> 1);
+                            first_doubled = (first & 1u) != 0;
+                            second_doubled = (second & 1u) != 0;
+                        }
+                    }
+                    const BufferResource out_row = make_uniform_resource(end_spec->out + (((first_ct * 2 + c) * L + r) << LOGN), 8u << LOGN);
+                    [[maybe_unused]] BufferResource moved_row = out_row, own_row = last_row;
+                    if constexpr (END == kEndExpand) {
+                        moved_row = make_uniform_resource(end_spec->out + (((second_ct * 2 + c) * L + r) << LOGN), 8u << LOGN);
+                        own_row = make_resource(end_spec->own_base + poly * end_spec->ct_stride + ((size_t(c) * L + r) << LOGN), 8u << LOGN);
+                    }
 #pragma unroll
                     for (int base = 0; base < E; base += CHUNK) {
                         uint64_t last[CHUNK], added[CHUNK];
