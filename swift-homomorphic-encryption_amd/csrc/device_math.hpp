@@ -311,7 +311,7 @@ __device__ __forceinline__ uint64_t split_mul_add(uint64_t addend, uint64_t y, u
 // The same product for a SIGNED multiplicand d = b0 + b1 2^32 (b1 signed, any 64-bit d): the inverse butterfly's x - y
 // as it leaves the subtraction, without the bound that would keep it non-negative (one 64-bit addition per butterfly).
 // The constant's second word comes in signed-limb form, wt = t0s + t1' 2^32 with t0s = the low word read as signed and
-// t1' = hi32(wt) + (t0 >> 31) (the inverse tables of the split-mode moduli hold it that way, poly_context.cpp), so that
+// t1' = hi32(wt) + (t0 >> 31) (DeviceContext::inverse_split_pairs_signed holds it that way, poly_context.cpp), so that
 // V = b0 w + b1 wt = d w (mod p) is formed by signed multiply-adds on b1 (v_mad_i64_i32) -- V in (-2^31 p, 3 2^31 p).
 // Its quotient by 2p, Q = floor((b0 f + b1 ft) / 2^32) in [-2^30, 2^31 + 2^30), fits no 32-bit word of either signedness;
 // Q' = Q + 2^30 does (the estimate's chain starts at 2^62 -- the inline constant 2.0 read as a 64-bit operand), and
