@@ -57,6 +57,17 @@ struct DeviceContext {
     const U64x2* inverse_split_pairs_signed;  // [L][N] the same with w 2^32 mod p in signed limbs (kModeSplitSigned)
     const uint64_t* forward_split_factors; // [L][N]
     const uint64_t* inverse_split_factors; // [L][N]
+    // The same tables with every stage's block lane-major (ntt_common.hpp Twiddles::lanes) for the pass structures of the
+    // tiled kernels with 8 words per lane at N = 4096 and N = 8192; nullptr at other degrees.  `_lanes`: the partition with
+    // the partial pass on the low bits (N = 8192: 12-10 | 9-7 | 6-4 | 3-1 | 0; N = 4096: four full passes) -- every forward
+    // kernel and the fused inverse ones; `_lanes_top`: 2-0 | 5-3 | 8-6 | 11-9 | 12, the plain-slab inverse at N = 8192.
+    const U64x2* forward_split_pairs_lanes;
+    const U64x2* inverse_split_pairs_lanes;
+    const U64x2* inverse_split_pairs_signed_lanes;
+    const U64x2* inverse_split_pairs_lanes_top;
+    const uint64_t* forward_split_factors_lanes;
+    const uint64_t* inverse_split_factors_lanes;
+    const uint64_t* inverse_split_factors_lanes_top;
     uint32_t degree;
     uint32_t log_degree;
     uint32_t moduli_count;         // active moduli (a prefix of the context's list)

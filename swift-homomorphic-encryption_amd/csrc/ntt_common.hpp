@@ -177,16 +177,32 @@ struct Twiddles {
     const uint64_t* factors;
     BufferResource pair_resource, factor_resource;  // split mode gathers
     uint32_t shift;                                 // kModeSplitShift: the modulus's split_shift (wave-uniform)
+    // Lane-major stage blocks (DeviceContext::*_split_pairs_lanes): within the block of a stage whose lanes hold 2^g twiddles
+    // each (g = the pass's register bits above the stage's bit), entry o sits at (o mod 2^g) (m / 2^g) + (o >> g) -- the k-th
+    // twiddle of all lanes of a wave is then one contiguous run (whole cache lines per request) instead of every 2^g-th entry
+    // of a run 2^g times as long, fetched 2^g times over unless the vector L1 still holds it.
+    bool lanes;
     // `skip`: the table as seen from entry `skip` on (the sub-transforms of an interleaved row index the tail of the
     // inverse table, ntt_kernels.hip ntt_inverse_interleaved)
     __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree,
-                                        uint32_t skip = 0) {
+                                        uint32_t skip = 0, int lane_major = 0) {
         const size_t at = (static_cast<size_t>(modulus_index) << log_degree) + skip;
         shift = 0;
+        lanes = lane_major != 0;
         if constexpr (is_split(MODE) || is_fold(MODE)) {  // (w, w 2^32 mod p); the fold butterflies use no factors
             pairs = (inverse ? (MODE == kModeSplitSigned ? ctx.inverse_split_pairs_signed : ctx.inverse_split_pairs)
                              : ctx.forward_split_pairs) + at;
             factors = (inverse ? ctx.inverse_split_factors : ctx.forward_split_factors) + at;
+            // (lane_major is a constant at every call site: 1 = the pass partition with the partial pass on the low bits,
+            // 2 = on the top bit -- the plain-slab inverse at N = 8192)
+            if (lane_major == 1) {
+                pairs = (inverse ? (MODE == kModeSplitSigned ? ctx.inverse_split_pairs_signed_lanes : ctx.inverse_split_pairs_lanes)
+                                 : ctx.forward_split_pairs_lanes) + at;
+                factors = (inverse ? ctx.inverse_split_factors_lanes : ctx.forward_split_factors_lanes) + at;
+            } else if (lane_major == 2) {
+                pairs = ctx.inverse_split_pairs_lanes_top + at;
+                factors = ctx.inverse_split_factors_lanes_top + at;
+            }
             pair_resource = make_resource(pairs, (16u << log_degree) - 16u * skip);
             factor_resource = make_resource(factors, (8u << log_degree) - 8u * skip);
             if constexpr (MODE == kModeSplitShift) {
@@ -391,8 +407,14 @@ __device__ __forceinline__ TwiddleWords forward_twiddle(const Twiddles<MODE>& tw
     const int s = LOGN - 1 - b;        // global stage number; m = 2^s groups
     const int stride = 1 << (b - LO);  // register distance of a pair
     // twiddle index = 2^s + (element index >> (b+1)); lane and register parts are disjoint bit fields
-    const uint32_t fixed = (1u << s) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
+    uint32_t fixed = (1u << s) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
     uint32_t lane_twiddle = lane_elements >> (b + 1);
+    const int g = LO + W - 1 - b;  // register bits of the pass above the stage's bit: 2^g twiddles per lane
+    if (tw.lanes && g > 0) {
+        const uint32_t within = register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1);  // < 2^g
+        fixed = (1u << s) + within * ((1u << s) >> g);
+        lane_twiddle = lane_elements >> (b + 1 + g);
+    }
     if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
         return fetch_twiddle<MODE, true>(tw, __builtin_amdgcn_readfirstlane(lane_twiddle), fixed);
     return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);
@@ -511,8 +533,14 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
     if (b == LOGN - 1) return TwiddleWords{0, 0, 0};
     const int stride = 1 << (b - LO);
     const uint32_t m = N >> (b + 1);
-    const uint32_t fixed = (N - 2 * m + 1) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
+    uint32_t fixed = (N - 2 * m + 1) + (register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1));
     uint32_t lane_twiddle = lane_elements >> (b + 1);
+    const int g = LO + W - 1 - b;  // as forward_twiddle: the stage's block is lane-major where tw.lanes
+    if (tw.lanes && g > 0) {
+        const uint32_t within = register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1);
+        fixed = (N - 2 * m + 1) + within * (m >> g);
+        lane_twiddle = lane_elements >> (b + 1 + g);
+    }
     if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
         return fetch_twiddle<MODE, true>(tw, __builtin_amdgcn_readfirstlane(lane_twiddle), fixed);
     return fetch_twiddle<MODE, false>(tw, lane_twiddle, fixed);

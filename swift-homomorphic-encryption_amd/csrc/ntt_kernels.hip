@@ -150,6 +150,16 @@ constexpr bool kTopPartialOrder = LOGN == 13 && LOGE == 3 && INVERSE && FROM_SLA
 // kLateLaneAddresses: every step derives its lane addresses (LDS slots, twiddle offsets) from an opaque copy of the lane
 // index, i.e. next to where it uses them -- the compiler otherwise computes all of them at the top of the kernel and
 // carries them through the passes, in scratch where the register file is full.
+// Lane-major twiddle blocks (ntt_common.hpp Twiddles::lanes, built by PolyContext::upload for N = 4096 and N = 8192): which copy of
+// the tables a tiled kernel with 8 words per lane reads -- 0: the plain tables (other shapes; the [0, 8p) / exact butterflies,
+// whose tables have no lane-major copy), 1: the partition with the partial pass on the low bits (every forward kernel, the fused
+// inverse ones, N = 4096), 2: on the top bit (the plain-slab inverse at N = 8192).  L2 read requests per launch of the headline
+// pair: 24.2 -> 20.9 M forward, 31.9 -> 23.0 M inverse (profiles/r04x_lane_major_twiddles.txt).
+template <int LOGN, int LOGT, int MODE, bool INVERSE, bool PLAIN>
+constexpr int kLaneMajorTwiddles =
+    !((LOGN == 13 && LOGT == 10) || (LOGN == 12 && LOGT == 9)) || !(is_split(MODE) || is_fold(MODE)) ? 0
+    : (INVERSE && PLAIN && LOGN == 13)                                                              ? 2
+                                                                                                    : 1;
 constexpr bool kLateLaneAddresses = true;
 // The lane index again, without a vector register between uses: wave base (the first lane's index -- one scalar register,
 // computed once) + the lane's position in its wave (two instructions where it is needed).
@@ -366,7 +376,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     }
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
-    const Twiddles<MODE> tw(ctx, false, mi, LOGN);
+    const Twiddles<MODE> tw(ctx, false, mi, LOGN, 0, kLaneMajorTwiddles<LOGN, LOGT, MODE, false, true>);
     const uint64_t p = mod.p;
     uint64_t v[ROWS][E];
 
@@ -568,7 +578,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     }
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
-    const Twiddles<MODE> tw(ctx, true, mi, LOGN);
+    const Twiddles<MODE> tw(ctx, true, mi, LOGN, 0, kLaneMajorTwiddles<LOGN, LOGT, MODE, true, FROM_SLAB>);
     uint64_t v[ROWS][E];
 
     if constexpr (S::P == 1) {

@@ -175,7 +175,9 @@ int PolyContext::upload() {
     const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
     // limb-wise Shoup form of both twiddle tables: pairs (16 B) and quotient factors (8 B) per entry
     const size_t bytes_factors = round_up(count * n * sizeof(u64));
-    const size_t total = bytes_moduli + 5 * bytes_twiddles + bytes_inverse_q_last + 2 * bytes_factors;
+    // lane-major stage blocks for the tiled kernels with 8 words per lane (ntt_kernels.hip kLaneMajorTwiddles): N = 4096, 8192
+    const bool lane_major = log_degree_ == 12 || log_degree_ == 13;
+    const size_t total = bytes_moduli + (lane_major ? 9 : 5) * bytes_twiddles + bytes_inverse_q_last + (lane_major ? 5 : 2) * bytes_factors;
     HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
     char* base = static_cast<char*>(device_block_);
     HEAMD_HIP_TRY(hipMemcpy(base, host_moduli_.data(), count * sizeof(DeviceModulus), hipMemcpyHostToDevice));
@@ -191,9 +193,34 @@ int PolyContext::upload() {
     char* forward_factors = inverse_pairs + bytes_twiddles;
     char* inverse_factors = forward_factors + bytes_factors;
     char* inverse_pairs_signed = inverse_factors + bytes_factors;
+    // lane-major copies: pairs forward | inverse | inverse signed | inverse, top partition; factors forward | inverse | inverse, top
+    char* lanes_pairs = inverse_pairs_signed + bytes_twiddles;
+    char* lanes_factors = lanes_pairs + 4 * bytes_twiddles;
     {
-        std::vector<U64x2> pairs(count * n);
-        std::vector<u64> factors(count * n);
+        // Every stage's block lane-major (ntt_common.hpp Twiddles::lanes): the stage on element bit b lies in a pass whose highest
+        // bit is top(b); its lanes hold 2^g twiddles each, g = top(b) - b, and entry o of its block moves to
+        // (o mod 2^g) (m / 2^g) + (o >> g).  Forward block of bit b: [2^s, 2^(s+1)), s = logN - 1 - b, m = 2^s; inverse block:
+        // [N - 2m + 1, N - m], m = N >> (b + 1).  Partitions (8 words per lane = passes of three bits): partial pass on the low
+        // bits (every forward kernel, the fused inverse ones; N = 8192: 0 | 3-1 | 6-4 | 9-7 | 12-10, N = 4096: four full passes) or
+        // on the top bit (the plain-slab inverse at N = 8192: 2-0 | 5-3 | 8-6 | 11-9 | 12).
+        const int logn = static_cast<int>(log_degree_);
+        const int partial = logn % 3;  // width of the partial pass (0: none)
+        auto top_low = [&](int b) { return b < partial ? partial - 1 : partial + ((b - partial) / 3) * 3 + 2; };
+        auto top_top = [&](int b) { const int t = (b / 3) * 3 + 2; return t < logn ? t : logn - 1; };
+        auto lane_major_copy = [&](bool inverse_direction, bool top_partition, const auto& source, auto& out) {
+            out = source;
+            for (int b = 0; b < logn; ++b) {
+                const int g = (top_partition ? top_top(b) : top_low(b)) - b;
+                if (g == 0) continue;
+                const size_t m = inverse_direction ? (n >> (b + 1)) : (size_t(1) << (logn - 1 - b));
+                const size_t start = inverse_direction ? n - 2 * m + 1 : m;
+                for (size_t i = 0; i < count; ++i)
+                    for (size_t o = 0; o < m; ++o)
+                        out[i * n + start + (o & ((size_t(1) << g) - 1)) * (m >> g) + (o >> g)] = source[i * n + start + o];
+            }
+        };
+        std::vector<U64x2> pairs(count * n), moved_pairs;
+        std::vector<u64> factors(count * n), moved_factors;
         for (int direction = 0; direction < 2; ++direction) {
             const std::vector<U64x2>& table = direction == 0 ? host_forward_ : host_inverse_;
             for (size_t i = 0; i < count; ++i) {
@@ -208,16 +235,46 @@ int PolyContext::upload() {
                                     count * n * sizeof(U64x2), hipMemcpyHostToDevice));
             HEAMD_HIP_TRY(hipMemcpy(direction == 0 ? forward_factors : inverse_factors, factors.data(),
                                     count * n * sizeof(u64), hipMemcpyHostToDevice));
+            if (lane_major) {
+                lane_major_copy(direction == 1, false, pairs, moved_pairs);
+                lane_major_copy(direction == 1, false, factors, moved_factors);
+                HEAMD_HIP_TRY(hipMemcpy(lanes_pairs + direction * bytes_twiddles, moved_pairs.data(), count * n * sizeof(U64x2),
+                                        hipMemcpyHostToDevice));
+                HEAMD_HIP_TRY(hipMemcpy(lanes_factors + direction * bytes_factors, moved_factors.data(), count * n * sizeof(u64),
+                                        hipMemcpyHostToDevice));
+                if (direction == 1) {
+                    lane_major_copy(true, true, pairs, moved_pairs);
+                    lane_major_copy(true, true, factors, moved_factors);
+                    HEAMD_HIP_TRY(hipMemcpy(lanes_pairs + 3 * bytes_twiddles, moved_pairs.data(), count * n * sizeof(U64x2),
+                                            hipMemcpyHostToDevice));
+                    HEAMD_HIP_TRY(hipMemcpy(lanes_factors + 2 * bytes_factors, moved_factors.data(), count * n * sizeof(u64),
+                                            hipMemcpyHostToDevice));
+                }
+            }
         }
         // the inverse table once more with w 2^32 mod p in signed limbs, t0s + t1' 2^32 with t1' = t1 + (t0 >> 31): the
         // butterflies of kModeSplitSigned multiply a signed difference (device_math.hpp split_mul_signed); `pairs` still
         // holds the inverse direction
         for (U64x2& pair : pairs) pair.y += (pair.y & 0x80000000ull) << 1;
         HEAMD_HIP_TRY(hipMemcpy(inverse_pairs_signed, pairs.data(), count * n * sizeof(U64x2), hipMemcpyHostToDevice));
+        if (lane_major) {
+            lane_major_copy(true, false, pairs, moved_pairs);
+            HEAMD_HIP_TRY(hipMemcpy(lanes_pairs + 2 * bytes_twiddles, moved_pairs.data(), count * n * sizeof(U64x2),
+                                    hipMemcpyHostToDevice));
+        }
     }
     dev_.forward_split_pairs = reinterpret_cast<const U64x2*>(forward_pairs);
     dev_.inverse_split_pairs = reinterpret_cast<const U64x2*>(inverse_pairs);
     dev_.inverse_split_pairs_signed = reinterpret_cast<const U64x2*>(inverse_pairs_signed);
+    auto pairs_at = [&](int k) { return lane_major ? reinterpret_cast<const U64x2*>(lanes_pairs + k * bytes_twiddles) : nullptr; };
+    auto factors_at = [&](int k) { return lane_major ? reinterpret_cast<const u64*>(lanes_factors + k * bytes_factors) : nullptr; };
+    dev_.forward_split_pairs_lanes = pairs_at(0);
+    dev_.inverse_split_pairs_lanes = pairs_at(1);
+    dev_.inverse_split_pairs_signed_lanes = pairs_at(2);
+    dev_.inverse_split_pairs_lanes_top = pairs_at(3);
+    dev_.forward_split_factors_lanes = factors_at(0);
+    dev_.inverse_split_factors_lanes = factors_at(1);
+    dev_.inverse_split_factors_lanes_top = factors_at(2);
     dev_.forward_split_factors = reinterpret_cast<const u64*>(forward_factors);
     dev_.inverse_split_factors = reinterpret_cast<const u64*>(inverse_factors);
     dev_.moduli = reinterpret_cast<const DeviceModulus*>(base);
