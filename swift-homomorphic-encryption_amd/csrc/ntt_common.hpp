@@ -411,8 +411,9 @@ __device__ __forceinline__ TwiddleWords forward_twiddle(const Twiddles<MODE>& tw
     uint32_t lane_twiddle = lane_elements >> (b + 1);
     const int g = LO + W - 1 - b;  // register bits of the pass above the stage's bit: 2^g twiddles per lane
     if (tw.lanes && g > 0) {
-        const uint32_t within = register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1);  // < 2^g
-        fixed = (1u << s) + within * ((1u << s) >> g);
+        // (its low g bits say which of the lane's twiddles; a partial pass's extra register bits lie above them)
+        const uint32_t within = register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1);
+        fixed = (1u << s) + (within & ((1u << g) - 1u)) * ((1u << s) >> g) + (within >> g);
         lane_twiddle = lane_elements >> (b + 1 + g);
     }
     if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
@@ -538,7 +539,7 @@ __device__ __forceinline__ TwiddleWords inverse_twiddle(const Twiddles<MODE>& tw
     const int g = LO + W - 1 - b;  // as forward_twiddle: the stage's block is lane-major where tw.lanes
     if (tw.lanes && g > 0) {
         const uint32_t within = register_part<LOGN, LOGE, LO, W>(idx * 2 * stride) >> (b + 1);
-        fixed = (N - 2 * m + 1) + within * (m >> g);
+        fixed = (N - 2 * m + 1) + (within & ((1u << g) - 1u)) * (m >> g) + (within >> g);
         lane_twiddle = lane_elements >> (b + 1 + g);
     }
     if (stage_is_uniform<LOGN, LOGE, LO, W, UNIFORM_TWIDDLES>(b))
