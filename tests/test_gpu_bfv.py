@@ -674,8 +674,9 @@ def test_inner_product_ct_ct_config3_shape(oracle, config3):
 
 def test_mul_and_relinearize_full_batch_properties(oracle, config3):
     """BASELINE config 3 at its full batch (1024 ciphertext pairs, generated on the device): every output word is
-    canonical, items sampled across the batch (first, last, a middle one and the one straddling the odd workgroup tail)
-    equal the oracle word for word, and the batch result does not depend on the batch it was computed in."""
+    canonical, EVERY product and every relinearized ciphertext equals the multi-threaded oracle's word for word (on a host
+    with fewer than 8 threads: items sampled across the batch -- first, last, a middle one and the one straddling the odd
+    workgroup tail), and the batch result does not depend on the batch it was computed in."""
     import torch
 
     ours, ref = config3
@@ -692,11 +693,28 @@ def test_mul_and_relinearize_full_batch_properties(oracle, config3):
     product = ours.mul(lhs, rhs)
     relin = ours.relinearize(product, key_dev)
     assert bool((product < bound).all()) and bool((relin < bound).all())
-    sample = [0, 511, 1022, 1023]
-    host_lhs, host_rhs = heamd.to_host(lhs[sample].contiguous()), heamd.to_host(rhs[sample].contiguous())
-    expected_product = ref.mul(host_lhs, host_rhs)
-    assert np.array_equal(heamd.to_host(product[sample].contiguous()), expected_product)
-    assert np.array_equal(heamd.to_host(relin[sample].contiguous()), ref.relinearize(expected_product, key))
+    from conftest import exhaustive_parity, host_threads
+
+    if exhaustive_parity():
+        # every product and every relinearized ciphertext against the multi-threaded oracle, 128 items (100 MiB) at a time
+        compared = 0
+        for first in range(0, batch, 128):
+            part = slice(first, first + 128)
+            expected_product = ref.mul(heamd.to_host(lhs[part].contiguous()), heamd.to_host(rhs[part].contiguous()),
+                                       threads=host_threads())
+            assert np.array_equal(heamd.to_host(product[part].contiguous()), expected_product), first
+            assert np.array_equal(heamd.to_host(relin[part].contiguous()),
+                                  ref.relinearize(expected_product, key, threads=host_threads())), first
+            compared += expected_product.shape[0]
+        assert compared == batch
+        print(f"ct x ct + relinearize: {compared} of {batch} items compared with the oracle word for word")
+    else:
+        sample = [0, 511, 1022, 1023]
+        host_lhs, host_rhs = heamd.to_host(lhs[sample].contiguous()), heamd.to_host(rhs[sample].contiguous())
+        expected_product = ref.mul(host_lhs, host_rhs)
+        assert np.array_equal(heamd.to_host(product[sample].contiguous()), expected_product)
+        assert np.array_equal(heamd.to_host(relin[sample].contiguous()), ref.relinearize(expected_product, key))
+        print(f"ct x ct + relinearize: {len(sample)} of {batch} items compared with the oracle (small host)")
     # an odd sub-batch (the ragged tail of the row-pair launches) gives the same words as the full batch
     sub = slice(513, 1020)
     again = ours.relinearize(ours.mul(lhs[sub].contiguous(), rhs[sub].contiguous()), key_dev)

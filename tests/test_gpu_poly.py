@@ -132,10 +132,11 @@ def test_lazy_product_accumulation(oracle):
 
 def test_mod_switch_at_the_benchmark_size(oracle):
     """BASELINE configs[3] at the size bench.py times it: N=16384, 6 -> 5 moduli, 8192 polynomials (6 GiB in, 5 GiB out,
-    device-generated).  Polynomials sampled over the whole slab -- the first, the last, and several whose input AND
-    output byte offsets lie beyond 4 GiB (786 432 B per input polynomial: from index 5462 on; 655 360 B per output
-    polynomial: from index 6554 on) -- equal the oracle's divideAndRoundQLast (PolyRq.swift:365-393) word for word, and
-    every output word is canonical."""
+    device-generated).  EVERY polynomial equals the oracle's divideAndRoundQLast (PolyRq.swift:365-393) word for word
+    (multi-threaded oracle, 512 polynomials at a time; on a host with fewer than 8 threads: polynomials sampled over the
+    whole slab -- the first, the last, and several whose input AND output byte offsets lie beyond 4 GiB, 786 432 B per
+    input polynomial: from index 5462 on; 655 360 B per output polynomial: from index 6554 on), and every output word is
+    canonical."""
     import torch
 
     degree, batch = 16384, 8192
@@ -152,6 +153,18 @@ def test_mod_switch_at_the_benchmark_size(oracle):
     for part in range(0, batch, 1024):  # canonical everywhere (in slices: the comparison's temporaries stay small)
         piece = out[part:part + 1024]
         assert int((piece >= bound[:, :-1]).sum()) == 0 and int((piece < 0).sum()) == 0
-    sample = [0, 1, 2047, 4096, 5461, 5462, 6553, 6554, 7000, 8190, 8191]
-    assert sample[5] * len(moduli) * degree * 8 > 1 << 32 and sample[7] * (len(moduli) - 1) * degree * 8 > 1 << 32
-    assert np.array_equal(heamd.to_host(out[sample]), ref.divide_and_round_q_last(heamd.to_host(x[sample])))
+    from conftest import exhaustive_parity, host_threads
+
+    if exhaustive_parity():
+        compared = 0
+        for first in range(0, batch, 512):  # 384 MiB in, 320 MiB out per slice
+            want = ref.divide_and_round_q_last(heamd.to_host(x[first:first + 512]), threads=host_threads())
+            assert np.array_equal(heamd.to_host(out[first:first + 512]), want), first
+            compared += want.shape[0]
+        assert compared == batch
+        print(f"divideAndRoundQLast: {compared} of {batch} polynomials compared with the oracle word for word")
+    else:
+        sample = [0, 1, 2047, 4096, 5461, 5462, 6553, 6554, 7000, 8190, 8191]
+        assert sample[5] * len(moduli) * degree * 8 > 1 << 32 and sample[7] * (len(moduli) - 1) * degree * 8 > 1 << 32
+        assert np.array_equal(heamd.to_host(out[sample]), ref.divide_and_round_q_last(heamd.to_host(x[sample])))
+        print(f"divideAndRoundQLast: {len(sample)} of {batch} polynomials compared with the oracle (small host)")
