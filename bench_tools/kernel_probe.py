@@ -35,7 +35,7 @@ def main():
         else:
             raise SystemExit("unknown option " + args[0])
     source = open(os.path.join(CSRC, "ntt_kernels.hip")).read()
-    head = source[:source.index("template <typename Kernel>\nhipError_t allow_dynamic_lds")]
+    head = source[:source.index("// Row pairs: where the register file allows it")]
     body = head + "\n".join(f"template __global__ void {k}{SIGNATURES[k.split('<')[0].strip()]};" for k in args)
     body += "\n}  // namespace\n}  // namespace heamd\n"
     with tempfile.TemporaryDirectory() as work:

@@ -1,7 +1,8 @@
+COMPILE = ["ntt_kernels.hip", "behz_kernels.hip"]  # the edited text lives in a header both include
 DESCRIPTION = ("the plain-slab inverse at N = 8192 (unsigned butterflies) with the lane index re-derived per step instead of carried in a "
                "register: no scratch with the lane-major twiddle blocks (12 B with the register)")
 EDITS = [
-    ("ntt_kernels.hip", """template <int MODE>
+    ("ntt_rows.hpp", """template <int MODE>
 __device__ __forceinline__ uint32_t step_lane(uint32_t lane) {
     if constexpr (!kLateLaneAddresses) return lane;
     else if constexpr (MODE == kModeSplitSigned) return late_lane(lane);""",
@@ -9,6 +10,6 @@ __device__ __forceinline__ uint32_t step_lane(uint32_t lane) {
 __device__ __forceinline__ uint32_t step_lane(uint32_t lane) {
     if constexpr (!kLateLaneAddresses) return lane;
     else if constexpr (INVERSE && (MODE == kModeSplitSigned || MODE == kModeSplit)) return late_lane(lane);"""),
-    ("ntt_kernels.hip", "    const uint32_t tid = step_lane<MODE>(lane);\n    const TwiddleWords first = forward_first_twiddle",
+    ("ntt_rows.hpp", "    const uint32_t tid = step_lane<MODE>(lane);\n    const TwiddleWords first = forward_first_twiddle",
      "    const uint32_t tid = step_lane<MODE, false>(lane);\n    const TwiddleWords first = forward_first_twiddle"),
 ]

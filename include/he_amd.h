@@ -248,8 +248,9 @@ int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const ui
                       uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s);
 /* Bfv.relinearize (Bfv/Bfv.swift:201-219) via _computeKeySwitchingUpdate (Bfv/Bfv+Keys.swift:123-208).
  * ct3: [batch][3][L][N] Coeff; key: the relinearization key's L_top ciphertexts, [L_top][2][L_top+1][N] Eval over
- * the top key-switching context (Keys.swift:66-99); out: [batch][2][L][N] Coeff, not aliasing ct3 (the last kernel adds
- * the update to (c0, c1) as it reads them, item by item in no particular order).  key == NULL ->
+ * the top key-switching context (Keys.swift:66-99); out: [batch][2][L][N] Coeff, not overlapping ct3 (the last kernel adds
+ * the update to (c0, c1) as it reads them, item by item in no particular order): an overlap is HE_ERR_INVALID_ARGUMENT,
+ * except a single ciphertext (batch == 1) relinearized onto its own first two polynomials (out == ct3).  key == NULL ->
  * missingRelinearizationKey. */
 int he_bfv_relinearize_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* ct3,
                               const uint64_t* key, uint64_t* out, size_t batch, void* workspace,

@@ -2,6 +2,7 @@
 // (reference Sources/HomomorphicEncryption/Bfv/*.swift).  Each operation is a short pipeline of HIP kernels on the
 // caller's stream; nothing here touches the data on the host.
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "api_internal.hpp"
@@ -186,6 +187,27 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
     return ntt_records(false, lifted, *tool.qbsk, tool.qbsk->device_context(), rows, items * 4, stream);
 }
 
+// multiplyWithoutScaling's transforms and tensor product and dropExtendedBase's inverse transforms row by row
+// (behz_kernels.hip): the lift writes the Bsk rows of the four operands, then ONE kernel per row band takes every
+// (item, [Q, Bsk] row) from its four Coeff rows to its three scaled Coeff product rows -- the Eval rows never reach HBM.
+// *fused = false (nothing launched): the degree or the batch has no such kernel; the caller runs the unfused pipeline.
+constexpr bool kBehzRowsFused = true;
+int mul_rows_fused(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs, const uint64_t* rhs,
+                   uint64_t* lifted, uint64_t* tensor, size_t batch, hipStream_t stream, bool* fused) {
+    *fused = false;
+    if (!kBehzRowsFused) return HE_OK;
+    DeviceContext scaled = tool.qbsk->device_context();
+    scaled.moduli = tool.qbsk_moduli_scaled_by_t;  // folds dropExtendedBase's multiplication by t into N^-1
+    scaled.scaled_inverse_degree = 1;
+    const uint32_t rows = 2 * L + 1;
+    if (!heamd::behz_rows_fused_supported(scaled, rows, L, batch)) return HE_OK;
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false));
+    HEAMD_HIP_TRY(heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream));
+    *fused = true;
+    return HE_OK;
+}
+
 // Bfv.mulAssign(ct, ct) (Bfv/Bfv+Multiply.swift:18-85) on slabs of W
 template <typename W>
 int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L, const W* lhs, const W* rhs, W* out,
@@ -198,6 +220,15 @@ int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L
     W* ws = reinterpret_cast<W*>(raw);
     W* lifted = ws;                   // [batch][4][2L+1][N]  (a0, a1, b0, b1)
     W* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
+    if constexpr (std::is_same<W, uint64_t>::value) {
+        bool fused = false;
+        status = mul_rows_fused(*tool, L, n, ext, lhs, rhs, lifted, tensor, batch, stream, &fused);
+        if (status != HE_OK) return status;
+        if (fused) {
+            HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
+            return HE_OK;
+        }
+    }
     HEAMD_HIP_TRY(lift_pairs_to_eval(*tool, L, n, ext, lhs, rhs, lifted, batch, stream));
     bool in_coeff_form = false;
     status = tensor_and_inverse(*tool, lifted, tensor, batch, stream, &in_coeff_form);
@@ -533,6 +564,19 @@ int relinearize_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W*
     }
     if (batch == 0) return HE_OK;
     if (ct3 == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    {
+        // out must not overlap ct3: the last kernel adds the update to (c0, c1) of one item while it stores another item's
+        // result (items are 3 L N words apart in ct3 and 2 L N apart in out), in no particular order -- and which kernel
+        // that is depends on the batch size, so an overlap would be right for some batches and silently wrong for others.
+        // The one overlap that is word-for-word in place -- a single ciphertext relinearized onto its own (c0, c1) -- is
+        // allowed: it takes the element-wise finish kernel (a batch of one is never fused).
+        const size_t words = size_t(moduli_count) * ctx->impl->degree();
+        const uintptr_t in_begin = reinterpret_cast<uintptr_t>(ct3), in_end = in_begin + batch * 3 * words * sizeof(W);
+        const uintptr_t out_begin = reinterpret_cast<uintptr_t>(out), out_end = out_begin + batch * 2 * words * sizeof(W);
+        const bool overlap = out_begin < in_end && in_begin < out_end;
+        if (overlap && !(batch == 1 && out_begin == in_begin))
+            return invalid_argument("relinearize: out overlaps ct3 (only a single ciphertext may be relinearized in place)");
+    }
     return relinearize_pipeline(ctx, moduli_count, ct3, key, out, batch, workspace, workspace_bytes, as_stream(s));
 }
 }  // namespace

@@ -48,6 +48,17 @@ hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, u
                                      hipStream_t stream);
 hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, const DeviceContext& ctx, uint32_t record_rows,
                                      size_t items, hipStream_t stream);
+// behz_kernels.hip -- BEHZ multiplication row by row (Bfv+Multiply.swift:18-85): per (item, [Q, Bsk] row) the four forward
+// transforms, the tensor product and the three inverse transforms scaled by t in one workgroup, the transformed rows never
+// leaving its registers.  lhs, rhs: [items][2][source_moduli][N] Coeff, items ct_stride words apart (their rows are the Q
+// rows of the lifted polynomials); lifted: [items][4][record_rows][N] with the Bsk rows written by the lift (the Q rows are
+// not read); scaled_qbsk: the [Q, Bsk] context with t N^-1 as inverse-degree constants; out: [items][3][record_rows][N]
+// Coeff, what launch_floor_qbsk_to_q takes.  hipErrorNotSupported (nothing launched, behz_rows_fused_supported false):
+// launch_ntt_lifted_forward + launch_ntt_tensor_inverse.
+bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items);
+hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size_t ct_stride, const uint64_t* lifted,
+                                  uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,
+                                  size_t items, hipStream_t stream);
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
 // launch_ntt_key_mac_inverse with the key switch's last step (drop the special modulus, add the update to the first

@@ -114,24 +114,31 @@ public final class DeviceBuffer: @unchecked Sendable {
         try heAmdCheck(he_stream_synchronize(stream.raw))
     }
 
-    /// Copies the words of `poly` to word offset `offset` (one staged copy, no wait).
+    /// Copies the words of `poly` to word offset `offset`.  A single polynomial goes through the borrowed-pointer path
+    /// (`upload(words:)`: copy, then wait): page-locking a block per small object costs more than the wait it saves --
+    /// `hipHostMalloc` is slow and `hipHostFree` synchronizes the device.
     public func upload<F: PolyFormat>(_ poly: PolyRq<UInt64, F>, at offset: Int, on stream: HeAmdStream) throws {
-        let staging = try HostStaging(capacity: poly.data.count)
-        staging.append(poly)
-        try upload(staged: staging, at: offset, on: stream)
+        try poly.data.withDataSpan { span in
+            try span.withUnsafeBufferPointer { words in try upload(words: words, at: offset, on: stream) }
+        }
     }
 
-    /// All polynomials of `ciphertext`, back to back, starting at word offset `offset`: one staged copy, no wait.
+    /// All polynomials of `ciphertext`, back to back, starting at word offset `offset` (a single ciphertext: the
+    /// borrowed-pointer path, polynomial by polynomial).
     public func upload<S: HeScheme, F: PolyFormat>(_ ciphertext: Ciphertext<S, F>, at offset: Int,
                                                    on stream: HeAmdStream) throws where S.Scalar == UInt64
     {
-        let staging = try HostStaging(capacity: ciphertext.polys.reduce(0) { $0 + $1.data.count })
-        staging.append(ciphertext)
-        try upload(staged: staging, at: offset, on: stream)
+        var at = offset
+        for poly in ciphertext.polys {
+            try upload(poly, at: at, on: stream)
+            at += poly.data.count
+        }
     }
 
-    /// `ciphertexts` back to back from word offset `offset` (a query, the operands of an inner product): ONE copy.
-    public func upload<S: HeScheme, F: PolyFormat>(contentsOf ciphertexts: [Ciphertext<S, F>], at offset: Int,
+    /// `ciphertexts` back to back from word offset `offset` (a query, the operands of an inner product, a key): ONE staged
+    /// copy, no wait.  Any collection of ciphertexts (the PIR protocol hands over generic `Collection`s).  The staging
+    /// stays with the buffer until `releaseStaging()` -- call it once the stream has been waited for.
+    public func upload<S: HeScheme, F: PolyFormat>(contentsOf ciphertexts: some Collection<Ciphertext<S, F>>, at offset: Int,
                                                    on stream: HeAmdStream) throws where S.Scalar == UInt64
     {
         let words = ciphertexts.reduce(0) { sum, ciphertext in sum + ciphertext.polys.reduce(0) { $0 + $1.data.count } }
@@ -227,6 +234,12 @@ public final class DeviceKeySwitchKey: @unchecked Sendable {
         let words = ciphertexts.reduce(0) { sum, ct in sum + ct.polys.reduce(0) { $0 + $1.data.count } }
         buffer = try DeviceBuffer(count: words)
         try buffer.upload(contentsOf: ciphertexts, at: 0, on: stream) // the whole key: one staged copy
+    }
+
+    /// The key is resident: call once the upload stream has been waited for.  Drops the page-locked copy of the key (a
+    /// resident key would otherwise pin its own size in host memory for as long as it stays in the cache).
+    public func uploadCompleted() {
+        buffer.releaseStaging()
     }
 
     /// Bytes of HBM the key occupies.

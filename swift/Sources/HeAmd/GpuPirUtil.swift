@@ -81,7 +81,8 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
         try await stream.completion()
         let single = singleModulusContext(of: polyContext)
         let responseWords = 2 * degree
-        let perIndex: [[Scheme.CoeffCiphertext]] = try withExtendedLifetime((resident, keys)) {
+        // (inputs, databases and keys stay alive until the results are back: the call above only enqueued the kernels)
+        let perIndex: [[Scheme.CoeffCiphertext]] = try withExtendedLifetime((resident, keys, ciphertexts)) {
             try (0..<query.indicesCount).map { index in
                 try (0..<chunkCount).map { chunk in
                     try responses.downloadCiphertext(context: context, polyContext: single, polyCount: 2,
@@ -120,7 +121,7 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
             }
         }
         try await stream.completion()
-        return try withExtendedLifetime(keys) {
+        return try withExtendedLifetime((keys, input)) {
             try (0..<outputCount).map { index in
                 try output.downloadCiphertext(context: context, polyContext: polyContext, polyCount: 2,
                                               at: index * 2 * polyWords, on: stream)
@@ -182,7 +183,7 @@ public enum GpuPirUtil<Scheme: HeScheme>: PirUtilProtocol
         }
         try await stream.completion()
         let single = singleModulusContext(of: polyContext)
-        return try withExtendedLifetime(keys) {
+        return try withExtendedLifetime((keys, dim0, rest, database)) {
             try response.downloadCiphertext(context: context, polyContext: single, polyCount: 2, at: 0, on: stream)
         }
     }

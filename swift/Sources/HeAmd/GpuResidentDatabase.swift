@@ -61,6 +61,12 @@ public final class GpuEvaluationKey: @unchecked Sendable {
         relinearizationKey = try evaluationKey._relinearizationKey.map { // Keys.swift:108-117
             try DeviceKeySwitchKey($0._keySwitchKey, on: stream)
         }
+        // The uploads were only enqueued, on a stream that dies with this initialiser, and the kernels that read the keys
+        // run on OTHER non-blocking streams with no ordering against it: wait here, so that a resident key is a landed
+        // key, then hand back the page-locked copies (up to the cache's budget of unswappable host memory otherwise).
+        try stream.synchronize()
+        for key in galoisKeys { key.uploadCompleted() }
+        relinearizationKey?.uploadCompleted()
     }
 
     var galoisPointers: [UnsafePointer<UInt64>?] {

@@ -117,6 +117,63 @@ def test_relinearize_matches_oracle(oracle, small, level):
     assert err.value.name == "missingRelinearizationKey"
 
 
+@pytest.mark.parametrize("degree,bits,batch,level", [
+    (8192, [55] * 5, 33, None),      # BASELINE config 3's moduli: Q band limb-wise (signed inverse), Bsk band fold (2^60 + e)
+    (8192, [55] * 5, 61, 3),         # below the top level (seven [Q, Bsk] rows)
+    (8192, [55] * 5, 130, 1),        # a single ciphertext modulus (three rows)
+    (8192, [29, 60, 60], 60, None),  # the reference's n_8192_logq_29_60_60: 29 | 60 (fold, 2^60 - d) | Bsk
+    (4096, [27, 28, 28], 300, None), # n_4096_logq_27_28_28: every ciphertext modulus below 2^40 -- the [0, 8p) butterflies
+    (4096, [60, 60, 60], 90, None),  # all-60-bit moduli at N = 4096
+    (4096, [50, 61, 55], 70, None),  # 50 (limb-wise) | 61 bits not next to a power of two ([0, 8p)) | Bsk
+    (4096, [62, 62, 50], 64, None),  # 62-bit moduli: the exact butterflies for the whole record
+])
+def test_mul_row_fused_matches_oracle(oracle, degree, bits, batch, level):
+    """ct x ct on batches wide enough for behz_kernels.hip (one workgroup per (item, [Q, Bsk] row): four forward transforms,
+    the tensor product, three scaled inverse transforms, the Eval rows never in HBM) -- every butterfly class the row bands
+    take (limb-wise, fold of either form, [0, 8p), exact), levels below the top, odd batches; EVERY product word for word
+    against the oracle's multiplyWithoutScaling + dropExtendedBase (Bfv+Multiply.swift:18-85), and the same words as the
+    unfused pipeline computes for a batch too small for the fused kernel."""
+    from conftest import host_threads
+
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    L = ours.L if level is None else level
+    moduli = ref.ciphertext_context(L).moduli
+    rng = np.random.default_rng(degree + batch)
+    lhs, rhs = _uniform(rng, (batch, 2), moduli, degree), _uniform(rng, (batch, 2), moduli, degree)
+    lhs[0, :, :, :2] = 0  # the extremes of every residue
+    for i, m in enumerate(moduli):
+        lhs[1, :, i, :] = m - 1
+        rhs[1, :, i, :] = m - 1
+    got = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), L))
+    assert np.array_equal(got, ref.mul(lhs, rhs, L, threads=host_threads()))
+    few = heamd.to_host(ours.mul(heamd.to_device(lhs[:3].copy()), heamd.to_device(rhs[:3].copy()), L))  # the unfused pipeline
+    assert np.array_equal(few, got[:3])
+
+
+def test_relinearize_refuses_overlapping_output(oracle, small):
+    """he_bfv_relinearize_device: out overlapping ct3 is HE_ERR_INVALID_ARGUMENT whatever the batch size (the key switch's
+    last kernel -- which one depends on the batch -- reads (c0, c1) of one item while it stores another's result); the one
+    word-for-word in-place form, a single ciphertext onto its own (c0, c1), is allowed and equals the oracle."""
+    ours, ref, _ = small
+    L, n = ours.L, ours.degree
+    moduli = ref.ciphertext_context(L).moduli
+    rng = np.random.default_rng(77)
+    ct3 = _uniform(rng, (3, 3), moduli, n)
+    key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, n)
+    lib = heamd.load_library()
+    dev_ct3, dev_key = heamd.to_device(ct3), heamd.to_device(key)
+    words = L * n
+    for shift_words in (0, 2 * words, 3 * 3 * words - 1):  # the same start, inside, the last word
+        out_ptr = dev_ct3.data_ptr() + 8 * shift_words
+        assert lib.he_bfv_relinearize_device(ours.h, L, dev_ct3.data_ptr(), dev_key.data_ptr(), out_ptr, 3, None, 0, None) == 16
+    assert np.array_equal(heamd.to_host(dev_ct3), ct3)  # nothing was launched
+    single = heamd.to_device(ct3[:1].copy())
+    assert lib.he_bfv_relinearize_device(ours.h, L, single.data_ptr(), dev_key.data_ptr(), single.data_ptr(), 1, None, 0, None) == 0
+    assert np.array_equal(heamd.to_host(single)[0, :2], ref.relinearize(ct3[:1], key, L)[0])
+
+
 def test_mul_and_relinearize_config3(oracle, config3):
     """BASELINE config 3 shape (N=8192, L=4): batch of 16, two items checked word for word against the oracle."""
     ours, ref = config3

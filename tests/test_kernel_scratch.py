@@ -34,7 +34,7 @@ def test_production_shapes_keep_no_array_in_scratch():
                                       "ntt_inverse_tiled<13, 10,", "ntt_forward_interleaved<1,", "ntt_inverse_interleaved<1,"))
         if production and scratch > 64:
             offenders.append((name, scratch))
-    for obj in ("rns_kernels.o", "poly_kernels.o", "galois_kernels.o", "word32_kernels.o"):
+    for obj in ("rns_kernels.o", "poly_kernels.o", "galois_kernels.o", "word32_kernels.o", "behz_kernels.o"):
         for name, scratch in _kernels(obj):
             if scratch > 64:
                 offenders.append((name, scratch))
