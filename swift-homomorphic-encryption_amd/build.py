@@ -38,12 +38,33 @@ def _headers_mtime():
     return newest
 
 
+def _dependencies(depfile):
+    """The prerequisites hipcc recorded for an object (-MD): the source and every header it really includes."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    return [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in text.split(":", 1)[1].split() if d]
+
+
 def _compile(src, force, header_time):
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    dep = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".d")
     path = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), header_time):
-        return obj, False
-    cmd = [_hipcc(), *FLAGS, "-c", path, "-o", obj]
+    if not force and os.path.exists(obj):
+        built = os.path.getmtime(obj)
+        deps = _dependencies(dep)
+        if deps is not None:
+            # rebuild only when something this object was compiled from is newer (a header one unit includes does not
+            # cost the four minutes of ntt_kernels.hip)
+            if all(os.path.exists(d) and os.path.getmtime(d) <= built for d in deps):
+                return obj, False
+        elif built >= max(os.path.getmtime(path), header_time):
+            return obj, False
+    cmd = [_hipcc(), *FLAGS, "-MMD", "-MF", dep, "-c", path, "-o", obj]
     if src.endswith(".cpp"):
         cmd[1:1] = ["-x", "hip"]
     result = subprocess.run(cmd, capture_output=True, text=True)

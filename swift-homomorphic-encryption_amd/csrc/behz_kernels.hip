@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, kBe
     {
         constexpr int INPUT_STAGES = kLazyTransformInput<MODE_I> ? kLazyInputStages : 0;
         const Twiddles<MODE_I> tw(ctx, true, mi, LOGN, 0, kLaneMajorTwiddles<LOGN, LOGT, MODE_I, true, false>);
-        TwiddleWords head[1];
-        inverse_row_head<LOGN, LOGE, MODE_I, false, 1>(head, tw, tid);
-        inverse_row<LOGN, LOGE, MODE_I, kBehzProducts, true, INPUT_STAGES, LOGN, false, 1>(products, tid, tw, mod, lds, head);
+        constexpr int HEAD = kGroupTwiddlesAhead<MODE_I, kBehzProducts>;
+        TwiddleWords head[HEAD];
+        inverse_row_head<LOGN, LOGE, MODE_I, false, HEAD>(head, tw, tid);
+        inverse_row<LOGN, LOGE, MODE_I, kBehzProducts, true, INPUT_STAGES, LOGN, false, HEAD>(products, tid, tw, mod, lds, head);
     }
     const uint32_t store_lane = step_lane<MODE_I>(tid);
 #pragma unroll
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, kBe
 template <int LOGN, int LOGT, int MODE_F, int MODE_I>
 hipError_t launch_band(uint64_t* out, const DeviceContext& ctx, const RowMap& map, size_t workgroups, const BehzRows& src,
                        hipStream_t stream) {
-    constexpr size_t lds_bytes = lds_words(1u << LOGN) * sizeof(uint64_t);
+    constexpr size_t lds_bytes = kGroupTiles<kBehzOperands> * lds_words(1u << LOGN) * sizeof(uint64_t);
     auto kernel = behz_rows_fused<LOGN, LOGT, MODE_F, MODE_I>;
     if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(workgroups)), dim3(1u << LOGT), lds_bytes, stream, out, ctx, map, src);

@@ -260,6 +260,11 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 // 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt).
 template <int MODE>
 constexpr int kTwiddlesAhead = 1;
+// ... and of the row groups of three and four (behz_kernels.hip: one workgroup per CU at 128 registers per lane -- there are
+// registers for deeper requests, and with 4 wavefronts per SIMD less else to hide a gather's latency)
+constexpr int kWideGroupTwiddlesAhead = 1;
+template <int MODE, int ROWS>
+constexpr int kGroupTwiddlesAhead = ROWS >= 3 ? kWideGroupTwiddlesAhead : kTwiddlesAhead<MODE>;
 
 template <int MODE>
 struct Lazy {
@@ -472,7 +477,7 @@ __device__ __forceinline__ void forward_pass(uint64_t (&v)[ROWS][1 << LOGE], uin
     static_assert(!is_split(MODE) || 1 + (LOGN << Lazy<MODE>::kProductLog) <= 511, "split mode: growth must stay below 2^9 p");
     const uint32_t lane_elements = lane_part<LOGN, LOGE, LO, W>(tid);
     const FoldConstants fc = mode_fold_constants<MODE>(p);
-    constexpr int AHEAD = kTwiddlesAhead<MODE>;
+    constexpr int AHEAD = kGroupTwiddlesAhead<MODE, ROWS>;
     TwiddleWords pending[AHEAD];
     pending[0] = first;
 #pragma unroll

@@ -70,15 +70,27 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // spills three words, spills six with them and loses more (0.572 -> 0.585 ms) than the conflict-free transposes give,
 // so it keeps the common rule; the forward kernels (0.510 -> 0.505 ms) and the [0, 8p) inverse (0.668 -> 0.659 ms) take
 // the per-transpose rules (profiles/r02ze_lds_schemes.txt).
+// Row groups of three and four (behz_kernels.hip) have the CU's LDS to themselves and may go through kWideGroupTiles tiles
+// side by side: that many rows per store / fence / load round, i.e. fewer fences (workgroup barriers in two of the four
+// transposes) and more LDS operations in flight per wave.
+constexpr int kWideGroupTiles = 1;
+template <int ROWS>
+constexpr int kGroupTiles = ROWS >= 3 ? kWideGroupTiles : 1;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS, bool PER_TRANSPOSE = true>
 __device__ __forceinline__ void exchange(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, uint64_t* lds) {
+    constexpr int TILES = kGroupTiles<ROWS>;
+    constexpr uint32_t TILE_WORDS = lds_words(1u << LOGN);
+    constexpr int SCHEME = PER_TRANSPOSE ? transpose_scheme<LOGN, LOGE, LO_FROM, LO_TO>() : 0;
 #pragma unroll
-    for (int row = 0; row < ROWS; ++row) {
-        constexpr int SCHEME = PER_TRANSPOSE ? transpose_scheme<LOGN, LOGE, LO_FROM, LO_TO>() : 0;
+    for (int row = 0; row < ROWS; row += TILES) {
         if (row > 0) lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
-        lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[row], tid, lds);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            if (row + t < ROWS) lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[row + t], tid, lds + t * TILE_WORDS);
         lds_transpose_fence<LOGN, LOGE, LO_FROM, LO_TO>();
-        lds_load<LOGN, LOGE, LO_TO, W_TO, SCHEME>(v[row], tid, lds);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            if (row + t < ROWS) lds_load<LOGN, LOGE, LO_TO, W_TO, SCHEME>(v[row + t], tid, lds + t * TILE_WORDS);
     }
 }
 
@@ -193,19 +205,21 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // doubles the inverse kernel's spills to scratch -- 0.659 against 0.620 ms per launch (profiles/r02d_ntt_ab_inverse_variants.txt).
 template <int MODE>
 constexpr bool kInverseFirstTwiddleEarly = false;
+constexpr bool kWideGroupFirstTwiddleEarly = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
           int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
     const uint32_t tid = step_lane<MODE>(lane);
-    TwiddleWords first{0, 0, 0};
-    if constexpr (kInverseFirstTwiddleEarly<MODE>)
-        first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
+    // (row groups of three and four -- behz_kernels.hip, 128 registers per lane -- have the registers for requests before the
+    // exchange and for more than one twiddle in flight: kWideGroupFirstTwiddleEarly, ntt_common.hpp kWideGroupTwiddlesAhead)
+    constexpr int AHEAD = kGroupTwiddlesAhead<MODE, ROWS>;
+    constexpr bool EARLY = ROWS >= 3 ? kWideGroupFirstTwiddleEarly : kInverseFirstTwiddleEarly<MODE>;
+    TwiddleWords head[AHEAD];
+    if constexpr (EARLY) inverse_first_twiddles<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, AHEAD, FIRST_STAGE>(head, tw, tid);
     exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
-    if constexpr (!kInverseFirstTwiddleEarly<MODE>)
-        first = inverse_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, FIRST_STAGE>(tw, tid);
-    const TwiddleWords head[1] = {first};
-    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE, 1>(v, tid, tw, mod, false, head);
+    if constexpr (!EARLY) inverse_first_twiddles<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, AHEAD, FIRST_STAGE>(head, tw, tid);
+    inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE, AHEAD>(v, tid, tw, mod, false, head);
 }
 
 // ROWS residue rows of the inverse transform, registers to registers: in -- the words of the low pass

@@ -435,6 +435,17 @@ class PolyContext:
         _check(load_library().he_ntt_forward(self.h, out.ctypes.data_as(U64P), self._batch_np(out)))
         return out
 
+    def forward_ntt_host_(self, array):
+        """In place on a host array (C-contiguous uint64): the call PolyRq.forwardNtt() on a host polynomial maps to."""
+        assert array.dtype == np.uint64 and array.flags["C_CONTIGUOUS"] and array.flags["WRITEABLE"]
+        _check(load_library().he_ntt_forward(self.h, array.ctypes.data_as(U64P), self._batch_np(array)))
+        return array
+
+    def inverse_ntt_host_(self, array):
+        assert array.dtype == np.uint64 and array.flags["C_CONTIGUOUS"] and array.flags["WRITEABLE"]
+        _check(load_library().he_ntt_inverse(self.h, array.ctypes.data_as(U64P), self._batch_np(array)))
+        return array
+
     def inverse_ntt_host(self, array):
         out = _u64(array).copy()
         _check(load_library().he_ntt_inverse(self.h, out.ctypes.data_as(U64P), self._batch_np(out)))
