@@ -16,7 +16,7 @@
 //
 // 7 row moves per 7 transforms instead of 14 + the tensor load's re-reads; two launches (Q band, Bsk band) instead of
 // four.  One 1024-lane workgroup per CU at 128 registers per lane (4 rows x 8 words = 64 registers of row data); the rows
-// share ONE transposition tile in turn, as the row pairs of the plain transforms do.
+// go through two transposition tiles side by side, two rows per round (ntt_rows.hpp kWideGroupTiles).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

@@ -3,12 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
-#include <atomic>
-#include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "api_internal.hpp"
@@ -38,141 +35,6 @@ int with_device_copy(uint64_t* host, size_t words, Body body) {
     (void)hipFree(device);
     if (status != HE_OK) return status;
     if (e != hipSuccess) return heamd::device_failure(e, "host-pointer round trip");
-    return HE_OK;
-}
-
-// ---- the host-pointer seam, pipelined -----------------------------------------------------------------------------------
-// PolyRq.forwardNtt() on a host slab (what the reference's benchmark loop times, Benchmarks/PolyBenchmark/
-// PolyBenchmark.swift:148-158) is upload + transform + download.  One blocking copy-kernel-copy from pageable memory runs
-// at the rate of the driver's internal bounce buffer (12.7 GB/s of host traffic measured); polynomials are independent, so
-// the slab goes in chunks of kStageBytes through page-locked staging instead: kStageWorkers host threads each take chunks
-// in turn -- memcpy into their own pinned block, asynchronous upload, transform and download on their own stream, memcpy
-// back -- so that one chunk's host copies run under the others' DMA and kernels (both copy engines and the link's two
-// directions busy at once).  The caller's pointer is not retained: every worker is joined before the call returns.
-// Blocks and streams are kept for the next call (page-locking costs more than the copy it serves): at most kStageKept of
-// them, per device; he_device_trim_scratch releases them.
-constexpr size_t kStageBytes = size_t(4) << 20;
-constexpr size_t kStageWorkers = 8, kStageKept = 16;
-struct Stage {
-    int device = 0;
-    void* block = nullptr;  // kStageBytes of page-locked host memory
-    hipStream_t stream = nullptr;
-};
-struct StagePool {
-    std::mutex mutex;
-    std::vector<Stage> idle;
-};
-StagePool& stage_pool() {
-    static StagePool pool;
-    return pool;
-}
-hipError_t stage_acquire(int device, Stage& out) {
-    {
-        StagePool& pool = stage_pool();
-        std::lock_guard<std::mutex> lock(pool.mutex);
-        for (size_t k = 0; k < pool.idle.size(); ++k) {
-            if (pool.idle[k].device != device) continue;
-            out = pool.idle[k];
-            pool.idle.erase(pool.idle.begin() + static_cast<std::ptrdiff_t>(k));
-            return hipSuccess;
-        }
-    }
-    out = Stage{device, nullptr, nullptr};
-    if (hipError_t e = hipHostMalloc(&out.block, kStageBytes, hipHostMallocDefault); e != hipSuccess) return e;
-    if (hipError_t e = hipStreamCreateWithFlags(&out.stream, hipStreamNonBlocking); e != hipSuccess) {
-        (void)hipHostFree(out.block);
-        out.block = nullptr;
-        return e;
-    }
-    return hipSuccess;
-}
-void stage_destroy(Stage& stage) {
-    if (stage.stream != nullptr) (void)hipStreamDestroy(stage.stream);
-    if (stage.block != nullptr) (void)hipHostFree(stage.block);
-    stage = Stage{};
-}
-void stage_release(Stage& stage) {
-    if (stage.block == nullptr) return;
-    StagePool& pool = stage_pool();
-    {
-        std::lock_guard<std::mutex> lock(pool.mutex);
-        if (pool.idle.size() < kStageKept) {
-            pool.idle.push_back(stage);
-            stage = Stage{};
-            return;
-        }
-    }
-    stage_destroy(stage);
-}
-void stage_trim() {
-    std::vector<Stage> idle;
-    {
-        StagePool& pool = stage_pool();
-        std::lock_guard<std::mutex> lock(pool.mutex);
-        idle.swap(pool.idle);
-    }
-    for (Stage& stage : idle) stage_destroy(stage);
-}
-
-// body(device words of the chunk, polynomials in it, stream): enqueues the chunk's work
-template <typename Body>
-int with_device_copy_pipelined(uint64_t* host, size_t batch, size_t poly_words, Body body) {
-    const size_t poly_bytes = poly_words * sizeof(uint64_t);
-    const size_t per_chunk = kStageBytes / poly_bytes;
-    const size_t chunks = per_chunk == 0 ? 0 : (batch + per_chunk - 1) / per_chunk;
-    if (chunks < 2) {  // a polynomial or two, or polynomials larger than a block: the plain round trip
-        return with_device_copy(host, batch * poly_words, [&](uint64_t* device, hipStream_t stream) { return body(device, batch, stream); });
-    }
-    int device = 0;
-    HEAMD_HIP_TRY(hipGetDevice(&device));
-    void* slab = nullptr;
-    HEAMD_HIP_TRY(hipMalloc(&slab, batch * poly_bytes));
-    std::atomic<size_t> next{0};
-    std::atomic<int> failed_status{HE_OK};
-    std::atomic<int> failed_hip{static_cast<int>(hipSuccess)};
-    auto worker = [&]() {
-        auto hip_failed = [&](hipError_t e) {
-            if (e == hipSuccess) return false;
-            int expected = static_cast<int>(hipSuccess);
-            failed_hip.compare_exchange_strong(expected, static_cast<int>(e));
-            return true;
-        };
-        if (hip_failed(hipSetDevice(device))) return;
-        Stage stage;
-        if (hip_failed(stage_acquire(device, stage))) return;
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= chunks || failed_status.load() != HE_OK || failed_hip.load() != static_cast<int>(hipSuccess)) break;
-            const size_t first = k * per_chunk, polys = batch - first < per_chunk ? batch - first : per_chunk;
-            const size_t bytes = polys * poly_bytes;
-            uint64_t* const on_host = host + first * poly_words;
-            uint64_t* const on_device = static_cast<uint64_t*>(slab) + first * poly_words;
-            std::memcpy(stage.block, on_host, bytes);
-            if (hip_failed(hipMemcpyAsync(on_device, stage.block, bytes, hipMemcpyHostToDevice, stage.stream))) break;
-            const int status = body(on_device, polys, stage.stream);
-            if (status != HE_OK) {
-                int expected = HE_OK;
-                failed_status.compare_exchange_strong(expected, status);
-                (void)hipStreamSynchronize(stage.stream);
-                break;
-            }
-            if (hip_failed(hipMemcpyAsync(stage.block, on_device, bytes, hipMemcpyDeviceToHost, stage.stream))) break;
-            if (hip_failed(hipStreamSynchronize(stage.stream))) break;
-            std::memcpy(on_host, stage.block, bytes);
-        }
-        (void)hipStreamSynchronize(stage.stream);  // nothing of this call is in flight when the block goes back
-        stage_release(stage);
-    };
-    const size_t workers = chunks < kStageWorkers ? chunks : kStageWorkers;
-    std::vector<std::thread> threads;
-    threads.reserve(workers - 1);
-    for (size_t t = 1; t < workers; ++t) threads.emplace_back(worker);
-    worker();
-    for (std::thread& t : threads) t.join();
-    (void)hipFree(slab);
-    if (failed_status.load() != HE_OK) return failed_status.load();
-    if (failed_hip.load() != static_cast<int>(hipSuccess))
-        return heamd::device_failure(static_cast<hipError_t>(failed_hip.load()), "host-pointer round trip");
     return HE_OK;
 }
 
@@ -338,7 +200,6 @@ int he_set_scratch_cache(uint64_t bytes) {
     return HE_OK;
 }
 int he_device_trim_scratch(uint64_t keep_bytes) {
-    if (keep_bytes == 0) stage_trim();  // the page-locked staging blocks of the host-pointer seam (ntt_host below)
     hipMemPool_t pool = scratch_pool();
     if (pool == nullptr) return HE_OK;  // nothing cached
     HEAMD_HIP_TRY(hipMemPoolTrimTo(pool, static_cast<size_t>(keep_bytes)));
@@ -549,10 +410,14 @@ static int ntt_host(const he_poly_context* ctx, uint64_t* host_slab, size_t batc
     if (host_slab == nullptr) return invalid_argument("null slab");
     int status = pc.check_device();
     if (status != HE_OK) return status;
-    return with_device_copy_pipelined(host_slab, batch, size_t(pc.moduli_count()) * pc.degree(),
-                                      [&](uint64_t* device, size_t polys, hipStream_t stream) {
-                                          return ntt_device(ctx, device, polys, inverse, stream);
-                                      });
+    // One blocking copy - kernel - copy on the calling thread's stream.  hipMemcpyAsync from pageable memory runs at the
+    // link's rate here (51 GB/s of host traffic for a 64 MiB slab, both directions counted); a pipeline of page-locked
+    // staging blocks filled by worker threads was built and measured SLOWER (43 GB/s: the host-side memcpy into the blocks
+    // costs more than the overlap gains) -- profiles/r05d_host_seam_pipelined_vs_blocking.txt.
+    const size_t words = batch * pc.moduli_count() * pc.degree();
+    return with_device_copy(host_slab, words, [&](uint64_t* device, hipStream_t stream) {
+        return ntt_device(ctx, device, batch, inverse, stream);
+    });
 }
 int he_ntt_forward(const he_poly_context* ctx, uint64_t* host_slab, size_t batch) {
     return ntt_host(ctx, host_slab, batch, false);

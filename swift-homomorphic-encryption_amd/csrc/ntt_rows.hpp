@@ -70,10 +70,11 @@ constexpr int min_waves_per_simd(int log_words_per_lane, int rows = 1) {
 // spills three words, spills six with them and loses more (0.572 -> 0.585 ms) than the conflict-free transposes give,
 // so it keeps the common rule; the forward kernels (0.510 -> 0.505 ms) and the [0, 8p) inverse (0.668 -> 0.659 ms) take
 // the per-transpose rules (profiles/r02ze_lds_schemes.txt).
-// Row groups of three and four (behz_kernels.hip) have the CU's LDS to themselves and may go through kWideGroupTiles tiles
-// side by side: that many rows per store / fence / load round, i.e. fewer fences (workgroup barriers in two of the four
-// transposes) and more LDS operations in flight per wave.
-constexpr int kWideGroupTiles = 1;
+// Row groups of three and four (behz_kernels.hip) have the CU's LDS to themselves and go through kWideGroupTiles tiles side
+// by side (2 x 76 KB of the CU's 160): that many rows per store / fence / load round, i.e. half the fences (workgroup
+// barriers in two of the four transposes) and more LDS operations in flight per wave -- ct x ct +2.3 % over one tile
+// (profiles/r05e_behz_tiles_and_lds_rules_ab.txt).
+constexpr int kWideGroupTiles = 2;
 template <int ROWS>
 constexpr int kGroupTiles = ROWS >= 3 ? kWideGroupTiles : 1;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int W_TO, int ROWS, bool PER_TRANSPOSE = true>
@@ -206,6 +207,9 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 template <int MODE>
 constexpr bool kInverseFirstTwiddleEarly = false;
 constexpr bool kWideGroupFirstTwiddleEarly = false;
+// the limb-wise inverse of a wide row group may take the per-transpose LDS padding rules (ntt_common.hpp transpose_scheme)
+// that the 64-register kernels cannot afford (exchange<> PER_TRANSPOSE)
+constexpr bool kWideGroupPerTransposeLds = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
           int LOGD = LOGN, int FIRST_STAGE = 0>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
@@ -217,7 +221,7 @@ __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uin
     constexpr bool EARLY = ROWS >= 3 ? kWideGroupFirstTwiddleEarly : kInverseFirstTwiddleEarly<MODE>;
     TwiddleWords head[AHEAD];
     if constexpr (EARLY) inverse_first_twiddles<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, AHEAD, FIRST_STAGE>(head, tw, tid);
-    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE)>(v, tid, lds);
+    exchange<LOGN, LOGE, LO_FROM, W_FROM, LO_TO, LOGE, ROWS, !is_split(MODE) || (ROWS >= 3 && kWideGroupPerTransposeLds)>(v, tid, lds);
     if constexpr (!EARLY) inverse_first_twiddles<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, AHEAD, FIRST_STAGE>(head, tw, tid);
     inverse_pass<LOGN, LOGE, LO_TO, LOGE, MODE, UNIFORM, ROWS, SCALED, PRIOR, LOGD, FIRST_STAGE, AHEAD>(v, tid, tw, mod, false, head);
 }
