@@ -52,7 +52,7 @@ BATCH = 4096
 PRE_ROLL_S = 0.25  # untimed set-up run of the job before the W warm-up steps (run_benchmark)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 HBM_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md: measured float4 streaming copy (79 % of peak)
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 ROOFLINE_WARMUPS, ROOFLINE_LAUNCHES = 10, 30  # >= 10 warm-ups, median of >= 30 launches
 
 
@@ -391,6 +391,7 @@ class NttWorkload:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_live": False,  # counter bytes per launch REPLAYED from the committed rocprofv3 --pmc passes (traffic_source) at this run's launch time; bench.py cannot run rocprofv3 around itself
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.bytes_per_transform * polys,
             "avg_launch_ms": forward_s * 1e3,
@@ -513,14 +514,16 @@ class CtMulWorkload:
         traffic = profile["hbm_bytes_per_unit"] * self.units / t_both / 1e9 if profile else None
         roofline = {
             "bound": "hbm",
-            "kernel": "pipeline of 10 launches (lift x2, [Q,Bsk] forward NTT x2 bands, tensor + inverse NTT x2 bands, "
-                      "floor, spread + forward NTT, key MAC + inverse NTT of the q_ks row, key MAC + inverse NTT of the "
-                      "other rows with the key switch's end in its store); achieved = compulsory bytes / time",
+            "kernel": "pipeline of 8 launches (lift x2, the row-fused BEHZ kernel x2 bands: four forward NTTs, tensor product and "
+                      "three inverse NTTs per (item, [Q,Bsk] row) in one workgroup; floor, spread + forward NTT, key MAC + "
+                      "inverse NTT of the q_ks row, key MAC + inverse NTT of the other rows with the key switch's end in its "
+                      "store); achieved = compulsory bytes / time",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_live": False,  # counter bytes per launch REPLAYED from the committed rocprofv3 --pmc passes (traffic_source) at this run's launch time; bench.py cannot run rocprofv3 around itself
             "traffic_frac": traffic / HBM_PEAK_GBPS if traffic else None,  # what the pipeline really moves, against the peak
             "traffic_bytes_per_unit": (profile or {}).get("hbm_bytes_per_unit"),
             "traffic_source": (profile or {}).get("source"),
@@ -584,6 +587,7 @@ class ModSwitchWorkload:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_live": False,  # counter bytes per launch REPLAYED from the committed rocprofv3 --pmc passes (traffic_source) at this run's launch time; bench.py cannot run rocprofv3 around itself
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.bytes_per_poly * self.units,
             "avg_launch_ms": t * 1e3,
@@ -667,6 +671,7 @@ class PirDim0Workload:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_live": False,  # counter bytes per launch REPLAYED from the committed rocprofv3 --pmc passes (traffic_source) at this run's launch time; bench.py cannot run rocprofv3 around itself
             "traffic_source": (profile or {}).get("source"),
             "algorithmic_bytes_per_launch": self.db_bytes,
             "avg_launch_ms": t * 1e3,

@@ -19,8 +19,8 @@ CSRC = os.path.join(ROOT, "swift-homomorphic-encryption_amd", "csrc")
 SIGNATURES = {
     "ntt_forward_tiled": "(uint64_t*, const DeviceContext, const RowMap, const SpreadSource)",
     "ntt_inverse_tiled": "(uint64_t*, const DeviceContext, const RowMap, const InverseSource)",
-    "ntt_forward_interleaved": "(uint64_t*, const DeviceContext, const RowMap)",
-    "ntt_inverse_interleaved": "(uint64_t*, const DeviceContext, const RowMap)",
+    "ntt_forward_interleaved": "(uint64_t*, const DeviceContext, const RowMap, const SpreadSource)",
+    "ntt_inverse_interleaved": "(uint64_t*, const DeviceContext, const RowMap, const InverseSource)",
 }
 
 

@@ -38,6 +38,12 @@ for leg in ${LEGS:-c3ab c3table}; do
        for lib in swift-homomorphic-encryption_amd/lib/variants/libhe_amd_host_seam_*.so; do
          [ -e "$lib" ] && { echo "$(basename $lib .so | sed s/libhe_amd_//)"; HEAMD_LIBRARY=$PWD/$lib timeout 300 python bench_tools/host_seam_probe.py; }
        done) > $O/host_seam.txt 2>&1; cat $O/host_seam.txt ;;
+    params)  # the reference's 60-bit parameter sets and N = 16384, production and the variant libraries named in PARAM_VARIANTS
+      (echo "production: $(timeout 600 python bench_tools/param_sets_bench.py 2>&1 | tail -1)"
+       for v in ${PARAM_VARIANTS:-}; do
+         lib=swift-homomorphic-encryption_amd/lib/variants/libhe_amd_$v.so
+         [ -e "$lib" ] && echo "$v: $(HEAMD_LIBRARY=$PWD/$lib timeout 600 python bench_tools/param_sets_bench.py 2>&1 | tail -1)"
+       done) > $O/param_sets.txt; cat $O/param_sets.txt ;;
     *) echo "unknown leg $leg" ;;
   esac
 done

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 closing pass: parity, the driver's bench command (+ rocprofv3 kernel stats of the same command), HBM counters
-# of the four workloads (-> profiles/r04_pmc_traffic.json, what bench.py reports as `traffic`), the other workload lines,
-# next-row and UInt32 benches.   bash bench_tools/r04_final.sh TAG
+# Round-5 closing pass (run ONCE per round): parity, the driver's bench command (+ rocprofv3 kernel stats of the same command), HBM counters
+# of the four workloads (-> profiles/r05_pmc_traffic.json, what bench.py reports as `traffic`), the other workload lines,
+# next-row and UInt32 benches.   bash bench_tools/r05_final.sh TAG
 cd "$GRAFT_REPO_ROOT"
-T=${1:-r04z}
+T=${1:-r05z}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
 O=gpurun_out/$T
@@ -21,8 +21,8 @@ pmc c3 bench_tools/c3_profile_target.py
 pmc c4 bench_tools/c4_profile_target.py
 pmc c5 bench_tools/c5_profile_target.py
 (for d in c2 c3 c4 c5; do echo "== $d"; python bench_tools/pmc_traffic.py $O/pmc_$d | grep -v "at::\|rocclr"; done) > $O/pmc_traffic_per_kernel.txt
-python bench_tools/traffic_json.py $O/pmc_c2 $O/pmc_c3 $O/pmc_c4 $O/pmc_c5 $O/r04_pmc_traffic.json > /dev/null
-cp $O/r04_pmc_traffic.json profiles/r04_pmc_traffic.json
+python bench_tools/traffic_json.py $O/pmc_c2 $O/pmc_c3 $O/pmc_c4 $O/pmc_c5 $O/r05_pmc_traffic.json > /dev/null
+cp $O/r05_pmc_traffic.json profiles/r05_pmc_traffic.json
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
 cut -c1-400 $O/bench.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --skip-other-configs --no-cpu-baseline > $O/bench_ntt_only.json 2> $O/bench_stats.err
@@ -37,11 +37,14 @@ timeout 600 python bench_tools/word32_scheme_bench.py > $O/word32_scheme.json 2>
 timeout 600 python bench_tools/ntt_variants.py > $O/ntt_variants.txt 2>&1
 timeout 600 python bench_tools/expand_batch_profile_target.py > $O/expand_batch.txt 2>&1
 timeout 600 python bench_tools/wire_format_bench.py > $O/wire_format.json 2>&1
+timeout 300 python bench_tools/host_seam_probe.py > $O/host_seam.txt 2>&1
+timeout 600 python bench_tools/param_sets_bench.py > $O/param_sets.txt 2>&1
 # register / scratch figures of the built library's headline, key-MAC and interleaved kernels, and the static instruction
 # mix of the headline pair (the build's own code objects; no GPU involved)
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 3" > $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 7" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<12, 9, " >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "interleaved" >> $O/isa_stats.txt 2>&1
+python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/behz_kernels.o --filter "behz" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py --spills-only >> $O/isa_stats.txt 2>&1
 rm -rf $O/bench_stats $O/c3_stats $O/pmc_c2/*/ $O/pmc_c3/*/ $O/pmc_c4/*/ $O/pmc_c5/*/

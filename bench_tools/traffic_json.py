@@ -1,4 +1,4 @@
-"""Builds profiles/r04_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
+"""Builds profiles/r05_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
 bench_tools/pmc_traffic.py leaves in the PMC pass directories of the four workloads.
 
   python bench_tools/traffic_json.py <ntt-dir> <c3-dir> <c4-dir> <c5-dir> <out.json>
@@ -29,7 +29,7 @@ def bytes_per_dispatch(report, needle, exclude=()):
 
 def main():
     ntt_dir, c3_dir, c4_dir, c5_dir, out = sys.argv[1:6]
-    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r04_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
+    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r05_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
     result = {}
     ntt = load(ntt_dir)
     forward, names = bytes_per_dispatch(ntt, "ntt_forward_tiled")

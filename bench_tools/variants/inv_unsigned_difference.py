@@ -4,8 +4,5 @@ DESCRIPTION = ("every limb-wise inverse transform multiplies x + bound - y as an
 EDITS = [
     ("ntt_kernels.hip", "constexpr bool kSignedInverse = !(LOGN == 13 && (SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled));",
      "constexpr bool kSignedInverse = false;"),
-    ("ntt_kernels.hip", "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, true>",
-     "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, true>"),
-    ("ntt_kernels.hip", "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, false>",
-     "        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplit, false>"),
+    ("ntt_kernels.hip", "constexpr int kInterleavedInverseSplit = kModeSplitSigned;", "constexpr int kInterleavedInverseSplit = kModeSplit;"),
 ]

@@ -44,9 +44,35 @@ struct BehzRows {
 
 constexpr int kBehzOperands = 4, kBehzProducts = 3;
 
-// a0 b0 | a0 b1 + a1 b0 | a1 b1 of canonical words, as the inverse transform of MODE takes them: in [0, 5p) for the
-// limb-wise and fold butterflies (ntt_rows.hpp kLazyTransformInput), canonical otherwise.  The cross term is one exact
-// 128-bit sum and one reduction.
+// The transformed operand words as the tensor product takes them.  Where the products go through the one-word-quotient Barrett
+// (reduce_product_sum_bounded_lazy: any sum below 2^(63 + bits(p))) the words stay in [0, 2p) -- the last conditional subtract
+// of every word is not spent: the cross term of such words is below 8 p^2, which is inside the bound for every modulus these
+// butterfly classes admit (limb-wise: p < 2^55; fold: p = 2^b - d with b <= 60, or 2^60 + e with e < 2^24, whose 8 p^2 is
+// 2^123 (1 + 2^-35)); the [0, 8p) and exact classes hand over canonical words.
+constexpr bool kBehzLazyOperands = true;
+template <int MODE, int ROWS, int E>
+__device__ __forceinline__ void reduce_operands(uint64_t (&v)[ROWS][E], uint64_t p) {
+    if constexpr (!kLazyTransformInput<MODE> || !kBehzLazyOperands) {
+        canonicalize_all<MODE>(v, p);
+    } else {
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                if constexpr (is_split(MODE)) {
+                    v[row][r] = LazyReducer(p).lazy(v[row][r]);  // below 2^10 p -> [0, 2p)
+                } else {
+                    static_assert(is_fold(MODE), "the lazy transform inputs are the limb-wise and the fold classes");
+                    v[row][r] = csub_uniform(csub_uniform(csub_uniform(v[row][r], 8 * p), 4 * p), 2 * p);  // below 14p -> [0, 2p)
+                }
+            }
+        }
+    }
+}
+
+// a0 b0 | a0 b1 + a1 b0 | a1 b1, as the inverse transform of MODE takes them: in [0, 5p) for the limb-wise and fold
+// butterflies (ntt_rows.hpp kLazyTransformInput; operands in [0, 2p), reduce_operands), canonical otherwise (canonical
+// operands).  The cross term is one exact 128-bit sum and one reduction.
 template <int MODE, int E>
 __device__ __forceinline__ void tensor_rows(uint64_t (&v)[kBehzOperands][E], const DeviceModulus& mod) {
 #pragma unroll
@@ -102,8 +128,10 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, kBe
     const DeviceModulus mod = ctx.moduli[mi];
     {
         const Twiddles<MODE_F> tw(ctx, false, mi, LOGN, 0, kLaneMajorTwiddles<LOGN, LOGT, MODE_F, false, true>);
-        forward_row<LOGN, LOGE, MODE_F, kBehzOperands, true, false>(v, tid, tw, mod.p, lds);
+        forward_row<LOGN, LOGE, MODE_F, kBehzOperands, false, false>(v, tid, tw, mod.p, lds);
     }
+    static_assert(kLazyTransformInput<MODE_F> == kLazyTransformInput<MODE_I>, "one butterfly class per band");
+    reduce_operands<MODE_F>(v, mod.p);
     // ---- the tensor product where the words lie: forward_row leaves them in the layout of the pass on the low bits, which
     // is the layout inverse_row takes them in
     tensor_rows<MODE_I>(v, mod);

@@ -635,7 +635,8 @@ __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 
 }
 
 // inverse cross stage c pairs sub-row bit c (element bit c): m = N >> (c + 1) groups, twiddle (N - 2m + 1) + (idx >> (c + 1))
-template <int LOGS, int MODE>
+// PRIOR: the words enter in the lazy range of a row whose first PRIOR stages already ran (the fused loads' [0, 5p) words)
+template <int LOGS, int MODE, int PRIOR = 0>
 __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
                                                      const Twiddles<MODE>& tw, uint64_t p) {
     constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog;
@@ -644,7 +645,7 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
     const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
 #pragma unroll
     for (int c = 0; c < LOGS; ++c) {
-        const int in_shift = inverse_in_shift<MODE>(c);
+        const int in_shift = inverse_in_shift<MODE>(c + PRIOR);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;
         const uint32_t m = N >> (c + 1);
@@ -676,9 +677,9 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
 }
 
 // Words i = r 1024 + tid (top-pass layout of the sub-rows) of all sub-rows: 8 2^LOGS contiguous bytes of the row per lane.
-template <int LOGS, bool STORE>
+template <int LOGS, bool STORE, int POLICY = row_policy<kSubLogN + LOGS>()>
 __device__ __forceinline__ void interleaved_top_words(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid, BufferResource row) {
-    constexpr int ROWS = 1 << LOGS, POLICY = row_policy<kSubLogN + LOGS>();
+    constexpr int ROWS = 1 << LOGS;
     const uint32_t lane_bytes = tid << (3 + LOGS);
 #pragma unroll
     for (int r = 0; r < (1 << kSubLogE); ++r) {
@@ -776,21 +777,64 @@ __device__ __forceinline__ void interleaved_low_words_staged(uint64_t (&v)[1 << 
     }
 }
 
-template <int LOGS, int MODE>
+// SPREAD: the row sources of ntt_forward_tiled (kSourceSpread without the automorphism, kSourceLift, kSourceRows) -- the step
+// that would otherwise write the slab is applied to the words as they are loaded, in the top-pass layout of the sub-rows
+// (a lane's words of all sub-rows are contiguous bytes of the SOURCE row too).
+template <int LOGS, int MODE, int SPREAD = kSourceSlab>
 __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 << LOGS))
-    ntt_forward_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map) {
-    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS;
+    ntt_forward_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const SpreadSource spread) {
+    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS, E = 1 << kSubLogE;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[1];
-    locate_rows<1>(map, blockIdx.x, rows, record, within);
+    if constexpr (SPREAD == kSourceSpread || SPREAD == kSourceLift) {
+        // the band_rows output rows of a record are transforms of one source row: one replica set per record
+        uint32_t group;
+        locate_replica(blockIdx.x, gridDim.x / map.band_rows, map.band_rows, group, within);
+        record = map.record_base + group;
+        rows[0] = size_t(record) * (map.record_rows == 0 ? map.band_rows : map.record_rows) + map.band_offset + within;
+    } else {
+        locate_rows<1>(map, blockIdx.x, rows, record, within);
+    }
     const uint32_t mi = map.mod_base + within;
-    const uint64_t p = ctx.moduli[mi].p;
+    const DeviceModulus mod = ctx.moduli[mi];
+    const uint64_t p = mod.p;
     const Twiddles<MODE> tw(ctx, false, mi, LOGD);
     const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
-    uint64_t v[ROWS][1 << kSubLogE];
-    interleaved_top_words<LOGS, false>(v, tid, row);
+    uint64_t v[ROWS][E];
+    if constexpr (SPREAD == kSourceRows) {
+        const uint64_t* source;
+        if (spread.second == nullptr) {
+            source = spread.base + size_t(record) * spread.stride + (static_cast<size_t>(within) << LOGD);
+        } else {
+            const size_t item = record >> 2, slot = record & 3;
+            source = ((slot & 2) != 0 ? spread.second : spread.base) + item * spread.stride + (((slot & 1) * spread.L + within) << LOGD);
+        }
+        interleaved_top_words<LOGS, false>(v, tid, make_uniform_resource(source, 8u << LOGD));
+    } else if constexpr (SPREAD != kSourceSlab) {
+        const size_t poly = record / spread.L, j = record - poly * spread.L;  // record = poly * L + j
+        // cached: the other rows of this record read the same words
+        interleaved_top_words<LOGS, false, 0>(v, tid, make_uniform_resource(spread.base + poly * spread.stride + (j << LOGD), 8u << LOGD));
+        if constexpr (SPREAD == kSourceLift) {
+            const uint64_t threshold = (spread.plaintext_modulus + 1) >> 1, increment = p - spread.plaintext_modulus;
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h)
+#pragma unroll
+                for (int r = 0; r < E; ++r) v[h][r] = v[h][r] < threshold ? v[h][r] : v[h][r] + increment;
+        } else {
+            // rare (moduli of very different sizes; ntt_forward_tiled): the source row is canonical mod a larger modulus
+            const bool reduce = ctx.moduli[j].p > p && !(is_split(MODE) && ctx.moduli[j].p < 2 * p);  // wave-uniform
+            if (reduce) {
+#pragma unroll
+                for (int h = 0; h < ROWS; ++h)
+#pragma unroll
+                    for (int r = 0; r < E; ++r) v[h][r] = reduce ? barrett_reduce64_uniform(v[h][r], p, mod.barrett64) : v[h][r];
+            }
+        }
+    } else {
+        interleaved_top_words<LOGS, false>(v, tid, row);
+    }
     forward_row<kSubLogN, kSubLogE, MODE, ROWS, false>(v, tid, tw, p, lds);
     forward_cross_stages<LOGS, MODE>(v, tid, tw, p);
     canonicalize_all<MODE>(v, p);
@@ -800,27 +844,124 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     else interleaved_low_words<LOGS, true>(v, tid, row);
 }
 
-template <int LOGS, int MODE, bool SCALED>
+// SOURCE: kInverseFromSlab, or the fused loads of ntt_inverse_tiled -- kInverseFromTensor (the BEHZ tensor product) and
+// kInverseFromKeyMac (the lazy inner product with the key-switching key) -- formed in the low-pass layout of the sub-rows: the
+// words (element i, sub-rows h, h + 1) are 16 contiguous bytes of every source row.
+template <int LOGS, int MODE, bool SCALED, int SOURCE = kInverseFromSlab>
 __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 << LOGS))
-    ntt_inverse_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map) {
-    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS;
+    ntt_inverse_interleaved(uint64_t* __restrict__ slab, const DeviceContext ctx, const RowMap map, const InverseSource source_spec) {
+    constexpr int ROWS = 1 << LOGS, LOGD = kSubLogN + LOGS, E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R;
+    constexpr bool TENSOR = SOURCE == kInverseFromTensor, KEYMAC = SOURCE == kInverseFromKeyMac;
+    static_assert(SOURCE == kInverseFromSlab || TENSOR || KEYMAC, "the key switch's end stays with the tiled kernel");
+    static_assert(!TENSOR || SCALED, "the fused tensor load belongs to dropExtendedBase (t N^-1)");
+    constexpr int INPUT_STAGES = (TENSOR || KEYMAC) && kLazyTransformInput<MODE> ? kLazyInputStages : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
     size_t rows[1];
-    locate_rows<1>(map, blockIdx.x, rows, record, within);
+    if constexpr (TENSOR || KEYMAC) {
+        constexpr uint32_t REPLICAS = TENSOR ? 3 : 2;  // records (item, c) of one item read the same source rows
+        uint32_t set, c, group;
+        locate_replica(blockIdx.x, gridDim.x / REPLICAS, REPLICAS, set, c);
+        locate(map, set, group, within);
+        record = (map.record_base + group) * REPLICAS + c;
+        rows[0] = size_t(record) * map.record_rows + map.band_offset + within;
+    } else {
+        locate_rows<1>(map, blockIdx.x, rows, record, within);
+    }
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> cross(ctx, true, mi, LOGD);
     const Twiddles<MODE> tail(ctx, true, mi, LOGD, (1u << LOGD) - (1u << kSubLogN));
     const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
-    uint64_t v[ROWS][1 << kSubLogE];
-    if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
-    else interleaved_low_words<LOGS, false>(v, tid, row);
-    inverse_cross_stages<LOGS, MODE>(v, tid, cross, mod.p);
+    uint64_t v[ROWS][E];
+    if constexpr (TENSOR) {
+        const size_t item = record / 3;
+        const uint32_t c = static_cast<uint32_t>(record - item * 3);  // wave-uniform
+        const size_t poly_words = static_cast<size_t>(map.record_rows) << LOGD;
+        const uint64_t* const source = source_spec.first + item * 4 * poly_words + (static_cast<size_t>(map.band_offset + within) << LOGD);
+        const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid) << LOGS;
+        auto reduce = [&](const ProductSum& sum) {
+            if constexpr (kLazyTransformInput<MODE>) return reduce_product_sum_bounded_lazy(sum, mod);
+            else return mod.wide_shift != 0 ? reduce_product_sum_bounded(sum, mod) : reduce_product_sum(sum, mod);  // wave-uniform
+        };
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+#pragma unroll
+            for (int h = 0; h < ROWS; h += 2) {
+                const size_t at = (register_part<kSubLogN, kSubLogE, 0, R>(r) << LOGS) + lane_words + h;
+                if (c != 1) {
+                    const U64x2 a = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 0 : 1) * poly_words + at);
+                    const U64x2 b = *reinterpret_cast<const U64x2*>(source + (c == 0 ? 2 : 3) * poly_words + at);
+                    if constexpr (kLazyTransformInput<MODE>) {
+                        v[h][r] = reduce_product_sum_bounded_lazy(product_sum_first(a.x, b.x), mod);
+                        v[h + 1][r] = reduce_product_sum_bounded_lazy(product_sum_first(a.y, b.y), mod);
+                    } else {
+                        v[h][r] = barrett_mul(a.x, b.x, mod.p, mod.product_factor, static_cast<int>(mod.product_shift));
+                        v[h + 1][r] = barrett_mul(a.y, b.y, mod.p, mod.product_factor, static_cast<int>(mod.product_shift));
+                    }
+                } else {
+                    const U64x2 a0 = *reinterpret_cast<const U64x2*>(source + at);
+                    const U64x2 a1 = *reinterpret_cast<const U64x2*>(source + poly_words + at);
+                    const U64x2 b0 = *reinterpret_cast<const U64x2*>(source + 2 * poly_words + at);
+                    const U64x2 b1 = *reinterpret_cast<const U64x2*>(source + 3 * poly_words + at);
+                    ProductSum cross0 = product_sum_first(a0.x, b1.x), cross1 = product_sum_first(a0.y, b1.y);
+                    product_sum_add(cross0, a1.x, b0.x);
+                    product_sum_add(cross1, a1.y, b0.y);
+                    v[h][r] = reduce(cross0);
+                    v[h + 1][r] = reduce(cross1);
+                }
+            }
+        }
+    } else if constexpr (KEYMAC) {
+        const size_t poly = record >> 1, c = record & 1;  // record = poly * 2 + c
+        const uint32_t L = source_spec.L, top_rows = source_spec.top_rows;
+        const uint32_t band_row = map.band_offset + within;
+        const uint32_t key_row = (band_row == L) ? top_rows - 1 : band_row;  // Bfv+Keys.swift:153
+        const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid) << LOGS;
+        const bool bounded = kKeyMacBoundedReduce && mod.wide_shift != 0 && L <= 8 && uint64_t(L) * mod.p < (uint64_t(1) << 63);  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+#pragma unroll
+            for (int h = 0; h < ROWS; h += 2) {
+                const uint32_t at = (register_part<kSubLogN, kSubLogE, 0, R>(r) << LOGS) + h;
+                // the words of term j + 1 are requested before term j is accumulated (ntt_inverse_tiled)
+                const uint64_t* const flat_spread = source_spec.first + ((poly * L * (L + 1) + band_row) << LOGD) + lane_words + at;
+                const uint64_t* const flat_key = source_spec.second + ((c * top_rows + key_row) << LOGD) + lane_words + at;
+                U64x2 xs = *reinterpret_cast<const U64x2*>(flat_spread);
+                U64x2 ks = *reinterpret_cast<const U64x2*>(flat_key);
+                ProductSum acc0 = product_sum_zero(), acc1 = product_sum_zero();
+                for (uint32_t j = 0; j < L; ++j) {
+                    const uint32_t ahead = j + 1 < L ? j + 1 : j;
+                    const U64x2 xn = *reinterpret_cast<const U64x2*>(flat_spread + ((size_t(ahead) * (L + 1)) << LOGD));
+                    const U64x2 kn = *reinterpret_cast<const U64x2*>(flat_key + ((size_t(ahead) * 2 * top_rows) << LOGD));
+                    product_sum_add_one<is_split(MODE)>(acc0, xs.x, ks.x);
+                    product_sum_add_one<is_split(MODE)>(acc1, xs.y, ks.y);
+                    xs = xn;
+                    ks = kn;
+                }
+                if (bounded) {
+                    if constexpr (kLazyTransformInput<MODE>) {
+                        v[h][r] = reduce_product_sum_bounded_lazy(acc0, mod);
+                        v[h + 1][r] = reduce_product_sum_bounded_lazy(acc1, mod);
+                    } else {
+                        v[h][r] = reduce_product_sum_bounded(acc0, mod);
+                        v[h + 1][r] = reduce_product_sum_bounded(acc1, mod);
+                    }
+                } else {
+                    v[h][r] = reduce_product_sum(acc0, mod);
+                    v[h + 1][r] = reduce_product_sum(acc1, mod);
+                }
+            }
+        }
+    } else {
+        if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
+        else interleaved_low_words<LOGS, false>(v, tid, row);
+    }
+    inverse_cross_stages<LOGS, MODE, INPUT_STAGES>(v, tid, cross, mod.p);
     TwiddleWords head[1];
     inverse_row_head<kSubLogN, kSubLogE, MODE, false, 1>(head, tail, tid);
-    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS, LOGD>(v, tid, tail, mod, lds, head);
+    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS + INPUT_STAGES, LOGD>(v, tid, tail, mod, lds, head);
     interleaved_top_words<LOGS, true>(v, tid, row);
 }
 
@@ -933,6 +1074,72 @@ constexpr int kTensorRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kTensorRowGroup 
 template <int LOGN, int LOGT>
 constexpr int kKeyMacRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kKeyMacRowGroup : 1;
 
+// Interleaved launches (ntt_forward_interleaved / ntt_inverse_interleaved): one workgroup per row of 2^(13 + LOGS) words.
+// N = 16384 takes them for plain slabs instead of the streamed rows (profiles/r03p_ntt_interleaved.txt); N = 32768 has no
+// other tiled kernel.  Round 5: the fused loads at N = 16384 (key-switching decomposition, plaintext lift, the Q band of the
+// lifted records into the forward transform; tensor product and key inner product into the inverse one) take the same form
+// -- two workgroups per CU at 64 registers instead of the 16-words-per-lane tile at one (kInterleavedFusedLoads).
+constexpr bool kInterleaved16384 = true;
+constexpr bool kInterleavedFusedLoads = true;
+// (the key MAC's rows r < L stay on the 16-words-per-lane tile, whose store carries the key switch's end: interleaved sub-rows
+// plus the separate finish kernel measured 134.9 k relinearize/s at N = 16384, L = 6 against 157.8 k this way and 143.7 k with
+// every fused load on the tile -- profiles/r05f_fused_loads_16384_ab.txt; the q_ks row and the other fused loads are interleaved)
+constexpr bool kInterleavedKeyMacAt16384 = false;
+// (four sub-rows -- N = 32768, one workgroup per CU at 128 registers -- go through two tiles side by side like the row groups
+// of behz_kernels.hip: ntt_rows.hpp kGroupTiles)
+template <int LOGS>
+constexpr size_t kInterleavedLdsBytes = kGroupTiles<(1 << LOGS)> * lds_words(1u << kSubLogN) * sizeof(uint64_t);
+template <int LOGS, int SPREAD>
+hipError_t launch_interleaved_forward(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+                                      const SpreadSource& spread, hipStream_t stream) {
+    auto kernel = mode == kModeSplit    ? ntt_forward_interleaved<LOGS, kModeSplit, SPREAD>
+                  : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox, SPREAD>
+                                        : ntt_forward_interleaved<LOGS, kModeExact, SPREAD>;
+    if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
+                       spread);
+    return hipGetLastError();
+}
+// the limb-wise butterflies of the interleaved inverse: the signed difference (ntt_common.hpp kModeSplitSigned; N = 16384 -3.9 %,
+// profiles/r04t_inverse_forms_ab.txt)
+constexpr int kInterleavedInverseSplit = kModeSplitSigned;
+template <int LOGS, int SOURCE>
+hipError_t launch_interleaved_inverse(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+                                      const InverseSource& source_spec, hipStream_t stream) {
+    using Kernel = void (*)(uint64_t*, const DeviceContext, const RowMap, const InverseSource);
+    Kernel kernel;
+    if constexpr (SOURCE == kInverseFromTensor) {
+        if (ctx.scaled_inverse_degree == 0) return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kInterleavedInverseSplit, true, SOURCE>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, true, SOURCE>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, true, SOURCE>;
+    } else if constexpr (SOURCE == kInverseFromKeyMac) {
+        if (ctx.scaled_inverse_degree != 0) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kInterleavedInverseSplit, false, SOURCE>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false, SOURCE>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, false, SOURCE>;
+    } else if (ctx.scaled_inverse_degree != 0) {
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kInterleavedInverseSplit, true, SOURCE>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, true, SOURCE>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, true, SOURCE>;
+    } else {
+        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kInterleavedInverseSplit, false, SOURCE>
+                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false, SOURCE>
+                                       : ntt_inverse_interleaved<LOGS, kModeExact, false, SOURCE>;
+    }
+    if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
+                       source_spec);
+    return hipGetLastError();
+}
+template <int LOGS>
+hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
+                              hipStream_t stream) {
+    if (!inverse) return launch_interleaved_forward<LOGS, kSourceSlab>(mode, slab, ctx, map, rows, SpreadSource{nullptr, 0, 0, 0, 0}, stream);
+    return launch_interleaved_inverse<LOGS, kInverseFromSlab>(mode, slab, ctx, map, rows,
+                                                              InverseSource{nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0}, stream);
+}
+
 template <int LOGN, int LOGT, int SPREAD, int ROWS>
 hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
                                  const SpreadSource& spread, hipStream_t stream) {
@@ -963,6 +1170,12 @@ template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                 uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream,
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
+    if constexpr (LOGN == 14 && LOGT == 10 && SPREAD != kSourceSlab && kInterleavedFusedLoads) {
+        // as two interleaved sub-rows (the automorphism of a Galois key switch permutes whole rows: tiled kernel below)
+        if (spread.galois_inverse == 0)
+            return launch_interleaved_forward<1, SPREAD>(mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                                                         rows, spread, stream);
+    }
     size_t paired_records = 0;  // records covered by the launch of row groups
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
     if constexpr (GROUP > 1) {
@@ -1004,34 +1217,6 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     return hipGetLastError();
 }
 
-// Interleaved launches (ntt_forward_interleaved / ntt_inverse_interleaved): one workgroup per row of 2^(13 + LOGS) words.
-// N = 16384 takes them for plain slabs instead of the streamed rows (profiles/r03p_ntt_interleaved.txt); N = 32768 has no
-// other tiled kernel.
-constexpr bool kInterleaved16384 = true;
-template <int LOGS>
-hipError_t launch_interleaved(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, const RowMap& map, size_t rows,
-                              hipStream_t stream) {
-    constexpr size_t lds_bytes = lds_words(1u << kSubLogN) * sizeof(uint64_t);
-    using Kernel = void (*)(uint64_t*, const DeviceContext, const RowMap);
-    Kernel kernel;
-    if (!inverse) {
-        kernel = mode == kModeSplit    ? ntt_forward_interleaved<LOGS, kModeSplit>
-                 : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox>
-                                       : ntt_forward_interleaved<LOGS, kModeExact>;
-    } else if (ctx.scaled_inverse_degree != 0) {
-        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, true>
-                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, true>
-                                       : ntt_inverse_interleaved<LOGS, kModeExact, true>;
-    } else {
-        kernel = mode == kModeSplit    ? ntt_inverse_interleaved<LOGS, kModeSplitSigned, false>
-                 : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false>
-                                       : ntt_inverse_interleaved<LOGS, kModeExact, false>;
-    }
-    if (hipError_t e = allow_dynamic_lds(kernel, lds_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), lds_bytes, stream, slab, ctx, map);
-    return hipGetLastError();
-}
-
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
@@ -1058,6 +1243,14 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
         return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
     }
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+    if constexpr (LOGN == 14 && LOGT == 10 && kInterleavedFusedLoads) {
+        // tensor product / key inner product into the interleaved inverse: one record (item, c) per workgroup; the key switch's
+        // fused end (kInverseFromKeyMacFinish) is not offered at this degree (ntt_key_mac_finish_supported)
+        if (source == kInverseFromTensor)
+            return launch_interleaved_inverse<1, kInverseFromTensor>(mode, slab, ctx, map, rows, source_spec, stream);
+        if (source == kInverseFromKeyMac)
+            return launch_interleaved_inverse<1, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+    }
     if (source == kInverseFromTensor || is_key_mac(source)) {
         // records are (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the odd items at
         // the end go one per workgroup.  record_base counts items for these kernels.
@@ -1290,6 +1483,9 @@ bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t po
     // transform and the small element-wise kernel -- single-query expansions lost 11-29 % with the fused end at every
     // level, and the Galois key switch crosses over between 96 and 128 ciphertexts at N = 8192, L = 4:
     // profiles/r04m_galois_fused_end_ab.txt)
+    // (N = 16384: the key MAC runs as interleaved sub-rows, two workgroups per CU, and ends in the separate finish kernel --
+    // kInterleavedKeyMacAt16384, measured against the 16-words-per-lane tile with the fused end)
+    if (ks.log_degree == 14 && kInterleavedFusedLoads && kInterleavedKeyMacAt16384) return false;
     return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && polys * 2 * (L + 1) > 2 * kOneGeneration &&
            polys * 2 * (L + 1) <= (size_t(1) << 30);
 }

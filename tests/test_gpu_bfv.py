@@ -665,6 +665,38 @@ def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     assert np.array_equal(lifted, np.concatenate([ref.plaintext_to_eval(v) for v in values]).reshape(lifted.shape))
 
 
+@pytest.mark.parametrize("bits,batch", [([55, 55, 55, 55], 9), ([55, 41, 50, 55], 5), ([61, 45, 62, 55], 3), ([50, 55], 140)])
+def test_interleaved_fused_loads_at_16384(oracle, bits, batch):
+    """N = 16384: the transforms with a fused load stage run as two interleaved sub-rows of the 8192-point kernel (round 5;
+    ntt_forward_interleaved<1, MODE, kSourceSpread | kSourceLift | kSourceRows>, ntt_inverse_interleaved<1, MODE, ...,
+    kInverseFromTensor | kInverseFromKeyMac>) -- ct x ct, relinearize, applyGalois' decomposition without the automorphism and
+    Plaintext.convertToEvalFormat on odd batches: limb-wise moduli, moduli of very different sizes (the decomposition reduces
+    its source row first), 61 / 62-bit moduli (the [0, 8p) and the exact butterflies) and a batch wide enough for the key
+    switch's fused end on the other degrees.  Word for word against the oracle (EncryptionParameters.swift:200-206 allows the
+    degree)."""
+    from conftest import host_threads
+
+    degree = 16384
+    t = oracle.generate_primes([17], True, degree)[0]
+    q = oracle.generate_primes(bits, False, degree)
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli, L = q[:-1], len(q) - 1
+    rng = np.random.default_rng(16384 + batch)
+    lhs, rhs = _uniform(rng, (batch, 2), moduli, degree), _uniform(rng, (batch, 2), moduli, degree)
+    for i, m in enumerate(moduli):
+        lhs[0, :, i, :] = m - 1
+        rhs[0, :, i, :] = m - 1
+    product = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs)))
+    expected = ref.mul(lhs, rhs, threads=host_threads())
+    assert np.array_equal(product, expected)
+    key = _uniform(rng, (L, 2), q, degree)
+    relin = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key)))
+    assert np.array_equal(relin, ref.relinearize(expected, key, threads=host_threads()))
+    values = rng.integers(0, t, size=(3, degree), dtype=np.uint64)
+    lifted = heamd.to_host(ours.plaintext_to_eval(heamd.to_device(values)))
+    assert np.array_equal(lifted, np.concatenate([ref.plaintext_to_eval(v) for v in values]).reshape(lifted.shape))
+
+
 @pytest.mark.parametrize("bits,count", [([62, 62, 62], 21), ([62, 45, 61, 62], 9), ([62] * 9, 17)])
 def test_inner_product_ct_ct_reduction_cadence(oracle, bits, count):
     """Bfv.innerProduct(ct, ct) where the [Q, Bsk] accumulators must be reduced inside the loop (Bfv.swift:339-353):
