@@ -44,6 +44,12 @@ for leg in ${LEGS:-c3ab c3table}; do
          lib=swift-homomorphic-encryption_amd/lib/variants/libhe_amd_$v.so
          [ -e "$lib" ] && echo "$v: $(HEAMD_LIBRARY=$PWD/$lib timeout 600 python bench_tools/param_sets_bench.py 2>&1 | tail -1)"
        done) > $O/param_sets.txt; cat $O/param_sets.txt ;;
+    smallmul)  # ct x ct on small batches, production and the variant libraries named in SMALL_VARIANTS
+      (echo "== production"; timeout 300 python bench_tools/small_batch_mul_bench.py 2>&1 | grep batch
+       for v in ${SMALL_VARIANTS:-}; do
+         lib=swift-homomorphic-encryption_amd/lib/variants/libhe_amd_$v.so
+         [ -e "$lib" ] && { echo "== $v"; HEAMD_LIBRARY=$PWD/$lib timeout 300 python bench_tools/small_batch_mul_bench.py 2>&1 | grep batch; }
+       done) > $O/small_batch_mul.txt; cat $O/small_batch_mul.txt ;;
     *) echo "unknown leg $leg" ;;
   esac
 done

@@ -216,7 +216,7 @@ constexpr bool kSignedInverse = !(LOGN == 13 && (SOURCE == kInverseFromSlab || S
 // kernel (profiles/r03z_pmc_traffic_per_kernel.txt), which suggested pairing the two COLUMNS of one polynomial instead
 // (every spread word fetched once).  Measured both ways and dropped: with per-word sums (8-byte loads at a 16-byte lane
 // stride, twice the load instructions) relinearize 727 -> 671 k/s (profiles/r04j_keymac_loads_and_column_words_ab.txt,
-// bench_tools/variants/keymac_column_words.py); with the two columns summed one after the other through the same 16-byte
+// the variant lived under bench_tools/variants/ until round 4, commit 006a646); with the two columns summed one after the other through the same 16-byte
 // loads 723 -> 708 k/s
 // (profiles/r04c_keymac_columns_in_turn_ab.txt).  The slab's re-reads come out of L2 / the memory-side cache; they are not
 // what binds the kernel.
@@ -1170,28 +1170,35 @@ template <int LOGN, int LOGT, int SPREAD>
 hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                                 uint32_t mod_period, size_t rows, const SpreadSource& spread, hipStream_t stream,
                                 uint32_t row_period = 0, uint32_t row_offset = 0) {
-    if constexpr (LOGN == 14 && LOGT == 10 && SPREAD != kSourceSlab && kInterleavedFusedLoads) {
-        // as two interleaved sub-rows (the automorphism of a Galois key switch permutes whole rows: tiled kernel below)
-        if (spread.galois_inverse == 0)
-            return launch_interleaved_forward<1, SPREAD>(mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
-                                                         rows, spread, stream);
-    }
-    size_t paired_records = 0;  // records covered by the launch of row groups
-    constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
-    if constexpr (GROUP > 1) {
-        paired_records = (rows / mod_period) / GROUP * GROUP;
-        if (paired_records != 0) {
-            hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, GROUP>(
-                mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
-                paired_records / GROUP * mod_period, spread, stream);
-            if (e != hipSuccess) return e;
+    constexpr bool INTERLEAVED = LOGN == 14 && LOGT == 10 && SPREAD != kSourceSlab && kInterleavedFusedLoads;
+    if constexpr (INTERLEAVED && SPREAD != kSourceSpread) {
+        // as two interleaved sub-rows (the tile kernel of this source is not instantiated)
+        return launch_interleaved_forward<1, SPREAD>(mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset), rows,
+                                                     spread, stream);
+    } else {
+        if constexpr (INTERLEAVED) {
+            // (the automorphism of a Galois key switch permutes whole rows through the tile: the tiled kernel below)
+            if (spread.galois_inverse == 0)
+                return launch_interleaved_forward<1, SPREAD>(mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                                                             rows, spread, stream);
         }
+        size_t paired_records = 0;  // records covered by the launch of row groups
+        constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
+        if constexpr (GROUP > 1) {
+            paired_records = (rows / mod_period) / GROUP * GROUP;
+            if (paired_records != 0) {
+                hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, GROUP>(
+                    mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
+                    paired_records / GROUP * mod_period, spread, stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+        const size_t rest = rows - paired_records * mod_period;
+        if (rest == 0) return hipSuccess;
+        return launch_forward_kernel<LOGN, LOGT, SPREAD, 1>(
+            mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(paired_records)),
+            rest, spread, stream);
     }
-    const size_t rest = rows - paired_records * mod_period;
-    if (rest == 0) return hipSuccess;
-    return launch_forward_kernel<LOGN, LOGT, SPREAD, 1>(
-        mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(paired_records)),
-        rest, spread, stream);
 }
 
 template <int LOGN, int LOGT, int SOURCE, int ROWS>
@@ -1217,6 +1224,32 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     return hipGetLastError();
 }
 
+// One fused inverse source over records (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the
+// odd items at the end go one per workgroup.  record_base counts items for these kernels.
+template <int LOGN, int LOGT, int SOURCE>
+hipError_t launch_fused_inverse(int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
+                                size_t rows, uint32_t row_period, uint32_t row_offset, const InverseSource& source_spec,
+                                hipStream_t stream) {
+    constexpr bool TENSOR = SOURCE == kInverseFromTensor;
+    constexpr size_t REPLICAS = TENSOR ? 3 : 2;
+    constexpr int GROUP = TENSOR ? kTensorRows<LOGN, LOGT> : kKeyMacRows<LOGN, LOGT>;
+    const size_t items = rows / mod_period / REPLICAS;
+    const size_t grouped = GROUP > 1 ? items / GROUP * GROUP : 0;
+    auto map_from = [&](size_t first_item) {
+        return make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(first_item));
+    };
+    if constexpr (GROUP > 1) {
+        if (grouped != 0) {
+            hipError_t e = launch_inverse_kernel<LOGN, LOGT, SOURCE, GROUP>(mode, slab, ctx, map_from(0),
+                                                                            grouped / GROUP * REPLICAS * mod_period, source_spec, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (items == grouped) return hipSuccess;
+    return launch_inverse_kernel<LOGN, LOGT, SOURCE, 1>(mode, slab, ctx, map_from(grouped), (items - grouped) * REPLICAS * mod_period,
+                                                        source_spec, stream);
+}
+
 template <int LOGN, int LOGT>
 hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
                         uint32_t mod_period, size_t rows, hipStream_t stream, uint32_t row_period = 0,
@@ -1235,12 +1268,21 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     constexpr int LOGE = LOGN - LOGT;
     if (source != kInverseFromSlab && (row_period == 0 || Schedule<LOGN, LOGE>::P == 1)) return hipErrorInvalidValue;
     const RowMap map = make_row_map(mod_base, mod_period, row_period, row_offset);
-    if (ctx.scaled_inverse_degree != 0) {
-        if (is_key_mac(source)) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
-        if (source == kInverseFromSlab)
-            return launch_inverse_kernel<LOGN, LOGT, kInverseFromSlabScaled, 1>(mode, slab, ctx, map, rows, source_spec, stream);
-    } else if (source == kInverseFromTensor) {
-        return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
+    // The fused loads and the scaled contexts of dropExtendedBase exist for the PRODUCTION shape of each degree only (8 words
+    // per lane; N = 16384: 16): the 16- and 32-words-per-lane shapes are test variants of the plain transform
+    // (kNttVariantWide / kNttVariantTiled, public contexts only) -- instantiating every source for them was a hundred kernels
+    // nobody could launch, the exact-mode ones among them with their register tile in scratch.
+    constexpr bool FUSED_SHAPE = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10) || (LOGN == 14 && LOGT == 10);
+    if constexpr (!FUSED_SHAPE) {
+        if (source != kInverseFromSlab || ctx.scaled_inverse_degree != 0) return hipErrorInvalidValue;
+    } else {
+        if (ctx.scaled_inverse_degree != 0) {
+            if (is_key_mac(source)) return hipErrorInvalidValue;  // the key-switching contexts are never scaled
+            if (source == kInverseFromSlab)
+                return launch_inverse_kernel<LOGN, LOGT, kInverseFromSlabScaled, 1>(mode, slab, ctx, map, rows, source_spec, stream);
+        } else if (source == kInverseFromTensor) {
+            return hipErrorInvalidValue;  // the fused tensor load belongs to dropExtendedBase (t N^-1)
+        }
     }
     constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
     if constexpr (LOGN == 14 && LOGT == 10 && kInterleavedFusedLoads) {
@@ -1251,35 +1293,23 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
         if (source == kInverseFromKeyMac)
             return launch_interleaved_inverse<1, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
     }
-    if (source == kInverseFromTensor || is_key_mac(source)) {
-        // records are (item, c): groups of consecutive ITEMS share a workgroup (same c, same band row); the odd items at
-        // the end go one per workgroup.  record_base counts items for these kernels.
-        const bool tensor = source == kInverseFromTensor, finish = source == kInverseFromKeyMacFinish;
-        const size_t replicas = tensor ? 3 : 2;
-        const size_t items = rows / mod_period / replicas;
-        const size_t group = tensor ? kTensorRows<LOGN, LOGT> : kKeyMacRows<LOGN, LOGT>;
-        const size_t grouped = group > 1 ? items / group * group : 0;
-        auto map_from = [&](size_t first_item) {
-            return make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(first_item));
-        };
-        if (grouped != 0) {
-            const size_t workgroups = grouped / group * replicas * mod_period;
-            hipError_t e = tensor ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, kTensorRows<LOGN, LOGT>>(
-                                        mode, slab, ctx, map_from(0), workgroups, source_spec, stream)
-                           : finish ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, kKeyMacRows<LOGN, LOGT>>(
-                                          mode, slab, ctx, map_from(0), workgroups, source_spec, stream)
-                                    : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, kKeyMacRows<LOGN, LOGT>>(
-                                          mode, slab, ctx, map_from(0), workgroups, source_spec, stream);
-            if (e != hipSuccess) return e;
+    if constexpr (FUSED_SHAPE) {
+        // (N = 16384 with the interleaved fused loads: only the key switch's fused end is left to the tile -- the others are
+        // not instantiated for it)
+        constexpr bool ONLY_FINISH = LOGN == 14 && kInterleavedFusedLoads;
+        if (source == kInverseFromKeyMacFinish)
+            return launch_fused_inverse<LOGN, LOGT, kInverseFromKeyMacFinish>(mode, slab, ctx, mod_base, mod_period, rows, row_period,
+                                                                              row_offset, source_spec, stream);
+        if constexpr (!ONLY_FINISH) {
+            if (source == kInverseFromTensor)
+                return launch_fused_inverse<LOGN, LOGT, kInverseFromTensor>(mode, slab, ctx, mod_base, mod_period, rows, row_period,
+                                                                            row_offset, source_spec, stream);
+            if (source == kInverseFromKeyMac)
+                return launch_fused_inverse<LOGN, LOGT, kInverseFromKeyMac>(mode, slab, ctx, mod_base, mod_period, rows, row_period,
+                                                                            row_offset, source_spec, stream);
+        } else if (source != kInverseFromSlab) {
+            return hipErrorInvalidValue;
         }
-        if (items == grouped) return hipSuccess;
-        const size_t workgroups = (items - grouped) * replicas * mod_period;
-        return tensor   ? launch_inverse_kernel<LOGN, LOGT, kInverseFromTensor, 1>(mode, slab, ctx, map_from(grouped),
-                                                                                  workgroups, source_spec, stream)
-               : finish ? launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMacFinish, 1>(mode, slab, ctx, map_from(grouped),
-                                                                                        workgroups, source_spec, stream)
-                        : launch_inverse_kernel<LOGN, LOGT, kInverseFromKeyMac, 1>(mode, slab, ctx, map_from(grouped),
-                                                                                  workgroups, source_spec, stream);
     }
     size_t paired_records = 0;
     if constexpr (GROUP > 1) {
