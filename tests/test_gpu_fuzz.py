@@ -84,6 +84,36 @@ def test_random_parameter_shapes(oracle, seed):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
+def test_random_row_fused_products(oracle, seed):
+    """ct x ct through behz_kernels.hip (batches from half a workgroup generation of [Q, Bsk] rows up, N = 4096 / 8192) on random
+    moduli mixes -- which rows form a run of one butterfly class (limb-wise | fold - | fold + | [0, 8p) | exact for the whole
+    record), where the Q rows end inside or at the edge of a run -- random levels and ragged batches; every word of every
+    product against the multi-threaded oracle, extremes of every residue included."""
+    from conftest import host_threads
+
+    rnd = random.Random(7000 + seed)
+    for trial in range(3):
+        degree = rnd.choice([4096, 8192])
+        top = rnd.randint(1, 4)
+        bits = [rnd.choice(SIZES + [29, 33]) for _ in range(top + 1)]
+        q = oracle.generate_primes(bits, False, degree)
+        t = oracle.generate_primes([rnd.choice([13, 17, 20])], True, degree)[0]
+        ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+        L = rnd.randint(1, top)
+        rows = 2 * L + 1
+        batch = 256 // rows + 1 + rnd.randint(0, 9)  # just past the threshold of the fused kernel
+        moduli = ref.ciphertext_context(L).moduli
+        rng = np.random.default_rng(seed * 1000 + trial)
+        lhs, rhs = _uniform(rng, (batch, 2), moduli, degree), _uniform(rng, (batch, 2), moduli, degree)
+        for i, m in enumerate(moduli):
+            lhs[-1, :, i, :] = m - 1
+            rhs[-1, :, i, :] = m - 1
+            lhs[0, 0, i, ::2] = 0
+        got = heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), L))
+        assert np.array_equal(got, ref.mul(lhs, rhs, L, threads=host_threads())), (degree, bits, L, batch)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_expansions(oracle, seed):
     """PirUtil.expand over random output counts and random subsets of Galois keys (levels with their own key take the
     fused path, the others reach their element by repeated application; leaves at every depth, doubled or not), one and
