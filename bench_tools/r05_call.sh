@@ -12,10 +12,10 @@ mkdir -p $O
 export TMPDIR=/tmp
 if [ "${PYTEST:-all}" != "none" ]; then
   sel=(); [ "${PYTEST:-all}" != "all" ] && sel=(-k "$PYTEST")
-  timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s -x "${sel[@]}" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+  timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s ${PYTEST_FLAGS:--x} "${sel[@]}" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
   grep -E "compared with the oracle|passed|failed|rc=" $O/pytest.log | tail -12
 fi
-for leg in ${LEGS:-c3ab c3table}; do
+for leg in ${LEGS-c3ab c3table}; do
   case $leg in
     c3ab) timeout 900 python bench_tools/ab_variants.py run --what c3 --rounds ${ROUNDS:-3} ${C3_VARIANTS:-} > $O/ab_c3.txt 2>&1; cat $O/ab_c3.txt ;;
     nttab) timeout 900 python bench_tools/ab_variants.py run --what ${NTT_WHAT:-ntt} --rounds ${ROUNDS:-3} ${NTT_VARIANTS:-} > $O/ab_ntt.txt 2>&1; cat $O/ab_ntt.txt ;;

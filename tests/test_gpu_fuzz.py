@@ -95,9 +95,11 @@ def test_random_row_fused_products(oracle, seed):
     for trial in range(3):
         degree = rnd.choice([4096, 8192])
         top = rnd.randint(1, 4)
-        bits = [rnd.choice(SIZES + [29, 33]) for _ in range(top + 1)]
+        bits = [rnd.choice(SIZES) for _ in range(top + 1)]
+        if rnd.random() < 0.3:
+            bits[rnd.randrange(top)] = rnd.choice([29, 33])  # one small modulus (there are few such primes: at most one)
         q = oracle.generate_primes(bits, False, degree)
-        t = oracle.generate_primes([rnd.choice([13, 17, 20])], True, degree)[0]
+        t = oracle.generate_primes([rnd.choice([17, 20])], True, degree)[0]
         ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
         L = rnd.randint(1, top)
         rows = 2 * L + 1
