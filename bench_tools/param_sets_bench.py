@@ -37,7 +37,7 @@ if __name__ == "__main__":
     out = []
     # (N = 16384, L = 6: EncryptionParameters.swift:200-206 allows the degree; 256 pairs = 3.6 GB of workspace)
     for degree, bits, batch in [(8192, [29, 60, 60], 1024), (8192, [40, 60, 60], 1024), (4096, [60, 60, 60], 1024),
-                                (8192, [55, 55, 55, 55, 55], 1024), (16384, [55] * 7, 256)]:
+                                (8192, [55, 55, 55, 55, 55], 1024), (16384, [55] * 7, 256), (32768, [55] * 7, 128)]:
         mul, relin = run(degree, bits, batch)
         out.append("N=%d %s ct x ct %.1f k/s  relinearize %.1f k/s" % (degree, bits, mul / 1e3, relin / 1e3))
     print(" | ".join(out))

@@ -1081,6 +1081,14 @@ constexpr int kKeyMacRows = kRowsPerWorkgroup<LOGN, LOGT> > 1 ? kKeyMacRowGroup 
 // -- two workgroups per CU at 64 registers instead of the 16-words-per-lane tile at one (kInterleavedFusedLoads).
 constexpr bool kInterleaved16384 = true;
 constexpr bool kInterleavedFusedLoads = true;
+// The largest degree whose pipelines take the fused loads (2^15: as four interleaved sub-rows, round 5; 14: N = 32768 runs its
+// pipelines unfused over the plain interleaved transforms, rounds 3-4)
+constexpr uint32_t kMaxFusedLoadLogDegree = 15;
+// ... of which, at N = 32768, the key switch's two are decided on their own measurements (128 pairs, L = 6,
+// profiles/r05p_fused_loads_32768_ab.txt): the decomposition into the forward transform gains (relinearize 50.5 -> 62.4 k/s),
+// the key inner product into the inverse one -- a rolled loop over the terms in a 128-register workgroup that is alone on its
+// CU -- loses (40.5 k/s with both, 34.9 k/s with it alone) and stays a kernel of its own in front of the plain transforms
+constexpr bool kFusedSpreadAt32768 = true, kFusedKeyMacAt32768 = false;
 // (the key MAC's rows r < L stay on the 16-words-per-lane tile, whose store carries the key switch's end: interleaved sub-rows
 // plus the separate finish kernel measured 134.9 k relinearize/s at N = 16384, L = 6 against 157.8 k this way and 143.7 k with
 // every fused load on the tile -- profiles/r05f_fused_loads_16384_ab.txt; the q_ks row and the other fused loads are interleaved)
@@ -1346,6 +1354,10 @@ hipError_t launch_ntt_spread(const uint64_t* source, size_t poly_stride, uint32_
             case 12: return launch_forward_tiled<12, 9, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
             case 13: return launch_forward_tiled<13, 10, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
             case 14: return launch_forward_tiled<14, 10, kSourceSpread>(mode, spread, ks_ctx, base, band, band_total, src, stream, row_period, base);
+            case 15:  // four interleaved sub-rows (the automorphism of a Galois key switch: the caller's unfused path)
+                if (galois_inverse != 0 || kMaxFusedLoadLogDegree < 15 || !kFusedSpreadAt32768) return hipErrorNotSupported;
+                return launch_interleaved_forward<2, kSourceSpread>(mode, spread, ks_ctx, make_row_map(base, band, row_period, base),
+                                                                    band_total, src, stream);
             default: return hipErrorNotSupported;  // caller falls back to spread kernel + launch_ntt
         }
     };
@@ -1369,6 +1381,9 @@ hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulu
         case 12: return launch_forward_tiled<12, 9, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
         case 13: return launch_forward_tiled<13, 10, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
         case 14: return launch_forward_tiled<14, 10, kSourceLift>(mode, out, ctx, 0, period, rows, src, stream);
+        case 15:
+            if (kMaxFusedLoadLogDegree < 15) return hipErrorNotSupported;
+            return launch_interleaved_forward<2, kSourceLift>(mode, out, ctx, make_row_map(0, period, 0, 0), rows, src, stream);
         default: return hipErrorNotSupported;  // caller falls back to the lift kernel + launch_ntt
     }
 }
@@ -1394,9 +1409,14 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
         case 12: return launch_tiled<12, 9>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
         case 13: return launch_tiled<13, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
         case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, band_rows, rows, stream, record_rows, band_offset, source, source_spec);
-        case 15:
-            if (source != kInverseFromSlab && inverse) return hipErrorNotSupported;
-            return launch_interleaved<2>(inverse, mode, slab, ctx, make_row_map(mod_base, band_rows, record_rows, band_offset), rows, stream);
+        case 15: {
+            const RowMap map = make_row_map(mod_base, band_rows, record_rows, band_offset);
+            if (kMaxFusedLoadLogDegree < 15 && inverse && source != kInverseFromSlab) return hipErrorNotSupported;
+            if (inverse && source == kInverseFromTensor) return launch_interleaved_inverse<2, kInverseFromTensor>(mode, slab, ctx, map, rows, source_spec, stream);
+            if (inverse && source == kInverseFromKeyMac) return launch_interleaved_inverse<2, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+            if (inverse && source != kInverseFromSlab) return hipErrorNotSupported;  // the key switch's fused end: not at this degree
+            return launch_interleaved<2>(inverse, mode, slab, ctx, map, rows, stream);
+        }
         default: return hipErrorNotSupported;
     }
 }
@@ -1406,7 +1426,7 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
 // the same slab.  Falls back to one launch when the context has no such prefix or no tiled kernel.
 hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
                             hipStream_t stream) {
-    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= kMaxFusedLoadLogDegree;
     BandRun runs[kMaxBandRuns];
     const int count = tiled ? band_runs(ctx, record_rows, runs) : 0;
     if (count <= 1 || records * record_rows > (size_t(1) << 30) || records * record_rows <= kOneGeneration)
@@ -1425,7 +1445,7 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
 // prefix of exactly source_moduli rows or no tiled kernel -- the caller then lifts with the copy and runs
 // launch_ntt_mixed.
 bool ntt_lifted_forward_supported(const DeviceContext& ctx, uint32_t record_rows, uint32_t source_moduli, size_t records) {
-    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= kMaxFusedLoadLogDegree;
     return tiled && source_moduli != 0 && source_moduli < record_rows && ctx.headroom_prefix == source_moduli &&
            ctx.approx_ok != 0 && ctx.forward_split_pairs != nullptr && records * record_rows > kOneGeneration &&
            records * record_rows <= (size_t(1) << 30);
@@ -1441,7 +1461,8 @@ hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, u
     switch (ctx.log_degree) {
         case 12: e = launch_forward_tiled<12, 9, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
         case 13: e = launch_forward_tiled<13, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
-        default: e = launch_forward_tiled<14, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
+        case 14: e = launch_forward_tiled<14, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
+        default: e = launch_interleaved_forward<2, kSourceRows>(kModeSplit, slab, ctx, make_row_map(0, source_moduli, record_rows, 0), rows, src, stream); break;
     }
     if (e != hipSuccess) return e;
     return launch_ntt_band(false, slab, ctx, source_moduli, record_rows - source_moduli, record_rows, source_moduli, records,
@@ -1453,7 +1474,7 @@ hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, u
 // then runs launch_tensor + launch_ntt_mixed).
 hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, const DeviceContext& ctx, uint32_t record_rows,
                                      size_t items, hipStream_t stream) {
-    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= 14;
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= kMaxFusedLoadLogDegree;
     const size_t records = items * 3;
     if (!tiled || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
@@ -1494,7 +1515,7 @@ hipError_t launch_key_mac_runs(uint64_t* prod, const DeviceContext& ks, uint32_t
 
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
-    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= 14;
+    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= (kFusedKeyMacAt32768 ? kMaxFusedLoadLogDegree : 14u);
     const size_t records = polys * 2;
     if (!tiled || L > 64 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;

@@ -644,8 +644,8 @@ def test_inner_product_plain_narrow_moduli(oracle, bits, polys):
 def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     """The transforms with a fused load stage (key-switching decomposition, plaintext lift, tensor product, key inner
     product) exist per tiled degree: N = 4096 and 16384 instantiations, headroom and mixed [Q, Bsk] bands, and moduli
-    that force the exact butterflies; N = 32768 runs the same pipelines unfused over the interleaved transforms (row
-    bands of the [Q, Bsk] records, t N^-1 contexts); the reference's 60-bit parameter sets (n_8192_logq_29_60_60 and its
+    that force the exact butterflies; N = 32768 runs them as four interleaved sub-rows with the fused loads that pay there
+    (Q band, tensor product, plaintext lift, key-switching decomposition -- round 5) and the key inner product unfused; the reference's 60-bit parameter sets (n_8192_logq_29_60_60 and its
     siblings, EncryptionParameters.swift:257-263) split their [Q, Bsk] records into runs of one butterfly class each -- the
     small modulus, the 60-bit ones on the fold butterflies, the auxiliary primes on the other fold form.  Word for word
     against the oracle."""
