@@ -1089,6 +1089,11 @@ constexpr uint32_t kMaxFusedLoadLogDegree = 15;
 // the key inner product into the inverse one -- a rolled loop over the terms in a 128-register workgroup that is alone on its
 // CU -- loses (40.5 k/s with both, 34.9 k/s with it alone) and stays a kernel of its own in front of the plain transforms
 constexpr bool kFusedSpreadAt32768 = true, kFusedKeyMacAt32768 = false;
+// N = 16384: the key inner product as a kernel of its own in front of the plain interleaved inverse transforms, then the finish
+// kernel: 163.3 k relinearize/s at L = 6 against 157.4 k with the q_ks row's MAC fused into the interleaved inverse and the other
+// rows on the 16-words-per-lane tile with the fused end (profiles/r05s_keymac_16384_ab.txt) -- a fused load pays where its kernel
+// has a second workgroup on the CU to run under it (N = 4096 / 8192), not where the workgroup is alone
+constexpr bool kFusedKeyMacAt16384 = false;
 // (the key MAC's rows r < L stay on the 16-words-per-lane tile, whose store carries the key switch's end: interleaved sub-rows
 // plus the separate finish kernel measured 134.9 k relinearize/s at N = 16384, L = 6 against 157.8 k this way and 143.7 k with
 // every fused load on the tile -- profiles/r05f_fused_loads_16384_ab.txt; the q_ks row and the other fused loads are interleaved)
@@ -1298,16 +1303,20 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
         // fused end (kInverseFromKeyMacFinish) is not offered at this degree (ntt_key_mac_finish_supported)
         if (source == kInverseFromTensor)
             return launch_interleaved_inverse<1, kInverseFromTensor>(mode, slab, ctx, map, rows, source_spec, stream);
-        if (source == kInverseFromKeyMac)
-            return launch_interleaved_inverse<1, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+        if constexpr (kFusedKeyMacAt16384) {
+            if (source == kInverseFromKeyMac)
+                return launch_interleaved_inverse<1, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+        }
     }
     if constexpr (FUSED_SHAPE) {
         // (N = 16384 with the interleaved fused loads: only the key switch's fused end is left to the tile -- the others are
         // not instantiated for it)
         constexpr bool ONLY_FINISH = LOGN == 14 && kInterleavedFusedLoads;
-        if (source == kInverseFromKeyMacFinish)
-            return launch_fused_inverse<LOGN, LOGT, kInverseFromKeyMacFinish>(mode, slab, ctx, mod_base, mod_period, rows, row_period,
-                                                                              row_offset, source_spec, stream);
+        if constexpr (LOGN != 14 || kFusedKeyMacAt16384) {
+            if (source == kInverseFromKeyMacFinish)
+                return launch_fused_inverse<LOGN, LOGT, kInverseFromKeyMacFinish>(mode, slab, ctx, mod_base, mod_period, rows,
+                                                                                  row_period, row_offset, source_spec, stream);
+        }
         if constexpr (!ONLY_FINISH) {
             if (source == kInverseFromTensor)
                 return launch_fused_inverse<LOGN, LOGT, kInverseFromTensor>(mode, slab, ctx, mod_base, mod_period, rows, row_period,
@@ -1413,7 +1422,9 @@ hipError_t launch_ntt_band(bool inverse, uint64_t* slab, const DeviceContext& ct
             const RowMap map = make_row_map(mod_base, band_rows, record_rows, band_offset);
             if (kMaxFusedLoadLogDegree < 15 && inverse && source != kInverseFromSlab) return hipErrorNotSupported;
             if (inverse && source == kInverseFromTensor) return launch_interleaved_inverse<2, kInverseFromTensor>(mode, slab, ctx, map, rows, source_spec, stream);
-            if (inverse && source == kInverseFromKeyMac) return launch_interleaved_inverse<2, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+            if constexpr (kFusedKeyMacAt32768) {  // (not instantiated otherwise)
+                if (inverse && source == kInverseFromKeyMac) return launch_interleaved_inverse<2, kInverseFromKeyMac>(mode, slab, ctx, map, rows, source_spec, stream);
+            }
             if (inverse && source != kInverseFromSlab) return hipErrorNotSupported;  // the key switch's fused end: not at this degree
             return launch_interleaved<2>(inverse, mode, slab, ctx, map, rows, stream);
         }
@@ -1515,7 +1526,8 @@ hipError_t launch_key_mac_runs(uint64_t* prod, const DeviceContext& ks, uint32_t
 
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream) {
-    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= (kFusedKeyMacAt32768 ? kMaxFusedLoadLogDegree : 14u);
+    const bool tiled = ks.log_degree >= 12 && ks.log_degree <= (kFusedKeyMacAt32768 ? kMaxFusedLoadLogDegree : 14u) &&
+                       (kFusedKeyMacAt16384 || ks.log_degree != 14);
     const size_t records = polys * 2;
     if (!tiled || L > 64 || records * (L + 1) > (size_t(1) << 30)) return hipErrorNotSupported;
     if (records == 0) return hipSuccess;
@@ -1536,7 +1548,7 @@ bool ntt_key_mac_finish_supported(const DeviceContext& ks, uint32_t L, size_t po
     // profiles/r04m_galois_fused_end_ab.txt)
     // (N = 16384: the key MAC runs as interleaved sub-rows, two workgroups per CU, and ends in the separate finish kernel --
     // kInterleavedKeyMacAt16384, measured against the 16-words-per-lane tile with the fused end)
-    if (ks.log_degree == 14 && kInterleavedFusedLoads && kInterleavedKeyMacAt16384) return false;
+    if (ks.log_degree == 14 && ((kInterleavedFusedLoads && kInterleavedKeyMacAt16384) || !kFusedKeyMacAt16384)) return false;
     return tiled && L >= 1 && L < 64 && ks.moduli_count == L + 1 && polys * 2 * (L + 1) > 2 * kOneGeneration &&
            polys * 2 * (L + 1) <= (size_t(1) << 30);
 }
