@@ -189,7 +189,7 @@ bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, 
 
 hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size_t ct_stride, const uint64_t* lifted,
                                   uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,
-                                  size_t items, hipStream_t stream) {
+                                  size_t items, hipStream_t stream, int part) {
     if (items == 0) return hipSuccess;
     if (!behz_rows_fused_supported(scaled_qbsk, record_rows, source_moduli, items) || scaled_qbsk.scaled_inverse_degree == 0)
         return hipErrorNotSupported;
@@ -202,9 +202,14 @@ hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size
     };
     ntt::BandRun runs[ntt::kMaxBandRuns];
     const int count = ntt::band_runs(scaled_qbsk, record_rows, runs);
-    if (count <= 1) return launch(ntt::production_mode(scaled_qbsk), 0, record_rows);
-    for (int k = 0; k < count; ++k)
+    // `part`: kBehzAllRows, or the runs that read nothing of the lift's (every row below source_moduli: kBehzCiphertextRows) /
+    // the others (kBehzLiftedRows) -- the first kind does not wait for the lift
+    if (count <= 1) return part == kBehzCiphertextRows ? hipSuccess : launch(ntt::production_mode(scaled_qbsk), 0, record_rows);
+    for (int k = 0; k < count; ++k) {
+        const bool from_ciphertexts = runs[k].base + runs[k].rows <= source_moduli;
+        if ((part == kBehzCiphertextRows && !from_ciphertexts) || (part == kBehzLiftedRows && from_ciphertexts)) continue;
         if (hipError_t e = launch(runs[k].mode, runs[k].base, runs[k].rows); e != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 

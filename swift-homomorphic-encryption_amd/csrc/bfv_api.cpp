@@ -2,6 +2,7 @@
 // (reference Sources/HomomorphicEncryption/Bfv/*.swift).  Each operation is a short pipeline of HIP kernels on the
 // caller's stream; nothing here touches the data on the host.
 #include <memory>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -18,11 +19,45 @@ using heamd::PolyContext;
 using heamd::RnsToolLevel;
 using heamd::Scratch;
 
+// A second stream of the context's own, forked off the caller's stream and joined back inside ONE call (events on both
+// sides): work of a pipeline that does not depend on its neighbour runs beside it.  Created on first use, never synchronised;
+// calls that use it enqueue under its mutex, so that an event is always waited for by the call that recorded it.
+struct SideLane {
+    std::mutex mutex;
+    hipStream_t stream = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr;
+    ~SideLane() {
+        if (forked != nullptr) (void)hipEventDestroy(forked);
+        if (joined != nullptr) (void)hipEventDestroy(joined);
+        if (stream != nullptr) (void)hipStreamDestroy(stream);
+    }
+    // (under the mutex)
+    hipError_t ensure() {
+        if (stream != nullptr) return hipSuccess;
+        hipStream_t s = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (a != nullptr) (void)hipEventDestroy(a);
+            if (b != nullptr) (void)hipEventDestroy(b);
+            if (s != nullptr) (void)hipStreamDestroy(s);
+            return e;
+        }
+        stream = s;
+        forked = a;
+        joined = b;
+        return hipSuccess;
+    }
+};
+
 struct he_bfv_context {
     std::unique_ptr<BfvContext> impl;
     // non-owning he_poly_context views handed out by he_bfv_*_context(), index = ciphertext moduli count
     std::vector<std::unique_ptr<he_poly_context>> ciphertext, key_switching, qbsk;
     mutable heamd::ExpandPlanCache expand_plans;  // PirUtil.expand shapes seen so far (api_internal.hpp)
+    mutable SideLane side;                         // mul_rows_fused: the Q band of ct x ct beside the lift
 };
 
 namespace heamd {
@@ -192,8 +227,9 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
 // (item, [Q, Bsk] row) from its four Coeff rows to its three scaled Coeff product rows -- the Eval rows never reach HBM.
 // *fused = false (nothing launched): the degree or the batch has no such kernel; the caller runs the unfused pipeline.
 constexpr bool kBehzRowsFused = true;
-int mul_rows_fused(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs, const uint64_t* rhs,
-                   uint64_t* lifted, uint64_t* tensor, size_t batch, hipStream_t stream, bool* fused) {
+constexpr bool kBehzCiphertextRowsBesideLift = true;
+int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs,
+                   const uint64_t* rhs, uint64_t* lifted, uint64_t* tensor, size_t batch, hipStream_t stream, bool* fused) {
     *fused = false;
     if (!kBehzRowsFused) return HE_OK;
     DeviceContext scaled = tool.qbsk->device_context();
@@ -201,10 +237,40 @@ int mul_rows_fused(const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, c
     scaled.scaled_inverse_degree = 1;
     const uint32_t rows = 2 * L + 1;
     if (!heamd::behz_rows_fused_supported(scaled, rows, L, batch)) return HE_OK;
+    *fused = true;
+    // The row bands that read the ciphertexts themselves (the Q rows) do not depend on the lift: on the context's side lane they
+    // run beside it -- a 128-register row-fused workgroup leaves room on its CU for the lift's 256-lane workgroups of 40
+    // registers (ct x ct +2.6 %, profiles/r05v_behz_q_band_beside_lift_ab.txt).  From four workgroup generations of Q rows up;
+    // not while the caller's stream is being captured into a graph (the lane is shared by the context's callers).
+    if (kBehzCiphertextRowsBesideLift && batch * L >= 1024) {
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+            (void)hipGetLastError();
+            capture = hipStreamCaptureStatusActive;  // (the legacy default stream cannot be queried: stay on it)
+        }
+        if (capture == hipStreamCaptureStatusNone) {
+            SideLane& lane = ctx->side;
+            std::lock_guard<std::mutex> lock(lane.mutex);
+            HEAMD_HIP_TRY(lane.ensure());
+            HEAMD_HIP_TRY(hipEventRecord(lane.forked, stream));
+            HEAMD_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.forked, 0));
+            hipError_t e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, lane.stream,
+                                                         heamd::kBehzCiphertextRows);
+            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false);
+            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false);
+            if (e == hipSuccess) e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream,
+                                                                   heamd::kBehzLiftedRows);
+            // the join is enqueued whatever happened in between: the caller's stream never runs ahead of the lane's work
+            const hipError_t recorded = hipEventRecord(lane.joined, lane.stream);
+            const hipError_t waited = recorded == hipSuccess ? hipStreamWaitEvent(stream, lane.joined, 0) : recorded;
+            HEAMD_HIP_TRY(e);
+            HEAMD_HIP_TRY(waited);
+            return HE_OK;
+        }
+    }
     HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false));
     HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false));
     HEAMD_HIP_TRY(heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream));
-    *fused = true;
     return HE_OK;
 }
 
@@ -222,7 +288,7 @@ int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L
     W* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
     if constexpr (std::is_same<W, uint64_t>::value) {
         bool fused = false;
-        status = mul_rows_fused(*tool, L, n, ext, lhs, rhs, lifted, tensor, batch, stream, &fused);
+        status = mul_rows_fused(ctx, *tool, L, n, ext, lhs, rhs, lifted, tensor, batch, stream, &fused);
         if (status != HE_OK) return status;
         if (fused) {
             HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));

@@ -56,9 +56,10 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
 // Coeff, what launch_floor_qbsk_to_q takes.  hipErrorNotSupported (nothing launched, behz_rows_fused_supported false):
 // launch_ntt_lifted_forward + launch_ntt_tensor_inverse.
 bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items);
+constexpr int kBehzAllRows = 0, kBehzCiphertextRows = 1, kBehzLiftedRows = 2;
 hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size_t ct_stride, const uint64_t* lifted,
                                   uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,
-                                  size_t items, hipStream_t stream);
+                                  size_t items, hipStream_t stream, int part = kBehzAllRows);
 hipError_t launch_ntt_key_mac_inverse(const uint64_t* spread, const uint64_t* key, uint64_t* out, const DeviceContext& ks,
                                       uint32_t L, uint32_t top_rows, size_t polys, hipStream_t stream);
 // launch_ntt_key_mac_inverse with the key switch's last step (drop the special modulus, add the update to the first

@@ -51,6 +51,67 @@ def test_threads_share_one_context(oracle):
         assert np.array_equal(got, want)
 
 
+def test_row_fused_mul_shares_the_side_lane_and_is_capturable(oracle):
+    """ct x ct on batches that take the row-fused kernels with the Q band on the context's side lane (a second stream forked off
+    the caller's and joined back inside the call, bfv_api.cpp SideLane): four host threads on their own streams share one
+    context -- and one lane -- and every product equals the oracle's; the same call captured into a HIP graph (where the lane
+    is not used) replays on new operands."""
+    import torch
+    from conftest import host_threads
+
+    degree, batch = 4096, 512
+    q = oracle.generate_primes([55, 55, 55], False, degree)
+    t = oracle.generate_primes([17], True, degree)[0]
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    assert batch * ours.L >= 1024
+    rng = np.random.default_rng(92)
+
+    def uniform(prefix):
+        rows = [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in moduli]
+        return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
+
+    operands = [(uniform((batch, 2)), uniform((batch, 2))) for _ in range(4)]
+    expected = [ref.mul(a, b, threads=host_threads()) for a, b in operands]
+    results, errors = [None] * 4, []
+
+    def worker(index):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                lhs, rhs = heamd.to_device(operands[index][0]), heamd.to_device(operands[index][1])
+                out = None
+                for _ in range(3):
+                    out = ours.mul(lhs, rhs, stream=stream)
+                stream.synchronize()
+                results[index] = heamd.to_host(out)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for got, want in zip(results, expected):
+        assert np.array_equal(got, want)
+    # captured: one stream, replayed on new operands
+    lhs_static, rhs_static = heamd.to_device(operands[0][0]), heamd.to_device(operands[0][1])
+    workspace = torch.empty(ours.mul_workspace_bytes(batch) // 8, dtype=torch.int64, device="cuda")
+    ours.mul(lhs_static, rhs_static, workspace=workspace)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_static = ours.mul(lhs_static, rhs_static, workspace=workspace)
+    for trial in (1, 2):
+        lhs_static.copy_(heamd.to_device(operands[trial][0]))
+        rhs_static.copy_(heamd.to_device(operands[trial][1]))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(heamd.to_host(out_static), expected[trial]), trial
+
+
 def test_mul_relinearize_pipeline_in_a_hip_graph(oracle):
     """ct x ct + relinearize is ten kernel launches; with caller-provided workspaces nothing in it allocates or
     synchronises, so it can be captured once and replayed (hipGraph) on new inputs."""
