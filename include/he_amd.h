@@ -243,7 +243,9 @@ size_t he_bfv_mul_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_cou
 size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
 
 /* Bfv.mulAssign(_: inout CanonicalCiphertext, _: CanonicalCiphertext) = multiplyWithoutScaling + dropExtendedBase
- * (Bfv/Bfv+Multiply.swift:18-85).  lhs, rhs: [batch][2][L][N] Coeff; out: [batch][3][L][N] Coeff. */
+ * (Bfv/Bfv+Multiply.swift:18-85).  lhs, rhs: [batch][2][L][N] Coeff; out: [batch][3][L][N] Coeff.  Enqueue-only on `s` as seen
+ * from the caller: large batches also run part of the pipeline on a second stream the context owns, forked off `s` and joined
+ * back into `s` by events before the call returns (not while `s` is being captured into a graph). */
 int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
                       uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s);
 /* Bfv.relinearize (Bfv/Bfv.swift:201-219) via _computeKeySwitchingUpdate (Bfv/Bfv+Keys.swift:123-208).
