@@ -24,30 +24,35 @@ using heamd::Scratch;
 // calls that use it enqueue under its mutex, so that an event is always waited for by the call that recorded it.
 struct SideLane {
     std::mutex mutex;
+    static constexpr int kStages = 4;
     hipStream_t stream = nullptr;
     hipEvent_t forked = nullptr, joined = nullptr;
+    hipEvent_t stage[kStages] = {};  // the caller's stream has reached a point the lane's next piece of work depends on
     ~SideLane() {
         if (forked != nullptr) (void)hipEventDestroy(forked);
         if (joined != nullptr) (void)hipEventDestroy(joined);
+        for (hipEvent_t e : stage)
+            if (e != nullptr) (void)hipEventDestroy(e);
         if (stream != nullptr) (void)hipStreamDestroy(stream);
     }
     // (under the mutex)
     hipError_t ensure() {
         if (stream != nullptr) return hipSuccess;
         hipStream_t s = nullptr;
-        hipEvent_t a = nullptr, b = nullptr;
+        hipEvent_t made[2 + kStages] = {};
         hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        for (hipEvent_t& event : made)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&event, hipEventDisableTiming);
         if (e != hipSuccess) {
-            if (a != nullptr) (void)hipEventDestroy(a);
-            if (b != nullptr) (void)hipEventDestroy(b);
+            for (hipEvent_t event : made)
+                if (event != nullptr) (void)hipEventDestroy(event);
             if (s != nullptr) (void)hipStreamDestroy(s);
             return e;
         }
         stream = s;
-        forked = a;
-        joined = b;
+        forked = made[0];
+        joined = made[1];
+        for (int k = 0; k < kStages; ++k) stage[k] = made[2 + k];
         return hipSuccess;
     }
 };
@@ -228,8 +233,11 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
 // *fused = false (nothing launched): the degree or the batch has no such kernel; the caller runs the unfused pipeline.
 constexpr bool kBehzRowsFused = true;
 constexpr bool kBehzCiphertextRowsBesideLift = true;
+constexpr size_t kBehzFloorParts = 2;  // <= SideLane::kStages + 1
 int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs,
-                   const uint64_t* rhs, uint64_t* lifted, uint64_t* tensor, size_t batch, hipStream_t stream, bool* fused) {
+                   const uint64_t* rhs, uint64_t* lifted, uint64_t* tensor, uint64_t* out, size_t batch, hipStream_t stream,
+                   bool* fused, bool* floored) {
+    *floored = false;
     *fused = false;
     if (!kBehzRowsFused) return HE_OK;
     DeviceContext scaled = tool.qbsk->device_context();
@@ -258,13 +266,34 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
                                                          heamd::kBehzCiphertextRows);
             if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false);
             if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false);
-            if (e == hipSuccess) e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream,
-                                                                   heamd::kBehzLiftedRows);
+            // The Bsk band and the floor in kBehzFloorParts parts of the batch: a part's floor -- 256-lane workgroups of 41
+            // registers -- follows the Q band on the lane and runs beside the NEXT part's Bsk band on the caller's stream;
+            // only the last part's floor is left to run on its own.
+            const size_t parts = (kBehzFloorParts > 1 && batch >= 256 * kBehzFloorParts) ? kBehzFloorParts : 1;
+            const size_t per_part = (batch + parts - 1) / parts;
+            for (size_t k = 0, first = 0; k < parts && first < batch; ++k, first += per_part) {
+                const size_t items = batch - first < per_part ? batch - first : per_part;
+                if (e == hipSuccess)
+                    e = heamd::launch_behz_rows_fused(lhs + first * 2 * L * n, rhs + first * 2 * L * n, 2 * L * n, lifted + first * 4 * ext,
+                                                      tensor + first * 3 * ext, scaled, rows, L, items, stream, heamd::kBehzLiftedRows);
+                if (parts > 1 && k + 1 < parts) {
+                    if (e == hipSuccess) e = hipEventRecord(lane.stage[k], stream);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(lane.stream, lane.stage[k], 0);
+                    if (e == hipSuccess)
+                        e = heamd::launch_floor_qbsk_to_q(tensor + first * 3 * ext, out + first * 3 * L * n, tool.device, items * 3, lane.stream);
+                }
+            }
             // the join is enqueued whatever happened in between: the caller's stream never runs ahead of the lane's work
             const hipError_t recorded = hipEventRecord(lane.joined, lane.stream);
             const hipError_t waited = recorded == hipSuccess ? hipStreamWaitEvent(stream, lane.joined, 0) : recorded;
             HEAMD_HIP_TRY(e);
             HEAMD_HIP_TRY(waited);
+            if (parts > 1) {  // the last part's floor, behind the join (it reads the Q band's rows too)
+                const size_t first = (parts - 1) * per_part;
+                HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor + first * 3 * ext, out + first * 3 * L * n, tool.device,
+                                                            (batch - first) * 3, stream));
+                *floored = true;
+            }
             return HE_OK;
         }
     }
@@ -288,10 +317,11 @@ int mul_pipeline(const he_bfv_context* ctx, const RnsToolLevel* tool, uint32_t L
     W* tensor = ws + batch * 4 * ext; // [batch][3][2L+1][N]
     if constexpr (std::is_same<W, uint64_t>::value) {
         bool fused = false;
-        status = mul_rows_fused(ctx, *tool, L, n, ext, lhs, rhs, lifted, tensor, batch, stream, &fused);
+        bool floored = false;
+        status = mul_rows_fused(ctx, *tool, L, n, ext, lhs, rhs, lifted, tensor, out, batch, stream, &fused, &floored);
         if (status != HE_OK) return status;
         if (fused) {
-            HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
+            if (!floored) HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor, out, tool->device, batch * 3, stream));
             return HE_OK;
         }
     }
