@@ -38,18 +38,27 @@ def main():
                                 "algorithmic_bytes_per_launch": 2 * 4 * 8192 * 8 * 4096,
                                 "inverse_hbm_bytes_per_launch": inverse, "source": source}
     c3 = load(c3_dir)
-    mul_kernels = ["lift_kernel", "floor_kernel"]
+    # How many times a kernel is launched per CALL of its pipeline comes from the dispatch counts themselves: the profile
+    # target runs ct x ct and relinearize some number of times each; a pipeline's calls = the smallest dispatch count among its
+    # kernels (the kernels launched once per call), a kernel's launches per call = its dispatches over that (the lift: 2; since
+    # round 5 the Bsk band of the row-fused kernel and the floor go in two parts of the batch: 2 each).
+    mul_kernels = ("lift_kernel", "floor_kernel", "behz_rows_fused", "ntt_forward_tiled<13, 10, 3, 3", "ntt_forward_tiled<13, 10, 6, 0",
+                   "ntt_inverse_tiled<13, 10, 6, 1", "ntt_inverse_tiled<13, 10, 7, 1", "tensor_kernel")
+    rows = {k: r for k, r in c3.items() if not (k.startswith("_") or "at::" in k or "rocclr" in k)}
+    is_mul = {k: any(m in k for m in mul_kernels) for k in rows}
+    calls = {True: min((r["dispatches"] for k, r in rows.items() if is_mul[k]), default=1),
+             False: min((r["dispatches"] for k, r in rows.items() if not is_mul[k]), default=1)}
     per_batch = 0.0
-    detail = {}
-    for kernel, row in c3.items():
-        if kernel.startswith("_") or "at::" in kernel or "rocclr" in kernel:
-            continue
+    detail, launches = {}, {}
+    for kernel, row in rows.items():
         b = (row["fetch_KiB_per_dispatch"] + row["write_KiB_per_dispatch"]) * 1024.0
-        times = 2 if "lift_kernel" in kernel else 1  # two lift launches per product batch
+        times = row["dispatches"] / calls[is_mul[kernel]]
         per_batch += b * times
         detail[kernel] = b * times / 1024
+        launches[kernel] = round(times, 3)
     result["c3_ct_mul_relinearize"] = {"hbm_bytes_per_unit": per_batch / 1024, "algorithmic_bytes_per_unit": 1572864,
-                                       "per_kernel_bytes_per_unit": detail, "batch": 1024, "source": source}
+                                       "per_kernel_bytes_per_unit": detail, "launches_per_call": launches, "batch": 1024,
+                                       "source": source}
     c4 = load(c4_dir)
     b, names = bytes_per_dispatch(c4, "divide_and_round")
     result["c4_mod_switch"] = {"kernel": names, "hbm_bytes_per_unit": b / 8192,
