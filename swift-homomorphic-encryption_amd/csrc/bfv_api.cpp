@@ -234,6 +234,7 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
 constexpr bool kBehzRowsFused = true;
 constexpr bool kBehzCiphertextRowsBesideLift = true;
 constexpr size_t kBehzFloorParts = 2;  // <= SideLane::kStages + 1
+constexpr size_t kBehzFirstPartEighths = 4;  // two parts: the first one's share of the batch, in eighths
 int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t L, size_t n, size_t ext, const uint64_t* lhs,
                    const uint64_t* rhs, uint64_t* lifted, uint64_t* tensor, uint64_t* out, size_t batch, hipStream_t stream,
                    bool* fused, bool* floored) {
@@ -270,13 +271,18 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             // registers -- follows the Q band on the lane and runs beside the NEXT part's Bsk band on the caller's stream;
             // only the last part's floor is left to run on its own.
             const size_t parts = (kBehzFloorParts > 1 && batch >= 256 * kBehzFloorParts) ? kBehzFloorParts : 1;
-            const size_t per_part = (batch + parts - 1) / parts;
-            for (size_t k = 0, first = 0; k < parts && first < batch; ++k, first += per_part) {
-                const size_t items = batch - first < per_part ? batch - first : per_part;
+            // (two parts: the first one larger -- its floor has the whole of the second part's Bsk band to run beside, and the
+            // second part's floor is what is left exposed)
+            size_t bounds[SideLane::kStages + 2] = {0};
+            for (size_t k = 1; k <= parts; ++k) bounds[k] = batch * k / parts;
+            if (parts == 2) bounds[1] = batch * kBehzFirstPartEighths / 8;
+            for (size_t k = 0; k < parts; ++k) {
+                const size_t first = bounds[k], items = bounds[k + 1] - first;
+                if (items == 0) continue;
                 if (e == hipSuccess)
                     e = heamd::launch_behz_rows_fused(lhs + first * 2 * L * n, rhs + first * 2 * L * n, 2 * L * n, lifted + first * 4 * ext,
                                                       tensor + first * 3 * ext, scaled, rows, L, items, stream, heamd::kBehzLiftedRows);
-                if (parts > 1 && k + 1 < parts) {
+                if (k + 1 < parts) {
                     if (e == hipSuccess) e = hipEventRecord(lane.stage[k], stream);
                     if (e == hipSuccess) e = hipStreamWaitEvent(lane.stream, lane.stage[k], 0);
                     if (e == hipSuccess)
@@ -289,7 +295,7 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             HEAMD_HIP_TRY(e);
             HEAMD_HIP_TRY(waited);
             if (parts > 1) {  // the last part's floor, behind the join (it reads the Q band's rows too)
-                const size_t first = (parts - 1) * per_part;
+                const size_t first = bounds[parts - 1];
                 HEAMD_HIP_TRY(heamd::launch_floor_qbsk_to_q(tensor + first * 3 * ext, out + first * 3 * L * n, tool.device,
                                                             (batch - first) * 3, stream));
                 *floored = true;
