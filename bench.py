@@ -82,7 +82,7 @@ def synthetic_slab(torch, moduli, prefix, degree, seed):
 
 
 def _mangled_kernel(name):
-    """Itanium-mangled fragment of a kernel name as pmc_traffic.py prints it ('ntt_forward_tiled<13, 10, 3, 0, 2>',
+    """Itanium-mangled fragment of a kernel name as pmc_traffic.py prints it ('ntt_forward_tiled<13, 10, 4, 0, 2>',
     'floor_kernel<4, unsigned long, true>') -- what the library's symbol table holds for the instantiation."""
     base, _, args = name.partition("<")
     if not args:
@@ -384,8 +384,9 @@ class NttWorkload:
             traffic = profile["hbm_bytes_per_launch"] / forward_s / 1e9
         roofline = {
             "bound": "hbm",
-            "kernel": "ntt_forward_tiled<13, 10, 3, 0, 2> (forward NTT: one 1024-lane workgroup per pair of residue rows "
-                      "of one modulus, 8 words per lane per row, limb-wise Shoup butterflies)",
+            "kernel": "ntt_forward_tiled<13, 10, 4, 0, 2> (forward NTT: one 1024-lane workgroup per pair of residue rows "
+                      "of one modulus, 8 words per lane per row, butterflies whose products fold by a shift at 2^(b+2) "
+                      "for the moduli 2^b - d)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

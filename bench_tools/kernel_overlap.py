@@ -16,7 +16,7 @@ def short(name):
 
 def main():
     path = sys.argv[1]
-    first = sys.argv[2] if len(sys.argv) > 2 else "behz_rows_fused<13, 10, 3"
+    first = sys.argv[2] if len(sys.argv) > 2 else "behz_rows_fused<13, 10, 4"
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
     if not starts:

@@ -43,6 +43,7 @@ timeout 600 python bench_tools/param_sets_bench.py > $O/param_sets.txt 2>&1
 # mix of the headline pair (the build's own code objects; no GPU involved)
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 3" > $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 7" >> $O/isa_stats.txt 2>&1
+python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<13, 10, 4" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "<12, 9, " >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/ntt_kernels.o --filter "interleaved" >> $O/isa_stats.txt 2>&1
 python bench_tools/kernel_metadata.py swift-homomorphic-encryption_amd/csrc/build/behz_kernels.o --filter "behz" >> $O/isa_stats.txt 2>&1

@@ -42,8 +42,8 @@ def main():
     # target runs ct x ct and relinearize some number of times each; a pipeline's calls = the smallest dispatch count among its
     # kernels (the kernels launched once per call), a kernel's launches per call = its dispatches over that (the lift: 2; since
     # round 5 the Bsk band of the row-fused kernel and the floor go in two parts of the batch: 2 each).
-    mul_kernels = ("lift_kernel", "floor_kernel", "behz_rows_fused", "ntt_forward_tiled<13, 10, 3, 3", "ntt_forward_tiled<13, 10, 6, 0",
-                   "ntt_inverse_tiled<13, 10, 6, 1", "ntt_inverse_tiled<13, 10, 7, 1", "tensor_kernel")
+    mul_kernels = ("lift_kernel", "floor_kernel", "behz_rows_fused", "ntt_forward_tiled<13, 10, 3, 3", "ntt_forward_tiled<13, 10, 4, 3", "ntt_forward_tiled<13, 10, 6, 0",
+                   "ntt_inverse_tiled<13, 10, 6, 1", "ntt_inverse_tiled<13, 10, 7, 1", "ntt_inverse_tiled<13, 10, 4, 1", "tensor_kernel")
     rows = {k: r for k, r in c3.items() if not (k.startswith("_") or "at::" in k or "rocclr" in k)}
     is_mul = {k: any(m in k for m in mul_kernels) for k in rows}
     calls = {True: min((r["dispatches"] for k, r in rows.items() if is_mul[k]), default=1),

@@ -127,13 +127,16 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    w 2^32 mod p in signed limbs for that) -- one 64-bit addition less per butterfly.  Used where it
 //                    measures faster: every limb-wise inverse kernel but the plain-slab one at N = 8192
 //                    (profiles/r04t_inverse_forms_ab.txt).
-//   kModeSplitShift  the same for moduli just below a power of two (DeviceModulus::split_shift != 0): a gathered twiddle
-//                    is its 16 bytes (w, w 2^32 mod p) alone and the two 31-bit quotient factors are read off those
-//                    words by a shift instead of fetched -- one gather instruction per twiddle instead of two.  A shifted
-//                    factor is at most one below the tabulated one, which lowers the quotient by at most 2 more:
-//                    products in [0, 12p), one more fold in the inverse.  Used where it measures faster (forward
-//                    transforms at N = 4096 -5 %; N = 8192 and the interleaved rows are indifferent to their gathers'
-//                    bytes: profiles/r03k_ntt_shift_factors.txt, r03p_ntt_interleaved.txt).
+//   kModeSplitShift  the same SCHEDULE (spare top bits, no conditional subtract per butterfly) for moduli just below a power
+//                    of two, p = 2^b - d with d < 2^(b-33), 41 <= b <= 55 (DeviceModulus::split_shift != 0: what
+//                    generatePrimes(preferringSmall: false) returns, i.e. every parameter set of the reference), with the
+//                    product FOLDED BY A SHIFT at 2^(b+2) = 4d (mod p) instead of reduced by an estimated quotient
+//                    (device_math.hpp fold_mul, the fold modes' product): 5 multiply-adds instead of 8, no factor table -- a
+//                    gathered twiddle is its 16 bytes (w, w 2^32 mod p), 4 registers instead of 6, so two of them are kept
+//                    in flight (kTwiddlesAhead) -- products below 2^(b+2) + 2^33 d < 6p for ANY 64-bit multiplicand, hence the
+//                    same bounds as kModeSplit's [0, 8p).  Round 5: forward -3.4 %, inverse -9 % at N = 8192, -3 % / -5.5 % at
+//                    N = 4096, relinearize +4 % (profiles/r05ad_fold_lazy_butterflies_ab.txt).  (Rounds 3-4 used the name for
+//                    limb-wise products whose quotient factors were read off the constants by a shift.)
 //   kModeFoldMinus / kModeFoldPlus   2^55 < p < 2^60.2 next to a power of two -- p = 2^b - d, 56 <= b <= 60 (the largest
 //                    b-bit primes: the reference's 60-bit parameter sets) or p = 2^60 + e (the BEHZ auxiliary primes): the
 //                    product folds back by a shift (device_math.hpp fold_mul: 5 multiply-adds, products in [0, 6p), no
@@ -145,7 +148,7 @@ constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSp
 constexpr bool is_fold(int mode) { return mode == kModeFoldMinus || mode == kModeFoldPlus; }
 template <int MODE>
 __device__ __forceinline__ FoldConstants mode_fold_constants(uint64_t p) {
-    if constexpr (is_fold(MODE)) return fold_constants<MODE == kModeFoldPlus>(p);
+    if constexpr (is_fold(MODE) || MODE == kModeSplitShift) return fold_constants<MODE == kModeFoldPlus>(p);
     else return FoldConstants{};
 }
 
@@ -176,7 +179,6 @@ struct Twiddles {
     const U64x2* pairs;
     const uint64_t* factors;
     BufferResource pair_resource, factor_resource;  // split mode gathers
-    uint32_t shift;                                 // kModeSplitShift: the modulus's split_shift (wave-uniform)
     // Lane-major stage blocks (DeviceContext::*_split_pairs_lanes): within the block of a stage whose lanes hold 2^g twiddles
     // each (g = the pass's register bits above the stage's bit), entry o sits at (o mod 2^g) (m / 2^g) + (o >> g) -- the k-th
     // twiddle of all lanes of a wave is then one contiguous run (whole cache lines per request) instead of every 2^g-th entry
@@ -187,7 +189,6 @@ struct Twiddles {
     __device__ __forceinline__ Twiddles(const DeviceContext& ctx, bool inverse, uint32_t modulus_index, int log_degree,
                                         uint32_t skip = 0, int lane_major = 0) {
         const size_t at = (static_cast<size_t>(modulus_index) << log_degree) + skip;
-        shift = 0;
         lanes = lane_major != 0;
         if constexpr (is_split(MODE) || is_fold(MODE)) {  // (w, w 2^32 mod p); the fold butterflies use no factors
             pairs = (inverse ? (MODE == kModeSplitSigned ? ctx.inverse_split_pairs_signed : ctx.inverse_split_pairs)
@@ -205,10 +206,6 @@ struct Twiddles {
             }
             pair_resource = make_resource(pairs, (16u << log_degree) - 16u * skip);
             factor_resource = make_resource(factors, (8u << log_degree) - 8u * skip);
-            if constexpr (MODE == kModeSplitShift) {
-                using ConstWord = const __attribute__((address_space(4))) uint32_t;
-                shift = *(ConstWord*)(&ctx.moduli[modulus_index].split_shift);
-            }
         } else {
             pairs = (inverse ? ctx.inverse_twiddles : ctx.forward_twiddles) + at;
             factors = nullptr;
@@ -228,24 +225,18 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
         t.w = pair.x;
         t.second = pair.y;
         t.factors = 0;
-        if constexpr (is_split(MODE)) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
+        if constexpr (MODE == kModeSplit || MODE == kModeSplitSigned) t.factors = load_twiddle_word(tw.factors + fixed_index + lane_index);
     } else if constexpr (MODE == kModeSplit || MODE == kModeSplitSigned) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         const Dwordx2 factors = __builtin_amdgcn_raw_buffer_load_b64(tw.factor_resource, lane_index << 3, fixed_index << 3, 0);
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
         t.factors = pack64(factors.x, factors.y);
-    } else if constexpr (is_fold(MODE)) {
+    } else if constexpr (is_fold(MODE) || MODE == kModeSplitShift) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
         t.factors = 0;
-    } else if constexpr (MODE == kModeSplitShift) {
-        const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
-        t.w = pack64(pair.x, pair.y);
-        t.second = pack64(pair.z, pair.w);
-        // the low word of each constant >> shift (shift = bits(p) - 31 in [10, 24]; the constants are below 2^55)
-        t.factors = pack64(__builtin_amdgcn_alignbit(pair.y, pair.x, tw.shift), __builtin_amdgcn_alignbit(pair.w, pair.z, tw.shift));
     } else {
         const U64x2 pair = load_twiddle(tw.pairs + fixed_index + lane_index);
         t.w = pair.x;
@@ -259,7 +250,7 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 // its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels -- two ahead lose
 // 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt).
 template <int MODE>
-constexpr int kTwiddlesAhead = 1;
+constexpr int kTwiddlesAhead = MODE == kModeSplitShift ? 2 : 1;
 // ... and of the row groups of three and four (behz_kernels.hip: one workgroup per CU at 128 registers per lane -- there are
 // registers for deeper requests, and with 4 wavefronts per SIMD less else to hide a gather's latency)
 constexpr int kWideGroupTwiddlesAhead = 1;
@@ -272,13 +263,15 @@ struct Lazy {
     // products < p << this (split: [0, 8p); with shifted factors [0, 12p))
     // (the fold modes keep their own fixed ranges -- products below 6p, forward words below 14p, inverse words below 6p --
     // in forward_butterfly / inverse_butterfly; the two constants below are not used for them)
-    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : (MODE == kModeSplit || MODE == kModeSplitSigned) ? 3 : is_fold(MODE) ? 3 : 4;
+    static constexpr int kProductLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : 3;
     // cap on stage inputs of the inverse transform, as a shift of p (split: sums of two stay below 2^9 p < 2^64)
     static constexpr int kInverseCapLog = MODE == kModeExact ? 1 : MODE == kModeApprox ? 2 : is_fold(MODE) ? 3 : 8;
     // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
     template <bool UNIFORM = false>
     __device__ static __forceinline__ uint64_t mul(uint64_t x, const TwiddleWords& w, uint64_t reduction) {
-        if constexpr (kSplit) {
+        if constexpr (MODE == kModeSplitShift) {
+            return fold_mul<UNIFORM, false>(x, w.w, w.second, fold_constants<false>((0 - reduction) >> 1));
+        } else if constexpr (kSplit) {
             return split_mul_add<UNIFORM, false>(0, x, w.w, w.second, w.factors, reduction);
         } else if constexpr (MODE == kModeApprox && UNIFORM) {
             return shoup_lazy4_uniform(x, w.w, w.second, reduction);
@@ -442,6 +435,13 @@ __device__ __forceinline__ void forward_butterfly(uint64_t& first, uint64_t& sec
         const uint64_t r = uniform ? fold_mul<true, PLUS>(y, w.w, w.second, fc) : fold_mul<false, PLUS>(y, w.w, w.second, fc);
         first = x + r;
         second = x + 6 * p - r;
+        return;
+    }
+    if constexpr (MODE == kModeSplitShift) {
+        // the product folded at 2^(b+2) (below 6p for any 64-bit y), no quotient, no factors; nothing ever brought back
+        const uint64_t r = uniform ? fold_mul<true, false>(y, w.w, w.second, fc) : fold_mul<false, false>(y, w.w, w.second, fc);
+        first = x + r;
+        second = x + half_bound - r;
         return;
     }
     if (!is_split(MODE) && fold) x = csub_uniform(x, half_bound);

@@ -605,6 +605,7 @@ __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 
     static_assert(!is_split(MODE) || 1 + ((kSubLogN + LOGS) << Lazy<MODE>::kProductLog) <= 511, "growth stays below 2^9 p");
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;
+    const FoldConstants fc = mode_fold_constants<MODE>(p);
     const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
 #pragma unroll
     for (int c = 0; c < LOGS; ++c) {
@@ -627,7 +628,7 @@ __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 
 #pragma unroll
             for (int low = 0; low < span; ++low) {
                 const int h = (upper << (LOGS - c)) | low;
-                forward_butterfly<MODE>(v[h][r], v[h + span][r], w, false, neg_p, half_bound, true);
+                forward_butterfly<MODE>(v[h][r], v[h + span][r], w, false, neg_p, half_bound, true, fc);
             }
             if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
         }
@@ -642,6 +643,7 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
     constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog;
     constexpr uint32_t N = 1u << (kSubLogN + LOGS);
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
+    const FoldConstants fc = mode_fold_constants<MODE>(p);
     const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
 #pragma unroll
     for (int c = 0; c < LOGS; ++c) {
@@ -669,7 +671,7 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
 #pragma unroll
             for (int low = 0; low < span; ++low) {
                 const int h = (upper << (c + 1)) | low;
-                inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold, FoldConstants{}, split_signed_bias(p));
+                inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold, fc, split_signed_bias(p));
             }
             if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1049,14 +1051,19 @@ __global__ void __launch_bounds__(256)
 
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
-// Where the shifted-factor butterflies (ntt_common.hpp kModeSplitShift) replace the tabulated ones for the contexts that
-// allow them: the plain-slab launches they measured faster on -- the forward transform at N = 4096
-// (profiles/r03k_ntt_shift_factors.txt; the interleaved rows are indifferent: profiles/r03p_ntt_interleaved.txt).  Forward
-// transforms only: the inverse tables hold their second word in signed limbs (ntt_common.hpp inverse_butterfly), which no
-// factor can be read off; the inverse transform with shifted factors measured 3 % slower anyway
-// (profiles/r04a_inverse_variants_ab.txt).
-template <int LOGN>
-constexpr bool kShiftFactors = LOGN == 12;
+// Where the shift-folded products (ntt_common.hpp kModeSplitShift) replace the limb-wise Shoup ones for launches whose moduli
+// are all of the form 2^b - d (DeviceContext::shift_prefix): every kernel of the 8-words-per-lane shapes at N = 4096 / 8192 --
+// plain slabs and the fused loads, both directions -- and the Q band of the row-fused ct x ct kernel (behz_kernels.hip).  Not the
+// interleaved sub-rows of N = 16384 / 32768, which measured the same either way (profiles/r05af_fold_lazy_interleaved_ab.txt).
+template <int LOGN, int LOGT>
+constexpr bool kShiftFactors = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
+template <int LOGN, int LOGT, int SOURCE>
+constexpr bool kShiftFactorsInverse = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
+constexpr bool kShiftFactorsInterleaved = false;
+// every modulus of a launch is of the form 2^b - d (DeviceContext::shift_prefix)
+inline bool shift_band(const DeviceContext& ctx, const RowMap& map) {
+    return map.band_rows != 0 && map.mod_base + map.band_rows <= ctx.shift_prefix;
+}
 
 constexpr int kRowGroup = 2;
 template <int LOGN, int LOGT>
@@ -1108,6 +1115,9 @@ hipError_t launch_interleaved_forward(int mode, uint64_t* slab, const DeviceCont
     auto kernel = mode == kModeSplit    ? ntt_forward_interleaved<LOGS, kModeSplit, SPREAD>
                   : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox, SPREAD>
                                         : ntt_forward_interleaved<LOGS, kModeExact, SPREAD>;
+    if constexpr (kShiftFactorsInterleaved) {
+        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_forward_interleaved<LOGS, kModeSplitShift, SPREAD>;
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
                        spread);
@@ -1140,6 +1150,15 @@ hipError_t launch_interleaved_inverse(int mode, uint64_t* slab, const DeviceCont
                  : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false, SOURCE>
                                        : ntt_inverse_interleaved<LOGS, kModeExact, false, SOURCE>;
     }
+    if constexpr (kShiftFactorsInterleaved) {
+        if (mode == kModeSplit && shift_band(ctx, map)) {
+            constexpr bool ALWAYS_SCALED = SOURCE == kInverseFromTensor, NEVER_SCALED = SOURCE == kInverseFromKeyMac;
+            if constexpr (ALWAYS_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, true, SOURCE>;
+            else if constexpr (NEVER_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, false, SOURCE>;
+            else kernel = ctx.scaled_inverse_degree != 0 ? ntt_inverse_interleaved<LOGS, kModeSplitShift, true, SOURCE>
+                                                         : ntt_inverse_interleaved<LOGS, kModeSplitShift, false, SOURCE>;
+        }
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
                        source_spec);
@@ -1161,10 +1180,9 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD, ROWS>
                   : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD, ROWS>
                                         : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD, ROWS>;
-    if constexpr (kShiftFactors<LOGN> && SPREAD == kSourceSlab) {
-        // every modulus of the launch is just below a power of two: the gathered twiddles' factors come by a shift
-        if (mode == kModeSplit && map.mod_base + map.band_rows <= ctx.shift_prefix)
-            kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
+    if constexpr (kShiftFactors<LOGN, LOGT>) {
+        // every modulus of the launch is just below a power of two: products folded by a shift, no quotient, no factors
+        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
     }
     if constexpr (kFoldShape<LOGN, LOGT> && (SPREAD == kSourceSlab || SPREAD == kSourceSpread)) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
@@ -1224,6 +1242,9 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, SPLIT, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
+    if constexpr (kShiftFactorsInverse<LOGN, LOGT, SOURCE>) {
+        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
+    }
     if constexpr (kFoldShape<LOGN, LOGT>) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
             const int fold = fold_mode(ctx, map.mod_base, map.band_rows);

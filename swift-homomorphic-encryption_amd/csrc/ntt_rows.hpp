@@ -323,7 +323,7 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
 // those of a row whose first kLazyInputStages stages already ran: inverse_in_shift(3) = 5 covers 5p) and the fold ones
 // (words below 6p).  Three conditional subtracts less per word; the [0, 8p) / exact butterflies keep canonical input.
 template <int MODE>
-constexpr bool kLazyTransformInput = MODE == kModeSplit || MODE == kModeSplitSigned || is_fold(MODE);
+constexpr bool kLazyTransformInput = is_split(MODE) || is_fold(MODE);
 constexpr int kLazyInputStages = 3;
 template <typename Kernel>
 inline hipError_t allow_dynamic_lds(Kernel kernel, size_t lds_bytes) {
