@@ -998,3 +998,32 @@ def test_key_switch_on_runs_of_butterfly_classes(oracle, degree, bits, batch):
     ct = _uniform(rng, (batch, 2), moduli, degree)
     rotated = heamd.to_host(ours.apply_galois(heamd.to_device(ct), element, heamd.to_device(key)))
     assert np.array_equal(rotated, ref.apply_galois(ct, element, key))
+
+
+def test_pipelines_on_moduli_at_the_edge_of_the_shift_folded_products(oracle):
+    """ct x ct (row-fused and unfused) and relinearize with ciphertext moduli 2^b - d whose d is as large as kModeSplitShift
+    allows (tests/test_gpu_ntt.py _primes_below_power_of_two) -- the generated primes of every other test sit at the small end --
+    and with one modulus just past the bound among them (that band then runs the limb-wise products): word for word."""
+    from conftest import host_threads
+    from test_gpu_ntt import _primes_below_power_of_two
+
+    degree = 4096
+    t = oracle.generate_primes([17], True, degree)[0]
+    edge = [p for bits in (55, 54, 52, 50) for p in _primes_below_power_of_two(oracle, bits, degree, True)]
+    past = _primes_below_power_of_two(oracle, 55, degree, False)
+    for q in (edge, edge[:2] + past + edge[2:3]):
+        ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+        L = ours.L
+        moduli = ref.ciphertext_context(L).moduli
+        rng = np.random.default_rng(len(q) + q[2] % 97)
+        batch = 48  # 48 x 7 rows: wide enough for behz_kernels.hip
+        lhs, rhs = _uniform(rng, (batch, 2), moduli, degree), _uniform(rng, (batch, 2), moduli, degree)
+        for i, m in enumerate(moduli):
+            lhs[1, :, i, :] = m - 1
+            rhs[1, :, i, :] = m - 1
+        product = ref.mul(lhs, rhs, L, threads=host_threads())
+        assert np.array_equal(heamd.to_host(ours.mul(heamd.to_device(lhs), heamd.to_device(rhs), L)), product), q
+        assert np.array_equal(heamd.to_host(ours.mul(heamd.to_device(lhs[:2].copy()), heamd.to_device(rhs[:2].copy()), L)), product[:2]), q
+        key = _uniform(rng, (ours.L, 2), ref.key_switching_context().moduli, degree)
+        got = heamd.to_host(ours.relinearize(heamd.to_device(product), heamd.to_device(key), L))
+        assert np.array_equal(got, ref.relinearize(product, key, L, threads=host_threads())), q

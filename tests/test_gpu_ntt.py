@@ -376,3 +376,40 @@ def test_ntt_full_size_properties(oracle):
     del s, y
     ours.inverse_ntt_(x)
     assert torch.equal(x, original)
+
+
+def _primes_below_power_of_two(oracle, bits, degree, eligible, count=1):
+    """NTT primes p = 2^bits - d (p = 1 mod 2N) with d as LARGE as the shift-folded products allow (d < 2^(bits-33):
+    csrc/poly_context.cpp split_shift) when `eligible`, or the first ones just past that bound otherwise."""
+    step, top = 2 * degree, 1 << (bits - 33)
+    found = []
+    k = (top + 1) // step if eligible else (top + 1) // step + 1
+    while len(found) < count and k >= 1 and k * step - 1 < (1 << (bits - 1)):
+        d = k * step - 1
+        p = (1 << bits) - d
+        if (d < top) == eligible and oracle.is_prime(p):
+            found.append(p)
+        k += -1 if eligible else 1
+    return found
+
+
+@pytest.mark.parametrize("degree", [4096, 8192])
+def test_shift_folded_products_at_the_edge_of_their_moduli(oracle, degree):
+    """kModeSplitShift (csrc/ntt_common.hpp): the transforms of moduli 2^b - d fold their products by a shift, which wants
+    d < 2^(b-33).  The primes generatePrimes returns sit at the small end of d; these sit at the LARGE end (the product's
+    bound 2^(b+2) + 2^33 d is nearly reached), next to primes just past the bound (limb-wise products) in the same context --
+    the launch then falls back as a whole -- and alone.  Extreme words in every residue."""
+    edge = [p for bits in (55, 54, 52, 50) for p in _primes_below_power_of_two(oracle, bits, degree, True)]
+    past = [p for bits in (55, 52) for p in _primes_below_power_of_two(oracle, bits, degree, False)]
+    assert len(edge) >= 3 and len(past) == 2, (edge, past)
+    rng = np.random.default_rng(degree)
+    for moduli in (edge, edge[:1], edge[:2] + past[:1], past):
+        ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
+        slab = _rand_slab(rng, 5, moduli, degree)
+        slab[0] = 0
+        for i, m in enumerate(moduli):
+            slab[1, i, :] = m - 1
+            slab[2, i, ::2] = m - 1
+            slab[2, i, 1::2] = 0
+        assert np.array_equal(heamd.to_host(ours.forward_ntt_(heamd.to_device(slab))), ref.forward_ntt(slab)), moduli
+        assert np.array_equal(heamd.to_host(ours.inverse_ntt_(heamd.to_device(slab))), ref.inverse_ntt(slab)), moduli
