@@ -45,7 +45,48 @@ __global__ void product_kernel(const uint64_t* __restrict__ operand, const uint6
     }
 }
 
+// kinds 4 / 5: fold_mul<false, false> / fold_mul<true, false> (p = 2^b - d: kModeSplitShift and kModeFoldMinus); kinds 6 / 7:
+// fold_mul<false, true> / fold_mul<true, true> (p = 2^60 + e: kModeFoldPlus).  The uniform kinds take constant 0 for every lane.
+template <bool UNIFORM, bool PLUS>
+__global__ void fold_kernel(const uint64_t* __restrict__ operand, const uint64_t* __restrict__ w, const uint64_t* __restrict__ wt,
+                            uint64_t p, uint64_t* __restrict__ out, size_t count) {
+    const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (i >= count) return;
+    const FoldConstants fc = fold_constants<PLUS>(uniform_word(p));
+    if constexpr (UNIFORM) out[i] = fold_mul<true, PLUS>(operand[i], uniform_word(w[0]), uniform_word(wt[0]), fc);
+    else out[i] = fold_mul<false, PLUS>(operand[i], w[i], wt[i], fc);
+}
+
 }  // namespace
+
+// operand[count], constant[count] -> out[count] = the shift-folded product (kinds 4..7 above).  Host pointers.
+extern "C" int arith_probe_fold_product(int kind, uint64_t p, const uint64_t* operand, const uint64_t* constant, size_t count,
+                                        uint64_t* out) {
+    if (kind < 4 || kind > 7 || count == 0) return -1;
+    uint64_t* host = static_cast<uint64_t*>(malloc(count * sizeof(uint64_t)));
+    for (size_t i = 0; i < count; ++i) host[i] = heamd::split_shifted(constant[i], p);
+    uint64_t* device = nullptr;
+    hipError_t e = hipMalloc(&device, 4 * count * sizeof(uint64_t));
+    if (e != hipSuccess) { free(host); return int(e); }
+    uint64_t *d_operand = device, *d_w = device + count, *d_wt = device + 2 * count, *d_out = device + 3 * count;
+    e = hipMemcpy(d_operand, operand, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_w, constant, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_wt, host, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const dim3 grid(static_cast<unsigned>((count + 255) / 256)), block(256);
+        switch (kind) {
+            case 4: hipLaunchKernelGGL((fold_kernel<false, false>), grid, block, 0, 0, d_operand, d_w, d_wt, p, d_out, count); break;
+            case 5: hipLaunchKernelGGL((fold_kernel<true, false>), grid, block, 0, 0, d_operand, d_w, d_wt, p, d_out, count); break;
+            case 6: hipLaunchKernelGGL((fold_kernel<false, true>), grid, block, 0, 0, d_operand, d_w, d_wt, p, d_out, count); break;
+            default: hipLaunchKernelGGL((fold_kernel<true, true>), grid, block, 0, 0, d_operand, d_w, d_wt, p, d_out, count); break;
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, count * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(device);
+    free(host);
+    return int(e);
+}
 
 // operand[count], constant[count] (constants below p; kinds 2 / 3 use constant[0] for every operand) -> out[count].
 // Host pointers.  Returns 0 or the hipError_t that stopped it.
