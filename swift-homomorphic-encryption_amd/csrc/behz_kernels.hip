@@ -193,6 +193,16 @@ bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, 
            items * record_rows > ntt::kOneGeneration / 2 && items * record_rows <= (size_t(1) << 30);
 }
 
+constexpr bool kBehzLazyLiftedRows = true;
+bool behz_lifted_rows_may_be_lazy(const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli) {
+    if (!kBehzLazyLiftedRows || !kFoldButterflies || record_rows > 64 || source_moduli >= record_rows) return false;
+    if (scaled_qbsk.log_degree != 12 && scaled_qbsk.log_degree != 13) return false;
+    ntt::BandRun runs[ntt::kMaxBandRuns];
+    if (ntt::band_runs(scaled_qbsk, record_rows, runs) <= 1) return false;  // one launch in one mode for every row
+    const uint64_t lifted = ((record_rows == 64 ? ~uint64_t(0) : (uint64_t(1) << record_rows) - 1) >> source_moduli) << source_moduli;
+    return (scaled_qbsk.fold_plus_mask & lifted) == lifted && scaled_qbsk.forward_split_pairs != nullptr;
+}
+
 hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size_t ct_stride, const uint64_t* lifted,
                                   uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,
                                   size_t items, hipStream_t stream, int part) {

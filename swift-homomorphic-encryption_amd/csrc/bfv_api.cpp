@@ -247,6 +247,8 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
     const uint32_t rows = 2 * L + 1;
     if (!heamd::behz_rows_fused_supported(scaled, rows, L, batch)) return HE_OK;
     *fused = true;
+    // (the fold butterflies of the Bsk band take the lift's rows as its reduction leaves them, below 5p)
+    const bool lazy = heamd::behz_lifted_rows_may_be_lazy(scaled, rows, L);
     // The row bands that read the ciphertexts themselves (the Q rows) do not depend on the lift: on the context's side lane they
     // run beside it -- a 128-register row-fused workgroup leaves room on its CU for the lift's 256-lane workgroups of 40
     // registers (ct x ct +2.6 %, profiles/r05v_behz_q_band_beside_lift_ab.txt).  From four workgroup generations of Q rows up;
@@ -265,8 +267,8 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             HEAMD_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.forked, 0));
             hipError_t e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, lane.stream,
                                                          heamd::kBehzCiphertextRows);
-            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false);
-            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false);
+            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false, lazy);
+            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false, lazy);
             // The Bsk band and the floor in kBehzFloorParts parts of the batch: a part's floor -- 256-lane workgroups of 41
             // registers -- follows the Q band on the lane and runs beside the NEXT part's Bsk band on the caller's stream;
             // only the last part's floor is left to run on its own.
@@ -303,8 +305,8 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             return HE_OK;
         }
     }
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false, lazy));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false, lazy));
     HEAMD_HIP_TRY(heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream));
     return HE_OK;
 }

@@ -56,6 +56,9 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
 // Coeff, what launch_floor_qbsk_to_q takes.  hipErrorNotSupported (nothing launched, behz_rows_fused_supported false):
 // launch_ntt_lifted_forward + launch_ntt_tensor_inverse.
 bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items);
+// whether the row bands that read the lift's rows take them in [0, 5p) (every such row on the fold butterflies of the plus form,
+// whose first stage wants x < 8p and any y): the lift may then skip its three conditional subtracts per word
+bool behz_lifted_rows_may_be_lazy(const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli);
 constexpr int kBehzAllRows = 0, kBehzCiphertextRows = 1, kBehzLiftedRows = 2;
 hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size_t ct_stride, const uint64_t* lifted,
                                   uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,

@@ -175,6 +175,9 @@ inline bool quad_aligned(const W* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct LiftLayout {
     size_t polys_per_item, in_item_stride, out_item_stride;
     uint32_t store_input;  // 0: rows [0, L) of the output are left to the transform that follows (it reads the input itself)
+    // 1: the Bsk rows may be left as the one-word-quotient reduction hands them over, in [0, 5p), for a consumer that takes such
+    // words (the row-fused ct x ct kernel's fold butterflies: behz_kernels.hip) -- three conditional subtracts per word less
+    uint32_t lazy_output;
 };
 
 // W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
@@ -250,7 +253,8 @@ __global__ void __launch_bounds__(kThreads)
                     // the two terms stay unfolded (< 5p and < 3p; the extended moduli are < 2^61) and the sum is folded once
                     unfolded = A::template reduce_lazy<BOUNDED>(sum, m) + A::shoup_lazy(centered, scaled, m.p);
                 }
-                lifted[v] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
+                if (BOUNDED && sizeof(W) == 8 && layout.lazy_output != 0) lifted[v] = unfolded;  // (wave-uniform branch)
+                else lifted[v] = csub_uniform(csub_uniform(csub_uniform(unfolded, 4 * m.p), 2 * m.p), m.p);
             }
             store_words<V>(dst + (L + j) * n, lifted);
         }
@@ -856,16 +860,16 @@ template <typename W>
 hipError_t launch_lift_q_to_qbsk(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     const size_t n = size_t(1) << tool.log_degree;
-    const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n, 1};
+    const LiftLayout layout{1, tool.L * n, (2 * size_t(tool.L) + 1) * n, 1, 0};
     return dispatch_L<LiftLauncher>(tool.L, in, out, tool, polys, layout, stream);
 }
 
 template <typename W>
 hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevice& tool, size_t items,
                                          size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
-                                         size_t out_offset, hipStream_t stream, bool store_input) {
+                                         size_t out_offset, hipStream_t stream, bool store_input, bool lazy_output) {
     if (items == 0 || polys_per_item == 0) return hipSuccess;
-    const LiftLayout layout{polys_per_item, in_item_stride, out_item_stride, store_input ? 1u : 0u};
+    const LiftLayout layout{polys_per_item, in_item_stride, out_item_stride, store_input ? 1u : 0u, lazy_output ? 1u : 0u};
     return dispatch_L<LiftLauncher>(tool.L, in, out + out_offset, tool, items * polys_per_item, layout, stream);
 }
 
@@ -979,7 +983,7 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
                                                       hipStream_t);                                                       \
     template hipError_t launch_lift_q_to_qbsk<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);                \
     template hipError_t launch_lift_q_to_qbsk_strided<W>(const W*, W*, const RnsToolDevice&, size_t, size_t, size_t,      \
-                                                         size_t, size_t, hipStream_t, bool);                              \
+                                                         size_t, size_t, hipStream_t, bool, bool);                        \
     template hipError_t launch_floor_qbsk_to_q<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);               \
     template hipError_t launch_tensor<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);                        \
     template hipError_t launch_tensor_accumulate<W>(const W*, W*, const DeviceContext&, size_t, uint64_t, hipStream_t);   \

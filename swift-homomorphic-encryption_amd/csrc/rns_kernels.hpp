@@ -19,11 +19,13 @@ hipError_t launch_lift_q_to_qbsk(const W* in, W* out, const RnsToolDevice& tool,
 // Strided form: item i's `polys_per_item` polynomials are read at in + i*in_item_stride (+ c*L*N) and written at
 // out + out_offset + i*out_item_stride (+ c*(2L+1)*N); strides and offset in words.  store_input = false leaves rows
 // [0, L) of every output polynomial (the copy of the input) unwritten: the transform that follows reads the input itself
-// (kernels.hpp launch_ntt_lifted_forward).
+// (kernels.hpp launch_ntt_lifted_forward).  lazy_output = true allows the Bsk rows to be left in [0, 5p) (8-byte slabs with the
+// one-word-quotient reduction; other shapes store canonical words all the same): only for a consumer that takes such words
+// (kernels.hpp behz_lifted_rows_may_be_lazy).
 template <typename W>
 hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevice& tool, size_t items,
                                          size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
-                                         size_t out_offset, hipStream_t stream, bool store_input = true);
+                                         size_t out_offset, hipStream_t stream, bool store_input = true, bool lazy_output = false);
 // in [polys][2L+1][N] -> out [polys][L][N]
 template <typename W>
 hipError_t launch_floor_qbsk_to_q(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream);
