@@ -7,9 +7,9 @@ EDITS = [("ntt_common.hpp",
           "        t.w = pack64(pair.x, pair.y);\n"
           "        t.second = pack64(pair.z, pair.w);\n"
           "        t.factors = pack64(factors.x, factors.y);\n"
-          "    } else if constexpr (is_fold(MODE) || MODE == kModeSplitShift) {",
+          "    } else if constexpr (is_fold(MODE) || MODE == kModeFoldLazy) {",
           "        const U64x2 pair = tw.pairs[size_t(lane_index + fixed_index)];\n"
           "        t.w = pair.x;\n"
           "        t.second = pair.y;\n"
           "        t.factors = tw.factors[size_t(lane_index + fixed_index)];\n"
-          "    } else if constexpr (is_fold(MODE) || MODE == kModeSplitShift) {")]
+          "    } else if constexpr (is_fold(MODE) || MODE == kModeFoldLazy) {")]

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, kBe
     }
 }
 
-constexpr bool kBehzShiftFactors = true;
+constexpr bool kBehzFoldLazy = true;
 template <int LOGN, int LOGT, int MODE_F, int MODE_I>
 hipError_t launch_band(uint64_t* out, const DeviceContext& ctx, const RowMap& map, size_t workgroups, const BehzRows& src,
                        hipStream_t stream) {
@@ -169,9 +169,9 @@ template <int LOGN, int LOGT>
 hipError_t launch_band_in_mode(int mode, uint64_t* out, const DeviceContext& ctx, const RowMap& map, size_t workgroups,
                                const BehzRows& src, hipStream_t stream) {
     if (mode == kModeSplit) {
-        // moduli 2^b - d (every parameter set of the reference): the products folded by a shift (ntt_common.hpp kModeSplitShift)
-        if (kBehzShiftFactors && map.mod_base + map.band_rows <= ctx.shift_prefix)
-            return launch_band<LOGN, LOGT, kModeSplitShift, kModeSplitShift>(out, ctx, map, workgroups, src, stream);
+        // moduli 2^b - d (every parameter set of the reference): the products folded by a shift (ntt_common.hpp kModeFoldLazy)
+        if (kBehzFoldLazy && map.mod_base + map.band_rows <= ctx.shift_prefix)
+            return launch_band<LOGN, LOGT, kModeFoldLazy, kModeFoldLazy>(out, ctx, map, workgroups, src, stream);
         return launch_band<LOGN, LOGT, kModeSplit, kModeSplitSigned>(out, ctx, map, workgroups, src, stream);
     }
     if (mode == kModeApprox) {

@@ -42,7 +42,7 @@ struct DeviceModulus {
     // power of two, p = 2^b - delta with delta < 2^(b - 33) (what generatePrimes(preferringSmall: false) returns, i.e.
     // every parameter set of the reference), floor(c 2^32 / 2p) is c >> split_shift or one more, split_shift = b - 31.
     // 0 where the modulus is not of that form.  Since round 5 the flag selects the shift-folded products of ntt_common.hpp
-    // kModeSplitShift (2^(b+2) = 4d mod p); the value itself is no longer read on the device.
+    // kModeFoldLazy (2^(b+2) = 4d mod p); the value itself is no longer read on the device.
     uint32_t split_shift;
 };
 

@@ -127,7 +127,7 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    w 2^32 mod p in signed limbs for that) -- one 64-bit addition less per butterfly.  Used where it
 //                    measures faster: every limb-wise inverse kernel but the plain-slab one at N = 8192
 //                    (profiles/r04t_inverse_forms_ab.txt).
-//   kModeSplitShift  the same SCHEDULE (spare top bits, no conditional subtract per butterfly) for moduli just below a power
+//   kModeFoldLazy  the same SCHEDULE (spare top bits, no conditional subtract per butterfly) for moduli just below a power
 //                    of two, p = 2^b - d with d < 2^(b-33), 41 <= b <= 55 (DeviceModulus::split_shift != 0: what
 //                    generatePrimes(preferringSmall: false) returns, i.e. every parameter set of the reference), with the
 //                    product FOLDED BY A SHIFT at 2^(b+2) = 4d (mod p) instead of reduced by an estimated quotient
@@ -135,20 +135,20 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    gathered twiddle is its 16 bytes (w, w 2^32 mod p), 4 registers instead of 6, so two of them are kept
 //                    in flight (kTwiddlesAhead) -- products below 2^(b+2) + 2^33 d < 6p for ANY 64-bit multiplicand, hence the
 //                    same bounds as kModeSplit's [0, 8p).  Round 5: forward -3.4 %, inverse -9 % at N = 8192, -3 % / -5.5 % at
-//                    N = 4096, relinearize +4 % (profiles/r05ad_fold_lazy_butterflies_ab.txt).  (Rounds 3-4 used the name for
-//                    limb-wise products whose quotient factors were read off the constants by a shift.)
+//                    N = 4096, relinearize +4 % (profiles/r05ad_fold_lazy_butterflies_ab.txt).  (Rounds 3-4 had a kModeSplitShift in this
+//                    slot: limb-wise products whose quotient factors were read off the constants by a shift.)
 //   kModeFoldMinus / kModeFoldPlus   2^55 < p < 2^60.2 next to a power of two -- p = 2^b - d, 56 <= b <= 60 (the largest
 //                    b-bit primes: the reference's 60-bit parameter sets) or p = 2^60 + e (the BEHZ auxiliary primes): the
 //                    product folds back by a shift (device_math.hpp fold_mul: 5 multiply-adds, products in [0, 6p), no
 //                    factor table), values in [0, 14p) with one conditional subtract per butterfly like the [0, 8p)
 //                    schedule it replaces where the moduli allow it (DeviceContext::fold_minus_mask / fold_plus_mask).
-constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeSplitShift = 4, kModeFoldMinus = 5, kModeFoldPlus = 6,
+constexpr int kModeExact = 0, kModeApprox = 1, kModeSplit = 3, kModeFoldLazy = 4, kModeFoldMinus = 5, kModeFoldPlus = 6,
               kModeSplitSigned = 7;
-constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeSplitShift || mode == kModeSplitSigned; }
+constexpr bool is_split(int mode) { return mode == kModeSplit || mode == kModeFoldLazy || mode == kModeSplitSigned; }
 constexpr bool is_fold(int mode) { return mode == kModeFoldMinus || mode == kModeFoldPlus; }
 template <int MODE>
 __device__ __forceinline__ FoldConstants mode_fold_constants(uint64_t p) {
-    if constexpr (is_fold(MODE) || MODE == kModeSplitShift) return fold_constants<MODE == kModeFoldPlus>(p);
+    if constexpr (is_fold(MODE) || MODE == kModeFoldLazy) return fold_constants<MODE == kModeFoldPlus>(p);
     else return FoldConstants{};
 }
 
@@ -232,7 +232,7 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
         t.factors = pack64(factors.x, factors.y);
-    } else if constexpr (is_fold(MODE) || MODE == kModeSplitShift) {
+    } else if constexpr (is_fold(MODE) || MODE == kModeFoldLazy) {
         const Dwordx4 pair = __builtin_amdgcn_raw_buffer_load_b128(tw.pair_resource, lane_index << 4, fixed_index << 4, 0);
         t.w = pack64(pair.x, pair.y);
         t.second = pack64(pair.z, pair.w);
@@ -250,7 +250,7 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 // its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels -- two ahead lose
 // 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt).
 template <int MODE>
-constexpr int kTwiddlesAhead = MODE == kModeSplitShift ? 2 : 1;
+constexpr int kTwiddlesAhead = MODE == kModeFoldLazy ? 2 : 1;
 // ... and of the row groups of three and four (behz_kernels.hip: one workgroup per CU at 128 registers per lane -- there are
 // registers for deeper requests, and with 4 wavefronts per SIMD less else to hide a gather's latency)
 constexpr int kWideGroupTwiddlesAhead = 1;
@@ -269,7 +269,7 @@ struct Lazy {
     // `reduction` = 2^64 - p (exact / approx) or 2^64 - 2p (split)
     template <bool UNIFORM = false>
     __device__ static __forceinline__ uint64_t mul(uint64_t x, const TwiddleWords& w, uint64_t reduction) {
-        if constexpr (MODE == kModeSplitShift) {
+        if constexpr (MODE == kModeFoldLazy) {
             return fold_mul<UNIFORM, false>(x, w.w, w.second, fold_constants<false>((0 - reduction) >> 1));
         } else if constexpr (kSplit) {
             return split_mul_add<UNIFORM, false>(0, x, w.w, w.second, w.factors, reduction);
@@ -437,7 +437,7 @@ __device__ __forceinline__ void forward_butterfly(uint64_t& first, uint64_t& sec
         second = x + 6 * p - r;
         return;
     }
-    if constexpr (MODE == kModeSplitShift) {
+    if constexpr (MODE == kModeFoldLazy) {
         // the product folded at 2^(b+2) (below 6p for any 64-bit y), no quotient, no factors; nothing ever brought back
         const uint64_t r = uniform ? fold_mul<true, false>(y, w.w, w.second, fc) : fold_mul<false, false>(y, w.w, w.second, fc);
         first = x + r;

@@ -1051,17 +1051,17 @@ __global__ void __launch_bounds__(256)
 
 // Row pairs: where the register file allows it (8 words per lane), a workgroup transforms the same band row of two
 // consecutive records -- one modulus, every twiddle fetched once for both.
-// Where the shift-folded products (ntt_common.hpp kModeSplitShift) replace the limb-wise Shoup ones for launches whose moduli
+// Where the shift-folded products (ntt_common.hpp kModeFoldLazy) replace the limb-wise Shoup ones for launches whose moduli
 // are all of the form 2^b - d (DeviceContext::shift_prefix): every kernel of the 8-words-per-lane shapes at N = 4096 / 8192 --
 // plain slabs and the fused loads, both directions -- and the Q band of the row-fused ct x ct kernel (behz_kernels.hip).  Not the
 // interleaved sub-rows of N = 16384 / 32768, which measured the same either way (profiles/r05af_fold_lazy_interleaved_ab.txt).
 template <int LOGN, int LOGT>
-constexpr bool kShiftFactors = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
+constexpr bool kFoldLazyForward = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
 template <int LOGN, int LOGT, int SOURCE>
-constexpr bool kShiftFactorsInverse = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
-constexpr bool kShiftFactorsInterleaved = false;
+constexpr bool kFoldLazyInverse = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
+constexpr bool kFoldLazyInterleaved = false;
 // every modulus of a launch is of the form 2^b - d (DeviceContext::shift_prefix)
-inline bool shift_band(const DeviceContext& ctx, const RowMap& map) {
+inline bool fold_lazy_band(const DeviceContext& ctx, const RowMap& map) {
     return map.band_rows != 0 && map.mod_base + map.band_rows <= ctx.shift_prefix;
 }
 
@@ -1115,8 +1115,8 @@ hipError_t launch_interleaved_forward(int mode, uint64_t* slab, const DeviceCont
     auto kernel = mode == kModeSplit    ? ntt_forward_interleaved<LOGS, kModeSplit, SPREAD>
                   : mode == kModeApprox ? ntt_forward_interleaved<LOGS, kModeApprox, SPREAD>
                                         : ntt_forward_interleaved<LOGS, kModeExact, SPREAD>;
-    if constexpr (kShiftFactorsInterleaved) {
-        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_forward_interleaved<LOGS, kModeSplitShift, SPREAD>;
+    if constexpr (kFoldLazyInterleaved) {
+        if (mode == kModeSplit && fold_lazy_band(ctx, map)) kernel = ntt_forward_interleaved<LOGS, kModeFoldLazy, SPREAD>;
     }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
@@ -1150,13 +1150,13 @@ hipError_t launch_interleaved_inverse(int mode, uint64_t* slab, const DeviceCont
                  : mode == kModeApprox ? ntt_inverse_interleaved<LOGS, kModeApprox, false, SOURCE>
                                        : ntt_inverse_interleaved<LOGS, kModeExact, false, SOURCE>;
     }
-    if constexpr (kShiftFactorsInterleaved) {
-        if (mode == kModeSplit && shift_band(ctx, map)) {
+    if constexpr (kFoldLazyInterleaved) {
+        if (mode == kModeSplit && fold_lazy_band(ctx, map)) {
             constexpr bool ALWAYS_SCALED = SOURCE == kInverseFromTensor, NEVER_SCALED = SOURCE == kInverseFromKeyMac;
-            if constexpr (ALWAYS_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, true, SOURCE>;
-            else if constexpr (NEVER_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeSplitShift, false, SOURCE>;
-            else kernel = ctx.scaled_inverse_degree != 0 ? ntt_inverse_interleaved<LOGS, kModeSplitShift, true, SOURCE>
-                                                         : ntt_inverse_interleaved<LOGS, kModeSplitShift, false, SOURCE>;
+            if constexpr (ALWAYS_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeFoldLazy, true, SOURCE>;
+            else if constexpr (NEVER_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeFoldLazy, false, SOURCE>;
+            else kernel = ctx.scaled_inverse_degree != 0 ? ntt_inverse_interleaved<LOGS, kModeFoldLazy, true, SOURCE>
+                                                         : ntt_inverse_interleaved<LOGS, kModeFoldLazy, false, SOURCE>;
         }
     }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
@@ -1180,9 +1180,9 @@ hipError_t launch_forward_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_forward_tiled<LOGN, LOGT, kModeSplit, SPREAD, ROWS>
                   : mode == kModeApprox ? ntt_forward_tiled<LOGN, LOGT, kModeApprox, SPREAD, ROWS>
                                         : ntt_forward_tiled<LOGN, LOGT, kModeExact, SPREAD, ROWS>;
-    if constexpr (kShiftFactors<LOGN, LOGT>) {
+    if constexpr (kFoldLazyForward<LOGN, LOGT>) {
         // every modulus of the launch is just below a power of two: products folded by a shift, no quotient, no factors
-        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_forward_tiled<LOGN, LOGT, kModeSplitShift, SPREAD, ROWS>;
+        if (mode == kModeSplit && fold_lazy_band(ctx, map)) kernel = ntt_forward_tiled<LOGN, LOGT, kModeFoldLazy, SPREAD, ROWS>;
     }
     if constexpr (kFoldShape<LOGN, LOGT> && (SPREAD == kSourceSlab || SPREAD == kSourceSpread)) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {
@@ -1242,8 +1242,8 @@ hipError_t launch_inverse_kernel(int mode, uint64_t* slab, const DeviceContext& 
     auto kernel = mode == kModeSplit    ? ntt_inverse_tiled<LOGN, LOGT, SPLIT, SOURCE, ROWS>
                   : mode == kModeApprox ? ntt_inverse_tiled<LOGN, LOGT, kModeApprox, SOURCE, ROWS>
                                         : ntt_inverse_tiled<LOGN, LOGT, kModeExact, SOURCE, ROWS>;
-    if constexpr (kShiftFactorsInverse<LOGN, LOGT, SOURCE>) {
-        if (mode == kModeSplit && shift_band(ctx, map)) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeSplitShift, SOURCE, ROWS>;
+    if constexpr (kFoldLazyInverse<LOGN, LOGT, SOURCE>) {
+        if (mode == kModeSplit && fold_lazy_band(ctx, map)) kernel = ntt_inverse_tiled<LOGN, LOGT, kModeFoldLazy, SOURCE, ROWS>;
     }
     if constexpr (kFoldShape<LOGN, LOGT>) {
         if (mode == kModeApprox && ctx.forward_split_pairs != nullptr) {

@@ -45,7 +45,7 @@ __global__ void product_kernel(const uint64_t* __restrict__ operand, const uint6
     }
 }
 
-// kinds 4 / 5: fold_mul<false, false> / fold_mul<true, false> (p = 2^b - d: kModeSplitShift and kModeFoldMinus); kinds 6 / 7:
+// kinds 4 / 5: fold_mul<false, false> / fold_mul<true, false> (p = 2^b - d: kModeFoldLazy and kModeFoldMinus); kinds 6 / 7:
 // fold_mul<false, true> / fold_mul<true, true> (p = 2^60 + e: kModeFoldPlus).  The uniform kinds take constant 0 for every lane.
 template <bool UNIFORM, bool PLUS>
 __global__ void fold_kernel(const uint64_t* __restrict__ operand, const uint64_t* __restrict__ w, const uint64_t* __restrict__ wt,

@@ -1,4 +1,4 @@
-"""The arithmetic claims behind the shift-folded butterfly products (csrc/device_math.hpp fold_mul as kModeSplitShift uses it,
+"""The arithmetic claims behind the shift-folded butterfly products (csrc/device_math.hpp fold_mul as kModeFoldLazy uses it,
 csrc/ntt_common.hpp), restated limb by limb on Python integers and held at the corners the proof names:
 
     p = 2^b - d, 41 <= b <= 55, d < 2^(b-33);  y any 64-bit word = b0 + b1 2^32;  constants w < p, wt = w 2^32 mod p;

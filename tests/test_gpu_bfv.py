@@ -1001,7 +1001,7 @@ def test_key_switch_on_runs_of_butterfly_classes(oracle, degree, bits, batch):
 
 
 def test_pipelines_on_moduli_at_the_edge_of_the_shift_folded_products(oracle):
-    """ct x ct (row-fused and unfused) and relinearize with ciphertext moduli 2^b - d whose d is as large as kModeSplitShift
+    """ct x ct (row-fused and unfused) and relinearize with ciphertext moduli 2^b - d whose d is as large as kModeFoldLazy
     allows (tests/test_gpu_ntt.py _primes_below_power_of_two) -- the generated primes of every other test sit at the small end --
     and with one modulus just past the bound among them (that band then runs the limb-wise products): word for word."""
     from conftest import host_threads

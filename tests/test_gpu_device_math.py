@@ -84,7 +84,7 @@ def test_split_products_any_word(probe, p):
                 assert (0 <= r < 8 * p) if kind == 2 else (0 < r < 6 * p), (kind, hex(y), w, r // p)
 
 
-# p = 2^b - d at both ends of d < 2^(b-33) for b = 41, 47, 52, 55 (kModeSplitShift), 56 and 60 (kModeFoldMinus: d < 2^(b-33) too)
+# p = 2^b - d at both ends of d < 2^(b-33) for b = 41, 47, 52, 55 (kModeFoldLazy), 56 and 60 (kModeFoldMinus: d < 2^(b-33) too)
 FOLD_MINUS = [(1 << 41) - 1, (1 << 41) - 255, (1 << 47) - 8191, (1 << 47) - 16383, (1 << 52) - 245759, (1 << 52) - 524287,
               (1 << 55) - 55, (1 << 55) - 4087807, (1 << 55) - 4194303, (1 << 56) - 27, (1 << 56) - 8388607, (1 << 60) - 93,
               (1 << 60) - 134217727]
@@ -95,7 +95,7 @@ FOLD_PLUS = [(1 << 60) + 33, (1 << 60) + 1, (1 << 60) + (1 << 24) - 1, (1 << 60)
 @pytest.mark.parametrize("p", FOLD_MINUS + FOLD_PLUS)
 def test_folded_products_any_word(probe, p):
     """fold_mul (csrc/device_math.hpp): the product by a constant folded by a shift at 2^(b+2) (p = 2^b - d) or 2^62 (p = 2^60 + e):
-    congruent to y w and below 6p for EVERY 64-bit y -- what lets kModeSplitShift's butterflies run without a conditional
+    congruent to y w and below 6p for EVERY 64-bit y -- what lets kModeFoldLazy's butterflies run without a conditional
     subtract (tests/test_fold_product_bounds.py holds the same claims on Python integers); constants in vector registers and
     wave-uniform."""
     plus = p > (1 << 60)

@@ -395,7 +395,7 @@ def _primes_below_power_of_two(oracle, bits, degree, eligible, count=1):
 
 @pytest.mark.parametrize("degree", [4096, 8192])
 def test_shift_folded_products_at_the_edge_of_their_moduli(oracle, degree):
-    """kModeSplitShift (csrc/ntt_common.hpp): the transforms of moduli 2^b - d fold their products by a shift, which wants
+    """kModeFoldLazy (csrc/ntt_common.hpp): the transforms of moduli 2^b - d fold their products by a shift, which wants
     d < 2^(b-33).  The primes generatePrimes returns sit at the small end of d; these sit at the LARGE end (the product's
     bound 2^(b+2) + 2^33 d is nearly reached), next to primes just past the bound (limb-wise products) in the same context --
     the launch then falls back as a whole -- and alone.  Extreme words in every residue."""
