@@ -247,10 +247,12 @@ __device__ __forceinline__ TwiddleWords fetch_twiddle(const Twiddles<MODE>& tw, 
 }
 
 // How many twiddles of a pass are in flight ahead of the butterflies (forward_pass / inverse_pass): every one held costs
-// its registers (6, with shifted factors 4) under the 64-register cap of the 8-words-per-lane kernels -- two ahead lose
-// 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt).
+// its registers under the 64-register cap of the 8-words-per-lane kernels -- 6 for the limb-wise products, where two ahead lose
+// 2-12 % to scratch (profiles/r03q_ntt_twiddles_ahead.txt); 4 for the shift-folded ones, which keep three: inverse -2 % / -2 % and
+// forward 0 / -0.7 % at N = 8192 for the second and the third (profiles/r05ad_fold_lazy_butterflies_ab.txt,
+// r05ap_twiddles_in_flight_ab.txt).
 template <int MODE>
-constexpr int kTwiddlesAhead = MODE == kModeFoldLazy ? 2 : 1;
+constexpr int kTwiddlesAhead = MODE == kModeFoldLazy ? 3 : 1;
 // ... and of the row groups of three and four (behz_kernels.hip: one workgroup per CU at 128 registers per lane -- there are
 // registers for deeper requests, and with 4 wavefronts per SIMD less else to hide a gather's latency)
 constexpr int kWideGroupTwiddlesAhead = 1;

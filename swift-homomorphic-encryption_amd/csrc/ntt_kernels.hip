@@ -261,9 +261,12 @@ struct InverseSource {
 };
 
 // How many twiddles of the first (gather-heavy) pass are requested before the rows are loaded and then kept in flight
-// through that pass (inverse_row_head).  1: the first one only, requested once the rows are in (the schedule of rounds 2-3).
+// through that pass (inverse_row_head).  1: the first one only, requested once the rows are in (the schedule of rounds 2-3, and
+// of every limb-wise kernel: their twiddles are 6 registers each).  The plain-slab transform on the shift-folded products
+// (4 registers per twiddle, 62 of its 64 in use) takes three: -2.9 % at N = 8192 (two: -2.0 %; four spill: +7.7 %;
+// profiles/r05ao_inverse_head_twiddles_ab.txt) -- with no gathers at all the kernel would be 12 % faster (r05an).
 template <int LOGN, int LOGE, int MODE, int SOURCE, int ROWS>
-constexpr int kInverseHeadTwiddles = 1;
+constexpr int kInverseHeadTwiddles = (MODE == kModeFoldLazy && SOURCE == 0) ? 3 : 1;
 
 template <int LOGN, int LOGT, int MODE, int SOURCE = kInverseFromSlab, int ROWS = 1>
 __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROWS))
