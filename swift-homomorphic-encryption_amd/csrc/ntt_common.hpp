@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    generatePrimes(preferringSmall: false) returns, i.e. every parameter set of the reference), with the
 //                    product FOLDED BY A SHIFT at 2^(b+2) = 4d (mod p) instead of reduced by an estimated quotient
 //                    (device_math.hpp fold_mul, the fold modes' product): 5 multiply-adds instead of 8, no factor table -- a
-//                    gathered twiddle is its 16 bytes (w, w 2^32 mod p), 4 registers instead of 6, so two of them are kept
+//                    gathered twiddle is its 16 bytes (w, w 2^32 mod p), 4 registers instead of 6, so three of them are kept
 //                    in flight (kTwiddlesAhead) -- products below 2^(b+2) + 2^33 d < 6p for ANY 64-bit multiplicand, hence the
 //                    same bounds as kModeSplit's [0, 8p).  Round 5: forward -3.4 %, inverse -9 % at N = 8192, -3 % / -5.5 % at
 //                    N = 4096, relinearize +4 % (profiles/r05ad_fold_lazy_butterflies_ab.txt).  (Rounds 3-4 had a kModeSplitShift in this
