@@ -14,9 +14,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "swift-homomorphic-encryption_amd"))
 
 
+class Timing(float):
+    """Seconds per call (the mean over the back-to-back timed calls) that also carries the spread of the single calls."""
+
+    spread = None  # {"calls", "min_ms", "median_ms", "max_ms"}: device time between the events either side of each call
+    per_call_ms = None
+    host_enqueue_ms = None  # host time each call took to return (a blocking allocation shows here)
+
+
 def _timed(torch, fn, reps, warmup=2, settle_s=0.03):
     """Seconds per call.  The first calls after another kernel mix run at whatever clocks that mix left behind (N=4096
-    NTTs measured 18 % slow over 12 launches): warm up for at least `settle_s` of GPU time, and time at least as long."""
+    NTTs measured 18 % slow over 12 launches): warm up for at least `settle_s` of GPU time, and time at least as long.
+    The calls are enqueued back to back with one event between each pair: the result is the mean, its `.spread` the
+    minimum / median / maximum of the single calls -- a one-off stall inside the timed region shows as max >> median
+    instead of hiding in the mean."""
     import time
 
     for _ in range(warmup):
@@ -29,14 +40,22 @@ def _timed(torch, fn, reps, warmup=2, settle_s=0.03):
         extra += 1
     per_call = (time.perf_counter() - begin) / max(extra, 1)
     reps = max(reps, int(2 * settle_s / max(per_call, 1e-6)))
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    host = []
     torch.cuda.synchronize()
-    start.record()
-    for _ in range(reps):
+    events[0].record()
+    for i in range(reps):
+        t0 = time.perf_counter()
         fn()
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / reps
+        host.append((time.perf_counter() - t0) * 1e3)
+        events[i + 1].record()
+    events[-1].synchronize()
+    calls = [events[i].elapsed_time(events[i + 1]) for i in range(reps)]
+    ordered = sorted(calls)
+    result = Timing(events[0].elapsed_time(events[-1]) * 1e-3 / reps)
+    result.per_call_ms, result.host_enqueue_ms = calls, host
+    result.spread = {"calls": reps, "min_ms": ordered[0], "median_ms": ordered[reps // 2], "max_ms": ordered[-1]}
+    return result
 
 
 def _uniform(torch, moduli, prefix, degree, seed):
@@ -68,7 +87,8 @@ def config1_ntt(torch, heamd, batch=8192, reps=10, degree=4096, moduli_count=2):
     forward = _timed(torch, lambda: ctx.forward_ntt_(x), reps)
     inverse = _timed(torch, lambda: ctx.inverse_ntt_(x), reps)
     bytes_per_poly = 2 * moduli_count * degree * 8
-    return {"batch": batch, "forward_poly_ntt_per_s": batch / forward, "inverse_poly_ntt_per_s": batch / inverse,
+    return {"batch": batch, "spread_ms": {"forward": forward.spread, "inverse": inverse.spread},
+            "forward_poly_ntt_per_s": batch / forward, "inverse_poly_ntt_per_s": batch / inverse,
             "forward_GBps": bytes_per_poly * batch / forward / 1e9, "inverse_GBps": bytes_per_poly * batch / inverse / 1e9,
             "forward_frac_of_8TBps": bytes_per_poly * batch / forward / 8e12,
             "inverse_frac_of_8TBps": bytes_per_poly * batch / inverse / 8e12}
@@ -103,6 +123,7 @@ def config3_ct_mul(torch, heamd, batch=1024, reps=5):
     compulsory = 1_572_864  # read 2 cts x 2 polys + write 2 polys
     return {
         "batch": batch,
+        "spread_ms": {"ct_mul": t_mul.spread, "relinearize": t_relin.spread, "ct_mul_relinearize": t_both.spread},
         "ct_mul_per_s": batch / t_mul,
         "relinearize_per_s": batch / t_relin,
         "ct_mul_relinearize_per_s": batch / t_both,
@@ -124,7 +145,7 @@ def config4_mod_switch(torch, heamd, batch=8192, reps=5):
     t = _timed(torch, lambda: ctx.divide_and_round_q_last(x), reps)
     bytes_per_poly = (6 + 5) * degree * 8
     measured = (_profiled("c4_mod_switch") or {}).get("hbm_bytes_per_unit")
-    return {"batch": batch, "poly_per_s": batch / t, "GBps": bytes_per_poly * batch / t / 1e9,
+    return {"batch": batch, "spread_ms": t.spread, "poly_per_s": batch / t, "GBps": bytes_per_poly * batch / t / 1e9,
             "frac_of_8TBps": bytes_per_poly * batch / t / 8e12,
             "traffic_GBps": measured * batch / t / 1e9 if measured else None}
 
@@ -151,6 +172,7 @@ def config5_inner_product(torch, heamd, count=256, columns=64, reps=3, queries=1
     db_bytes = macs * 4 * degree * 8
     measured = (_profiled("c5_inner_product_plain") or {}).get("hbm_bytes_per_unit") if queries == 1 else None
     return {"count": count, "columns": columns, "queries": queries, "masked": masked, "packed": packed,
+            "spread_ms": t.spread,
             "ct_pt_mac_per_s": queries * macs / t,
             "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12,
             "traffic_GBps": measured * macs / t / 1e9 if measured else None}
@@ -169,7 +191,7 @@ def config5_pir_chunk(torch, heamd, d0=256, d1=64, reps=3):
     key = _uniform(torch, q, (ctx.L, 2), degree, 10)
     t = _timed(torch, lambda: ctx.pir_compute_response_chunk([d0, d1], dim0, rest, database, None, key), reps)
     db_bytes = d0 * d1 * 4 * degree * 8
-    return {"dimensions": [d0, d1], "database_GB": db_bytes / 1e9, "chunk_response_ms": t * 1e3,
+    return {"dimensions": [d0, d1], "database_GB": db_bytes / 1e9, "chunk_response_ms": t * 1e3, "spread_ms": t.spread,
             "chunk_responses_per_s": 1 / t, "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12}
 
 
@@ -187,6 +209,7 @@ def config5_pir_chunk_loop(torch, heamd, d0=256, d1=64, chunks=8, reps=3):
     t = _timed(torch, lambda: ctx.pir_compute_response([d0, d1], dim0, rest, database, chunks, relinearization_key=key), reps)
     db_bytes = chunks * d0 * d1 * 4 * degree * 8
     return {"dimensions": [d0, d1], "chunks": chunks, "database_GB": db_bytes / 1e9, "ms_per_chunk": t / chunks * 1e3,
+            "spread_ms": t.spread,
             "chunk_responses_per_s": chunks / t, "database_GBps": db_bytes / t / 1e9, "frac_of_8TBps": db_bytes / t / 8e12}
 
 
@@ -203,7 +226,8 @@ def config5_pir_queries(torch, heamd, d0=256, d1=64, chunks=8, queries=4, reps=3
     keys = [_uniform(torch, q, (ctx.L, 2), degree, 10 + i) for i in range(queries)]
     t = _timed(torch, lambda: ctx.pir_compute_response_queries([d0, d1], dim0, rest, database, chunks, keys), reps)
     db_bytes = chunks * d0 * d1 * 4 * degree * 8
-    return {"dimensions": [d0, d1], "chunks": chunks, "queries": queries, "ms_per_chunk_per_query": t / chunks / queries * 1e3,
+    return {"dimensions": [d0, d1], "chunks": chunks, "queries": queries, "spread_ms": t.spread,
+            "ms_per_chunk_per_query": t / chunks / queries * 1e3,
             "chunk_responses_per_s": chunks * queries / t, "database_GBps_per_query_share": db_bytes * queries / t / 1e9}
 
 
@@ -222,38 +246,44 @@ def config5_pir_whole_query(torch, heamd, d0=256, d1=64, chunks=8, indices=1, re
     relin = _uniform(torch, q, (ctx.L, 2), degree, 10)
     database = _uniform(torch, moduli, (chunks, d0 * d1), degree, 9)
     t = _timed(torch, lambda: ctx.pir_compute_response_to_query([d0, d1], query, indices, galois, relin, database, chunks),
-               reps)
+               max(reps, 30))
     return {"dimensions": [d0, d1], "chunks": chunks, "indices": indices, "ms_per_query": t * 1e3,
+            "ms_per_query_min": t.spread["min_ms"], "ms_per_query_median": t.spread["median_ms"],
+            "ms_per_query_max": t.spread["max_ms"], "calls": t.spread["calls"],
+            "per_call_ms": [round(x, 3) for x in t.per_call_ms], "host_enqueue_ms": [round(x, 3) for x in t.host_enqueue_ms],
             "ms_per_index": t / indices * 1e3, "chunk_responses_per_s": chunks * indices / t}
 
 
-def run_all(quick=False):
+def run_all(quick=False, only=None):
+    """Every leg, in the order bench.py reports them; `only`: the names of the legs to run."""
     import torch
 
     import heamd
 
+    heamd.set_scratch_cache()  # a server's setting: the library keeps its released scratch (he_set_scratch_cache)
 
-    heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
-
-    out = {}
-    out["config1_ntt_n4096_l2"] = config1_ntt(torch, heamd, batch=1024 if quick else 8192)
-    out["ntt_n16384_l4"] = config1_ntt(torch, heamd, batch=256 if quick else 1024, degree=16384, moduli_count=4)
-    out["config3_ct_mul"] = config3_ct_mul(torch, heamd, batch=256 if quick else 1024)
-    out["config4_mod_switch"] = config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)
-    # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)
-    out["config5_inner_product_1gpu"] = config5_inner_product(torch, heamd, count=64 if quick else 1024,
-                                                              columns=16 if quick else 128)
-    out["config5_pir_chunk_response_1gpu"] = config5_pir_chunk(torch, heamd, d0=64 if quick else 256,
-                                                                d1=16 if quick else 64)
-    out["config5_pir_chunk_loop_1gpu"] = config5_pir_chunk_loop(torch, heamd, d0=64 if quick else 256,
-                                                                d1=16 if quick else 64, chunks=2 if quick else 8)
-    # four queries that share one pass over the same database (not a BASELINE line: the reference answers one at a time)
-    out["config5_pir_4_queries_1gpu"] = config5_pir_queries(torch, heamd, d0=64 if quick else 256, d1=16 if quick else 64,
-                                                            chunks=2 if quick else 8, queries=4)
-    out["config5_pir_whole_query_1gpu"] = config5_pir_whole_query(torch, heamd, d0=64 if quick else 256,
-                                                                  d1=16 if quick else 64, chunks=2 if quick else 8, indices=1)
-    return out
+    legs = [
+        ("config1_ntt_n4096_l2", lambda: config1_ntt(torch, heamd, batch=1024 if quick else 8192)),
+        ("ntt_n16384_l4", lambda: config1_ntt(torch, heamd, batch=256 if quick else 1024, degree=16384, moduli_count=4)),
+        ("config3_ct_mul", lambda: config3_ct_mul(torch, heamd, batch=256 if quick else 1024)),
+        ("config4_mod_switch", lambda: config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)),
+        # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)
+        ("config5_inner_product_1gpu", lambda: config5_inner_product(torch, heamd, count=64 if quick else 1024,
+                                                                     columns=16 if quick else 128)),
+        ("config5_pir_chunk_response_1gpu", lambda: config5_pir_chunk(torch, heamd, d0=64 if quick else 256,
+                                                                      d1=16 if quick else 64)),
+        ("config5_pir_chunk_loop_1gpu", lambda: config5_pir_chunk_loop(torch, heamd, d0=64 if quick else 256,
+                                                                       d1=16 if quick else 64, chunks=2 if quick else 8)),
+        # four queries that share one pass over the same database (not a BASELINE line: the reference answers one at a time)
+        ("config5_pir_4_queries_1gpu", lambda: config5_pir_queries(torch, heamd, d0=64 if quick else 256,
+                                                                   d1=16 if quick else 64, chunks=2 if quick else 8, queries=4)),
+        ("config5_pir_whole_query_1gpu", lambda: config5_pir_whole_query(torch, heamd, d0=64 if quick else 256,
+                                                                         d1=16 if quick else 64, chunks=2 if quick else 8,
+                                                                         indices=1)),
+    ]
+    return {name: leg() for name, leg in legs if only is None or name in only}
 
 
 if __name__ == "__main__":
-    print(json.dumps(run_all("--quick" in sys.argv), indent=1))
+    chosen = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")]
+    print(json.dumps(run_all("--quick" in sys.argv, only=chosen[0] if chosen else None), indent=1))

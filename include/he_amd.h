@@ -85,13 +85,18 @@ int he_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes, he_strea
 int he_stream_synchronize(he_stream stream);
 int he_stream_create(he_stream* out);   /* a non-blocking HIP stream */
 int he_stream_destroy(he_stream stream);
-/* Scratch of the `_device` calls that take no workspace comes stream-ordered from a memory pool the library owns (one per
- * device, never the process's default pool).  By default nothing is retained: freed scratch returns to the driver at the
- * next synchronisation.  he_set_scratch_cache(bytes) lets the current device's pool keep up to `bytes` of freed scratch
- * (UINT64_MAX: everything) -- what a server that expands queries sets once, because mapping tens of gigabytes per call
- * costs seconds; he_device_trim_scratch(keep_bytes) hands everything above `keep_bytes` back. */
+/* Scratch of the `_device` calls that take no workspace is stream-ordered and the library's own (never the process's
+ * default pool).  By default nothing is retained: it comes from a HIP memory pool with release threshold 0 and returns to the
+ * driver at the next synchronisation -- and, a property of hipFreeAsync in ROCm 7.2, a call that took scratch returns only
+ * once the work enqueued before the previous release of that scratch has finished.  he_set_scratch_cache(bytes) switches the
+ * current device to a block cache inside the library that keeps up to `bytes` of released scratch (UINT64_MAX: everything):
+ * a stream gets the blocks it released back without any driver call, another stream after an event wait, and the `_device`
+ * calls are enqueue-only.  What a server sets once (mapping tens of gigabytes per expansion costs seconds otherwise);
+ * he_device_trim_scratch(keep_bytes) hands everything above `keep_bytes` back; he_scratch_cached_bytes reads what is held.
+ * While a stream is being captured into a graph its scratch always comes from the HIP pool (allocation nodes). */
 int he_set_scratch_cache(uint64_t bytes);
 int he_device_trim_scratch(uint64_t keep_bytes);
+int he_scratch_cached_bytes(uint64_t* out_bytes);
 
 /* ---- completion primitives: what the reference's `...Async` twins (HomomorphicEncryption/HeSchemeAsync.swift:16-141)
  * await.  A Swift `async` wrapper enqueues the `_device` call and then either suspends in a continuation resumed by
@@ -243,9 +248,12 @@ size_t he_bfv_mul_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_cou
 size_t he_bfv_relinearize_workspace_bytes(const he_bfv_context* ctx, uint32_t moduli_count, size_t batch);
 
 /* Bfv.mulAssign(_: inout CanonicalCiphertext, _: CanonicalCiphertext) = multiplyWithoutScaling + dropExtendedBase
- * (Bfv/Bfv+Multiply.swift:18-85).  lhs, rhs: [batch][2][L][N] Coeff; out: [batch][3][L][N] Coeff.  Enqueue-only on `s` as seen
+ * (Bfv/Bfv+Multiply.swift:18-85).  lhs, rhs: [batch][2][L][N] Coeff; out: [batch][3][L][N] Coeff, overlapping neither
+ * operand (HE_ERR_INVALID_ARGUMENT: parts of the batch are stored while others are still read).  Enqueue-only on `s` as seen
  * from the caller: large batches also run part of the pipeline on a second stream the context owns, forked off `s` and joined
- * back into `s` by events before the call returns (not while `s` is being captured into a graph). */
+ * back into `s` by events before the call returns (not while `s` is being captured into a graph).  The context keeps up to 8
+ * such streams and gives each caller stream the one it used last, so calls on different streams do not queue behind one
+ * another's backlog; a call that finds all of them taken runs entirely on `s`. */
 int he_bfv_mul_device(const he_bfv_context* ctx, uint32_t moduli_count, const uint64_t* lhs, const uint64_t* rhs,
                       uint64_t* out, size_t batch, void* workspace, size_t workspace_bytes, he_stream s);
 /* Bfv.relinearize (Bfv/Bfv.swift:201-219) via _computeKeySwitchingUpdate (Bfv/Bfv+Keys.swift:123-208).

@@ -32,12 +32,13 @@ inline int invalid_argument(const char* what) {
     return HE_ERR_INVALID_ARGUMENT;
 }
 
-// Stream-ordered scratch comes from a memory pool the LIBRARY owns (one per device, created on first use; c_api.cpp) --
-// never from the device's default pool, which belongs to the host process and its other HIP users.  The pool's release
-// threshold is 0 unless the host opts in with he_set_scratch_cache(bytes): freed scratch then goes back to the driver at
-// the next synchronisation.  A server that expands queries (tens of gigabytes of scratch per call) sets the threshold
-// once and gives memory back with he_device_trim_scratch.
+// Stream-ordered scratch (c_api.cpp): from a memory pool the LIBRARY owns (one per device, release threshold 0 -- never the
+// device's default pool, which belongs to the host process and its other HIP users) until the host opts in with
+// he_set_scratch_cache(bytes); from then on from the library's own block cache, which hands a stream the blocks it released
+// without a driver call.  scratch_release is the only way a block goes back.
 hipError_t scratch_allocate(void** out, size_t bytes, hipStream_t stream);
+void scratch_release(void* ptr, hipStream_t stream);
+void scratch_forget_stream(hipStream_t stream);
 
 // The recursion tree of PirUtil.expand for one (ciphertext count, output count) on one ring: the data movement of every
 // level (pir_api.cpp).  Planned on the first use, kept by the context with its table on the device, so that later
@@ -87,12 +88,12 @@ int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t*
                           const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
                           hipStream_t stream, const uint64_t* rotated = nullptr);
 
-// Stream-ordered scratch buffer (scratch_allocate / hipFreeAsync on the same stream).
+// Stream-ordered scratch buffer (scratch_allocate / scratch_release on the same stream).
 class Scratch {
   public:
     explicit Scratch(hipStream_t stream) : stream_(stream) {}
     ~Scratch() {
-        if (ptr_ != nullptr) (void)hipFreeAsync(ptr_, stream_);
+        if (ptr_ != nullptr) scratch_release(ptr_, stream_);
     }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;

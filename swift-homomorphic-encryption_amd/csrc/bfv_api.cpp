@@ -10,6 +10,7 @@
 #include "bfv_context.hpp"
 #include "kernels.hpp"
 #include "rns_kernels.hpp"
+#include "side_lane.hpp"
 
 using heamd::as_stream;
 using heamd::BfvContext;
@@ -18,55 +19,19 @@ using heamd::invalid_argument;
 using heamd::PolyContext;
 using heamd::RnsToolLevel;
 using heamd::Scratch;
-
-// A second stream of the context's own, forked off the caller's stream and joined back inside ONE call (events on both
-// sides): work of a pipeline that does not depend on its neighbour runs beside it.  Created on first use, never synchronised;
-// calls that use it enqueue under its mutex, so that an event is always waited for by the call that recorded it.
-struct SideLane {
-    std::mutex mutex;
-    static constexpr int kStages = 4;
-    hipStream_t stream = nullptr;
-    hipEvent_t forked = nullptr, joined = nullptr;
-    hipEvent_t stage[kStages] = {};  // the caller's stream has reached a point the lane's next piece of work depends on
-    ~SideLane() {
-        if (forked != nullptr) (void)hipEventDestroy(forked);
-        if (joined != nullptr) (void)hipEventDestroy(joined);
-        for (hipEvent_t e : stage)
-            if (e != nullptr) (void)hipEventDestroy(e);
-        if (stream != nullptr) (void)hipStreamDestroy(stream);
-    }
-    // (under the mutex)
-    hipError_t ensure() {
-        if (stream != nullptr) return hipSuccess;
-        hipStream_t s = nullptr;
-        hipEvent_t made[2 + kStages] = {};
-        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-        for (hipEvent_t& event : made)
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&event, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            for (hipEvent_t event : made)
-                if (event != nullptr) (void)hipEventDestroy(event);
-            if (s != nullptr) (void)hipStreamDestroy(s);
-            return e;
-        }
-        stream = s;
-        forked = made[0];
-        joined = made[1];
-        for (int k = 0; k < kStages; ++k) stage[k] = made[2 + k];
-        return hipSuccess;
-    }
-};
+using heamd::SideLane;
 
 struct he_bfv_context {
     std::unique_ptr<BfvContext> impl;
     // non-owning he_poly_context views handed out by he_bfv_*_context(), index = ciphertext moduli count
     std::vector<std::unique_ptr<he_poly_context>> ciphertext, key_switching, qbsk;
     mutable heamd::ExpandPlanCache expand_plans;  // PirUtil.expand shapes seen so far (api_internal.hpp)
-    mutable SideLane side;                         // mul_rows_fused: the Q band of ct x ct beside the lift
+    mutable heamd::LanePool lanes;                 // side_lane.hpp: streams for work of one call that runs beside its neighbour
 };
 
 namespace heamd {
 ExpandPlanCache& expand_plans(const he_bfv_context* ctx) { return ctx->expand_plans; }
+LanePool& lane_pool(const he_bfv_context* ctx) { return ctx->lanes; }
 }  // namespace heamd
 
 namespace {
@@ -252,17 +217,12 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
     // The row bands that read the ciphertexts themselves (the Q rows) do not depend on the lift: on the context's side lane they
     // run beside it -- a 128-register row-fused workgroup leaves room on its CU for the lift's 256-lane workgroups of 40
     // registers (ct x ct +2.6 %, profiles/r05v_behz_q_band_beside_lift_ab.txt).  From four workgroup generations of Q rows up;
-    // not while the caller's stream is being captured into a graph (the lane is shared by the context's callers).
+    // not while the caller's stream is being captured into a graph, nor when every lane of the context is leased
+    // (side_lane.hpp).
     if (kBehzCiphertextRowsBesideLift && batch * L >= 1024) {
-        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
-            (void)hipGetLastError();
-            capture = hipStreamCaptureStatusActive;  // (the legacy default stream cannot be queried: stay on it)
-        }
-        if (capture == hipStreamCaptureStatusNone) {
-            SideLane& lane = ctx->side;
-            std::lock_guard<std::mutex> lock(lane.mutex);
-            HEAMD_HIP_TRY(lane.ensure());
+        heamd::LaneLease lease(heamd::lane_pool(ctx), stream);
+        if (lease.lane != nullptr) {
+            SideLane& lane = *lease.lane;
             HEAMD_HIP_TRY(hipEventRecord(lane.forked, stream));
             HEAMD_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.forked, 0));
             hipError_t e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, lane.stream,
@@ -632,6 +592,17 @@ int mul_entry(const he_bfv_context* ctx, uint32_t moduli_count, const W* lhs, co
     if (sizeof(W) == 4 && ctx->impl->word_bits() != 32) return invalid_argument("4-byte slabs need a Bfv<UInt32> context");
     if (batch == 0) return HE_OK;
     if (lhs == nullptr || rhs == nullptr || out == nullptr) return invalid_argument("null ciphertext");
+    {
+        // out must not overlap lhs or rhs: with the batch in parts, one part's floor stores its products while another
+        // part's row band still reads the operands -- whether that happens depends on the batch size and the moduli, so an
+        // overlap would be right for some shapes and silently wrong for others
+        const size_t words = size_t(moduli_count) * ctx->impl->degree();
+        const uintptr_t out_begin = reinterpret_cast<uintptr_t>(out), out_end = out_begin + batch * 3 * words * sizeof(W);
+        for (const W* operand : {lhs, rhs}) {
+            const uintptr_t begin = reinterpret_cast<uintptr_t>(operand), end = begin + batch * 2 * words * sizeof(W);
+            if (out_begin < end && begin < out_end) return invalid_argument("ct x ct: out overlaps an operand");
+        }
+    }
     return mul_pipeline(ctx, tool, moduli_count, lhs, rhs, out, batch, workspace, workspace_bytes, as_stream(s));
 }
 }  // namespace

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -91,27 +92,47 @@ int elementwise(const he_poly_context* ctx, heamd::ElementwiseOp op, uint64_t* l
 
 }  // namespace
 
-// ---- the library's own scratch pools (api_internal.hpp scratch_allocate) ----
+// ---- scratch (api_internal.hpp scratch_allocate / scratch_release) ----------------------------------------------------
+// Two sources, per device:
+//  * a HIP memory pool the library creates (release threshold 0): what scratch comes from while the host has not asked for a
+//    cache, and always while the stream is being captured into a graph (allocation and free become graph nodes);
+//  * the library's own stream-ordered block cache, once he_set_scratch_cache(bytes > 0) was called: blocks from hipMalloc,
+//    kept on a free list with the stream they were released on and an event recorded there.  A later request on the SAME
+//    stream takes a block without any driver call (stream order makes it safe); a request on another stream first makes that
+//    stream wait for the block's event.  Why not the HIP pool with a high release threshold: hipFreeAsync of ROCm 7.2 holds
+//    the calling thread until the work enqueued before the PREVIOUS release of that block has finished
+//    (bench_tools/pool_probe.hip, profiles/r06b_pool_probe.txt: 106 ms kernels, every free from the second cycle on returns
+//    after 106 ms) -- every call that takes scratch would return one call late instead of being enqueue-only.
 namespace {
 constexpr int kMaxDevices = 64;
-struct ScratchPools {
-    std::mutex mutex;
-    hipMemPool_t pool[kMaxDevices] = {};
-    bool failed[kMaxDevices] = {};  // pool creation refused: fall back to the default pool, untouched
-    uint64_t threshold[kMaxDevices] = {};
+struct CachedBlock {
+    void* ptr;
+    size_t bytes;
+    hipStream_t stream;  // released on
+    hipEvent_t freed;    // recorded on `stream` at the release
+    uint64_t tick;
 };
-ScratchPools& scratch_pools() {
-    static ScratchPools* pools = new ScratchPools();  // never destroyed: HIP may already be gone at exit
-    return *pools;
+struct ScratchState {
+    std::mutex mutex;
+    hipMemPool_t pool = nullptr;
+    bool pool_failed = false;  // pool creation refused: fall back to the default pool, untouched
+    uint64_t limit = 0;        // he_set_scratch_cache: bytes of released scratch the block cache may keep; 0 = cache off
+    size_t cached_bytes = 0;
+    uint64_t tick = 0;
+    std::vector<CachedBlock> free_blocks;
+    std::map<void*, size_t> lent;  // blocks of the cache that are in use -> their size
+    std::vector<hipEvent_t> spare_events;
+};
+ScratchState& scratch_state(int device) {
+    static ScratchState* states = new ScratchState[kMaxDevices];  // never destroyed: HIP may already be gone at exit
+    return states[device];
 }
-// the current device's pool, or nullptr
-hipMemPool_t scratch_pool(int* device_out = nullptr) {
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return nullptr;
-    if (device_out != nullptr) *device_out = device;
-    ScratchPools& pools = scratch_pools();
-    std::lock_guard<std::mutex> lock(pools.mutex);
-    if (pools.pool[device] == nullptr && !pools.failed[device]) {
+bool current_device(int* device) {
+    return hipGetDevice(device) == hipSuccess && *device >= 0 && *device < kMaxDevices;
+}
+// (under the state's mutex) the device's HIP pool, or nullptr
+hipMemPool_t hip_pool_locked(ScratchState& state, int device) {
+    if (state.pool == nullptr && !state.pool_failed) {
         hipMemPoolProps props = {};
         props.allocType = hipMemAllocationTypePinned;
         props.handleTypes = hipMemHandleTypeNone;
@@ -119,21 +140,146 @@ hipMemPool_t scratch_pool(int* device_out = nullptr) {
         props.location.id = device;
         hipMemPool_t pool = nullptr;
         if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool != nullptr) {
-            uint64_t threshold = pools.threshold[device];
+            uint64_t threshold = 0;
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
-            pools.pool[device] = pool;
+            state.pool = pool;
         } else {
-            pools.failed[device] = true;
+            state.pool_failed = true;
         }
         (void)hipGetLastError();
     }
-    return pools.pool[device];
+    return state.pool;
+}
+bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();  // the legacy default stream cannot be queried -- nor captured
+        return false;
+    }
+    return capture != hipStreamCaptureStatusNone;
+}
+size_t block_size(size_t bytes) {
+    const size_t grain = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(64) << 10);
+    return (bytes + grain - 1) / grain * grain;
+}
+// (under the mutex) gives cached blocks whose release has completed back to the driver, oldest first, until at most `keep`
+// bytes stay cached; blocks still in flight stay.  hipFree may wait for the device: only trims and over-limit releases
+// come here.
+void evict_locked(ScratchState& state, size_t keep) {
+    while (state.cached_bytes > keep) {
+        size_t pick = state.free_blocks.size();
+        for (size_t i = 0; i < state.free_blocks.size(); ++i) {
+            if (hipEventQuery(state.free_blocks[i].freed) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;
+            }
+            if (pick == state.free_blocks.size() || state.free_blocks[i].tick < state.free_blocks[pick].tick) pick = i;
+        }
+        if (pick == state.free_blocks.size()) return;
+        CachedBlock block = state.free_blocks[pick];
+        state.free_blocks.erase(state.free_blocks.begin() + static_cast<long>(pick));
+        state.cached_bytes -= block.bytes;
+        state.spare_events.push_back(block.freed);
+        (void)hipFree(block.ptr);
+    }
 }
 }  // namespace
 
+// he_stream_destroy: a later stream may get the same handle -- the blocks released on this one no longer count as released
+// on "the same stream" (their events still order them)
+void heamd::scratch_forget_stream(hipStream_t stream) {
+    if (stream == nullptr) return;
+    int device = 0;
+    if (!current_device(&device)) return;
+    ScratchState& state = scratch_state(device);
+    std::lock_guard<std::mutex> lock(state.mutex);
+    for (CachedBlock& block : state.free_blocks)
+        if (block.stream == stream) block.stream = reinterpret_cast<hipStream_t>(~uintptr_t(0));
+}
+
 hipError_t heamd::scratch_allocate(void** out, size_t bytes, hipStream_t stream) {
-    if (hipMemPool_t pool = scratch_pool(); pool != nullptr) return hipMallocFromPoolAsync(out, bytes, pool, stream);
-    return hipMallocAsync(out, bytes, stream);
+    int device = 0;
+    if (!current_device(&device)) return hipMallocAsync(out, bytes, stream);
+    ScratchState& state = scratch_state(device);
+    std::unique_lock<std::mutex> lock(state.mutex);
+    if (state.limit == 0 || stream_is_capturing(stream)) {
+        hipMemPool_t pool = hip_pool_locked(state, device);
+        lock.unlock();
+        return pool != nullptr ? hipMallocFromPoolAsync(out, bytes, pool, stream) : hipMallocAsync(out, bytes, stream);
+    }
+    const size_t want = block_size(bytes);
+    // the smallest cached block that holds the request without wasting more than half of itself; one released on this very
+    // stream first (no wait), then any other
+    size_t pick = state.free_blocks.size();
+    for (size_t i = 0; i < state.free_blocks.size(); ++i) {
+        const CachedBlock& b = state.free_blocks[i];
+        if (b.bytes < want || b.bytes > 2 * want) continue;
+        if (pick == state.free_blocks.size()) {
+            pick = i;
+            continue;
+        }
+        const CachedBlock& best = state.free_blocks[pick];
+        const bool same = b.stream == stream, best_same = best.stream == stream;
+        if (same != best_same ? same : b.bytes < best.bytes) pick = i;
+    }
+    if (pick != state.free_blocks.size()) {
+        CachedBlock block = state.free_blocks[pick];
+        if (block.stream != stream) {
+            const hipError_t e = hipStreamWaitEvent(stream, block.freed, 0);
+            if (e != hipSuccess) return e;
+        }
+        state.free_blocks.erase(state.free_blocks.begin() + static_cast<long>(pick));
+        state.cached_bytes -= block.bytes;
+        state.spare_events.push_back(block.freed);
+        state.lent[block.ptr] = block.bytes;
+        *out = block.ptr;
+        return hipSuccess;
+    }
+    void* ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipErrorOutOfMemory) {  // the cache itself may be what fills the device
+        (void)hipGetLastError();
+        evict_locked(state, 0);
+        e = hipMalloc(&ptr, want);
+    }
+    if (e != hipSuccess) return e;
+    state.lent[ptr] = want;
+    *out = ptr;
+    return hipSuccess;
+}
+
+void heamd::scratch_release(void* ptr, hipStream_t stream) {
+    if (ptr == nullptr) return;
+    int device = 0;
+    if (current_device(&device)) {
+        ScratchState& state = scratch_state(device);
+        std::lock_guard<std::mutex> lock(state.mutex);
+        auto it = state.lent.find(ptr);
+        if (it != state.lent.end()) {
+            const size_t bytes = it->second;
+            state.lent.erase(it);
+            hipEvent_t event = nullptr;
+            if (!state.spare_events.empty()) {
+                event = state.spare_events.back();
+                state.spare_events.pop_back();
+            } else if (hipEventCreateWithFlags(&event, hipEventDisableTiming) != hipSuccess) {
+                event = nullptr;
+            }
+            if (event == nullptr || hipEventRecord(event, stream) != hipSuccess) {
+                // no way to tell when the block is free again: wait for the stream, then hand it back
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(stream);
+                (void)hipFree(ptr);
+                if (event != nullptr) state.spare_events.push_back(event);
+                return;
+            }
+            state.free_blocks.push_back(CachedBlock{ptr, bytes, stream, event, ++state.tick});
+            state.cached_bytes += bytes;
+            if (state.cached_bytes > state.limit) evict_locked(state, static_cast<size_t>(state.limit));
+            return;
+        }
+    }
+    (void)hipFreeAsync(ptr, stream);  // from the HIP pool
 }
 
 extern "C" {
@@ -187,22 +333,33 @@ int he_set_device(int device) {
 
 int he_set_scratch_cache(uint64_t bytes) {
     int device = 0;
-    hipMemPool_t pool = scratch_pool(&device);
-    if (pool == nullptr) {
-        heamd::set_last_error("no library scratch pool on this device");
+    if (!current_device(&device)) {
+        heamd::set_last_error("no current device");
         return HE_ERR_DEVICE;
     }
-    ScratchPools& pools = scratch_pools();
-    std::lock_guard<std::mutex> lock(pools.mutex);
-    uint64_t threshold = bytes;
-    HEAMD_HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
-    pools.threshold[device] = bytes;
+    ScratchState& state = scratch_state(device);
+    std::lock_guard<std::mutex> lock(state.mutex);
+    state.limit = bytes;
+    if (state.cached_bytes > bytes) evict_locked(state, static_cast<size_t>(bytes));
     return HE_OK;
 }
 int he_device_trim_scratch(uint64_t keep_bytes) {
-    hipMemPool_t pool = scratch_pool();
-    if (pool == nullptr) return HE_OK;  // nothing cached
-    HEAMD_HIP_TRY(hipMemPoolTrimTo(pool, static_cast<size_t>(keep_bytes)));
+    int device = 0;
+    if (!current_device(&device)) return HE_OK;
+    ScratchState& state = scratch_state(device);
+    std::lock_guard<std::mutex> lock(state.mutex);
+    evict_locked(state, static_cast<size_t>(keep_bytes));
+    if (state.pool != nullptr) HEAMD_HIP_TRY(hipMemPoolTrimTo(state.pool, static_cast<size_t>(keep_bytes)));
+    return HE_OK;
+}
+int he_scratch_cached_bytes(uint64_t* out_bytes) {
+    if (out_bytes == nullptr) return invalid_argument("null out_bytes");
+    *out_bytes = 0;
+    int device = 0;
+    if (!current_device(&device)) return HE_OK;
+    ScratchState& state = scratch_state(device);
+    std::lock_guard<std::mutex> lock(state.mutex);
+    *out_bytes = state.cached_bytes;
     return HE_OK;
 }
 
@@ -249,6 +406,7 @@ int he_stream_create(he_stream* out) {
 }
 int he_stream_destroy(he_stream stream) {
     if (stream == nullptr) return HE_OK;
+    heamd::scratch_forget_stream(as_stream(stream));
     HEAMD_HIP_TRY(hipStreamDestroy(as_stream(stream)));
     return HE_OK;
 }

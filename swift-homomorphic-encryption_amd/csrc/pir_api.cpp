@@ -10,12 +10,17 @@
 // launches) of the kernels behind the B3 entry points on the caller's stream -- no stage returns to the host.
 #include <vector>
 
+#include <cstdlib>
+#include <memory>
+
 #include "api_internal.hpp"
 #include "kernels.hpp"
+#include "side_lane.hpp"
 
 using heamd::as_stream;
 using heamd::invalid_argument;
 using heamd::Scratch;
+using heamd::SideLane;
 
 #define HEAMD_TRY_STATUS(expr)            \
     do {                                  \
@@ -127,21 +132,80 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
     return he_bfv_mod_switch_down_to_single_device(ctx, L, 2, current, out, chunks, s);
 }
 
-// `chunks` chunks with a device-resident mask, enqueue-only: one dim-0 launch over the columns of all chunks, then the
-// remaining dimensions of all chunks together
+// The chunks of a response are independent, and the reference answers them as concurrent tasks (PirUtil.swift:538-563):
+// while one task streams its chunk of the database another is in its ct x ct stage.  The device counterpart -- the chunks in
+// pieces, a piece's dim-0 pass over the database on the caller's stream and its remaining dimensions on a lane of the context
+// beside the NEXT piece's dim-0 pass -- is built and tested (tests/test_gpu_pir.py) and OFF: measured on 8 chunks of 256 x 64
+// it is slower than one dim-0 launch over all chunks followed by one batch per remaining stage (6.46 ms; pieces of 4 / 2 / 1
+// chunks 6.91 / 7.32 / 8.07 ms, the lane at either priority: profiles/r06_pir_overlap.txt).  Why: the dim-0 kernel is not
+// idle on the multiplier side -- on 224 of the 256 CUs it already loses 6 % (profiles/r06f_cu_mask_probe.txt) -- and the
+// remaining dimensions' 1024-lane transform workgroups only get a CU once the dim-0 kernel's queued 256-lane workgroups stop
+// refilling it (a 129 us transform takes 1.3-2.5 ms beside it), so the lane's work mostly runs after the pass it was meant to
+// hide under, on smaller, less efficient launches.  HEAMD_PIR_PIECE_CHUNKS=k forces pieces of k chunks (the sweep and the
+// tests); unset, a response is one piece.
+size_t overlap_piece_chunks(uint32_t dimension_count, size_t chunks) {
+    if (dimension_count < 2 || chunks < 2) return chunks;
+    if (const char* forced = std::getenv("HEAMD_PIR_PIECE_CHUNKS")) {
+        const size_t piece = static_cast<size_t>(std::strtoull(forced, nullptr, 10));
+        return piece == 0 || piece > chunks ? chunks : piece;
+    }
+    return chunks;
+}
+
+// `chunks` chunks with a device-resident mask, enqueue-only: per piece one dim-0 launch over the columns of its chunks, then
+// the remaining dimensions of those chunks together (beside the next piece's dim-0 launch)
 int response_chunks_resident(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                              const ChunkShape& shape, size_t chunks, const uint64_t* dim0_query_eval,
-                             const uint64_t* remaining_query, const uint64_t* database, bool packed,
+                             const uint64_t* remaining_query, const uint64_t* database, size_t chunk_words, bool packed,
                              const uint8_t* present_device, const uint64_t* relinearization_key, uint64_t* out,
                              he_stream s) {
-    Scratch results_mem(as_stream(s));
-    HEAMD_HIP_TRY(results_mem.allocate(chunks * shape.columns * 2 * size_t(shape.L) * shape.n * sizeof(uint64_t)));
+    hipStream_t stream = as_stream(s);
+    const size_t ct2 = 2 * size_t(shape.L) * shape.n, out_words = 2 * shape.n;
+    Scratch results_mem(stream);
+    HEAMD_HIP_TRY(results_mem.allocate(chunks * shape.columns * ct2 * sizeof(uint64_t)));
     uint64_t* results = static_cast<uint64_t*>(results_mem.get());
-    // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
-    HEAMD_TRY_STATUS(dim0_columns(ctx, dim0_query_eval, shape.d0, database, packed, present_device, chunks * shape.columns,
-                                  results, s));
-    return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
-                                relinearization_key, out, s);
+    const size_t piece = overlap_piece_chunks(dimension_count, chunks);
+    if (piece >= chunks) {
+        // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
+        HEAMD_TRY_STATUS(dim0_columns(ctx, dim0_query_eval, shape.d0, database, packed, present_device, chunks * shape.columns,
+                                      results, s));
+        return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
+                                    relinearization_key, out, s);
+    }
+    heamd::LaneLease lease(heamd::lane_pool(ctx), stream);
+    if (lease.lane == nullptr) {
+        // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
+        HEAMD_TRY_STATUS(dim0_columns(ctx, dim0_query_eval, shape.d0, database, packed, present_device, chunks * shape.columns,
+                                      results, s));
+        return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
+                                    relinearization_key, out, s);
+    }
+    SideLane& lane = *lease.lane;
+    int status = HE_OK;
+    hipError_t e = hipSuccess;
+    bool forked = false;
+    for (size_t first = 0; first < chunks && status == HE_OK && e == hipSuccess; first += piece) {
+        const size_t now = chunks - first < piece ? chunks - first : piece;
+        uint64_t* piece_results = results + first * shape.columns * ct2;
+        status = dim0_columns(ctx, dim0_query_eval, shape.d0, database + first * chunk_words, packed,
+                              present_device ? present_device + first * shape.per_chunk : nullptr, now * shape.columns,
+                              piece_results, s);
+        if (status != HE_OK) break;
+        e = hipEventRecord(lane.stage[0], stream);  // (re-recorded per piece: a wait takes the event as it is when enqueued)
+        if (e == hipSuccess) e = hipStreamWaitEvent(lane.stream, lane.stage[0], 0);
+        if (e != hipSuccess) break;
+        forked = true;
+        status = remaining_dimensions(ctx, dimensions, dimension_count, shape, now, piece_results, remaining_query,
+                                      relinearization_key, out + first * out_words, static_cast<he_stream>(lane.stream));
+    }
+    if (forked) {  // the join is enqueued whatever happened in between: the caller's stream never runs ahead of the lane's work
+        const hipError_t recorded = hipEventRecord(lane.joined, lane.stream);
+        const hipError_t waited = recorded == hipSuccess ? hipStreamWaitEvent(stream, lane.joined, 0) : recorded;
+        if (e == hipSuccess) e = waited;
+    }
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(e);
+    return HE_OK;
 }
 }  // namespace
 
@@ -175,7 +239,8 @@ extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, c
         present_device = static_cast<const uint8_t*>(mask_mem.get());
     }
     return response_chunks_resident(ctx, dimensions, dimension_count, shape, 1, dim0_query_eval, remaining_query, database,
-                                    false, present_device, relinearization_key, out, s);
+                                    shape.per_chunk * size_t(shape.L) * shape.n, false, present_device, relinearization_key,
+                                    out, s);
 }
 
 namespace {
@@ -203,7 +268,7 @@ int compute_response(const he_bfv_context* ctx, const uint32_t* dimensions, uint
         const size_t now = chunk_count - first < group ? chunk_count - first : group;
         HEAMD_TRY_STATUS(response_chunks_resident(
             ctx, dimensions, dimension_count, shape, now, dim0_query_eval, remaining_query, database + first * chunk_words,
-            packed, present_device ? present_device + first * shape.per_chunk : nullptr, relinearization_key,
+            chunk_words, packed, present_device ? present_device + first * shape.per_chunk : nullptr, relinearization_key,
             out + first * out_words, s));
     }
     return HE_OK;
@@ -415,24 +480,58 @@ int compute_response_queries(const he_bfv_context* ctx, const uint32_t* dimensio
     HEAMD_HIP_TRY(one_mem.allocate(group * shape.columns * ct_bytes));
     uint64_t* all = static_cast<uint64_t*>(all_mem.get());  // [chunk][column][query][2][L][N]
     uint64_t* one = static_cast<uint64_t*>(one_mem.get());  // [chunk][column][2][L][N] of one query
-    for (size_t first = 0; first < chunk_count; first += group) {
-        const size_t now = chunk_count - first < group ? chunk_count - first : group;
+    // As response_chunks_resident (one piece unless forced): a piece's dim-0 pass for every query (PirUtil.swift:428-438) on
+    // the caller's stream, the queries' remaining dimensions on a lane beside the next piece's pass.  (`one` is only touched
+    // on the stream the remaining dimensions run on: its uses are ordered there.)
+    const size_t piece = overlap_piece_chunks(dimension_count, group);
+    std::unique_ptr<heamd::LaneLease> lease;
+    if (piece < group) lease.reset(new heamd::LaneLease(heamd::lane_pool(ctx), stream));
+    SideLane* lane = lease ? lease->lane : nullptr;
+    hipStream_t tail_stream = lane != nullptr ? lane->stream : stream;
+    int status = HE_OK;
+    hipError_t e = hipSuccess;
+    bool forked = false;
+    for (size_t first = 0, now = 0; first < chunk_count && status == HE_OK && e == hipSuccess; first += now) {
+        now = chunk_count - first < piece ? chunk_count - first : piece;
+        now = group - first % group < now ? group - first % group : now;  // (a piece does not straddle the slabs' end)
         const size_t columns = now * shape.columns;
-        // PirUtil.swift:428-438 for every query at once
-        HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(
+        uint64_t* piece_all = all + (first % group) * shape.columns * queries * ct_words;
+        if (lane != nullptr && first != 0 && first % group == 0) {
+            // the slabs wrap around: the lane's work on the previous `group` chunks first
+            e = hipEventRecord(lane->joined, lane->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, lane->joined, 0);
+            if (e != hipSuccess) break;
+        }
+        status = he_bfv_inner_product_plain_resident_device(
             ctx, L, static_cast<uint32_t>(2 * queries), dim0_queries_eval, database + first * chunk_words,
-            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, columns, all, s));
-        HEAMD_TRY_STATUS(he_ntt_inverse_device(shape.q_ctx, all, columns * 2 * queries, s));
-        for (size_t q = 0; q < queries; ++q) {
+            present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, columns, piece_all, s);
+        if (status == HE_OK) status = he_ntt_inverse_device(shape.q_ctx, piece_all, columns * 2 * queries, s);
+        if (status != HE_OK) break;
+        if (lane != nullptr) {
+            e = hipEventRecord(lane->stage[0], stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(lane->stream, lane->stage[0], 0);
+            if (e != hipSuccess) break;
+            forked = true;
+        }
+        for (size_t q = 0; q < queries && status == HE_OK && e == hipSuccess; ++q) {
             // this query's results, column after column (a strided copy: they sit `queries` ciphertexts apart)
-            HEAMD_HIP_TRY(hipMemcpy2DAsync(one, ct_bytes, all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
-                                           hipMemcpyDeviceToDevice, stream));
-            HEAMD_TRY_STATUS(remaining_dimensions(
+            e = hipMemcpy2DAsync(one, ct_bytes, piece_all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
+                                 hipMemcpyDeviceToDevice, tail_stream);
+            if (e != hipSuccess) break;
+            status = remaining_dimensions(
                 ctx, dimensions, dimension_count, shape, now, one,
                 remaining_queries ? remaining_queries + q * remaining_stride * ct_words : nullptr,
-                relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words, s));
+                relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words,
+                static_cast<he_stream>(tail_stream));
         }
     }
+    if (forked) {  // the join is enqueued whatever happened in between
+        const hipError_t recorded = hipEventRecord(lane->joined, lane->stream);
+        const hipError_t waited = recorded == hipSuccess ? hipStreamWaitEvent(stream, lane->joined, 0) : recorded;
+        if (e == hipSuccess) e = waited;
+    }
+    if (status != HE_OK) return status;
+    HEAMD_HIP_TRY(e);
     return HE_OK;
 }
 }  // namespace

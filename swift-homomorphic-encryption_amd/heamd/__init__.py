@@ -21,6 +21,7 @@ from .binding import (  # noqa: F401
     load_library,
     narrow_u64,
     set_device,
+    scratch_cached_bytes,
     set_scratch_cache,
     stream_copy,
     to_device,

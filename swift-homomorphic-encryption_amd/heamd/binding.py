@@ -46,6 +46,7 @@ SIGNATURES = [
     ("he_set_device", ctypes.c_int, [ctypes.c_int]),
     ("he_set_scratch_cache", ctypes.c_int, [c_u64]),
     ("he_device_trim_scratch", ctypes.c_int, [c_u64]),
+    ("he_scratch_cached_bytes", ctypes.c_int, [ctypes.POINTER(c_u64)]),
     ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
     ("he_device_free", ctypes.c_int, [vp]),
     ("he_host_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
@@ -253,6 +254,13 @@ def set_scratch_cache(nbytes=2**64 - 1):
 
 def trim_scratch(keep_bytes=0):
     _check(load_library().he_device_trim_scratch(keep_bytes))
+
+
+def scratch_cached_bytes():
+    """Bytes of released scratch the library's cache holds on the current device (he_scratch_cached_bytes)."""
+    out = c_u64(0)
+    _check(load_library().he_scratch_cached_bytes(ctypes.byref(out)))
+    return out.value
 
 
 def stream_copy(src, dst, non_temporal=False, stream=None):

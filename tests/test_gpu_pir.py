@@ -252,11 +252,18 @@ def test_column_sharded_response_equals_unsharded(oracle, small, shards):
     assert np.array_equal(got, whole)
 
 
-def test_multi_chunk_response_matches_oracle(oracle, small):
+@pytest.mark.parametrize("piece,cache", [(None, False), ("1", True), ("2", True), ("2", False)])
+def test_multi_chunk_response_matches_oracle(oracle, small, monkeypatch, piece, cache):
     """PirUtil.computeResponse's chunk loop (PirUtil.swift:533-563): three chunks of one database answered with one
-    query, each chunk word for word the oracle's computeResponseForOneChunk; nil plaintexts in the second chunk."""
+    query, each chunk word for word the oracle's computeResponseForOneChunk; nil plaintexts in the second chunk.
+    piece: the chunks answered in pieces of that many (a ragged last one), each piece's remaining dimensions on a lane of
+    the context beside the next piece's dim-0 pass (pir_api.cpp overlap_piece_chunks; at this size only when forced);
+    cache: scratch from the library's block cache (he_set_scratch_cache) instead of the HIP pool."""
     import torch
 
+    if piece is not None:
+        monkeypatch.setenv("HEAMD_PIR_PIECE_CHUNKS", piece)
+    heamd.set_scratch_cache(2**64 - 1 if cache else 0)
     ours, ref, client = small
     rng = random.Random(71)
     dims, chunks = [4, 3], 3
@@ -281,18 +288,23 @@ def test_multi_chunk_response_matches_oracle(oracle, small):
         assert np.array_equal(got[chunk], expected), chunk
         want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
         assert client.decrypt(got[chunk], moduli_count=1) == want
+    heamd.set_scratch_cache(0)
 
 
-@pytest.mark.parametrize("queries", [2, 3, 4])
-def test_queries_share_one_pass_over_the_database(oracle, small, queries):
+@pytest.mark.parametrize("queries,piece", [(2, None), (3, None), (4, None), (3, "1"), (4, "2")])
+def test_queries_share_one_pass_over_the_database(oracle, small, monkeypatch, queries, piece):
     """he_pir_compute_response_queries_device: the dim-0 inner products of several queries stream the database once;
     every query's responses are the oracle's computeResponseForOneChunk for that query alone (different selections,
-    different clients' relinearization keys), nil plaintexts included, and decrypt to the selected entries."""
+    different clients' relinearization keys), nil plaintexts included, and decrypt to the selected entries.
+    piece: as in test_multi_chunk_response_matches_oracle (three chunks then)."""
     import torch
 
     ours, ref, client = small
     rng = random.Random(300 + queries)
-    dims, chunks, per_chunk = [4, 3], 2, 12
+    dims, chunks, per_chunk = [4, 3], 2 if piece is None else 3, 12
+    if piece is not None:
+        monkeypatch.setenv("HEAMD_PIR_PIECE_CHUNKS", piece)
+        heamd.set_scratch_cache()
     entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(per_chunk * chunks)]
     database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64)).reshape(chunks, per_chunk, ref.L, ref.degree)
     present = np.ones((chunks, per_chunk), dtype=np.uint8)
@@ -318,6 +330,7 @@ def test_queries_share_one_pass_over_the_database(oracle, small, queries):
             assert np.array_equal(got[q, chunk], expected), (q, chunk)
             want = entries[chunk * per_chunk + index] if present[chunk, index] else zero
             assert client.decrypt(got[q, chunk], moduli_count=1) == want
+    heamd.set_scratch_cache(0)
 
 
 def test_queries_over_a_one_dimensional_database(oracle, small):

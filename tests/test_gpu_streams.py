@@ -266,3 +266,70 @@ def test_pinned_host_staging_round_trip(oracle):
     assert lib.he_host_free(staging) == 0 and lib.he_host_free(None) == 0
     assert lib.he_device_free(device) == 0 and lib.he_stream_destroy(stream) == 0
     assert lib.he_host_malloc(None, 8) == 16  # invalidArgument
+
+
+def test_scratch_cache_is_enqueue_only_and_shared_by_streams(oracle):
+    """he_set_scratch_cache: with the library's block cache on, calls that take scratch (relinearize without a workspace)
+    return to the host while their work is still queued -- the HIP pool's hipFreeAsync holds every such call until the
+    previous one's work has finished (profiles/r06b_pool_probe.txt) -- the cache stops growing once the shapes have been
+    seen, two streams taking turns on the same blocks (an event wait, no driver allocation) both give the oracle's words,
+    the same call captured into a graph still works (scratch from the HIP pool there), and a trim hands everything back."""
+    import time
+
+    import torch
+
+    degree, batch = 4096, 512
+    q = oracle.generate_primes([55, 55, 55], False, degree)
+    t = oracle.generate_primes([17], True, degree)[0]
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(93)
+
+    def uniform(prefix, mods):
+        rows = [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in mods]
+        return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
+
+    ct3, key = uniform((batch, 3), moduli), uniform((ours.L, 2), q)
+    expected = ref.relinearize(ct3, key)
+    ct3_device, key_device = heamd.to_device(ct3), heamd.to_device(key)
+    heamd.trim_scratch(0)
+    heamd.set_scratch_cache()
+    try:
+        assert heamd.scratch_cached_bytes() == 0
+        first = ours.relinearize(ct3_device, key_device)
+        torch.cuda.synchronize()
+        held = heamd.scratch_cached_bytes()
+        assert held >= ours.relinearize_workspace_bytes(batch)
+        # enqueue-only: many calls queue up behind one another without the host waiting for any of them
+        calls = 40
+        begin = time.perf_counter()
+        outs = [ours.relinearize(ct3_device, key_device) for _ in range(calls)]
+        host_s = time.perf_counter() - begin
+        torch.cuda.synchronize()
+        device_s = time.perf_counter() - begin
+        assert heamd.scratch_cached_bytes() == held, "the cache grew on a shape it had seen"
+        assert host_s < 0.6 * device_s, (host_s, device_s)
+        for out in (first, outs[0], outs[-1]):
+            assert np.array_equal(heamd.to_host(out), expected)
+        # another stream takes the cached block over (the event orders it behind the last release), then the first again
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            other = ours.relinearize(ct3_device, key_device, stream=side)
+        back = ours.relinearize(ct3_device, key_device)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(heamd.to_host(other), expected) and np.array_equal(heamd.to_host(back), expected)
+        assert heamd.scratch_cached_bytes() <= 2 * held
+        # captured: allocation nodes of the HIP pool, the cache is left alone
+        before = heamd.scratch_cached_bytes()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = ours.relinearize(ct3_device, key_device)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(heamd.to_host(captured), expected)
+        assert heamd.scratch_cached_bytes() == before
+        heamd.trim_scratch(0)
+        assert heamd.scratch_cached_bytes() == 0
+    finally:
+        heamd.set_scratch_cache(0)
