@@ -563,6 +563,50 @@ int he_pir_expand_batch_device(const he_bfv_context* ctx, const uint64_t* cipher
                                const uint64_t* const* galois_keys, size_t galois_key_count, uint64_t* out, he_stream s);
 
 /* =====================================================================================================
+ * Device groups: the path's multi-GPU split in one process
+ * =====================================================================================================
+ * Every unit of the path -- a polynomial of a batch (Bfv.swift:266-287), a database column of a PIR chunk
+ * (PirUtil.swift:424-445) -- is independent; the reference spreads them over the tasks of one process.  A device group spreads
+ * them over GPUs: one he_bfv_context and one stream per member device (contexts replicated, a few MiB of tables each), `total`
+ * units split by he_shard_bounds -- member m owns [begin, end), the first total % members members one unit more -- and nothing
+ * on the data path crossing devices: the query is copied to the members on the way in, the finished shards to the home
+ * device (member 0's) on the way out, as peer copies on the members' streams joined into the caller's stream by events.
+ * A device may be listed more than once (two shards on one GPU).  HE_GROUP_STAGE_ALL makes every member but the first go
+ * through the copies of a remote device even when it is the same GPU -- the whole exchange on a one-GPU box (tests).
+ * Group calls are enqueue-only; `home_stream` is a stream of member 0's device (NULL: its default stream), pointers
+ * marked "home" live there, shard m lives on member m's device. */
+typedef struct he_device_group he_device_group;
+#define HE_GROUP_STAGE_ALL 1u
+int he_shard_bounds(size_t total, uint32_t members, uint32_t member, size_t* out_begin, size_t* out_end);
+int he_device_group_create(const int* devices, uint32_t device_count, uint32_t flags, uint32_t degree,
+                           uint64_t plaintext_modulus, const uint64_t* coefficient_moduli, uint32_t moduli_count,
+                           he_device_group** out);
+void he_device_group_destroy(he_device_group* group);
+uint32_t he_device_group_size(const he_device_group* group);
+int he_device_group_device(const he_device_group* group, uint32_t member, int* out_device);
+const he_bfv_context* he_device_group_context(const he_device_group* group, uint32_t member); /* owned by the group */
+he_stream he_device_group_stream(const he_device_group* group, uint32_t member);              /* owned by the group */
+int he_device_group_synchronize(he_device_group* group); /* blocks until every member's stream has drained */
+/* PolyContext.forwardNtt / inverseNtt over a batch that lives sharded: member m transforms
+ * slab_shards[m] = [its share of batch][moduli_count][N] in place on its own stream; nothing moves between devices. */
+int he_ntt_forward_group(he_device_group* group, uint32_t moduli_count, uint64_t* const* slab_shards, size_t batch);
+int he_ntt_inverse_group(he_device_group* group, uint32_t moduli_count, uint64_t* const* slab_shards, size_t batch);
+/* he_pir_dim0_columns_device over a database sharded by column (BASELINE configs[4]): database_shards[m] =
+ * [its share of columns][d0][L][N] Eval (present_shards[m] its mask or NULL; present_shards itself may be NULL);
+ * dim0_query_eval (home) is replicated to the members; out (home) [columns][2][L][N] Coeff receives every member's columns
+ * at their place.  Whole columns stay on one device, so there is no reduction, only this gather. */
+int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query_eval, size_t d0,
+                              const uint64_t* const* database_shards, const uint8_t* const* present_shards, size_t columns,
+                              uint64_t* out, he_stream home_stream);
+/* computeResponseForOneChunk over the group: he_pir_dim0_columns_group, then he_pir_remaining_dimensions_device on the home
+ * device (the remaining dimensions need every column).  remaining_query, relinearization_key, out: home. */
+int he_pir_compute_response_chunk_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
+                                        const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                                        size_t remaining_query_count, const uint64_t* const* database_shards,
+                                        const uint8_t* const* present_shards, const uint64_t* relinearization_key,
+                                        uint64_t* out, he_stream home_stream);
+
+/* =====================================================================================================
  * Diagnostics and test hooks (not part of the reference's surface)
  * =================================================================================================== */
 

@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 global_load<LOGN, LOGE, LO0, LOGE>(v[k], tid, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
         }
         using O = PassOrder<LOGN, LOGE, kTopPartialOrder<LOGN, LOGE, false, SPREAD == kSourceSlab>>;
-        forward_row<LOGN, LOGE, MODE, ROWS, true, O::kTop>(v, tid, tw, p, lds);
+        // (N = 4096, two rows per workgroup on the shift-folded products: one register short with a carried lane index)
+        constexpr bool LATE = LOGN == 12 && ROWS == 2 && MODE == kModeFoldLazy;
+        forward_row<LOGN, LOGE, MODE, ROWS, true, O::kTop, LATE>(v, tid, tw, p, lds);
         constexpr int LO_BEFORE_LOW = O::kTop ? O::lo(S::P - 2) : LOGN - (S::P - 1) * LOGE;
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
@@ -277,6 +279,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
     constexpr bool FROM_SLAB = SOURCE == kInverseFromSlab || SOURCE == kInverseFromSlabScaled;
     constexpr bool KEYMAC = is_key_mac(SOURCE), FINISH = SOURCE == kInverseFromKeyMacFinish;
     constexpr int INPUT_STAGES = (TENSOR || KEYMAC) && kLazyTransformInput<MODE> ? kLazyInputStages : 0;
+    constexpr bool LATE = KEYMAC && ROWS == 2;  // (ntt_rows.hpp step_lane)
     static_assert(ROWS == 1 || SOURCE != kInverseFromSlabScaled, "scaled plain slabs go one row per workgroup");
     const uint64_t* __restrict__ tensor_source = source_spec.first;
     constexpr int LOGE = LOGN - LOGT;
@@ -468,7 +471,7 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             const bool wide = half >= p;
             constexpr int kEndPlain = 0, kEndGalois = 1, kEndExpand = 2;
             auto finish = [&](int k, uint64_t (&row)[E]) {
-                const uint32_t lane = step_lane<MODE>(tid);
+                const uint32_t lane = step_lane<MODE, LATE>(tid);
                 const uint32_t lane_words = lane_part<LOGN, LOGE, LOL, LOGE>(lane), lane_bytes = lane_words << 3;
                 constexpr int CHUNK = 4;  // words in flight: the q_ks and ciphertext words of a chunk are requested together
                 auto word = [](Dwordx2 w) { return pack64(w.x, w.y); };
@@ -574,10 +577,10 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
                 if (wide) with_end(std::true_type{});
                 else with_end(std::false_type{});
             };
-            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head, finish);
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD, LATE>(v, tid, tw, mod, lds, head, finish);
         } else {
-            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD>(v, tid, tw, mod, lds, head);
-            const uint32_t store_lane = step_lane<MODE>(tid);
+            inverse_row<LOGN, LOGE, MODE, ROWS, SCALED, INPUT_STAGES, LOGN, O::kTop, HEAD, LATE>(v, tid, tw, mod, lds, head);
+            const uint32_t store_lane = step_lane<MODE, LATE>(tid);
 #pragma unroll
             for (int k = 0; k < ROWS; ++k)
                 global_store<LOGN, LOGE, LOL, LOGE>(v[k], store_lane, make_resource(slab + (rows[k] << LOGN), 8u << LOGN));
@@ -860,6 +863,7 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     static_assert(SOURCE == kInverseFromSlab || TENSOR || KEYMAC, "the key switch's end stays with the tiled kernel");
     static_assert(!TENSOR || SCALED, "the fused tensor load belongs to dropExtendedBase (t N^-1)");
     constexpr int INPUT_STAGES = (TENSOR || KEYMAC) && kLazyTransformInput<MODE> ? kLazyInputStages : 0;
+    constexpr bool LATE = KEYMAC && ROWS == 2;  // (ntt_rows.hpp step_lane)
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;

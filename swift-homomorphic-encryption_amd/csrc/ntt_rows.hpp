@@ -136,16 +136,19 @@ __device__ __forceinline__ uint32_t late_lane(uint32_t lane) {
 // nothing to spare: no scratch in the plain-slab inverse at N = 4096 and in the key-MAC transform that way, N = 4096 inverse
 // -2 ... -4 %); the others carry an opaque copy (the plain-slab inverse at N = 8192 is 2 % faster with it, and the forward
 // kernels fit either way) -- profiles/r04t_inverse_forms_ab.txt.
-template <int MODE>
+// LATE: re-derive whatever the mode (the key-MAC transforms on the shift-folded products: their 64 registers hold two rows,
+// four operand pairs of the inner product in flight and the sums -- a carried lane index and the addresses derived from it
+// went to scratch, 20 B per lane at N = 8192; profiles/r06g_key_mac_scratch.txt).
+template <int MODE, bool LATE = false>
 __device__ __forceinline__ uint32_t step_lane(uint32_t lane) {
     if constexpr (!kLateLaneAddresses) return lane;
-    else if constexpr (MODE == kModeSplitSigned) return late_lane(lane);
+    else if constexpr (MODE == kModeSplitSigned || LATE) return late_lane(lane);
     else return opaque32(lane);
 }
-template <int LOGN, int LOGE, int LO_FROM, int LO_TO, int MODE, int ROWS>
+template <int LOGN, int LOGE, int LO_FROM, int LO_TO, int MODE, int ROWS, bool LATE = false>
 __device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw, uint64_t p,
                                              uint64_t* lds) {
-    const uint32_t tid = step_lane<MODE>(lane);
+    const uint32_t tid = step_lane<MODE, LATE>(lane);
     const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO_TO, LOGE, MODE, false>(tw, tid);
     exchange<LOGN, LOGE, LO_FROM, LOGE, LO_TO, LOGE, ROWS>(v, tid, lds);
     forward_pass<LOGN, LOGE, LO_TO, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
@@ -153,7 +156,7 @@ __device__ __forceinline__ void forward_step(uint64_t (&v)[ROWS][1 << LOGE], uin
 
 // TOP: the pass order with the partial pass on the top bits (ntt_common.hpp PassOrder); out -- the layout of the full pass
 // on bits [0, LOGE).
-template <int LOGN, int LOGE, int MODE, int ROWS, bool CANONICAL = true, bool TOP = false>
+template <int LOGN, int LOGE, int MODE, int ROWS, bool CANONICAL = true, bool TOP = false, bool LATE = false>
 __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             uint64_t p, uint64_t* lds) {
     using S = Schedule<LOGN, LOGE>;
@@ -163,39 +166,45 @@ __device__ __forceinline__ void forward_row(uint64_t (&v)[ROWS][1 << LOGE], uint
         // the partial pass in the layout of a full top pass: its stages pair the layout's top R bits
         forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS, S::R>(
             v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
-        forward_step<LOGN, LOGE, LO0, O::lo(1), MODE, ROWS>(v, tid, tw, p, lds);
-        if constexpr (S::P >= 3) forward_step<LOGN, LOGE, O::lo(1), O::lo(2), MODE, ROWS>(v, tid, tw, p, lds);
-        if constexpr (S::P >= 4) forward_step<LOGN, LOGE, O::lo(2), O::lo(3), MODE, ROWS>(v, tid, tw, p, lds);
-        if constexpr (S::P >= 5) forward_step<LOGN, LOGE, O::lo(3), O::lo(4), MODE, ROWS>(v, tid, tw, p, lds);
+        forward_step<LOGN, LOGE, LO0, O::lo(1), MODE, ROWS, LATE>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 3) forward_step<LOGN, LOGE, O::lo(1), O::lo(2), MODE, ROWS, LATE>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 4) forward_step<LOGN, LOGE, O::lo(2), O::lo(3), MODE, ROWS, LATE>(v, tid, tw, p, lds);
+        if constexpr (S::P >= 5) forward_step<LOGN, LOGE, O::lo(3), O::lo(4), MODE, ROWS, LATE>(v, tid, tw, p, lds);
         static_assert(O::lo(S::P - 1) == 0, "the last full pass sits on bits [0, LOGE)");
         if constexpr (CANONICAL) canonicalize_all<MODE>(v, p);
         return;
     }
     forward_pass<LOGN, LOGE, LO0, LOGE, MODE, true, ROWS>(
         v, tid, tw, p, true, forward_first_twiddle<LOGN, LOGE, LO0, LOGE, MODE, true>(tw, tid));
+    // (LATE: each step re-derives the lane index -- step_lane; this order otherwise takes the kernel's own copy)
+    [[maybe_unused]] auto at_step = [&]() { return LATE ? late_lane(tid) : tid; };
     if constexpr (S::P >= 3) {
         constexpr int LO1 = LOGN - 2 * LOGE;
-        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO0, LOGE, LO1, LOGE, ROWS>(v, tid, lds);
-        forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
+        const uint32_t lane = at_step();
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO1, LOGE, MODE, false>(tw, lane);
+        exchange<LOGN, LOGE, LO0, LOGE, LO1, LOGE, ROWS>(v, lane, lds);
+        forward_pass<LOGN, LOGE, LO1, LOGE, MODE, false, ROWS>(v, lane, tw, p, false, first);
     }
     if constexpr (S::P >= 4) {
         constexpr int LO1 = LOGN - 2 * LOGE, LO2 = LOGN - 3 * LOGE;
-        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, tid, lds);
-        forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
+        const uint32_t lane = at_step();
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO2, LOGE, MODE, false>(tw, lane);
+        exchange<LOGN, LOGE, LO1, LOGE, LO2, LOGE, ROWS>(v, lane, lds);
+        forward_pass<LOGN, LOGE, LO2, LOGE, MODE, false, ROWS>(v, lane, tw, p, false, first);
     }
     if constexpr (S::P >= 5) {
         constexpr int LO2 = LOGN - 3 * LOGE, LO3 = LOGN - 4 * LOGE;
-        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, tid, lds);
-        forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, tid, tw, p, false, first);
+        const uint32_t lane = at_step();
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, LO3, LOGE, MODE, false>(tw, lane);
+        exchange<LOGN, LOGE, LO2, LOGE, LO3, LOGE, ROWS>(v, lane, lds);
+        forward_pass<LOGN, LOGE, LO3, LOGE, MODE, false, ROWS>(v, lane, tw, p, false, first);
     }
     {
         constexpr int LO_PREVIOUS = LOGN - (S::P - 1) * LOGE;
-        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, tid);
-        exchange<LOGN, LOGE, LO_PREVIOUS, LOGE, 0, S::R, ROWS>(v, tid, lds);
-        forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, tid, tw, p, false, first);
+        const uint32_t lane = at_step();
+        const TwiddleWords first = forward_first_twiddle<LOGN, LOGE, 0, S::R, MODE, false>(tw, lane);
+        exchange<LOGN, LOGE, LO_PREVIOUS, LOGE, 0, S::R, ROWS>(v, lane, lds);
+        forward_pass<LOGN, LOGE, 0, S::R, MODE, false, ROWS>(v, lane, tw, p, false, first);
     }
     if constexpr (CANONICAL) canonicalize_all<MODE>(v, p);
 }
@@ -211,10 +220,10 @@ constexpr bool kWideGroupFirstTwiddleEarly = false;
 // that the 64-register kernels cannot afford (exchange<> PER_TRANSPOSE)
 constexpr bool kWideGroupPerTransposeLds = false;
 template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int LO_TO, int MODE, bool UNIFORM, int ROWS, bool SCALED, int PRIOR = 0,
-          int LOGD = LOGN, int FIRST_STAGE = 0>
+          int LOGD = LOGN, int FIRST_STAGE = 0, bool LATE = false>
 __device__ __forceinline__ void inverse_step(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                              const DeviceModulus& mod, uint64_t* lds) {
-    const uint32_t tid = step_lane<MODE>(lane);
+    const uint32_t tid = step_lane<MODE, LATE>(lane);
     // (row groups of three and four -- behz_kernels.hip, 128 registers per lane -- have the registers for requests before the
     // exchange and for more than one twiddle in flight: kWideGroupFirstTwiddleEarly, ntt_common.hpp kWideGroupTwiddlesAhead)
     constexpr int AHEAD = kGroupTwiddlesAhead<MODE, ROWS>;
@@ -244,11 +253,11 @@ __device__ __forceinline__ void inverse_row_head(TwiddleWords (&head)[HEAD], con
 // store) -- and is picked up afterwards.  Same barriers as the exchange of both rows; the pass's wave-uniform twiddles are
 // scalar loads and are simply read again for the second row.
 struct NoFinish {};
-template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int MODE, int ROWS, bool SCALED, int PRIOR, int LOGD, typename Finish>
+template <int LOGN, int LOGE, int LO_FROM, int W_FROM, int MODE, int ROWS, bool SCALED, int PRIOR, int LOGD, bool LATE, typename Finish>
 __device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t lane, const Twiddles<MODE>& tw,
                                                          const DeviceModulus& mod, uint64_t* lds, Finish& finish) {
     static_assert(ROWS <= 2, "one row in registers, one parked in the tile");
-    const uint32_t tid = step_lane<MODE>(lane);
+    const uint32_t tid = step_lane<MODE, LATE>(lane);
     constexpr int E = 1 << LOGE, LOL = LOGN - LOGE;
     constexpr int SCHEME = !is_split(MODE) ? transpose_scheme<LOGN, LOGE, LO_FROM, LOL>() : 0;  // as exchange<> in inverse_step
     lds_store<LOGN, LOGE, LO_FROM, W_FROM, SCHEME>(v[0], tid, lds);
@@ -278,7 +287,7 @@ __device__ __forceinline__ void inverse_last_step_by_row(uint64_t (&v)[ROWS][1 <
 // Finish: NoFinish, or a callable (row index, the row's canonical words in the top layout) that takes over each row as it
 // is completed (inverse_last_step_by_row; only with the partial pass on the low bits).
 template <int LOGN, int LOGE, int MODE, int ROWS, bool SCALED, int PRIOR = 0, int LOGD = LOGN, bool TOP = false, int HEAD = 1,
-          typename Finish = NoFinish>
+          bool LATE = false, typename Finish = NoFinish>
 __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint32_t tid, const Twiddles<MODE>& tw,
                                             const DeviceModulus& mod, uint64_t* lds, const TwiddleWords (&head)[HEAD],
                                             Finish finish = Finish{}) {
@@ -292,29 +301,29 @@ __device__ __forceinline__ void inverse_row(uint64_t (&v)[ROWS][1 << LOGE], uint
         using O = PassOrder<LOGN, LOGE, TOP>;
         inverse_pass<LOGN, LOGE, 0, LOGE, MODE, false, ROWS, false, PRIOR, LOGD, 0, HEAD>(v, tid, tw, mod, PRIOR == 0, head);
         if constexpr (S::P >= 5)
-            inverse_step<LOGN, LOGE, O::lo(4), LOGE, O::lo(3), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+            inverse_step<LOGN, LOGE, O::lo(4), LOGE, O::lo(3), MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
         if constexpr (S::P >= 4)
-            inverse_step<LOGN, LOGE, O::lo(3), LOGE, O::lo(2), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+            inverse_step<LOGN, LOGE, O::lo(3), LOGE, O::lo(2), MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
         if constexpr (S::P >= 3)
-            inverse_step<LOGN, LOGE, O::lo(2), LOGE, O::lo(1), MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
-        inverse_step<LOGN, LOGE, O::lo(1), LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, LOGE - R>(v, tid, tw, mod, lds);
+            inverse_step<LOGN, LOGE, O::lo(2), LOGE, O::lo(1), MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, O::lo(1), LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, LOGE - R, LATE>(v, tid, tw, mod, lds);
         return;
     }
     inverse_pass<LOGN, LOGE, 0, R, MODE, false, ROWS, false, PRIOR, LOGD, 0, HEAD>(v, tid, tw, mod, PRIOR == 0, head);
     if constexpr (S::P >= 3)
-        inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, 0, R, R, MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 4)
-        inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, R, LOGE, R + LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
     if constexpr (S::P >= 5)
-        inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, R + LOGE, LOGE, R + 2 * LOGE, MODE, false, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
     // into the top pass (uniform twiddles; its last stage folds in N^-1)
     if constexpr (BY_ROW) {
-        if constexpr (S::P == 2) inverse_last_step_by_row<LOGN, LOGE, 0, R, MODE, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds, finish);
-        else inverse_last_step_by_row<LOGN, LOGE, LOL - LOGE, LOGE, MODE, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds, finish);
+        if constexpr (S::P == 2) inverse_last_step_by_row<LOGN, LOGE, 0, R, MODE, ROWS, SCALED, PRIOR, LOGD, LATE>(v, tid, tw, mod, lds, finish);
+        else inverse_last_step_by_row<LOGN, LOGE, LOL - LOGE, LOGE, MODE, ROWS, SCALED, PRIOR, LOGD, LATE>(v, tid, tw, mod, lds, finish);
     } else if constexpr (S::P == 2) {
-        inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, 0, R, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
     } else {
-        inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD>(v, tid, tw, mod, lds);
+        inverse_step<LOGN, LOGE, LOL - LOGE, LOGE, LOL, MODE, true, ROWS, SCALED, PRIOR, LOGD, 0, LATE>(v, tid, tw, mod, lds);
     }
 }
 

@@ -10,6 +10,7 @@ Names follow the reference (Sources/HomomorphicEncryption): PolyContext.forwardN
 from .binding import (  # noqa: F401
     BfvContext,
     BfvContext32,
+    DeviceGroup,
     HeError,
     PolyContext,
     current_device,
@@ -22,6 +23,7 @@ from .binding import (  # noqa: F401
     narrow_u64,
     set_device,
     scratch_cached_bytes,
+    shard_bounds,
     set_scratch_cache,
     stream_copy,
     to_device,

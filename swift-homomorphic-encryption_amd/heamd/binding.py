@@ -47,6 +47,20 @@ SIGNATURES = [
     ("he_set_scratch_cache", ctypes.c_int, [c_u64]),
     ("he_device_trim_scratch", ctypes.c_int, [c_u64]),
     ("he_scratch_cached_bytes", ctypes.c_int, [ctypes.POINTER(c_u64)]),
+    ("he_shard_bounds", ctypes.c_int, [c_size, c_u32, c_u32, ctypes.POINTER(c_size), ctypes.POINTER(c_size)]),
+    ("he_device_group_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_u32, c_u32, c_u32, c_u64,
+                                              ctypes.POINTER(c_u64), c_u32, ctypes.POINTER(vp)]),
+    ("he_device_group_destroy", None, [vp]),
+    ("he_device_group_size", c_u32, [vp]),
+    ("he_device_group_device", ctypes.c_int, [vp, c_u32, ctypes.POINTER(ctypes.c_int)]),
+    ("he_device_group_context", vp, [vp, c_u32]),
+    ("he_device_group_stream", vp, [vp, c_u32]),
+    ("he_device_group_synchronize", ctypes.c_int, [vp]),
+    ("he_ntt_forward_group", ctypes.c_int, [vp, c_u32, ctypes.POINTER(vp), c_size]),
+    ("he_ntt_inverse_group", ctypes.c_int, [vp, c_u32, ctypes.POINTER(vp), c_size]),
+    ("he_pir_dim0_columns_group", ctypes.c_int, [vp, vp, c_size, ctypes.POINTER(vp), ctypes.POINTER(vp), c_size, vp, vp]),
+    ("he_pir_compute_response_chunk_group", ctypes.c_int, [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size,
+                                                           ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp, vp]),
     ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
     ("he_device_free", ctypes.c_int, [vp]),
     ("he_host_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
@@ -261,6 +275,92 @@ def scratch_cached_bytes():
     out = c_u64(0)
     _check(load_library().he_scratch_cached_bytes(ctypes.byref(out)))
     return out.value
+
+
+def shard_bounds(total, members, member):
+    """he_shard_bounds: member `member` of `members` owns units [begin, end) of `total`."""
+    begin, end = c_size(0), c_size(0)
+    _check(load_library().he_shard_bounds(total, members, member, ctypes.byref(begin), ctypes.byref(end)))
+    return begin.value, end.value
+
+
+GROUP_STAGE_ALL = 1
+
+
+class DeviceGroup:
+    """he_device_group: one Context<Bfv<UInt64>> and one stream per member device of ONE process; the units of a call split
+    over the members by shard_bounds, the finished shards gathered on member 0's device (include/he_amd.h "Device groups")."""
+
+    def __init__(self, devices, degree, plaintext_modulus, coefficient_moduli, stage_all=False):
+        ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        q = (c_u64 * len(coefficient_moduli))(*[int(m) for m in coefficient_moduli])
+        handle = vp()
+        _check(load_library().he_device_group_create(ids, len(devices), GROUP_STAGE_ALL if stage_all else 0, degree,
+                                                     int(plaintext_modulus), q, len(coefficient_moduli), ctypes.byref(handle)))
+        self.h = handle
+        self.degree = degree
+        self.devices = [int(d) for d in devices]
+        self.L = len(coefficient_moduli) - 1 if len(coefficient_moduli) > 1 else 1
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load_library().he_device_group_destroy(self.h)
+            self.h = None
+
+    def __len__(self):
+        return int(load_library().he_device_group_size(self.h))
+
+    def bounds(self, total, member):
+        return shard_bounds(total, len(self), member)
+
+    def stream(self, member):
+        """The member's stream as a torch stream (owned by the group)."""
+        import torch
+
+        return torch.cuda.ExternalStream(int(load_library().he_device_group_stream(self.h, member)),
+                                         device=self.devices[member])
+
+    def synchronize(self):
+        _check(load_library().he_device_group_synchronize(self.h))
+
+    def _shards(self, tensors):
+        return (vp * len(tensors))(*[vp(0) if t is None else vp(t.data_ptr()) for t in tensors])
+
+    def forward_ntt_(self, slab_shards, batch, moduli_count=None):
+        _check(load_library().he_ntt_forward_group(self.h, moduli_count or self.L, self._shards(slab_shards), batch))
+        return slab_shards
+
+    def inverse_ntt_(self, slab_shards, batch, moduli_count=None):
+        _check(load_library().he_ntt_inverse_group(self.h, moduli_count or self.L, self._shards(slab_shards), batch))
+        return slab_shards
+
+    def pir_dim0_columns(self, dim0_query_eval, database_shards, columns, present_shards=None, stream=None):
+        """he_pir_dim0_columns_group: database_shards[m] = member m's columns [share][d0][L][N] on its device; the result
+        [columns][2][L][N] on member 0's device (where dim0_query_eval lives)."""
+        import torch
+
+        d0 = dim0_query_eval.numel() // (2 * self.L * self.degree)
+        out = torch.empty((columns, 2, self.L, self.degree), dtype=dim0_query_eval.dtype, device=dim0_query_eval.device)
+        masks = None if present_shards is None else self._shards(present_shards)
+        _check(load_library().he_pir_dim0_columns_group(self.h, _ptr(dim0_query_eval), d0, self._shards(database_shards),
+                                                        masks, columns, _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response_chunk(self, dimensions, dim0_query_eval, remaining_query, database_shards,
+                                   present_shards=None, relinearization_key=None, stream=None):
+        """he_pir_compute_response_chunk_group -> [2][1][N] on member 0's device."""
+        import torch
+
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = torch.empty((2, 1, self.degree), dtype=dim0_query_eval.dtype, device=dim0_query_eval.device)
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        masks = None if present_shards is None else self._shards(present_shards)
+        _check(load_library().he_pir_compute_response_chunk_group(self.h, dims, len(dims), _ptr(dim0_query_eval), rest,
+                                                                  rest_count, self._shards(database_shards), masks, key,
+                                                                  _ptr(out), _stream(stream)))
+        return out
 
 
 def stream_copy(src, dst, non_temporal=False, stream=None):

@@ -793,3 +793,69 @@ def test_column_shard_at_the_benchmark_size(oracle):
     assert all(verdicts), [c for c, ok in zip(sample, verdicts) if not ok]
     print(f"dim-0 columns: {len(sample)} of {columns} columns ({len(sample) * d0} of {columns * d0} ct x pt products) "
           "compared with the oracle word for word")
+
+
+@pytest.mark.parametrize("members,stage_all", [(1, False), (2, False), (2, True), (3, True)])
+def test_device_group_equals_single_device(oracle, small, members, stage_all):
+    """he_device_group (include/he_amd.h "Device groups"): the columns of a chunk split over the members of a group -- the
+    one GPU listed `members` times, with stage_all every member but the first through the copies of a remote device (query
+    in, finished columns out) -- give word for word the single-device dim-0 results and the oracle's chunk response; 5
+    columns over 2 / 3 members is a ragged split, 2 columns over 3 an empty shard; nil plaintexts per shard."""
+    import torch
+
+    ours, ref, client = small
+    group = heamd.DeviceGroup([0] * members, ref.degree, ref.t, ref.coefficient_moduli, stage_all=stage_all)
+    assert len(group) == members
+    rng = random.Random(500 + members)
+    qctx = ref.ciphertext_context()
+    host_key = client.relinearization_key()
+    key = heamd.to_device(host_key)
+    one, zero = [1] + [0] * (ref.degree - 1), [0] * ref.degree
+    for dims in ([4, 5], [3, 2]):
+        d0, columns = dims
+        entries = [[rng.randrange(ref.t) for _ in range(ref.degree)] for _ in range(d0 * columns)]
+        database = ref.plaintext_to_eval(np.array(entries, dtype=np.uint64))  # plaintext k of column c at c * d0 + k
+        present = np.ones(d0 * columns, dtype=np.uint8)
+        present[[1, d0 * columns - 2]] = 0
+        selection = (d0 - 1, columns - 1)
+        dim0 = np.stack([qctx.forward_ntt(client.encrypt(one if k == selection[0] else zero)) for k in range(d0)])
+        rest = np.stack([client.encrypt(one if k == selection[1] else zero) for k in range(columns)])
+        dim0_device, rest_device = heamd.to_device(dim0), heamd.to_device(rest)
+        database_device = heamd.to_device(database).view(columns, d0, ref.L, ref.degree)
+        present_device = torch.from_numpy(present).cuda().view(columns, d0)
+        shards, masks = [], []
+        for m in range(members):
+            begin, end = group.bounds(columns, m)
+            assert (begin, end) == heamd.shard_bounds(columns, members, m)
+            shards.append(database_device[begin:end].contiguous() if end > begin else None)
+            masks.append(present_device[begin:end].contiguous() if end > begin else None)
+        whole = ours.pir_dim0_columns(dim0_device, database_device, present_device=present_device)
+        split = group.pir_dim0_columns(dim0_device, shards, columns, present_shards=masks)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, split), dims
+        got = heamd.to_host(group.pir_compute_response_chunk(dims, dim0_device, rest_device, shards, present_shards=masks,
+                                                             relinearization_key=key))
+        expected = oracle.pir.compute_response_for_one_chunk(ref, dims, dim0, rest,
+                                                             database.reshape(d0 * columns, ref.L, ref.degree), present,
+                                                             host_key)
+        assert np.array_equal(got, expected), dims
+        index = selection[0] + d0 * selection[1]
+        assert client.decrypt(got, moduli_count=1) == (entries[index] if present[index] else zero)
+    # a batch of polynomials that lives sharded: every member transforms its own share in place
+    batch = 7
+    slab = _uniform(np.random.default_rng(9), (batch,), ref.coefficient_moduli[:-1], ref.degree)
+    pieces = []
+    for m in range(members):
+        begin, end = group.bounds(batch, m)
+        pieces.append(heamd.to_device(slab[begin:end]) if end > begin else None)
+    group.forward_ntt_(pieces, batch)
+    group.synchronize()
+    forward = np.concatenate([heamd.to_host(p) for p in pieces if p is not None])
+    assert np.array_equal(forward, qctx.forward_ntt(slab))
+    group.inverse_ntt_(pieces, batch)
+    group.synchronize()
+    assert np.array_equal(np.concatenate([heamd.to_host(p) for p in pieces if p is not None]), slab)
+    with pytest.raises(heamd.HeError):
+        heamd.DeviceGroup([], ref.degree, ref.t, ref.coefficient_moduli)
+    with pytest.raises(heamd.HeError):
+        heamd.DeviceGroup([99], ref.degree, ref.t, ref.coefficient_moduli)

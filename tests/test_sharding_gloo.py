@@ -303,3 +303,19 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1 and sizes == sharding.shard_sizes(total, world)
     with pytest.raises(ValueError):
         sharding.shard_bounds(4, 2, 2)
+
+
+def test_c_abi_shard_bounds_is_the_same_partition():
+    """he_shard_bounds -- what a device group splits a call's units by (include/he_amd.h "Device groups") -- is the
+    partition the one-process-per-GPU harness uses; its argument errors are HE_ERR_INVALID_ARGUMENT.  No GPU involved."""
+    import heamd
+    from heamd import sharding
+
+    for total in (0, 1, 5, 128, 4097):
+        for members in (1, 2, 3, 8):
+            for member in range(members):
+                assert heamd.shard_bounds(total, members, member) == sharding.shard_bounds(total, members, member)
+    for bad in ((4, 0, 0), (4, 2, 2)):
+        with pytest.raises(heamd.HeError) as err:
+            heamd.shard_bounds(*bad)
+        assert err.value.name == "invalidArgument"
