@@ -53,6 +53,10 @@ PRE_ROLL_S = 0.25  # untimed set-up run of the job before the W warm-up steps (r
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 HBM_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md: measured float4 streaming copy (79 % of peak)
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+VALU_PROFILE = os.path.join(ROOT, "profiles", "r06_c3_valu.json")  # bench_tools/valu_json.py
+# lane instructions per second of one opcode alone at 8 waves per SIMD, measured by bench_tools/microbench on an MI355X
+# (profiles/r06i_microbench.txt) -- what valu_roofline() falls back to when the tool cannot be run beside the bench
+RECORDED_RATES_T = {"v_mad_u64_u32": 35.743, "v_add_u32": 61.507}
 ROOFLINE_WARMUPS, ROOFLINE_LAUNCHES = 10, 30  # >= 10 warm-ups, median of >= 30 launches
 
 
@@ -68,6 +72,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="polynomials in the CPU sample (0 = auto)")
     ap.add_argument("--skip-gather", action="store_true")
+    ap.add_argument("--device-group", type=int, default=0,
+                    help="c5 in ONE process over a he_device_group of this many members (the visible GPUs in turn; all on GPU 0 "
+                         "when there is one): the C ABI's own multi-GPU split instead of one process per GPU")
     ap.add_argument("--skip-other-configs", action="store_true", help="do not time configs 3-5 (extras only)")
     return ap.parse_args()
 
@@ -145,6 +152,69 @@ def profiled_traffic(key, algorithmic_bytes_per_unit=None):
                   f"accesses only; MI355X_MICROARCH.md)", file=sys.stderr)
             return None
     return entry
+
+
+_INSTRUCTION_RATES = None
+
+
+def instruction_rates():
+    """({opcode: T lane instructions / s at 8 waves per SIMD}, live?) from bench_tools/microbench run on this GPU now (a second
+    of dependent-free chains per opcode); the recorded rates when the binary is missing or fails."""
+    global _INSTRUCTION_RATES
+    if _INSTRUCTION_RATES is None:
+        import re
+        import subprocess
+
+        rates, live = dict(RECORDED_RATES_T), False
+        tool = os.path.join(ROOT, "bench_tools", "microbench")
+        try:
+            text = subprocess.run([tool], capture_output=True, text=True, timeout=120, check=True).stdout
+            found = {m.group(1): float(m.group(2))
+                     for m in re.finditer(r"^(\S+)\s+waves/SIMD=8\s.*Tlane_instr/s=([0-9.]+)", text, re.M)}
+            if all(k in found for k in rates):
+                rates, live = {k: found[k] for k in rates}, True
+        except Exception as err:  # noqa: BLE001
+            print(f"bench.py: {tool} did not run ({err}); recorded instruction rates used", file=sys.stderr)
+        _INSTRUCTION_RATES = (rates, live)
+    return _INSTRUCTION_RATES
+
+
+def valu_roofline(products_per_s):
+    """The vector-ALU roofline of ct x ct + relinearize: what binds the pipeline is 64-bit integer multiply issue, not HBM
+    (DESIGN.md 4.3).  Numerator: the VALU wave instructions per product the rocprofv3 --pmc pass counted on the pipeline's
+    seven kernels (SQ_INSTS_VALU, SQ_INSTS_VALU_INT64, SQ_INSTS_VALU_INT32 -- profiles/r06_c3_valu.json, replayed like the HBM
+    counter bytes: `counts_live` false).  Denominator: this GPU's measured issue rates -- 64-bit integer instructions at the
+    v_mad_u64_u32 rate, every other VALU instruction at the v_add_u32 rate.  `frac` is the 64-bit-integer instruction stream
+    alone against its rate; `issue_frac` the whole VALU stream against the time the part needs to issue it."""
+    try:
+        with open(VALU_PROFILE) as f:
+            counts = json.load(f)
+    except OSError:
+        return None
+    missing = kernels_in_library(counts.get("kernel") or [])
+    if missing:
+        print(f"bench.py: ignoring {VALU_PROFILE}: counted on kernels the library no longer has: {missing}", file=sys.stderr)
+        return None
+    rates, live = instruction_rates()
+    int64 = counts["int64_wave_instructions_per_product"] * 64
+    other = (counts["valu_wave_instructions_per_product"] - counts["int64_wave_instructions_per_product"]) * 64
+    achieved = int64 * products_per_s / 1e12
+    issue_s_per_product = int64 / (rates["v_mad_u64_u32"] * 1e12) + other / (rates["v_add_u32"] * 1e12)
+    return {
+        "bound": "valu",
+        "unit": "T lane-instr/s",
+        "achieved": achieved,                       # 64-bit integer VALU instructions (multiply-adds, 64-bit adds / shifts)
+        "peak": rates["v_mad_u64_u32"],
+        "frac": achieved / rates["v_mad_u64_u32"],
+        "issue_frac": issue_s_per_product * products_per_s,
+        "products_per_s_at_issue_rate": 1.0 / issue_s_per_product,
+        "int64_lane_instructions_per_product": int64,
+        "valu_lane_instructions_per_product": int64 + other,
+        "other_rate": rates["v_add_u32"],
+        "rates_live": live,
+        "counts_live": False,
+        "counts_source": counts.get("source"),
+    }
 
 
 def time_kernel(torch, fn, reps, warmups=0):
@@ -533,6 +603,8 @@ class CtMulWorkload:
         }
         if rank == 0:  # is the pipeline at the socket's power cap too?  (rocm-smi while it runs back to back)
             roofline["under_load"] = clocks_under_load(torch, lambda: (mul(), relin()), seconds=3.0, launches_per_sync=4)
+        # the roofline that binds: vector-ALU issue (the HBM figures above are the contract's line, 0.04 of its peak)
+        roofline["valu"] = valu_roofline(self.units / t_both)
         extras = {"ct_mul_per_s": self.units / t_mul, "relinearize_per_s": self.units / t_relin}
         return roofline, extras
 
@@ -616,6 +688,32 @@ class PirDim0Workload:
         self.query = synthetic_slab(torch, moduli, (self.D0, 2), DEGREE, 5)  # replicated on every rank (same seed)
         # this rank's columns of the database: plaintext k of column c at [c][k] (MulPir.swift:547-555)
         self.database = synthetic_slab(torch, moduli, (self.columns, self.D0), DEGREE, 600 + rank)
+        # --device-group K: the same columns split over the K members of a he_device_group in this one process (members on
+        # the visible GPUs in turn; the per-GPU share of the database stays what the contract's c5 line streams per GPU)
+        self.group = self.shards = None
+        self.members = getattr(args, "device_group", 0)
+        if self.members:
+            if world != 1:
+                raise SystemExit("--device-group is the single-process mode: run it without torchrun")
+            visible = torch.cuda.device_count()
+            devices = [m % visible for m in range(self.members)]
+            gpus = len(set(devices))
+            if gpus > 1:  # more GPUs: more columns, the same share per GPU
+                self.total_columns = self.columns = self.columns_per_gpu * gpus
+                self.database = None
+            self.group = heamd.DeviceGroup(devices, DEGREE, 557057, q)
+            self.shards = []
+            for m, device in enumerate(devices):
+                begin, end = self.group.bounds(self.columns, m)
+                if end == begin:
+                    self.shards.append(None)
+                elif self.database is not None:
+                    self.shards.append(self.database[begin:end])  # one GPU: views of the one slab
+                else:
+                    with torch.cuda.device(device):
+                        self.shards.append(synthetic_slab(torch, moduli, (end - begin, self.D0), DEGREE, 600 + m))
+            torch.cuda.set_device(devices[0])
+            self.group_devices = devices
         self.units = self.columns * self.D0
         self.db_bytes = self.units * len(moduli) * DEGREE * 8
         self.out = None
@@ -628,7 +726,11 @@ class PirDim0Workload:
 
     def step(self):
         # this rank's columns: the ct x pt inner products and their inverse NTT (he_pir_dim0_columns_device)
-        self.out = self.ctx.pir_dim0_columns(self.query, self.database)
+        if self.group is not None:
+            # he_pir_dim0_columns_group: every member its columns on its own stream, gathered on member 0's device
+            self.out = self.group.pir_dim0_columns(self.query, self.shards, self.columns)
+        else:
+            self.out = self.ctx.pir_dim0_columns(self.query, self.database)
 
     def result(self):
         return self.out, self.total_columns
@@ -653,8 +755,11 @@ class PirDim0Workload:
                 "moduli": self.q,
                 "rows": self.D0,
                 "columns_per_gpu": self.columns_per_gpu,
-                "parallelism": "database sharded by column over %d GPU(s), query replicated, no data-path collective; "
-                               "the all-gather of the column results is timed separately" % world,
+                "parallelism": ("one process, he_device_group of %d members on devices %s: database sharded by column over the "
+                                "members, query replicated, the members' columns gathered on member 0's device inside the "
+                                "timed call" % (self.members, self.group_devices)) if self.group is not None else (
+                               "database sharded by column over %d GPU(s), query replicated, no data-path collective; "
+                               "the all-gather of the column results is timed separately" % world),
             },
         }
 

@@ -1,4 +1,5 @@
-"""Small fixed workload for rocprofv3 counter passes: N=8192, L=4, 4096 polys, forward+inverse, auto and wide."""
+"""Small fixed workload for rocprofv3 counter passes: N=8192, L=4, 4096 polys, forward+inverse, auto and wide
+(NTT_DEGREE / NTT_BATCH in the environment: another ring size, e.g. 16384 / 1024)."""
 import os
 import sys
 
@@ -12,7 +13,7 @@ import heamd  # noqa: E402
 
 heamd.set_scratch_cache()  # a server's setting: the library keeps its freed scratch (he_set_scratch_cache)
 
-degree, bits, batch = 8192, [55] * 4, 4096
+degree, bits, batch = int(os.environ.get("NTT_DEGREE", "8192")), [55] * 4, int(os.environ.get("NTT_BATCH", "4096"))
 moduli = heamd.generate_primes(bits, False, degree)
 ctx = heamd.PolyContext(degree, moduli)
 bound = torch.tensor(moduli, dtype=torch.int64, device="cuda").view(1, len(moduli), 1)

@@ -121,6 +121,9 @@ def config3_ct_mul(torch, heamd, batch=1024, reps=5):
     t_relin = _timed(torch, relin, reps)
     t_both = _timed(torch, both, reps)
     compulsory = 1_572_864  # read 2 cts x 2 polys + write 2 polys
+    import bench
+
+    valu = bench.valu_roofline(batch / t_both) or {}
     return {
         "batch": batch,
         "spread_ms": {"ct_mul": t_mul.spread, "relinearize": t_relin.spread, "ct_mul_relinearize": t_both.spread},
@@ -129,6 +132,11 @@ def config3_ct_mul(torch, heamd, batch=1024, reps=5):
         "ct_mul_relinearize_per_s": batch / t_both,
         "compulsory_GBps": compulsory * batch / t_both / 1e9,
         "frac_of_8TBps_at_compulsory_bytes": compulsory * batch / t_both / 8e12,
+        # the binding roofline (bench.py valu_roofline): the pipeline's 64-bit integer instruction stream against the measured
+        # v_mad_u64_u32 rate, and its whole VALU stream against the time the part needs to issue it
+        "valu_frac": valu.get("frac"),
+        "valu_issue_frac": valu.get("issue_frac"),
+        "valu": valu or None,
         # counter-measured HBM bytes per product (rocprofv3 --pmc passes, profiles/) at this run's rate
         "measured_bytes_per_product": (_profiled("c3_ct_mul_relinearize") or {}).get("hbm_bytes_per_unit"),
         "traffic_GBps": ((_profiled("c3_ct_mul_relinearize") or {}).get("hbm_bytes_per_unit", 0) * batch / t_both / 1e9

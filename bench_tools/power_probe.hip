@@ -1,7 +1,8 @@
 // power_probe.hip -- the two halves of the forward NTT on their own, each for a given number of seconds, so that rocm-smi
 // can be sampled beside them (bench_tools/power_probe.py): register-resident limb-wise butterflies at full occupancy (no
 // memory), and the streaming copy of a 1 GiB slab at the transform's access width (8 bytes per lane, non-temporal).
-//   hipcc --offload-arch=gfx950 -O3 -o power_probe power_probe.hip ;  ./power_probe butterflies|copy SECONDS
+//   hipcc --offload-arch=gfx950 -O3 -o power_probe power_probe.hip ;  ./power_probe butterflies|fold|copy SECONDS
+// (butterflies: the limb-wise products of rounds 2-4; fold: the shift-folded products the transforms run on since round 5)
 // Prints the sustained rate: T butterflies/s, or TB/s read + written.
 #include <hip/hip_runtime.h>
 
@@ -48,6 +49,39 @@ __global__ void __launch_bounds__(256) butterflies(uint64_t* out, uint64_t p, in
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
+// the production arithmetic since round 5: the product folded by a shift (fold_mul, 5 multiply-adds, no factors), sums
+// never brought back (the mask below stands in for the transform's bounded growth)
+__global__ void __launch_bounds__(256) butterflies_fold(uint64_t* out, uint64_t p, int iters) {
+    uint64_t v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = (0x9E3779B97F4A7C15ull * (r + 1) + threadIdx.x * 977u + blockIdx.x) % p;
+    const uint64_t w = (0xD1B54A32D192ED03ull * (threadIdx.x + 1)) % p;
+    const uint64_t wt = static_cast<uint64_t>((static_cast<unsigned __int128>(w) << 32) % p);
+    const FoldConstants fc = fold_constants<false>(p);
+    const uint64_t half_bound = 8 * p;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int stride = 8 >> j;
+#pragma unroll
+            for (int base = 0; base < 16; base += 2 * stride)
+#pragma unroll
+                for (int o = 0; o < stride; ++o) {
+                    const uint64_t x = v[base + o], y = v[base + o + stride];
+                    const uint64_t r = fold_mul<false, false>(y, w, wt, fc);
+                    v[base + o] = x + r;
+                    v[base + o + stride] = x + half_bound - r;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] &= 0x00FFFFFFFFFFFFFFull;
+    }
+    uint64_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum ^= v[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 __global__ void __launch_bounds__(256) copy8(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t words) {
     for (size_t i = blockIdx.x * size_t(256) + threadIdx.x; i < words; i += size_t(gridDim.x) * 256)
         __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
@@ -60,13 +94,17 @@ int main(int argc, char** argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    if (strcmp(argv[1], "butterflies") == 0) {
+    if (strcmp(argv[1], "butterflies") == 0 || strcmp(argv[1], "fold") == 0) {
+        const bool fold = strcmp(argv[1], "fold") == 0;
         const int blocks = prop.multiProcessorCount * 8, iters = 2000;
         uint64_t* out;
         CHECK(hipMalloc(&out, size_t(blocks) * 256 * 8));
         double done = 0;
         while (elapsed() < seconds) {
-            for (int k = 0; k < 8; ++k) butterflies<<<blocks, 256>>>(out, 36028797018652673ull, iters);
+            for (int k = 0; k < 8; ++k) {
+                if (fold) butterflies_fold<<<blocks, 256>>>(out, 36028797018652673ull, iters);
+                else butterflies<<<blocks, 256>>>(out, 36028797018652673ull, iters);
+            }
             CHECK(hipDeviceSynchronize());
             done += 8.0 * blocks * 256 * iters * 32;
         }

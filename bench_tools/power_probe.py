@@ -72,23 +72,53 @@ def main():
             launches += 200
         return "forward NTT %.4f ms per launch" % ((time.perf_counter() - t0) / launches * 1e3)
 
+    variant = os.path.join(ROOT, "swift-homomorphic-encryption_amd", "lib", "variants", "libhe_amd_timing_only_no_butterflies.so")
+    transform_script = (
+        "import sys, time; sys.path[:0] = [%r, %r]; import torch, heamd\n"
+        "moduli = heamd.generate_primes([55] * 4, False, 8192); ctx = heamd.PolyContext(8192, moduli)\n"
+        "bound = torch.tensor(moduli, dtype=torch.int64, device='cuda').view(1, -1, 1)\n"
+        "slab = torch.randint(0, 1 << 62, (4096, 4, 8192), dtype=torch.int64, device='cuda') %% bound\n"
+        "n, t0 = 0, time.perf_counter()\n"
+        "while time.perf_counter() - t0 < %f:\n"
+        "    for _ in range(200): ctx.forward_ntt_(slab)\n"
+        "    torch.cuda.synchronize(); n += 200\n"
+        "print('forward NTT %%.4f ms per launch' %% ((time.perf_counter() - t0) / n * 1e3))\n"
+        % (ROOT, os.path.join(ROOT, "swift-homomorphic-encryption_amd"), SECONDS))
+
+    def rows_only():  # the transform's rows, exchanges and gathers without its butterflies (a TIMING-ONLY variant library)
+        env = dict(os.environ, HEAMD_LIBRARY=variant)
+        return subprocess.run([sys.executable, "-c", transform_script], capture_output=True, text=True, env=env).stdout.strip()
+
     legs = {}
-    for name, run in (("butterflies", binary("butterflies")), ("copy", binary("copy")), ("ntt", transform)):
+    runs = [("butterflies", binary("butterflies")), ("fold", binary("fold")), ("copy", binary("copy")), ("ntt", transform)]
+    if os.path.exists(variant):
+        runs.append(("rows only", rows_only))
+    for name, run in runs:
         legs[name] = measured(run)
         time.sleep(1.0)
         print("%-12s %-36s %6.0f MHz  %7.1f W  (%d samples)" % ((name,) + legs[name]))
-    rate_b = float(re.search(r"([0-9.]+) T/s", legs["butterflies"][0]).group(1)) * 1e12
     rate_c = float(re.search(r"([0-9.]+) TB/s", legs["copy"][0]).group(1)) * 1e12
     t_ntt = float(re.search(r"([0-9.]+) ms", legs["ntt"][0]).group(1)) * 1e-3
     butterflies_per_launch = 4096 * 4 * 13 * 4096  # rows x stages x N / 2
     bytes_per_launch = 2 * 4096 * 4 * 8192 * 8
-    t_b, t_c = butterflies_per_launch / rate_b, bytes_per_launch / rate_c
-    e_b, e_c, e_ntt = t_b * legs["butterflies"][2], t_c * legs["copy"][2], t_ntt * legs["ntt"][2]
-    cap = legs["ntt"][2]
-    print("one launch's butterflies alone: %.3f ms, %.3f J | its slab copied alone: %.3f ms, %.3f J | the transform: %.3f ms, %.3f J"
-          % (t_b * 1e3, e_b, t_c * 1e3, e_c, t_ntt * 1e3, e_ntt))
-    print("(E_butterflies + E_copy) / P(transform) = %.3f ms; max(t_butterflies, t_copy) = %.3f ms; measured %.3f ms"
-          % ((e_b + e_c) / cap * 1e3, max(t_b, t_c) * 1e3, t_ntt * 1e3))
+    t_c = bytes_per_launch / rate_c
+    e_c, e_ntt, cap = t_c * legs["copy"][2], t_ntt * legs["ntt"][2], legs["ntt"][2]
+    print("the transform: %.3f ms, %.3f J | its slab copied alone: %.3f ms, %.3f J" % (t_ntt * 1e3, e_ntt, t_c * 1e3, e_c))
+    for name, what in (("butterflies", "limb-wise products (rounds 2-4)"), ("fold", "shift-folded products (production)")):
+        rate_b = float(re.search(r"([0-9.]+) T/s", legs[name][0]).group(1)) * 1e12
+        t_b = butterflies_per_launch / rate_b
+        e_b = t_b * legs[name][2]
+        print("%s: one launch's butterflies alone %.3f ms, %.3f J; (E_butterflies + E_copy) / P(transform) = %.3f ms; "
+              "max(t_butterflies, t_copy) = %.3f ms; measured %.3f ms" % (what, t_b * 1e3, e_b, (e_b + e_c) / cap * 1e3,
+                                                                       max(t_b, t_c) * 1e3, t_ntt * 1e3))
+    if "rows only" in legs:
+        t_rows = float(re.search(r"([0-9.]+) ms", legs["rows only"][0]).group(1)) * 1e-3
+        e_rows = t_rows * legs["rows only"][2]
+        rate_b = float(re.search(r"([0-9.]+) T/s", legs["fold"][0]).group(1)) * 1e12
+        e_b = butterflies_per_launch / rate_b * legs["fold"][2]
+        print("rows, exchanges and gathers without butterflies: %.3f ms, %.3f J; + the fold butterflies' energy = %.3f J -> "
+              "%.3f ms at the transform's power; measured %.3f ms" % (t_rows * 1e3, e_rows, e_rows + e_b, (e_rows + e_b) / cap * 1e3,
+                                                                      t_ntt * 1e3))
 
 
 if __name__ == "__main__":

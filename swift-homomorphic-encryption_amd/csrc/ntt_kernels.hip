@@ -602,12 +602,27 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
 // N - 8192).  In the top-pass layout a lane's words i = r 1024 + tid of all sub-rows are 16 (32) contiguous bytes of
 // the row: the forward load and the inverse store move whole lines with 16-byte accesses.
 constexpr int kSubLogN = 13, kSubLogT = 10, kSubLogE = kSubLogN - kSubLogT;
+// The sub-rows' 8192-point transforms read lane-major stage blocks like the N = 8192 kernels (ntt_rows.hpp kLaneMajorTwiddles,
+// built by PolyContext::upload inside the degree's own tables): with the plain tables a wave's gather of one twiddle touches
+// every 2^g-th entry of a run, up to 64 cache lines for 1 KiB -- made-up twiddles showed the gathers cost the inverse 19 % and
+// the forward transform 8 % at N = 16384 (profiles/r06j_n16384_what_binds.txt).
+template <int MODE>
+constexpr int kInterleavedLaneMajor = (is_split(MODE) || is_fold(MODE)) ? 1 : 0;
 
 // forward cross stage c (global stage 13 + c) pairs sub-row bit LOGS - 1 - c; twiddle 2^(13+c) + (idx >> (LOGS - c))
+// Twiddles in flight: a cross stage's twiddles serve ONE butterfly per pair of sub-rows each (N = 16384: 8 gathers per lane, one
+// butterfly between two of them), so with one request ahead every gather's L2 round trip is waited out in full -- the shift-folded
+// products (4 registers per twiddle) keep kTwiddlesAhead of them in flight, the limb-wise ones (6) one.
+// (measured at N = 16384, profiles/r06n_n16384_cross_stage_prefetch_ab.txt: two or three limb-wise twiddles in flight spill
+// -- 16 / 40 B -- and lose 1 / 8 %; the first one requested before the row's loads: +-0)
+constexpr int kCrossAheadSplit = 1;
+constexpr bool kCrossEarlySplit = false;
+template <int MODE>
+constexpr int kCrossAhead = MODE == kModeFoldLazy ? 3 : (is_split(MODE) ? kCrossAheadSplit : 1);
 template <int LOGS, int MODE>
 __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
                                                      const Twiddles<MODE>& tw, uint64_t p) {
-    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R;
+    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, AHEAD = kCrossAhead<MODE>;
     static_assert(!is_split(MODE) || 1 + ((kSubLogN + LOGS) << Lazy<MODE>::kProductLog) <= 511, "growth stays below 2^9 p");
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const uint64_t half_bound = p << Lazy<MODE>::kProductLog;
@@ -621,12 +636,14 @@ __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 
             const uint32_t fixed = (1u << (kSubLogN + c)) + (register_part<kSubLogN, kSubLogE, 0, R>(r) << c) + upper;
             return fetch_twiddle<MODE, false>(tw, lane_words << c, fixed);
         };
-        TwiddleWords pending = request(0);
+        TwiddleWords ring[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) ring[a] = request(a < count ? a : count - 1);
 #pragma unroll
         for (int k = 0; k < count; ++k) {
-            const TwiddleWords w = pending;
-            if (k + 1 < count) {
-                pending = request(k + 1);
+            const TwiddleWords w = ring[k % AHEAD];
+            if (k + AHEAD < count) {
+                ring[k % AHEAD] = request(k + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int r = k >> c, upper = k & ((1 << c) - 1);
@@ -636,18 +653,38 @@ __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 
                 const int h = (upper << (LOGS - c)) | low;
                 forward_butterfly<MODE>(v[h][r], v[h + span][r], w, false, neg_p, half_bound, true, fc);
             }
-            if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
+            if (k + AHEAD < count) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // inverse cross stage c pairs sub-row bit c (element bit c): m = N >> (c + 1) groups, twiddle (N - 2m + 1) + (idx >> (c + 1))
 // PRIOR: the words enter in the lazy range of a row whose first PRIOR stages already ran (the fused loads' [0, 5p) words)
+// `head`: the first kTwiddlesAhead twiddles of stage 0, requested by the caller BEFORE it loads the row (inverse_cross_head): the
+// transform opens with this stage, and its gathers then travel beside the row's loads instead of starting behind them.
+template <int LOGS, int MODE>
+__device__ __forceinline__ TwiddleWords inverse_cross_twiddle(const Twiddles<MODE>& tw, uint32_t lane_words, int c, int k) {
+    constexpr int R = Schedule<kSubLogN, kSubLogE>::R;
+    constexpr uint32_t N = 1u << (kSubLogN + LOGS);
+    const uint32_t m = N >> (c + 1);
+    const int upper_bits = LOGS - 1 - c;  // sub-row bits above the paired one
+    const int r = k >> upper_bits, upper = k & ((1 << upper_bits) - 1);
+    const uint32_t fixed = (N - 2 * m + 1) + (register_part<kSubLogN, kSubLogE, 0, R>(r) << upper_bits) + upper;
+    return fetch_twiddle<MODE, false>(tw, lane_words << upper_bits, fixed);
+}
+template <int LOGS, int MODE>
+__device__ __forceinline__ void inverse_cross_head(TwiddleWords (&head)[kCrossAhead<MODE>], uint32_t tid, const Twiddles<MODE>& tw) {
+    constexpr int R = Schedule<kSubLogN, kSubLogE>::R;
+    const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
+#pragma unroll
+    for (int a = 0; a < kCrossAhead<MODE>; ++a) head[a] = inverse_cross_twiddle<LOGS, MODE>(tw, lane_words, 0, a);
+}
 template <int LOGS, int MODE, int PRIOR = 0>
 __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
-                                                     const Twiddles<MODE>& tw, uint64_t p) {
-    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog;
-    constexpr uint32_t N = 1u << (kSubLogN + LOGS);
+                                                     const Twiddles<MODE>& tw, uint64_t p,
+                                                     const TwiddleWords (&head)[kCrossAhead<MODE>]) {
+    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog, AHEAD = kCrossAhead<MODE>;
+    static_assert(AHEAD <= E, "the head twiddles are all of stage 0");
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const FoldConstants fc = mode_fold_constants<MODE>(p);
     const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
@@ -656,30 +693,27 @@ __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 
         const int in_shift = inverse_in_shift<MODE>(c + PRIOR);
         const uint64_t bound = p << in_shift;
         const bool fold = in_shift + 1 > H;
-        const uint32_t m = N >> (c + 1);
         const int upper_bits = LOGS - 1 - c;  // sub-row bits above the paired one
         const int count = E << upper_bits;
-        auto request = [&](int k) {
-            const int r = k >> upper_bits, upper = k & ((1 << upper_bits) - 1);
-            const uint32_t fixed = (N - 2 * m + 1) + (register_part<kSubLogN, kSubLogE, 0, R>(r) << upper_bits) + upper;
-            return fetch_twiddle<MODE, false>(tw, lane_words << upper_bits, fixed);
-        };
-        TwiddleWords pending = request(0);
+        TwiddleWords ring[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a)
+            ring[a] = c == 0 ? head[a] : inverse_cross_twiddle<LOGS, MODE>(tw, lane_words, c, a < count ? a : count - 1);
 #pragma unroll
         for (int k = 0; k < count; ++k) {
-            const TwiddleWords w = pending;
-            if (k + 1 < count) {
-                pending = request(k + 1);
+            const TwiddleWords w = ring[k % AHEAD];
+            if (k + AHEAD < count) {
+                ring[k % AHEAD] = inverse_cross_twiddle<LOGS, MODE>(tw, lane_words, c, k + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int r = k >> upper_bits, upper = k & ((1 << upper_bits) - 1);
+            const int upper = k & ((1 << upper_bits) - 1), r = k >> upper_bits;
             const int span = 1 << c;
 #pragma unroll
             for (int low = 0; low < span; ++low) {
                 const int h = (upper << (c + 1)) | low;
                 inverse_butterfly<MODE>(v[h][r], v[h + span][r], w, false, p, neg_p, bound, fold, fc, split_signed_bias(p));
             }
-            if (k + 1 < count) __builtin_amdgcn_sched_barrier(0);
+            if (k + AHEAD < count) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -808,7 +842,7 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const uint64_t p = mod.p;
-    const Twiddles<MODE> tw(ctx, false, mi, LOGD);
+    const Twiddles<MODE> tw(ctx, false, mi, LOGD, 0, kInterleavedLaneMajor<MODE>);  // (the cross stages' block is not permuted)
     const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
     uint64_t v[ROWS][E];
     if constexpr (SPREAD == kSourceRows) {
@@ -863,7 +897,6 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     static_assert(SOURCE == kInverseFromSlab || TENSOR || KEYMAC, "the key switch's end stays with the tiled kernel");
     static_assert(!TENSOR || SCALED, "the fused tensor load belongs to dropExtendedBase (t N^-1)");
     constexpr int INPUT_STAGES = (TENSOR || KEYMAC) && kLazyTransformInput<MODE> ? kLazyInputStages : 0;
-    constexpr bool LATE = KEYMAC && ROWS == 2;  // (ntt_rows.hpp step_lane)
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     const uint32_t tid = threadIdx.x;
     uint32_t record, within;
@@ -881,8 +914,13 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     const uint32_t mi = map.mod_base + within;
     const DeviceModulus mod = ctx.moduli[mi];
     const Twiddles<MODE> cross(ctx, true, mi, LOGD);
-    const Twiddles<MODE> tail(ctx, true, mi, LOGD, (1u << LOGD) - (1u << kSubLogN));
+    const Twiddles<MODE> tail(ctx, true, mi, LOGD, (1u << LOGD) - (1u << kSubLogN), kInterleavedLaneMajor<MODE>);
     const BufferResource row = make_resource(slab + (rows[0] << LOGD), 8u << LOGD);
+    // (before the row's loads where the registers allow it: the plain slab on the shift-folded products -- a fused load needs
+    // them for its operands, a limb-wise twiddle is 6 registers)
+    constexpr bool EARLY_HEAD = SOURCE == kInverseFromSlab && (MODE == kModeFoldLazy || kCrossEarlySplit);
+    TwiddleWords cross_head[kCrossAhead<MODE>];
+    if constexpr (EARLY_HEAD) inverse_cross_head<LOGS, MODE>(cross_head, tid, cross);
     uint64_t v[ROWS][E];
     if constexpr (TENSOR) {
         const size_t item = record / 3;
@@ -967,11 +1005,14 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
         if constexpr (kInterleavedStaged) interleaved_low_words_staged<LOGS, false>(v, tid, row, lds);
         else interleaved_low_words<LOGS, false>(v, tid, row);
     }
-    inverse_cross_stages<LOGS, MODE, INPUT_STAGES>(v, tid, cross, mod.p);
+    if constexpr (!EARLY_HEAD) inverse_cross_head<LOGS, MODE>(cross_head, tid, cross);
+    inverse_cross_stages<LOGS, MODE, INPUT_STAGES>(v, tid, cross, mod.p, cross_head);
     TwiddleWords head[1];
     inverse_row_head<kSubLogN, kSubLogE, MODE, false, 1>(head, tail, tid);
-    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS + INPUT_STAGES, LOGD>(v, tid, tail, mod, lds, head);
-    interleaved_top_words<LOGS, true>(v, tid, row);
+    // (two sub-rows on the shift-folded products: every step re-derives the lane index, as the key-MAC transforms -- step_lane)
+    constexpr bool LATE = ROWS == 2 && MODE == kModeFoldLazy;
+    inverse_row<kSubLogN, kSubLogE, MODE, ROWS, SCALED, LOGS + INPUT_STAGES, LOGD, false, 1, LATE>(v, tid, tail, mod, lds, head);
+    interleaved_top_words<LOGS, true>(v, LATE ? late_lane(tid) : tid, row);
 }
 
 // ---- any power-of-two degree: one workgroup per row, radix-2 stage loop over an LDS (or, for rows that do not

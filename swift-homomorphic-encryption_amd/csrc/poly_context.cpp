@@ -175,8 +175,12 @@ int PolyContext::upload() {
     const size_t bytes_inverse_q_last = round_up(count * count * sizeof(U64x2));
     // limb-wise Shoup form of both twiddle tables: pairs (16 B) and quotient factors (8 B) per entry
     const size_t bytes_factors = round_up(count * n * sizeof(u64));
-    // lane-major stage blocks for the tiled kernels with 8 words per lane (ntt_kernels.hip kLaneMajorTwiddles): N = 4096, 8192
-    const bool lane_major = log_degree_ == 12 || log_degree_ == 13;
+    // lane-major stage blocks for the tiled kernels with 8 words per lane (ntt_kernels.hip kLaneMajorTwiddles): N = 4096, 8192;
+    // N = 16384 / 32768: for the 8192-point transforms of the interleaved sub-rows (ntt_forward_interleaved /
+    // ntt_inverse_interleaved), which index the first 8192 entries of the forward table and the last 8192 of the inverse one
+    // exactly as an N = 8192 transform indexes its own
+    const bool sub_rows = log_degree_ == 14 || log_degree_ == 15;
+    const bool lane_major = log_degree_ == 12 || log_degree_ == 13 || sub_rows;
     const size_t total = bytes_moduli + (lane_major ? 9 : 5) * bytes_twiddles + bytes_inverse_q_last + (lane_major ? 5 : 2) * bytes_factors;
     HEAMD_HIP_TRY(hipMalloc(&device_block_, total));
     char* base = static_cast<char*>(device_block_);
@@ -203,7 +207,10 @@ int PolyContext::upload() {
         // [N - 2m + 1, N - m], m = N >> (b + 1).  Partitions (8 words per lane = passes of three bits): partial pass on the low
         // bits (every forward kernel, the fused inverse ones; N = 8192: 0 | 3-1 | 6-4 | 9-7 | 12-10, N = 4096: four full passes) or
         // on the top bit (the plain-slab inverse at N = 8192: 2-0 | 5-3 | 8-6 | 11-9 | 12).
-        const int logn = static_cast<int>(log_degree_);
+        // (interleaved sub-rows: the blocks of a 13-bit transform, found `region` entries into the table -- 0 for the forward
+        // table, N - 8192 for the inverse one; the entries outside them, which the cross stages read, stay where they are)
+        const int logn = sub_rows ? 13 : static_cast<int>(log_degree_);
+        const size_t sub_n = size_t(1) << logn;
         const int partial = logn % 3;  // width of the partial pass (0: none)
         auto top_low = [&](int b) { return b < partial ? partial - 1 : partial + ((b - partial) / 3) * 3 + 2; };
         auto top_top = [&](int b) { const int t = (b / 3) * 3 + 2; return t < logn ? t : logn - 1; };
@@ -212,8 +219,9 @@ int PolyContext::upload() {
             for (int b = 0; b < logn; ++b) {
                 const int g = (top_partition ? top_top(b) : top_low(b)) - b;
                 if (g == 0) continue;
-                const size_t m = inverse_direction ? (n >> (b + 1)) : (size_t(1) << (logn - 1 - b));
-                const size_t start = inverse_direction ? n - 2 * m + 1 : m;
+                const size_t m = inverse_direction ? (sub_n >> (b + 1)) : (size_t(1) << (logn - 1 - b));
+                const size_t region = inverse_direction ? n - sub_n : 0;
+                const size_t start = region + (inverse_direction ? sub_n - 2 * m + 1 : m);
                 for (size_t i = 0; i < count; ++i)
                     for (size_t o = 0; o < m; ++o)
                         out[i * n + start + (o & ((size_t(1) << g) - 1)) * (m >> g) + (o >> g)] = source[i * n + start + o];
@@ -242,7 +250,7 @@ int PolyContext::upload() {
                                         hipMemcpyHostToDevice));
                 HEAMD_HIP_TRY(hipMemcpy(lanes_factors + direction * bytes_factors, moved_factors.data(), count * n * sizeof(u64),
                                         hipMemcpyHostToDevice));
-                if (direction == 1) {
+                if (direction == 1 && !sub_rows) {
                     lane_major_copy(true, true, pairs, moved_pairs);
                     lane_major_copy(true, true, factors, moved_factors);
                     HEAMD_HIP_TRY(hipMemcpy(lanes_pairs + 3 * bytes_twiddles, moved_pairs.data(), count * n * sizeof(U64x2),

@@ -119,3 +119,18 @@ def test_integration_md_listings_are_excerpts_of_the_package():
         for piece in block.split("\n// ...\n"):  # an elision marker on its own line splits an excerpt
             piece = re.sub(r"\s+", " ", piece).strip()
             assert piece and piece in normalised, f"INTEGRATION.md shows Swift that is not in swift/:\n{piece[:300]}"
+
+
+def test_ci_recipe_names_what_is_missing():
+    """swift/ci.sh -- the one-command build + test of the package against a reference checkout -- refuses to start without
+    its prerequisites and says which ones (there is no Swift toolchain in this image: exit status 2, nothing built)."""
+    import shutil
+    import subprocess
+
+    script = os.path.join(SWIFT, "ci.sh")
+    assert os.access(script, os.X_OK)
+    if shutil.which("swift") is not None:
+        pytest.skip("a Swift toolchain is present: run swift/ci.sh itself")
+    result = subprocess.run(["bash", script, "/nonexistent/checkout"], capture_output=True, text=True)
+    assert result.returncode == 2
+    assert "no swift on PATH" in result.stderr and "no reference checkout at /nonexistent/checkout" in result.stderr
