@@ -52,7 +52,7 @@ BATCH = 4096
 PRE_ROLL_S = 0.25  # untimed set-up run of the job before the W warm-up steps (run_benchmark)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 HBM_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md: measured float4 streaming copy (79 % of peak)
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 VALU_PROFILE = os.path.join(ROOT, "profiles", "r06_c3_valu.json")  # bench_tools/valu_json.py
 # lane instructions per second of one opcode alone at 8 waves per SIMD, measured by bench_tools/microbench on an MI355X
 # (profiles/r06i_microbench.txt) -- what valu_roofline() falls back to when the tool cannot be run beside the bench
@@ -168,6 +168,8 @@ def instruction_rates():
         rates, live = dict(RECORDED_RATES_T), False
         tool = os.path.join(ROOT, "bench_tools", "microbench")
         try:
+            if os.environ.get("HEAMD_RECORDED_RATES"):  # (profile targets: no second program under the profiler)
+                raise RuntimeError("HEAMD_RECORDED_RATES is set")
             text = subprocess.run([tool], capture_output=True, text=True, timeout=120, check=True).stdout
             found = {m.group(1): float(m.group(2))
                      for m in re.finditer(r"^(\S+)\s+waves/SIMD=8\s.*Tlane_instr/s=([0-9.]+)", text, re.M)}

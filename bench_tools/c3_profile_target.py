@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "swift-homomorphic-encryption_amd"))
 sys.path.insert(0, os.path.join(ROOT, "bench_tools"))
+os.environ.setdefault("HEAMD_RECORDED_RATES", "1")  # no tool in a child process under the profiler
 import torch  # noqa: E402
 
 import heamd  # noqa: E402

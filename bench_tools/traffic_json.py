@@ -1,4 +1,4 @@
-"""Builds profiles/r05_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
+"""Builds profiles/r06_pmc_traffic.json (read by bench.py / path_bench.py) from the per-kernel traffic.json files that
 bench_tools/pmc_traffic.py leaves in the PMC pass directories of the four workloads.
 
   python bench_tools/traffic_json.py <ntt-dir> <c3-dir> <c4-dir> <c5-dir> <out.json>
@@ -29,7 +29,7 @@ def bytes_per_dispatch(report, needle, exclude=()):
 
 def main():
     ntt_dir, c3_dir, c4_dir, c5_dir, out = sys.argv[1:6]
-    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r05_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
+    source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench_tools/r06_final.sh -> pmc_traffic.py), FETCH_SIZE x2 on gfx950"
     result = {}
     ntt = load(ntt_dir)
     forward, names = bytes_per_dispatch(ntt, "ntt_forward_tiled")
@@ -44,7 +44,10 @@ def main():
     # round 5 the Bsk band of the row-fused kernel and the floor go in two parts of the batch: 2 each).
     mul_kernels = ("lift_kernel", "floor_kernel", "behz_rows_fused", "ntt_forward_tiled<13, 10, 3, 3", "ntt_forward_tiled<13, 10, 4, 3", "ntt_forward_tiled<13, 10, 6, 0",
                    "ntt_inverse_tiled<13, 10, 6, 1", "ntt_inverse_tiled<13, 10, 7, 1", "ntt_inverse_tiled<13, 10, 4, 1", "tensor_kernel")
-    rows = {k: r for k, r in c3.items() if not (k.startswith("_") or "at::" in k or "rocclr" in k)}
+    # (only the pipeline's own kernels: the profile target may have run other device code beside it -- PyTorch's generators, a
+    # tool in a child process)
+    pipeline = ("lift_kernel", "floor_kernel", "behz_rows_fused", "ntt_forward_", "ntt_inverse_", "tensor_", "key_switch_")
+    rows = {k: r for k, r in c3.items() if any(k.startswith(name) for name in pipeline)}
     is_mul = {k: any(m in k for m in mul_kernels) for k in rows}
     calls = {True: min((r["dispatches"] for k, r in rows.items() if is_mul[k]), default=1),
              False: min((r["dispatches"] for k, r in rows.items() if not is_mul[k]), default=1)}

@@ -6,7 +6,9 @@ hipcc cross-compiles without a GPU.  Objects go to csrc/build/, the library to l
 shipped to the GPU box with the repo snapshot).
 """
 import concurrent.futures
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -47,14 +49,40 @@ def _dependencies(depfile):
     text = text.replace("\\\n", " ")
     if ":" not in text:
         return None
-    return [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in text.split(":", 1)[1].split() if d]
+    # make's escapes: a space inside a path is written "\\ " -- split on unescaped whitespace only
+    names = [n.replace("\\ ", " ") for n in re.findall(r"(?:\\ |\S)+", text.split(":", 1)[1])]
+    return [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in names if d]
+
+
+_COMPILER_ID = None
+
+
+def _command_stamp(cmd):
+    """What an object was built with: the full compile command and the compiler's own version string.  A change of FLAGS,
+    ARCH or hipcc (a ROCm upgrade: -MMD does not list system headers) rebuilds the object even though no source moved."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            _COMPILER_ID = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            _COMPILER_ID = "unknown"
+    return hashlib.sha256(("\0".join(cmd) + "\0" + _COMPILER_ID).encode()).hexdigest()
 
 
 def _compile(src, force, header_time):
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
     dep = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".d")
+    stamp_path = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".cmd")
     path = os.path.join(CSRC, src)
-    if not force and os.path.exists(obj):
+    cmd = [_hipcc(), *FLAGS, "-MMD", "-MF", dep, "-c", path, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd[1:1] = ["-x", "hip"]
+    stamp = _command_stamp(cmd)
+    try:
+        same_command = open(stamp_path).read() == stamp
+    except OSError:
+        same_command = False
+    if not force and same_command and os.path.exists(obj):
         built = os.path.getmtime(obj)
         deps = _dependencies(dep)
         if deps is not None:
@@ -64,12 +92,11 @@ def _compile(src, force, header_time):
                 return obj, False
         elif built >= max(os.path.getmtime(path), header_time):
             return obj, False
-    cmd = [_hipcc(), *FLAGS, "-MMD", "-MF", dep, "-c", path, "-o", obj]
-    if src.endswith(".cpp"):
-        cmd[1:1] = ["-x", "hip"]
     result = subprocess.run(cmd, capture_output=True, text=True)
     if result.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{result.stdout}\n{result.stderr}")
+    with open(stamp_path, "w") as f:
+        f.write(stamp)
     return obj, True
 
 

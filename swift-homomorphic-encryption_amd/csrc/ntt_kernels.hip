@@ -1542,7 +1542,8 @@ hipError_t launch_ntt_lifted_forward(uint64_t* slab, const DeviceContext& ctx, u
         case 12: e = launch_forward_tiled<12, 9, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
         case 13: e = launch_forward_tiled<13, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
         case 14: e = launch_forward_tiled<14, 10, kSourceRows>(kModeSplit, slab, ctx, 0, source_moduli, rows, src, stream, record_rows, 0); break;
-        default: e = launch_interleaved_forward<2, kSourceRows>(kModeSplit, slab, ctx, make_row_map(0, source_moduli, record_rows, 0), rows, src, stream); break;
+        case 15: e = launch_interleaved_forward<2, kSourceRows>(kModeSplit, slab, ctx, make_row_map(0, source_moduli, record_rows, 0), rows, src, stream); break;
+        default: return hipErrorNotSupported;  // (ntt_lifted_forward_supported says so first; a new degree must be named here)
     }
     if (e != hipSuccess) return e;
     return launch_ntt_band(false, slab, ctx, source_moduli, record_rows - source_moduli, record_rows, source_moduli, records,
