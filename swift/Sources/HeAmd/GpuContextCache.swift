@@ -65,13 +65,14 @@ final class GpuContextCache: @unchecked Sendable {
     }
 }
 
-/// The library's scratch pool on the current HIP device (include/he_amd.h `he_set_scratch_cache`).  By default nothing is
-/// retained: scratch of the multi-kernel calls returns to the driver at the next synchronisation.  A server that expands
-/// queries opts in ONCE with a bound it chooses -- a batched expansion takes tens of gigabytes, and mapping them anew costs
-/// a second per call -- and hands the memory back with `trimScratch` when it goes idle.  The package never opts in on the
-/// host's behalf.
+/// The library's scratch on the current HIP device (include/he_amd.h `he_set_scratch_cache`).  By default nothing is retained
+/// (a HIP memory pool with release threshold 0) -- and a call that took scratch returns one call late, because `hipFreeAsync`
+/// waits for the work before the block's previous release.  A server opts in ONCE with a bound it chooses: the library then
+/// keeps released scratch in its own stream-ordered block cache, its calls are enqueue-only, and a batched expansion's tens of
+/// gigabytes are not mapped anew per call.  `trimScratch` hands the memory back when the server goes idle.  The package never
+/// opts in on the host's behalf.
 public enum HeAmdScratch {
-    /// Lets the current device's pool keep up to `bytes` of freed scratch (`UInt64.max`: everything).
+    /// Lets the library keep up to `bytes` of released scratch on the current device (`UInt64.max`: everything).
     public static func setScratchCache(bytes: UInt64) throws {
         try heAmdCheck(he_set_scratch_cache(bytes))
     }
