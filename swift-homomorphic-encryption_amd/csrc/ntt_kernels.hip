@@ -1101,13 +1101,17 @@ __global__ void __launch_bounds__(256)
 // consecutive records -- one modulus, every twiddle fetched once for both.
 // Where the shift-folded products (ntt_common.hpp kModeFoldLazy) replace the limb-wise Shoup ones for launches whose moduli
 // are all of the form 2^b - d (DeviceContext::shift_prefix): every kernel of the 8-words-per-lane shapes at N = 4096 / 8192 --
-// plain slabs and the fused loads, both directions -- and the Q band of the row-fused ct x ct kernel (behz_kernels.hip).  Not the
-// interleaved sub-rows of N = 16384 / 32768, which measured the same either way (profiles/r05af_fold_lazy_interleaved_ab.txt).
+// plain slabs and the fused loads, both directions -- and the Q band of the row-fused ct x ct kernel (behz_kernels.hip); since
+// round 6 the interleaved sub-rows of N = 16384 / 32768 too, where every modulus of the launch qualifies (at N = 16384 only the
+// first two of the standard 55-bit primes do: with 4-register twiddles the cross stages keep three in flight and the inverse
+// requests its first ones before the row's loads -- forward -4 %, inverse -3 % on two such moduli,
+// profiles/r06p_fold_interleaved_eligible_moduli_ab.txt; round 5's "the same either way" was measured on a context that did
+// not qualify).
 template <int LOGN, int LOGT>
 constexpr bool kFoldLazyForward = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
 template <int LOGN, int LOGT, int SOURCE>
 constexpr bool kFoldLazyInverse = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
-constexpr bool kFoldLazyInterleaved = false;
+constexpr bool kFoldLazyInterleaved = true;
 // every modulus of a launch is of the form 2^b - d (DeviceContext::shift_prefix)
 inline bool fold_lazy_band(const DeviceContext& ctx, const RowMap& map) {
     return map.band_rows != 0 && map.mod_base + map.band_rows <= ctx.shift_prefix;

@@ -665,14 +665,16 @@ def test_fused_transform_loads_other_degrees(oracle, degree, bits):
     assert np.array_equal(lifted, np.concatenate([ref.plaintext_to_eval(v) for v in values]).reshape(lifted.shape))
 
 
-@pytest.mark.parametrize("bits,batch", [([55, 55, 55, 55], 9), ([55, 41, 50, 55], 5), ([61, 45, 62, 55], 3), ([50, 55], 140)])
+@pytest.mark.parametrize("bits,batch", [([55, 55, 55, 55], 9), ([55, 41, 50, 55], 5), ([61, 45, 62, 55], 3), ([50, 55], 140),
+                                        ([55, 55], 7), ([55, 55, 54], 6)])
 def test_interleaved_fused_loads_at_16384(oracle, bits, batch):
     """N = 16384: the transforms with a fused load stage run as two interleaved sub-rows of the 8192-point kernel (round 5;
     ntt_forward_interleaved<1, MODE, kSourceSpread | kSourceLift | kSourceRows>, ntt_inverse_interleaved<1, MODE, ...,
     kInverseFromTensor | kInverseFromKeyMac>) -- ct x ct, relinearize, applyGalois' decomposition without the automorphism and
     Plaintext.convertToEvalFormat on odd batches: limb-wise moduli, moduli of very different sizes (the decomposition reduces
-    its source row first), 61 / 62-bit moduli (the [0, 8p) and the exact butterflies) and a batch wide enough for the key
-    switch's fused end on the other degrees.  Word for word against the oracle (EncryptionParameters.swift:200-206 allows the
+    its source row first), 61 / 62-bit moduli (the [0, 8p) and the exact butterflies), a batch wide enough for the key
+    switch's fused end on the other degrees, and moduli 2^b - d that all qualify for the shift-folded products (the first two
+    55-bit primes of the degree; a 54-bit one beside them): every fused load on those products.  Word for word against the oracle (EncryptionParameters.swift:200-206 allows the
     degree)."""
     from conftest import host_threads
 

@@ -393,15 +393,17 @@ def _primes_below_power_of_two(oracle, bits, degree, eligible, count=1):
     return found
 
 
-@pytest.mark.parametrize("degree", [4096, 8192])
+@pytest.mark.parametrize("degree", [4096, 8192, 16384, 32768])
 def test_shift_folded_products_at_the_edge_of_their_moduli(oracle, degree):
     """kModeFoldLazy (csrc/ntt_common.hpp): the transforms of moduli 2^b - d fold their products by a shift, which wants
     d < 2^(b-33).  The primes generatePrimes returns sit at the small end of d; these sit at the LARGE end (the product's
     bound 2^(b+2) + 2^33 d is nearly reached), next to primes just past the bound (limb-wise products) in the same context --
-    the launch then falls back as a whole -- and alone.  Extreme words in every residue."""
+    the launch then falls back as a whole -- and alone.  Extreme words in every residue.  N = 16384 / 32768: the interleaved
+    sub-row kernels on the same products (cross stages with three twiddles in flight)."""
     edge = [p for bits in (55, 54, 52, 50) for p in _primes_below_power_of_two(oracle, bits, degree, True)]
     past = [p for bits in (55, 52) for p in _primes_below_power_of_two(oracle, bits, degree, False)]
-    assert len(edge) >= 3 and len(past) == 2, (edge, past)
+    # (NTT-friendly primes are 2N apart: the larger degrees have fewer of them inside the bound)
+    assert len(edge) >= (3 if degree <= 8192 else 1) and len(past) == 2, (edge, past)
     rng = np.random.default_rng(degree)
     for moduli in (edge, edge[:1], edge[:2] + past[:1], past):
         ours, ref = heamd.PolyContext(degree, moduli), oracle.PolyContext(degree, moduli)
