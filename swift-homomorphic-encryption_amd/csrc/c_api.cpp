@@ -248,11 +248,26 @@ hipError_t heamd::scratch_allocate(void** out, size_t bytes, hipStream_t stream)
     return hipSuccess;
 }
 
+namespace {
+// (under the state's mutex) takes `ptr` back into `state`'s cache if it was lent from it
+bool release_into(ScratchState& state, void* ptr, hipStream_t stream);
+}  // namespace
+
 void heamd::scratch_release(void* ptr, hipStream_t stream) {
     if (ptr == nullptr) return;
     int device = 0;
-    if (current_device(&device)) {
-        ScratchState& state = scratch_state(device);
+    const bool known = current_device(&device);
+    if (known && release_into(scratch_state(device), ptr, stream)) return;
+    // a block of another device's cache (the caller changed the current device between the two ends of a call: the event is
+    // then recorded on a stream of the block's own device, which `stream` is)
+    for (int other = 0; other < kMaxDevices; ++other)
+        if (!(known && other == device) && release_into(scratch_state(other), ptr, stream)) return;
+    (void)hipFreeAsync(ptr, stream);  // from the HIP pool
+}
+
+namespace {
+bool release_into(ScratchState& state, void* ptr, hipStream_t stream) {
+    {
         std::lock_guard<std::mutex> lock(state.mutex);
         auto it = state.lent.find(ptr);
         if (it != state.lent.end()) {
@@ -271,16 +286,17 @@ void heamd::scratch_release(void* ptr, hipStream_t stream) {
                 (void)hipStreamSynchronize(stream);
                 (void)hipFree(ptr);
                 if (event != nullptr) state.spare_events.push_back(event);
-                return;
+                return true;
             }
             state.free_blocks.push_back(CachedBlock{ptr, bytes, stream, event, ++state.tick});
             state.cached_bytes += bytes;
             if (state.cached_bytes > state.limit) evict_locked(state, static_cast<size_t>(state.limit));
-            return;
+            return true;
         }
     }
-    (void)hipFreeAsync(ptr, stream);  // from the HIP pool
+    return false;
 }
+}  // namespace
 
 extern "C" {
 

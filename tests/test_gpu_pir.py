@@ -859,3 +859,39 @@ def test_device_group_equals_single_device(oracle, small, members, stage_all):
         heamd.DeviceGroup([], ref.degree, ref.t, ref.coefficient_moduli)
     with pytest.raises(heamd.HeError):
         heamd.DeviceGroup([99], ref.degree, ref.t, ref.coefficient_moduli)
+
+
+def test_device_group_at_the_benchmark_ring(oracle):
+    """The group path on the production kernels (N = 8192, L = 4: the replica-set inner product, the tiled inverse transform, the
+    row-fused ct x ct of the remaining dimension): 3 members on the one GPU, every member but the first through the staging
+    copies, 16 columns of 32 rows (a ragged 6 / 5 / 5 split) -- the gathered columns equal the single-device call's word for
+    word, the chunk response the single-device chunk response."""
+    import torch
+
+    degree, d0, columns = 8192, 32, 16
+    q = oracle.generate_primes([55] * 5, False, degree)
+    t = oracle.generate_primes([20], True, degree)[0]
+    ours = heamd.BfvContext(degree, t, q)
+    group = heamd.DeviceGroup([0, 0, 0], degree, t, q, stage_all=True)
+    rng = np.random.default_rng(77)
+    moduli = q[:-1]
+    dim0 = heamd.to_device(_uniform(rng, (d0, 2), moduli, degree))
+    rest = heamd.to_device(_uniform(rng, (columns, 2), moduli, degree))
+    key = heamd.to_device(_uniform(rng, (ours.L, 2), q, degree))
+    database = heamd.to_device(_uniform(rng, (columns, d0), moduli, degree))
+    present = (torch.arange(columns * d0, device="cuda") % 7 != 3).to(torch.uint8).view(columns, d0)
+    shards, masks = [], []
+    for m in range(3):
+        begin, end = group.bounds(columns, m)
+        shards.append(database[begin:end].contiguous())
+        masks.append(present[begin:end].contiguous())
+    assert [s.shape[0] for s in shards] == [6, 5, 5]
+    whole = ours.pir_dim0_columns(dim0, database, present_device=present)
+    split = group.pir_dim0_columns(dim0, shards, columns, present_shards=masks)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, split)
+    single = ours.pir_compute_response_chunk([d0, columns], dim0, rest, database.view(columns * d0, ours.L, degree),
+                                             present.view(-1).cpu().numpy(), key)
+    grouped = group.pir_compute_response_chunk([d0, columns], dim0, rest, shards, present_shards=masks, relinearization_key=key)
+    torch.cuda.synchronize()
+    assert torch.equal(single, grouped)
