@@ -626,7 +626,7 @@ int he_poly_context_copy_ntt_tables(const he_poly_context* ctx, uint32_t rns_ind
 int he_words_copy_device(const uint64_t* device_in, uint64_t* device_out, size_t words, int non_temporal, he_stream s);
 /* NTT with a named kernel schedule -- every accepted variant computes the same canonical transform (parity tests
  * pin each schedule against the oracle): 0 = auto (production), 1 = exact-quotient butterflies, 2 = generic radix-2
- * kernel, 3 = 16 words per lane, 8 = 32 words per lane, 10 = [0, 8p) butterflies.  Anything else:
+ * kernel, 3 = 16 words per lane, 10 = [0, 8p) butterflies.  Anything else:
  * HE_ERR_INVALID_ARGUMENT. */
 int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, size_t batch, int inverse, int variant,
                           he_stream stream);

@@ -608,7 +608,7 @@ int he_ntt_device_variant(const he_poly_context* ctx, uint64_t* device_slab, siz
     if (!pc.all_ntt(pc.moduli_count())) return HE_ERR_INVALID_NTT_MODULUS;
     switch (variant) {
         case heamd::kNttVariantAuto: case heamd::kNttVariantExact: case heamd::kNttVariantGeneric:
-        case heamd::kNttVariantWide: case heamd::kNttVariantTiled: case heamd::kNttVariantApprox: break;
+        case heamd::kNttVariantWide: case heamd::kNttVariantApprox: break;
         default: return invalid_argument("unknown NTT variant");
     }
     if (batch == 0) return HE_OK;

@@ -16,7 +16,6 @@ enum {
     kNttVariantExact = 1,    // same kernel, exact-quotient butterflies (what moduli >= 2^61 get)
     kNttVariantGeneric = 2,  // radix-2 stage loop (what degrees without a tiled kernel get)
     kNttVariantWide = 3,     // tiled kernel, 16 words per lane
-    kNttVariantTiled = 8,    // tiled kernel, 32 words per lane
     kNttVariantApprox = 10   // production kernel pinned to the [0, 8p) butterflies (what 56..61-bit moduli get)
 };
 

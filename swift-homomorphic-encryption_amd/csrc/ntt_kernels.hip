@@ -1356,7 +1356,7 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     const RowMap map = make_row_map(mod_base, mod_period, row_period, row_offset);
     // The fused loads and the scaled contexts of dropExtendedBase exist for the PRODUCTION shape of each degree only (8 words
     // per lane; N = 16384: 16): the 16- and 32-words-per-lane shapes are test variants of the plain transform
-    // (kNttVariantWide / kNttVariantTiled, public contexts only) -- instantiating every source for them was a hundred kernels
+    // (kNttVariantWide, public contexts only) -- instantiating every source for them was a hundred kernels
     // nobody could launch, the exact-mode ones among them with their register tile in scratch.
     constexpr bool FUSED_SHAPE = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10) || (LOGN == 14 && LOGT == 10);
     if constexpr (!FUSED_SHAPE) {
@@ -1658,7 +1658,7 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
     }
     switch (force_variant) {
         case kNttVariantAuto: case kNttVariantExact: case kNttVariantGeneric: case kNttVariantWide:
-        case kNttVariantTiled: case kNttVariantApprox: break;
+        case kNttVariantApprox: break;
         default: return hipErrorInvalidValue;
     }
     // kNttVariantExact / kNttVariantApprox pin the butterfly schedule (tests); every variant computes the same transform
@@ -1682,14 +1682,6 @@ hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, ui
             case 12: return launch_tiled<12, 8>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 13: return launch_tiled<13, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             case 14: return launch_tiled<14, 10>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
-            default: break;
-        }
-    }
-    if (force_variant == kNttVariantTiled) {  // 32 words per lane
-        switch (ctx.log_degree) {
-            case 12: return launch_tiled<12, 7>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
-            case 13: return launch_tiled<13, 8>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
-            case 14: return launch_tiled<14, 9>(inverse, mode, slab, ctx, mod_base, mod_period, rows, stream);
             default: break;
         }
     }

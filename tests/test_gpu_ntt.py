@@ -75,10 +75,10 @@ def test_ntt_matches_oracle(oracle, degree, bits, batch):
 
 
 @pytest.mark.parametrize("degree,bits", [(4096, [55, 55]), (8192, [55, 55, 55, 55]), (16384, [55, 55])])
-@pytest.mark.parametrize("variant", [1, 2, 3, 8, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 10])
 def test_ntt_kernel_variants_agree(oracle, degree, bits, variant):
     """Every named schedule computes the reference transform: exact-quotient butterflies (1), generic radix-2 kernel
-    (2), 16 words per lane (3), 32 words per lane (8), [0, 8p) butterflies (10)."""
+    (2), 16 words per lane (3), [0, 8p) butterflies (10)."""
     moduli = oracle.generate_primes(bits, False, degree)
     ours = heamd.PolyContext(degree, moduli)
     ref = oracle.PolyContext(degree, moduli)
@@ -114,7 +114,7 @@ def test_ntt_unknown_variant_is_rejected(oracle):
     moduli = oracle.generate_primes([55, 55], False, 8192)
     ours = heamd.PolyContext(8192, moduli)
     slab = heamd.to_device(np.zeros((1, 2, 8192), dtype=np.uint64))
-    for variant in (4, 9, 12, 16, 17, 48, 1040, -1):
+    for variant in (4, 8, 9, 12, 16, 17, 48, 1040, -1):
         with pytest.raises(heamd.HeError):
             ours.ntt_variant_(slab, False, variant)
 
