@@ -52,10 +52,10 @@ def test_threads_share_one_context(oracle):
 
 
 def test_row_fused_mul_shares_the_side_lane_and_is_capturable(oracle):
-    """ct x ct on batches that take the row-fused kernels with the Q band on the context's side lane (a second stream forked off
-    the caller's and joined back inside the call, bfv_api.cpp SideLane): four host threads on their own streams share one
-    context -- and one lane -- and every product equals the oracle's; the same call captured into a HIP graph (where the lane
-    is not used) replays on new operands."""
+    """ct x ct on batches that take the row-fused kernels with the Q band on a lane of the context (a second stream forked off
+    the caller's and joined back inside the call, csrc/side_lane.hpp): four host threads on their own streams share one
+    context -- each stream gets a lane of its own from the context's pool -- and every product equals the oracle's; the same
+    call captured into a HIP graph (where no lane is used) replays on new operands."""
     import torch
     from conftest import host_threads
 
