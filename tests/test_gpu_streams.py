@@ -333,3 +333,63 @@ def test_scratch_cache_is_enqueue_only_and_shared_by_streams(oracle):
         assert heamd.scratch_cached_bytes() == 0
     finally:
         heamd.set_scratch_cache(0)
+
+
+def test_scratch_cache_with_a_small_bound_evicts_and_stays_correct(oracle):
+    """he_set_scratch_cache(bytes) with a bound smaller than one call's scratch: released blocks beyond the bound go back to the
+    driver once their release has completed (blocks still in flight stay), two threads on their own streams keep calling through
+    it, every result is the oracle's, and what stays cached after a synchronisation and another release is within the bound."""
+    import torch
+
+    degree, batch = 4096, 96
+    q = oracle.generate_primes([55, 55, 55], False, degree)
+    t = oracle.generate_primes([17], True, degree)[0]
+    ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
+    moduli = q[:-1]
+    rng = np.random.default_rng(94)
+
+    def uniform(prefix, mods):
+        rows = [rng.integers(0, m, size=tuple(prefix) + (degree,), dtype=np.uint64) for m in mods]
+        return np.ascontiguousarray(np.stack(rows, axis=len(prefix)))
+
+    ct3, key = uniform((batch, 3), moduli), uniform((ours.L, 2), q)
+    expected = ref.relinearize(ct3, key)
+    ct3_device, key_device = heamd.to_device(ct3), heamd.to_device(key)
+    bound = 1 << 20
+    assert ours.relinearize_workspace_bytes(batch) > 4 * bound
+    heamd.trim_scratch(0)
+    heamd.set_scratch_cache(bound)
+    results, errors = {}, []
+
+    def worker(index):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                outs = [ours.relinearize(ct3_device, key_device, stream=stream) for _ in range(6)]
+                stream.synchronize()
+                results[index] = [heamd.to_host(o) for o in (outs[0], outs[-1])]
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    try:
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        for outs in results.values():
+            for out in outs:
+                assert np.array_equal(out, expected)
+        torch.cuda.synchronize()
+        last = ours.relinearize(ct3_device, key_device)  # its release evicts what has completed
+        torch.cuda.synchronize()
+        assert np.array_equal(heamd.to_host(last), expected)
+        once_more = ours.relinearize(ct3_device, key_device)
+        torch.cuda.synchronize()
+        assert np.array_equal(heamd.to_host(once_more), expected)
+        assert heamd.scratch_cached_bytes() <= ours.relinearize_workspace_bytes(batch) + (2 << 20)
+        heamd.trim_scratch(0)
+        assert heamd.scratch_cached_bytes() == 0
+    finally:
+        heamd.set_scratch_cache(0)
