@@ -481,6 +481,13 @@ int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, const uint32_t
                                        uint64_t* intermediate, const uint64_t* remaining_query,
                                        size_t remaining_query_count, const uint64_t* relinearization_key, uint64_t* out,
                                        he_stream s);
+/* he_pir_remaining_dimensions_device for `chunk_count` chunks at once: intermediate [chunk][columns][2][L][N] Coeff (consumed)
+ * -> out [chunk][2][1][N]; every stage one batch over the result groups of all chunks (what the chunk loop below runs after its
+ * dim-0 launch, for callers that produced the dim-0 results themselves: he_pir_compute_response_group). */
+int he_pir_remaining_dimensions_chunks_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                              uint32_t dimension_count, size_t chunk_count, uint64_t* intermediate,
+                                              const uint64_t* remaining_query, size_t remaining_query_count,
+                                              const uint64_t* relinearization_key, uint64_t* out, he_stream s);
 /* PirUtilProtocol.computeResponse's chunk loop for one query (PirUtil.swift:533-563): the database holds `chunk_count`
  * chunks of prod(dimensions) plaintexts each ([chunk][prod(dimensions)][L][N] Eval), the same expanded query serves
  * every chunk, out [chunk_count][2][1][N].  The chunks are independent (the reference maps them over tasks) and are
@@ -598,8 +605,16 @@ int he_ntt_inverse_group(he_device_group* group, uint32_t moduli_count, uint64_t
 int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query_eval, size_t d0,
                               const uint64_t* const* database_shards, const uint8_t* const* present_shards, size_t columns,
                               uint64_t* out, he_stream home_stream);
-/* computeResponseForOneChunk over the group: he_pir_dim0_columns_group, then he_pir_remaining_dimensions_device on the home
- * device (the remaining dimensions need every column).  remaining_query, relinearization_key, out: home. */
+/* computeResponseForOneChunk over the group (chunk_count = 1): he_pir_dim0_columns_group, then the remaining dimensions on the
+ * home device (they need every column).  remaining_query, relinearization_key, out: home. */
+/* The chunk loop of PirUtil.computeResponse (PirUtil.swift:533-563) over the group: the columns of all `chunk_count` chunks are
+ * one column range, sharded as above (database_shards[m] = member m's share of chunk_count x columns columns); one dim-0 pass
+ * per member, the gather, then he_pir_remaining_dimensions_chunks_device on the home device.  out (home) [chunk_count][2][1][N]. */
+int he_pir_compute_response_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
+                                  const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                                  size_t remaining_query_count, const uint64_t* const* database_shards,
+                                  const uint8_t* const* present_shards, size_t chunk_count,
+                                  const uint64_t* relinearization_key, uint64_t* out, he_stream home_stream);
 int he_pir_compute_response_chunk_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
                                         const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
                                         size_t remaining_query_count, const uint64_t* const* database_shards,

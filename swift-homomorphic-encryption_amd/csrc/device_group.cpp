@@ -262,19 +262,21 @@ int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query
     return HE_OK;
 }
 
-int he_pir_compute_response_chunk_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
-                                        const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
-                                        size_t remaining_query_count, const uint64_t* const* database_shards,
-                                        const uint8_t* const* present_shards, const uint64_t* relinearization_key,
-                                        uint64_t* out, he_stream home_stream) {
+int he_pir_compute_response_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
+                                  const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                                  size_t remaining_query_count, const uint64_t* const* database_shards,
+                                  const uint8_t* const* present_shards, size_t chunk_count,
+                                  const uint64_t* relinearization_key, uint64_t* out, he_stream home_stream) {
     if (group == nullptr) return invalid_argument("null group");
     if (dimensions == nullptr || dimension_count == 0) return invalid_argument("empty dimensions");
+    if (chunk_count == 0) return HE_OK;
     size_t per_chunk = 1;
     for (uint32_t i = 0; i < dimension_count; ++i) {
         if (dimensions[i] == 0) return invalid_argument("zero dimension");
         per_chunk *= dimensions[i];
     }
-    const size_t d0 = dimensions[0], columns = per_chunk / d0;
+    // the columns of all chunks are one column range (a chunk is [columns][d0] plaintexts, the chunks are contiguous)
+    const size_t d0 = dimensions[0], columns = per_chunk / d0 * chunk_count;
     const he_device_group::Member& home = group->members[0];
     const uint32_t L = he_bfv_ciphertext_moduli_count(home.ctx);
     const size_t n = he_poly_context_degree(he_bfv_ciphertext_context(home.ctx, L));
@@ -287,10 +289,21 @@ int he_pir_compute_response_chunk_group(he_device_group* group, const uint32_t* 
                                            home_stream);
     if (status == HE_OK) {
         HEAMD_HIP_TRY(hipSetDevice(home.device));
-        status = he_pir_remaining_dimensions_device(home.ctx, dimensions, dimension_count, results, remaining_query,
-                                                    remaining_query_count, relinearization_key, out, home_stream);
+        status = he_pir_remaining_dimensions_chunks_device(home.ctx, dimensions, dimension_count, chunk_count, results,
+                                                           remaining_query, remaining_query_count, relinearization_key, out,
+                                                           home_stream);
     }
     return status;
+}
+
+int he_pir_compute_response_chunk_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
+                                        const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
+                                        size_t remaining_query_count, const uint64_t* const* database_shards,
+                                        const uint8_t* const* present_shards, const uint64_t* relinearization_key,
+                                        uint64_t* out, he_stream home_stream) {
+    return he_pir_compute_response_group(group, dimensions, dimension_count, dim0_query_eval, remaining_query,
+                                         remaining_query_count, database_shards, present_shards, 1, relinearization_key, out,
+                                         home_stream);
 }
 
 }  // extern "C"

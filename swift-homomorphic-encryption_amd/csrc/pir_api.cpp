@@ -220,6 +220,21 @@ extern "C" int he_pir_remaining_dimensions_device(const he_bfv_context* ctx, con
                                 relinearization_key, out, s);
 }
 
+// The remaining dimensions of `chunk_count` chunks at once (the chunk loop's second half, for callers that produced the dim-0
+// results themselves -- a device group, device_group.cpp): intermediate [chunk][columns][2][L][N] Coeff (consumed) ->
+// out [chunk][2][1][N]; every stage one batch over the result groups of all chunks.
+extern "C" int he_pir_remaining_dimensions_chunks_device(const he_bfv_context* ctx, const uint32_t* dimensions,
+                                                         uint32_t dimension_count, size_t chunk_count, uint64_t* intermediate,
+                                                         const uint64_t* remaining_query, size_t remaining_query_count,
+                                                         const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (chunk_count == 0) return HE_OK;
+    if (intermediate == nullptr || out == nullptr) return invalid_argument("null operand");
+    return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunk_count, intermediate, remaining_query,
+                                relinearization_key, out, s);
+}
+
 extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
                                                     uint32_t dimension_count, const uint64_t* dim0_query_eval,
                                                     const uint64_t* remaining_query, size_t remaining_query_count,

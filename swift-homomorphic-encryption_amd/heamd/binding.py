@@ -61,6 +61,10 @@ SIGNATURES = [
     ("he_pir_dim0_columns_group", ctypes.c_int, [vp, vp, c_size, ctypes.POINTER(vp), ctypes.POINTER(vp), c_size, vp, vp]),
     ("he_pir_compute_response_chunk_group", ctypes.c_int, [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size,
                                                            ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp, vp]),
+    ("he_pir_compute_response_group", ctypes.c_int, [vp, ctypes.POINTER(c_u32), c_u32, vp, vp, c_size, ctypes.POINTER(vp),
+                                                     ctypes.POINTER(vp), c_size, vp, vp, vp]),
+    ("he_pir_remaining_dimensions_chunks_device", ctypes.c_int, [vp, ctypes.POINTER(c_u32), c_u32, c_size, vp, vp, c_size, vp,
+                                                                 vp, vp]),
     ("he_device_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
     ("he_device_free", ctypes.c_int, [vp]),
     ("he_host_malloc", ctypes.c_int, [ctypes.POINTER(vp), c_size]),
@@ -344,6 +348,23 @@ class DeviceGroup:
         masks = None if present_shards is None else self._shards(present_shards)
         _check(load_library().he_pir_dim0_columns_group(self.h, _ptr(dim0_query_eval), d0, self._shards(database_shards),
                                                         masks, columns, _ptr(out), _stream(stream)))
+        return out
+
+    def pir_compute_response(self, dimensions, dim0_query_eval, remaining_query, database_shards, chunk_count,
+                             present_shards=None, relinearization_key=None, stream=None):
+        """he_pir_compute_response_group: the chunk loop over the group; database_shards[m] = member m's share of the
+        chunk_count x columns columns of all chunks -> [chunks][2][1][N] on member 0's device."""
+        import torch
+
+        dims = (c_u32 * len(dimensions))(*[int(d) for d in dimensions])
+        out = torch.empty((chunk_count, 2, 1, self.degree), dtype=dim0_query_eval.dtype, device=dim0_query_eval.device)
+        rest = vp() if remaining_query is None else _ptr(remaining_query)
+        rest_count = 0 if remaining_query is None else remaining_query.numel() // (2 * self.L * self.degree)
+        key = vp() if relinearization_key is None else _ptr(relinearization_key)
+        masks = None if present_shards is None else self._shards(present_shards)
+        _check(load_library().he_pir_compute_response_group(self.h, dims, len(dims), _ptr(dim0_query_eval), rest, rest_count,
+                                                            self._shards(database_shards), masks, chunk_count, key,
+                                                            _ptr(out), _stream(stream)))
         return out
 
     def pir_compute_response_chunk(self, dimensions, dim0_query_eval, remaining_query, database_shards,

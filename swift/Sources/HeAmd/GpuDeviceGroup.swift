@@ -4,8 +4,8 @@
 // (Sources/PrivateInformationRetrieval/IndexPir/PirUtil.swift:424-445) made over devices.  Whole columns stay on one GPU, so
 // nothing is reduced across GPUs; the remaining dimensions (PirUtil.swift:448-485) run on the home device (member 0).
 //   GpuDeviceGroup            he_device_group: the members, he_shard_bounds, a member's device made current
-//   GpuShardedChunk           one chunk's plaintexts, member m holding its share of the columns (+ the nil mask), uploaded once
-//   GpuPirUtil.computeResponseForOneChunk(group:...)   PirUtil.swift:408-486 over the group, one C call
+//   GpuShardedChunk           the plaintexts of one or more chunks, member m holding its share of their columns (+ the nil mask), uploaded once
+//   GpuPirUtil.computeResponseForChunks(group:...)     PirUtil.swift:408-486 for every chunk over the group, one C call
 import CHeAmd
 import HomomorphicEncryption
 import PrivateInformationRetrieval
@@ -66,23 +66,25 @@ public final class GpuDeviceGroup: @unchecked Sendable {
     }
 }
 
-/// One chunk of a database -- `prod(dimensions)` optional Eval plaintexts, plaintext k of column c at index c * d0 + k
-/// (MulPir.swift:547-555) -- with member m of `group` holding its share of the columns in its own HBM.
+/// `chunkCount` chunks of a database -- each `prod(dimensions)` optional Eval plaintexts, plaintext k of column c at index
+/// c * d0 + k (MulPir.swift:547-555), the chunks back to back, so that their columns form ONE column range -- with member m of
+/// `group` holding its share of that range in its own HBM.
 public final class GpuShardedChunk<Scheme: HeScheme>: @unchecked Sendable where Scheme.Scalar == UInt64 {
     public let group: GpuDeviceGroup
     public let dimensions: [Int]
+    public let chunkCount: Int
     /// Per member: its columns' plaintexts `[share][d0][L][N]` and their nil mask (one byte per plaintext); nil = no column.
     let shards: [DeviceBuffer?]
     let masks: [DeviceBuffer?]
 
-    public init(_ dataChunk: some Collection<Plaintext<Scheme, Eval>?>, dimensions: [Int], polyContext: PolyContext<UInt64>,
-                group: GpuDeviceGroup) throws
+    public init(_ dataChunk: some Collection<Plaintext<Scheme, Eval>?>, dimensions: [Int], chunkCount: Int = 1,
+                polyContext: PolyContext<UInt64>, group: GpuDeviceGroup) throws
     {
         let polyWords = polyContext.moduli.count * polyContext.degree
         let perChunk = dimensions.reduce(1, *)
-        let d0 = dimensions[0], columns = perChunk / d0
-        precondition(dataChunk.count >= perChunk)
-        let plaintexts = Array(dataChunk.prefix(perChunk))
+        let d0 = dimensions[0], columns = perChunk / d0 * chunkCount
+        precondition(dataChunk.count >= perChunk * chunkCount)
+        let plaintexts = Array(dataChunk.prefix(perChunk * chunkCount))
         var shards: [DeviceBuffer?] = [], masks: [DeviceBuffer?] = []
         for member in 0..<group.count {
             let mine = try group.bounds(of: columns, member: member)
@@ -108,6 +110,7 @@ public final class GpuShardedChunk<Scheme: HeScheme>: @unchecked Sendable where 
         }
         self.group = group
         self.dimensions = dimensions
+        self.chunkCount = chunkCount
         self.shards = shards
         self.masks = masks
     }
@@ -122,16 +125,18 @@ public final class GpuShardedChunk<Scheme: HeScheme>: @unchecked Sendable where 
 }
 
 public extension GpuPirUtil {
-    /// `computeResponseForOneChunk` (PirUtil.swift:408-486) over a device group: the dim-0 inner products of every column on
-    /// the GPU that holds the column (PirUtil.swift:428-446), the columns gathered on the home device, the remaining
-    /// dimensions and `modSwitchDownToSingle` there (PirUtil.swift:448-485).  The queries and the key go to the home device.
-    static func computeResponseForOneChunk(
+    /// `computeResponseForOneChunk` (PirUtil.swift:408-486) for every chunk of `chunk` over a device group -- the chunk loop of
+    /// `computeResponse` (PirUtil.swift:533-563): the dim-0 inner products of every column on the GPU that holds the column
+    /// (PirUtil.swift:428-446), the columns gathered on the home device, the remaining dimensions and
+    /// `modSwitchDownToSingle` there (PirUtil.swift:448-485).  The queries and the key go to the home device.  One response
+    /// ciphertext per chunk.
+    static func computeResponseForChunks(
         group: GpuDeviceGroup,
         expandedDim0Query: [Ciphertext<Scheme, Eval>],
         expandedRemainingQuery: [CanonicalCiphertext],
         chunk: GpuShardedChunk<Scheme>,
         using evaluationKey: EvaluationKey<Scheme>,
-        callOptions _: CallOptions) async throws -> Ciphertext<Scheme, Coeff>
+        callOptions _: CallOptions) async throws -> [Ciphertext<Scheme, Coeff>]
     {
         guard let first = expandedDim0Query.first else {
             throw HeError.incompatibleCiphertextCount("empty dim-0 query")
@@ -139,6 +144,7 @@ public extension GpuPirUtil {
         let context = first.context
         let polyContext = first.polys[0].context
         let degree = polyContext.degree, polyWords = polyContext.moduli.count * degree
+        let chunkCount = chunk.chunkCount
         let columns = chunk.dimensions.reduce(1, *) / chunk.dimensions[0]
         precondition(columns == 1 || columns == expandedRemainingQuery.count) // PirUtil.swift:422
         let dimensions = chunk.dimensions.map { UInt32($0) }
@@ -159,13 +165,13 @@ public extension GpuPirUtil {
             if chunk.dimensions.count > 1, keys.relinearizationKey == nil {
                 throw HeError.missingRelinearizationKey
             }
-            response = try DeviceBuffer(count: 2 * degree) // [2][1][N] after modSwitchDownToSingle
+            response = try DeviceBuffer(count: chunkCount * 2 * degree) // [chunk][2][1][N] after modSwitchDownToSingle
             try dimensions.withUnsafeBufferPointer { dims in
                 try shardPointers.withUnsafeBufferPointer { slabs in
                     try maskPointers.withUnsafeBufferPointer { masks in
-                        try heAmdCheck(he_pir_compute_response_chunk_group(
+                        try heAmdCheck(he_pir_compute_response_group(
                             group.raw, dims.baseAddress, UInt32(dims.count), dim0.pointer, rest.pointer, remainingCount,
-                            slabs.baseAddress, masks.baseAddress, keys.relinearizationKey?.buffer.pointer,
+                            slabs.baseAddress, masks.baseAddress, chunkCount, keys.relinearizationKey?.buffer.pointer,
                             response.pointer, stream.raw))
                     }
                 }
@@ -176,7 +182,10 @@ public extension GpuPirUtil {
         return try withExtendedLifetime((dim0, rest, keys, chunk)) {
             let resumed = try group.makeCurrent(member: 0)
             defer { group.restore(device: resumed) }
-            return try response.downloadCiphertext(context: context, polyContext: single, polyCount: 2, at: 0, on: stream)
+            return try (0..<chunkCount).map { index in
+                try response.downloadCiphertext(context: context, polyContext: single, polyCount: 2, at: index * 2 * degree,
+                                                on: stream)
+            }
         }
     }
 }
