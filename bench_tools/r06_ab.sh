@@ -3,7 +3,7 @@
 # (b) the forward kernel's power model on the production arithmetic; (c) c5 through a device group in one process.
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 T=${1:-r06j}; O=gpurun_out/$T; mkdir -p $O
-python bench_tools/ab_variants.py run --what degrees --rounds 3 timing_only_no_split_gathers timing_only_no_cross_stage timing_only_no_lds_exchange fold_interleaved > $O/ab_16384.txt 2>&1
+python bench_tools/ab_variants.py run --what degrees --rounds 3 timing_only_no_split_gathers timing_only_no_cross_stage timing_only_no_lds_exchange > $O/ab_16384.txt 2>&1
 cat $O/ab_16384.txt
 python bench_tools/power_probe.py > $O/power_probe.txt 2>&1; grep -v amdgpu.ids $O/power_probe.txt
 timeout 600 python bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
