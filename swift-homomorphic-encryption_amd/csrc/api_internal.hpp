@@ -27,6 +27,28 @@ namespace heamd {
 
 inline hipStream_t as_stream(he_stream s) { return static_cast<hipStream_t>(s); }
 
+// Destroy / free entry points run whenever the host's memory management says so -- a Swift deinit, a Python finaliser -- also
+// while some stream of the process is being captured in hipStreamCaptureModeGlobal, where hipFree / hipStreamDestroy /
+// hipEventDestroy from ANY thread invalidate that capture (seen: a garbage-collected context of an earlier test finalised inside
+// torch.cuda.graph, "operation failed due to a previous error during capture").  The calling thread's capture mode is relaxed
+// for the duration of such a call; nothing these calls touch belongs to a capture.
+class RelaxedCapture {
+  public:
+    RelaxedCapture() {
+        exchanged_ = hipThreadExchangeStreamCaptureMode(&mode_) == hipSuccess;
+        if (!exchanged_) (void)hipGetLastError();
+    }
+    ~RelaxedCapture() {
+        if (exchanged_) (void)hipThreadExchangeStreamCaptureMode(&mode_);
+    }
+    RelaxedCapture(const RelaxedCapture&) = delete;
+    RelaxedCapture& operator=(const RelaxedCapture&) = delete;
+
+  private:
+    hipStreamCaptureMode mode_ = hipStreamCaptureModeRelaxed;
+    bool exchanged_ = false;
+};
+
 inline int invalid_argument(const char* what) {
     set_last_error(std::string("invalid argument: ") + what);
     return HE_ERR_INVALID_ARGUMENT;

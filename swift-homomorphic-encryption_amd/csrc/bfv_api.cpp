@@ -536,7 +536,10 @@ int he_bfv_context_create_u32(uint32_t degree, uint64_t plaintext_modulus, const
                               uint32_t moduli_count, he_bfv_context** out) {
     return bfv_create(degree, plaintext_modulus, coefficient_moduli, moduli_count, false, out, 32);
 }
-void he_bfv_context_destroy(he_bfv_context* ctx) { delete ctx; }
+void he_bfv_context_destroy(he_bfv_context* ctx) {
+    heamd::RelaxedCapture relaxed;  // (api_internal.hpp: safe beside another thread's -- or this thread's -- graph capture)
+    delete ctx;
+}
 uint32_t he_bfv_ciphertext_moduli_count(const he_bfv_context* ctx) { return ctx ? ctx->impl->top_level() : 0; }
 const he_poly_context* he_bfv_ciphertext_context(const he_bfv_context* ctx, uint32_t k) {
     return (ctx && ctx->impl->valid(k)) ? ctx->ciphertext[k].get() : nullptr;

@@ -386,6 +386,7 @@ int he_device_malloc(void** out_ptr, size_t bytes) {
     return HE_OK;
 }
 int he_device_free(void* ptr) {
+    heamd::RelaxedCapture relaxed;
     if (ptr == nullptr) return HE_OK;
     HEAMD_HIP_TRY(hipFree(ptr));
     return HE_OK;
@@ -397,6 +398,7 @@ int he_host_malloc(void** out_ptr, size_t bytes) {
     return HE_OK;
 }
 int he_host_free(void* ptr) {
+    heamd::RelaxedCapture relaxed;
     if (ptr == nullptr) return HE_OK;
     HEAMD_HIP_TRY(hipHostFree(ptr));
     return HE_OK;
@@ -421,6 +423,7 @@ int he_stream_create(he_stream* out) {
     return HE_OK;
 }
 int he_stream_destroy(he_stream stream) {
+    heamd::RelaxedCapture relaxed;
     if (stream == nullptr) return HE_OK;
     heamd::scratch_forget_stream(as_stream(stream));
     HEAMD_HIP_TRY(hipStreamDestroy(as_stream(stream)));
@@ -438,6 +441,7 @@ int he_event_create(he_event* out) {
     return HE_OK;
 }
 int he_event_destroy(he_event event) {
+    heamd::RelaxedCapture relaxed;
     if (event == nullptr) return HE_OK;
     HEAMD_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
     return HE_OK;
@@ -512,7 +516,10 @@ int he_poly_context_create_host_only(uint32_t degree, const uint64_t* moduli, ui
                                      he_poly_context** out) {
     return poly_context_create(degree, moduli, moduli_count, true, out);
 }
-void he_poly_context_destroy(he_poly_context* ctx) { delete ctx; }
+void he_poly_context_destroy(he_poly_context* ctx) {
+    heamd::RelaxedCapture relaxed;
+    delete ctx;
+}
 uint32_t he_poly_context_degree(const he_poly_context* ctx) { return ctx ? ctx->impl->degree() : 0; }
 uint32_t he_poly_context_moduli_count(const he_poly_context* ctx) { return ctx ? ctx->impl->moduli_count() : 0; }
 int he_poly_context_moduli(const he_poly_context* ctx, uint64_t* out_moduli) {

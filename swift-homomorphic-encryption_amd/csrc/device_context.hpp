@@ -38,11 +38,11 @@ struct DeviceModulus {
     // (p below 2^33, above 2^61, or a power of two)
     uint64_t wide_factor;
     uint32_t wide_shift;
-    // The limb-wise quotient factors of a constant c -- floor(c 2^32 / 2p) -- read off c itself: for a modulus just below a
-    // power of two, p = 2^b - delta with delta < 2^(b - 33) (what generatePrimes(preferringSmall: false) returns, i.e.
-    // every parameter set of the reference), floor(c 2^32 / 2p) is c >> split_shift or one more, split_shift = b - 31.
-    // 0 where the modulus is not of that form.  Since round 5 the flag selects the shift-folded products of ntt_common.hpp
-    // kModeFoldLazy (2^(b+2) = 4d mod p); the value itself is no longer read on the device.
+    // != 0 (= b - 31) for a modulus just below a power of two, p = 2^b - delta, 41 <= b <= 55, delta < 2^(b - 32) -- what
+    // generatePrimes(preferringSmall: false) returns, i.e. every parameter set of the reference: the flag that selects the
+    // shift-folded products of ntt_common.hpp kModeFoldLazy (2^(b+2) = 4 delta mod p; products below 6p for any 64-bit word,
+    // poly_context.cpp).  The value itself (rounds 3-4: the shift that read quotient factors off a constant) is not read on
+    // the device.
     uint32_t split_shift;
 };
 

@@ -130,6 +130,7 @@ int he_device_group_create(const int* devices, uint32_t device_count, uint32_t f
 
 void he_device_group_destroy(he_device_group* group) {
     if (group == nullptr) return;
+    heamd::RelaxedCapture relaxed;
     DeviceGuard guard;
     destroy_members(group);
     delete group;

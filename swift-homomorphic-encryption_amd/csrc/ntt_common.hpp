@@ -128,7 +128,7 @@ __device__ __forceinline__ uint64_t load_twiddle_word(const uint64_t* entry) {
 //                    measures faster: every limb-wise inverse kernel but the plain-slab one at N = 8192
 //                    (profiles/r04t_inverse_forms_ab.txt).
 //   kModeFoldLazy  the same SCHEDULE (spare top bits, no conditional subtract per butterfly) for moduli just below a power
-//                    of two, p = 2^b - d with d < 2^(b-33), 41 <= b <= 55 (DeviceModulus::split_shift != 0: what
+//                    of two, p = 2^b - d with d < 2^(b-32), 41 <= b <= 55 (DeviceModulus::split_shift != 0: what
 //                    generatePrimes(preferringSmall: false) returns, i.e. every parameter set of the reference), with the
 //                    product FOLDED BY A SHIFT at 2^(b+2) = 4d (mod p) instead of reduced by an estimated quotient
 //                    (device_math.hpp fold_mul, the fold modes' product): 5 multiply-adds instead of 8, no factor table -- a

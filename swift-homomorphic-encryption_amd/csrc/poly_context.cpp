@@ -67,9 +67,13 @@ static DeviceModulus make_constants(u64 p) {
         m.wide_shift = static_cast<uint32_t>(bits - 1);
         m.wide_factor = static_cast<u64>((static_cast<u128>(1) << (64 + bits - 1)) / p);
     }
-    // p = 2^bits - delta, delta < 2^(bits - 33): for every c < p, c 2^32 / 2p - c / 2^(bits - 31) = (c / 2^(bits - 31))
-    // (delta / p) < 2^31 2^(bits - 33) / 2^(bits - 1) = 1/2, so floor(c 2^32 / 2p) is c >> (bits - 31) or one more
-    if (bits >= 41 && bits <= 55 && ((static_cast<u64>(1) << bits) - p) < (static_cast<u64>(1) << (bits - 33)))
+    // p = 2^bits - delta with delta < 2^(bits - 32): the shift-folded product (device_math.hpp fold_mul) of any 64-bit word by a
+    // constant below p is r = (V mod 2^(bits+2)) + (V >> (bits+2)) 4 delta with V < 2^(bits+33), so
+    // r <= 2^(bits+2) - 1 + (2^31 - 1) 4 delta < 6p  <=>  delta (2^33 + 2) < 2^(bits+1), which delta < 2^(bits-32) gives for
+    // every bits < 64 (tests/test_fold_product_bounds.py holds the corners).  Rounds 3-5 asked for delta < 2^(bits-33), the
+    // bound of the shifted quotient factors this flag was introduced for; the folded product never needed it, and at
+    // N = 16384 only two of the four standard 55-bit primes met it (NTT-friendly primes are 2N apart).
+    if (bits >= 41 && bits <= 55 && ((static_cast<u64>(1) << bits) - p) < (static_cast<u64>(1) << (bits - 32)))
         m.split_shift = static_cast<uint32_t>(bits - 31);
     return m;
 }

@@ -1,7 +1,7 @@
 """The arithmetic claims behind the shift-folded butterfly products (csrc/device_math.hpp fold_mul as kModeFoldLazy uses it,
 csrc/ntt_common.hpp), restated limb by limb on Python integers and held at the corners the proof names:
 
-    p = 2^b - d, 41 <= b <= 55, d < 2^(b-33);  y any 64-bit word = b0 + b1 2^32;  constants w < p, wt = w 2^32 mod p;
+    p = 2^b - d, 41 <= b <= 55, d < 2^(b-32);  y any 64-bit word = b0 + b1 2^32;  constants w < p, wt = w 2^32 mod p;
     V = b0 w + b1 wt  (formed in two 64-bit columns, one carry),  F = 2^(b+2) = 4d (mod p),
     r = (V mod F) + (V >> (b+2)) 4d  =  w y (mod p),   0 <= r < 6p,   every intermediate inside its register.
 
@@ -37,11 +37,11 @@ def fold_mul(y, w, wt, p):
 
 
 def corner_moduli():
-    """(b, d) at the edges of eligibility (poly_context.cpp: 41 <= bits <= 55, d < 2^(bits-33)); p need not be prime for the
+    """(b, d) at the edges of eligibility (poly_context.cpp: 41 <= bits <= 55, d < 2^(bits-32)); p need not be prime for the
     congruence and the bounds to hold."""
     for b in (41, 42, 47, 50, 54, 55):
-        top = 1 << (b - 33)
-        for d in {1, 3, top // 2 + 1, top - 1}:
+        top = 1 << (b - 32)
+        for d in {1, 3, top // 4 + 1, top // 2 - 1, top // 2 + 1, top - 1}:
             if 0 < d < top:
                 yield b, d
 
@@ -62,8 +62,8 @@ def test_folded_product_is_congruent_and_below_6p():
                 assert r % p == (w * y) % p, (b, d, w, y)
                 worst = max(worst, r)
         assert worst < 6 * p, (b, d, worst / p)
-        # the bound itself: F + (2^31 - 1) 4d < 2^(b+2) + 2^33 d < 5 * 2^b < 6p
-        assert (1 << (b + 2)) + ((1 << 31) - 1) * 4 * d < 6 * p
+        # the bound itself: F - 1 + (2^31 - 1) 4d < 6p  <=>  d (2^33 + 2) < 2^(b+1), true for every d < 2^(b-32)
+        assert (1 << (b + 2)) - 1 + ((1 << 31) - 1) * 4 * d < 6 * p
 
 
 def test_forward_schedule_never_leaves_its_ceiling():

@@ -84,9 +84,11 @@ def test_split_products_any_word(probe, p):
                 assert (0 <= r < 8 * p) if kind == 2 else (0 < r < 6 * p), (kind, hex(y), w, r // p)
 
 
-# p = 2^b - d at both ends of d < 2^(b-33) for b = 41, 47, 52, 55 (kModeFoldLazy), 56 and 60 (kModeFoldMinus: d < 2^(b-33) too)
-FOLD_MINUS = [(1 << 41) - 1, (1 << 41) - 255, (1 << 47) - 8191, (1 << 47) - 16383, (1 << 52) - 245759, (1 << 52) - 524287,
-              (1 << 55) - 55, (1 << 55) - 4087807, (1 << 55) - 4194303, (1 << 56) - 27, (1 << 56) - 8388607, (1 << 60) - 93,
+# p = 2^b - d at both ends of d < 2^(b-32) for b = 41, 47, 52, 55 (kModeFoldLazy: the bound since round 6, 2^(b-33) before --
+# both kept), 56 and 60 (kModeFoldMinus: d < 2^(b-33))
+FOLD_MINUS = [(1 << 41) - 1, (1 << 41) - 255, (1 << 41) - 511, (1 << 47) - 8191, (1 << 47) - 16383, (1 << 47) - 32767,
+              (1 << 52) - 245759, (1 << 52) - 524287, (1 << 52) - 1048575, (1 << 55) - 55, (1 << 55) - 4087807,
+              (1 << 55) - 4194303, (1 << 55) - 8388607, (1 << 56) - 27, (1 << 56) - 8388607, (1 << 60) - 93,
               (1 << 60) - 134217727]
 # p = 2^60 + e, e < 2^24 (the BEHZ auxiliary primes' form)
 FOLD_PLUS = [(1 << 60) + 33, (1 << 60) + 1, (1 << 60) + (1 << 24) - 1, (1 << 60) + 8380417]

@@ -379,9 +379,9 @@ def test_ntt_full_size_properties(oracle):
 
 
 def _primes_below_power_of_two(oracle, bits, degree, eligible, count=1):
-    """NTT primes p = 2^bits - d (p = 1 mod 2N) with d as LARGE as the shift-folded products allow (d < 2^(bits-33):
+    """NTT primes p = 2^bits - d (p = 1 mod 2N) with d as LARGE as the shift-folded products allow (d < 2^(bits-32):
     csrc/poly_context.cpp split_shift) when `eligible`, or the first ones just past that bound otherwise."""
-    step, top = 2 * degree, 1 << (bits - 33)
+    step, top = 2 * degree, 1 << (bits - 32)
     found = []
     k = (top + 1) // step if eligible else (top + 1) // step + 1
     while len(found) < count and k >= 1 and k * step - 1 < (1 << (bits - 1)):
@@ -396,7 +396,7 @@ def _primes_below_power_of_two(oracle, bits, degree, eligible, count=1):
 @pytest.mark.parametrize("degree", [4096, 8192, 16384, 32768])
 def test_shift_folded_products_at_the_edge_of_their_moduli(oracle, degree):
     """kModeFoldLazy (csrc/ntt_common.hpp): the transforms of moduli 2^b - d fold their products by a shift, which wants
-    d < 2^(b-33).  The primes generatePrimes returns sit at the small end of d; these sit at the LARGE end (the product's
+    d < 2^(b-32).  The primes generatePrimes returns sit at the small end of d; these sit at the LARGE end (the product's
     bound 2^(b+2) + 2^33 d is nearly reached), next to primes just past the bound (limb-wise products) in the same context --
     the launch then falls back as a whole -- and alone.  Extreme words in every residue.  N = 16384 / 32768: the interleaved
     sub-row kernels on the same products (cross stages with three twiddles in flight)."""
