@@ -75,6 +75,10 @@ int he_get_device(int* out_device); /* the calling thread's current HIP device: 
 int he_set_device(int device);
 int he_device_malloc(void** out_ptr, size_t bytes);
 int he_device_free(void* ptr);
+/* (every destroy / free entry point of this header -- he_device_free, he_host_free, he_stream_destroy, he_event_destroy,
+ * he_*_context_destroy, he_device_group_destroy -- may be called at any time from any thread, also while a stream of the
+ * process is being captured into a graph: a deinit or finaliser cannot choose its moment, so these calls relax the calling
+ * thread's capture mode for their duration instead of invalidating the capture) */
 /* Page-locked host memory: a copy between it and the device is truly asynchronous (from pageable memory the runtime
  * stages the bytes before he_memcpy_h2d returns, and a borrowed pageable pointer has to be waited for).  What the Swift
  * host stages ciphertexts, keys and databases in: one copy and no wait per object instead of one per polynomial. */
