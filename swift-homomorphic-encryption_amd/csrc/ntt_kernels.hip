@@ -619,6 +619,10 @@ constexpr int kCrossAheadSplit = 1;
 constexpr bool kCrossEarlySplit = false;
 template <int MODE>
 constexpr int kCrossAhead = MODE == kModeFoldLazy ? 3 : (is_split(MODE) ? kCrossAheadSplit : 1);
+// the inverse carries the finished sub-rows through its cross stages, so its third twiddle in flight costs it 20 B of scratch:
+// two measure 4-5 % faster at N = 16384 and keep none (profiles/r06v_interleaved_fold_inverse_ab.txt)
+template <int MODE>
+constexpr int kCrossAheadInverse = MODE == kModeFoldLazy ? 2 : kCrossAhead<MODE>;
 template <int LOGS, int MODE>
 __device__ __forceinline__ void forward_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
                                                      const Twiddles<MODE>& tw, uint64_t p) {
@@ -673,17 +677,17 @@ __device__ __forceinline__ TwiddleWords inverse_cross_twiddle(const Twiddles<MOD
     return fetch_twiddle<MODE, false>(tw, lane_words << upper_bits, fixed);
 }
 template <int LOGS, int MODE>
-__device__ __forceinline__ void inverse_cross_head(TwiddleWords (&head)[kCrossAhead<MODE>], uint32_t tid, const Twiddles<MODE>& tw) {
+__device__ __forceinline__ void inverse_cross_head(TwiddleWords (&head)[kCrossAheadInverse<MODE>], uint32_t tid, const Twiddles<MODE>& tw) {
     constexpr int R = Schedule<kSubLogN, kSubLogE>::R;
     const uint32_t lane_words = lane_part<kSubLogN, kSubLogE, 0, R>(tid);
 #pragma unroll
-    for (int a = 0; a < kCrossAhead<MODE>; ++a) head[a] = inverse_cross_twiddle<LOGS, MODE>(tw, lane_words, 0, a);
+    for (int a = 0; a < kCrossAheadInverse<MODE>; ++a) head[a] = inverse_cross_twiddle<LOGS, MODE>(tw, lane_words, 0, a);
 }
 template <int LOGS, int MODE, int PRIOR = 0>
 __device__ __forceinline__ void inverse_cross_stages(uint64_t (&v)[1 << LOGS][1 << kSubLogE], uint32_t tid,
                                                      const Twiddles<MODE>& tw, uint64_t p,
-                                                     const TwiddleWords (&head)[kCrossAhead<MODE>]) {
-    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog, AHEAD = kCrossAhead<MODE>;
+                                                     const TwiddleWords (&head)[kCrossAheadInverse<MODE>]) {
+    constexpr int E = 1 << kSubLogE, R = Schedule<kSubLogN, kSubLogE>::R, H = Lazy<MODE>::kInverseCapLog, AHEAD = kCrossAheadInverse<MODE>;
     static_assert(AHEAD <= E, "the head twiddles are all of stage 0");
     const uint64_t neg_p = Lazy<MODE>::reduction_constant(p);
     const FoldConstants fc = mode_fold_constants<MODE>(p);
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(1 << kSubLogT, min_waves_per_simd(kSubLogE, 1 
     // (before the row's loads where the registers allow it: the plain slab on the shift-folded products -- a fused load needs
     // them for its operands, a limb-wise twiddle is 6 registers)
     constexpr bool EARLY_HEAD = SOURCE == kInverseFromSlab && (MODE == kModeFoldLazy || kCrossEarlySplit);
-    TwiddleWords cross_head[kCrossAhead<MODE>];
+    TwiddleWords cross_head[kCrossAheadInverse<MODE>];
     if constexpr (EARLY_HEAD) inverse_cross_head<LOGS, MODE>(cross_head, tid, cross);
     uint64_t v[ROWS][E];
     if constexpr (TENSOR) {
