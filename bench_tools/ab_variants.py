@@ -9,7 +9,7 @@ an error: the experiment has drifted from the source and must be updated), recom
 and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
 
   python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
-  python bench_tools/ab_variants.py run [--what ntt|degrees|c3] [--rounds N] [NAME ...]     (on the GPU box)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3] [--rounds N] [NAME ...]     (on the GPU box)
       times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
       so that clock drift shows up as spread
 """
@@ -51,7 +51,8 @@ for degree, count, batch in %%s:
         out.append("N=%%%%d %%%%s %%%%.4f" %%%% (degree, "inv" if inverse else "fwd", a.elapsed_time(b) / 50))
 print("  ".join(out))
 ''' % PKG
-SHAPES = {"ntt": [(8192, 4, 4096)], "degrees": [(4096, 2, 8192), (8192, 4, 4096), (16384, 4, 1024)]}
+SHAPES = {"ntt": [(8192, 4, 4096)], "degrees": [(4096, 2, 8192), (8192, 4, 4096), (16384, 4, 1024)],
+          "large": [(16384, 4, 1024), (32768, 4, 512), (32768, 8, 256)]}
 C3_TIMER = ("import sys; sys.path[:0] = [%r, %r, %r]; import torch, heamd, path_bench, json; heamd.set_scratch_cache(); "
             "r = path_bench.config3_ct_mul(torch, heamd, batch=1024, reps=5); "
             "print('ct x ct %%.1f k/s  relinearize %%.1f k/s  both %%.1f k/s' %% (r['ct_mul_per_s'] / 1e3, "
