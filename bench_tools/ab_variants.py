@@ -9,7 +9,7 @@ an error: the experiment has drifted from the source and must be updated), recom
 and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
 
   python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
-  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3] [--rounds N] [NAME ...]     (on the GPU box)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small] [--rounds N] [NAME ...]     (on the GPU box)
       times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
       so that clock drift shows up as spread
 """
@@ -58,6 +58,37 @@ C3_TIMER = ("import sys; sys.path[:0] = [%r, %r, %r]; import torch, heamd, path_
             "print('ct x ct %%.1f k/s  relinearize %%.1f k/s  both %%.1f k/s' %% (r['ct_mul_per_s'] / 1e3, "
             "r['relinearize_per_s'] / 1e3, r['ct_mul_relinearize_per_s'] / 1e3))" % (
                 ROOT, PKG, os.path.join(ROOT, "bench_tools")))
+
+# latency-bound chains of small launches: a single query's expansion, ct x ct and relinearize on 1 / 8 ciphertexts
+SMALL_TIMER = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import torch, heamd
+from path_bench import _timed, _uniform
+heamd.set_scratch_cache()
+degree = 8192
+q = heamd.generate_primes([55] * 5, False, degree)
+bfv = heamd.BfvContext(degree, 557057, q)
+moduli = q[:-1]
+elements = sorted({(degree >> level) + 1 for level in range(10)})
+keys = {e: _uniform(torch, q, (bfv.L, 2), degree, 100 + i) for i, e in enumerate(elements)}
+query = _uniform(torch, moduli, (1, 2), degree, 14)
+out = []
+for outputs in (320, 1024):
+    t = _timed(torch, lambda: bfv.pir_expand(query, outputs, keys), 10)
+    out.append("expand %%d %%.4f ms" %% (outputs, float(t) * 1e3))
+key = _uniform(torch, q, (bfv.L, 2), degree, 3)
+for batch in (1, 8, 64):
+    lhs = _uniform(torch, moduli, (batch, 2), degree, 1)
+    rhs = _uniform(torch, moduli, (batch, 2), degree, 2)
+    state = {}
+    def mul(): state["ct3"] = bfv.mul(lhs, rhs)
+    def relin(): state["ct2"] = bfv.relinearize(state["ct3"], key)
+    t_mul = _timed(torch, mul, 20)
+    t_relin = _timed(torch, relin, 20)
+    out.append("batch %%d ct x ct %%.1f us relinearize %%.1f us" %% (batch, float(t_mul) * 1e6, float(t_relin) * 1e6))
+print("  ".join(out))
+''' % (ROOT, PKG, os.path.join(ROOT, "bench_tools"))
 
 
 def load_spec(name):
@@ -133,7 +164,7 @@ def run(args):
             rounds = int(args.pop(0))
         else:
             names.append(a)
-    timer = C3_TIMER if what == "c3" else NTT_TIMER % repr(SHAPES[what])
+    timer = C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else NTT_TIMER % repr(SHAPES[what])
     libs = {"production": None}
     for path in sorted(glob.glob(os.path.join(VARIANTS, "libhe_amd_*.so"))):
         name = os.path.basename(path)[len("libhe_amd_"):-3]

@@ -1,4 +1,4 @@
-"""PirUtil.expand (1 query ciphertext -> 1024 outputs, N = 8192, L = 4) for rocprofv3 --kernel-trace --stats."""
+"""PirUtil.expand (1 query ciphertext -> EXPAND_OUTPUTS outputs, default 1024; N = 8192, L = 4) for rocprofv3 --kernel-trace --stats."""
 import os
 import sys
 
@@ -21,4 +21,5 @@ moduli = q[:-1]
 elements = sorted({(degree >> level) + 1 for level in range(10)})
 keys = {e: _uniform(torch, q, (bfv.L, 2), degree, 100 + i) for i, e in enumerate(elements)}
 query = _uniform(torch, moduli, (1, 2), degree, 14)
-print("expand ms:", _timed(torch, lambda: bfv.pir_expand(query, 1024, keys), 5) * 1e3)
+outputs = int(os.environ.get("EXPAND_OUTPUTS", "1024"))
+print("expand to %d outputs, ms:" % outputs, _timed(torch, lambda: bfv.pir_expand(query, outputs, keys), 5) * 1e3)

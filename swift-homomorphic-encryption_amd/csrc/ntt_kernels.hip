@@ -1122,6 +1122,12 @@ inline bool fold_lazy_band(const DeviceContext& ctx, const RowMap& map) {
 }
 
 constexpr int kRowGroup = 2;
+// ... unless the launch is small: below a few rows per workgroup slot (256 CUs x 2 workgroups of 64 registers) a pair only
+// doubles the launch's latency -- the levels of a query's expansion and key switches on a few ciphertexts are chains of such
+// launches.  Measured (profiles/r06w_small_launches.txt): one query's expansion to 320 ciphertexts 1.078 -> 0.898 ms,
+// relinearize on 8 / 64 ciphertexts 67.7 -> 45.5 / 133 -> 114 us; from 8192 rows up the pairs win (the key MAC of 1024
+// ciphertexts -1.3 %, the headline transform's 16384 rows -6 % without them).
+constexpr size_t kUngroupedBelowRows = 4096;
 template <int LOGN, int LOGT>
 constexpr int kRowsPerWorkgroup = (LOGN - LOGT <= 3 && Schedule<LOGN, LOGN - LOGT>::P >= 2) ? kRowGroup : 1;
 
@@ -1272,7 +1278,7 @@ hipError_t launch_forward_tiled(int mode, uint64_t* slab, const DeviceContext& c
         size_t paired_records = 0;  // records covered by the launch of row groups
         constexpr int GROUP = kRowsPerWorkgroup<LOGN, LOGT>;
         if constexpr (GROUP > 1) {
-            paired_records = (rows / mod_period) / GROUP * GROUP;
+            paired_records = rows <= kUngroupedBelowRows ? 0 : (rows / mod_period) / GROUP * GROUP;
             if (paired_records != 0) {
                 hipError_t e = launch_forward_kernel<LOGN, LOGT, SPREAD, GROUP>(
                     mode, slab, ctx, make_row_map(mod_base, mod_period, row_period, row_offset),
@@ -1324,7 +1330,7 @@ hipError_t launch_fused_inverse(int mode, uint64_t* slab, const DeviceContext& c
     constexpr size_t REPLICAS = TENSOR ? 3 : 2;
     constexpr int GROUP = TENSOR ? kTensorRows<LOGN, LOGT> : kKeyMacRows<LOGN, LOGT>;
     const size_t items = rows / mod_period / REPLICAS;
-    const size_t grouped = GROUP > 1 ? items / GROUP * GROUP : 0;
+    const size_t grouped = (GROUP > 1 && rows > kUngroupedBelowRows) ? items / GROUP * GROUP : 0;
     auto map_from = [&](size_t first_item) {
         return make_row_map(mod_base, mod_period, row_period, row_offset, static_cast<uint32_t>(first_item));
     };
@@ -1407,7 +1413,7 @@ hipError_t launch_tiled(bool inverse, int mode, uint64_t* slab, const DeviceCont
     }
     size_t paired_records = 0;
     if constexpr (GROUP > 1) {
-        paired_records = (rows / mod_period) / GROUP * GROUP;
+        paired_records = rows <= kUngroupedBelowRows ? 0 : (rows / mod_period) / GROUP * GROUP;
         if (paired_records != 0) {
             hipError_t e = launch_inverse_kernel<LOGN, LOGT, kInverseFromSlab, GROUP>(
                 mode, slab, ctx, map, paired_records / GROUP * mod_period, source_spec, stream);
