@@ -167,11 +167,8 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
     const DeviceContext qbsk = tool.qbsk->device_context();
     const uint32_t rows = 2 * L + 1;
     const bool from_source = heamd::ntt_lifted_forward_supported(qbsk, rows, L, items * 4);
-    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream,
-                                                        !from_source);
-    if (e != hipSuccess) return e;
-    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream,
-                                             !from_source);
+    hipError_t e = heamd::launch_lift_pair_q_to_qbsk_strided(lhs, rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, 2 * ext,
+                                                             stream, !from_source);
     if (e != hipSuccess) return e;
     if (from_source) return heamd::launch_ntt_lifted_forward(lifted, qbsk, rows, items * 4, lhs, rhs, 2 * L * n, L, stream);
     return ntt_records(false, lifted, *tool.qbsk, qbsk, rows, items * 4, stream);
@@ -182,11 +179,8 @@ hipError_t lift_pairs_to_eval(const RnsToolLevel& tool, uint32_t L, size_t n, si
     heamd::DeviceContext32 qbsk32{};
     if (tool.qbsk->device_context32(rows, qbsk32) != HE_OK) return hipErrorInvalidValue;
     const bool from_source = heamd::ntt32_lifted_forward_supported(qbsk32) && items * 4 * rows <= (size_t(1) << 30);
-    hipError_t e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, stream,
-                                                        !from_source);
-    if (e != hipSuccess) return e;
-    e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 2 * ext, stream,
-                                             !from_source);
+    hipError_t e = heamd::launch_lift_pair_q_to_qbsk_strided(lhs, rhs, lifted, tool.device, items, 2, 2 * L * n, 4 * ext, 0, 2 * ext,
+                                                             stream, !from_source);
     if (e != hipSuccess) return e;
     if (from_source) return heamd::launch_ntt32_lifted_forward(lifted, qbsk32, rows, items, lhs, rhs, 2 * L * n, L, stream);
     return ntt_records(false, lifted, *tool.qbsk, tool.qbsk->device_context(), rows, items * 4, stream);
@@ -227,8 +221,8 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             HEAMD_HIP_TRY(hipStreamWaitEvent(lane.stream, lane.forked, 0));
             hipError_t e = heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, lane.stream,
                                                          heamd::kBehzCiphertextRows);
-            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false, lazy);
-            if (e == hipSuccess) e = heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false, lazy);
+            if (e == hipSuccess)
+                e = heamd::launch_lift_pair_q_to_qbsk_strided(lhs, rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, 2 * ext, stream, false, lazy);
             // The Bsk band and the floor in kBehzFloorParts parts of the batch: a part's floor -- 256-lane workgroups of 41
             // registers -- follows the Q band on the lane and runs beside the NEXT part's Bsk band on the caller's stream;
             // only the last part's floor is left to run on its own.
@@ -265,8 +259,7 @@ int mul_rows_fused(const he_bfv_context* ctx, const RnsToolLevel& tool, uint32_t
             return HE_OK;
         }
     }
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(lhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, stream, false, lazy));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 2 * ext, stream, false, lazy));
+    HEAMD_HIP_TRY(heamd::launch_lift_pair_q_to_qbsk_strided(lhs, rhs, lifted, tool.device, batch, 2, 2 * L * n, 4 * ext, 0, 2 * ext, stream, false, lazy));
     HEAMD_HIP_TRY(heamd::launch_behz_rows_fused(lhs, rhs, 2 * L * n, lifted, tensor, scaled, rows, L, batch, stream));
     return HE_OK;
 }

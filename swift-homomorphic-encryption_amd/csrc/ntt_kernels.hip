@@ -1575,7 +1575,10 @@ hipError_t launch_ntt_tensor_inverse(const uint64_t* lifted, uint64_t* out, cons
     if (records == 0) return hipSuccess;
     const InverseSource spec{lifted, nullptr, 0, 0, nullptr, 0, nullptr, 0};
     BandRun runs[kMaxBandRuns];
-    const int count = band_runs(ctx, record_rows, runs);
+    // (a product of a few ciphertexts is one workgroup generation whichever butterflies it takes: one launch over all rows in
+    // the mode every modulus of the context accepts, like launch_ntt_mixed -- 13.6 + 14.5 -> 15 us on one ciphertext pair,
+    // profiles/r06x_small_chains.txt)
+    const int count = records * record_rows <= kOneGeneration ? 0 : band_runs(ctx, record_rows, runs);
     if (count <= 1)
         return launch_ntt_band(true, out, ctx, 0, record_rows, record_rows, 0, records, production_mode(ctx), stream,
                                kInverseFromTensor, spec);

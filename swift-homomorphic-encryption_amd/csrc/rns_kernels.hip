@@ -178,6 +178,12 @@ struct LiftLayout {
     // 1: the Bsk rows may be left as the one-word-quotient reduction hands them over, in [0, 5p), for a consumer that takes such
     // words (the row-fused ct x ct kernel's fold butterflies: behz_kernels.hip) -- three conditional subtracts per word less
     uint32_t lazy_output;
+    // a second operand in the same launch (ct x ct lifts both ciphertexts of every pair): polynomials [first_polys, polys) are
+    // read from `second` with the same strides and written second_out_delta words from where the first operand's are; nullptr:
+    // one operand
+    const void* second = nullptr;
+    size_t first_polys = 0;
+    ptrdiff_t second_out_delta = 0;
 };
 
 // W: the slab's word type -- uint64_t (Bfv<UInt64>) or uint32_t (Bfv<UInt32>: every modulus <= 2^30 - 1).  Words are
@@ -194,10 +200,18 @@ __global__ void __launch_bounds__(kThreads)
     // V coefficients per lane, no grid-stride loop: with a loop hipcc hoists every table constant out of it and
     // spills SGPRs into VGPR lanes
     for (size_t idx = (blockIdx.x * size_t(kThreads) + threadIdx.x) * V; idx < total; idx = total) {
-        const size_t poly = idx >> logn, k = idx & (n - 1);
+        size_t poly = idx >> logn;
+        const size_t k = idx & (n - 1);
+        const W* operand = in;
+        W* lifted_base = out;
+        if (layout.second != nullptr && poly >= layout.first_polys) {  // (uniform: a workgroup's lanes share the polynomial)
+            poly -= layout.first_polys;
+            operand = static_cast<const W*>(layout.second);
+            lifted_base = out + layout.second_out_delta;
+        }
         const size_t item = poly / layout.polys_per_item, c = poly - item * layout.polys_per_item;
-        const W* src = in + item * layout.in_item_stride + c * L * n + k;
-        W* dst = out + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
+        const W* src = operand + item * layout.in_item_stride + c * L * n + k;
+        W* dst = lifted_base + item * layout.out_item_stride + c * (2 * L + 1) * n + k;
         uint64_t y[V][L];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
@@ -874,6 +888,19 @@ hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevic
 }
 
 template <typename W>
+hipError_t launch_lift_pair_q_to_qbsk_strided(const W* first, const W* second, W* out, const RnsToolDevice& tool, size_t items,
+                                              size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
+                                              size_t first_out_offset, size_t second_out_offset, hipStream_t stream,
+                                              bool store_input, bool lazy_output) {
+    if (items == 0 || polys_per_item == 0) return hipSuccess;
+    LiftLayout layout{polys_per_item, in_item_stride, out_item_stride, store_input ? 1u : 0u, lazy_output ? 1u : 0u};
+    layout.second = second;
+    layout.first_polys = items * polys_per_item;
+    layout.second_out_delta = static_cast<ptrdiff_t>(second_out_offset) - static_cast<ptrdiff_t>(first_out_offset);
+    return dispatch_L<LiftLauncher>(tool.L, first, out + first_out_offset, tool, 2 * items * polys_per_item, layout, stream);
+}
+
+template <typename W>
 hipError_t launch_floor_qbsk_to_q(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     return dispatch_L<FloorLauncher>(tool.L, in, out, tool, polys, stream);
@@ -984,6 +1011,8 @@ hipError_t launch_galois_finish(const W* prod, const W* ct_base, size_t ct_strid
     template hipError_t launch_lift_q_to_qbsk<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);                \
     template hipError_t launch_lift_q_to_qbsk_strided<W>(const W*, W*, const RnsToolDevice&, size_t, size_t, size_t,      \
                                                          size_t, size_t, hipStream_t, bool, bool);                        \
+    template hipError_t launch_lift_pair_q_to_qbsk_strided<W>(const W*, const W*, W*, const RnsToolDevice&, size_t, size_t, \
+                                                              size_t, size_t, size_t, size_t, hipStream_t, bool, bool);   \
     template hipError_t launch_floor_qbsk_to_q<W>(const W*, W*, const RnsToolDevice&, size_t, hipStream_t);               \
     template hipError_t launch_tensor<W>(const W*, W*, const DeviceContext&, size_t, hipStream_t);                        \
     template hipError_t launch_tensor_accumulate<W>(const W*, W*, const DeviceContext&, size_t, uint64_t, hipStream_t);   \

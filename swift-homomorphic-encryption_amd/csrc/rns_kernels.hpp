@@ -26,6 +26,13 @@ template <typename W>
 hipError_t launch_lift_q_to_qbsk_strided(const W* in, W* out, const RnsToolDevice& tool, size_t items,
                                          size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
                                          size_t out_offset, hipStream_t stream, bool store_input = true, bool lazy_output = false);
+// Two operands in ONE launch (the two ciphertexts of every ct x ct pair): `first` as above at out + first_out_offset, `second`
+// with the same strides at out + second_out_offset.
+template <typename W>
+hipError_t launch_lift_pair_q_to_qbsk_strided(const W* first, const W* second, W* out, const RnsToolDevice& tool, size_t items,
+                                              size_t polys_per_item, size_t in_item_stride, size_t out_item_stride,
+                                              size_t first_out_offset, size_t second_out_offset, hipStream_t stream,
+                                              bool store_input = true, bool lazy_output = false);
 // in [polys][2L+1][N] -> out [polys][L][N]
 template <typename W>
 hipError_t launch_floor_qbsk_to_q(const W* in, W* out, const RnsToolDevice& tool, size_t polys, hipStream_t stream);
