@@ -9,7 +9,7 @@ an error: the experiment has drifted from the source and must be updated), recom
 and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
 
   python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
-  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small] [--rounds N] [NAME ...]     (on the GPU box)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small|pir] [--rounds N] [NAME ...]     (on the GPU box)
       times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
       so that clock drift shows up as spread
 """
@@ -90,6 +90,32 @@ for batch in (1, 8, 64):
 print("  ".join(out))
 ''' % (ROOT, PKG, os.path.join(ROOT, "bench_tools"))
 
+# the PIR server loop: 8 chunks of 256 x 64 (34 GB), one query -- chunk loop and whole query, median of 20 calls each
+PIR_TIMER = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import torch, heamd
+from path_bench import _timed, _uniform
+heamd.set_scratch_cache()
+degree, d0, d1, chunks = 8192, 256, 64, 8
+q = heamd.generate_primes([55] * 5, False, degree)
+ctx = heamd.BfvContext(degree, 557057, q)
+moduli = q[:-1]
+total = d0 + d1
+query = _uniform(torch, moduli, (1, 2), degree, 7)
+elements = sorted({(degree >> level) + 1 for level in range((total - 1).bit_length())})
+galois = {e: _uniform(torch, q, (ctx.L, 2), degree, 20 + i) for i, e in enumerate(elements)}
+relin = _uniform(torch, q, (ctx.L, 2), degree, 10)
+database = _uniform(torch, moduli, (chunks, d0 * d1), degree, 9)
+expanded = ctx.pir_expand(query, total, galois)
+dim0 = ctx.ciphertext_context().forward_ntt_(expanded[:d0].clone())
+loop = _timed(torch, lambda: ctx.pir_compute_response([d0, d1], dim0, expanded[d0:], database, chunks, relinearization_key=relin), 20)
+whole = _timed(torch, lambda: ctx.pir_compute_response_to_query([d0, d1], query, 1, galois, relin, database, chunks), 20)
+print("chunk loop median %%.3f ms (min %%.3f max %%.3f)  whole query median %%.3f ms (min %%.3f max %%.3f)" %% (
+    loop.spread["median_ms"], loop.spread["min_ms"], loop.spread["max_ms"],
+    whole.spread["median_ms"], whole.spread["min_ms"], whole.spread["max_ms"]))
+''' % (ROOT, PKG, os.path.join(ROOT, "bench_tools"))
+
 
 def load_spec(name):
     path = os.path.join(SPECS, name + ".py")
@@ -164,7 +190,7 @@ def run(args):
             rounds = int(args.pop(0))
         else:
             names.append(a)
-    timer = C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else NTT_TIMER % repr(SHAPES[what])
+    timer = C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else PIR_TIMER if what == "pir" else NTT_TIMER % repr(SHAPES[what])
     libs = {"production": None}
     for path in sorted(glob.glob(os.path.join(VARIANTS, "libhe_amd_*.so"))):
         name = os.path.basename(path)[len("libhe_amd_"):-3]

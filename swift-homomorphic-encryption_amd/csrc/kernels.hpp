@@ -37,6 +37,9 @@ hipError_t launch_ntt_lift(const uint64_t* plaintexts, uint64_t plaintext_modulu
 // the fold-free butterflies and the rest on the [0, 8p) ones (the [Q, Bsk] slabs of BEHZ multiplication)
 hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, size_t records,
                             hipStream_t stream);
+// The rows [first, first + count) of every record only; hipErrorNotSupported (nothing launched) for degrees without a tiled kernel.
+hipError_t launch_ntt_record_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, uint32_t first,
+                                  uint32_t count, size_t records, hipStream_t stream);
 // Forward NTT of lifted [Q, Bsk] records [records][record_rows][N] whose first source_moduli rows were left unwritten by
 // the lift: they are read from the source polynomials -- record = item * 4 + slot from polynomial slot & 1 of item
 // `item` of `base` (slots 0, 1) or `second` (slots 2, 3), items `stride` words apart; second == nullptr: record r from
@@ -173,6 +176,10 @@ hipError_t launch_elementwise32(ElementwiseOp op, uint32_t* lhs, const uint32_t*
 // packed [UInt32] words <-> the zero-extended 8-byte words of the Bfv<UInt32> scheme layer (16-byte aligned slabs)
 hipError_t launch_widen_words(const uint32_t* in, uint64_t* out, size_t words, hipStream_t stream);
 hipError_t launch_stream_copy(const uint64_t* in, uint64_t* out, size_t words, bool non_temporal, hipStream_t stream);
+// `records` runs of record_words words from runs src_stride words apart to runs dst_stride apart (record_words a multiple of 2048,
+// 16-byte aligned slabs, even strides; hipErrorInvalidValue otherwise)
+hipError_t launch_copy_records(const uint64_t* in, size_t src_stride, uint64_t* out, size_t dst_stride, size_t record_words,
+                               size_t records, hipStream_t stream);
 hipError_t launch_narrow_words(const uint64_t* in, uint32_t* out, size_t words, hipStream_t stream);
 hipError_t launch_divide_and_round_q_last32(const uint32_t* in, uint32_t* out, const DeviceContext32& ctx,
                                             uint32_t moduli_count, size_t polys, hipStream_t stream);

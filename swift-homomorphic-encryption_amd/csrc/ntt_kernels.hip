@@ -1533,6 +1533,26 @@ hipError_t launch_ntt_mixed(bool inverse, uint64_t* slab, const DeviceContext& c
     return hipSuccess;
 }
 
+// The rows [first, first + count) of every record only (row r uses modulus r), one launch per run of moduli of one butterfly
+// class inside that range: e.g. the Bsk rows of lifted records whose Q rows already hold their transform.
+hipError_t launch_ntt_record_band(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t record_rows, uint32_t first,
+                                  uint32_t count, size_t records, hipStream_t stream) {
+    if (records == 0 || count == 0) return hipSuccess;
+    const bool tiled = ctx.log_degree >= 12 && ctx.log_degree <= kMaxFusedLoadLogDegree;
+    if (!tiled || first + count > record_rows || records * record_rows > (size_t(1) << 30)) return hipErrorNotSupported;
+    BandRun runs[kMaxBandRuns];
+    const int run_count = band_runs(ctx, record_rows, runs);
+    if (run_count <= 1) return launch_ntt_band(inverse, slab, ctx, first, count, record_rows, first, records, production_mode(ctx), stream);
+    for (int k = 0; k < run_count; ++k) {
+        const uint32_t begin = runs[k].base > first ? runs[k].base : first;
+        const uint32_t end = runs[k].base + runs[k].rows < first + count ? runs[k].base + runs[k].rows : first + count;
+        if (begin >= end) continue;
+        hipError_t e = launch_ntt_band(inverse, slab, ctx, begin, end - begin, record_rows, begin, records, runs[k].mode, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // Forward NTT of lifted [Q, Bsk] records whose Q rows are still where the ciphertexts lie (the lift was told not to copy
 // them, rns_kernels launch_lift_q_to_qbsk_strided): the Q band is read from the source polynomials (kSourceRows) and
 // written into the slab, the Bsk band is transformed in place.  hipErrorNotSupported when the context has no fold-free

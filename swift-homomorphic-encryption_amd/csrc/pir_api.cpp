@@ -65,7 +65,7 @@ namespace {
 // every column's ct . pt inner product in one launch (PirUtil.swift:428-437), then back to Coeff (:438); packed: the
 // database holds packed plaintexts (he_amd.h he_bfv_pack_plaintexts_device)
 int dim0_columns(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0, const uint64_t* database, bool packed,
-                 const uint8_t* present_device, size_t columns, uint64_t* out, he_stream s) {
+                 const uint8_t* present_device, size_t columns, uint64_t* out, he_stream s, bool leave_in_eval = false) {
     if (ctx == nullptr) return invalid_argument("null context");
     if (columns == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database == nullptr || out == nullptr) return invalid_argument("null operand");
@@ -78,6 +78,7 @@ int dim0_columns(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, siz
     else
         HEAMD_TRY_STATUS(he_bfv_inner_product_plain_resident_device(ctx, L, 2, dim0_query_eval, database, present_device,
                                                                     d0, columns, out, s));
+    if (leave_in_eval) return HE_OK;  // (remaining_dimensions takes them as they are: results_in_eval)
     return he_ntt_inverse_device(q_ctx, out, columns * 2, s);
 }
 }  // namespace
@@ -99,7 +100,7 @@ namespace {
 // dimension is one batch over chunks x groups.
 int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
                          const ChunkShape& shape, size_t chunks, uint64_t* results, const uint64_t* remaining_query,
-                         const uint64_t* relinearization_key, uint64_t* out, he_stream s) {
+                         const uint64_t* relinearization_key, uint64_t* out, he_stream s, bool results_in_eval = false) {
     hipStream_t stream = as_stream(s);
     const uint32_t L = shape.L;
     const size_t n = shape.n, poly = size_t(L) * n, ct2 = 2 * poly, ct3 = 3 * poly;
@@ -119,7 +120,20 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
         if (count % d != 0) return invalid_argument("intermediate results do not divide by the dimension");
         const size_t items = chunks * (count / d);  // groups of d consecutive results, chunk after chunk
         const uint64_t* query = remaining_query + cursor * ct2;
-        HEAMD_TRY_STATUS(he_bfv_inner_product_shared_device(ctx, L, query, current, d, items, products, s));
+        // results_in_eval: the dim-0 inner products came as their kernel left them, in Eval form -- the first dimension's ct x ct
+        // inner products then keep those words as the Q rows of their lifted operands instead of transforming them back
+        // (profiles/r06y_pir_tail_eval_rows.txt)
+        int status = heamd::kInnerProductEvalUnavailable;
+        if (results_in_eval && i == 1)
+            status = heamd::bfv_inner_product_shared_eval_rhs(ctx, L, query, current, d, items, products, stream);
+        if (status == heamd::kInnerProductEvalUnavailable) {
+            if (results_in_eval && i == 1) {  // PirUtil.swift:438
+                const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
+                HEAMD_TRY_STATUS(he_ntt_inverse_device(q_ctx, current, chunks * count * 2, s));
+            }
+            status = he_bfv_inner_product_shared_device(ctx, L, query, current, d, items, products, s);
+        }
+        HEAMD_TRY_STATUS(status);
         HEAMD_TRY_STATUS(he_bfv_relinearize_device(ctx, L, products, relinearization_key, other, items, nullptr, 0, s));
         uint64_t* swap = current;
         current = other;
@@ -128,6 +142,10 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
         cursor += d;
     }
     if (count != 1) return invalid_argument("dimensions leave more than one ciphertext");  // PirUtil.swift:481-482
+    if (results_in_eval && dimension_count == 1) {  // PirUtil.swift:438 with nothing after it
+        const he_poly_context* q_ctx = he_bfv_ciphertext_context(ctx, L);
+        HEAMD_TRY_STATUS(he_ntt_inverse_device(q_ctx, current, chunks * 2, s));
+    }
     // modSwitchDownToSingle (:483) on the chunks' 2-polynomial ciphertexts
     return he_bfv_mod_switch_down_to_single_device(ctx, L, 2, current, out, chunks, s);
 }
@@ -168,9 +186,9 @@ int response_chunks_resident(const he_bfv_context* ctx, const uint32_t* dimensio
     if (piece >= chunks) {
         // a chunk is [columns][d0] plaintexts and the chunks are contiguous: all their columns form one column range
         HEAMD_TRY_STATUS(dim0_columns(ctx, dim0_query_eval, shape.d0, database, packed, present_device, chunks * shape.columns,
-                                      results, s));
+                                      results, s, true));
         return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunks, results, remaining_query,
-                                    relinearization_key, out, s);
+                                    relinearization_key, out, s, true);
     }
     heamd::LaneLease lease(heamd::lane_pool(ctx), stream);
     if (lease.lane == nullptr) {
@@ -520,7 +538,7 @@ int compute_response_queries(const he_bfv_context* ctx, const uint32_t* dimensio
         status = he_bfv_inner_product_plain_resident_device(
             ctx, L, static_cast<uint32_t>(2 * queries), dim0_queries_eval, database + first * chunk_words,
             present_device ? present_device + first * shape.per_chunk : nullptr, shape.d0, columns, piece_all, s);
-        if (status == HE_OK) status = he_ntt_inverse_device(shape.q_ctx, piece_all, columns * 2 * queries, s);
+        // (left in Eval form: remaining_dimensions, results_in_eval)
         if (status != HE_OK) break;
         if (lane != nullptr) {
             e = hipEventRecord(lane->stage[0], stream);
@@ -530,14 +548,18 @@ int compute_response_queries(const he_bfv_context* ctx, const uint32_t* dimensio
         }
         for (size_t q = 0; q < queries && status == HE_OK && e == hipSuccess; ++q) {
             // this query's results, column after column (a strided copy: they sit `queries` ciphertexts apart)
-            e = hipMemcpy2DAsync(one, ct_bytes, piece_all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
-                                 hipMemcpyDeviceToDevice, tail_stream);
+            e = heamd::launch_copy_records(piece_all + q * ct_words, queries * ct_words, one, ct_words, ct_words, columns, tail_stream);
+            if (e == hipErrorInvalidValue) {  // (a degree below the copy kernel's granule)
+                (void)hipGetLastError();
+                e = hipMemcpy2DAsync(one, ct_bytes, piece_all + q * ct_words, queries * ct_bytes, ct_bytes, columns,
+                                     hipMemcpyDeviceToDevice, tail_stream);
+            }
             if (e != hipSuccess) break;
             status = remaining_dimensions(
                 ctx, dimensions, dimension_count, shape, now, one,
                 remaining_queries ? remaining_queries + q * remaining_stride * ct_words : nullptr,
                 relinearization_keys ? relinearization_keys[q] : nullptr, out + (q * chunk_count + first) * out_words,
-                static_cast<he_stream>(tail_stream));
+                static_cast<he_stream>(tail_stream), true);
         }
     }
     if (forked) {  // the join is enqueued whatever happened in between
