@@ -110,10 +110,10 @@ int bfv_expand_step_fused(const he_bfv_context* ctx, uint32_t L, const uint64_t*
                           const uint32_t* leaf_table, size_t leaf_stride, void* workspace, size_t workspace_bytes,
                           hipStream_t stream, const uint64_t* rotated = nullptr);
 
-// bfv_api.cpp: `items` ct x ct inner products that share lhs, the right-hand side arriving in Eval form over Q and leaving in
-// Coeff form (the first remaining dimension of a PIR response; not exported)
+// bfv_api.cpp: `items` ct x ct inner products that share lhs, the right-hand side given in Eval form over Q (the first remaining
+// dimension of a PIR response; not exported)
 constexpr int kInnerProductEvalUnavailable = -2;
-int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, const uint64_t* lhs, uint64_t* rhs_eval,
+int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, const uint64_t* lhs, const uint64_t* rhs_eval,
                                       size_t count, size_t items, uint64_t* out, hipStream_t stream);
 
 // Stream-ordered scratch buffer (scratch_allocate / scratch_release on the same stream).

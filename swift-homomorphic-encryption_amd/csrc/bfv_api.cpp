@@ -1153,6 +1153,17 @@ int inner_product_shared_pipeline(const he_bfv_context* ctx, const RnsToolLevel*
     const DeviceContext qbsk = tool->qbsk->device_context();
     // lifted_l and lifted_r are adjacent: one transform launch over both
     HEAMD_HIP_TRY(ntt_records(false, lifted_l, *tool->qbsk, qbsk, static_cast<uint32_t>(rows), (1 + items) * count * 2, stream));
+    if constexpr (std::is_same<W, uint64_t>::value) {
+        // the carry-counting sums where they exist (rns_kernels.hip tensor_accumulate_shared_sums_kernel)
+        const uint64_t cadence = heamd::tensor_sums_cadence(tool->qbsk->moduli().data(), static_cast<uint32_t>(rows));
+        const hipError_t sums = heamd::launch_tensor_accumulate_shared_sums(lifted_l, lifted_r, nullptr, 0, sum, qbsk, count, items,
+                                                                           cadence, stream);
+        if (sums != hipErrorNotSupported) {
+            HEAMD_HIP_TRY(sums);
+            return drop_extended_base(*tool, sum, out, items * 3, stream);
+        }
+        (void)hipGetLastError();
+    }
     const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(static_cast<uint32_t>(rows)) / 2;
     HEAMD_HIP_TRY(heamd::launch_tensor_accumulate_shared(static_cast<const W*>(lifted_l), static_cast<const W*>(lifted_r), sum,
                                                          qbsk, count, items, max_lazy ? max_lazy : 1, stream));
@@ -1162,14 +1173,14 @@ int inner_product_shared_pipeline(const he_bfv_context* ctx, const RnsToolLevel*
 }  // extern "C++"
 
 // inner_product_shared_pipeline for a right-hand side that arrives in EVAL form over Q (the dim-0 inner products of a PIR
-// response as their kernel leaves them, PirUtil.swift:428-437): the Q rows of its lifted records are those words themselves --
-// the forward transform of the inverse transform of a canonical row is the row -- so they are copied into place, and only the
-// Bsk rows go through inverse transform, lift and forward transform.  rhs is left in Coeff form (what convertToCoeffFormat,
-// PirUtil.swift:438, hands the reference's innerProduct).  kInnerProductEvalUnavailable: nothing launched, the caller takes
-// rhs to Coeff and calls he_bfv_inner_product_shared_device.
+// response as their kernel leaves them, PirUtil.swift:428-437): the Q rows of its lifted records would be those words themselves
+// -- the forward transform of the inverse transform of a canonical row is the row -- so the sums read them where they lie, and
+// only the Bsk rows go through the inverse transform (out of place, into a Coeff copy), the lift and the forward transform.
+// rhs_eval is not written.  kInnerProductEvalUnavailable: nothing launched, the caller takes rhs to Coeff
+// (convertToCoeffFormat, PirUtil.swift:438) and calls he_bfv_inner_product_shared_device.
 extern "C++" {
 namespace heamd {
-int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, const uint64_t* lhs, uint64_t* rhs_eval,
+int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, const uint64_t* lhs, const uint64_t* rhs_eval,
                                       size_t count, size_t items, uint64_t* out, hipStream_t stream) {
     const RnsToolLevel* tool = nullptr;
     int status = check_level(ctx, L, &tool);
@@ -1178,23 +1189,27 @@ int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, con
     const DeviceContext qbsk = tool->qbsk->device_context();
     const uint32_t rows = 2 * L + 1;
     const size_t n = ctx->impl->degree(), ext = qbsk_poly_words(*ctx->impl, L), polys = items * count * 2;
-    if (q_ctx == nullptr || polys == 0 || qbsk.log_degree < 12 || qbsk.log_degree > 13 || polys * rows > (size_t(1) << 30))
-        return heamd::kInnerProductEvalUnavailable;
-    Scratch scratch(stream);
+    const uint64_t cadence = heamd::tensor_sums_cadence(tool->qbsk->moduli().data(), rows);
+    if (q_ctx == nullptr || polys == 0 || cadence == 0 || qbsk.log_degree < 12 || qbsk.log_degree > 13 ||
+        polys * rows > (size_t(1) << 30))
+        return kInnerProductEvalUnavailable;
+    const DeviceContext q_device = q_ctx->device_context();
+    if (q_device.approx_ok == 0) return kInnerProductEvalUnavailable;  // (no out-of-place transform for such moduli)
+    Scratch scratch(stream), coeff_mem(stream);
     HEAMD_HIP_TRY(scratch.allocate((count * 2 + polys + items * 3) * ext * sizeof(uint64_t)));
+    HEAMD_HIP_TRY(coeff_mem.allocate(polys * size_t(L) * n * sizeof(uint64_t)));
     uint64_t* lifted_l = static_cast<uint64_t*>(scratch.get());  // [count][2][2L+1][N]
-    uint64_t* lifted_r = lifted_l + count * 2 * ext;              // [items][count][2][2L+1][N]
+    uint64_t* lifted_r = lifted_l + count * 2 * ext;              // [items][count][2][2L+1][N]: only the Bsk rows are used
     uint64_t* sum = lifted_r + polys * ext;                       // [items][3][2L+1][N]
+    uint64_t* coeff = static_cast<uint64_t*>(coeff_mem.get());    // [items][count][2][L][N]
     HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk(lhs, lifted_l, tool->device, count * 2, stream));
     HEAMD_HIP_TRY(ntt_records(false, lifted_l, *tool->qbsk, qbsk, rows, count * 2, stream));
-    HEAMD_HIP_TRY(heamd::launch_copy_records(rhs_eval, size_t(L) * n, lifted_r, ext, size_t(L) * n, polys, stream));
-    HEAMD_HIP_TRY(heamd::launch_ntt(true, rhs_eval, q_ctx->device_context(), 0, L, polys * L, stream));
-    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(static_cast<const uint64_t*>(rhs_eval), lifted_r, tool->device, polys, 1,
+    HEAMD_HIP_TRY(heamd::launch_ntt_inverse_out_of_place(rhs_eval, coeff, q_device, 0, L, polys * L, stream));
+    HEAMD_HIP_TRY(heamd::launch_lift_q_to_qbsk_strided(static_cast<const uint64_t*>(coeff), lifted_r, tool->device, polys, 1,
                                                        size_t(L) * n, ext, 0, stream, false));
     HEAMD_HIP_TRY(heamd::launch_ntt_record_band(false, lifted_r, qbsk, rows, L, rows - L, polys, stream));
-    const uint64_t max_lazy = tool->qbsk->max_lazy_product_accumulation_count(rows) / 2;
-    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate_shared(static_cast<const uint64_t*>(lifted_l), static_cast<const uint64_t*>(lifted_r),
-                                                         sum, qbsk, count, items, max_lazy ? max_lazy : 1, stream));
+    HEAMD_HIP_TRY(heamd::launch_tensor_accumulate_shared_sums(lifted_l, lifted_r, rhs_eval, L, sum, qbsk, count, items, cadence,
+                                                              stream));
     return drop_extended_base(*tool, sum, out, items * 3, stream);
 }
 }  // namespace heamd

@@ -22,6 +22,10 @@ enum {
 // NTT of `rows` contiguous length-N rows.  Row r uses modulus index mod_base + (r % mod_period).
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,
                       size_t rows, hipStream_t stream, int force_variant = kNttVariantAuto);
+// Inverse NTT out of place: rows read from `source`, written to the same places of `slab` (N = 4096 / 8192 with every modulus
+// below 2^61; hipErrorNotSupported, nothing launched, elsewhere)
+hipError_t launch_ntt_inverse_out_of_place(const uint64_t* source, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+                                           uint32_t mod_period, size_t rows, hipStream_t stream);
 // Key-switching decomposition fused into the forward NTT (Bfv+Keys.swift:165-179): spread [polys][L][L+1][N] row
 // (poly, j, r) = NTT_{ks modulus r}( source row j of polynomial `poly`, reduced mod r when q_j > modulus r ), read
 // from source + poly * poly_stride + j * N.  galois_inverse = g^-1 mod 2N: the source polynomial is first taken through

@@ -424,9 +424,12 @@ __global__ void __launch_bounds__(1 << LOGT, min_waves_per_simd(LOGN - LOGT, ROW
             }
         } else {
             [[maybe_unused]] const uint64_t p = mod.p;
+            // (plain slabs may be transformed OUT OF PLACE: rows read from source_spec.first, laid out like the slab, when it is set)
+            const uint64_t* load_base = slab;
+            if constexpr (SOURCE == kInverseFromSlab) load_base = tensor_source != nullptr ? tensor_source : slab;
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) {
-                const BufferResource in = make_resource(slab + (rows[k] << LOGN), 8u << LOGN);
+                const BufferResource in = make_resource(load_base + (rows[k] << LOGN), 8u << LOGN);
                 if constexpr (kStagedLoad<LOGN, LOGE, LOW>) {
                     global_load_staged<LOGN, LOGE, LOW>(v[k], tid, in, lds);
                 } else {
@@ -1671,6 +1674,20 @@ hipError_t launch_ntt_key_mac_inverse_finish(const uint64_t* spread, const uint6
     hipError_t e = launch_key_mac_runs(prod, ks, L, 1, L, polys * 2, kInverseFromKeyMac, spec, stream);
     if (e != hipSuccess) return e;
     return launch_key_mac_runs(prod, ks, 0, L, L, polys * 2, kInverseFromKeyMacFinish, spec, stream);
+}
+
+// Inverse NTT of `rows` rows read from `source` and written to the same places of `slab` (the tiled 8-words-per-lane kernels of
+// N = 4096 / 8192 load their rows through source_spec.first when it is set); hipErrorNotSupported (nothing launched) elsewhere.
+hipError_t launch_ntt_inverse_out_of_place(const uint64_t* source, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base,
+                                           uint32_t mod_period, size_t rows, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    if (source == nullptr || ctx.scaled_inverse_degree != 0 || ctx.approx_ok == 0 || rows > (size_t(1) << 30)) return hipErrorNotSupported;
+    const InverseSource spec{source, nullptr, 0, 0, nullptr, 0, nullptr, 0};
+    switch (ctx.log_degree) {
+        case 12: return launch_tiled<12, 9>(true, production_mode(ctx), slab, ctx, mod_base, mod_period, rows, stream, 0, 0, kInverseFromSlab, spec);
+        case 13: return launch_tiled<13, 10>(true, production_mode(ctx), slab, ctx, mod_base, mod_period, rows, stream, 0, 0, kInverseFromSlab, spec);
+        default: return hipErrorNotSupported;
+    }
 }
 
 hipError_t launch_ntt(bool inverse, uint64_t* slab, const DeviceContext& ctx, uint32_t mod_base, uint32_t mod_period,

@@ -121,8 +121,8 @@ int remaining_dimensions(const he_bfv_context* ctx, const uint32_t* dimensions, 
         const size_t items = chunks * (count / d);  // groups of d consecutive results, chunk after chunk
         const uint64_t* query = remaining_query + cursor * ct2;
         // results_in_eval: the dim-0 inner products came as their kernel left them, in Eval form -- the first dimension's ct x ct
-        // inner products then keep those words as the Q rows of their lifted operands instead of transforming them back
-        // (profiles/r06y_pir_tail_eval_rows.txt)
+        // inner products then read those words as the Q rows of their lifted operands instead of transforming them back and
+        // forth (the tail of 8 chunks of 256 x 64: 0.91 -> 0.74 ms, profiles/r06y_pir_tail_eval_rows.txt)
         int status = heamd::kInnerProductEvalUnavailable;
         if (results_in_eval && i == 1)
             status = heamd::bfv_inner_product_shared_eval_rhs(ctx, L, query, current, d, items, products, stream);

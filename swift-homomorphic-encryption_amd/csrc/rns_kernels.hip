@@ -576,6 +576,65 @@ __global__ void __launch_bounds__(kThreads)
     }
 }
 
+// The same sums on the carry-counting accumulator (device_math.hpp ProductSum: 7 instructions per product against ~18 for a
+// 128-bit multiply-add -- at 64 terms the 128-bit form was bound by the multiplier, 177 us where the operands stream in 100),
+// 8-byte words.  `cadence` terms at most between folds, chosen by the launcher so that the middle sum (two products per term)
+// stays below 2^127 (reduce_product_sum's contract); the canonical result does not depend on it.
+// rhs_q != nullptr: rows [0, q_rows) of the right-hand polynomials are read from there instead -- [items][count][2][q_rows][N],
+// the Eval-form ciphertexts a caller already holds (bfv_api.cpp bfv_inner_product_shared_eval_rhs) -- and the lifted records'
+// own first q_rows rows are not touched.
+__global__ void __launch_bounds__(kThreads)
+    tensor_accumulate_shared_sums_kernel(const uint64_t* __restrict__ lhs, const uint64_t* __restrict__ rhs,
+                                         const uint64_t* __restrict__ rhs_q, uint32_t q_rows, uint64_t* __restrict__ out,
+                                         const DeviceContext ctx, size_t count, uint64_t cadence) {
+    const uint32_t logn = ctx.log_degree;
+    const size_t poly_words = size_t(ctx.moduli_count) << logn;
+    const size_t item = blockIdx.y;
+    const size_t w = blockIdx.x * size_t(kThreads) + threadIdx.x;  // (the grid covers poly_words exactly: degree >= kThreads)
+    const uint32_t row = static_cast<uint32_t>((blockIdx.x * size_t(kThreads)) >> logn);  // uniform
+    const DeviceModulus m = ctx.moduli[row];
+    const bool from_q = rhs_q != nullptr && row < q_rows;
+    const size_t right_poly = from_q ? size_t(q_rows) << logn : poly_words;
+    const uint64_t* __restrict__ a = lhs + w;
+    const uint64_t* __restrict__ b = (from_q ? rhs_q : rhs) + item * count * 2 * right_poly + w;
+    ProductSum d0 = product_sum_zero(), d1 = product_sum_zero(), d2 = product_sum_zero();
+    // the operands of kAhead terms in flight.  (Two measured slower: 66 registers, 156 against 145 us for the 8 x 64 terms of the
+    // PIR tail -- which streams 604 MB, so 100 us is the floor; the 128-bit sums took 177 us at 74 registers.)
+    constexpr int kAhead = 1;
+    uint64_t a0[kAhead], a1[kAhead], b0[kAhead], b1[kAhead];
+    auto fetch = [&](int slot, size_t k) {
+        const size_t term = k < count ? k : count - 1;  // (past the end: the last term again -- no branch around the loads)
+        a0[slot] = a[term * 2 * poly_words];
+        a1[slot] = a[term * 2 * poly_words + poly_words];
+        b0[slot] = __builtin_nontemporal_load(b + term * 2 * right_poly);
+        b1[slot] = __builtin_nontemporal_load(b + term * 2 * right_poly + right_poly);
+    };
+#pragma unroll
+    for (int slot = 0; slot < kAhead; ++slot) fetch(slot, slot);
+    uint64_t since = 0;
+    for (size_t k = 0; k < count; k += kAhead) {
+#pragma unroll
+        for (int slot = 0; slot < kAhead; ++slot) {
+            const uint64_t x0 = a0[slot], x1 = a1[slot], y0 = b0[slot], y1 = b1[slot];
+            fetch(slot, k + slot + kAhead);
+            if (k + slot < count) {  // (uniform)
+                product_sum_add_pair<false>(d0, d1, x0, x1, y0);  // d0 += a0 b0, d1 += a1 b0
+                product_sum_add_pair<false>(d1, d2, x0, x1, y1);  // d1 += a0 b1, d2 += a1 b1
+                if (++since >= cadence) {
+                    since = 0;
+                    d0 = ProductSum{reduce_product_sum(d0, m), 0, 0, 0, 0};
+                    d1 = ProductSum{reduce_product_sum(d1, m), 0, 0, 0, 0};
+                    d2 = ProductSum{reduce_product_sum(d2, m), 0, 0, 0, 0};
+                }
+            }
+        }
+    }
+    uint64_t* __restrict__ sum = out + item * 3 * poly_words + w;
+    sum[0] = reduce_product_sum(d0, m);
+    sum[poly_words] = reduce_product_sum(d1, m);
+    sum[2 * poly_words] = reduce_product_sum(d2, m);
+}
+
 // ---- key switching, step 1: decompose-and-spread (Bfv+Keys.swift:165-172) ----------------------------------------
 // target: row j of polynomial `poly` at  target_base + poly * target_stride + j * N   (Coeff, mod q_j)
 // out: [polys][L][L+1][N]: word (poly, j, r, k) = target[j][k] mod ks_modulus[r]  (reduced only when q_j > modulus r)
@@ -929,6 +988,38 @@ hipError_t launch_tensor_accumulate(const W* in, W* out, const DeviceContext& qb
     hipLaunchKernelGGL(tensor_accumulate_kernel<W>, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, qbsk,
                        count, max_lazy);
     return hipGetLastError();
+}
+
+// the terms the carry-counting sums take between folds: the middle sum's 2 products per term below 2^127, starting from a
+// folded residue (moduli: the context's, host copies); 0: a modulus too wide for them
+uint64_t tensor_sums_cadence(const uint64_t* moduli, uint32_t count) {
+    unsigned __int128 cadence = ~uint64_t(0);
+    for (uint32_t i = 0; i < count; ++i) {
+        const unsigned __int128 below = moduli[i] - 1;
+        if (below == 0) continue;
+        const unsigned __int128 limit = ((static_cast<unsigned __int128>(1) << 127) - moduli[i]) / (below * below) / 2;
+        if (limit < cadence) cadence = limit;
+    }
+    return static_cast<uint64_t>(cadence);
+}
+
+hipError_t launch_tensor_accumulate_shared_sums(const uint64_t* lhs, const uint64_t* rhs, const uint64_t* rhs_q, uint32_t q_rows,
+                                                uint64_t* out, const DeviceContext& qbsk, size_t count, size_t items,
+                                                uint64_t cadence, hipStream_t stream) {
+    if (items == 0) return hipSuccess;
+    const size_t total = size_t(qbsk.moduli_count) << qbsk.log_degree;
+    if (cadence == 0 || qbsk.degree < kThreads || total / kThreads >= (size_t(1) << 31)) return hipErrorNotSupported;
+    const size_t right = rhs_q != nullptr ? size_t(q_rows) << qbsk.log_degree : 0;
+    for (size_t done = 0; done < items; done += 65535) {  // grid.y carries the item
+        const size_t now = items - done < 65535 ? items - done : 65535;
+        hipLaunchKernelGGL(tensor_accumulate_shared_sums_kernel, dim3(static_cast<unsigned>(total / kThreads), static_cast<unsigned>(now)),
+                           dim3(kThreads), 0, stream, lhs, rhs + done * count * 2 * total,
+                           rhs_q != nullptr ? rhs_q + done * count * 2 * right : nullptr, q_rows, out + done * 3 * total, qbsk, count,
+                           cadence);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <typename W>

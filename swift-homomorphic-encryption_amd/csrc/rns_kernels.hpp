@@ -43,6 +43,13 @@ hipError_t launch_tensor(const W* in, W* out, const DeviceContext& qbsk, size_t 
 template <typename W>
 hipError_t launch_tensor_accumulate(const W* in, W* out, const DeviceContext& qbsk, size_t count, uint64_t max_lazy,
                                     hipStream_t stream);
+// The shared-lhs sums below on the carry-counting accumulator (8-byte words, degree >= 256): `cadence` terms between folds from
+// tensor_sums_cadence (0: hipErrorNotSupported, nothing launched).  rhs_q != nullptr: rows [0, q_rows) of the right-hand
+// polynomials come from rhs_q [items][count][2][q_rows][N] instead of the lifted records.
+uint64_t tensor_sums_cadence(const uint64_t* moduli, uint32_t count);
+hipError_t launch_tensor_accumulate_shared_sums(const uint64_t* lhs, const uint64_t* rhs, const uint64_t* rhs_q, uint32_t q_rows,
+                                                uint64_t* out, const DeviceContext& qbsk, size_t count, size_t items,
+                                                uint64_t cadence, hipStream_t stream);
 // `items` sums that share lhs: lhs [count][2][rows][N], rhs [items][count][2][rows][N] -> out [items][3][rows][N]
 template <typename W>
 hipError_t launch_tensor_accumulate_shared(const W* lhs, const W* rhs, W* out, const DeviceContext& qbsk, size_t count,
