@@ -9,7 +9,7 @@ an error: the experiment has drifted from the source and must be updated), recom
 and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
 
   python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
-  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small|pir] [--rounds N] [NAME ...]     (on the GPU box)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small|pir|c4|script:PATH] [--rounds N] [NAME ...]     (on the GPU box)
       times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
       so that clock drift shows up as spread
 """
@@ -116,6 +116,11 @@ print("chunk loop median %%.3f ms (min %%.3f max %%.3f)  whole query median %%.3
     whole.spread["median_ms"], whole.spread["min_ms"], whole.spread["max_ms"]))
 ''' % (ROOT, PKG, os.path.join(ROOT, "bench_tools"))
 
+C4_TIMER = ("import sys; sys.path[:0] = [%r, %r, %r]; import torch, heamd, path_bench; heamd.set_scratch_cache(); "
+            "r = path_bench.config4_mod_switch(torch, heamd, batch=8192, reps=10); "
+            "print('N=16384 6->5 moduli: %%.3f M poly/s  frac of 8 TB/s %%.4f  median %%.4f ms' %% (r['poly_per_s'] / 1e6, "
+            "r['frac_of_8TBps'], r['spread_ms']['median_ms']))" % (ROOT, PKG, os.path.join(ROOT, "bench_tools")))
+
 
 def load_spec(name):
     path = os.path.join(SPECS, name + ".py")
@@ -190,7 +195,10 @@ def run(args):
             rounds = int(args.pop(0))
         else:
             names.append(a)
-    timer = C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else PIR_TIMER if what == "pir" else NTT_TIMER % repr(SHAPES[what])
+    script = what[len("script:"):] if what.startswith("script:") else None  # any bench script: every line it prints
+    if script:
+        SHAPES[what] = []
+    timer = ("import runpy, sys; sys.argv = [%r]; runpy.run_path(%r, run_name='__main__')" % (script, script)) if script else C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else PIR_TIMER if what == "pir" else C4_TIMER if what == "c4" else NTT_TIMER % repr(SHAPES[what])
     libs = {"production": None}
     for path in sorted(glob.glob(os.path.join(VARIANTS, "libhe_amd_*.so"))):
         name = os.path.basename(path)[len("libhe_amd_"):-3]
@@ -202,6 +210,10 @@ def run(args):
             if path:
                 env["HEAMD_LIBRARY"] = path
             result = subprocess.run([sys.executable, "-c", timer], env=env, capture_output=True, text=True)
+            if script and result.returncode == 0:
+                for line in result.stdout.strip().splitlines():
+                    print(f"round {round_index}  {name:24s} {line}", flush=True)
+                continue
             line = result.stdout.strip().splitlines()[-1] if result.returncode == 0 and result.stdout.strip() else (
                 "FAILED " + result.stderr[-300:])
             print(f"round {round_index}  {name:24s} {line}", flush=True)

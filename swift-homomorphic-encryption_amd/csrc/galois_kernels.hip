@@ -23,10 +23,20 @@ namespace {
 
 constexpr unsigned kThreads = 256;
 
+constexpr size_t kGridCap = (size_t(1) << 31) - 1;
+// One workgroup per kThreads work items, up to the grid limit: the kernels keep their grid-stride loops for what lies beyond it,
+// but a lane that walks many items serialises its loads -- divideAndRoundQLast at N = 16384, L = 6 ran at 0.66 of 8 TB/s on
+// 256 x 8 workgroups and at 0.79 with one item per lane (profiles/r06y_exact_grids.txt)
 inline unsigned grid_for(size_t work_items) {
     const size_t blocks = (work_items + kThreads - 1) / kThreads;
-    const size_t cap = 256 * 8;
+    const size_t cap = kGridCap;
     return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+// ... except the gathers that measured faster on a few workgroups per CU walking their items (the Coeff-form automorphism:
+// 0.67 against 0.57 of 8 TB/s; the plaintext unlift)
+inline unsigned grid_capped(size_t work_items) {
+    const unsigned blocks = grid_for(work_items);
+    return blocks < 256u * 8u ? blocks : 256u * 8u;
 }
 
 // Output word j of a row takes input word src (sign flipped when `negate`): shared by the automorphism and by the
@@ -183,7 +193,7 @@ hipError_t launch_galois_coeff(const W* in, W* out, const DeviceContext& ctx, ui
                                hipStream_t stream) {
     const size_t words = rows << ctx.log_degree;
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL((coeff_permute_kernel<CoeffMap::Galois, W>), dim3(grid_for(words)), dim3(kThreads), 0, stream, in,
+    hipLaunchKernelGGL((coeff_permute_kernel<CoeffMap::Galois, W>), dim3(grid_capped(words)), dim3(kThreads), 0, stream, in,
                        out, ctx, inverse_element, words);
     return hipGetLastError();
 }
@@ -223,7 +233,7 @@ hipError_t launch_plaintext_lift(const W* plaintext, W* out, const DeviceContext
 template <typename W>
 hipError_t launch_plaintext_unlift(W* rows, uint64_t q0, uint64_t t, size_t words, hipStream_t stream) {
     if (words == 0) return hipSuccess;
-    hipLaunchKernelGGL(plaintext_unlift_kernel<W>, dim3(grid_for(words)), dim3(kThreads), 0, stream, rows, q0, t, words);
+    hipLaunchKernelGGL(plaintext_unlift_kernel<W>, dim3(grid_capped(words)), dim3(kThreads), 0, stream, rows, q0, t, words);
     return hipGetLastError();
 }
 

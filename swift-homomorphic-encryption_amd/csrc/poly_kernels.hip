@@ -20,9 +20,13 @@ namespace {
 
 constexpr unsigned kThreads = 256;
 
+constexpr size_t kGridCap = (size_t(1) << 31) - 1;
+// One workgroup per kThreads work items, up to the grid limit: the kernels keep their grid-stride loops for what lies beyond it,
+// but a lane that walks many items serialises its loads -- divideAndRoundQLast at N = 16384, L = 6 ran at 0.66 of 8 TB/s on
+// 256 x 8 workgroups and at 0.79 with one item per lane (profiles/r06y_exact_grids.txt)
 inline unsigned grid_for(size_t work_items) {
     const size_t blocks = (work_items + kThreads - 1) / kThreads;
-    const size_t cap = 256 * 8;  // 256 CUs x 8 workgroups
+    const size_t cap = kGridCap;
     return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
@@ -157,6 +161,49 @@ __global__ void __launch_bounds__(kThreads)
             x.y = shoup_mul_uniform(negative1 ? add_mod_uniform(x.y, t1, m.p) : sub_mod_uniform(x.y, t1, m.p), inv.x,
                                     inv.y, m.p);
             stream_store(dst + static_cast<size_t>(row) * pairs_per_row, x);
+        }
+    }
+}
+
+// The same with the number of rows known at compile time: all L loads of a coefficient pair are issued before the first one is
+// used (the loop above has one in flight per lane, which at 8 waves per SIMD is half of what the memory system needs to stay
+// busy: 0.70 of 8 TB/s at N = 16384, L = 6 against the copy's 0.78).
+template <int L>
+__global__ void __launch_bounds__(kThreads)
+    divide_and_round_q_last_rows_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const DeviceContext ctx,
+                                        size_t polys) {
+    constexpr int last = L - 1;
+    const uint32_t pairs_per_row = ctx.degree >> 1;
+    const size_t total = polys * pairs_per_row;
+    const uint64_t q_last = ctx.moduli[last].p;
+    const uint64_t q_last_div2 = q_last >> 1;
+    const U64x2* __restrict__ inverse_q_last = ctx.inverse_q_last + static_cast<size_t>(last) * ctx.moduli_stride;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kThreads) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t poly = i / pairs_per_row;
+        const uint32_t k = static_cast<uint32_t>(i - poly * pairs_per_row);
+        const U64x2* src = reinterpret_cast<const U64x2*>(in) + poly * L * pairs_per_row + k;
+        U64x2* dst = reinterpret_cast<U64x2*>(out) + poly * last * pairs_per_row + k;
+        U64x2 x[L];
+#pragma unroll
+        for (int row = 0; row < L; ++row) x[row] = stream_load(src + static_cast<size_t>(row) * pairs_per_row);
+        const uint64_t r0 = add_mod_uniform(x[last].x, q_last_div2, q_last);
+        const uint64_t r1 = add_mod_uniform(x[last].y, q_last_div2, q_last);
+        const bool negative0 = r0 < q_last_div2, negative1 = r1 < q_last_div2;
+        const uint64_t magnitude0 = negative0 ? q_last_div2 - r0 : r0 - q_last_div2;
+        const uint64_t magnitude1 = negative1 ? q_last_div2 - r1 : r1 - q_last_div2;
+#pragma unroll
+        for (int row = 0; row < last; ++row) {
+            const DeviceModulus m = ctx.moduli[row];
+            const U64x2 inv = inverse_q_last[row];
+            const uint64_t t0 = barrett_reduce64_uniform(magnitude0, m.p, m.barrett64);
+            const uint64_t t1 = barrett_reduce64_uniform(magnitude1, m.p, m.barrett64);
+            U64x2 y;
+            y.x = shoup_mul_uniform(negative0 ? add_mod_uniform(x[row].x, t0, m.p) : sub_mod_uniform(x[row].x, t0, m.p), inv.x,
+                                    inv.y, m.p);
+            y.y = shoup_mul_uniform(negative1 ? add_mod_uniform(x[row].y, t1, m.p) : sub_mod_uniform(x[row].y, t1, m.p), inv.x,
+                                    inv.y, m.p);
+            stream_store(dst + static_cast<size_t>(row) * pairs_per_row, y);
         }
     }
 }
@@ -640,11 +687,30 @@ hipError_t launch_mul_plain(uint64_t* ct, const uint64_t* pt, const DeviceContex
     return hipGetLastError();
 }
 
+constexpr bool kDivideAndRoundRowsAtCompileTime = true;
 hipError_t launch_divide_and_round_q_last(const uint64_t* in, uint64_t* out, const DeviceContext& ctx,
                                           uint32_t moduli_count, size_t polys, hipStream_t stream) {
     if (polys == 0) return hipSuccess;
     if (ctx.degree < 2 || moduli_count < 2) return hipErrorInvalidValue;
     const size_t total = polys * (ctx.degree / 2);
+#define HEAMD_Q_LAST_CASE(L)                                                                                              \
+    case L:                                                                                                               \
+        hipLaunchKernelGGL(divide_and_round_q_last_rows_kernel<L>, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, \
+                           ctx, polys);                                                                                   \
+        return hipGetLastError()
+    if (kDivideAndRoundRowsAtCompileTime) {
+        switch (moduli_count) {
+            HEAMD_Q_LAST_CASE(2);
+            HEAMD_Q_LAST_CASE(3);
+            HEAMD_Q_LAST_CASE(4);
+            HEAMD_Q_LAST_CASE(5);
+            HEAMD_Q_LAST_CASE(6);
+            HEAMD_Q_LAST_CASE(7);
+            HEAMD_Q_LAST_CASE(8);
+            default: break;  // longer chains: the rolled loop over the rows
+        }
+    }
+#undef HEAMD_Q_LAST_CASE
     hipLaunchKernelGGL(divide_and_round_q_last_kernel, dim3(grid_for(total)), dim3(kThreads), 0, stream, in, out, ctx,
                        moduli_count, polys);
     return hipGetLastError();

@@ -23,9 +23,13 @@ namespace {
 
 constexpr unsigned kThreads = 256;
 
+constexpr size_t kGridCap = (size_t(1) << 31) - 1;
+// One workgroup per kThreads work items, up to the grid limit: the kernels keep their grid-stride loops for what lies beyond it,
+// but a lane that walks many items serialises its loads -- divideAndRoundQLast at N = 16384, L = 6 ran at 0.66 of 8 TB/s on
+// 256 x 8 workgroups and at 0.79 with one item per lane (profiles/r06y_exact_grids.txt)
 inline unsigned grid_for(size_t work_items) {
     const size_t blocks = (work_items + kThreads - 1) / kThreads;
-    const size_t cap = 256 * 8;
+    const size_t cap = kGridCap;
     return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
