@@ -116,6 +116,15 @@ constexpr int kInnerProductEvalUnavailable = -2;
 int bfv_inner_product_shared_eval_rhs(const he_bfv_context* ctx, uint32_t L, const uint64_t* lhs, const uint64_t* rhs_eval,
                                       size_t count, size_t items, uint64_t* out, hipStream_t stream);
 
+// pir_api.cpp: he_pir_dim0_columns_device without its last step (the results stay in Eval form) and
+// he_pir_remaining_dimensions_chunks_device for such results (not exported)
+int pir_dim0_columns_eval(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0, const uint64_t* database,
+                          const uint8_t* present_device, size_t columns, uint64_t* out, he_stream s);
+int pir_remaining_dimensions_chunks_eval(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                                         size_t chunk_count, uint64_t* intermediate_eval, const uint64_t* remaining_query,
+                                         size_t remaining_query_count, const uint64_t* relinearization_key, uint64_t* out,
+                                         he_stream s);
+
 // Stream-ordered scratch buffer (scratch_allocate / scratch_release on the same stream).
 class Scratch {
   public:

@@ -193,9 +193,13 @@ int he_ntt_inverse_group(he_device_group* group, uint32_t moduli_count, uint64_t
     return ntt_group(group, moduli_count, slab_shards, batch, true);
 }
 
-int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query_eval, size_t d0,
-                              const uint64_t* const* database_shards, const uint8_t* const* present_shards, size_t columns,
-                              uint64_t* out, he_stream home_stream) {
+}  // extern "C"
+namespace {
+// leave_in_eval: the members skip the inverse transform of their columns (PirUtil.swift:438); the home device's remaining
+// dimensions take them as they are (pir_api.cpp remaining_dimensions, results_in_eval)
+int dim0_columns_group(he_device_group* group, const uint64_t* dim0_query_eval, size_t d0,
+                       const uint64_t* const* database_shards, const uint8_t* const* present_shards, size_t columns,
+                       uint64_t* out, he_stream home_stream, bool leave_in_eval) {
     if (group == nullptr) return invalid_argument("null group");
     if (columns == 0) return HE_OK;
     if (dim0_query_eval == nullptr || database_shards == nullptr || out == nullptr) return invalid_argument("null operand");
@@ -241,8 +245,11 @@ int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query
             status = heamd::device_failure(e, "device group: member setup");
             break;
         }
-        status = he_pir_dim0_columns_device(m.ctx, query, d0, database_shards[i],
-                                            present_shards != nullptr ? present_shards[i] : nullptr, mine, result, m.stream);
+        status = leave_in_eval
+                     ? heamd::pir_dim0_columns_eval(m.ctx, query, d0, database_shards[i],
+                                                    present_shards != nullptr ? present_shards[i] : nullptr, mine, result, m.stream)
+                     : he_pir_dim0_columns_device(m.ctx, query, d0, database_shards[i],
+                                                  present_shards != nullptr ? present_shards[i] : nullptr, mine, result, m.stream);
         if (status != HE_OK) break;
         if (m.remote)
             e = copy_between(out + begin * ct_words, home.device, result, m.device, mine * ct_words * sizeof(uint64_t), m.stream);
@@ -261,6 +268,14 @@ int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query
     if (status != HE_OK) return status;
     HEAMD_HIP_TRY(back);
     return HE_OK;
+}
+}  // namespace
+extern "C" {
+
+int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query_eval, size_t d0,
+                              const uint64_t* const* database_shards, const uint8_t* const* present_shards, size_t columns,
+                              uint64_t* out, he_stream home_stream) {
+    return dim0_columns_group(group, dim0_query_eval, d0, database_shards, present_shards, columns, out, home_stream, false);
 }
 
 int he_pir_compute_response_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
@@ -286,13 +301,13 @@ int he_pir_compute_response_group(he_device_group* group, const uint32_t* dimens
     Scratch intermediate(as_stream(home_stream));
     HEAMD_HIP_TRY(intermediate.allocate(columns * 2 * size_t(L) * n * sizeof(uint64_t)));
     uint64_t* results = static_cast<uint64_t*>(intermediate.get());
-    int status = he_pir_dim0_columns_group(group, dim0_query_eval, d0, database_shards, present_shards, columns, results,
-                                           home_stream);
+    int status = dim0_columns_group(group, dim0_query_eval, d0, database_shards, present_shards, columns, results, home_stream,
+                                    true);
     if (status == HE_OK) {
         HEAMD_HIP_TRY(hipSetDevice(home.device));
-        status = he_pir_remaining_dimensions_chunks_device(home.ctx, dimensions, dimension_count, chunk_count, results,
-                                                           remaining_query, remaining_query_count, relinearization_key, out,
-                                                           home_stream);
+        status = heamd::pir_remaining_dimensions_chunks_eval(home.ctx, dimensions, dimension_count, chunk_count, results,
+                                                             remaining_query, remaining_query_count, relinearization_key, out,
+                                                             home_stream);
     }
     return status;
 }

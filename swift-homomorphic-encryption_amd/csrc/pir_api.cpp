@@ -253,6 +253,24 @@ extern "C" int he_pir_remaining_dimensions_chunks_device(const he_bfv_context* c
                                 relinearization_key, out, s);
 }
 
+// The two halves for a caller that joins them itself (a device group: device_group.cpp) with the dim-0 results passed on in
+// EVAL form, as response_chunks_resident does inside one device (api_internal.hpp; not exported)
+int heamd::pir_dim0_columns_eval(const he_bfv_context* ctx, const uint64_t* dim0_query_eval, size_t d0, const uint64_t* database,
+                                 const uint8_t* present_device, size_t columns, uint64_t* out, he_stream s) {
+    return dim0_columns(ctx, dim0_query_eval, d0, database, false, present_device, columns, out, s, true);
+}
+int heamd::pir_remaining_dimensions_chunks_eval(const he_bfv_context* ctx, const uint32_t* dimensions, uint32_t dimension_count,
+                                                size_t chunk_count, uint64_t* intermediate_eval, const uint64_t* remaining_query,
+                                                size_t remaining_query_count, const uint64_t* relinearization_key, uint64_t* out,
+                                                he_stream s) {
+    ChunkShape shape;
+    HEAMD_TRY_STATUS(chunk_shape(ctx, dimensions, dimension_count, remaining_query, remaining_query_count, shape));
+    if (chunk_count == 0) return HE_OK;
+    if (intermediate_eval == nullptr || out == nullptr) return invalid_argument("null operand");
+    return remaining_dimensions(ctx, dimensions, dimension_count, shape, chunk_count, intermediate_eval, remaining_query,
+                                relinearization_key, out, s, true);
+}
+
 extern "C" int he_pir_compute_response_chunk_device(const he_bfv_context* ctx, const uint32_t* dimensions,
                                                     uint32_t dimension_count, const uint64_t* dim0_query_eval,
                                                     const uint64_t* remaining_query, size_t remaining_query_count,
