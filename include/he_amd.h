@@ -613,7 +613,10 @@ int he_pir_dim0_columns_group(he_device_group* group, const uint64_t* dim0_query
  * home device (they need every column).  remaining_query, relinearization_key, out: home. */
 /* The chunk loop of PirUtil.computeResponse (PirUtil.swift:533-563) over the group: the columns of all `chunk_count` chunks are
  * one column range, sharded as above (database_shards[m] = member m's share of chunk_count x columns columns); one dim-0 pass
- * per member, the gather, then he_pir_remaining_dimensions_chunks_device on the home device.  out (home) [chunk_count][2][1][N]. */
+ * per member, the gather, then the remaining dimensions of all chunks on the home device.  out (home) [chunk_count][2][1][N].
+ * Where he_shard_bounds falls on chunk boundaries for every member (chunk_count a multiple of the group's size) each member
+ * answers its chunks from start to finish instead -- he_pir_compute_response_device on its own stream, the queries and the key
+ * replicated to it -- and only the finished responses come back: no part of the call is left to one device alone. */
 int he_pir_compute_response_group(he_device_group* group, const uint32_t* dimensions, uint32_t dimension_count,
                                   const uint64_t* dim0_query_eval, const uint64_t* remaining_query,
                                   size_t remaining_query_count, const uint64_t* const* database_shards,
