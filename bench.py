@@ -656,7 +656,7 @@ class ModSwitchWorkload:
         traffic = profile["hbm_bytes_per_unit"] * self.units / t / 1e9 if profile else None
         return {
             "bound": "hbm",
-            "kernel": "divide_and_round_q_last_kernel (16 B per lane, grid-stride)",
+            "kernel": "divide_and_round_q_last_rows_kernel<6> (16 B per lane, one coefficient pair per lane, the six row loads issued first)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
