@@ -13,12 +13,12 @@ import sys
 BATCH = 1024
 # launches per call of (ct x ct, relinearize) over the whole batch; the parts of a kernel that runs in parts add up to the batch
 LAUNCHES = {
-    "lift_kernel<4, unsigned long, true, 2>": 2,       # lhs, rhs (each over the whole batch)
+    "lift_kernel<4, unsigned long, true, 2>": 1,       # both operands in one launch (launch_lift_pair_q_to_qbsk_strided)
     "behz_rows_fused<13, 10, 4, 4>": 1,
     "behz_rows_fused<13, 10, 6, 6>": 1,                # two launches of half the batch each: per-launch averages x 2 / 2
     "floor_kernel<4, unsigned long, true, 1>": 1,      # likewise
     "ntt_forward_tiled<13, 10, 4, 1, 2>": 1,
-    "ntt_inverse_tiled<13, 10, 4, 2, 2>": 1,
+    "ntt_inverse_tiled<13, 10, 4, 2, 1>": 1,           # the q_ks rows: 2048 rows, one per workgroup (kUngroupedBelowRows)
     "ntt_inverse_tiled<13, 10, 4, 4, 2>": 1,
 }
 HALVES = {"behz_rows_fused<13, 10, 6, 6>", "floor_kernel<4, unsigned long, true, 1>"}  # a launch covers half the batch
