@@ -68,10 +68,12 @@ def test_pir_response_rejects_mismatched_dimensions(small):
     assert err.value.name == "invalidArgument"
 
 
-def test_pir_response_config_shape(oracle):
-    """N=8192, L=4 (BASELINE configs[4] ring), a 16 x 8 chunk of uniform words: exact words vs the oracle."""
-    degree = 8192
-    q = oracle.generate_primes([55] * 5, False, degree)
+@pytest.mark.parametrize("degree,bits", [(8192, [55] * 5), (4096, [55] * 3), (8192, [29, 60, 60])])
+def test_pir_response_config_shape(oracle, degree, bits):
+    """N=8192, L=4 (BASELINE configs[4] ring), a 16 x 8 chunk of uniform words: exact words vs the oracle -- on the degrees whose
+    first remaining dimension reads the dim-0 results in Eval form (pir_api.cpp results_in_eval: out-of-place inverse transform,
+    carry-counting sums), N = 4096 and one of the reference's 60-bit parameter sets beside it."""
+    q = oracle.generate_primes(bits, False, degree)
     ours, ref = heamd.BfvContext(degree, 557057, q), oracle.BfvContext(degree, 557057, q)
     rng = np.random.default_rng(62)
     dims = [16, 8]
