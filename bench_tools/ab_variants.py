@@ -9,7 +9,7 @@ an error: the experiment has drifted from the source and must be updated), recom
 and links them with the production objects into lib/variants/libhe_amd_NAME.so.  The product sources carry no hooks.
 
   python bench_tools/ab_variants.py build NAME [NAME ...]     (no GPU needed; `all` = every module in variants/)
-  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small|pir|c4|script:PATH] [--rounds N] [NAME ...]     (on the GPU box)
+  python bench_tools/ab_variants.py run [--what ntt|degrees|large|c3|small|pir|c4|mid|script:PATH] [--rounds N] [NAME ...]     (on the GPU box)
       times the production library and each variant, one process per library (HEAMD_LIBRARY), interleaved over rounds
       so that clock drift shows up as spread
 """
@@ -121,6 +121,9 @@ C4_TIMER = ("import sys; sys.path[:0] = [%r, %r, %r]; import torch, heamd, path_
             "print('N=16384 6->5 moduli: %%.3f M poly/s  frac of 8 TB/s %%.4f  median %%.4f ms' %% (r['poly_per_s'] / 1e6, "
             "r['frac_of_8TBps'], r['spread_ms']['median_ms']))" % (ROOT, PKG, os.path.join(ROOT, "bench_tools")))
 
+# ct x ct and relinearize on batches between the latency-bound and the throughput-bound ends
+MID_TIMER = SMALL_TIMER.replace("for outputs in (320, 1024):", "for outputs in ():").replace("for batch in (1, 8, 64):", "for batch in (16, 32, 64, 128, 256, 512):")
+
 
 def load_spec(name):
     path = os.path.join(SPECS, name + ".py")
@@ -198,7 +201,7 @@ def run(args):
     script = what[len("script:"):] if what.startswith("script:") else None  # any bench script: every line it prints
     if script:
         SHAPES[what] = []
-    timer = ("import runpy, sys; sys.argv = [%r]; runpy.run_path(%r, run_name='__main__')" % (script, script)) if script else C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else PIR_TIMER if what == "pir" else C4_TIMER if what == "c4" else NTT_TIMER % repr(SHAPES[what])
+    timer = ("import runpy, sys; sys.argv = [%r]; runpy.run_path(%r, run_name='__main__')" % (script, script)) if script else C3_TIMER if what == "c3" else SMALL_TIMER if what == "small" else PIR_TIMER if what == "pir" else MID_TIMER if what == "mid" else C4_TIMER if what == "c4" else NTT_TIMER % repr(SHAPES[what])
     libs = {"production": None}
     for path in sorted(glob.glob(os.path.join(VARIANTS, "libhe_amd_*.so"))):
         name = os.path.basename(path)[len("libhe_amd_"):-3]

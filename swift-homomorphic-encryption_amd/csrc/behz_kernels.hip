@@ -19,6 +19,8 @@
 // go through two transposition tiles side by side, two rows per round (ntt_rows.hpp kWideGroupTiles).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <type_traits>
 
 #include "device_context.hpp"
@@ -185,12 +187,25 @@ hipError_t launch_band_in_mode(int mode, uint64_t* out, const DeviceContext& ctx
 
 }  // namespace
 
-bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items) {
-    // the degrees whose tiled transform holds a row in 8 words per lane (four rows = 64 registers); batches of at least one
-    // workgroup generation (below that the unfused launches, three workgroups per row, fill more of the device)
+// (item, row) workgroups from which the row-fused kernels are taken: a row-fused workgroup runs seven transforms in a row, alone on
+// its CU -- below a few generations of them the unfused launches (one transform per workgroup, two per CU) finish sooner: ct x ct
+// on 32 / 64 ciphertext pairs 172 -> 158 / 287 -> 268 us, equal at 128, the fused kernels ahead from 256 on
+// (profiles/r06x_small_chains.txt).  The callers' parts of a batch (bfv_api.cpp kBehzFloorParts: at least 256 items) stay above it.
+constexpr size_t kBehzRowsFusedAbove = 1152;
+namespace {
+// the degrees whose tiled transform holds a row in 8 words per lane (four rows = 64 registers)
+bool rows_fused_shape(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items) {
     const bool tiled = qbsk.log_degree == 12 || qbsk.log_degree == 13;
     return tiled && source_moduli != 0 && source_moduli < record_rows && record_rows <= 64 && qbsk.moduli_count >= record_rows &&
-           items * record_rows > ntt::kOneGeneration / 2 && items * record_rows <= (size_t(1) << 30);
+           items != 0 && items * record_rows <= (size_t(1) << 30);
+}
+}  // namespace
+// (the batch threshold is the CALLER's question -- a part of a batch that passed it is launched whatever its own size)
+// HEAMD_BEHZ_FUSED_ABOVE=k overrides the threshold (the parity tests put small batches through the row-fused kernels with it)
+bool behz_rows_fused_supported(const DeviceContext& qbsk, uint32_t record_rows, uint32_t source_moduli, size_t items) {
+    size_t above = kBehzRowsFusedAbove;
+    if (const char* forced = std::getenv("HEAMD_BEHZ_FUSED_ABOVE")) above = static_cast<size_t>(std::strtoull(forced, nullptr, 10));
+    return rows_fused_shape(qbsk, record_rows, source_moduli, items) && items * record_rows > above;
 }
 
 constexpr bool kBehzLazyLiftedRows = true;
@@ -207,7 +222,7 @@ hipError_t launch_behz_rows_fused(const uint64_t* lhs, const uint64_t* rhs, size
                                   uint64_t* out, const DeviceContext& scaled_qbsk, uint32_t record_rows, uint32_t source_moduli,
                                   size_t items, hipStream_t stream, int part) {
     if (items == 0) return hipSuccess;
-    if (!behz_rows_fused_supported(scaled_qbsk, record_rows, source_moduli, items) || scaled_qbsk.scaled_inverse_degree == 0)
+    if (!rows_fused_shape(scaled_qbsk, record_rows, source_moduli, items) || scaled_qbsk.scaled_inverse_degree == 0)
         return hipErrorNotSupported;
     const BehzRows src{lhs, rhs, ct_stride, lifted, source_moduli};
     auto launch = [&](int mode, uint32_t base, uint32_t band) {

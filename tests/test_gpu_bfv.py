@@ -127,14 +127,16 @@ def test_relinearize_matches_oracle(oracle, small, level):
     (4096, [50, 61, 55], 70, None),  # 50 (limb-wise) | 61 bits not next to a power of two ([0, 8p)) | Bsk
     (4096, [62, 62, 50], 64, None),  # 62-bit moduli: the exact butterflies for the whole record
 ])
-def test_mul_row_fused_matches_oracle(oracle, degree, bits, batch, level):
-    """ct x ct on batches wide enough for behz_kernels.hip (one workgroup per (item, [Q, Bsk] row): four forward transforms,
+def test_mul_row_fused_matches_oracle(oracle, monkeypatch, degree, bits, batch, level):
+    """ct x ct on batches wide enough for behz_kernels.hip (HEAMD_BEHZ_FUSED_ABOVE=256 puts them through the row-fused kernels:
+    in production those start at 1152 (item, row) workgroups, where they overtake the unfused launches) (one workgroup per (item, [Q, Bsk] row): four forward transforms,
     the tensor product, three scaled inverse transforms, the Eval rows never in HBM) -- every butterfly class the row bands
     take (limb-wise, fold of either form, [0, 8p), exact), levels below the top, odd batches; EVERY product word for word
     against the oracle's multiplyWithoutScaling + dropExtendedBase (Bfv+Multiply.swift:18-85), and the same words as the
     unfused pipeline computes for a batch too small for the fused kernel."""
     from conftest import host_threads
 
+    monkeypatch.setenv("HEAMD_BEHZ_FUSED_ABOVE", "256")
     t = oracle.generate_primes([17], True, degree)[0]
     q = oracle.generate_primes(bits, False, degree)
     ours, ref = heamd.BfvContext(degree, t, q), oracle.BfvContext(degree, t, q)
@@ -1002,13 +1004,14 @@ def test_key_switch_on_runs_of_butterfly_classes(oracle, degree, bits, batch):
     assert np.array_equal(rotated, ref.apply_galois(ct, element, key))
 
 
-def test_pipelines_on_moduli_at_the_edge_of_the_shift_folded_products(oracle):
+def test_pipelines_on_moduli_at_the_edge_of_the_shift_folded_products(oracle, monkeypatch):
     """ct x ct (row-fused and unfused) and relinearize with ciphertext moduli 2^b - d whose d is as large as kModeFoldLazy
     allows (tests/test_gpu_ntt.py _primes_below_power_of_two) -- the generated primes of every other test sit at the small end --
     and with one modulus just past the bound among them (that band then runs the limb-wise products): word for word."""
     from conftest import host_threads
     from test_gpu_ntt import _primes_below_power_of_two
 
+    monkeypatch.setenv("HEAMD_BEHZ_FUSED_ABOVE", "256")  # (the row-fused kernels from 29 pairs on, as the batch below assumes)
     degree = 4096
     t = oracle.generate_primes([17], True, degree)[0]
     edge = [p for bits in (55, 54, 52, 50) for p in _primes_below_power_of_two(oracle, bits, degree, True)]

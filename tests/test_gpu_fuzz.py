@@ -84,13 +84,14 @@ def test_random_parameter_shapes(oracle, seed):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_row_fused_products(oracle, seed):
+def test_random_row_fused_products(oracle, monkeypatch, seed):
     """ct x ct through behz_kernels.hip (batches from half a workgroup generation of [Q, Bsk] rows up, N = 4096 / 8192) on random
     moduli mixes -- which rows form a run of one butterfly class (limb-wise | fold - | fold + | [0, 8p) | exact for the whole
     record), where the Q rows end inside or at the edge of a run -- random levels and ragged batches; every word of every
     product against the multi-threaded oracle, extremes of every residue included."""
     from conftest import host_threads
 
+    monkeypatch.setenv("HEAMD_BEHZ_FUSED_ABOVE", "256")  # (production takes these kernels from 1152 workgroups on)
     rnd = random.Random(7000 + seed)
     for trial in range(3):
         degree = rnd.choice([4096, 8192])
