@@ -1119,6 +1119,10 @@ constexpr bool kFoldLazyForward = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LO
 template <int LOGN, int LOGT, int SOURCE>
 constexpr bool kFoldLazyInverse = (LOGN == 12 && LOGT == 9) || (LOGN == 13 && LOGT == 10);
 constexpr bool kFoldLazyInterleaved = true;
+// ... and the fold butterflies of the plus form (ntt_common.hpp kModeFoldPlus) for the BEHZ primes' rows of N = 16384 / 32768: the
+// Bsk bands of ct x ct ran on the [0, 8p) butterflies there (0.38 / 0.27 of 8 TB/s forward / inverse at N = 16384 against the Q
+// band's 0.54 / 0.35: profiles/r06q_fold_plus_interleaved.txt)
+constexpr bool kFoldPlusInterleaved = true;
 // every modulus of a launch is of the form 2^b - d (DeviceContext::shift_prefix)
 inline bool fold_lazy_band(const DeviceContext& ctx, const RowMap& map) {
     return map.band_rows != 0 && map.mod_base + map.band_rows <= ctx.shift_prefix;
@@ -1183,6 +1187,11 @@ hipError_t launch_interleaved_forward(int mode, uint64_t* slab, const DeviceCont
     if constexpr (kFoldLazyInterleaved) {
         if (mode == kModeSplit && fold_lazy_band(ctx, map)) kernel = ntt_forward_interleaved<LOGS, kModeFoldLazy, SPREAD>;
     }
+    if constexpr (kFoldPlusInterleaved && SPREAD == kSourceSlab) {
+        // the BEHZ primes 2^60 + e (the Bsk band of a lifted record, transformed in place) on the fold butterflies, as at N = 8192
+        if (mode == kModeApprox && ctx.forward_split_pairs != nullptr && fold_mode(ctx, map.mod_base, map.band_rows) == kModeFoldPlus)
+            kernel = ntt_forward_interleaved<LOGS, kModeFoldPlus, SPREAD>;
+    }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(rows)), dim3(1u << kSubLogT), kInterleavedLdsBytes<LOGS>, stream, slab, ctx, map,
                        spread);
@@ -1222,6 +1231,13 @@ hipError_t launch_interleaved_inverse(int mode, uint64_t* slab, const DeviceCont
             else if constexpr (NEVER_SCALED) kernel = ntt_inverse_interleaved<LOGS, kModeFoldLazy, false, SOURCE>;
             else kernel = ctx.scaled_inverse_degree != 0 ? ntt_inverse_interleaved<LOGS, kModeFoldLazy, true, SOURCE>
                                                          : ntt_inverse_interleaved<LOGS, kModeFoldLazy, false, SOURCE>;
+        }
+    }
+    if constexpr (kFoldPlusInterleaved && (SOURCE == kInverseFromSlab || SOURCE == kInverseFromTensor)) {
+        if (mode == kModeApprox && ctx.forward_split_pairs != nullptr && fold_mode(ctx, map.mod_base, map.band_rows) == kModeFoldPlus) {
+            if constexpr (SOURCE == kInverseFromTensor) kernel = ntt_inverse_interleaved<LOGS, kModeFoldPlus, true, SOURCE>;
+            else kernel = ctx.scaled_inverse_degree != 0 ? ntt_inverse_interleaved<LOGS, kModeFoldPlus, true, SOURCE>
+                                                         : ntt_inverse_interleaved<LOGS, kModeFoldPlus, false, SOURCE>;
         }
     }
     if (hipError_t e = allow_dynamic_lds(kernel, kInterleavedLdsBytes<LOGS>); e != hipSuccess) return e;
