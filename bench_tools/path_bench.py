@@ -144,6 +144,30 @@ def config3_ct_mul(torch, heamd, batch=1024, reps=5):
     }
 
 
+def config3_small_batches(torch, heamd, batches=(1, 8, 64), reps=20):
+    """The same pipeline on a few ciphertexts -- what a caller's single mulAssign / relinearize is: chains of small launches
+    whose cost is latency (microseconds per call, device time)."""
+    degree = 8192
+    q = heamd.generate_primes([55] * 5, False, degree)
+    ctx = heamd.BfvContext(degree, 557057, q)
+    moduli = q[:-1]
+    key = _uniform(torch, q, (ctx.L, 2), degree, 3)
+    out = {}
+    for batch in batches:
+        lhs, rhs = _uniform(torch, moduli, (batch, 2), degree, 1), _uniform(torch, moduli, (batch, 2), degree, 2)
+        state = {}
+
+        def mul():
+            state["ct3"] = ctx.mul(lhs, rhs)
+
+        def relin():
+            state["ct2"] = ctx.relinearize(state["ct3"], key)
+
+        t_mul, t_relin = _timed(torch, mul, reps), _timed(torch, relin, reps)
+        out["batch_%d" % batch] = {"ct_mul_us": t_mul.spread["median_ms"] * 1e3, "relinearize_us": t_relin.spread["median_ms"] * 1e3}
+    return out
+
+
 def config4_mod_switch(torch, heamd, batch=8192, reps=5):
     """divideAndRoundQLast, N=16384, 6 -> 5 moduli (BASELINE configs[3])."""
     degree = 16384
@@ -274,6 +298,7 @@ def run_all(quick=False, only=None):
         ("config1_ntt_n4096_l2", lambda: config1_ntt(torch, heamd, batch=1024 if quick else 8192)),
         ("ntt_n16384_l4", lambda: config1_ntt(torch, heamd, batch=256 if quick else 1024, degree=16384, moduli_count=4)),
         ("config3_ct_mul", lambda: config3_ct_mul(torch, heamd, batch=256 if quick else 1024)),
+        ("config3_small_batches", lambda: config3_small_batches(torch, heamd)),
         ("config4_mod_switch", lambda: config4_mod_switch(torch, heamd, batch=1024 if quick else 8192)),
         # the per-GPU shard of BASELINE configs[4]: d0 = 1024 rows x d1 / 8 = 128 columns (34 GB of plaintexts)
         ("config5_inner_product_1gpu", lambda: config5_inner_product(torch, heamd, count=64 if quick else 1024,
